@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""bench.py -- KGWAS hot path on MI355X: full fast-mode KG minibatch training.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one training step of kgwas/kgwas.py:129-151 on one 512-seed batch per GPU: device-side
+2-hop full-neighbourhood sampling, feature slicing, 3 feature MLPs, 2 fused attention-aggregate
+layers, read-out, LD-weighted MSE, backward, Adam -- on the workload BASELINE.json's metric is quoted
+on (configs[1]): SynthKG-fast (784 256 SNPs / 20 032 genes / ~20.6 M directed edges, features
+20 / 5120 / 128), causal-simulation-like labels, seed 1.  Inputs (graph, features, labels) are resident
+in HBM before the timed region starts.
+
+Metric: edges aggregated per second = sum over timed steps, layers and live relations of the edges the
+aggregate kernels actually gather, over wall time (max over ranks); N > 1 is weak scaling (every rank
+trains on its own 512-seed batches, one flat gradient all-reduce per step over RCCL).
+Extra keys: ``roofline`` (layer-1 forward aggregate kernel: algorithmic bytes / HIP-event time vs the
+8 TB/s HBM peak), ``cpu_baseline`` (the CPU oracle = op-for-op PyG restatement, timed on this box's host
+cores on a bounded sample of the same batches), ``breakdown`` (per-kernel event times).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable by a float4 copy)
+
+
+def algorithmic_bytes_fwd(n_edges, z_rows):
+    """B_f = E*(4C+8) + N_d*(4C+8), C = 128  ->  520 B per edge + 520 B per (row, relation)."""
+    return 520 * n_edges + 520 * z_rows
+
+
+def algorithmic_bytes_bwd(n_edges, z_rows, n_src):
+    """B_b = E*(8C+24) + (N_d + N_s)*(4C+8)."""
+    return 1048 * n_edges + 520 * (z_rows + n_src)
+
+
+def cpu_baseline(data, batch_size, budget_s=25.0, max_steps=3):
+    """Reference PyG CPU path, restated (oracle/): numpy full-neighbour sampler + x[n_id] slicing + unpruned
+    2-layer HeteroGNN forward/backward + Adam, all host cores.  Bounded sample: as many steps as fit in
+    ~budget_s (at least 1 after 1 warm-up)."""
+    from oracle.gat_oracle import HeteroGNNOracle, weighted_mse
+    from oracle.sampler_np import FullNeighborSamplerNP
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = data.data
+    t0 = time.time()
+    smp = FullNeighborSamplerNP(g.edge_index_dict, g.num_nodes_dict, 2)
+    torch.manual_seed(1)
+    model = HeteroGNNOracle(g.edge_types, 128, 1, 2, 'GAT', 'sum', data.snp_init_dim_size, data.gene_init_dim_size,
+                            data.go_init_dim_size, 1)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-4)
+    setup_s = time.time() - t0
+    ids = np.asarray(data.train_input_nodes[1])
+    y_all = g['SNP'].y
+    w_all = torch.zeros(g['SNP'].x.shape[0], dtype=torch.float64)
+    w_all[torch.from_numpy(np.asarray(data.all_ids))] = torch.from_numpy(np.asarray(data.ldsc_weight))
+    times, edges = [], []
+    for step in range(max_steps + 1):
+        seeds = ids[step * batch_size:(step + 1) * batch_size]
+        t = time.time()
+        n_id, ei = smp.sample('SNP', seeds)
+        x = {k: g[k].x[v] for k, v in n_id.items()}
+        opt.zero_grad()
+        out = model(x, ei, batch_size)
+        loss = weighted_mse(out, y_all[n_id['SNP'][:batch_size]], w_all[n_id['SNP'][:batch_size]])
+        loss.backward()
+        opt.step()
+        dt = time.time() - t
+        if step > 0:
+            times.append(dt)
+            edges.append(2 * sum(int(v.shape[1]) for v in ei.values()))      # both layers touch every sampled edge
+        if step > 0 and sum(times) + dt > budget_s:
+            break
+    tot_t = sum(times)
+    return {'value': sum(edges) / tot_t, 'unit': 'edges/s', 'cores': cores, 'kind': 'port',
+            's_per_step': tot_t / len(times),
+            'sample': f'{len(times)} training steps (after 1 warm-up) of batch {batch_size} on the same SynthKG-fast '
+                      f'batches; unpruned (both layers over every sampled edge) like PyG; torch threads={cores}'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--scale', type=float, default=1.0, help='SynthKG scale (1.0 = reference size)')
+    ap.add_argument('--batch-size', type=int, default=512)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}')
+    assert torch.cuda.is_available(), 'bench.py needs a ROCm GPU'
+    torch.cuda.set_device(local_rank)
+    dev = f'cuda:{local_rank}'
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device(dev))
+
+    from kgwas_amd import dist as kdist
+    from kgwas_amd import ops
+    from kgwas_amd.kgwas import KGWAS
+    from kgwas_amd.kgwas_data import KGWAS_Data
+    from kgwas_amd.sampler import NeighborLoader
+
+    t0 = time.time()
+    data = KGWAS_Data.from_synthetic(scale=args.scale, seed=1, mode='fast', gwas_kind='causal',
+                                     data_path=f'/tmp/kgwas_bench_{rank}')
+    run = KGWAS(data, device=dev, seed=1)
+    run.initialize_model()
+    if world > 1:
+        kdist.broadcast_params(run.model)
+    opt = torch.optim.Adam(run.model.parameters(), lr=1e-4, weight_decay=5e-4)
+    ld_w = run._ld_weight_vector()
+    bs = args.batch_size
+    need = (args.steps + args.warmup) * bs
+    ids = np.asarray(data.train_input_nodes[1])
+    # weak scaling: rank r trains on batches r, r+world, ... of the reference's fixed batch order
+    nb = len(ids) // bs
+    mine = ids[:nb * bs].reshape(nb, bs)[rank::world].reshape(-1)
+    if len(mine) < need:
+        mine = np.resize(mine, need)
+    loader = NeighborLoader(data.data, [-1, -1], ('SNP', mine[:need]), batch_size=bs, drop_last=True, device=dev)
+    it = iter(loader)
+    run.model.train()
+    setup_s = time.time() - t0
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run.train_step(next(it), opt, ld_w, world)
+    ops.TIMER.enabled = not args.no_kernel_timing
+    edges_kernel = edges_ref = seeds = 0
+    sync()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        batch = next(it)
+        run.train_step(batch, opt, ld_w, world)
+        edges_kernel += sum(batch.n_edges_per_layer)
+        edges_ref += 2 * batch.n_edges_sampled
+        seeds += bs
+    sync()
+    elapsed = time.perf_counter() - t_start
+    ops.TIMER.enabled = False
+
+    stats = torch.tensor([elapsed, float(edges_kernel), float(edges_ref), float(seeds)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[:1].clone()
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        tot = stats[1:].clone()
+        torch.distributed.all_reduce(tot, op=torch.distributed.ReduceOp.SUM)
+        elapsed = float(tmax[0]); edges_kernel, edges_ref, seeds = (float(x) for x in tot)
+
+    if rank != 0:
+        return
+    summ = ops.TIMER.summary()
+    breakdown, roof = {}, None
+    for (tag, layer), d in sorted(summ.items()):
+        byts = algorithmic_bytes_fwd(d['edges'], d['z_rows']) if tag == 'fwd' else None
+        entry = {'launches': d['n'], 'avg_ms': d['ms'] / d['n'], 'edges_per_launch': d['edges'] / d['n']}
+        if tag == 'fwd':
+            entry['algorithmic_GBs'] = byts / (d['ms'] * 1e-3) / 1e9
+        elif tag == 'bwd_dst':
+            entry['algorithmic_GBs'] = (528 * d['edges'] + 1028 * d['z_rows']) / (d['ms'] * 1e-3) / 1e9
+        elif tag == 'bwd_src':
+            entry['algorithmic_GBs'] = (528 * d['edges'] + 520 * d['n_src']) / (d['ms'] * 1e-3) / 1e9
+        breakdown[f'agg_{tag}_l{layer}'] = entry
+    if ('fwd', 1) in summ:
+        d = summ[('fwd', 1)]
+        ach = algorithmic_bytes_fwd(d['edges'], d['z_rows']) / (d['ms'] * 1e-3) / 1e9
+        roof = {'kernel': 'k_agg_fwd (layer-1 attention aggregate, forward)', 'bound': 'hbm', 'achieved': ach,
+                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                'bytes_per_launch': algorithmic_bytes_fwd(d['edges'], d['z_rows']) / d['n'],
+                'avg_launch_ms': d['ms'] / d['n'], 'traffic': None}
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_agg_fwd.json')
+        if os.path.exists(pmc):
+            try:
+                roof['traffic'] = json.load(open(pmc)).get('hbm_bytes_per_launch')
+            except Exception:
+                pass
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline(data, bs)
+    ms = elapsed / args.steps * 1e3
+    out = {
+        'metric': 'edges aggregated/sec (full fast-mode KG minibatch training; epoch time in config)',
+        'value': edges_kernel / elapsed, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'SynthKG-fast full KG (784256 SNP / 20032 Gene / ~20.6M directed edges; features '
+                               '20/5120/128) + causal-simulation GWAS seed=1, batch 512 seeds per GPU, 2-layer GAT-128, '
+                               'Adam(1e-4, wd 5e-4) -- BASELINE.json configs[1]',
+                   'scale': args.scale, 'batch_size_per_gpu': bs, 'parallelism': f'seed-dp{world}',
+                   'edges_per_step_kernel': edges_kernel / args.steps / world,
+                   'edges_per_step_reference_equivalent': edges_ref / args.steps / world,
+                   'reference_equivalent_edges_per_s': edges_ref / elapsed,
+                   'seeds_per_s': seeds / elapsed,
+                   'epoch_time_s_956_steps': 956 * ms / 1e3 / world,
+                   'setup_s': setup_s},
+        'roofline': roof, 'cpu_baseline': cpu, 'breakdown': breakdown,
+    }
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

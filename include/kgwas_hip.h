@@ -1,0 +1,177 @@
+/*
+ * kgwas_hip.h -- C ABI of libkgwas_hip.so, the MI355X (gfx950) hot path of KGWAS.
+ *
+ * The reference (snap-stanford/KGWAS) is pure Python and has NO FFI / plugin boundary of its own
+ * (SURVEY.md 8b): its native work happens inside third-party wheels (torch_geometric,
+ * torch_sparse / pyg_lib, torch_scatter).  This header is therefore the seam *under* the
+ * reference's Python API; each entry point names the reference call site whose native work it
+ * replaces.  All pointers are device pointers unless named *_host; all buffers are owned by the
+ * caller (torch-allocated); no function allocates, frees or synchronises; every function only
+ * enqueues work on `stream` (a hipStream_t) and returns a status:
+ *      0 = ok, <0 = argument error (KGW_E_*), >0 = hipError_t from a launch.
+ * No C++ exceptions cross this boundary.  Functions are re-entrant (no global mutable state).
+ *
+ * Vocabulary (the reference's domain): node types, relations (= edge types), seeds, hops,
+ * segments (= one destination row of one relation), chunks (<= KGW_CHUNK edges of one segment).
+ */
+#ifndef KGWAS_HIP_H
+#define KGWAS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KGW_VERSION      100          /* 0.1.0 */
+#define KGW_MAX_TYPES    8
+#define KGW_MAX_RELS     64
+#define KGW_MAX_LAYERS   4
+#define KGW_CHUNK        256          /* edges per chunk (one wavefront processes one chunk)  */
+#define KGW_TILE         1024         /* scan tile; per-type node regions are padded to this  */
+#define KGW_C            128          /* hidden width (gnn_hidden_dim, kgwas/kgwas.py:52)     */
+
+#define KGW_OK           0
+#define KGW_E_NULL      -1
+#define KGW_E_RANGE     -2
+#define KGW_E_UNSUPPORTED -3
+
+typedef void* kgw_stream_t;           /* hipStream_t */
+
+/* Resident knowledge graph: one dst-major CSR per relation, (dst, src)-sorted like the CSC that
+ * NeighborLoader builds once per edge type (kgwas/kgwas.py:99-113; PyG to_csc).               */
+typedef struct KgwGraph {
+    int32_t n_types, n_rels, n_layers, n_hops;  /* n_hops = n_layers (minibatch) or 1 (full graph) */
+    int32_t n_nodes[KGW_MAX_TYPES];       /* N_T                                             */
+    int32_t node_base[KGW_MAX_TYPES + 1]; /* KGW_TILE-aligned start of type T in g2l / n_id   */
+    int32_t R_dst[KGW_MAX_TYPES];         /* #relations whose destination type is T           */
+    int32_t R_src[KGW_MAX_TYPES];         /* #relations whose source type is T                */
+    int32_t rel_src[KGW_MAX_RELS];
+    int32_t rel_dst[KGW_MAX_RELS];
+    int32_t rel_slot_dst[KGW_MAX_RELS];   /* column block of relation r in Z[dst type]        */
+    int32_t rel_slot_src[KGW_MAX_RELS];
+    int64_t rowptr_off[KGW_MAX_RELS];     /* element offset of relation r inside g_rowptr     */
+    int64_t col_off[KGW_MAX_RELS];        /* element offset of relation r inside g_col        */
+    uint8_t rel_live[KGW_MAX_LAYERS][KGW_MAX_RELS]; /* [l-1][r]: layer l computes relation r  */
+    const int32_t* g_rowptr;              /* per relation N_dst+1 entries, relative to col_off */
+    const int32_t* g_col;                 /* global source ids                                */
+} KgwGraph;
+
+/* Counts and layouts of one sampled batch; written by the device, copied to meta_host.        */
+typedef struct KgwBatchMeta {
+    int32_t hop_cnt[KGW_MAX_TYPES][KGW_MAX_LAYERS + 1];   /* new nodes of type T at hop k      */
+    int32_t node_off[KGW_MAX_TYPES][KGW_MAX_LAYERS + 2];  /* prefix over hops (local id ranges) */
+    int32_t seg_off[KGW_MAX_LAYERS][KGW_MAX_RELS + 1];    /* first segment of (dst hop h, rel r) */
+    int32_t seg_end[KGW_MAX_LAYERS];     /* cumulative #segments through dst hop h             */
+    int32_t edge_end[KGW_MAX_LAYERS];    /* cumulative #edges    through dst hop h             */
+    int32_t chunk_end[KGW_MAX_LAYERS];   /* cumulative #chunks   through dst hop h             */
+    int32_t multi_cnt[KGW_MAX_LAYERS];   /* #multi-chunk segments in dst hop h                 */
+    /* per layer l (index l-1): */
+    int32_t n_rows[KGW_MAX_LAYERS][KGW_MAX_TYPES];   /* destination rows of type T            */
+    int32_t z_base[KGW_MAX_LAYERS][KGW_MAX_TYPES + 1]; /* first Z row (of 128 floats) of type T */
+    int32_t n_src[KGW_MAX_LAYERS][KGW_MAX_TYPES];    /* source rows of type T in the layer input */
+    int32_t src_base[KGW_MAX_LAYERS][KGW_MAX_TYPES + 1]; /* first H row of type T             */
+    int32_t t_base[KGW_MAX_LAYERS][KGW_MAX_TYPES + 1];   /* first transposed row of type T    */
+    int32_t n_chunks[KGW_MAX_LAYERS];    /* chunks used by layer l                             */
+    int32_t n_edges[KGW_MAX_LAYERS];     /* edges aggregated by layer l                        */
+    int32_t t_entries[KGW_MAX_LAYERS];   /* entries in the layer's src-major structure         */
+    int32_t cur[8];                      /* device-side scratch cursors                        */
+    int32_t error;                       /* !=0: a capacity was exceeded                       */
+    int32_t pad_[3];
+} KgwBatchMeta;
+
+/* Chunk record: <= KGW_CHUNK consecutive edges of one segment.  8 x int32 = 32 bytes.          */
+typedef struct KgwChunk {
+    int32_t e0, e1;        /* local (batch) edge range                                        */
+    int32_t row;           /* destination row (local id inside its node type)                 */
+    int32_t rel;           /* relation id                                                     */
+    int32_t first;         /* index of the first chunk of this segment                        */
+    int32_t nch;           /* #chunks of this segment (1 => this chunk writes final results)   */
+    int32_t gpos_lo, gpos_hi; /* position of edge e0 inside g_col (64-bit)                     */
+} KgwChunk;
+
+/* Buffers of one sampled batch (all device memory, worst-case sized by the caller).            */
+typedef struct KgwBatchBuf {
+    int32_t* g2l;          /* [node_base[n_types]] global -> local id, -1 = not sampled        */
+    int32_t* n_id;         /* [node_base[n_types]] local -> global id, per type region         */
+    int32_t* seg_deg;      /* [seg_cap]                                                        */
+    int32_t* seg_nch;      /* [seg_cap]                                                        */
+    int32_t* seg_ptr;      /* [seg_cap + 1]  first local edge of each segment                  */
+    int32_t* seg_chptr;    /* [seg_cap + 1]  first chunk of each segment                       */
+    int32_t* col_local;    /* [edge_cap]     source local id of each local edge                */
+    KgwChunk* chunks;      /* [chunk_cap]                                                      */
+    int32_t* multi;        /* [n_hops][multi_cap][4] = {first, nch, row, rel}                  */
+    int32_t* t_cnt[KGW_MAX_LAYERS];   /* [trow_cap + 1] histogram / cursor scratch             */
+    int32_t* t_ptr[KGW_MAX_LAYERS];   /* [trow_cap + 1] src-major row pointers                 */
+    int32_t* t_edge[KGW_MAX_LAYERS];  /* [edge_cap] local edge id of each entry                */
+    int32_t* t_zrow[KGW_MAX_LAYERS];  /* [edge_cap] Z row (dst row * R_dst + slot) of the entry */
+    int32_t* scan_tmp;     /* [2 * (max(seg_cap, node_cap, trow_cap) / KGW_TILE + 2)]          */
+    KgwBatchMeta* meta;    /* device                                                           */
+    KgwBatchMeta* meta_host; /* pinned host mirror (async D2H at the end of sampling)          */
+    int64_t seg_cap, edge_cap, chunk_cap, multi_cap, trow_cap, scan_cap;
+} KgwBatchBuf;
+
+/* One attention-aggregate layer over a sampled batch (kgwas/conv.py:177-190 for every relation
+ * of the layer at once + the relation sum of PyG HeteroConv, kgwas/model.py:74).               */
+typedef struct KgwLayerArgs {
+    int32_t layer;                 /* 1-based                                                  */
+    int32_t n_chunks, n_multi_hops;/* chunks [0,n_chunks); multi lists of dst hops [0,n_multi_hops) */
+    int32_t n_src_rows;            /* rows of H                                                */
+    float   neg_slope, inv_temp;   /* LeakyReLU slope (0.2), 1/temperature (1)                 */
+    const KgwGraph* graph_host;    /* host copy, passed by value to the kernels               */
+    const KgwBatchMeta* meta_host; /* host copy (after the sampling event completed)          */
+    const KgwChunk* chunks;
+    const int32_t* multi;  int64_t multi_cap;
+    const int32_t* col_local;
+    const float* H;                /* [n_src_rows][128] layer input, type-major (src_base)     */
+    const float* a_dst;            /* [z rows]  <h_dst[i], W_dst^T att_dst> per (row, relation) */
+    const float* U;                /* [n_rels][128]  u_r = W_src^T att_src                     */
+    float* Z;                      /* [z rows][128]  sum_j alpha_ij h_src[j]  (pre-zeroed)      */
+    float* stat;                   /* [z rows][2]    (row max, denominator)                    */
+    float* e_edge;                 /* [n_edges]      leaky_relu logits per local edge          */
+    float* part;                   /* [n_chunks][130] partial (m, s, acc) of multi-chunk segs  */
+    /* backward */
+    const float* dZ;               /* [z rows][128]                                            */
+    float* adp;                    /* [n_edges][2]   (alpha, d pre-activation) per local edge  */
+    float* da_dst;                 /* [z rows]                                                 */
+    float* part_da;                /* [n_chunks]                                               */
+    const int32_t* t_ptr; const int32_t* t_edge; const int32_t* t_zrow;
+    float* dH;                     /* [n_src_rows][128]                                        */
+    float* da_src;                 /* [t rows] d a_src per (source row, relation slot)         */
+} KgwLayerArgs;
+
+/* ---- entry points ------------------------------------------------------------------------ */
+
+int kgw_version(void);
+const char* kgw_status_string(int status);
+/* sizeof() of the ABI structs in the order Graph, BatchMeta, Chunk, BatchBuf, LayerArgs -- lets a
+ * binding verify its mirror structs.                                                          */
+int kgw_struct_sizes(int64_t* out, int n);
+
+/* Replaces: NeighborLoader.__next__ (kgwas/kgwas.py:99-113,129; torch_sparse/pyg_lib
+ * hetero_neighbor_sample + relabel).  Expands `n_seeds` seed nodes of type `seed_type` over
+ * n_hops hops taking ALL in-neighbours, writes local ids, per-segment CSR, chunk lists and the
+ * src-major (transposed) structure of every layer, then copies KgwBatchMeta to meta_host.
+ * full_graph != 0: every node of every type is a seed (whole-graph inference / attention export,
+ * kgwas/utils.py:446-461).                                                                    */
+int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, const int64_t* seeds,
+                     int32_t n_seeds, int32_t seed_type, int32_t full_graph, kgw_stream_t stream);
+
+/* Replaces: GATConv.edge_update + message + aggregate (kgwas/conv.py:200-228,182) and their
+ * autograd for all relations of one layer.                                                    */
+int kgw_gat_aggregate_fwd(const KgwLayerArgs* args, kgw_stream_t stream);
+int kgw_gat_aggregate_bwd_dst(const KgwLayerArgs* args, kgw_stream_t stream);
+int kgw_gat_aggregate_bwd_src(const KgwLayerArgs* args, kgw_stream_t stream);
+
+/* Replaces: the index_select feature slicing of the loader (x[n_id], kgwas/kgwas.py:135).      */
+int kgw_gather_rows(const float* src, const int32_t* ids, int64_t n_rows, int32_t width,
+                    float* dst, kgw_stream_t stream);
+
+/* alpha_e = exp(e - max)/den per local edge of one layer (attention export,
+ * kgwas/conv.py:192-196; kgwas/utils.py:446-461).                                             */
+int kgw_edge_alpha(const KgwLayerArgs* args, float* alpha_out, kgw_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KGWAS_HIP_H */

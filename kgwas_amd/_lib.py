@@ -1,0 +1,148 @@
+"""ctypes binding of libkgwas_hip.so (include/kgwas_hip.h).  Fails loudly when the library is missing:
+there is NO CPU fallback for the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+KGW_MAX_TYPES = 8
+KGW_MAX_RELS = 64
+KGW_MAX_LAYERS = 4
+KGW_CHUNK = 256
+KGW_TILE = 1024
+KGW_C = 128
+PART_STRIDE = 132
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libkgwas_hip.so')
+
+
+class KgwGraph(C.Structure):
+    _fields_ = [
+        ('n_types', C.c_int32), ('n_rels', C.c_int32), ('n_layers', C.c_int32), ('n_hops', C.c_int32),
+        ('n_nodes', C.c_int32 * KGW_MAX_TYPES),
+        ('node_base', C.c_int32 * (KGW_MAX_TYPES + 1)),
+        ('R_dst', C.c_int32 * KGW_MAX_TYPES),
+        ('R_src', C.c_int32 * KGW_MAX_TYPES),
+        ('rel_src', C.c_int32 * KGW_MAX_RELS),
+        ('rel_dst', C.c_int32 * KGW_MAX_RELS),
+        ('rel_slot_dst', C.c_int32 * KGW_MAX_RELS),
+        ('rel_slot_src', C.c_int32 * KGW_MAX_RELS),
+        ('rowptr_off', C.c_int64 * KGW_MAX_RELS),
+        ('col_off', C.c_int64 * KGW_MAX_RELS),
+        ('rel_live', (C.c_uint8 * KGW_MAX_RELS) * KGW_MAX_LAYERS),
+        ('g_rowptr', C.c_void_p),
+        ('g_col', C.c_void_p),
+    ]
+
+
+class KgwBatchMeta(C.Structure):
+    _fields_ = [
+        ('hop_cnt', (C.c_int32 * (KGW_MAX_LAYERS + 1)) * KGW_MAX_TYPES),
+        ('node_off', (C.c_int32 * (KGW_MAX_LAYERS + 2)) * KGW_MAX_TYPES),
+        ('seg_off', (C.c_int32 * (KGW_MAX_RELS + 1)) * KGW_MAX_LAYERS),
+        ('seg_end', C.c_int32 * KGW_MAX_LAYERS),
+        ('edge_end', C.c_int32 * KGW_MAX_LAYERS),
+        ('chunk_end', C.c_int32 * KGW_MAX_LAYERS),
+        ('multi_cnt', C.c_int32 * KGW_MAX_LAYERS),
+        ('n_rows', (C.c_int32 * KGW_MAX_TYPES) * KGW_MAX_LAYERS),
+        ('z_base', (C.c_int32 * (KGW_MAX_TYPES + 1)) * KGW_MAX_LAYERS),
+        ('n_src', (C.c_int32 * KGW_MAX_TYPES) * KGW_MAX_LAYERS),
+        ('src_base', (C.c_int32 * (KGW_MAX_TYPES + 1)) * KGW_MAX_LAYERS),
+        ('t_base', (C.c_int32 * (KGW_MAX_TYPES + 1)) * KGW_MAX_LAYERS),
+        ('n_chunks', C.c_int32 * KGW_MAX_LAYERS),
+        ('n_edges', C.c_int32 * KGW_MAX_LAYERS),
+        ('t_entries', C.c_int32 * KGW_MAX_LAYERS),
+        ('cur', C.c_int32 * 8),
+        ('error', C.c_int32),
+        ('pad_', C.c_int32 * 3),
+    ]
+
+
+class KgwChunk(C.Structure):
+    _fields_ = [('e0', C.c_int32), ('e1', C.c_int32), ('row', C.c_int32), ('rel', C.c_int32),
+                ('first', C.c_int32), ('nch', C.c_int32), ('gpos_lo', C.c_int32), ('gpos_hi', C.c_int32)]
+
+
+class KgwBatchBuf(C.Structure):
+    _fields_ = [
+        ('g2l', C.c_void_p), ('n_id', C.c_void_p), ('seg_deg', C.c_void_p), ('seg_nch', C.c_void_p),
+        ('seg_ptr', C.c_void_p), ('seg_chptr', C.c_void_p), ('col_local', C.c_void_p),
+        ('chunks', C.c_void_p), ('multi', C.c_void_p),
+        ('t_cnt', C.c_void_p * KGW_MAX_LAYERS), ('t_ptr', C.c_void_p * KGW_MAX_LAYERS),
+        ('t_edge', C.c_void_p * KGW_MAX_LAYERS), ('t_zrow', C.c_void_p * KGW_MAX_LAYERS),
+        ('scan_tmp', C.c_void_p), ('meta', C.c_void_p), ('meta_host', C.c_void_p),
+        ('seg_cap', C.c_int64), ('edge_cap', C.c_int64), ('chunk_cap', C.c_int64),
+        ('multi_cap', C.c_int64), ('trow_cap', C.c_int64), ('scan_cap', C.c_int64),
+    ]
+
+
+class KgwLayerArgs(C.Structure):
+    _fields_ = [
+        ('layer', C.c_int32), ('n_chunks', C.c_int32), ('n_multi_hops', C.c_int32), ('n_src_rows', C.c_int32),
+        ('neg_slope', C.c_float), ('inv_temp', C.c_float),
+        ('graph_host', C.c_void_p), ('meta_host', C.c_void_p),
+        ('chunks', C.c_void_p), ('multi', C.c_void_p), ('multi_cap', C.c_int64),
+        ('col_local', C.c_void_p), ('H', C.c_void_p), ('a_dst', C.c_void_p), ('U', C.c_void_p),
+        ('Z', C.c_void_p), ('stat', C.c_void_p), ('e_edge', C.c_void_p), ('part', C.c_void_p),
+        ('dZ', C.c_void_p), ('adp', C.c_void_p), ('da_dst', C.c_void_p), ('part_da', C.c_void_p),
+        ('t_ptr', C.c_void_p), ('t_edge', C.c_void_p), ('t_zrow', C.c_void_p),
+        ('dH', C.c_void_p), ('da_src', C.c_void_p),
+    ]
+
+
+EXPORTS = ['kgw_version', 'kgw_status_string', 'kgw_struct_sizes', 'kgw_sample_batch',
+           'kgw_gat_aggregate_fwd', 'kgw_gat_aggregate_bwd_dst', 'kgw_gat_aggregate_bwd_src',
+           'kgw_gather_rows', 'kgw_edge_alpha']
+
+_lib = None
+
+
+class KgwasHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libkgwas_hip.so once.  Raises (never falls back) when it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KgwasHipError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950).  kgwas_amd has no CPU fallback.')
+    L = C.CDLL(LIB_PATH)
+    L.kgw_version.restype = C.c_int
+    L.kgw_status_string.restype = C.c_char_p
+    L.kgw_status_string.argtypes = [C.c_int]
+    L.kgw_struct_sizes.argtypes = [C.POINTER(C.c_int64), C.c_int]
+    sizes = (C.c_int64 * 5)()
+    L.kgw_struct_sizes(sizes, 5)
+    mine = [C.sizeof(KgwGraph), C.sizeof(KgwBatchMeta), C.sizeof(KgwChunk), C.sizeof(KgwBatchBuf),
+            C.sizeof(KgwLayerArgs)]
+    if list(sizes) != mine:
+        raise KgwasHipError(f'ABI struct size mismatch: library {list(sizes)} vs binding {mine}')
+    L.kgw_sample_batch.argtypes = [C.POINTER(KgwGraph), C.POINTER(KgwBatchBuf), C.c_void_p, C.c_int32,
+                                   C.c_int32, C.c_int32, C.c_void_p]
+    for name in ('kgw_gat_aggregate_fwd', 'kgw_gat_aggregate_bwd_dst', 'kgw_gat_aggregate_bwd_src'):
+        getattr(L, name).argtypes = [C.POINTER(KgwLayerArgs), C.c_void_p]
+    L.kgw_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+    L.kgw_edge_alpha.argtypes = [C.POINTER(KgwLayerArgs), C.c_void_p, C.c_void_p]
+    if hasattr(L, 'kgw_linear_fwd'):
+        L.kgw_linear_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_void_p]
+        L.kgw_linear_bwd_w.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_void_p]
+    _lib = L
+    return L
+
+
+def check(status: int, what: str):
+    if status != 0:
+        msg = lib().kgw_status_string(int(status))
+        raise KgwasHipError(f'{what} failed: status {status} ({msg.decode() if msg else "?"})')
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,530 @@
+// kgw_aggregate.hip -- fused per-relation graph-attention aggregate for KGWAS on gfx950 (CDNA4).
+//
+// Replaces, for ALL relations of one HeteroConv layer in one launch, the >= 14 unfused tensor ops
+// per relation that the reference runs through PyG (kgwas/conv.py:150-152,177,182,200-228):
+//      a_s[j] = <h_src[j], u_r>                       u_r = W_src^T att_src      (conv.py:150)
+//      e_ij   = leaky_relu(a_s[j] + a_d[i], 0.2)                                 (conv.py:205,217)
+//      alpha  = softmax_i(e_ij / T)   (max-subtracted, denominator + 1e-16)      (conv.py:223)
+//      z_i    = sum_j alpha_ij h_src[j]                                          (conv.py:227,182)
+// The per-relation linear map is applied AFTER the aggregation by the caller
+// (out_i = W_src z_i + bias, an exact re-association of conv.py:138-142 + :228), so the gathered rows
+// are the layer input itself and every relation sharing a source type gathers the same tensor.
+//
+// HBM roofline kernel.  Algorithmic bytes per edge: 4 (col) + 512 (one 128-float row) + 4 (logit).
+// Mapping: one wavefront per chunk (<= 256 edges of one destination row of one relation); each
+// 32-lane half-wave owns one edge at a time and reads its 512-byte row as one float4 per lane
+// (1 KiB per wave-instruction, 8 rows in flight per half); the dot product with u_r is reduced
+// inside the half-wave with 4 DPP butterflies + one v_permlane16_swap; softmax is online
+// (running max / sum), rescaled once per group of 8 edges; hub rows span several chunks whose
+// partial (max, sum, acc) are merged by a second tiny kernel.  No atomics anywhere.
+//
+// Backward is split the same way the data is laid out: a dst-major pass (re-gathers h_src rows,
+// produces per-edge (alpha, d pre-activation) and d a_dst) and a src-major pass over the transposed
+// structure built by the sampler (gathers dZ rows, produces dH and d a_src).
+#include "kgw_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int PART_STRIDE = 132;      // floats per partial record: [0]=max [1]=sum [4..131]=acc
+constexpr float NEG_BIG = -1.0e30f;
+
+struct LayerTab {
+    int32_t n_rels, n_types;
+    int32_t src_base[KGW_MAX_RELS];   // first H row of the relation's source type
+    int32_t z0[KGW_MAX_RELS];         // z_base[dst type] + slot_dst
+    int32_t zstride[KGW_MAX_RELS];    // R_dst[dst type]
+    int32_t live[KGW_MAX_RELS];
+    // src-major view
+    int32_t type_src_base[KGW_MAX_TYPES + 1];
+    int32_t type_t_base[KGW_MAX_TYPES + 1];
+    int32_t type_R_src[KGW_MAX_TYPES];
+    int32_t rel_of_slot[KGW_MAX_TYPES][KGW_MAX_RELS / 2];   // relation id of (source type, slot)
+};
+
+struct AggPtrs {
+    const KgwChunk* chunks;
+    const int32_t* col_local;
+    const float* H;
+    const float* a_dst;
+    const float* U;
+    float* Z;
+    float* stat;
+    float* e_edge;
+    float* part;
+    const float* dZ;
+    float* adp;
+    float* da_dst;
+    float* part_da;
+    const int32_t* t_ptr;
+    const int32_t* t_edge;
+    const int32_t* t_zrow;
+    float* dH;
+    float* da_src;
+    const int32_t* multi;
+    int64_t multi_cap;
+};
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+    return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+}
+__device__ __forceinline__ void fma4(float4& acc, float w, const float4& x) {
+    acc.x = fmaf(w, x.x, acc.x); acc.y = fmaf(w, x.y, acc.y);
+    acc.z = fmaf(w, x.z, acc.z); acc.w = fmaf(w, x.w, acc.w);
+}
+__device__ __forceinline__ void scale4(float4& a, float s) { a.x *= s; a.y *= s; a.z *= s; a.w *= s; }
+
+__device__ __forceinline__ KgwChunk load_chunk(const KgwChunk* chunks, int c) {
+    // c is wave-uniform: read through the scalar path
+    const int cu = __builtin_amdgcn_readfirstlane(c);
+    return chunks[cu];
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ void fwd_group(const float4* __restrict__ Hb4, int colv, int q0, int hn, int nb,
+                                          int half, int hl, const float4& u4, float ad, float slope,
+                                          float inv_temp, float& m, float& s, float4& acc, float& ev) {
+    float4 x[G];
+    bool valid[G];
+#pragma unroll
+    for (int p = 0; p < G; ++p) {
+        const int q = q0 + p;
+        const int i = half * hn + q;
+        valid[p] = (q < hn) && (i < nb);
+        const int cj = __shfl(colv, valid[p] ? i : 0, 64);
+        x[p] = Hb4[(int64_t)cj * 32 + hl];
+    }
+    float t[G];
+    float mb = -INFINITY;
+#pragma unroll
+    for (int p = 0; p < G; ++p) {
+        float d = kgw_half_allsum(dot4(x[p], u4)) + ad;
+        d = d > 0.f ? d : d * slope;
+        ev = (hl == q0 + p) ? d : ev;              // lane (half, hl) keeps the logit of edge half*hn+hl
+        t[p] = valid[p] ? d * inv_temp : -INFINITY;
+        mb = fmaxf(mb, t[p]);
+    }
+    const float mn = fmaxf(m, mb);
+    const float sc = __expf(m - mn);
+    s *= sc; scale4(acc, sc); m = mn;
+#pragma unroll
+    for (int p = 0; p < G; ++p) {
+        const float w = __expf(t[p] - mn);
+        s += w;
+        fma4(acc, w, x[p]);
+    }
+}
+
+__global__ void __launch_bounds__(KGW_BLK) k_agg_fwd(LayerTab T, AggPtrs P, int n_chunks, float slope, float inv_temp) {
+    const int lane = kgw_lane(), half = lane >> 5, hl = lane & 31;
+    const int nw = gridDim.x * 4;
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < n_chunks; c += nw) {
+        const KgwChunk ck = load_chunk(P.chunks, c);
+        const int r = ck.rel;
+        if (!T.live[r]) continue;
+        const int zrow = T.z0[r] + ck.row * T.zstride[r];
+        const float ad = P.a_dst[zrow];
+        const float4 u4 = ((const float4*)(P.U + (int64_t)r * KGW_C))[hl];
+        const float4* Hb4 = (const float4*)(P.H + (int64_t)T.src_base[r] * KGW_C);
+        float m = NEG_BIG, s = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int n = ck.e1 - ck.e0;
+        for (int b = 0; b < n; b += 64) {
+            const int nb = min(64, n - b);
+            const int hn = (nb + 1) >> 1;
+            const int colv = (lane < nb) ? P.col_local[ck.e0 + b + lane] : 0;
+            float ev = 0.f;
+            for (int q0 = 0; q0 < hn;) {
+                const int rem = hn - q0;
+                if (rem > 4)      { fwd_group<8>(Hb4, colv, q0, hn, nb, half, hl, u4, ad, slope, inv_temp, m, s, acc, ev); q0 += 8; }
+                else if (rem > 2) { fwd_group<4>(Hb4, colv, q0, hn, nb, half, hl, u4, ad, slope, inv_temp, m, s, acc, ev); q0 += 4; }
+                else              { fwd_group<2>(Hb4, colv, q0, hn, nb, half, hl, u4, ad, slope, inv_temp, m, s, acc, ev); q0 += 2; }
+            }
+            const int i = half * hn + hl;
+            if (hl < hn && i < nb) P.e_edge[ck.e0 + b + i] = ev;
+        }
+        // merge the two half-wave states
+        const float mo = kgw_xhalf(m);
+        const float M = fmaxf(m, mo);
+        const float f = __expf(m - M);
+        s *= f; scale4(acc, f);
+        const float S = s + kgw_xhalf(s);
+        acc.x += kgw_xhalf(acc.x); acc.y += kgw_xhalf(acc.y);
+        acc.z += kgw_xhalf(acc.z); acc.w += kgw_xhalf(acc.w);
+        if (ck.nch == 1) {
+            const float den = S + 1e-16f;
+            const float inv = 1.0f / den;
+            if (half == 0) {
+                scale4(acc, inv);
+                ((float4*)(P.Z + (int64_t)zrow * KGW_C))[hl] = acc;
+            }
+            if (lane == 0) { P.stat[2 * (int64_t)zrow] = M; P.stat[2 * (int64_t)zrow + 1] = den; }
+        } else {
+            float* pr = P.part + (int64_t)c * PART_STRIDE;
+            if (half == 0) ((float4*)(pr + 4))[hl] = acc;
+            if (lane == 0) { pr[0] = M; pr[1] = S; }
+        }
+    }
+}
+
+__device__ __forceinline__ float wave_allmax(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_allsum_slow(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// one wavefront per multi-chunk segment: merge partial (max, sum, acc)
+__global__ void __launch_bounds__(KGW_BLK) k_agg_fwd_combine(LayerTab T, AggPtrs P, int hop, int n_multi) {
+    const int lane = kgw_lane();
+    const int nw = gridDim.x * 4;
+    const int32_t* mm = P.multi + (int64_t)hop * P.multi_cap * 4;
+    for (int k = blockIdx.x * 4 + (threadIdx.x >> 6); k < n_multi; k += nw) {
+        const int first = mm[4 * k], nch = mm[4 * k + 1], row = mm[4 * k + 2], r = mm[4 * k + 3];
+        if (!T.live[r]) continue;
+        const int zrow = T.z0[r] + row * T.zstride[r];
+        float mx = NEG_BIG;
+        for (int c = lane; c < nch; c += 64) mx = fmaxf(mx, P.part[(int64_t)(first + c) * PART_STRIDE]);
+        const float M = wave_allmax(mx);
+        float S = 0.f;
+        float2 acc = make_float2(0.f, 0.f);
+        for (int c = 0; c < nch; ++c) {
+            const float* pr = P.part + (int64_t)(first + c) * PART_STRIDE;
+            const float f = __expf(pr[0] - M);
+            S = fmaf(pr[1], f, S);
+            const float2 a = ((const float2*)(pr + 4))[lane];
+            acc.x = fmaf(a.x, f, acc.x); acc.y = fmaf(a.y, f, acc.y);
+        }
+        const float den = S + 1e-16f, inv = 1.0f / den;
+        ((float2*)(P.Z + (int64_t)zrow * KGW_C))[lane] = make_float2(acc.x * inv, acc.y * inv);
+        if (lane == 0) { P.stat[2 * (int64_t)zrow] = M; P.stat[2 * (int64_t)zrow + 1] = den; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, dst-major pass
+// ------------------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ void bwd_group(const float4* __restrict__ Hb4, int colv, float evin, int q0, int hn,
+                                          int nb, int half, int hl, const float4& dz4, float cdot, float M,
+                                          float inv_den, float slope, float inv_temp, float& av, float& dv,
+                                          float& dsum) {
+    float4 x[G];
+    float t[G];
+#pragma unroll
+    for (int p = 0; p < G; ++p) {
+        const int q = q0 + p;
+        const int i = half * hn + q;
+        const bool valid = (q < hn) && (i < nb);
+        const int cj = __shfl(colv, valid ? i : 0, 64);
+        x[p] = Hb4[(int64_t)cj * 32 + hl];
+        const float e = __shfl(evin, half * 32 + (q & 31), 64);   // logit kept by lane (half, q)
+        t[p] = valid ? e : -INFINITY;
+    }
+#pragma unroll
+    for (int p = 0; p < G; ++p) {
+        const float dalpha = kgw_half_allsum(dot4(x[p], dz4));
+        const float alpha = __expf(t[p] * inv_temp - M) * inv_den;
+        const float dlogit = alpha * (dalpha - cdot);
+        const float dpre = dlogit * inv_temp * (t[p] > 0.f ? 1.0f : slope);
+        av = (hl == q0 + p) ? alpha : av;
+        dv = (hl == q0 + p) ? dpre : dv;
+        dsum += dpre;
+    }
+}
+
+__global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_dst(LayerTab T, AggPtrs P, int n_chunks, float slope, float inv_temp) {
+    const int lane = kgw_lane(), half = lane >> 5, hl = lane & 31;
+    const int nw = gridDim.x * 4;
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < n_chunks; c += nw) {
+        const KgwChunk ck = load_chunk(P.chunks, c);
+        const int r = ck.rel;
+        if (!T.live[r]) continue;
+        const int zrow = T.z0[r] + ck.row * T.zstride[r];
+        const float4 dz4 = ((const float4*)(P.dZ + (int64_t)zrow * KGW_C))[hl];
+        const float4 z4 = ((const float4*)(P.Z + (int64_t)zrow * KGW_C))[hl];
+        const float cdot = kgw_half_allsum(dot4(dz4, z4));     // sum_k alpha_ik dalpha_ik = <dz_i, z_i>
+        const float M = P.stat[2 * (int64_t)zrow];
+        const float inv_den = 1.0f / P.stat[2 * (int64_t)zrow + 1];
+        const float4* Hb4 = (const float4*)(P.H + (int64_t)T.src_base[r] * KGW_C);
+        float dsum = 0.f;
+        const int n = ck.e1 - ck.e0;
+        for (int b = 0; b < n; b += 64) {
+            const int nb = min(64, n - b);
+            const int hn = (nb + 1) >> 1;
+            const int colv = (lane < nb) ? P.col_local[ck.e0 + b + lane] : 0;
+            const int i = half * hn + hl;
+            const bool mine = (hl < hn) && (i < nb);
+            const float evin = mine ? P.e_edge[ck.e0 + b + i] : 0.f;
+            float av = 0.f, dv = 0.f;
+            for (int q0 = 0; q0 < hn;) {
+                const int rem = hn - q0;
+                if (rem > 4)      { bwd_group<8>(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum); q0 += 8; }
+                else if (rem > 2) { bwd_group<4>(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum); q0 += 4; }
+                else              { bwd_group<2>(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum); q0 += 2; }
+            }
+            if (mine) ((float2*)P.adp)[ck.e0 + b + i] = make_float2(av, dv);
+        }
+        const float tot = dsum + kgw_xhalf(dsum);
+        if (lane == 0) {
+            if (ck.nch == 1) P.da_dst[zrow] = tot; else P.part_da[c] = tot;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_combine(LayerTab T, AggPtrs P, int hop, int n_multi) {
+    const int lane = kgw_lane();
+    const int nw = gridDim.x * 4;
+    const int32_t* mm = P.multi + (int64_t)hop * P.multi_cap * 4;
+    for (int k = blockIdx.x * 4 + (threadIdx.x >> 6); k < n_multi; k += nw) {
+        const int first = mm[4 * k], nch = mm[4 * k + 1], row = mm[4 * k + 2], r = mm[4 * k + 3];
+        if (!T.live[r]) continue;
+        const int zrow = T.z0[r] + row * T.zstride[r];
+        // fixed-order tree: lane-strided partial sums, then butterfly
+        float s = 0.f;
+        for (int c = lane; c < nch; c += 64) s += P.part_da[first + c];
+        s = wave_allsum_slow(s);
+        if (lane == 0) P.da_dst[zrow] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, src-major pass: one wavefront per source row
+// ------------------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ void src_group(const float4* __restrict__ dZ4, int tz, float al, int q0, int hn,
+                                          int nb, int half, int hl, float4& acc) {
+    float4 x[G];
+    float w[G];
+#pragma unroll
+    for (int p = 0; p < G; ++p) {
+        const int q = q0 + p;
+        const int i = half * hn + q;
+        const bool valid = (q < hn) && (i < nb);
+        const int z = __shfl(tz, valid ? i : 0, 64);
+        const float a = __shfl(al, valid ? i : 0, 64);
+        w[p] = valid ? a : 0.f;
+        x[p] = dZ4[(int64_t)z * 32 + hl];
+    }
+#pragma unroll
+    for (int p = 0; p < G; ++p) fma4(acc, w[p], x[p]);
+}
+
+__global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, int n_src_rows) {
+    const int lane = kgw_lane(), half = lane >> 5, hl = lane & 31;
+    const int nw = gridDim.x * 4;
+    const float4* dZ4 = (const float4*)P.dZ;
+    for (int u0 = blockIdx.x * 4 + (threadIdx.x >> 6); u0 < n_src_rows; u0 += nw) {
+        const int u = __builtin_amdgcn_readfirstlane(u0);
+        int ty = 0;
+        while (ty + 1 < T.n_types && u >= T.type_src_base[ty + 1]) ++ty;
+        const int j = u - T.type_src_base[ty];
+        const int Rs = T.type_R_src[ty];
+        const int tb = T.type_t_base[ty] + j * Rs;
+        const int p0 = P.t_ptr[tb], p1 = P.t_ptr[tb + Rs];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float dasv = 0.f;                                    // lane k holds d a_src of slot k
+        for (int pb = p0; pb < p1; pb += 64) {
+            const int nb = min(64, p1 - pb);
+            const int hn = (nb + 1) >> 1;
+            int te = 0, tz = 0;
+            float al = 0.f, dp = 0.f;
+            if (lane < nb) {
+                te = P.t_edge[pb + lane];
+                tz = P.t_zrow[pb + lane];
+                const float2 a2 = ((const float2*)P.adp)[te];
+                al = a2.x; dp = a2.y;
+            }
+            // per-slot sums of d pre-activation (entries of one source are grouped by slot)
+            for (int k = 0; k < Rs; ++k) {
+                const int s0 = P.t_ptr[tb + k], s1 = P.t_ptr[tb + k + 1];
+                if (s1 <= pb || s0 >= pb + nb || s0 == s1) continue;
+                const int pos = pb + lane;
+                const float v = (lane < nb && pos >= s0 && pos < s1) ? dp : 0.f;
+                const float sk = kgw_wave_allsum(v);
+                dasv += (lane == k) ? sk : 0.f;
+            }
+            for (int q0 = 0; q0 < hn;) {
+                const int rem = hn - q0;
+                if (rem > 4)      { src_group<8>(dZ4, tz, al, q0, hn, nb, half, hl, acc); q0 += 8; }
+                else if (rem > 2) { src_group<4>(dZ4, tz, al, q0, hn, nb, half, hl, acc); q0 += 4; }
+                else              { src_group<2>(dZ4, tz, al, q0, hn, nb, half, hl, acc); q0 += 2; }
+            }
+        }
+        acc.x += kgw_xhalf(acc.x); acc.y += kgw_xhalf(acc.y);
+        acc.z += kgw_xhalf(acc.z); acc.w += kgw_xhalf(acc.w);
+        if (p1 > p0) {
+            // d a_src flows back into h_src through a_s = <h_src, u_r>
+            for (int k = 0; k < Rs; ++k) {
+                const float dk = __shfl(dasv, k, 64);
+                if (dk != 0.f) {
+                    const int r = T.rel_of_slot[ty][k];
+                    const float4 u4 = ((const float4*)(P.U + (int64_t)r * KGW_C))[hl];
+                    fma4(acc, dk, u4);
+                }
+            }
+        }
+        if (half == 0) ((float4*)(P.dH + (int64_t)u * KGW_C))[hl] = acc;
+        if (lane < Rs) P.da_src[tb + lane] = dasv;
+    }
+}
+
+// alpha per local edge (attention export)
+__global__ void __launch_bounds__(KGW_BLK) k_edge_alpha(LayerTab T, AggPtrs P, int n_chunks, float inv_temp, float* out) {
+    const int lane = kgw_lane();
+    const int nw = gridDim.x * 4;
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < n_chunks; c += nw) {
+        const KgwChunk ck = load_chunk(P.chunks, c);
+        const int r = ck.rel;
+        const int n = ck.e1 - ck.e0;
+        if (!T.live[r]) { for (int t = lane; t < n; t += 64) out[ck.e0 + t] = 0.f; continue; }
+        const int zrow = T.z0[r] + ck.row * T.zstride[r];
+        const float M = P.stat[2 * (int64_t)zrow];
+        const float inv_den = 1.0f / P.stat[2 * (int64_t)zrow + 1];
+        for (int t = lane; t < n; t += 64)
+            out[ck.e0 + t] = __expf(P.e_edge[ck.e0 + t] * inv_temp - M) * inv_den;
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+int build_tab(const KgwLayerArgs* a, LayerTab* T) {
+    const KgwGraph* G = a->graph_host;
+    const KgwBatchMeta* M = a->meta_host;
+    if (!G || !M) return KGW_E_NULL;
+    const int l = a->layer;
+    if (l < 1 || l > G->n_layers) return KGW_E_RANGE;
+    if (G->n_rels > KGW_MAX_RELS || G->n_types > KGW_MAX_TYPES) return KGW_E_RANGE;
+    T->n_rels = G->n_rels;
+    T->n_types = G->n_types;
+    for (int r = 0; r < G->n_rels; ++r) {
+        const int s = G->rel_src[r], d = G->rel_dst[r];
+        T->src_base[r] = M->src_base[l - 1][s];
+        T->z0[r] = M->z_base[l - 1][d] + G->rel_slot_dst[r];
+        T->zstride[r] = G->R_dst[d];
+        T->live[r] = G->rel_live[l - 1][r];
+        if (G->rel_slot_src[r] >= KGW_MAX_RELS / 2) return KGW_E_RANGE;
+        T->rel_of_slot[s][G->rel_slot_src[r]] = r;
+    }
+    for (int t = 0; t <= G->n_types; ++t) {
+        T->type_src_base[t] = M->src_base[l - 1][t];
+        T->type_t_base[t] = M->t_base[l - 1][t];
+        if (t < G->n_types) T->type_R_src[t] = G->R_src[t];
+    }
+    return KGW_OK;
+}
+
+AggPtrs build_ptrs(const KgwLayerArgs* a) {
+    AggPtrs P;
+    P.chunks = a->chunks; P.col_local = a->col_local; P.H = a->H; P.a_dst = a->a_dst; P.U = a->U;
+    P.Z = a->Z; P.stat = a->stat; P.e_edge = a->e_edge; P.part = a->part; P.dZ = a->dZ; P.adp = a->adp;
+    P.da_dst = a->da_dst; P.part_da = a->part_da; P.t_ptr = a->t_ptr; P.t_edge = a->t_edge;
+    P.t_zrow = a->t_zrow; P.dH = a->dH; P.da_src = a->da_src; P.multi = a->multi; P.multi_cap = a->multi_cap;
+    return P;
+}
+
+inline int grid_for_waves(int64_t n_waves) {
+    int64_t g = (n_waves + 3) / 4;
+    if (g > KGW_GRID) g = KGW_GRID;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int kgw_gat_aggregate_fwd(const KgwLayerArgs* a, kgw_stream_t stream_) {
+    if (!a) return KGW_E_NULL;
+    if (a->n_chunks == 0) return KGW_OK;
+    if (!a->chunks || !a->col_local || !a->H || !a->a_dst || !a->U || !a->Z || !a->stat || !a->e_edge || !a->part)
+        return KGW_E_NULL;
+    LayerTab T;
+    int rc = build_tab(a, &T);
+    if (rc) return rc;
+    AggPtrs P = build_ptrs(a);
+    hipStream_t st = (hipStream_t)stream_;
+    k_agg_fwd<<<grid_for_waves(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->n_chunks, a->neg_slope, a->inv_temp);
+    KGW_LAUNCH_CHECK();
+    for (int h = 0; h < a->n_multi_hops; ++h) {
+        const int nm = a->meta_host->multi_cnt[h];
+        if (nm == 0) continue;
+        if (!a->multi) return KGW_E_NULL;
+        k_agg_fwd_combine<<<grid_for_waves(nm), KGW_BLK, 0, st>>>(T, P, h, nm);
+        KGW_LAUNCH_CHECK();
+    }
+    return KGW_OK;
+}
+
+extern "C" int kgw_gat_aggregate_bwd_dst(const KgwLayerArgs* a, kgw_stream_t stream_) {
+    if (!a) return KGW_E_NULL;
+    if (a->n_chunks == 0) return KGW_OK;
+    if (!a->chunks || !a->col_local || !a->H || !a->Z || !a->stat || !a->e_edge || !a->dZ || !a->adp ||
+        !a->da_dst || !a->part_da)
+        return KGW_E_NULL;
+    LayerTab T;
+    int rc = build_tab(a, &T);
+    if (rc) return rc;
+    AggPtrs P = build_ptrs(a);
+    hipStream_t st = (hipStream_t)stream_;
+    k_agg_bwd_dst<<<grid_for_waves(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->n_chunks, a->neg_slope, a->inv_temp);
+    KGW_LAUNCH_CHECK();
+    for (int h = 0; h < a->n_multi_hops; ++h) {
+        const int nm = a->meta_host->multi_cnt[h];
+        if (nm == 0) continue;
+        if (!a->multi) return KGW_E_NULL;
+        k_agg_bwd_combine<<<grid_for_waves(nm), KGW_BLK, 0, st>>>(T, P, h, nm);
+        KGW_LAUNCH_CHECK();
+    }
+    return KGW_OK;
+}
+
+extern "C" int kgw_gat_aggregate_bwd_src(const KgwLayerArgs* a, kgw_stream_t stream_) {
+    if (!a) return KGW_E_NULL;
+    if (a->n_src_rows == 0) return KGW_OK;
+    if (!a->dZ || !a->adp || !a->t_ptr || !a->t_edge || !a->t_zrow || !a->dH || !a->da_src || !a->U)
+        return KGW_E_NULL;
+    LayerTab T;
+    int rc = build_tab(a, &T);
+    if (rc) return rc;
+    AggPtrs P = build_ptrs(a);
+    k_agg_bwd_src<<<grid_for_waves(a->n_src_rows), KGW_BLK, 0, (hipStream_t)stream_>>>(T, P, a->n_src_rows);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+extern "C" int kgw_edge_alpha(const KgwLayerArgs* a, float* alpha_out, kgw_stream_t stream_) {
+    if (!a || !alpha_out) return KGW_E_NULL;
+    if (a->n_chunks == 0) return KGW_OK;
+    if (!a->chunks || !a->stat || !a->e_edge) return KGW_E_NULL;
+    LayerTab T;
+    int rc = build_tab(a, &T);
+    if (rc) return rc;
+    AggPtrs P = build_ptrs(a);
+    k_edge_alpha<<<grid_for_waves(a->n_chunks), KGW_BLK, 0, (hipStream_t)stream_>>>(T, P, a->n_chunks, a->inv_temp, alpha_out);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+// ---- misc entry points -----------------------------------------------------------------------------
+extern "C" int kgw_version(void) { return KGW_VERSION; }
+
+extern "C" const char* kgw_status_string(int status) {
+    switch (status) {
+        case KGW_OK: return "ok";
+        case KGW_E_NULL: return "null pointer argument";
+        case KGW_E_RANGE: return "argument out of range";
+        case KGW_E_UNSUPPORTED: return "unsupported configuration";
+        default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown error";
+    }
+}
+
+extern "C" int kgw_struct_sizes(int64_t* out, int n) {
+    if (!out) return KGW_E_NULL;
+    const int64_t v[5] = {(int64_t)sizeof(KgwGraph), (int64_t)sizeof(KgwBatchMeta), (int64_t)sizeof(KgwChunk),
+                          (int64_t)sizeof(KgwBatchBuf), (int64_t)sizeof(KgwLayerArgs)};
+    for (int i = 0; i < n && i < 5; ++i) out[i] = v[i];
+    return KGW_OK;
+}

@@ -1,0 +1,75 @@
+// kgw_common.h -- shared device helpers for libkgwas_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kgwas_hip.h"
+
+#define KGW_PENDING (-2)
+
+static constexpr int KGW_BLK  = 256;    // 4 wavefronts of 64
+static constexpr int KGW_GRID = 2048;   // grid-stride launches: 8 blocks per CU on 256 CUs
+
+#define KGW_LAUNCH_CHECK()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return (int)e__;              \
+    } while (0)
+
+#define KGW_HIP(x)                                           \
+    do {                                                     \
+        hipError_t e__ = (x);                                \
+        if (e__ != hipSuccess) return (int)e__;              \
+    } while (0)
+
+// ---- wave-level helpers (wavefront = 64 lanes) -------------------------------------------------
+__device__ __forceinline__ int kgw_lane() { return threadIdx.x & 63; }
+
+// DPP controls (GCN3+/CDNA): quad_perm = 0x00..0xFF, row_shr:n = 0x110+n, row_mirror = 0x140,
+// row_half_mirror = 0x141.
+template <int CTRL>
+__device__ __forceinline__ float kgw_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// All-reduce (sum) inside each 32-lane half of the wavefront; every lane of a half gets its
+// half's total.  4 DPP butterflies inside rows of 16 + one v_permlane16_swap across the rows.
+__device__ __forceinline__ float kgw_half_allsum(float v) {
+    v += kgw_dpp<0xB1>(v);    // quad_perm [1,0,3,2]  (xor 1)
+    v += kgw_dpp<0x4E>(v);    // quad_perm [2,3,0,1]  (xor 2)
+    v += kgw_dpp<0x141>(v);   // row_half_mirror      (xor 4 once quads are uniform)
+    v += kgw_dpp<0x140>(v);   // row_mirror           (xor 8 once 8-groups are uniform)
+    // rows 0<->1 and 2<->3: gfx950 v_permlane16_swap exchanges odd rows of vdst with even rows of src
+    int a = __builtin_bit_cast(int, v);
+    auto r = __builtin_amdgcn_permlane16_swap(a, a, false, false);
+    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+
+// All-reduce (sum) across the whole wavefront.
+__device__ __forceinline__ float kgw_wave_allsum(float v) {
+    v = kgw_half_allsum(v);
+    int a = __builtin_bit_cast(int, v);
+    auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+
+__device__ __forceinline__ float kgw_xhalf(float v) {   // value held by the same lane of the other half
+    return __shfl_xor(v, 32, 64);
+}
+
+// block-wide exclusive scan of one int per thread (256 threads); returns exclusive prefix,
+// *total receives the block sum.  sm must hold 256 ints.
+__device__ __forceinline__ int kgw_block_exscan(int v, int* sm, int* total) {
+    const int tid = threadIdx.x;
+    sm[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < KGW_BLK; off <<= 1) {
+        int t = (tid >= off) ? sm[tid - off] : 0;
+        __syncthreads();
+        sm[tid] += t;
+        __syncthreads();
+    }
+    int incl = sm[tid];
+    *total = sm[KGW_BLK - 1];
+    __syncthreads();
+    return incl - v;
+}

@@ -1,0 +1,513 @@
+// kgw_sampler.hip -- device-resident full-neighbourhood minibatch sampler for KGWAS (gfx950).
+//
+// Replaces the work PyG's NeighborLoader(num_neighbors=[-1]*L) does on the CPU for the reference
+// (kgwas/kgwas.py:99-113,129): hop-by-hop expansion over ALL in-neighbours of every relation,
+// global->local relabelling (seeds first), per-relation local CSR -- plus what the fused kernels
+// need and PyG never builds: a chunk list (<= KGW_CHUNK edges of one destination row each, so hub
+// rows are split across wavefronts) and the src-major (transposed) structure of every layer for an
+// atomics-free backward.
+//
+// Everything is HBM-bound integer work: coalesced reads of the resident CSR (rowptr/col), byte-free
+// int32 maps, prefix sums.  All kernels are grid-stride over DEVICE-side counts (KgwBatchMeta), so
+// the whole batch is enqueued without a single host round trip; the host reads KgwBatchMeta once,
+// after the final async D2H copy.
+//
+// Local node order: per node type, hop-major; hop 0 = seeds in seed order, later hops sorted by
+// global id (flag + prefix-sum compaction => deterministic).  PyG's order for non-seed nodes is
+// first-seen; only the seeds-first contract is consumed by the reference (kgwas/model.py:86).
+#include "kgw_common.h"
+
+namespace {
+
+struct SampArgs {
+    KgwGraph G;        // by value: descriptor reads become scalar loads from the kernarg segment
+    KgwBatchBuf B;
+};
+
+// ---- small helpers -----------------------------------------------------------------------------
+__device__ __forceinline__ int find_rel(const int32_t* seg_off, int n_rels, int sigma) {
+    // seg_off[0..n_rels] ascending; return r with seg_off[r] <= sigma < seg_off[r+1]
+    int lo = 0, hi = n_rels;            // invariant: seg_off[lo] <= sigma < seg_off[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (seg_off[mid] <= sigma) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int type_of_node_slot(const KgwGraph& G, int i) {
+    int t = 0;
+    while (t + 1 < G.n_types && i >= G.node_base[t + 1]) ++t;
+    return t;
+}
+
+// ---- init --------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(KGW_BLK) k_init(SampArgs A, const int64_t* seeds, int n_seeds,
+                                                  int seed_type, int full) {
+    const KgwGraph& G = A.G;
+    KgwBatchMeta* M = A.B.meta;
+    const int64_t tid = (int64_t)blockIdx.x * KGW_BLK + threadIdx.x;
+    const int64_t nthr = (int64_t)gridDim.x * KGW_BLK;
+    if (full) {
+        const int total = G.node_base[G.n_types];
+        for (int64_t i = tid; i < total; i += nthr) {
+            int t = type_of_node_slot(G, (int)i);
+            int g = (int)i - G.node_base[t];
+            if (g < G.n_nodes[t]) { A.B.g2l[i] = g; A.B.n_id[i] = g; }
+        }
+    } else {
+        const int base = G.node_base[seed_type];
+        for (int64_t i = tid; i < n_seeds; i += nthr) {
+            int g = (int)seeds[i];
+            A.B.g2l[base + g] = (int)i;
+            A.B.n_id[base + i] = g;
+        }
+    }
+    if (tid == 0) {
+        for (int t = 0; t < G.n_types; ++t) {
+            int c = full ? G.n_nodes[t] : (t == seed_type ? n_seeds : 0);
+            M->hop_cnt[t][0] = c;
+            M->node_off[t][0] = 0;
+            M->node_off[t][1] = c;
+        }
+    }
+}
+
+// ---- per hop: segment bookkeeping --------------------------------------------------------------
+__global__ void k_hop_begin(SampArgs A, int h) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const KgwGraph& G = A.G;
+    KgwBatchMeta* M = A.B.meta;
+    int s = (h == 0) ? 0 : M->seg_end[h - 1];
+    const int begin = s;
+    for (int r = 0; r < G.n_rels; ++r) {
+        M->seg_off[h][r] = s;
+        s += M->hop_cnt[G.rel_dst[r]][h];
+    }
+    M->seg_off[h][G.n_rels] = s;
+    M->seg_end[h] = s;
+    if ((int64_t)s > A.B.seg_cap) { M->error |= 1; s = begin; }   // empty range: nothing runs past capacity
+    M->cur[0] = begin;   // scan range [cur0, cur1)
+    M->cur[1] = s;
+    M->cur[2] = (h == 0) ? 0 : M->edge_end[h - 1];    // carry-in for seg_ptr
+    M->cur[3] = (h == 0) ? 0 : M->chunk_end[h - 1];   // carry-in for seg_chptr
+}
+
+__global__ void __launch_bounds__(KGW_BLK) k_seg_deg(SampArgs A, int h) {
+    const KgwGraph& G = A.G;
+    const KgwBatchMeta* M = A.B.meta;
+    const int begin = M->cur[0], end = M->cur[1];
+    if ((int64_t)end > A.B.seg_cap) return;
+    for (int sg = begin + blockIdx.x * KGW_BLK + threadIdx.x; sg < end; sg += gridDim.x * KGW_BLK) {
+        int r = find_rel(M->seg_off[h], G.n_rels, sg);
+        int d = G.rel_dst[r];
+        int li = M->node_off[d][h] + (sg - M->seg_off[h][r]);
+        int g = A.B.n_id[G.node_base[d] + li];
+        const int32_t* rp = G.g_rowptr + G.rowptr_off[r];
+        int deg = rp[g + 1] - rp[g];
+        A.B.seg_deg[sg] = deg;
+        A.B.seg_nch[sg] = (deg + KGW_CHUNK - 1) / KGW_CHUNK;
+    }
+}
+
+// ---- generic 3-kernel exclusive scan over a device-side range ------------------------------------
+// K arrays scanned together.  Range [cur[0], cur[1]) ; tile t covers begin + t*KGW_TILE.
+template <int K>
+__global__ void __launch_bounds__(KGW_BLK) k_scan_tiles(const int32_t* in0, const int32_t* in1,
+                                                        const KgwBatchMeta* M, int32_t* tile_sums) {
+    __shared__ int sm[KGW_BLK];
+    const int begin = M->cur[0], end = M->cur[1];
+    const int ntiles = (end - begin + KGW_TILE - 1) / KGW_TILE;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int s0 = 0, s1 = 0;
+        for (int k = 0; k < KGW_TILE / KGW_BLK; ++k) {
+            int i = begin + t * KGW_TILE + k * KGW_BLK + threadIdx.x;
+            if (i < end) { s0 += in0[i]; if (K == 2) s1 += in1[i]; }
+        }
+        int tot;
+        kgw_block_exscan(s0, sm, &tot);
+        if (threadIdx.x == 0) tile_sums[K * t] = tot;
+        if (K == 2) {
+            kgw_block_exscan(s1, sm, &tot);
+            if (threadIdx.x == 0) tile_sums[K * t + 1] = tot;
+        }
+    }
+}
+
+// single block: exclusive scan of the tile sums (+ carry-in cur[2], cur[3]); total at [ntiles].
+template <int K>
+__global__ void __launch_bounds__(KGW_BLK) k_scan_top(int32_t* tile_sums, KgwBatchMeta* M, int use_carry) {
+    __shared__ int sm[KGW_BLK];
+    const int begin = M->cur[0], end = M->cur[1];
+    const int ntiles = (end - begin + KGW_TILE - 1) / KGW_TILE;
+    for (int k = 0; k < K; ++k) {
+        int carry = use_carry ? M->cur[2 + k] : 0;
+        for (int base = 0; base <= ntiles; base += KGW_BLK) {
+            int i = base + threadIdx.x;
+            int v = (i < ntiles) ? tile_sums[K * i + k] : 0;
+            int tot;
+            int ex = kgw_block_exscan(v, sm, &tot);
+            if (i <= ntiles) tile_sums[K * i + k] = carry + ex;
+            carry += tot;
+        }
+        if (threadIdx.x == 0) M->cur[4 + k] = carry;   // grand total (incl. carry-in)
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(KGW_BLK) k_scan_apply(const int32_t* in0, const int32_t* in1,
+                                                        int32_t* out0, int32_t* out1,
+                                                        const KgwBatchMeta* M, const int32_t* tile_sums) {
+    __shared__ int sm[KGW_BLK];
+    const int begin = M->cur[0], end = M->cur[1];
+    const int ntiles = (end - begin + KGW_TILE - 1) / KGW_TILE;
+    constexpr int PER = KGW_TILE / KGW_BLK;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int i0 = begin + t * KGW_TILE + threadIdx.x * PER;   // PER consecutive elements per thread
+        for (int k = 0; k < K; ++k) {
+            const int32_t* in = k ? in1 : in0;
+            int32_t* out = k ? out1 : out0;
+            int v[PER], s = 0;
+            for (int j = 0; j < PER; ++j) { v[j] = (i0 + j < end) ? in[i0 + j] : 0; s += v[j]; }
+            int tot;
+            int ex = kgw_block_exscan(s, sm, &tot) + tile_sums[K * t + k];
+            for (int j = 0; j < PER; ++j) { if (i0 + j < end) out[i0 + j] = ex; ex += v[j]; }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {          // end sentinel
+        out0[end] = M->cur[4];
+        if (K == 2) out1[end] = M->cur[5];
+    }
+}
+
+__global__ void k_hop_mid(SampArgs A, int h) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    KgwBatchMeta* M = A.B.meta;
+    M->edge_end[h] = M->cur[4];
+    M->chunk_end[h] = M->cur[5];
+    if ((int64_t)M->cur[4] > A.B.edge_cap) M->error |= 2;
+    if ((int64_t)M->cur[5] > A.B.chunk_cap) M->error |= 4;
+}
+
+__global__ void __launch_bounds__(KGW_BLK) k_fill_chunks(SampArgs A, int h) {
+    const KgwGraph& G = A.G;
+    KgwBatchMeta* M = A.B.meta;
+    if (M->error) return;
+    const int begin = M->cur[0], end = M->cur[1];
+    for (int sg = begin + blockIdx.x * KGW_BLK + threadIdx.x; sg < end; sg += gridDim.x * KGW_BLK) {
+        const int nch = A.B.seg_nch[sg];
+        if (nch == 0) continue;
+        const int r = find_rel(M->seg_off[h], G.n_rels, sg);
+        const int d = G.rel_dst[r];
+        const int li = M->node_off[d][h] + (sg - M->seg_off[h][r]);
+        const int g = A.B.n_id[G.node_base[d] + li];
+        const int32_t* rp = G.g_rowptr + G.rowptr_off[r];
+        int64_t gpos = G.col_off[r] + rp[g];
+        int e = A.B.seg_ptr[sg];
+        const int e_end = e + A.B.seg_deg[sg];
+        const int c0 = A.B.seg_chptr[sg];
+        for (int c = 0; c < nch; ++c) {
+            KgwChunk ck;
+            ck.e0 = e;
+            ck.e1 = min(e + KGW_CHUNK, e_end);
+            ck.row = li; ck.rel = r; ck.first = c0; ck.nch = nch;
+            ck.gpos_lo = (int32_t)(gpos & 0xFFFFFFFFll);
+            ck.gpos_hi = (int32_t)(gpos >> 32);
+            A.B.chunks[c0 + c] = ck;
+            e += KGW_CHUNK; gpos += KGW_CHUNK;
+        }
+        if (nch > 1) {
+            int idx = atomicAdd(&M->multi_cnt[h], 1);
+            if ((int64_t)idx < A.B.multi_cap) {
+                int32_t* mm = A.B.multi + ((int64_t)h * A.B.multi_cap + idx) * 4;
+                mm[0] = c0; mm[1] = nch; mm[2] = li; mm[3] = r;
+            } else {
+                M->error |= 8;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int64_t chunk_gpos(const KgwChunk& c) {
+    return ((int64_t)c.gpos_hi << 32) | (uint32_t)c.gpos_lo;
+}
+
+// one wavefront per chunk of dst hop h: flag every not-yet-sampled source node
+__global__ void __launch_bounds__(KGW_BLK) k_mark(SampArgs A, int h) {
+    const KgwGraph& G = A.G;
+    const KgwBatchMeta* M = A.B.meta;
+    if (M->error) return;
+    const int cb = (h == 0) ? 0 : M->chunk_end[h - 1], ce = M->chunk_end[h];
+    const int lane = kgw_lane();
+    for (int c = cb + blockIdx.x * 4 + (threadIdx.x >> 6); c < ce; c += gridDim.x * 4) {
+        const KgwChunk ck = A.B.chunks[c];
+        const int32_t* col = G.g_col + chunk_gpos(ck);
+        int32_t* g2l = A.B.g2l + G.node_base[G.rel_src[ck.rel]];
+        const int n = ck.e1 - ck.e0;
+        for (int t = lane; t < n; t += 64) {
+            int g = col[t];
+            if (g2l[g] == -1) g2l[g] = KGW_PENDING;   // benign race: every writer stores the same value
+        }
+    }
+}
+
+// compaction of the PENDING flags over the padded concatenated node space (host-known size)
+__global__ void __launch_bounds__(KGW_BLK) k_count_pending(SampArgs A, int32_t* tile_sums, int ntiles) {
+    __shared__ int sm[KGW_BLK];
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int s = 0;
+        for (int k = 0; k < KGW_TILE / KGW_BLK; ++k)
+            s += (A.B.g2l[t * KGW_TILE + k * KGW_BLK + threadIdx.x] == KGW_PENDING);
+        int tot;
+        kgw_block_exscan(s, sm, &tot);
+        if (threadIdx.x == 0) tile_sums[t] = tot;
+    }
+}
+
+__global__ void __launch_bounds__(KGW_BLK) k_scan_top_fixed(int32_t* tile_sums, int ntiles) {
+    __shared__ int sm[KGW_BLK];
+    int carry = 0;
+    for (int base = 0; base <= ntiles; base += KGW_BLK) {
+        int i = base + threadIdx.x;
+        int v = (i < ntiles) ? tile_sums[i] : 0;
+        int tot;
+        int ex = kgw_block_exscan(v, sm, &tot);
+        if (i <= ntiles) tile_sums[i] = carry + ex;
+        carry += tot;
+    }
+}
+
+__global__ void __launch_bounds__(KGW_BLK) k_assign(SampArgs A, const int32_t* tile_pref, int ntiles, int h) {
+    __shared__ int sm[KGW_BLK];
+    const KgwGraph& G = A.G;
+    const KgwBatchMeta* M = A.B.meta;
+    constexpr int PER = KGW_TILE / KGW_BLK;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        if (tile_pref[t + 1] == tile_pref[t]) continue;          // nothing pending in this tile
+        const int i0 = t * KGW_TILE + threadIdx.x * PER;
+        const int ty = type_of_node_slot(G, t * KGW_TILE);      // regions are tile aligned
+        const int base = G.node_base[ty];
+        const int off = M->node_off[ty][h + 1] + tile_pref[t] - tile_pref[base / KGW_TILE];
+        int f[PER], s = 0;
+        for (int j = 0; j < PER; ++j) { f[j] = (A.B.g2l[i0 + j] == KGW_PENDING); s += f[j]; }
+        int tot;
+        int ex = kgw_block_exscan(s, sm, &tot) + off;
+        for (int j = 0; j < PER; ++j) {
+            if (f[j]) { A.B.g2l[i0 + j] = ex; A.B.n_id[base + ex] = i0 + j - base; ++ex; }
+        }
+    }
+}
+
+__global__ void k_hop_end(SampArgs A, const int32_t* tile_pref, int h) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const KgwGraph& G = A.G;
+    KgwBatchMeta* M = A.B.meta;
+    for (int t = 0; t < G.n_types; ++t) {
+        int c = tile_pref[G.node_base[t + 1] / KGW_TILE] - tile_pref[G.node_base[t] / KGW_TILE];
+        M->hop_cnt[t][h + 1] = c;
+        M->node_off[t][h + 2] = M->node_off[t][h + 1] + c;
+    }
+}
+
+__global__ void __launch_bounds__(KGW_BLK) k_relabel(SampArgs A, int h) {
+    const KgwGraph& G = A.G;
+    const KgwBatchMeta* M = A.B.meta;
+    if (M->error) return;
+    const int cb = (h == 0) ? 0 : M->chunk_end[h - 1], ce = M->chunk_end[h];
+    const int lane = kgw_lane();
+    for (int c = cb + blockIdx.x * 4 + (threadIdx.x >> 6); c < ce; c += gridDim.x * 4) {
+        const KgwChunk ck = A.B.chunks[c];
+        const int32_t* col = G.g_col + chunk_gpos(ck);
+        const int32_t* g2l = A.B.g2l + G.node_base[G.rel_src[ck.rel]];
+        const int n = ck.e1 - ck.e0;
+        for (int t = lane; t < n; t += 64) A.B.col_local[ck.e0 + t] = g2l[col[t]];
+    }
+}
+
+// ---- per-layer layout tables -------------------------------------------------------------------
+__global__ void k_layer_tables(SampArgs A) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const KgwGraph& G = A.G;
+    KgwBatchMeta* M = A.B.meta;
+    const int L = G.n_layers;
+    // nodes first seen at the last hop keep node_off[.][n_hops+1]; fill the tail for uniform indexing
+    for (int l = 1; l <= L; ++l) {
+        const int hd = min(L - l, G.n_hops - 1);   // destination rows: hops <= hd
+        int zb = 0, sb = 0, tb = 0;
+        for (int t = 0; t < G.n_types; ++t) {
+            bool dst_live = false, src_live = false;
+            for (int r = 0; r < G.n_rels; ++r) {
+                if (!G.rel_live[l - 1][r]) continue;
+                dst_live |= (G.rel_dst[r] == t);
+                src_live |= (G.rel_src[r] == t);
+            }
+            const int nr = dst_live ? M->node_off[t][hd + 1] : 0;
+            const int ns = src_live ? M->node_off[t][hd + 2] : 0;
+            M->n_rows[l - 1][t] = nr;
+            M->z_base[l - 1][t] = zb;  zb += nr * G.R_dst[t];
+            M->n_src[l - 1][t] = ns;
+            M->src_base[l - 1][t] = sb; sb += ns;
+            M->t_base[l - 1][t] = tb;  tb += ns * G.R_src[t];
+        }
+        M->z_base[l - 1][G.n_types] = zb;
+        M->src_base[l - 1][G.n_types] = sb;
+        M->t_base[l - 1][G.n_types] = tb;
+        M->n_chunks[l - 1] = M->chunk_end[hd];
+        M->n_edges[l - 1] = M->edge_end[hd];
+        if ((int64_t)tb > A.B.trow_cap) M->error |= 16;
+    }
+}
+
+// ---- src-major (transposed) structure of one layer ------------------------------------------------
+__global__ void k_t_begin(SampArgs A, int l) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    KgwBatchMeta* M = A.B.meta;
+    M->cur[0] = 0;
+    M->cur[1] = M->error ? 0 : M->t_base[l - 1][A.G.n_types];
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(KGW_BLK) k_t_pass(SampArgs A, int l) {
+    const KgwGraph& G = A.G;
+    const KgwBatchMeta* M = A.B.meta;
+    if (M->error) return;
+    const int nc = M->n_chunks[l - 1];
+    const int lane = kgw_lane();
+    int32_t* cnt = A.B.t_cnt[l - 1];
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < nc; c += gridDim.x * 4) {
+        const KgwChunk ck = A.B.chunks[c];
+        const int r = ck.rel;
+        if (!G.rel_live[l - 1][r]) continue;
+        const int s = G.rel_src[r], d = G.rel_dst[r];
+        const int tb = M->t_base[l - 1][s] + G.rel_slot_src[r];
+        const int Rs = G.R_src[s];
+        const int zrow = M->z_base[l - 1][d] + ck.row * G.R_dst[d] + G.rel_slot_dst[r];
+        const int n = ck.e1 - ck.e0;
+        for (int t = lane; t < n; t += 64) {
+            const int e = ck.e0 + t;
+            const int trow = tb + A.B.col_local[e] * Rs;
+            if (!FILL) {
+                atomicAdd(&cnt[trow], 1);
+            } else {
+                const int pos = A.B.t_ptr[l - 1][trow] + atomicSub(&cnt[trow], 1) - 1;
+                A.B.t_edge[l - 1][pos] = e;
+                A.B.t_zrow[l - 1][pos] = zrow;
+            }
+        }
+    }
+}
+
+__global__ void k_t_end(SampArgs A, int l) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    A.B.meta->t_entries[l - 1] = A.B.meta->cur[4];
+}
+
+}  // namespace
+
+extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, const int64_t* seeds,
+                                int32_t n_seeds, int32_t seed_type, int32_t full_graph,
+                                kgw_stream_t stream_) {
+    if (!graph || !buf) return KGW_E_NULL;
+    if (!full_graph && (!seeds || n_seeds <= 0)) return KGW_E_NULL;
+    if (graph->n_types < 1 || graph->n_types > KGW_MAX_TYPES || graph->n_rels < 1 ||
+        graph->n_rels > KGW_MAX_RELS || graph->n_layers < 1 || graph->n_layers > KGW_MAX_LAYERS ||
+        graph->n_hops < 1 || graph->n_hops > graph->n_layers)
+        return KGW_E_RANGE;
+    if (!full_graph && (seed_type < 0 || seed_type >= graph->n_types || n_seeds > graph->n_nodes[seed_type]))
+        return KGW_E_RANGE;
+    hipStream_t st = (hipStream_t)stream_;
+    SampArgs A;
+    A.G = *graph;
+    A.B = *buf;
+    const int total_slots = graph->node_base[graph->n_types];
+    const int ntiles_nodes = total_slots / KGW_TILE;
+    if ((int64_t)ntiles_nodes + 2 > buf->scan_cap) return KGW_E_RANGE;
+
+    KGW_HIP(hipMemsetAsync(buf->g2l, 0xFF, (size_t)total_slots * sizeof(int32_t), st));
+    KGW_HIP(hipMemsetAsync(buf->meta, 0, sizeof(KgwBatchMeta), st));
+    k_init<<<full_graph ? KGW_GRID : 64, KGW_BLK, 0, st>>>(A, seeds, n_seeds, seed_type, full_graph);
+    KGW_LAUNCH_CHECK();
+
+    for (int h = 0; h < graph->n_hops; ++h) {
+        k_hop_begin<<<1, 64, 0, st>>>(A, h);
+        k_seg_deg<<<KGW_GRID, KGW_BLK, 0, st>>>(A, h);
+        k_scan_tiles<2><<<KGW_GRID, KGW_BLK, 0, st>>>(buf->seg_deg, buf->seg_nch, buf->meta, buf->scan_tmp);
+        k_scan_top<2><<<1, KGW_BLK, 0, st>>>(buf->scan_tmp, buf->meta, 1);
+        k_scan_apply<2><<<KGW_GRID, KGW_BLK, 0, st>>>(buf->seg_deg, buf->seg_nch, buf->seg_ptr,
+                                                      buf->seg_chptr, buf->meta, buf->scan_tmp);
+        k_hop_mid<<<1, 64, 0, st>>>(A, h);
+        k_fill_chunks<<<KGW_GRID, KGW_BLK, 0, st>>>(A, h);
+        KGW_LAUNCH_CHECK();
+        if (!full_graph) {
+            k_mark<<<KGW_GRID, KGW_BLK, 0, st>>>(A, h);
+            k_count_pending<<<KGW_GRID, KGW_BLK, 0, st>>>(A, buf->scan_tmp, ntiles_nodes);
+            k_scan_top_fixed<<<1, KGW_BLK, 0, st>>>(buf->scan_tmp, ntiles_nodes);
+            k_assign<<<KGW_GRID, KGW_BLK, 0, st>>>(A, buf->scan_tmp, ntiles_nodes, h);
+            k_hop_end<<<1, 64, 0, st>>>(A, buf->scan_tmp, h);
+        } else {
+            // every node is already a seed: hop h+1 adds nothing
+            KGW_HIP(hipMemsetAsync(buf->scan_tmp, 0, (size_t)(ntiles_nodes + 2) * sizeof(int32_t), st));
+            k_hop_end<<<1, 64, 0, st>>>(A, buf->scan_tmp, h);
+        }
+        k_relabel<<<KGW_GRID, KGW_BLK, 0, st>>>(A, h);
+        KGW_LAUNCH_CHECK();
+    }
+    k_layer_tables<<<1, 64, 0, st>>>(A);
+    KGW_LAUNCH_CHECK();
+
+    for (int l = 1; l <= graph->n_layers; ++l) {
+        if (!buf->t_cnt[l - 1] || !buf->t_ptr[l - 1] || !buf->t_edge[l - 1] || !buf->t_zrow[l - 1])
+            return KGW_E_NULL;
+        KGW_HIP(hipMemsetAsync(buf->t_cnt[l - 1], 0, (size_t)(buf->trow_cap + 1) * sizeof(int32_t), st));
+        k_t_begin<<<1, 64, 0, st>>>(A, l);
+        k_t_pass<false><<<KGW_GRID, KGW_BLK, 0, st>>>(A, l);
+        k_scan_tiles<1><<<KGW_GRID, KGW_BLK, 0, st>>>(buf->t_cnt[l - 1], nullptr, buf->meta, buf->scan_tmp);
+        k_scan_top<1><<<1, KGW_BLK, 0, st>>>(buf->scan_tmp, buf->meta, 0);
+        k_scan_apply<1><<<KGW_GRID, KGW_BLK, 0, st>>>(buf->t_cnt[l - 1], nullptr, buf->t_ptr[l - 1],
+                                                      nullptr, buf->meta, buf->scan_tmp);
+        k_t_pass<true><<<KGW_GRID, KGW_BLK, 0, st>>>(A, l);
+        k_t_end<<<1, 64, 0, st>>>(A, l);
+        KGW_LAUNCH_CHECK();
+    }
+    if (buf->meta_host)
+        KGW_HIP(hipMemcpyAsync(buf->meta_host, buf->meta, sizeof(KgwBatchMeta), hipMemcpyDeviceToHost, st));
+    return KGW_OK;
+}
+
+// ---- x[n_id] feature slicing ---------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(KGW_BLK) k_gather_rows(const float* __restrict__ src,
+                                                         const int32_t* __restrict__ ids, int64_t n_rows,
+                                                         int width, float* __restrict__ dst) {
+    // one wavefront per row; float4 when the row width allows, else scalar
+    const int lane = kgw_lane();
+    const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    if ((width & 3) == 0) {
+        const int w4 = width >> 2;
+        for (int64_t r = w0; r < n_rows; r += nw) {
+            const float4* s = (const float4*)(src + (int64_t)ids[r] * width);
+            float4* d = (float4*)(dst + r * width);
+            for (int k = lane; k < w4; k += 64) d[k] = s[k];
+        }
+    } else {
+        for (int64_t r = w0; r < n_rows; r += nw) {
+            const float* s = src + (int64_t)ids[r] * width;
+            float* d = dst + r * width;
+            for (int k = lane; k < width; k += 64) d[k] = s[k];
+        }
+    }
+}
+}  // namespace
+
+extern "C" int kgw_gather_rows(const float* src, const int32_t* ids, int64_t n_rows, int32_t width,
+                               float* dst, kgw_stream_t stream_) {
+    if (n_rows == 0) return KGW_OK;
+    if (!src || !ids || !dst) return KGW_E_NULL;
+    if (width <= 0 || n_rows < 0) return KGW_E_RANGE;
+    int grid = (int)((n_rows + 3) / 4);
+    if (grid > KGW_GRID * 4) grid = KGW_GRID * 4;
+    k_gather_rows<<<grid, KGW_BLK, 0, (hipStream_t)stream_>>>(src, ids, n_rows, width, dst);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}

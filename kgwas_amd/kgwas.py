@@ -1,0 +1,175 @@
+"""``KGWAS`` trainer -- the reference's driver API (kgwas/kgwas.py:25-212) on the MI355X path.
+
+Kept verbatim from the reference: constructor / ``initialize_model`` / ``train`` / ``load_pretrained``
+signatures and defaults, the attributes they set (``model``, ``best_model``, ``config``,
+``train_loader`` ... ``infer_loader``, ``save_name``, ``kgwas_res``), the LD-weighted MSE
+(kgwas.py:142-145), Adam(lr, weight_decay as L2) (kgwas.py:116), best-model selection by validation
+Pearson (kgwas.py:170-173), checkpoint files (utils.py:203-207).
+
+Deliberately different (Appendix A of SURVEY.md): no CUDA_LAUNCH_BLOCKING, no per-seed ``.item()``
+dict look-ups (LD weights are a resident float64 vector indexed by SNP id), evaluation under no_grad.
+Multi-GPU: one process per GPU (torch.distributed, RCCL); every rank trains on its own slice of each
+batch and parameter gradients are all-reduced in one flat bucket (kgwas_amd/dist.py).
+"""
+from __future__ import annotations
+
+import os
+import pickle
+from copy import deepcopy
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import dist as kdist
+from .model import HeteroGNN
+from .sampler import NeighborLoader
+from .utils import compute_metrics, evaluate_minibatch_clean, load_pretrained, print_sys, save_model
+
+
+class KGWAS:
+    def __init__(self, data, weight_bias_track=False, device='cuda', proj_name='KGWAS', exp_name='KGWAS',
+                 seed=42):
+        torch.manual_seed(seed)                                     # kgwas.py:33-35
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed(seed)
+        np.random.seed(seed)
+        self.seed = seed
+        self.device = device if torch.cuda.is_available() else 'cpu'
+        self.data = data
+        self.data_path = data.data_path
+        if weight_bias_track:
+            import wandb
+            wandb.init(project=proj_name, name=exp_name)
+            self.wandb = wandb
+        else:
+            self.wandb = False
+        self.exp_name = exp_name
+
+    def initialize_model(self, gnn_num_layers=2, gnn_hidden_dim=128, gnn_backbone='GAT', gnn_aggr='sum',
+                         gat_num_head=1, no_relu=False):
+        self.config = {'gnn_num_layers': gnn_num_layers, 'gnn_hidden_dim': gnn_hidden_dim,
+                       'gnn_backbone': gnn_backbone, 'gnn_aggr': gnn_aggr, 'gat_num_head': gat_num_head}
+        self.gnn_num_layers = gnn_num_layers
+        self.model = HeteroGNN(self.data.data, gnn_hidden_dim, 1, gnn_num_layers, gnn_backbone, gnn_aggr,
+                               self.data.snp_init_dim_size, self.data.gene_init_dim_size,
+                               self.data.go_init_dim_size, gat_num_head, no_relu=no_relu).to(self.device)
+
+    def load_pretrained(self, path):
+        import pandas as pd
+        with open(os.path.join(path, 'config.pkl'), 'rb') as f:
+            config = pickle.load(f)
+        self.initialize_model(**config)
+        self.config = config
+        self.model = load_pretrained(path, self.model).to(self.device)
+        self.best_model = self.model
+        pred_csv = os.path.join(path, 'pred.csv')
+        if os.path.exists(pred_csv):
+            self.kgwas_res = pd.read_csv(pred_csv, sep=None, engine='python')
+        self.save_name = path.split('/')[-1]
+
+    # ------------------------------------------------------------------------------------------
+    def _ld_weight_vector(self) -> torch.Tensor:
+        """float64 [N_SNP] LD-score regression weight per SNP index (kgwas.py:142-143 without the
+        per-step Python look-ups); SNPs without a weight get 0 and are never seeds."""
+        n = int(self.data.data['SNP'].x.shape[0])
+        w = torch.zeros(n, dtype=torch.float64)
+        ids = np.asarray(self.data.all_ids, dtype=np.int64)
+        w[torch.from_numpy(ids)] = torch.from_numpy(np.asarray(self.data.ldsc_weight, dtype=np.float64))
+        return w.to(self.device)
+
+    def make_loaders(self, batch_size, num_workers=0):
+        kwargs = {'batch_size': batch_size, 'num_workers': num_workers, 'drop_last': True, 'device': self.device}
+        eval_kwargs = {'batch_size': 512, 'num_workers': num_workers, 'drop_last': False, 'device': self.device}
+        L = self.gnn_num_layers
+        rank, world = kdist.rank_world()
+        tr_type, tr_ids = self.data.train_input_nodes
+        tr_ids = kdist.shard_batches(np.asarray(tr_ids), batch_size, rank, world)
+        tr_kwargs = dict(kwargs, batch_size=batch_size // world)      # each rank: its slice of every batch
+        self.train_loader = NeighborLoader(self.data.data, num_neighbors=[-1] * L, sampler=None,
+                                           input_nodes=(tr_type, tr_ids), **tr_kwargs)        # kgwas.py:99-101
+        self.val_loader = NeighborLoader(self.data.data, num_neighbors=[-1] * L,
+                                         input_nodes=self.data.val_input_nodes, **kwargs)     # :102-103
+        self.test_loader = NeighborLoader(self.data.data, num_neighbors=[-1] * L,
+                                          input_nodes=self.data.test_input_nodes, **eval_kwargs)  # :104-105
+        infer_idx = np.asarray(self.data.all_ids)                                             # :107-110
+        self.infer_loader = NeighborLoader(self.data.data, num_neighbors=[-1] * L,
+                                           input_nodes=('SNP', infer_idx), **eval_kwargs)     # :112-113
+
+    def train_step(self, batch, optimizer, ld_w, world: int = 1):
+        """kgwas.py:130-151 for one batch; returns the (float64) loss tensor, no host sync."""
+        optimizer.zero_grad(set_to_none=True)
+        bs = batch['SNP'].batch_size
+        out = self.model(batch.x_dict, batch.edge_index_dict, bs)
+        pred = out.reshape(-1)
+        n_id = batch.n_id('SNP')[:bs].long()
+        y = batch.dg.y['SNP'][n_id]
+        w = ld_w[n_id]
+        loss = torch.mean(w * (pred - y) ** 2)                       # float64, kgwas.py:145
+        loss.backward()
+        if world > 1:
+            kdist.allreduce_grads(self.model, world)
+        optimizer.step()
+        return loss
+
+    def train(self, batch_size=512, num_workers=0, lr=1e-4, weight_decay=5e-4, epoch=10, save_best_model=True,
+              save_name=None, data_to_cuda=False):
+        total_epoch = epoch
+        if save_name is None:
+            save_name = self.exp_name
+        self.save_name = save_name
+        print_sys('Creating data loader...')
+        self.make_loaders(batch_size, num_workers)
+        rank, world = kdist.rank_world()
+        if world > 1:
+            kdist.broadcast_params(self.model)
+        optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay)   # kgwas.py:116
+        ld_w = self._ld_weight_vector()
+        min_val = -1000
+        self.best_model = deepcopy(self.model).to(self.device)
+        print_sys('Start Training...')
+        for ep in range(total_epoch):
+            self.model.train()
+            for step, batch in enumerate(self.train_loader):
+                loss = self.train_step(batch, optimizer, ld_w, world)
+                if self.wandb:
+                    self.wandb.log({'training_loss': loss.item()})
+                if (step % 500 == 0) and (step >= 500):
+                    print_sys('Epoch {} Step {} Train Loss: {:.4f}'.format(ep + 1, step + 1, loss.item()))
+            val_res = evaluate_minibatch_clean(self.val_loader, self.model, self.device)
+            val_metrics = compute_metrics(val_res, False, -1, -1, F.mse_loss)
+            print_sys('Epoch {}: Validation MSE: {:.4f} Validation Pearson: {:.4f}. '.format(
+                ep + 1, val_metrics['mse'], val_metrics['pearsonr']))
+            self.val_metrics = val_metrics
+            if self.wandb:
+                for i, j in val_metrics.items():
+                    self.wandb.log({'val_' + i: j})
+            if val_metrics['pearsonr'] > min_val:                    # kgwas.py:170-173
+                min_val = val_metrics['pearsonr']
+                self.best_model = deepcopy(self.model)
+        if save_best_model and rank == 0:
+            save_model_path = os.path.join(self.data_path, 'model')
+            print_sys('Saving models to ' + os.path.join(save_model_path, save_name))
+            save_model(self.best_model, self.config, os.path.join(save_model_path, save_name))
+        test_res = evaluate_minibatch_clean(self.test_loader, self.best_model, self.device)
+        self.test_metrics = compute_metrics(test_res, False, -1, -1, F.mse_loss)
+        if self.wandb:
+            for i, j in self.test_metrics.items():
+                self.wandb.log({'test_' + i: j})
+        infer_res = evaluate_minibatch_clean(self.infer_loader, self.best_model, self.device)
+        self.data.lr_uni['pred'] = infer_res['pred']                 # kgwas.py:191
+        self._postprocess(save_name, save_best_model and rank == 0)
+
+    def _postprocess(self, save_name, save_best_model):
+        """kgwas.py:192-212: prediction-weighted p-values + calibration + CSVs.  The statistics live in
+        kgwas/eval_utils.py (CPU, pandas) -- SURVEY.md 8 row f-1, not yet rebuilt; predictions are saved."""
+        lr_uni_to_save = deepcopy(self.data.lr_uni)
+        out_dir = os.path.join(self.data_path, 'model_pred', 'new_experiments')
+        try:
+            os.makedirs(out_dir, exist_ok=True)
+            lr_uni_to_save.to_csv(os.path.join(out_dir, save_name + '_pred.csv'), index=False, sep='\t')
+            if save_best_model:
+                lr_uni_to_save.to_csv(os.path.join(self.data_path, 'model', save_name, 'pred.csv'), index=False, sep='\t')
+        except OSError as e:   # read-only data_path: keep results in memory
+            print_sys(f'could not write predictions: {e}')
+        self.kgwas_res = lr_uni_to_save

@@ -1,0 +1,160 @@
+"""autograd bridge to the fused attention-aggregate kernels (include/kgwas_hip.h).
+
+``gat_aggregate(batch, layer, H, a_dst, U)`` is, for every live relation r=(s,rel,d) of the layer at once,
+    e_ij  = leaky_relu(<H_s[j], U[r]> + a_dst[i, r])          kgwas/conv.py:150-152,205,217
+    alpha = softmax over the in-edges of destination i        kgwas/conv.py:223
+    Z[i, r, :] = sum_j alpha_ij H_s[j, :]                     kgwas/conv.py:227-228,182
+with hand-written backward (dst-major + src-major HIP passes, no atomics)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import KGW_C, PART_STRIDE, KgwLayerArgs
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else 0
+
+
+class KernelTimer:
+    """Optional HIP-event bracketing of the aggregate launches on the stream they are enqueued on
+    (bench.py's live roofline measurement).  Disabled by default: no events, no overhead."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []      # (tag, layer, start_event, end_event, n_edges, z_rows, n_src)
+
+    def bracket(self, tag, layer, n_edges, z_rows, n_src):
+        if not self.enabled:
+            return None
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream())
+        self.records.append((tag, layer, ev0, ev1, n_edges, z_rows, n_src))
+        return ev1
+
+    @staticmethod
+    def close(ev1):
+        if ev1 is not None:
+            ev1.record(torch.cuda.current_stream())
+
+    def summary(self):
+        """{(tag, layer): dict(n, ms_total, edges, z_rows, n_src)} -- call after a device sync."""
+        out = {}
+        for tag, layer, e0, e1, ne, zr, ns in self.records:
+            d = out.setdefault((tag, layer), dict(n=0, ms=0.0, edges=0, z_rows=0, n_src=0))
+            d['n'] += 1; d['ms'] += e0.elapsed_time(e1); d['edges'] += ne; d['z_rows'] += zr; d['n_src'] += ns
+        return out
+
+
+TIMER = KernelTimer()
+
+
+def _layer_args(batch, layer: int, neg_slope: float, inv_temp: float) -> KgwLayerArgs:
+    dg, buf, m = batch.dg, batch.buf, batch.meta
+    a = KgwLayerArgs()
+    a.layer = layer
+    a.n_chunks = int(m.n_chunks[layer - 1])
+    a.n_multi_hops = min(dg.num_layers - layer, dg.n_hops - 1) + 1
+    a.n_src_rows = int(m.src_base[layer - 1][dg.schema.NT])
+    a.neg_slope, a.inv_temp = neg_slope, inv_temp
+    a.graph_host = C.addressof(dg.kg)
+    a.meta_host = C.addressof(m)
+    a.chunks = _p(buf.chunks)
+    a.multi = _p(buf.multi)
+    a.multi_cap = dg.multi_cap
+    a.col_local = _p(buf.col_local)
+    a.t_ptr = _p(buf.t_ptr[layer - 1])
+    a.t_edge = _p(buf.t_edge[layer - 1])
+    a.t_zrow = _p(buf.t_zrow[layer - 1])
+    return a
+
+
+class _GatAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, H, a_dst, U, batch, layer, neg_slope, inv_temp):
+        dg, m = batch.dg, batch.meta
+        NT = dg.schema.NT
+        z_rows = int(m.z_base[layer - 1][NT])
+        n_edges = int(m.n_edges[layer - 1])
+        n_chunks = int(m.n_chunks[layer - 1])
+        n_src = int(m.src_base[layer - 1][NT])
+        H = H.contiguous(); a_dst = a_dst.contiguous(); U = U.contiguous()
+        assert H.dtype == torch.float32 and H.shape == (n_src, KGW_C), (H.shape, n_src)
+        assert a_dst.numel() == z_rows and U.shape == (dg.schema.NR, KGW_C)
+        dev = H.device
+        Z = torch.zeros(max(z_rows, 1), KGW_C, device=dev)
+        stat = torch.zeros(max(z_rows, 1), 2, device=dev)
+        e_edge = torch.empty(max(n_edges, 1), device=dev)
+        any_multi = any(int(m.multi_cnt[h]) for h in range(dg.n_hops))
+        part = torch.empty(max(n_chunks, 1) * PART_STRIDE if any_multi else 4, device=dev)
+        a = _layer_args(batch, layer, neg_slope, inv_temp)
+        a.H, a.a_dst, a.U = _p(H), _p(a_dst), _p(U)
+        a.Z, a.stat, a.e_edge, a.part = _p(Z), _p(stat), _p(e_edge), _p(part)
+        ev = TIMER.bracket('fwd', layer, n_edges, z_rows, n_src)
+        _lib.check(_lib.lib().kgw_gat_aggregate_fwd(C.byref(a), _lib.stream_ptr()), 'kgw_gat_aggregate_fwd')
+        TIMER.close(ev)
+        ctx.save_for_backward(H, U, Z, stat, e_edge)
+        ctx.batch, ctx.layer, ctx.neg_slope, ctx.inv_temp = batch, layer, neg_slope, inv_temp
+        ctx.mark_non_differentiable(stat, e_edge)
+        return Z[:z_rows], stat, e_edge
+
+    @staticmethod
+    def backward(ctx, dZ, _dstat, _de):
+        H, U, Z, stat, e_edge = ctx.saved_tensors
+        batch, layer = ctx.batch, ctx.layer
+        dg, m = batch.dg, batch.meta
+        sc = dg.schema
+        NT = sc.NT
+        z_rows = int(m.z_base[layer - 1][NT])
+        n_edges = int(m.n_edges[layer - 1])
+        n_chunks = int(m.n_chunks[layer - 1])
+        n_src = int(m.src_base[layer - 1][NT])
+        t_rows = int(m.t_base[layer - 1][NT])
+        dev = H.device
+        dZf = dZ.contiguous() if z_rows else torch.zeros(1, KGW_C, device=dev)
+        adp = torch.empty(max(n_edges, 1), 2, device=dev)
+        da_dst = torch.zeros(max(z_rows, 1), device=dev)
+        part_da = torch.empty(max(n_chunks, 1), device=dev)
+        dH = torch.empty(max(n_src, 1), KGW_C, device=dev)
+        da_src = torch.empty(max(t_rows, 1), device=dev)
+        a = _layer_args(batch, layer, ctx.neg_slope, ctx.inv_temp)
+        a.H, a.U, a.Z, a.stat, a.e_edge = _p(H), _p(U), _p(Z), _p(stat), _p(e_edge)
+        a.dZ, a.adp, a.da_dst, a.part_da = _p(dZf), _p(adp), _p(da_dst), _p(part_da)
+        a.dH, a.da_src = _p(dH), _p(da_src)
+        L = _lib.lib()
+        ev = TIMER.bracket('bwd_dst', layer, n_edges, z_rows, n_src)
+        _lib.check(L.kgw_gat_aggregate_bwd_dst(C.byref(a), _lib.stream_ptr()), 'kgw_gat_aggregate_bwd_dst')
+        TIMER.close(ev)
+        ev = TIMER.bracket('bwd_src', layer, n_edges, z_rows, n_src)
+        _lib.check(L.kgw_gat_aggregate_bwd_src(C.byref(a), _lib.stream_ptr()), 'kgw_gat_aggregate_bwd_src')
+        TIMER.close(ev)
+        # d u_r = sum_j d a_src[j, r] * H_s[j]   (a_s = <H_s[j], u_r>)
+        dU = torch.zeros_like(U)
+        for t in range(NT):
+            ns, Rs = int(m.n_src[layer - 1][t]), int(sc.R_src[t])
+            if ns == 0 or Rs == 0:
+                continue
+            tb, sb = int(m.t_base[layer - 1][t]), int(m.src_base[layer - 1][t])
+            blk = da_src[tb:tb + ns * Rs].view(ns, Rs)
+            dU[sc.rels_by_src[t]] = blk.t() @ H[sb:sb + ns]
+        return dH[:n_src], da_dst[:z_rows], dU, None, None, None, None
+
+
+def gat_aggregate(batch, layer: int, H: torch.Tensor, a_dst: torch.Tensor, U: torch.Tensor,
+                  neg_slope: float = 0.2, temperature: float = 1.0):
+    """Returns (Z [z_rows,128], stat [z_rows,2] = (row max, denominator), e_edge [n_edges])."""
+    return _GatAggregate.apply(H, a_dst, U, batch, layer, float(neg_slope), 1.0 / float(temperature))
+
+
+def edge_alpha(batch, layer: int, stat: torch.Tensor, e_edge: torch.Tensor, temperature: float = 1.0):
+    """alpha per local edge of one layer from the saved softmax statistics."""
+    a = _layer_args(batch, layer, 0.2, 1.0 / float(temperature))
+    n_edges = int(batch.meta.n_edges[layer - 1])
+    out = torch.zeros(max(n_edges, 1), device=e_edge.device)
+    a.stat, a.e_edge = _p(stat), _p(e_edge)
+    _lib.check(_lib.lib().kgw_edge_alpha(C.byref(a), C.c_void_p(out.data_ptr()), _lib.stream_ptr()), 'kgw_edge_alpha')
+    return out[:n_edges]

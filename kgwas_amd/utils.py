@@ -1,0 +1,82 @@
+"""Harness helpers with the reference's names and contracts (kgwas/utils.py:20-45,203-233,397-434)."""
+from __future__ import annotations
+
+import os
+import pickle
+import sys
+
+import numpy as np
+import torch
+
+
+def print_sys(s):
+    """kgwas/utils.py:227-233."""
+    print(s, flush=True, file=sys.stderr)
+
+
+def save_dict(path, obj):
+    with open(path, 'wb') as f:
+        pickle.dump(obj, f)
+
+
+def load_dict(path):
+    with open(path, 'rb') as f:
+        return pickle.load(f)
+
+
+def evaluate_minibatch_clean(loader, model, device):
+    """kgwas/utils.py:20-39: eval-mode forward over a loader; returns {'pred', 'truth'} numpy arrays.
+    Differences by design: wrapped in no_grad (the reference builds and frees autograd graphs), and
+    predictions stay on the GPU until the end (one D2H copy instead of one per batch)."""
+    model.eval()
+    preds, truths = [], []
+    with torch.no_grad():
+        for batch in loader:
+            batch = batch.to(device)
+            bs = batch['SNP'].batch_size
+            out = model(batch.x_dict, batch.edge_index_dict, bs)
+            preds.append(out.reshape(-1))
+            truths.append(batch['SNP'].y[:bs])
+    if not preds:
+        return {'pred': np.zeros(0, np.float32), 'truth': np.zeros(0, np.float32)}
+    return {'pred': torch.cat(preds).float().cpu().numpy(), 'truth': torch.cat(truths).float().cpu().numpy()}
+
+
+def compute_metrics(results, binary=False, coverage=None, uncertainty_reg=1, loss_fct=None):
+    """kgwas/utils.py:41-45: sklearn mean_squared_error + scipy pearsonr."""
+    from scipy.stats import pearsonr
+    from sklearn.metrics import mean_squared_error
+    return {'mse': mean_squared_error(results['pred'], results['truth']),
+            'pearsonr': pearsonr(results['pred'], results['truth'])[0]}
+
+
+def save_model(model, config, path_dir):
+    """kgwas/utils.py:203-207: model.pt (state_dict) + config.pkl."""
+    os.makedirs(path_dir, exist_ok=True)
+    torch.save(model.state_dict(), os.path.join(path_dir, 'model.pt'))
+    save_dict(os.path.join(path_dir, 'config.pkl'), config)
+
+
+def load_pretrained(path, model):
+    """kgwas/utils.py:209-222 (strips a DataParallel ``module.`` prefix)."""
+    state_dict = torch.load(os.path.join(path, 'model.pt'), map_location=torch.device('cpu'), weights_only=False)
+    if next(iter(state_dict))[:7] == 'module.':
+        from collections import OrderedDict
+        state_dict = OrderedDict((k[7:], v) for k, v in state_dict.items())
+    model.load_state_dict(state_dict)
+    return model
+
+
+def ldsc_regression_weights(ld, w_ld, N, M, hsq, intercept=None, ii=None):
+    """LD-score regression weights, kgwas/utils.py:397-434: 1 / (2 (intercept + hsq N ld / M)^2 w_ld)
+    with ld, w_ld floored at 1 and hsq clipped to [0, 1]."""
+    M = float(M)
+    if intercept is None:
+        intercept = 1
+    hsq = min(max(hsq, 0.0), 1.0)
+    ld = np.fmax(ld, 1.0)
+    w_ld = np.fmax(w_ld, 1.0)
+    c = hsq * N / M
+    het_w = 1.0 / (2 * np.square(intercept + np.multiply(c, ld)))
+    oc_w = 1.0 / w_ld
+    return np.multiply(het_w, oc_w)

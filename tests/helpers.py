@@ -1,0 +1,59 @@
+"""Shared test plumbing: run the CPU oracle on exactly the subgraph / weights the HIP path used."""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from oracle.gat_oracle import HeteroGNNOracle
+
+
+def product_dims(model):
+    return (model.snp_feat_mlp.FC_hidden.in_features, model.gene_feat_mlp.FC_hidden.in_features,
+            model.go_feat_mlp.FC_hidden.in_features)
+
+
+def oracle_from_product(model, dtype=torch.float64):
+    snp, gene, go = product_dims(model)
+    o = HeteroGNNOracle(model.edge_types, model.hidden, model.lin.out_features, model.num_layers, 'GAT', 'sum',
+                        snp, gene, go, 1, no_relu=model.no_relu, dtype=dtype)
+    sd = OrderedDict()
+    for k, v in model.state_dict().items():
+        if isinstance(v, torch.nn.parameter.UninitializedParameter):
+            continue
+        sd[k] = v.detach().cpu().to(dtype)
+    missing = o.load_state_dict(sd, strict=True)
+    return o
+
+
+def batch_cpu(batch, dtype=torch.float64):
+    x = {t: v.detach().cpu().to(dtype) for t, v in batch.x_dict.items()}
+    ei = OrderedDict((k, v.cpu()) for k, v in batch.edge_index_dict.items())
+    return x, ei
+
+
+def grads_by_name(model):
+    return {n: (p.grad.detach().cpu() if p.grad is not None else None) for n, p in model.named_parameters()}
+
+
+def assert_close(a, b, rtol, atol, what=''):
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if a.numel() == 0:
+        return
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bad.any(), (f'{what}: {int(bad.sum())}/{a.numel()} elements out of tolerance; max abs err '
+                           f'{float(err.max()):.3e}, max |ref| {float(b.abs().max()):.3e}')
+
+
+def global_edge_set(batch, et):
+    """Set of (global src, global dst) pairs of relation ``et`` in a sampled batch (multiset as sorted array)."""
+    ei = batch.edge_index_dict[et].cpu().numpy()
+    s, _, d = et
+    ns = batch.n_id(s).cpu().numpy().astype(np.int64)
+    nd = batch.n_id(d).cpu().numpy().astype(np.int64)
+    pairs = np.stack([ns[ei[0]], nd[ei[1]]], axis=1) if ei.shape[1] else np.zeros((0, 2), np.int64)
+    order = np.lexsort((pairs[:, 0], pairs[:, 1]))
+    return pairs[order]
