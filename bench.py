@@ -44,13 +44,15 @@ def algorithmic_bytes_bwd(n_edges, z_rows, n_src):
     return 1048 * n_edges + 520 * (z_rows + n_src)
 
 
-def cpu_baseline(data, batch_size, budget_s=25.0, max_steps=3):
+def cpu_baseline(data, batch_size, budget_s=25.0, max_steps=2):
     """Reference PyG CPU path, restated (oracle/): numpy full-neighbour sampler + x[n_id] slicing + unpruned
     2-layer HeteroGNN forward/backward + Adam, all host cores.  Bounded sample: as many steps as fit in
     ~budget_s (at least 1 after 1 warm-up)."""
     from oracle.gat_oracle import HeteroGNNOracle, weighted_mse
     from oracle.sampler_np import FullNeighborSamplerNP
-    cores = os.cpu_count() or 1
+    # more threads than ~16 only add OpenMP fork/join cost on these small scatter ops (256 threads: 355 s/step
+    # vs 13 s/step with 8); use what actually helps and report it
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     g = data.data
     t0 = time.time()

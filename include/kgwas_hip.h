@@ -171,6 +171,12 @@ int kgw_gather_rows(const float* src, const int32_t* ids, int64_t n_rows, int32_
  * kgwas/conv.py:192-196; kgwas/utils.py:446-461).                                             */
 int kgw_edge_alpha(const KgwLayerArgs* args, float* alpha_out, kgw_stream_t stream);
 
+/* Self-test of the cross-lane reductions used by the aggregate kernels (one wavefront):
+ * out_half[l] = sum over l's 32-lane half, out_wave[l] = sum over the wavefront,
+ * out_steps[4][64] = the four intra-row DPP butterfly stages.                                  */
+int kgw_debug_reduce(const float* in, float* out_half, float* out_wave, float* out_steps,
+                     kgw_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,9 +8,9 @@ there is no CPU fallback -- importing is fine anywhere, running needs a ROCm dev
 from .graph import HeteroGraph, GraphSchema
 from .kgwas_data import KGWAS_Data
 from .kgwas import KGWAS
-from .model import HeteroGNN, GATConv, HeteroConv, SimpleMLP
+from .model import HeteroGNN, RelationPack, SimpleMLP
 from .sampler import NeighborLoader, DeviceGraph, SampledBatch
 
 __version__ = '0.1.0'
-__all__ = ['KGWAS', 'KGWAS_Data', 'HeteroGNN', 'GATConv', 'HeteroConv', 'SimpleMLP', 'NeighborLoader',
+__all__ = ['KGWAS', 'KGWAS_Data', 'HeteroGNN', 'RelationPack', 'SimpleMLP', 'NeighborLoader',
            'DeviceGraph', 'SampledBatch', 'HeteroGraph', 'GraphSchema']

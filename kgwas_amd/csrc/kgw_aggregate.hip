@@ -528,3 +528,38 @@ extern "C" int kgw_struct_sizes(int64_t* out, int n) {
     for (int i = 0; i < n && i < 5; ++i) out[i] = v[i];
     return KGW_OK;
 }
+
+// ---- self-test of the cross-lane primitives (tests/test_gpu_primitives.py) -------------------------
+namespace {
+__global__ void k_debug_reduce(const float* in, float* out_half, float* out_wave, float* out_steps) {
+    const int lane = threadIdx.x;
+    float v = in[lane];
+    out_half[lane] = kgw_half_allsum(v);
+    out_wave[lane] = kgw_wave_allsum(v);
+    float a = v + kgw_dpp<0xB1>(v);
+    out_steps[lane] = a;
+    float b = a + kgw_dpp<0x4E>(a);
+    out_steps[64 + lane] = b;
+    float c = b + kgw_dpp<0x141>(b);
+    out_steps[128 + lane] = c;
+    float d = c + kgw_dpp<0x140>(c);
+    out_steps[192 + lane] = d;
+    // raw semantics of the two swap instructions on distinguishable inputs
+    int a16 = lane, b16 = 100 + lane;
+    auto r16 = __builtin_amdgcn_permlane16_swap(a16, b16, false, false);
+    out_steps[256 + lane] = (float)r16[0];
+    out_steps[320 + lane] = (float)r16[1];
+    int a32 = lane, b32 = 100 + lane;
+    auto r32 = __builtin_amdgcn_permlane32_swap(a32, b32, false, false);
+    out_steps[384 + lane] = (float)r32[0];
+    out_steps[448 + lane] = (float)r32[1];
+}
+}  // namespace
+
+extern "C" int kgw_debug_reduce(const float* in, float* out_half, float* out_wave, float* out_steps,
+                                kgw_stream_t stream_) {
+    if (!in || !out_half || !out_wave || !out_steps) return KGW_E_NULL;
+    k_debug_reduce<<<1, 64, 0, (hipStream_t)stream_>>>(in, out_half, out_wave, out_steps);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}

@@ -38,18 +38,22 @@ __device__ __forceinline__ float kgw_half_allsum(float v) {
     v += kgw_dpp<0x4E>(v);    // quad_perm [2,3,0,1]  (xor 2)
     v += kgw_dpp<0x141>(v);   // row_half_mirror      (xor 4 once quads are uniform)
     v += kgw_dpp<0x140>(v);   // row_mirror           (xor 8 once 8-groups are uniform)
-    // rows 0<->1 and 2<->3: gfx950 v_permlane16_swap exchanges odd rows of vdst with even rows of src
-    int a = __builtin_bit_cast(int, v);
-    auto r = __builtin_amdgcn_permlane16_swap(a, a, false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    // rows 0<->1 and 2<->3: v_permlane16_swap_b32 exchanges the odd rows of its first operand with the
+    // even rows of its second, in place.  Inline asm on purpose: hipcc (ROCm 7.2) folds the two results of
+    // __builtin_amdgcn_permlane16_swap(x, x) into one register (emits v_add v, r0, r0) -- verified in the
+    // ISA and by tests/test_gpu_primitives.py.  The two v_nop are the 2 wait states a VALU write needs
+    // before a v_permlane*_swap reads it (guide T21).
+    float a = v, b = v;
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1\n\tv_nop" : "+v"(a), "+v"(b));
+    return a + b;
 }
 
 // All-reduce (sum) across the whole wavefront.
 __device__ __forceinline__ float kgw_wave_allsum(float v) {
     v = kgw_half_allsum(v);
-    int a = __builtin_bit_cast(int, v);
-    auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    float a = v, b = v;
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1\n\tv_nop" : "+v"(a), "+v"(b));
+    return a + b;
 }
 
 __device__ __forceinline__ float kgw_xhalf(float v) {   // value held by the same lane of the other half

@@ -10,27 +10,37 @@ Execution plan of one HeteroConv layer (all relations at once):
   3. kgw_gat_aggregate: Z[i, r] = sum_j softmax_j(leaky_relu(<H_s[j],u_r> + a_d[i,r])) H_s[j];
   4. out_d = relu( [Z[:,r0] | Z[:,r1] | ...] @ [W_r0^T ; W_r1^T ; ...] + sum_r bias_r )  -- the
      per-relation linear maps of conv.py:138/142, the bias of :190, the relation sum of PyG HeteroConv
-     (model.py:74) and the ReLU of model.py:75 fused into one GEMM epilogue.
+     (model.py:74) and the ReLU of model.py:75 as ONE GEMM per destination type.
 Only what the seeds' prediction depends on is computed (layer l on rows of hop <= L-l); rows the
 reference computes and then discards (model.py:86 keeps [:batch_size]) carry zero gradient, so
 parameter gradients are identical.
+
+Parameter storage is MI355X-first: the ~30 relations x 5 tensors of a layer live in a handful of packed
+tensors (``RelationPack``), laid out so that step 4's concatenated weight is a free view and steps 1-2
+are three batched mat-vecs -- a step issues ~100 launches instead of ~1000.  ``state_dict()`` /
+``load_state_dict()`` translate to and from the reference's per-relation keys
+(``convs.<l>.convs.<src__rel__dst>.{lin_src.weight,lin_dst.weight,att_src,att_dst,bias}``), so a
+checkpoint written by either implementation loads in the other (kgwas/utils.py:203-222).
+Relations that are structurally disconnected from the read-out (e.g. every layer-2 relation whose
+destination is not SNP) are kept in a separate pack that never enters the autograd graph: like in the
+reference their gradient is None and Adam (incl. its weight decay) never touches them.
 """
 from __future__ import annotations
 
 import math
 from collections import OrderedDict
-from typing import Dict, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
 from .graph import GraphSchema, HeteroGraph
-from .sampler import BatchDict, SampledBatch, sample_full_graph
+from .sampler import SampledBatch, gather_rows, sample_full_graph
 
 EdgeType = Tuple[str, str, str]
 GO_TYPES = ('CellularComponent', 'BiologicalProcess', 'MolecularFunction')
+REL_FIELDS = ('att_src', 'att_dst', 'bias', 'lin_src.weight', 'lin_dst.weight')
 
 
 def edge_key(et: EdgeType) -> str:
@@ -38,8 +48,7 @@ def edge_key(et: EdgeType) -> str:
     return '__'.join(et)
 
 
-def _glorot_(t: torch.Tensor):
-    a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+def _uniform_(t: torch.Tensor, a: float):
     with torch.no_grad():
         t.uniform_(-a, a)
     return t
@@ -55,48 +64,67 @@ class SimpleMLP(nn.Module):
         self.FC_output = nn.Linear(hidden_dim, output_dim)
         self.ReLU = nn.ReLU()
 
+    def tail(self, h1):
+        return self.FC_output(self.ReLU(self.FC_hidden2(h1)))
+
     def forward(self, x):
-        h = self.ReLU(self.FC_hidden(x))
-        h = self.ReLU(self.FC_hidden2(h))
-        return self.FC_output(h)
+        return self.tail(self.ReLU(self.FC_hidden(x)))
 
 
-class GATConv(nn.Module):
-    """Parameter holder of one relation's attention conv (kgwas/conv.py:81-120): bias-free
-    ``lin_src`` / ``lin_dst`` (glorot), ``att_src`` / ``att_dst`` [1,H,C] (glorot), ``bias`` (zeros).
-    Same-type relations never materialise ``lin_dst`` in the reference (it stays a lazy parameter)."""
+class RelationPack(nn.Module):
+    """Parameters of a list of relations of one layer, packed (kgwas/conv.py:81-120 per relation):
+    ``w_src_t[i]`` = lin_src.weight^T  ([in k, out c], glorot), ``w_dst_t[j]`` = lin_dst.weight^T of the
+    j-th bipartite relation (same-type relations never materialise lin_dst in the reference),
+    ``att_src`` / ``att_dst`` (glorot on [1,1,C]), ``bias`` (zeros)."""
 
-    def __init__(self, in_channels: int, out_channels: int, bipartite: bool, heads: int = 1,
-                 negative_slope: float = 0.2, temperature: float = 1.0):
+    def __init__(self, edge_types: List[EdgeType], rel_ids: List[int], C: int):
         super().__init__()
-        if heads != 1:
-            raise NotImplementedError('gat_num_head > 1 breaks the reference read-out (model.py:50 expects '
-                                      'hidden_channels inputs); only heads=1 is supported')
-        self.heads, self.out_channels = heads, out_channels
-        self.negative_slope, self.temperature = negative_slope, temperature
-        self.lin_src = nn.Linear(in_channels, heads * out_channels, bias=False)
-        _glorot_(self.lin_src.weight)
-        if bipartite:
-            self.lin_dst = nn.Linear(in_channels, heads * out_channels, bias=False)
-            _glorot_(self.lin_dst.weight)
-        else:
-            self.lin_dst = None
-        self.att_src = nn.Parameter(_glorot_(torch.empty(1, heads, out_channels)))
-        self.att_dst = nn.Parameter(_glorot_(torch.empty(1, heads, out_channels)))
-        self.bias = nn.Parameter(torch.zeros(heads * out_channels))
+        self.rel_ids = list(rel_ids)
+        self.rel_types = [edge_types[r] for r in rel_ids]
+        n = len(rel_ids)
+        bip = [i for i, et in enumerate(self.rel_types) if et[0] != et[2]]
+        self.bip = bip
+        self.bip_pos = {i: j for j, i in enumerate(bip)}
+        a_w = math.sqrt(6.0 / (C + C))          # glorot on [C_out, C_in]
+        a_a = math.sqrt(6.0 / (1 + C))          # glorot on [1, heads=1, C]
+        self.w_src_t = nn.Parameter(_uniform_(torch.empty(n, C, C), a_w))
+        self.w_dst_t = nn.Parameter(_uniform_(torch.empty(len(bip), C, C), a_w))
+        self.att_src = nn.Parameter(_uniform_(torch.empty(n, C), a_a))
+        self.att_dst = nn.Parameter(_uniform_(torch.empty(n, C), a_a))
+        self.bias = nn.Parameter(torch.zeros(n, C))
+        self.register_buffer('rel_ids_t', torch.tensor(rel_ids, dtype=torch.long), persistent=False)
+        self.register_buffer('bip_t', torch.tensor(bip, dtype=torch.long), persistent=False)
 
+    # reference-named view of one tensor of relation slot i (value or gradient)
+    def get(self, i: int, field: str, grad: bool = False):
+        def pick(p):
+            if grad:
+                return None if p.grad is None else p.grad
+            return p.detach()
+        if field == 'lin_src.weight':
+            t = pick(self.w_src_t)
+            return None if t is None else t[i].t()
+        if field == 'lin_dst.weight':
+            if i not in self.bip_pos:
+                return 'lazy'
+            t = pick(self.w_dst_t)
+            return None if t is None else t[self.bip_pos[i]].t()
+        t = pick(getattr(self, field))
+        if t is None:
+            return None
+        return t[i].view(1, 1, -1) if field.startswith('att') else t[i]
 
-class HeteroConv(nn.Module):
-    """Container matching PyG HeteroConv's module tree: ``convs.<src__rel__dst>``."""
-
-    def __init__(self, convs: "OrderedDict[EdgeType, GATConv]", aggr: str = 'sum'):
-        super().__init__()
-        self.edge_types = list(convs.keys())
-        self.convs = nn.ModuleDict({edge_key(k): v for k, v in convs.items()})
-        self.aggr = aggr
-
-    def conv(self, et: EdgeType) -> GATConv:
-        return self.convs[edge_key(et)]
+    def set(self, i: int, field: str, value: torch.Tensor):
+        with torch.no_grad():
+            if field == 'lin_src.weight':
+                self.w_src_t[i].copy_(value.t())
+            elif field == 'lin_dst.weight':
+                if i in self.bip_pos:
+                    self.w_dst_t[self.bip_pos[i]].copy_(value.t())
+            elif field.startswith('att'):
+                getattr(self, field)[i].copy_(value.reshape(-1))
+            else:
+                getattr(self, field)[i].copy_(value)
 
 
 class HeteroGNN(nn.Module):
@@ -113,26 +141,48 @@ class HeteroGNN(nn.Module):
             raise NotImplementedError("gnn_aggr: only 'sum' (the reference default) is fused")
         if hidden_channels != 128:
             raise NotImplementedError('the fused kernels are specialised for gnn_hidden_dim=128')
+        if gat_num_head != 1:
+            raise NotImplementedError('gat_num_head > 1 breaks the reference read-out (model.py:50 expects '
+                                      'hidden_channels inputs); only heads=1 is supported')
         self.node_types = list(pyg_data.node_types)
         self.edge_types = [tuple(e) for e in pyg_data.edge_types]
         self.schema = GraphSchema(self.node_types, self.edge_types)
+        sc = self.schema
         self.num_layers = num_layers
         self.hidden = hidden_channels
-        self.convs = nn.ModuleList()
+        self.negative_slope, self.temperature = 0.2, 1.0          # conv.py:43,50 defaults (model.py:40-42)
+        self.live_rel, self.live_types = sc.live_relations(num_layers, 'SNP')
+        self.live_packs = nn.ModuleList()
+        self.dead_packs = nn.ModuleList()
+        self._slot: List[Dict[int, Tuple[str, int]]] = []        # per layer: relation id -> (pack, index)
+        self._dst_range: List[Dict[int, Tuple[int, int]]] = []   # per layer: dst type -> [lo, hi) in live pack
+        for l in range(1, num_layers + 1):
+            live = set(self.live_rel[l])
+            order = [r for t in range(sc.NT) for r in sc.rels_by_dst[t] if r in live]   # grouped by dst type
+            dead = [r for r in range(sc.NR) if r not in live]
+            self.live_packs.append(RelationPack(self.edge_types, order, hidden_channels))
+            self.dead_packs.append(RelationPack(self.edge_types, dead, hidden_channels))
+            slot = {r: ('live', i) for i, r in enumerate(order)}
+            slot.update({r: ('dead', i) for i, r in enumerate(dead)})
+            self._slot.append(slot)
+            rng, lo = {}, 0
+            for t in range(sc.NT):
+                k = sum(1 for r in sc.rels_by_dst[t] if r in live)
+                if k:
+                    assert k == len(sc.rels_by_dst[t])
+                    rng[t] = (lo, lo + k)
+                    lo += k
+            self._dst_range.append(rng)
         self.snp_feat_mlp = SimpleMLP(snp_init_dim_size, hidden_channels, hidden_channels)
         self.go_feat_mlp = SimpleMLP(go_init_dim_size, hidden_channels, hidden_channels)
         self.gene_feat_mlp = SimpleMLP(gene_init_dim_size, hidden_channels, hidden_channels)
         self.ReLU = nn.ReLU()
-        for _ in range(num_layers):
-            layer = OrderedDict()
-            for et in self.edge_types:
-                layer[et] = GATConv(hidden_channels, hidden_channels, bipartite=(et[0] != et[2]),
-                                    heads=gat_num_head)
-            self.convs.append(HeteroConv(layer, aggr=gnn_aggr))
         self.lin = nn.Linear(hidden_channels, out_channels)
         self.no_relu = no_relu
-        self.live_rel, self.live_types = self.schema.live_relations(num_layers, 'SNP')
         self.last_attention = None
+        # dead packs never receive gradients; keep them out of autograd entirely
+        for p in self.dead_packs.parameters():
+            p.requires_grad_(False)
 
     # ------------------------------------------------------------------------------------------
     def _mlp_for(self, t: str) -> SimpleMLP:
@@ -144,35 +194,42 @@ class HeteroGNN(nn.Module):
             return self.go_feat_mlp
         raise KeyError(f'no feature MLP for node type {t!r} (kgwas/model.py:56-60)')
 
-    def _packed(self, l: int):
-        """Stack the live relations' parameters of layer l (1-based) for the fused kernels."""
-        sc = self.schema
-        hc: HeteroConv = self.convs[l - 1]
-        live = set(self.live_rel[l])
-        dev = self.lin.weight.device
-        zero128 = torch.zeros(self.hidden, device=dev)
-        U, V = [], []
-        for r, et in enumerate(sc.edge_types):
-            if r not in live:
-                U.append(zero128); V.append(zero128)
-                continue
-            c = hc.conv(et)
-            w_src = c.lin_src.weight
-            w_dst = c.lin_dst.weight if c.lin_dst is not None else w_src
-            U.append(c.att_src.view(-1) @ w_src)            # u_r = W_src^T att_src
-            V.append(c.att_dst.view(-1) @ w_dst)            # v_r = W_dst^T att_dst
-        return torch.stack(U), torch.stack(V)
+    def _embed(self, batch: SampledBatch, x_dict, t: str):
+        """Feature MLP of the sampled nodes of type t (model.py:56-60).  When most of a type is in the batch
+        and its features are wide (the 5120 / 57742-wide gene matrix), the first Linear runs on the RESIDENT
+        matrix and the 128-wide result is sliced, instead of slicing 20 KB rows first: same values, the
+        x[n_id] copy (kgwas.py:135 moves it over PCIe every step) disappears."""
+        mlp = self._mlp_for(t)
+        dg = batch.dg
+        n = batch.n_nodes[t]
+        if n == 0:
+            return torch.zeros(0, self.hidden, device=self.lin.weight.device)
+        lazy = getattr(x_dict, 'kgw_batch', None) is batch and t in dg.x
+        if lazy and not dg.full_graph:
+            X = dg.x[t]
+            if X.shape[1] >= 512 and 2 * n > X.shape[0]:
+                h1_all = mlp.ReLU(mlp.FC_hidden(X))
+                return mlp.tail(h1_all.index_select(0, batch.n_id(t)))
+        return mlp(x_dict[t])
 
     def _fused_layers(self, batch: SampledBatch, h: Dict[str, torch.Tensor], want_attention=False):
         sc = self.schema
         m = batch.meta
-        NT = sc.NT
+        C = self.hidden
+        dev = self.lin.weight.device
         attn = []
         for l in range(1, self.num_layers + 1):
-            hc: HeteroConv = self.convs[l - 1]
-            U, V = self._packed(l)
-            # layer input, type-major (src_base)
-            parts = []
+            P: RelationPack = self.live_packs[l - 1]
+            rng = self._dst_range[l - 1]
+            # u_r = W_src^T att_src ; v_r = W_dst^T att_dst (W_src^T att_dst for same-type relations)
+            U_live = torch.bmm(P.w_src_t, P.att_src.unsqueeze(-1)).squeeze(-1)
+            V_live = torch.bmm(P.w_src_t, P.att_dst.unsqueeze(-1)).squeeze(-1)
+            if P.bip:
+                Vd = torch.bmm(P.w_dst_t, P.att_dst.index_select(0, P.bip_t).unsqueeze(-1)).squeeze(-1)
+                V_live = V_live.index_copy(0, P.bip_t, Vd)
+            U = torch.zeros(sc.NR, C, device=dev).index_copy(0, P.rel_ids_t, U_live)
+            # layer input, type-major (src_base) ; destination-side attention terms a_d[i, r]
+            parts, a_parts = [], []
             for t, name in enumerate(sc.node_types):
                 ns = int(m.n_src[l - 1][t])
                 if ns:
@@ -180,30 +237,26 @@ class HeteroGNN(nn.Module):
                         raise RuntimeError(f'layer {l}: node type {name!r} is a message source but has no '
                                            f'incoming relation to produce its layer-{l - 1} state')
                     parts.append(h[name][:ns])
-            H = torch.cat(parts, 0) if parts else torch.zeros(0, self.hidden, device=U.device)
-            # destination-side attention terms a_d[i, r]
-            a_parts = []
-            for t, name in enumerate(sc.node_types):
                 nr = int(m.n_rows[l - 1][t])
                 if nr:
-                    a_parts.append((h[name][:nr] @ V[sc.rels_by_dst[t]].t()).reshape(-1))
-            a_dst = torch.cat(a_parts) if a_parts else torch.zeros(0, device=U.device)
-            c0 = hc.conv(sc.edge_types[0])
-            Z, stat, e_edge = ops.gat_aggregate(batch, l, H, a_dst, U, c0.negative_slope, c0.temperature)
+                    lo, hi = rng[t]
+                    a_parts.append((h[name][:nr] @ V_live[lo:hi].t()).reshape(-1))
+            H = torch.cat(parts, 0) if len(parts) != 1 else parts[0]
+            a_dst = torch.cat(a_parts) if len(a_parts) != 1 else a_parts[0]
+            Z, stat, e_edge = ops.gat_aggregate(batch, l, H, a_dst, U, self.negative_slope, self.temperature)
             if want_attention:
-                attn.append(ops.edge_alpha(batch, l, stat, e_edge, c0.temperature))
-            # per-relation linear maps + bias + relation sum + ReLU
+                attn.append(ops.edge_alpha(batch, l, stat, e_edge, self.temperature))
+            # per-relation linear maps + bias + relation sum + ReLU: one GEMM per destination type
             h_next = {}
             for t, name in enumerate(sc.node_types):
                 nr = int(m.n_rows[l - 1][t])
                 if not nr:
                     continue
-                rels = sc.rels_by_dst[t]
+                lo, hi = rng[t]
+                R = hi - lo
                 zb = int(m.z_base[l - 1][t])
-                Zt = Z[zb:zb + nr * len(rels)].view(nr, len(rels) * self.hidden)
-                Wcat = torch.cat([hc.conv(sc.edge_types[r]).lin_src.weight.t() for r in rels], 0)
-                bsum = torch.stack([hc.conv(sc.edge_types[r]).bias for r in rels]).sum(0)
-                h_next[name] = torch.relu(torch.addmm(bsum, Zt, Wcat))
+                Zt = Z[zb:zb + nr * R].view(nr, R * C)
+                h_next[name] = torch.relu(torch.addmm(P.bias[lo:hi].sum(0), Zt, P.w_src_t[lo:hi].reshape(R * C, C)))
             h = h_next
         return h, attn
 
@@ -212,13 +265,7 @@ class HeteroGNN(nn.Module):
         batch: Optional[SampledBatch] = getattr(x_dict, 'kgw_batch', None) or getattr(edge_index_dict, 'kgw_batch', None)
         if batch is None:
             batch = self._block_from_coo(x_dict, edge_index_dict)
-        # feature MLPs (model.py:56-60); GO types share one MLP
-        h = {}
-        for t in self.node_types:
-            if t in x_dict and x_dict[t].shape[0] > 0:
-                h[t] = self._mlp_for(t)(x_dict[t])
-            elif t in x_dict:
-                h[t] = torch.zeros(0, self.hidden, device=self.lin.weight.device)
+        h = {t: self._embed(batch, x_dict, t) for t in self.node_types if t in x_dict}
         h, attn = self._fused_layers(batch, h, want_attention=return_attention_weights)
         snp = h['SNP']
         out = self.lin(snp)[:batch_size]
@@ -238,35 +285,76 @@ class HeteroGNN(nn.Module):
         dev = next(iter(x_dict.values())).device
         g = HeteroGraph()
         for t in self.node_types:
-            if t in x_dict:
-                g[t].num_nodes_ = int(x_dict[t].shape[0])
-            else:
-                g[t].num_nodes_ = 0
+            g[t].num_nodes_ = int(x_dict[t].shape[0]) if t in x_dict else 0
         for et in self.edge_types:
             ei = edge_index_dict.get(et)
             g[et].edge_index = ei if ei is not None else torch.zeros(2, 0, dtype=torch.long)
         return sample_full_graph(g, self.num_layers, dev)
 
-    # --- checkpoint compatibility (kgwas/utils.py:203-222) ---------------------------------------
-    def state_dict(self, *args, **kwargs):
-        sd = super().state_dict(*args, **kwargs)
-        prefix = kwargs.get('prefix', args[1] if len(args) > 1 else '')
-        out = OrderedDict()
-        for k, v in sd.items():
-            out[k] = v
-        # same-type relations: PyG keeps an uninitialised lazy ``lin_dst.weight`` in the state_dict
+    # --- reference-named parameters (checkpoints, tests) ------------------------------------------
+    def _rel_items(self, grad: bool = False):
+        """Yield (reference key, tensor | None | 'lazy') for every relation tensor of every layer."""
         for l in range(self.num_layers):
-            for et in self.edge_types:
-                if et[0] == et[2]:
-                    out[f'{prefix}convs.{l}.convs.{edge_key(et)}.lin_dst.weight'] = \
-                        torch.nn.parameter.UninitializedParameter()
+            for r, et in enumerate(self.edge_types):
+                which, i = self._slot[l][r]
+                pack = self.live_packs[l] if which == 'live' else self.dead_packs[l]
+                for f in REL_FIELDS:
+                    yield f'convs.{l}.convs.{edge_key(et)}.{f}', pack.get(i, f, grad)
+
+    def named_reference_tensors(self, grad: bool = False) -> "OrderedDict[str, Optional[torch.Tensor]]":
+        """Parameters (or their gradients) under the reference's names.  Lazy lin_dst of same-type relations
+        is omitted; structurally dead relations have gradient None."""
+        out = OrderedDict()
+        for k, v in self._rel_items(grad):
+            if isinstance(v, str):
+                continue
+            out[k] = v
+        for prefix, mod in (('snp_feat_mlp', self.snp_feat_mlp), ('go_feat_mlp', self.go_feat_mlp),
+                            ('gene_feat_mlp', self.gene_feat_mlp), ('lin', self.lin)):
+            for n, p in mod.named_parameters():
+                out[f'{prefix}.{n}'] = (p.grad if grad else p.detach())
+        return out
+
+    def state_dict(self, *args, destination=None, prefix='', keep_vars=False):
+        out = OrderedDict() if destination is None else destination
+        for k, v in self._rel_items():
+            out[prefix + k] = torch.nn.parameter.UninitializedParameter() if isinstance(v, str) else v.clone()
+        for name, mod in (('snp_feat_mlp', self.snp_feat_mlp), ('go_feat_mlp', self.go_feat_mlp),
+                          ('gene_feat_mlp', self.gene_feat_mlp), ('lin', self.lin)):
+            for n, p in mod.state_dict(keep_vars=keep_vars).items():
+                out[f'{prefix}{name}.{n}'] = p
         return out
 
     def load_state_dict(self, state_dict, strict=True, **kw):
-        sd = OrderedDict()
+        want = {}
+        for l in range(self.num_layers):
+            for r, et in enumerate(self.edge_types):
+                for f in REL_FIELDS:
+                    want[f'convs.{l}.convs.{edge_key(et)}.{f}'] = (l, r, f)
+        rest = OrderedDict()
+        seen = set()
         for k, v in state_dict.items():
-            if isinstance(v, torch.nn.parameter.UninitializedParameter):
-                continue                      # never-materialised lazy lin_dst of same-type relations
-            k = k.replace('<', '').replace('>', '').replace('___', '__')   # PyG >= 2.4 key style
-            sd[k] = v
-        return super().load_state_dict(sd, strict=strict, **kw)
+            k2 = k.replace('<', '').replace('>', '').replace('___', '__')     # PyG >= 2.4 key style
+            if k2 in want:
+                l, r, f = want[k2]
+                seen.add(k2)
+                if isinstance(v, torch.nn.parameter.UninitializedParameter):
+                    continue                  # never-materialised lazy lin_dst of same-type relations
+                which, i = self._slot[l][r]
+                (self.live_packs[l] if which == 'live' else self.dead_packs[l]).set(i, f, v)
+            else:
+                rest[k2] = v
+        missing = [k for k, (l, r, f) in want.items() if k not in seen and
+                   not (f == 'lin_dst.weight' and self.edge_types[r][0] == self.edge_types[r][2])]
+        unexpected = []
+        for name, mod in (('snp_feat_mlp', self.snp_feat_mlp), ('go_feat_mlp', self.go_feat_mlp),
+                          ('gene_feat_mlp', self.gene_feat_mlp), ('lin', self.lin)):
+            sub = OrderedDict((k[len(name) + 1:], v) for k, v in rest.items() if k.startswith(name + '.'))
+            res = mod.load_state_dict(sub, strict=False)
+            missing += [f'{name}.{k}' for k in res.missing_keys]
+            unexpected += [f'{name}.{k}' for k in res.unexpected_keys]
+        known = ('snp_feat_mlp.', 'go_feat_mlp.', 'gene_feat_mlp.', 'lin.')
+        unexpected += [k for k in rest if not k.startswith(known)]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f'load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}')
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)

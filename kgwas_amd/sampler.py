@@ -212,10 +212,10 @@ class SampledBatch:
 
     @property
     def x_dict(self) -> Dict[str, torch.Tensor]:
-        """Raw input features of the sampled nodes (the loader's x[n_id] slicing)."""
+        """Raw input features of the sampled nodes (the loader's x[n_id] slicing), sliced per node type on
+        first access: the fused model never asks for the 20 KB-per-row gene slice."""
         if self._x is None:
-            self._x = BatchDict(self, {t: gather_rows(self.dg.x[t], self.n_id(t)) for t in self.dg.schema.node_types
-                                       if t in self.dg.x})
+            self._x = LazyFeatureDict(self)
         return self._x
 
     @property
@@ -266,6 +266,41 @@ class BatchDict(dict):
     def __init__(self, batch: SampledBatch, *a, **k):
         super().__init__(*a, **k)
         self.kgw_batch = batch
+
+
+class LazyFeatureDict(BatchDict):
+    def __init__(self, batch: SampledBatch):
+        super().__init__(batch)
+        self._types = [t for t in batch.dg.schema.node_types if t in batch.dg.x]
+
+    def __missing__(self, t):
+        if t not in self._types:
+            raise KeyError(t)
+        b = self.kgw_batch
+        v = gather_rows(b.dg.x[t], b.n_id(t))
+        dict.__setitem__(self, t, v)
+        return v
+
+    def get(self, t, default=None):
+        return self[t] if t in self._types else default
+
+    def __contains__(self, t):
+        return t in self._types
+
+    def __iter__(self):
+        return iter(self._types)
+
+    def __len__(self):
+        return len(self._types)
+
+    def keys(self):
+        return list(self._types)
+
+    def values(self):
+        return [self[t] for t in self._types]
+
+    def items(self):
+        return [(t, self[t]) for t in self._types]
 
 
 class LazyEdgeIndexDict(BatchDict):

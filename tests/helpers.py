@@ -32,7 +32,17 @@ def batch_cpu(batch, dtype=torch.float64):
 
 
 def grads_by_name(model):
+    """Gradients under the reference's parameter names (the product keeps packed tensors internally)."""
+    if hasattr(model, 'named_reference_tensors'):
+        return {n: (g.detach().cpu() if g is not None else None)
+                for n, g in model.named_reference_tensors(grad=True).items()}
     return {n: (p.grad.detach().cpu() if p.grad is not None else None) for n, p in model.named_parameters()}
+
+
+def params_by_name(model):
+    if hasattr(model, 'named_reference_tensors'):
+        return {n: p.detach().cpu().double().clone() for n, p in model.named_reference_tensors().items()}
+    return {n: p.detach().cpu().double().clone() for n, p in model.named_parameters()}
 
 
 def assert_close(a, b, rtol, atol, what=''):

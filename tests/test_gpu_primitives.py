@@ -1,0 +1,27 @@
+"""-m gpu: the cross-lane reductions every aggregate kernel relies on (DPP butterflies +
+v_permlane16_swap / v_permlane32_swap), checked lane by lane."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_half_and_wave_allsum():
+    from kgwas_amd import _lib
+    L = _lib.lib()
+    x = torch.arange(64, dtype=torch.float32) ** 2 + 1.0          # asymmetric, exactly representable
+    xd = x.cuda()
+    oh, ow, st = torch.zeros(64).cuda(), torch.zeros(64).cuda(), torch.zeros(256).cuda()
+    _lib.check(L.kgw_debug_reduce(xd.data_ptr(), oh.data_ptr(), ow.data_ptr(), st.data_ptr(), _lib.stream_ptr()), 'dbg')
+    torch.cuda.synchronize()
+    xn = x.numpy().astype(np.float64)
+    st = st.cpu().numpy().reshape(4, 64)
+    for k, width in enumerate((2, 4, 8, 16)):
+        ref = xn.reshape(-1, width).sum(1).repeat(width)
+        assert np.array_equal(st[k], ref), f'DPP stage {k} (groups of {width}): {st[k][:16]} vs {ref[:16]}'
+    ref_half = np.concatenate([np.full(32, xn[:32].sum()), np.full(32, xn[32:].sum())])
+    assert np.array_equal(oh.cpu().numpy(), ref_half), (oh.cpu().numpy(), ref_half)
+    assert np.array_equal(ow.cpu().numpy(), np.full(64, xn.sum()))

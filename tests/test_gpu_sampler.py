@@ -63,13 +63,18 @@ def test_sampler_matches_pyg_semantics(small_kg, edge_case_graph, which, L):
         assert batch.n_edges_sampled == sum(len(v) for v in edges_o.values())
 
 
-def test_block_structures_are_consistent(small_kg):
+@pytest.mark.parametrize('which', ['small', 'edge'])
+def test_block_structures_are_consistent(small_kg, edge_case_graph, which):
     """Chunk list covers every local edge exactly once; multi-chunk segments are listed; the src-major
     structure of every layer is a permutation of the layer's live edges grouped by (source row, slot)."""
     from kgwas_amd._lib import KGW_CHUNK
-    data = small_kg.data
-    ids = np.random.default_rng(0).choice(data['SNP'].x.shape[0], size=64, replace=False)
-    batch = next(iter(_loader(data, ids, 64, L=2)))
+    if which == 'small':
+        data = small_kg.data
+        ids = np.random.default_rng(0).choice(data['SNP'].x.shape[0], size=512, replace=False)
+    else:   # seeds around the 1500-edge hub gene 0
+        data = edge_case_graph[0]
+        ids = np.random.default_rng(0).choice(1500, size=64, replace=False)
+    batch = next(iter(_loader(data, ids, len(ids), L=2)))
     dg, m, buf = batch.dg, batch.meta, batch.buf
     sc = dg.schema
     L = dg.num_layers

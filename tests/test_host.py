@@ -1,0 +1,131 @@
+"""CPU: host-side logic of the product and the C ABI surface (no kernel launches without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from kgwas_amd import _lib
+    lib = _lib.lib()
+    hdr = open(os.path.join(ROOT, 'include', 'kgwas_hip.h')).read()
+    declared = sorted(set(re.findall(r'\b(kgw_[a-z_0-9]+)\s*\(', hdr)))
+    assert len(declared) >= 9
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in kgwas_hip.h but not exported'
+    assert sorted(_lib.EXPORTS) == declared
+    assert lib.kgw_version() == 100
+    assert lib.kgw_status_string(-1) == b'null pointer argument'
+
+
+def test_abi_struct_sizes_and_argument_checks():
+    from kgwas_amd import _lib
+    lib = _lib.lib()
+    sizes = (C.c_int64 * 5)()
+    assert lib.kgw_struct_sizes(sizes, 5) == 0
+    assert list(sizes) == [C.sizeof(_lib.KgwGraph), C.sizeof(_lib.KgwBatchMeta), C.sizeof(_lib.KgwChunk),
+                           C.sizeof(_lib.KgwBatchBuf), C.sizeof(_lib.KgwLayerArgs)]
+    assert C.sizeof(_lib.KgwChunk) == 32
+    # argument errors are reported as negative status codes before any launch
+    assert lib.kgw_sample_batch(None, None, None, 0, 0, 0, None) == -1
+    assert lib.kgw_gat_aggregate_fwd(None, None) == -1
+    assert lib.kgw_gather_rows(None, None, 5, 4, None, None) == -1
+    g = _lib.KgwGraph()
+    b = _lib.KgwBatchBuf()
+    assert lib.kgw_sample_batch(C.byref(g), C.byref(b), None, 0, 0, 1, None) == -2     # n_types = 0 out of range
+
+
+def test_product_refuses_to_run_without_gpu():
+    """No CPU fallback: a CPU device is an error, not a slow path."""
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from kgwas_amd import _lib
+    from kgwas_amd.kgwas_data import KGWAS_Data
+    from kgwas_amd.sampler import NeighborLoader
+    d = KGWAS_Data.from_synthetic(scale=0.002, seed=3, feat_dims={'Gene': 40}, data_path='/tmp/kgwas_synth_tiny')
+    with pytest.raises(_lib.KgwasHipError):
+        NeighborLoader(d.data, [-1, -1], d.train_input_nodes, batch_size=8, device='cpu')
+
+
+def test_graph_schema_and_liveness(tiny_kg):
+    from kgwas_amd.graph import GraphSchema
+    sc = GraphSchema(tiny_kg.data.node_types, tiny_kg.data.edge_types)
+    assert sc.node_types[:2] == ['SNP', 'Gene'] and sc.NR == 29
+    live, types = sc.live_relations(2)
+    # layer 2: only relations into SNP; layer 1: relations into SNP or Gene
+    assert {sc.edge_types[r][2] for r in live[2]} == {'SNP'}
+    assert {sc.edge_types[r][2] for r in live[1]} == {'SNP', 'Gene'}
+    assert len(live[2]) == 6 and len(live[1]) == 23
+    assert types[2] == {sc.type_id['SNP']} and types[1] == {sc.type_id['SNP'], sc.type_id['Gene']}
+    # slots: position of a relation among the relations sharing its destination / source type
+    for t in range(sc.NT):
+        assert [int(sc.slot_dst[r]) for r in sc.rels_by_dst[t]] == list(range(int(sc.R_dst[t])))
+        assert [int(sc.slot_src[r]) for r in sc.rels_by_src[t]] == list(range(int(sc.R_src[t])))
+
+
+def test_build_csr_is_dst_major_src_sorted():
+    from kgwas_amd.graph import build_csr
+    ei = np.array([[5, 1, 3, 1, 0, 5], [2, 2, 0, 2, 1, 0]])
+    rp, col = build_csr(ei, 6, 3)
+    assert rp.tolist() == [0, 2, 3, 6]
+    assert col.tolist() == [3, 5, 0, 1, 1, 5]          # duplicates kept, sources ascending inside a row
+    with pytest.raises(ValueError):
+        build_csr(np.array([[7], [0]]), 6, 3)
+
+
+def test_synthetic_data_pipeline(small_kg):
+    d = small_kg
+    g = d.data
+    assert g.node_types == ['SNP', 'Gene', 'CellularComponent', 'BiologicalProcess', 'MolecularFunction']
+    assert len(g.edge_types) == 29 and ('Gene', 'rev_TSS', 'SNP') in g.edge_types
+    n = g['SNP'].x.shape[0]
+    assert g['SNP'].y.shape == (n,) and float(g['SNP'].y.min()) == -1.0       # -1 = unlabelled (kgwas_data.py:532)
+    tr, va, te = (np.asarray(x[1]) for x in (d.train_input_nodes, d.val_input_nodes, d.test_input_nodes))
+    assert len(set(tr) | set(va) | set(te)) == len(tr) + len(va) + len(te) == len(d.all_ids)
+    assert abs(np.mean(d.ldsc_weight) - 1.0) < 1e-9
+    assert d.rs_id_to_ldsc_weight[d.lr_uni.ID.values[0]] == d.ldsc_weight[0]
+    assert d.idx2id['SNP'][5] == 'rs5' and d.id2idx['SNP']['rs5'] == 5
+    assert (d.snp_init_dim_size, d.gene_init_dim_size, d.go_init_dim_size) == (20, 96, 128)
+
+
+def test_model_state_dict_uses_reference_keys(tiny_kg):
+    from kgwas_amd.model import HeteroGNN
+    m = HeteroGNN(tiny_kg.data, 128, 1, 2, 'GAT', 'sum', 20, 40, 128, 1)
+    sd = m.state_dict()
+    assert sd['convs.0.convs.SNP__ABC__Gene.lin_src.weight'].shape == (128, 128)
+    assert sd['convs.1.convs.Gene__rev_ABC__SNP.att_src'].shape == (1, 1, 128)
+    assert sd['convs.0.convs.SNP__ABC__Gene.bias'].shape == (128,)
+    assert sd['snp_feat_mlp.FC_hidden.weight'].shape == (128, 20) and sd['lin.weight'].shape == (1, 128)
+    # same-type relations: lin_dst is a never-materialised lazy parameter in the reference
+    assert isinstance(sd['convs.0.convs.Gene__Gene-Reaction-Gene__Gene.lin_dst.weight'],
+                      torch.nn.parameter.UninitializedParameter)
+    m2 = HeteroGNN(tiny_kg.data, 128, 1, 2, 'GAT', 'sum', 20, 40, 128, 1)
+    m2.load_state_dict(sd)
+    a, b = m.named_reference_tensors(), m2.named_reference_tensors()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    # PyG >= 2.4 key style loads too
+    m2.load_state_dict({k.replace('SNP__ABC__Gene', '<SNP___ABC___Gene>'): v for k, v in sd.items()})
+    with pytest.raises(RuntimeError):
+        m2.load_state_dict({k: v for k, v in sd.items() if 'lin.bias' not in k})
+    # unsupported reference options fail loudly instead of silently doing something else
+    for kw in (dict(gnn_backbone='SAGE'), dict(gnn_aggr='mean'), dict(gat_num_head=2)):
+        args = dict(gnn_backbone='GAT', gnn_aggr='sum', gat_num_head=1); args.update(kw)
+        with pytest.raises(NotImplementedError):
+            HeteroGNN(tiny_kg.data, 128, 1, 2, args['gnn_backbone'], args['gnn_aggr'], 20, 40, 128, args['gat_num_head'])
+
+
+def test_shard_batches_partitions_every_batch():
+    from kgwas_amd.dist import shard_batches
+    ids = np.arange(1000)
+    parts = [shard_batches(ids, 64, r, 4) for r in range(4)]
+    assert all(len(p) == 15 * 16 for p in parts)
+    for b in range(15):
+        got = np.concatenate([p[b * 16:(b + 1) * 16] for p in parts])
+        assert np.array_equal(np.sort(got), ids[b * 64:(b + 1) * 64])
+    with pytest.raises(ValueError):
+        shard_batches(ids, 10, 0, 4)
