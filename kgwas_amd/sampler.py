@@ -156,6 +156,16 @@ class BatchBuffers:
         self.ready = torch.cuda.Event()      # sampling finished
         self.released: Optional[torch.cuda.Event] = None   # consumer finished with the previous contents
 
+    def tensors(self):
+        return [self.g2l, self.n_id, self.seg_deg, self.seg_nch, self.seg_ptr, self.seg_chptr, self.col_local,
+                self.chunks, self.multi, self.scan_tmp, self.meta] + self.t_cnt + self.t_ptr + self.t_edge + self.t_zrow
+
+    def record_stream(self, stream):
+        """The buffers were allocated on the consumer's stream but are written on the sampler's side stream:
+        tell the caching allocator, so a buffer freed while sampling is still in flight is not handed out."""
+        for t in self.tensors():
+            t.record_stream(stream)
+
     def read_meta(self) -> KgwBatchMeta:
         m = KgwBatchMeta()
         C.memmove(C.addressof(m), self.meta_host.data_ptr(), C.sizeof(KgwBatchMeta))
@@ -408,6 +418,11 @@ class NeighborLoader:
         if self._bufs is None:
             self._bufs = [BatchBuffers(self.dg) for _ in range(2 if self.prefetch else 1)]
             self._stream = torch.cuda.Stream(device=self.device) if self.prefetch else None
+            if self._stream is not None:
+                # freshly allocated blocks may still be in use by earlier work of the allocating stream
+                self._stream.wait_stream(torch.cuda.current_stream())
+                for b in self._bufs:
+                    b.record_stream(self._stream)
 
     def _launch(self, i: int, buf: BatchBuffers):
         seeds = self.ids[i * self.batch_size:(i + 1) * self.batch_size]
