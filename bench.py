@@ -121,8 +121,10 @@ def main():
     from kgwas_amd.sampler import NeighborLoader
 
     t0 = time.time()
-    data = KGWAS_Data.from_synthetic(scale=args.scale, seed=1, mode='fast', gwas_kind='causal',
-                                     data_path=f'/tmp/kgwas_bench_{rank}')
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):        # stdout carries exactly one JSON line
+        data = KGWAS_Data.from_synthetic(scale=args.scale, seed=1, mode='fast', gwas_kind='causal',
+                                         data_path=f'/tmp/kgwas_bench_{rank}')
     run = KGWAS(data, device=dev, seed=1)
     run.initialize_model()
     if world > 1:

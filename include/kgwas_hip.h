@@ -171,6 +171,16 @@ int kgw_gather_rows(const float* src, const int32_t* ids, int64_t n_rows, int32_
  * kgwas/conv.py:192-196; kgwas/utils.py:446-461).                                             */
 int kgw_edge_alpha(const KgwLayerArgs* args, float* alpha_out, kgw_stream_t stream);
 
+/* C[M,N] = A[rows,M]^T * B[rows,N] (row-major, leading dimensions lda/ldb/ldc), optionally
+ * colsum_a[M] = column sums of A.  Split-K over the rows on fp32 MFMA, deterministic.  Replaces the
+ * weight / bias gradient GEMMs autograd runs for the Linear layers of the path
+ * (kgwas/model.py:13-21,50; kgwas/conv.py:82-89,150-151) whose reduction dimension is the number of
+ * sampled nodes.  workspace: kgw_tn_gemm_workspace_floats(rows, M, N) floats.                    */
+int64_t kgw_tn_gemm_workspace_floats(int64_t rows, int32_t M, int32_t N);
+int kgw_tn_gemm(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
+                int64_t rows, float* C, int64_t ldc, float* colsum_a, float* workspace,
+                int64_t workspace_floats, kgw_stream_t stream);
+
 /* Self-test of the cross-lane reductions used by the aggregate kernels (one wavefront):
  * out_half[l] = sum over l's 32-lane half, out_wave[l] = sum over the wavefront,
  * out_steps[4][64] = the four intra-row DPP butterfly stages.                                  */

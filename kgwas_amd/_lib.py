@@ -93,7 +93,7 @@ class KgwLayerArgs(C.Structure):
 
 EXPORTS = ['kgw_version', 'kgw_status_string', 'kgw_struct_sizes', 'kgw_sample_batch',
            'kgw_gat_aggregate_fwd', 'kgw_gat_aggregate_bwd_dst', 'kgw_gat_aggregate_bwd_src',
-           'kgw_gather_rows', 'kgw_edge_alpha', 'kgw_debug_reduce']
+           'kgw_gather_rows', 'kgw_edge_alpha', 'kgw_debug_reduce', 'kgw_tn_gemm', 'kgw_tn_gemm_workspace_floats']
 
 _lib = None
 
@@ -129,11 +129,10 @@ def lib():
     L.kgw_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     L.kgw_edge_alpha.argtypes = [C.POINTER(KgwLayerArgs), C.c_void_p, C.c_void_p]
     L.kgw_debug_reduce.argtypes = [C.c_void_p] * 5
-    if hasattr(L, 'kgw_linear_fwd'):
-        L.kgw_linear_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
-                                     C.c_int32, C.c_int32, C.c_void_p]
-        L.kgw_linear_bwd_w.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
-                                       C.c_void_p, C.c_void_p]
+    L.kgw_tn_gemm_workspace_floats.restype = C.c_int64
+    L.kgw_tn_gemm_workspace_floats.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+    L.kgw_tn_gemm.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
+                              C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     _lib = L
     return L
 

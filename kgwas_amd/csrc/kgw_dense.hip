@@ -1,0 +1,291 @@
+// kgw_dense.hip -- MFMA (fp32-in / fp32-accumulate, exact) kernels for the dense side of the KGWAS path.
+//
+// kgw_tn_gemm:  C[M,N] = A[rows,M]^T * B[rows,N]   (+ optional column sums of A)
+// for TALL inputs (rows ~ 1e5: every sampled SNP / gene) and small M, N -- the weight gradients of the
+// feature MLPs (kgwas/model.py:13-21), of the per-relation lin_src maps (kgwas/conv.py:138,142) and the
+// d u_r / d v_r attention-vector gradients.  A library GEMM runs these shapes on a few dozen workgroups
+// (K = rows is its reduction dimension: 290-340 us per product on MI355X); here the reduction is split over
+// every SIMD of the chip.
+//
+// Mapping (gfx950): v_mfma_f32_32x32x2_f32.  For a TN product the MFMA operand layout IS the memory layout:
+// lane l supplies A[row k = l>>5][column i = l&31] -- a wave-instruction reads two contiguous 128-float rows.
+// Columns are interleaved (tile t owns columns MT*i + t) so one 16-byte load per lane feeds all MT tiles.
+// One wavefront owns the whole (32 MT) x (32 NT) accumulator (up to 256 accumulator VGPRs, one wave per
+// SIMD) and streams its slice of rows: 2 KiB of loads per 16 MFMAs (1024 cycles) -- HBM and the matrix pipe
+// are balanced at ~5 TB/s.  Waves of a block are summed through LDS, blocks through a partial buffer and a
+// second kernel in a fixed order: no atomics, deterministic.
+#include "kgw_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int V> struct VecLoad;
+template <> struct VecLoad<1> {
+    static __device__ __forceinline__ void ld(const float* p, bool ok, float (&o)[1]) { float v = *p; o[0] = ok ? v : 0.f; }
+};
+template <> struct VecLoad<2> {
+    static __device__ __forceinline__ void ld(const float* p, bool ok, float (&o)[2]) {
+        float2 v = *(const float2*)p; o[0] = ok ? v.x : 0.f; o[1] = ok ? v.y : 0.f; }
+};
+template <> struct VecLoad<4> {
+    static __device__ __forceinline__ void ld(const float* p, bool ok, float (&o)[4]) {
+        float4 v = *(const float4*)p;
+        o[0] = ok ? v.x : 0.f; o[1] = ok ? v.y : 0.f; o[2] = ok ? v.z : 0.f; o[3] = ok ? v.w : 0.f; }
+};
+
+constexpr int TN_U = 4;   // row pairs per pipeline stage
+
+template <int MT, int NT>
+struct Stage { float a[TN_U][MT]; float b[TN_U][NT]; };
+
+// Unmasked stage load: TN_U row pairs starting at the lane's row pointer (pa/pb already include row k and
+// the lane's column).  Out-of-range COLUMNS are clamped to column 0 by the caller: they feed accumulator
+// rows / columns that are never stored, so they need no masking.
+template <int MT, int NT>
+__device__ __forceinline__ void tn_load(Stage<MT, NT>& s, const float* pa, int64_t lda2, const float* pb, int64_t ldb2) {
+#pragma unroll
+    for (int u = 0; u < TN_U; ++u) {
+        VecLoad<MT>::ld(pa + u * lda2, true, s.a[u]);
+        VecLoad<NT>::ld(pb + u * ldb2, true, s.b[u]);
+    }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void tn_mma(const Stage<MT, NT>& s, f32x16 (&acc)[MT][NT], float (&sa)[MT]) {
+#pragma unroll
+    for (int u = 0; u < TN_U; ++u) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            sa[a] += s.a[u][a];
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(s.a[u][a], s.b[u][b], acc[a][b], 0, 0, 0);
+        }
+    }
+}
+
+// ws layout per block: [MT][NT][16][64] floats (fragment order) ; colsum ws per block: [32*MT]
+template <int MT, int NT>
+__global__ void __launch_bounds__(256, 1) k_tn_gemm(const float* __restrict__ A, int64_t lda, int M,
+                                                    const float* __restrict__ B, int64_t ldb, int N, int64_t rows,
+                                                    int64_t rows_per_wave, float* __restrict__ ws,
+                                                    float* __restrict__ ws_colsum) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = lane >> 5, i = lane & 31;
+    const int m0 = blockIdx.y * 32 * MT, n0 = blockIdx.z * 32 * NT;
+    const int ca = m0 + MT * i, cb = n0 + NT * i;
+    const int cas = ca < M ? ca : 0, cbs = cb < N ? cb : 0;
+    const int64_t wg = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t r0 = wg * rows_per_wave;
+    const int64_t r1 = min(rows, r0 + rows_per_wave);
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    float sa[MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) sa[a] = 0.f;
+
+    if (r0 < r1) {
+        constexpr int STEP = 2 * TN_U;                      // rows per stage
+        const int64_t nfull = (r1 - r0) / STEP;             // stages made of valid rows only
+        const float* pa = A + (r0 + k) * lda + cas;
+        const float* pb = B + (r0 + k) * ldb + cbs;
+        const int64_t lda2 = 2 * lda, ldb2 = 2 * ldb;
+        if (nfull > 0) {
+            Stage<MT, NT> cur, nxt;
+            tn_load<MT, NT>(cur, pa, lda2, pb, ldb2);
+            for (int64_t it = 1; it < nfull; ++it) {
+                pa += STEP * lda; pb += STEP * ldb;
+                tn_load<MT, NT>(nxt, pa, lda2, pb, ldb2);   // in flight while the 16*TN_U MFMAs below run
+                tn_mma<MT, NT>(cur, acc, sa);
+                cur = nxt;
+            }
+            tn_mma<MT, NT>(cur, acc, sa);
+            pa += STEP * lda; pb += STEP * ldb;
+        }
+        // tail: < STEP rows, masked per row (loads clamped to the last valid row)
+        const int64_t rt = r0 + nfull * STEP;
+        if (rt < r1) {
+            Stage<MT, NT> t;
+#pragma unroll
+            for (int u = 0; u < TN_U; ++u) {
+                const int64_t row = rt + 2 * u + k;
+                const bool ok = row < r1;
+                const int64_t rc = ok ? row : (r1 - 1);
+                VecLoad<MT>::ld(A + rc * lda + cas, ok, t.a[u]);
+                VecLoad<NT>::ld(B + rc * ldb + cbs, ok, t.b[u]);
+            }
+            tn_mma<MT, NT>(t, acc, sa);
+        }
+    }
+
+    // ---- reduce the 4 waves of the block through LDS, fixed order (w0+w2) + (w1+w3) --------------------
+    // Accumulators live in AGPRs: they are only ever READ here (16 at a time), never written back -- a
+    // read-modify-write of all 256 would need 256 arch VGPRs at once and spill to scratch.
+    constexpr int FRAG = MT * NT * 16 * 64;              // floats per wave
+    float* reg0 = lds;
+    float* reg1 = lds + FRAG;
+    float* cs = lds + 2 * FRAG;                           // [4][32*MT] column sums
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+        const float t = sa[a] + kgw_xhalf(sa[a]);        // rows k = 0 and k = 1 of the pairs
+        if (k == 0) cs[wave * 32 * MT + MT * i + a] = t;
+    }
+    if (wave >= 2) {
+        float* dst = (wave == 2) ? reg0 : reg1;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dst[((a * NT + b) * 16 + e) * 64 + lane] = acc[a][b][e];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+    __syncthreads();
+    if (wave < 2) {
+        float* dst = (wave == 0) ? reg0 : reg1;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int idx = ((a * NT + b) * 16 + e) * 64 + lane;
+                    dst[idx] = acc[a][b][e] + dst[idx];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+    __syncthreads();
+    const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    float* out = ws + blk * FRAG;
+    for (int f = threadIdx.x * 4; f < FRAG; f += 256 * 4) {
+        const float4 x = *(const float4*)(reg0 + f), y = *(const float4*)(reg1 + f);
+        *(float4*)(out + f) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    }
+    if (ws_colsum && blockIdx.z == 0 && threadIdx.x < 32 * MT) {
+        const int c = threadIdx.x;
+        const float t = (cs[c] + cs[2 * 32 * MT + c]) + (cs[32 * MT + c] + cs[3 * 32 * MT + c]);
+        ws_colsum[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 * MT + c] = t;
+    }
+}
+
+// C[m][n] = sum over row-blocks of the partial fragments (fixed order); also the column sums.
+// Block = 64 fragment elements x 4 groups of row-blocks; every thread keeps 8 loads in flight.
+template <int MT, int NT>
+__global__ void __launch_bounds__(256) k_tn_reduce(const float* __restrict__ ws, const float* __restrict__ ws_colsum,
+                                                   int nblk, int gy, int M, int N, float* __restrict__ C, int64_t ldc,
+                                                   float* __restrict__ colsum) {
+    constexpr int FRAG = MT * NT * 16 * 64;
+    __shared__ float sm[256];
+    const int by = blockIdx.y, bz = blockIdx.z;
+    const int m0 = by * 32 * MT, n0 = bz * 32 * NT;
+    const int fl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int f = blockIdx.x * 64 + fl;
+    {
+        const float* p = ws + ((int64_t)bz * gy + by) * nblk * FRAG + f;
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int b = g;
+        for (; b + 28 < nblk; b += 32) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s8[q] += p[(int64_t)(b + 4 * q) * FRAG];
+        }
+        for (int q = 0; b < nblk; b += 4, ++q) s8[q & 7] += p[(int64_t)b * FRAG];
+        sm[threadIdx.x] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    }
+    __syncthreads();
+    if (g == 0) {
+        const float s = (sm[fl] + sm[64 + fl]) + (sm[128 + fl] + sm[192 + fl]);
+        const int lane = f & 63, e = (f >> 6) & 15, tb = (f >> 10) % NT, ta = (f >> 10) / NT;
+        const int ti = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);     // row of the 32x32 tile
+        const int tj = lane & 31;                                     // column of the tile
+        const int m = m0 + MT * ti + ta, n = n0 + NT * tj + tb;
+        if (m < M && n < N) C[(int64_t)m * ldc + n] = s;
+    }
+    if (colsum && bz == 0 && blockIdx.x == 0) {
+        // 32*MT columns x (256 / (32*MT)) groups of row-blocks, 4 loads in flight per thread, fixed order
+        constexpr int NC = 32 * MT, NG = 256 / NC;
+        __syncthreads();
+        const int c = threadIdx.x % NC, gq = threadIdx.x / NC;
+        const float* p = ws_colsum + (int64_t)by * nblk * NC + c;
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        int b = gq;
+        for (; b + 3 * NG < nblk; b += 4 * NG) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s4[q] += p[(int64_t)(b + q * NG) * NC];
+        }
+        for (int q = 0; b < nblk; b += NG, ++q) s4[q & 3] += p[(int64_t)b * NC];
+        sm[threadIdx.x] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        __syncthreads();
+        if (gq == 0) {
+            float t = 0.f;
+            for (int q = 0; q < NG; ++q) t += sm[q * NC + c];
+            if (m0 + c < M) colsum[m0 + c] = t;
+        }
+    }
+}
+
+template <int MT, int NT>
+int launch_tn(const float* A, int64_t lda, int M, const float* B, int64_t ldb, int N, int64_t rows, float* C,
+              int64_t ldc, float* colsum, float* ws, int64_t ws_floats, hipStream_t st) {
+    constexpr int FRAG = MT * NT * 16 * 64;
+    const int gy = (M + 32 * MT - 1) / (32 * MT), gz = (N + 32 * NT - 1) / (32 * NT);
+    // one block per CU at most; at least 64 rows per wavefront
+    int64_t nblk = (rows + 4 * 64 - 1) / (4 * 64);
+    int64_t cap = 256 / ((int64_t)gy * gz);
+    if (cap < 1) cap = 1;
+    if (nblk > cap) nblk = cap;
+    if (nblk < 1) nblk = 1;
+    int64_t rpw = (rows + nblk * 4 - 1) / (nblk * 4);
+    rpw = (rpw + 1) & ~(int64_t)1;
+    const int64_t need = nblk * gy * gz * FRAG + nblk * gy * 32 * MT;
+    if (need > ws_floats) return KGW_E_RANGE;
+    float* ws_cs = colsum ? ws + nblk * gy * gz * FRAG : nullptr;
+    const size_t lds_bytes = (size_t)(2 * FRAG + 4 * 32 * MT) * sizeof(float);
+    auto kern = k_tn_gemm<MT, NT>;
+    static bool attr_set = false;     // idempotent; a benign race at worst repeats the call
+    if (lds_bytes > 64 * 1024 && !attr_set) {
+        KGW_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    kern<<<dim3((unsigned)nblk, gy, gz), 256, lds_bytes, st>>>(A, lda, M, B, ldb, N, rows, rpw, ws, ws_cs);
+    KGW_LAUNCH_CHECK();
+    k_tn_reduce<MT, NT><<<dim3(FRAG / 64, gy, gz), 256, 0, st>>>(ws, ws_cs, (int)nblk, gy, M, N, C, ldc, colsum);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" int64_t kgw_tn_gemm_workspace_floats(int64_t rows, int M, int N) {
+    // upper bound over every tiling the dispatcher may choose
+    const int64_t gy1 = 4 * ((M + 127) / 128), gz1 = 4 * ((N + 127) / 128);   // tiles, rounded to the widest tiling
+    int64_t nblk = (rows + 255) / 256;
+    if (nblk > 256) nblk = 256;
+    if (nblk < 1) nblk = 1;
+    return nblk * gy1 * gz1 * 1024 + nblk * gy1 * 32 + 4096;   // 1024 floats per 32x32 tile per row-block
+}
+
+extern "C" int kgw_tn_gemm(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
+                           int64_t rows, float* C, int64_t ldc, float* colsum_a, float* workspace,
+                           int64_t workspace_floats, kgw_stream_t stream_) {
+    if (!A || !B || !C || !workspace) return KGW_E_NULL;
+    if (M <= 0 || N <= 0 || rows <= 0 || lda < M || ldb < N || ldc < N) return KGW_E_RANGE;
+    hipStream_t st = (hipStream_t)stream_;
+    const bool a4 = (M % 4 == 0) && (lda % 4 == 0) && aligned16(A) && M >= 128;
+    const bool b4 = (N % 4 == 0) && (ldb % 4 == 0) && aligned16(B) && N >= 128;
+    if (a4 && b4) return launch_tn<4, 4>(A, lda, M, B, ldb, N, rows, C, ldc, colsum_a, workspace, workspace_floats, st);
+    if (a4)       return launch_tn<4, 1>(A, lda, M, B, ldb, N, rows, C, ldc, colsum_a, workspace, workspace_floats, st);
+    if (b4)       return launch_tn<1, 4>(A, lda, M, B, ldb, N, rows, C, ldc, colsum_a, workspace, workspace_floats, st);
+    return launch_tn<1, 1>(A, lda, M, B, ldb, N, rows, C, ldc, colsum_a, workspace, workspace_floats, st);
+}

@@ -64,11 +64,16 @@ class SimpleMLP(nn.Module):
         self.FC_output = nn.Linear(hidden_dim, output_dim)
         self.ReLU = nn.ReLU()
 
+    def first(self, x):
+        """relu(FC_hidden(x)) -- one autograd node; weight gradient on the split-K MFMA kernel."""
+        return ops.linear_relu(x, self.FC_hidden.weight, self.FC_hidden.bias)
+
     def tail(self, h1):
-        return self.FC_output(self.ReLU(self.FC_hidden2(h1)))
+        """FC_output(relu(FC_hidden2(h1))) -- one autograd node."""
+        return ops.mlp_tail(h1, self.FC_hidden2.weight, self.FC_hidden2.bias, self.FC_output.weight, self.FC_output.bias)
 
     def forward(self, x):
-        return self.tail(self.ReLU(self.FC_hidden(x)))
+        return self.tail(self.first(x))
 
 
 class RelationPack(nn.Module):
@@ -208,9 +213,23 @@ class HeteroGNN(nn.Module):
         if lazy and not dg.full_graph:
             X = dg.x[t]
             if X.shape[1] >= 512 and 2 * n > X.shape[0]:
-                h1_all = mlp.ReLU(mlp.FC_hidden(X))
-                return mlp.tail(h1_all.index_select(0, batch.n_id(t)))
+                return mlp.tail(mlp.first(X).index_select(0, batch.n_id(t)))
         return mlp(x_dict[t])
+
+    def _embed_all(self, batch: SampledBatch, x_dict):
+        """All feature MLPs (model.py:56-60).  The three GO types share ``go_feat_mlp`` (model.py:58-60): their
+        rows go through it as ONE matrix."""
+        h = {}
+        go = [t for t in self.node_types if t in GO_TYPES and t in x_dict and batch.n_nodes.get(t, x_dict[t].shape[0]) > 0]
+        if len(go) > 1:
+            xs = [x_dict[t] for t in go]
+            out = self.go_feat_mlp(torch.cat(xs, 0))
+            for t, piece in zip(go, torch.split(out, [x.shape[0] for x in xs], 0)):
+                h[t] = piece
+        for t in self.node_types:
+            if t in x_dict and t not in h:
+                h[t] = self._embed(batch, x_dict, t)
+        return h
 
     def _fused_layers(self, batch: SampledBatch, h: Dict[str, torch.Tensor], want_attention=False):
         sc = self.schema
@@ -265,7 +284,7 @@ class HeteroGNN(nn.Module):
         batch: Optional[SampledBatch] = getattr(x_dict, 'kgw_batch', None) or getattr(edge_index_dict, 'kgw_batch', None)
         if batch is None:
             batch = self._block_from_coo(x_dict, edge_index_dict)
-        h = {t: self._embed(batch, x_dict, t) for t in self.node_types if t in x_dict}
+        h = self._embed_all(batch, x_dict)
         h, attn = self._fused_layers(batch, h, want_attention=return_attention_weights)
         snp = h['SNP']
         out = self.lin(snp)[:batch_size]

@@ -140,7 +140,8 @@ class _GatAggregate(torch.autograd.Function):
                 continue
             tb, sb = int(m.t_base[layer - 1][t]), int(m.src_base[layer - 1][t])
             blk = da_src[tb:tb + ns * Rs].view(ns, Rs)
-            dU[sc.rels_by_src[t]] = blk.t() @ H[sb:sb + ns]
+            Hs = H[sb:sb + ns]
+            dU[sc.rels_by_src[t]] = tn_gemm(blk, Hs) if ns >= _TN_MIN_ROWS else blk.t() @ Hs
         return dH[:n_src], da_dst[:z_rows], dU, None, None, None, None
 
 
@@ -158,3 +159,92 @@ def edge_alpha(batch, layer: int, stat: torch.Tensor, e_edge: torch.Tensor, temp
     a.stat, a.e_edge = _p(stat), _p(e_edge)
     _lib.check(_lib.lib().kgw_edge_alpha(C.byref(a), C.c_void_p(out.data_ptr()), _lib.stream_ptr()), 'kgw_edge_alpha')
     return out[:n_edges]
+
+
+# ------------------------------------------------------------------------------------------------------
+# dense helpers on the split-K MFMA kernel (kgw_tn_gemm)
+# ------------------------------------------------------------------------------------------------------
+_TN_MIN_ROWS = 4096       # below this a library GEMM is fine
+
+
+def tn_gemm(A: torch.Tensor, B: torch.Tensor, colsum: bool = False):
+    """C = A^T @ B for tall row-major A [rows, M], B [rows, N] (fp32, inner stride 1); optionally also the
+    column sums of A.  Deterministic split-K on fp32 MFMA."""
+    assert A.dim() == 2 and B.dim() == 2 and A.shape[0] == B.shape[0]
+    assert A.dtype == torch.float32 and B.dtype == torch.float32
+    if A.stride(1) != 1:
+        A = A.contiguous()
+    if B.stride(1) != 1:
+        B = B.contiguous()
+    rows, M = A.shape
+    N = B.shape[1]
+    dev = A.device
+    C_ = torch.empty(M, N, device=dev)
+    cs = torch.empty(M, device=dev) if colsum else None
+    if rows == 0:
+        C_.zero_()
+        if cs is not None:
+            cs.zero_()
+        return (C_, cs) if colsum else C_
+    L = _lib.lib()
+    nws = int(L.kgw_tn_gemm_workspace_floats(rows, M, N))
+    ws = torch.empty(nws, device=dev)
+    _lib.check(L.kgw_tn_gemm(_p(A), A.stride(0), M, _p(B), B.stride(0), N, rows, _p(C_), N, _p(cs), _p(ws), nws,
+                             _lib.stream_ptr()), 'kgw_tn_gemm')
+    return (C_, cs) if colsum else C_
+
+
+class _MLPTail(torch.autograd.Function):
+    """y = FC_output(relu(FC_hidden2(h1)))  (kgwas/model.py:19-21) as ONE autograd node: library GEMMs for the
+    forward / dX products, the split-K MFMA kernel for the tall weight-gradient products and bias sums."""
+
+    @staticmethod
+    def forward(ctx, h1, W2, b2, W3, b3):
+        h2 = torch.relu_(torch.addmm(b2, h1, W2.t()))
+        y = torch.addmm(b3, h2, W3.t())
+        ctx.save_for_backward(h1, h2, W2, W3)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h1, h2, W2, W3 = ctx.saved_tensors
+        dy = dy.contiguous()
+        dW3, db3 = linear_weight_grad(dy, h2)
+        dh2 = torch.mm(dy, W3).mul_(h2 > 0)
+        dW2, db2 = linear_weight_grad(dh2, h1)
+        dh1 = torch.mm(dh2, W2) if ctx.needs_input_grad[0] else None
+        return dh1, dW2, db2, dW3, db3
+
+
+class _LinearReLU(torch.autograd.Function):
+    """h = relu(x W^T + b) with the weight gradient on the split-K kernel; x gets a gradient only if asked."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        h = torch.relu_(torch.addmm(b, x, W.t()))
+        ctx.save_for_backward(x, h, W)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, h, W = ctx.saved_tensors
+        dz = dh * (h > 0)
+        dW, db = linear_weight_grad(dz, x)
+        dx = torch.mm(dz, W) if ctx.needs_input_grad[0] else None
+        return dx, dW, db
+
+
+def linear_weight_grad(dY: torch.Tensor, X: torch.Tensor):
+    """(dW [out,in], db [out]) of Y = X W^T + b given dY [rows,out], X [rows,in]."""
+    rows, K = X.shape
+    if rows >= _TN_MIN_ROWS and K <= 1024:
+        return tn_gemm(dY, X, colsum=True)
+    return dY.t().mm(X), dY.sum(0)
+
+
+def mlp_tail(h1, W2, b2, W3, b3):
+    return _MLPTail.apply(h1, W2, b2, W3, b3)
+
+
+def linear_relu(x, W, b):
+    return _LinearReLU.apply(x, W, b)

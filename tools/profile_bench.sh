@@ -1,0 +1,23 @@
+#!/bin/bash
+# rocprofv3 kernel trace of the default bench on a GPU box; prints the per-step kernel-time summary.
+# usage (from the repo root, via gpurun):  bash tools/profile_bench.sh <tag> [bench args]
+tag=${1:-run}; shift
+out=gpurun_out/prof_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-.}
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o r -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" > $out/bench.json 2> $out/err.log
+python - "$out" <<'PY'
+import csv, sys, json
+out = sys.argv[1]
+rows = list(csv.DictReader(open(out + '/r_kernel_stats.csv')))
+tot = sum(float(r['TotalDurationNs']) for r in rows)
+ncalls = sum(int(r['Calls']) for r in rows)
+print('kernel time total %.1f ms, %d launches  (23 steps + setup) -> %.2f ms/step, %d launches/step' % (tot / 1e6, ncalls, tot / 1e6 / 23, ncalls // 23))
+for r in rows[:22]:
+    print('%-64s calls %5s tot %7.2f ms avg %8.1f us %5.1f%%' % (r['Name'].replace('(anonymous namespace)::', '')[:64], r['Calls'], float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3, float(r['Percentage'])))
+try:
+    d = json.loads(open(out + '/bench.json').read().strip().splitlines()[-1])
+    print('bench under profiler: ms/step %.2f value %.3g roofline frac %.3f' % (d['ms_per_step'], d['value'], d['roofline']['frac']))
+except Exception as e:
+    print('no bench json', e)
+PY
