@@ -181,6 +181,14 @@ int kgw_tn_gemm(const float* A, int64_t lda, int32_t M, const float* B, int64_t 
                 int64_t rows, float* C, int64_t ldc, float* colsum_a, float* workspace,
                 int64_t workspace_floats, kgw_stream_t stream);
 
+/* Y[rows,N] = act(X[rows,K] * Wop + bias) * (mask > 0): the Linear layers of the path on fp32 MFMA.
+ * w_is_kn = 0: W is [N,K] (nn.Linear / PyG Linear forward, kgwas/model.py:13-21,50; kgwas/conv.py:138,142);
+ * w_is_kn = 1: W is [K,N] (the dX = dY * W product of their backward).  bias, mask may be NULL; relu 0/1.
+ * K, ldx, ldw (and N when w_is_kn) must be multiples of 4, X and W 16-byte aligned, else KGW_E_UNSUPPORTED. */
+int kgw_linear(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias,
+               const float* mask, int64_t ldm, float* Y, int64_t ldy, int64_t rows, int32_t K, int32_t N,
+               int32_t relu, int32_t w_is_kn, kgw_stream_t stream);
+
 /* Self-test of the cross-lane reductions used by the aggregate kernels (one wavefront):
  * out_half[l] = sum over l's 32-lane half, out_wave[l] = sum over the wavefront,
  * out_steps[4][64] = the four intra-row DPP butterfly stages.                                  */

@@ -289,3 +289,141 @@ extern "C" int kgw_tn_gemm(const float* A, int64_t lda, int32_t M, const float* 
     if (b4)       return launch_tn<1, 4>(A, lda, M, B, ldb, N, rows, C, ldc, colsum_a, workspace, workspace_floats, st);
     return launch_tn<1, 1>(A, lda, M, B, ldb, N, rows, C, ldc, colsum_a, workspace, workspace_floats, st);
 }
+
+// ======================================================================================================
+// kgw_linear: Y[rows,N] = act( X[rows,K] * Wop + bias ) (* relu-mask), fp32 MFMA, LDS-tiled.
+//   Wop = W^T with W [N,K] row-major (nn.Linear forward, kgwas/model.py:13-21; conv.py:138,142), or
+//   Wop = W   with W [K,N] row-major (the dX = dY * W product of the same layers' backward).
+// Block = 128 rows x 128 cols, BK = 32, 4 wavefronts (32 rows x 128 cols each = four 32x32x2 MFMA tiles);
+// the next K-tile is fetched into registers while the current one is consumed from LDS (row stride 33
+// floats: the 32 lanes of an MFMA operand read hit 32 different banks).
+// ======================================================================================================
+namespace {
+
+constexpr int LBM = 128, LBN = 128, LBK = 32, LPAD = 33;
+
+struct LinArgs {
+    const float* X; int64_t ldx;
+    const float* W; int64_t ldw;
+    const float* bias;      // [N] or null
+    const float* mask;      // [rows, ldm]: output multiplied by (mask > 0), or null
+    int64_t ldm;
+    float* Y; int64_t ldy;
+    int64_t rows; int K, N;
+    int relu, w_kn;
+};
+
+__global__ void __launch_bounds__(256, 2) k_linear(LinArgs a) {
+    __shared__ float Xs[LBM * LPAD];
+    __shared__ float Ws[LBN * LPAD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * LBM;
+    const int n0 = blockIdx.y * LBN;
+    const int li = lane & 31, lk = lane >> 5;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    float4 xr[4], wr[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = tid + 256 * j;
+            {   // X tile: 128 rows x 32 k, float4 along k
+                const int row = idx >> 3, kq = (idx & 7) * 4;
+                const int64_t r = r0 + row;
+                const bool ok = (r < a.rows) && (k0 + kq < a.K);
+                const float* p = a.X + (ok ? r : 0) * a.ldx + (ok ? k0 + kq : 0);
+                const float4 v = *(const float4*)p;
+                xr[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (!a.w_kn) {   // W [N,K]: 128 n x 32 k, float4 along k
+                const int n = idx >> 3, kq = (idx & 7) * 4;
+                const bool ok = (n0 + n < a.N) && (k0 + kq < a.K);
+                const float* p = a.W + (int64_t)(ok ? n0 + n : 0) * a.ldw + (ok ? k0 + kq : 0);
+                const float4 v = *(const float4*)p;
+                wr[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {         // W [K,N]: 32 k x 128 n, float4 along n
+                const int k = idx >> 5, nq = (idx & 31) * 4;
+                const bool ok = (k0 + k < a.K) && (n0 + nq < a.N);
+                const float* p = a.W + (int64_t)(ok ? k0 + k : 0) * a.ldw + (ok ? n0 + nq : 0);
+                const float4 v = *(const float4*)p;
+                wr[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = tid + 256 * j;
+            {
+                const int row = idx >> 3, kq = (idx & 7) * 4;
+                float* d = Xs + row * LPAD + kq;
+                d[0] = xr[j].x; d[1] = xr[j].y; d[2] = xr[j].z; d[3] = xr[j].w;
+            }
+            if (!a.w_kn) {
+                const int n = idx >> 3, kq = (idx & 7) * 4;
+                float* d = Ws + n * LPAD + kq;
+                d[0] = wr[j].x; d[1] = wr[j].y; d[2] = wr[j].z; d[3] = wr[j].w;
+            } else {
+                const int k = idx >> 5, nq = (idx & 31) * 4;
+                Ws[(nq + 0) * LPAD + k] = wr[j].x; Ws[(nq + 1) * LPAD + k] = wr[j].y;
+                Ws[(nq + 2) * LPAD + k] = wr[j].z; Ws[(nq + 3) * LPAD + k] = wr[j].w;
+            }
+        }
+    };
+
+    fetch(0);
+    for (int k0 = 0; k0 < a.K; k0 += LBK) {
+        __syncthreads();                 // previous tile fully consumed
+        stage();
+        __syncthreads();
+        if (k0 + LBK < a.K) fetch(k0 + LBK);          // in flight during the MFMAs below
+        const float* xa = Xs + (wave * 32 + li) * LPAD + lk;
+        const float* wb = Ws + li * LPAD + lk;
+#pragma unroll
+        for (int kp = 0; kp < LBK / 2; ++kp) {
+            const float av = xa[2 * kp];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[t * 32 * LPAD + 2 * kp], acc[t], 0, 0, 0);
+        }
+    }
+    // epilogue: bias, ReLU, mask; lanes 0-31 of a register write 32 consecutive floats of one row
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int col = n0 + t * 32 + li;
+        if (col >= a.N) continue;
+        const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t r = r0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+            if (r >= a.rows) continue;
+            float v = acc[t][e] + bv;
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (a.mask) v = (a.mask[r * a.ldm + col] > 0.f) ? v : 0.f;
+            a.Y[r * a.ldy + col] = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int kgw_linear(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias,
+                          const float* mask, int64_t ldm, float* Y, int64_t ldy, int64_t rows, int32_t K,
+                          int32_t N, int32_t relu, int32_t w_is_kn, kgw_stream_t stream_) {
+    if (rows == 0) return KGW_OK;
+    if (!X || !W || !Y) return KGW_E_NULL;
+    if (rows < 0 || K <= 0 || N <= 0) return KGW_E_RANGE;
+    // float4 tiles: leading dimensions and K (N for the [K,N] form) must be multiples of 4, bases 16-B aligned
+    if ((K & 3) || (ldx & 3) || (ldw & 3) || !aligned16(X) || !aligned16(W)) return KGW_E_UNSUPPORTED;
+    if (w_is_kn && (N & 3)) return KGW_E_UNSUPPORTED;
+    LinArgs a{X, ldx, W, ldw, bias, mask, ldm, Y, ldy, rows, K, N, relu, w_is_kn};
+    dim3 grid((unsigned)((rows + LBM - 1) / LBM), (unsigned)((N + LBN - 1) / LBN));
+    k_linear<<<grid, 256, 0, (hipStream_t)stream_>>>(a);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}

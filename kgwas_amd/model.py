@@ -275,7 +275,7 @@ class HeteroGNN(nn.Module):
                 R = hi - lo
                 zb = int(m.z_base[l - 1][t])
                 Zt = Z[zb:zb + nr * R].view(nr, R * C)
-                h_next[name] = torch.relu(torch.addmm(P.bias[lo:hi].sum(0), Zt, P.w_src_t[lo:hi].reshape(R * C, C)))
+                h_next[name] = ops.linear_act(Zt, P.w_src_t[lo:hi].reshape(R * C, C), P.bias[lo:hi].sum(0), True)
             h = h_next
         return h, attn
 

@@ -194,14 +194,45 @@ def tn_gemm(A: torch.Tensor, B: torch.Tensor, colsum: bool = False):
     return (C_, cs) if colsum else C_
 
 
+_LIN_MAX_K = 2304        # wider reductions (the 5120 / 57742-wide gene layer) go to the library GEMM
+
+
+def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask=None, w_kn: bool = False):
+    """Y = act(X @ Wop + bias) * (mask > 0) on the fp32-MFMA kernel (kgw_linear); Wop = W^T for W [N,K]
+    (nn.Linear forward) or W for W [K,N] (w_kn: the dX product).  Shapes the kernel does not take
+    (K or leading dimensions not multiples of 4, very wide K) run on the library GEMM with identical math."""
+    rows, K = X.shape
+    N = W.shape[1] if w_kn else W.shape[0]
+    ok = (X.dtype == torch.float32 and X.stride(1) == 1 and W.stride(1) == 1 and K % 4 == 0 and K <= _LIN_MAX_K
+          and X.stride(0) % 4 == 0 and W.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0
+          and (not w_kn or N % 4 == 0) and (mask is None or mask.stride(1) == 1)
+          # one 128x128 block per CU-slot and no split over K: short-and-wide problems stay on the library
+          and (rows >= 8192 or rows * K <= (1 << 19)))
+    if not ok:
+        Y = X @ (W if w_kn else W.t())
+        if bias is not None:
+            Y = Y + bias
+        if relu:
+            Y = torch.relu_(Y)
+        if mask is not None:
+            Y = Y * (mask > 0)
+        return Y
+    Y = torch.empty(rows, N, device=X.device)
+    if rows:
+        _lib.check(_lib.lib().kgw_linear(_p(X), X.stride(0), _p(W), W.stride(0), _p(bias), _p(mask),
+                                         mask.stride(0) if mask is not None else 0, _p(Y), N, rows, K, N,
+                                         1 if relu else 0, 1 if w_kn else 0, _lib.stream_ptr()), 'kgw_linear')
+    return Y
+
+
 class _MLPTail(torch.autograd.Function):
-    """y = FC_output(relu(FC_hidden2(h1)))  (kgwas/model.py:19-21) as ONE autograd node: library GEMMs for the
-    forward / dX products, the split-K MFMA kernel for the tall weight-gradient products and bias sums."""
+    """y = FC_output(relu(FC_hidden2(h1)))  (kgwas/model.py:19-21) as ONE autograd node: MFMA Linear kernels
+    forward and for dX (ReLU mask fused in the epilogue), split-K MFMA kernel for the weight / bias gradients."""
 
     @staticmethod
     def forward(ctx, h1, W2, b2, W3, b3):
-        h2 = torch.relu_(torch.addmm(b2, h1, W2.t()))
-        y = torch.addmm(b3, h2, W3.t())
+        h2 = linear(h1, W2, b2, relu=True)
+        y = linear(h2, W3, b3)
         ctx.save_for_backward(h1, h2, W2, W3)
         return y
 
@@ -210,9 +241,9 @@ class _MLPTail(torch.autograd.Function):
         h1, h2, W2, W3 = ctx.saved_tensors
         dy = dy.contiguous()
         dW3, db3 = linear_weight_grad(dy, h2)
-        dh2 = torch.mm(dy, W3).mul_(h2 > 0)
+        dh2 = linear(dy, W3, mask=h2, w_kn=True)                 # (dy @ W3) * (h2 > 0)
         dW2, db2 = linear_weight_grad(dh2, h1)
-        dh1 = torch.mm(dh2, W2) if ctx.needs_input_grad[0] else None
+        dh1 = linear(dh2, W2, w_kn=True) if ctx.needs_input_grad[0] else None
         return dh1, dW2, db2, dW3, db3
 
 
@@ -221,17 +252,42 @@ class _LinearReLU(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, b):
-        h = torch.relu_(torch.addmm(b, x, W.t()))
+        h = linear(x, W, b, relu=True)
         ctx.save_for_backward(x, h, W)
         return h
 
     @staticmethod
     def backward(ctx, dh):
         x, h, W = ctx.saved_tensors
-        dz = dh * (h > 0)
+        dz = torch.ops.aten.threshold_backward(dh.contiguous(), h, 0.0)      # dh * (h > 0), one launch
         dW, db = linear_weight_grad(dz, x)
-        dx = torch.mm(dz, W) if ctx.needs_input_grad[0] else None
+        dx = linear(dz, W, w_kn=True) if ctx.needs_input_grad[0] else None
         return dx, dW, db
+
+
+class _LinearAct(torch.autograd.Function):
+    """y = [relu](x W^T + b) for W given TRANSPOSED as Wt [K,N] (the packed per-relation weights) -- the
+    transform GEMM of a layer: per-relation lin_src + bias + relation sum (+ ReLU) in one launch."""
+
+    @staticmethod
+    def forward(ctx, x, Wt, b, relu):
+        y = linear(x, Wt, b, relu=relu, w_kn=True)
+        ctx.save_for_backward(x, y, Wt)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, Wt = ctx.saved_tensors
+        dz = torch.ops.aten.threshold_backward(dy.contiguous(), y, 0.0) if ctx.relu else dy.contiguous()
+        dWt = tn_gemm(x, dz) if x.shape[0] >= _TN_MIN_ROWS else x.t().mm(dz)          # [K,N]
+        db = dz.sum(0)
+        dx = linear(dz, Wt) if ctx.needs_input_grad[0] else None                       # dz @ Wt^T: Wt is [K,N] = "[N',K']" form
+        return dx, dWt, db, None
+
+
+def linear_act(x, Wt, b, relu=True):
+    return _LinearAct.apply(x, Wt, b, relu)
 
 
 def linear_weight_grad(dY: torch.Tensor, X: torch.Tensor):

@@ -56,3 +56,39 @@ def test_mlp_nodes_match_autograd():
     assert_close(y, yo, 1e-5, 1e-6, 'mlp y')
     for a, b, n_ in zip(mine, ps, 'W1 b1 W2 b2 W3 b3'.split()):
         assert_close(a, b.grad, 1e-4, 1e-6, 'grad ' + n_)
+
+
+@pytest.mark.parametrize('rows,K,N,kn', [(120003, 128, 128, False), (50001, 20, 128, False), (1000, 2176, 128, True),
+                                         (777, 128, 128, True), (130, 768, 128, True), (5, 16, 128, False),
+                                         (4097, 128, 20, True), (3000, 128, 260, False)])
+def test_linear_kernel_matches_fp64(rows, K, N, kn):
+    from kgwas_amd import ops
+    g = torch.Generator().manual_seed(rows + K)
+    X = torch.randn(rows, K, generator=g)
+    W = torch.randn(*((K, N) if kn else (N, K)), generator=g) * 0.3
+    b = torch.randn(N, generator=g)
+    Mk = torch.randn(rows, N, generator=g)
+    X[:, 0] += 2.0
+    ref = X.double() @ (W.double() if kn else W.double().t()) + b.double()
+    Y = ops.linear(X.cuda(), W.cuda(), b.cuda(), relu=False, w_kn=kn)
+    assert_close(Y, ref, 1e-5, 1e-6, 'linear', rel_to_max=2e-6)
+    Y2 = ops.linear(X.cuda(), W.cuda(), b.cuda(), relu=True, mask=Mk.cuda(), w_kn=kn)
+    assert_close(Y2, torch.relu(ref) * (Mk.double() > 0), 1e-5, 1e-6, 'linear relu+mask', rel_to_max=2e-6)
+
+
+def test_linear_act_node_matches_autograd():
+    from kgwas_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(6000, 768, generator=g).cuda().requires_grad_(True)
+    Wt = (torch.randn(768, 128, generator=g) * 0.05).cuda().requires_grad_(True)
+    b = torch.randn(128, generator=g).cuda().requires_grad_(True)
+    G = torch.randn(6000, 128, generator=g).cuda()
+    y = ops.linear_act(x, Wt, b, True)
+    (y * G).sum().backward()
+    xo, Wo, bo = (t.detach().double().requires_grad_(True) for t in (x, Wt, b))
+    yo = torch.relu(xo @ Wo + bo)
+    (yo * G.double()).sum().backward()
+    assert_close(y, yo, 1e-5, 1e-6, 'y')
+    assert_close(x.grad, xo.grad, 1e-4, 1e-6, 'dx')
+    assert_close(Wt.grad, Wo.grad, 1e-4, 1e-6, 'dWt')
+    assert_close(b.grad, bo.grad, 1e-4, 1e-6, 'db')
