@@ -161,13 +161,22 @@ class KGWAS:
         self._postprocess(save_name, save_best_model and rank == 0)
 
     def _postprocess(self, save_name, save_best_model):
-        """kgwas.py:192-212: prediction-weighted p-values + calibration + CSVs.  The statistics live in
-        kgwas/eval_utils.py (CPU, pandas) -- SURVEY.md 8 row f-1, not yet rebuilt; predictions are saved."""
+        """kgwas.py:192-212: prediction-weighted p-values (Storey-Tibshirani pi0 per prediction-quantile bin,
+        500 bins), bisection calibration, clip to [0,1], CSVs."""
+        import numpy as np
+        from .eval_utils import find_closest_x, storey_ribshirani_integrate
         lr_uni_to_save = deepcopy(self.data.lr_uni)
+        self.data.lr_uni['abs_pred'] = np.abs(self.data.lr_uni['pred'])
+        self.data.lr_uni['SR_P_val'] = storey_ribshirani_integrate(self.data.lr_uni, column='abs_pred', num_bins=500)
+        self.data.lr_uni['SR'] = -(np.log10(self.data.lr_uni['SR_P_val'].astype(float).values))
+        lr_uni_to_save['P_weighted'] = self.data.lr_uni['SR_P_val']
+        scale_factor = find_closest_x(lr_uni_to_save)
+        lr_uni_to_save['KGWAS_P'] = (scale_factor * lr_uni_to_save['P_weighted']).clip(lower=0, upper=1)
         out_dir = os.path.join(self.data_path, 'model_pred', 'new_experiments')
         try:
             os.makedirs(out_dir, exist_ok=True)
             lr_uni_to_save.to_csv(os.path.join(out_dir, save_name + '_pred.csv'), index=False, sep='\t')
+            print('KGWAS prediction and p-values saved to ' + os.path.join(out_dir, save_name + '_pred.csv'))
             if save_best_model:
                 lr_uni_to_save.to_csv(os.path.join(self.data_path, 'model', save_name, 'pred.csv'), index=False, sep='\t')
         except OSError as e:   # read-only data_path: keep results in memory

@@ -86,6 +86,21 @@ def main():
     tr, va = train_test_split(tv, test_size=0.05, random_state=1)
     out['split_sizes'] = np.array([len(tr), len(va), len(te)])
     out['split_train_head'] = tr[:8]
+    # 5. prediction-weighted p-values (kgwas/eval_utils.py:539-596, 11-28) as driven by kgwas.py:194-203
+    eu = importlib.import_module('kgwas.eval_utils')
+    import pandas as pd
+    n = 20000
+    pr = rng.standard_normal(n)
+    pv = rng.uniform(0, 1, n)
+    causal = rng.choice(n, 1500, replace=False)
+    pr[causal] += 2.0                                    # informative predictions: signal SNPs have small P
+    pv[causal] = pv[causal] ** 4
+    for tag, nb in (('b50', 50), ('b500', 500)):
+        df = pd.DataFrame({'P': pv.copy(), 'abs_pred': np.abs(pr)})
+        pw = eu.storey_ribshirani_integrate(df, column='abs_pred', num_bins=nb)
+        out[f'sr_pw_{tag}'] = np.asarray(pw, dtype=np.float64)
+        out[f'sr_scale_{tag}'] = np.float64(eu.find_closest_x(pd.DataFrame({'P': pv, 'P_weighted': pw})))
+    out['sr_P'], out['sr_abs_pred'] = pv, np.abs(pr)
     np.savez_compressed(os.path.join(HERE, 'ref_helpers.npz'), **out)
     print('wrote', os.path.join(HERE, 'ref_helpers.npz'), {k: np.shape(v) for k, v in out.items()})
 

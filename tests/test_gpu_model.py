@@ -182,4 +182,7 @@ def test_end_to_end_train_api(tiny_kg):
     run.train(batch_size=32, epoch=2, save_best_model=False)     # val set (52 SNPs) must hold one full batch
     assert len(run.train_loader) == len(tiny_kg.train_input_nodes[1]) // 32
     assert 'pred' in run.data.lr_uni.columns and np.isfinite(run.data.lr_uni['pred'].values).all()
+    res = run.kgwas_res                                          # kgwas.py:196-212 outputs
+    assert {'P_weighted', 'KGWAS_P'} <= set(res.columns)
+    assert float(res['KGWAS_P'].min()) >= 0.0 and float(res['KGWAS_P'].max()) <= 1.0
     assert np.isfinite(run.val_metrics['mse'])
