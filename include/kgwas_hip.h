@@ -53,6 +53,13 @@ typedef struct KgwGraph {
     int64_t rowptr_off[KGW_MAX_RELS];     /* element offset of relation r inside g_rowptr     */
     int64_t col_off[KGW_MAX_RELS];        /* element offset of relation r inside g_col        */
     uint8_t rel_live[KGW_MAX_LAYERS][KGW_MAX_RELS]; /* [l-1][r]: layer l computes relation r  */
+    /* Static layout (HIP-graph capture): when static_layout != 0 the row blocks of layer l are laid out
+     * with these fixed capacities instead of the batch's own counts, so every buffer address and launch
+     * geometry is batch independent; a batch that needs more sets KgwBatchMeta.error bit 5.          */
+    int32_t static_layout;
+    int32_t cap_rows[KGW_MAX_LAYERS][KGW_MAX_TYPES];  /* destination rows of type T in layer l        */
+    int32_t cap_src[KGW_MAX_LAYERS][KGW_MAX_TYPES];   /* source rows of type T in layer l             */
+    int32_t pad0_;
     const int32_t* g_rowptr;              /* per relation N_dst+1 entries, relative to col_off */
     const int32_t* g_col;                 /* global source ids                                */
 } KgwGraph;
@@ -72,6 +79,8 @@ typedef struct KgwBatchMeta {
     int32_t n_src[KGW_MAX_LAYERS][KGW_MAX_TYPES];    /* source rows of type T in the layer input */
     int32_t src_base[KGW_MAX_LAYERS][KGW_MAX_TYPES + 1]; /* first H row of type T             */
     int32_t t_base[KGW_MAX_LAYERS][KGW_MAX_TYPES + 1];   /* first transposed row of type T    */
+    int32_t lay_rows[KGW_MAX_LAYERS][KGW_MAX_TYPES]; /* row-block sizes the bases above were built from */
+    int32_t lay_src[KGW_MAX_LAYERS][KGW_MAX_TYPES];  /*  (= n_rows / n_src unless static_layout)        */
     int32_t n_chunks[KGW_MAX_LAYERS];    /* chunks used by layer l                             */
     int32_t n_edges[KGW_MAX_LAYERS];     /* edges aggregated by layer l                        */
     int32_t t_entries[KGW_MAX_LAYERS];   /* entries in the layer's src-major structure         */
@@ -115,11 +124,13 @@ typedef struct KgwBatchBuf {
  * of the layer at once + the relation sum of PyG HeteroConv, kgwas/model.py:74).               */
 typedef struct KgwLayerArgs {
     int32_t layer;                 /* 1-based                                                  */
-    int32_t n_chunks, n_multi_hops;/* chunks [0,n_chunks); multi lists of dst hops [0,n_multi_hops) */
-    int32_t n_src_rows;            /* rows of H                                                */
+    int32_t n_chunks, n_multi_hops;/* launch-size HINT (>= the batch's chunk count; the kernels read the
+                                      actual counts from meta_dev) ; multi lists of dst hops [0,n_multi_hops) */
+    int32_t n_src_rows;            /* rows of H / dH in the layout (src_base[n_types])         */
     float   neg_slope, inv_temp;   /* LeakyReLU slope (0.2), 1/temperature (1)                 */
     const KgwGraph* graph_host;    /* host copy, passed by value to the kernels               */
-    const KgwBatchMeta* meta_host; /* host copy (after the sampling event completed)          */
+    const KgwBatchMeta* meta_host; /* host struct holding the LAYOUT (z_base, src_base, t_base, lay_*) */
+    const KgwBatchMeta* meta_dev;  /* device struct written by kgw_sample_batch (actual counts)        */
     const KgwChunk* chunks;
     const int32_t* multi;  int64_t multi_cap;
     const int32_t* col_local;

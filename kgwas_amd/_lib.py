@@ -31,6 +31,10 @@ class KgwGraph(C.Structure):
         ('rowptr_off', C.c_int64 * KGW_MAX_RELS),
         ('col_off', C.c_int64 * KGW_MAX_RELS),
         ('rel_live', (C.c_uint8 * KGW_MAX_RELS) * KGW_MAX_LAYERS),
+        ('static_layout', C.c_int32),
+        ('cap_rows', (C.c_int32 * KGW_MAX_TYPES) * KGW_MAX_LAYERS),
+        ('cap_src', (C.c_int32 * KGW_MAX_TYPES) * KGW_MAX_LAYERS),
+        ('pad0_', C.c_int32),
         ('g_rowptr', C.c_void_p),
         ('g_col', C.c_void_p),
     ]
@@ -50,6 +54,8 @@ class KgwBatchMeta(C.Structure):
         ('n_src', (C.c_int32 * KGW_MAX_TYPES) * KGW_MAX_LAYERS),
         ('src_base', (C.c_int32 * (KGW_MAX_TYPES + 1)) * KGW_MAX_LAYERS),
         ('t_base', (C.c_int32 * (KGW_MAX_TYPES + 1)) * KGW_MAX_LAYERS),
+        ('lay_rows', (C.c_int32 * KGW_MAX_TYPES) * KGW_MAX_LAYERS),
+        ('lay_src', (C.c_int32 * KGW_MAX_TYPES) * KGW_MAX_LAYERS),
         ('n_chunks', C.c_int32 * KGW_MAX_LAYERS),
         ('n_edges', C.c_int32 * KGW_MAX_LAYERS),
         ('t_entries', C.c_int32 * KGW_MAX_LAYERS),
@@ -81,7 +87,7 @@ class KgwLayerArgs(C.Structure):
     _fields_ = [
         ('layer', C.c_int32), ('n_chunks', C.c_int32), ('n_multi_hops', C.c_int32), ('n_src_rows', C.c_int32),
         ('neg_slope', C.c_float), ('inv_temp', C.c_float),
-        ('graph_host', C.c_void_p), ('meta_host', C.c_void_p),
+        ('graph_host', C.c_void_p), ('meta_host', C.c_void_p), ('meta_dev', C.c_void_p),
         ('chunks', C.c_void_p), ('multi', C.c_void_p), ('multi_cap', C.c_int64),
         ('col_local', C.c_void_p), ('H', C.c_void_p), ('a_dst', C.c_void_p), ('U', C.c_void_p),
         ('Z', C.c_void_p), ('stat', C.c_void_p), ('e_edge', C.c_void_p), ('part', C.c_void_p),

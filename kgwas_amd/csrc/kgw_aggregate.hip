@@ -63,6 +63,8 @@ struct AggPtrs {
     float* da_src;
     const int32_t* multi;
     int64_t multi_cap;
+    const KgwBatchMeta* meta;     // device: actual counts of the batch
+    int layer;
 };
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
@@ -118,9 +120,10 @@ __device__ __forceinline__ void fwd_group(const float4* __restrict__ Hb4, int co
     }
 }
 
-__global__ void __launch_bounds__(KGW_BLK) k_agg_fwd(LayerTab T, AggPtrs P, int n_chunks, float slope, float inv_temp) {
+__global__ void __launch_bounds__(KGW_BLK) k_agg_fwd(LayerTab T, AggPtrs P, float slope, float inv_temp) {
     const int lane = kgw_lane(), half = lane >> 5, hl = lane & 31;
     const int nw = gridDim.x * 4;
+    const int n_chunks = P.meta->n_chunks[P.layer - 1];
     for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < n_chunks; c += nw) {
         const KgwChunk ck = load_chunk(P.chunks, c);
         const int r = ck.rel;
@@ -180,9 +183,10 @@ __device__ __forceinline__ float wave_allsum_slow(float v) {
 }
 
 // one wavefront per multi-chunk segment: merge partial (max, sum, acc)
-__global__ void __launch_bounds__(KGW_BLK) k_agg_fwd_combine(LayerTab T, AggPtrs P, int hop, int n_multi) {
+__global__ void __launch_bounds__(KGW_BLK) k_agg_fwd_combine(LayerTab T, AggPtrs P, int hop) {
     const int lane = kgw_lane();
     const int nw = gridDim.x * 4;
+    const int n_multi = P.meta->multi_cnt[hop];
     const int32_t* mm = P.multi + (int64_t)hop * P.multi_cap * 4;
     for (int k = blockIdx.x * 4 + (threadIdx.x >> 6); k < n_multi; k += nw) {
         const int first = mm[4 * k], nch = mm[4 * k + 1], row = mm[4 * k + 2], r = mm[4 * k + 3];
@@ -238,9 +242,10 @@ __device__ __forceinline__ void bwd_group(const float4* __restrict__ Hb4, int co
     }
 }
 
-__global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_dst(LayerTab T, AggPtrs P, int n_chunks, float slope, float inv_temp) {
+__global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_dst(LayerTab T, AggPtrs P, float slope, float inv_temp) {
     const int lane = kgw_lane(), half = lane >> 5, hl = lane & 31;
     const int nw = gridDim.x * 4;
+    const int n_chunks = P.meta->n_chunks[P.layer - 1];
     for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < n_chunks; c += nw) {
         const KgwChunk ck = load_chunk(P.chunks, c);
         const int r = ck.rel;
@@ -277,9 +282,10 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_dst(LayerTab T, AggPtrs P, 
     }
 }
 
-__global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_combine(LayerTab T, AggPtrs P, int hop, int n_multi) {
+__global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_combine(LayerTab T, AggPtrs P, int hop) {
     const int lane = kgw_lane();
     const int nw = gridDim.x * 4;
+    const int n_multi = P.meta->multi_cnt[hop];
     const int32_t* mm = P.multi + (int64_t)hop * P.multi_cap * 4;
     for (int k = blockIdx.x * 4 + (threadIdx.x >> 6); k < n_multi; k += nw) {
         const int first = mm[4 * k], nch = mm[4 * k + 1], row = mm[4 * k + 2], r = mm[4 * k + 3];
@@ -326,6 +332,11 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, 
         const int j = u - T.type_src_base[ty];
         const int Rs = T.type_R_src[ty];
         const int tb = T.type_t_base[ty] + j * Rs;
+        if (j >= P.meta->n_src[P.layer - 1][ty]) {          // padding row of a static layout: no gradient
+            if (half == 0) ((float4*)(P.dH + (int64_t)u * KGW_C))[hl] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane < Rs) P.da_src[tb + lane] = 0.f;
+            continue;
+        }
         const int p0 = P.t_ptr[tb], p1 = P.t_ptr[tb + Rs];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         float dasv = 0.f;                                    // lane k holds d a_src of slot k
@@ -375,9 +386,10 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, 
 }
 
 // alpha per local edge (attention export)
-__global__ void __launch_bounds__(KGW_BLK) k_edge_alpha(LayerTab T, AggPtrs P, int n_chunks, float inv_temp, float* out) {
+__global__ void __launch_bounds__(KGW_BLK) k_edge_alpha(LayerTab T, AggPtrs P, float inv_temp, float* out) {
     const int lane = kgw_lane();
     const int nw = gridDim.x * 4;
+    const int n_chunks = P.meta->n_chunks[P.layer - 1];
     for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < n_chunks; c += nw) {
         const KgwChunk ck = load_chunk(P.chunks, c);
         const int r = ck.rel;
@@ -424,6 +436,7 @@ AggPtrs build_ptrs(const KgwLayerArgs* a) {
     P.Z = a->Z; P.stat = a->stat; P.e_edge = a->e_edge; P.part = a->part; P.dZ = a->dZ; P.adp = a->adp;
     P.da_dst = a->da_dst; P.part_da = a->part_da; P.t_ptr = a->t_ptr; P.t_edge = a->t_edge;
     P.t_zrow = a->t_zrow; P.dH = a->dH; P.da_src = a->da_src; P.multi = a->multi; P.multi_cap = a->multi_cap;
+    P.meta = a->meta_dev; P.layer = a->layer;
     return P;
 }
 
@@ -439,21 +452,21 @@ inline int grid_for_waves(int64_t n_waves) {
 extern "C" int kgw_gat_aggregate_fwd(const KgwLayerArgs* a, kgw_stream_t stream_) {
     if (!a) return KGW_E_NULL;
     if (a->n_chunks == 0) return KGW_OK;
-    if (!a->chunks || !a->col_local || !a->H || !a->a_dst || !a->U || !a->Z || !a->stat || !a->e_edge || !a->part)
+    if (!a->chunks || !a->col_local || !a->H || !a->a_dst || !a->U || !a->Z || !a->stat || !a->e_edge || !a->part ||
+        !a->meta_dev)
         return KGW_E_NULL;
     LayerTab T;
     int rc = build_tab(a, &T);
     if (rc) return rc;
     AggPtrs P = build_ptrs(a);
     hipStream_t st = (hipStream_t)stream_;
-    k_agg_fwd<<<grid_for_waves(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->n_chunks, a->neg_slope, a->inv_temp);
+    k_agg_fwd<<<grid_for_waves(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
     KGW_LAUNCH_CHECK();
-    for (int h = 0; h < a->n_multi_hops; ++h) {
-        const int nm = a->meta_host->multi_cnt[h];
-        if (nm == 0) continue;
-        if (!a->multi) return KGW_E_NULL;
-        k_agg_fwd_combine<<<grid_for_waves(nm), KGW_BLK, 0, st>>>(T, P, h, nm);
-        KGW_LAUNCH_CHECK();
+    if (a->multi && a->multi_cap > 0) {     // hub rows: the number of multi-chunk segments is read on the device
+        for (int h = 0; h < a->n_multi_hops; ++h) {
+            k_agg_fwd_combine<<<grid_for_waves(a->multi_cap < 1024 ? a->multi_cap : 1024), KGW_BLK, 0, st>>>(T, P, h);
+            KGW_LAUNCH_CHECK();
+        }
     }
     return KGW_OK;
 }
@@ -462,21 +475,20 @@ extern "C" int kgw_gat_aggregate_bwd_dst(const KgwLayerArgs* a, kgw_stream_t str
     if (!a) return KGW_E_NULL;
     if (a->n_chunks == 0) return KGW_OK;
     if (!a->chunks || !a->col_local || !a->H || !a->Z || !a->stat || !a->e_edge || !a->dZ || !a->adp ||
-        !a->da_dst || !a->part_da)
+        !a->da_dst || !a->part_da || !a->meta_dev)
         return KGW_E_NULL;
     LayerTab T;
     int rc = build_tab(a, &T);
     if (rc) return rc;
     AggPtrs P = build_ptrs(a);
     hipStream_t st = (hipStream_t)stream_;
-    k_agg_bwd_dst<<<grid_for_waves(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->n_chunks, a->neg_slope, a->inv_temp);
+    k_agg_bwd_dst<<<grid_for_waves(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
     KGW_LAUNCH_CHECK();
-    for (int h = 0; h < a->n_multi_hops; ++h) {
-        const int nm = a->meta_host->multi_cnt[h];
-        if (nm == 0) continue;
-        if (!a->multi) return KGW_E_NULL;
-        k_agg_bwd_combine<<<grid_for_waves(nm), KGW_BLK, 0, st>>>(T, P, h, nm);
-        KGW_LAUNCH_CHECK();
+    if (a->multi && a->multi_cap > 0) {
+        for (int h = 0; h < a->n_multi_hops; ++h) {
+            k_agg_bwd_combine<<<grid_for_waves(a->multi_cap < 1024 ? a->multi_cap : 1024), KGW_BLK, 0, st>>>(T, P, h);
+            KGW_LAUNCH_CHECK();
+        }
     }
     return KGW_OK;
 }
@@ -484,7 +496,7 @@ extern "C" int kgw_gat_aggregate_bwd_dst(const KgwLayerArgs* a, kgw_stream_t str
 extern "C" int kgw_gat_aggregate_bwd_src(const KgwLayerArgs* a, kgw_stream_t stream_) {
     if (!a) return KGW_E_NULL;
     if (a->n_src_rows == 0) return KGW_OK;
-    if (!a->dZ || !a->adp || !a->t_ptr || !a->t_edge || !a->t_zrow || !a->dH || !a->da_src || !a->U)
+    if (!a->dZ || !a->adp || !a->t_ptr || !a->t_edge || !a->t_zrow || !a->dH || !a->da_src || !a->U || !a->meta_dev)
         return KGW_E_NULL;
     LayerTab T;
     int rc = build_tab(a, &T);
@@ -498,12 +510,12 @@ extern "C" int kgw_gat_aggregate_bwd_src(const KgwLayerArgs* a, kgw_stream_t str
 extern "C" int kgw_edge_alpha(const KgwLayerArgs* a, float* alpha_out, kgw_stream_t stream_) {
     if (!a || !alpha_out) return KGW_E_NULL;
     if (a->n_chunks == 0) return KGW_OK;
-    if (!a->chunks || !a->stat || !a->e_edge) return KGW_E_NULL;
+    if (!a->chunks || !a->stat || !a->e_edge || !a->meta_dev) return KGW_E_NULL;
     LayerTab T;
     int rc = build_tab(a, &T);
     if (rc) return rc;
     AggPtrs P = build_ptrs(a);
-    k_edge_alpha<<<grid_for_waves(a->n_chunks), KGW_BLK, 0, (hipStream_t)stream_>>>(T, P, a->n_chunks, a->inv_temp, alpha_out);
+    k_edge_alpha<<<grid_for_waves(a->n_chunks), KGW_BLK, 0, (hipStream_t)stream_>>>(T, P, a->inv_temp, alpha_out);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }

@@ -41,6 +41,38 @@ __device__ __forceinline__ int type_of_node_slot(const KgwGraph& G, int i) {
     return t;
 }
 
+// ---- fills / meta export as KERNELS (not hipMemsetAsync / hipMemcpyAsync) ------------------------------
+// The whole batch must be capturable in a HIP graph together with framework work that allocates from a
+// graph-private pool; on ROCm 7.2 a captured graph that mixes memset / D2H-memcpy nodes issued from here with
+// such allocations faulted on its second replay, while kernel nodes replay fine.  int4 stores, grid-stride.
+__global__ void __launch_bounds__(KGW_BLK) k_fill_i32(int32_t* __restrict__ p, int32_t v, int64_t n) {
+    const int64_t tid = (int64_t)blockIdx.x * KGW_BLK + threadIdx.x, nthr = (int64_t)gridDim.x * KGW_BLK;
+    const int64_t n4 = n >> 2;
+    int4* p4 = (int4*)p;
+    const int4 v4 = make_int4(v, v, v, v);
+    for (int64_t i = tid; i < n4; i += nthr) p4[i] = v4;
+    for (int64_t i = (n4 << 2) + tid; i < n; i += nthr) p[i] = v;
+}
+
+inline int fill_i32(int32_t* p, int32_t v, int64_t n, hipStream_t st) {
+    if (n <= 0) return KGW_OK;
+    int64_t g = (n / 4 + KGW_BLK - 1) / KGW_BLK;
+    if (g > KGW_GRID) g = KGW_GRID;
+    if (g < 1) g = 1;
+    k_fill_i32<<<(int)g, KGW_BLK, 0, st>>>(p, v, n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? KGW_OK : (int)e;
+}
+
+// device meta -> pinned host mirror (zero-copy store; visible to the host once the stream has drained)
+__global__ void k_meta_to_host(const KgwBatchMeta* __restrict__ src, KgwBatchMeta* __restrict__ dst) {
+    const int n = sizeof(KgwBatchMeta) / sizeof(int32_t);
+    const int32_t* s = (const int32_t*)src;
+    int32_t* d = (int32_t*)dst;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+    __threadfence_system();
+}
+
 // ---- init --------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(KGW_BLK) k_init(SampArgs A, const int64_t* seeds, int n_seeds,
                                                   int seed_type, int full) {
@@ -343,11 +375,20 @@ __global__ void k_layer_tables(SampArgs A) {
             }
             const int nr = dst_live ? M->node_off[t][hd + 1] : 0;
             const int ns = src_live ? M->node_off[t][hd + 2] : 0;
+            // row-block sizes of the layout: the batch's own counts, or fixed capacities (graph capture)
+            int lr = nr, ls = ns;
+            if (G.static_layout) {
+                lr = dst_live ? G.cap_rows[l - 1][t] : 0;
+                ls = src_live ? G.cap_src[l - 1][t] : 0;
+                if (nr > lr || ns > ls) M->error |= 32;
+            }
             M->n_rows[l - 1][t] = nr;
-            M->z_base[l - 1][t] = zb;  zb += nr * G.R_dst[t];
+            M->lay_rows[l - 1][t] = lr;
+            M->z_base[l - 1][t] = zb;  zb += lr * G.R_dst[t];
             M->n_src[l - 1][t] = ns;
-            M->src_base[l - 1][t] = sb; sb += ns;
-            M->t_base[l - 1][t] = tb;  tb += ns * G.R_src[t];
+            M->lay_src[l - 1][t] = ls;
+            M->src_base[l - 1][t] = sb; sb += ls;
+            M->t_base[l - 1][t] = tb;  tb += ls * G.R_src[t];
         }
         M->z_base[l - 1][G.n_types] = zb;
         M->src_base[l - 1][G.n_types] = sb;
@@ -423,8 +464,8 @@ extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, c
     const int ntiles_nodes = total_slots / KGW_TILE;
     if ((int64_t)ntiles_nodes + 2 > buf->scan_cap) return KGW_E_RANGE;
 
-    KGW_HIP(hipMemsetAsync(buf->g2l, 0xFF, (size_t)total_slots * sizeof(int32_t), st));
-    KGW_HIP(hipMemsetAsync(buf->meta, 0, sizeof(KgwBatchMeta), st));
+    { int rc = fill_i32(buf->g2l, -1, total_slots, st); if (rc) return rc; }
+    { int rc = fill_i32((int32_t*)buf->meta, 0, sizeof(KgwBatchMeta) / sizeof(int32_t), st); if (rc) return rc; }
     k_init<<<full_graph ? KGW_GRID : 64, KGW_BLK, 0, st>>>(A, seeds, n_seeds, seed_type, full_graph);
     KGW_LAUNCH_CHECK();
 
@@ -446,7 +487,7 @@ extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, c
             k_hop_end<<<1, 64, 0, st>>>(A, buf->scan_tmp, h);
         } else {
             // every node is already a seed: hop h+1 adds nothing
-            KGW_HIP(hipMemsetAsync(buf->scan_tmp, 0, (size_t)(ntiles_nodes + 2) * sizeof(int32_t), st));
+            { int rc = fill_i32(buf->scan_tmp, 0, ntiles_nodes + 2, st); if (rc) return rc; }
             k_hop_end<<<1, 64, 0, st>>>(A, buf->scan_tmp, h);
         }
         k_relabel<<<KGW_GRID, KGW_BLK, 0, st>>>(A, h);
@@ -458,7 +499,7 @@ extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, c
     for (int l = 1; l <= graph->n_layers; ++l) {
         if (!buf->t_cnt[l - 1] || !buf->t_ptr[l - 1] || !buf->t_edge[l - 1] || !buf->t_zrow[l - 1])
             return KGW_E_NULL;
-        KGW_HIP(hipMemsetAsync(buf->t_cnt[l - 1], 0, (size_t)(buf->trow_cap + 1) * sizeof(int32_t), st));
+        { int rc = fill_i32(buf->t_cnt[l - 1], 0, buf->trow_cap + 1, st); if (rc) return rc; }
         k_t_begin<<<1, 64, 0, st>>>(A, l);
         k_t_pass<false><<<KGW_GRID, KGW_BLK, 0, st>>>(A, l);
         k_scan_tiles<1><<<KGW_GRID, KGW_BLK, 0, st>>>(buf->t_cnt[l - 1], nullptr, buf->meta, buf->scan_tmp);
@@ -469,8 +510,10 @@ extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, c
         k_t_end<<<1, 64, 0, st>>>(A, l);
         KGW_LAUNCH_CHECK();
     }
-    if (buf->meta_host)
-        KGW_HIP(hipMemcpyAsync(buf->meta_host, buf->meta, sizeof(KgwBatchMeta), hipMemcpyDeviceToHost, st));
+    if (buf->meta_host) {
+        k_meta_to_host<<<1, KGW_BLK, 0, st>>>(buf->meta, buf->meta_host);
+        KGW_LAUNCH_CHECK();
+    }
     return KGW_OK;
 }
 

@@ -250,13 +250,13 @@ class HeteroGNN(nn.Module):
             # layer input, type-major (src_base) ; destination-side attention terms a_d[i, r]
             parts, a_parts = [], []
             for t, name in enumerate(sc.node_types):
-                ns = int(m.n_src[l - 1][t])
+                ns = int(m.lay_src[l - 1][t])
                 if ns:
                     if name not in h or h[name].shape[0] < ns:
                         raise RuntimeError(f'layer {l}: node type {name!r} is a message source but has no '
                                            f'incoming relation to produce its layer-{l - 1} state')
                     parts.append(h[name][:ns])
-                nr = int(m.n_rows[l - 1][t])
+                nr = int(m.lay_rows[l - 1][t])
                 if nr:
                     lo, hi = rng[t]
                     a_parts.append((h[name][:nr] @ V_live[lo:hi].t()).reshape(-1))
@@ -268,7 +268,7 @@ class HeteroGNN(nn.Module):
             # per-relation linear maps + bias + relation sum + ReLU: one GEMM per destination type
             h_next = {}
             for t, name in enumerate(sc.node_types):
-                nr = int(m.n_rows[l - 1][t])
+                nr = int(m.lay_rows[l - 1][t])
                 if not nr:
                     continue
                 lo, hi = rng[t]

@@ -63,6 +63,7 @@ def _layer_args(batch, layer: int, neg_slope: float, inv_temp: float) -> KgwLaye
     a.neg_slope, a.inv_temp = neg_slope, inv_temp
     a.graph_host = C.addressof(dg.kg)
     a.meta_host = C.addressof(m)
+    a.meta_dev = _p(buf.meta)
     a.chunks = _p(buf.chunks)
     a.multi = _p(buf.multi)
     a.multi_cap = dg.multi_cap
@@ -89,7 +90,7 @@ class _GatAggregate(torch.autograd.Function):
         Z = torch.zeros(max(z_rows, 1), KGW_C, device=dev)
         stat = torch.zeros(max(z_rows, 1), 2, device=dev)
         e_edge = torch.empty(max(n_edges, 1), device=dev)
-        any_multi = any(int(m.multi_cnt[h]) for h in range(dg.n_hops))
+        any_multi = batch.static or any(int(m.multi_cnt[h]) for h in range(dg.n_hops))
         part = torch.empty(max(n_chunks, 1) * PART_STRIDE if any_multi else 4, device=dev)
         a = _layer_args(batch, layer, neg_slope, inv_temp)
         a.H, a.a_dst, a.U = _p(H), _p(a_dst), _p(U)
@@ -135,13 +136,15 @@ class _GatAggregate(torch.autograd.Function):
         # d u_r = sum_j d a_src[j, r] * H_s[j]   (a_s = <H_s[j], u_r>)
         dU = torch.zeros_like(U)
         for t in range(NT):
-            ns, Rs = int(m.n_src[layer - 1][t]), int(sc.R_src[t])
+            ns, Rs = int(m.lay_src[layer - 1][t]), int(sc.R_src[t])
             if ns == 0 or Rs == 0:
                 continue
             tb, sb = int(m.t_base[layer - 1][t]), int(m.src_base[layer - 1][t])
             blk = da_src[tb:tb + ns * Rs].view(ns, Rs)
             Hs = H[sb:sb + ns]
-            dU[sc.rels_by_src[t]] = tn_gemm(blk, Hs) if ns >= _TN_MIN_ROWS else blk.t() @ Hs
+            # index tensors live on the device (a python list would be uploaded synchronously -- illegal while a
+            # HIP graph is being captured)
+            dU.index_copy_(0, dg.rels_by_src_t[t], tn_gemm(blk, Hs) if ns >= _TN_MIN_ROWS else blk.t() @ Hs)
         return dH[:n_src], da_dst[:z_rows], dU, None, None, None, None
 
 

@@ -83,6 +83,7 @@ class DeviceGraph:
             self.node_base.append(self.node_base[-1] + ((n + KGW_TILE - 1) // KGW_TILE) * KGW_TILE)
         self.node_slots = self.node_base[-1]
         self.live_rel, self.live_types = sc.live_relations(num_layers, out_type)
+        self.rels_by_src_t = [torch.tensor(sc.rels_by_src[t], dtype=torch.long, device=self.device) for t in range(sc.NT)]
 
         g = KgwGraph()
         g.n_types, g.n_rels, g.n_layers, g.n_hops = sc.NT, sc.NR, num_layers, self.n_hops
@@ -106,6 +107,51 @@ class DeviceGraph:
         self.x = {t: data[t].x.to(self.device, torch.float32).contiguous() for t in sc.node_types if 'x' in data[t]}
         self.y = {t: data[t].y.to(self.device) for t in sc.node_types if 'y' in data[t]}
 
+    def with_static_caps(self, caps: "BatchCaps") -> "DeviceGraph":
+        """Same resident graph, but batches are laid out with fixed row-block capacities (``caps``) so that
+        every buffer address and launch geometry is batch independent -- the precondition for capturing
+        the whole training step in a HIP graph."""
+        import copy
+        dg = copy.copy(self)                      # shares g_rowptr / g_col / features / labels
+        g = KgwGraph()
+        C.memmove(C.addressof(g), C.addressof(self.kg), C.sizeof(KgwGraph))
+        g.static_layout = 1
+        sc, L = self.schema, self.num_layers
+        for l in range(1, L + 1):
+            hd = min(L - l, self.n_hops - 1)
+            for t in range(sc.NT):
+                g.cap_rows[l - 1][t] = int(caps.node_off[t][hd + 1])
+                g.cap_src[l - 1][t] = int(caps.node_off[t][hd + 2])
+        dg.kg = g
+        dg.caps = caps
+        return dg
+
+    def static_meta(self) -> KgwBatchMeta:
+        """Host-side KgwBatchMeta holding the LAYOUT of a static-caps graph (same formulas as the device's
+        k_layer_tables); the counts of a particular batch stay on the device."""
+        m = KgwBatchMeta()
+        sc, L, g = self.schema, self.num_layers, self.kg
+        for l in range(1, L + 1):
+            live = [r for r in range(sc.NR) if g.rel_live[l - 1][r]]
+            zb = sb = tb = 0
+            for t in range(sc.NT):
+                dst_live = any(int(sc.dst_type[r]) == t for r in live)
+                src_live = any(int(sc.src_type[r]) == t for r in live)
+                lr = int(g.cap_rows[l - 1][t]) if dst_live else 0
+                ls = int(g.cap_src[l - 1][t]) if src_live else 0
+                m.lay_rows[l - 1][t], m.lay_src[l - 1][t] = lr, ls
+                m.n_rows[l - 1][t], m.n_src[l - 1][t] = lr, ls
+                m.z_base[l - 1][t] = zb; zb += lr * int(sc.R_dst[t])
+                m.src_base[l - 1][t] = sb; sb += ls
+                m.t_base[l - 1][t] = tb; tb += ls * int(sc.R_src[t])
+            m.z_base[l - 1][sc.NT], m.src_base[l - 1][sc.NT], m.t_base[l - 1][sc.NT] = zb, sb, tb
+            m.n_chunks[l - 1] = int(self.caps.chunks[l - 1])
+            m.n_edges[l - 1] = int(self.caps.edges[l - 1])
+        for t in range(sc.NT):
+            for k in range(L + 2):
+                m.node_off[t][k] = int(self.caps.node_off[t][k])
+        return m
+
     @staticmethod
     def get(data: HeteroGraph, num_layers: int, device, full_graph: bool = False) -> "DeviceGraph":
         cache = data._extra.setdefault('_device_graphs', {})
@@ -113,6 +159,19 @@ class DeviceGraph:
         if key not in cache:
             cache[key] = DeviceGraph(data, num_layers, device, full_graph=full_graph)
         return cache[key]
+
+
+class BatchCaps:
+    """Fixed capacities of a static batch layout: per node type the cumulative node counts per hop
+    (``node_off[t][k]``), per layer the edge and chunk counts.  Built by ``NeighborLoader.measure_caps``."""
+
+    def __init__(self, node_off, edges, chunks):
+        self.node_off = node_off        # [NT][L+2] ints
+        self.edges = edges              # [L]
+        self.chunks = chunks            # [L]
+
+    def __repr__(self):
+        return f'BatchCaps(node_off={self.node_off}, edges={self.edges}, chunks={self.chunks})'
 
 
 class BatchBuffers:
@@ -184,10 +243,14 @@ class SampledBatch:
     """One minibatch: local node ids per type (seeds first), per-layer block structure for the fused
     kernels, and lazily materialised PyG-style views."""
 
-    def __init__(self, dg: DeviceGraph, buf: BatchBuffers, meta: KgwBatchMeta, input_type: str, batch_size: int):
+    def __init__(self, dg: DeviceGraph, buf: BatchBuffers, meta: KgwBatchMeta, input_type: str, batch_size: int,
+                 static: bool = False):
+        """``meta``: host struct whose LAYOUT fields (z_base / src_base / t_base / lay_*) are valid; in a static
+        layout its counts are capacities and the batch's own counts live only on the device (buf.meta)."""
         self.dg, self.buf, self.meta = dg, buf, meta
         self.input_type = input_type
         self.batch_size = batch_size
+        self.static = static
         sc = dg.schema
         self.n_nodes = {t: int(meta.node_off[i][dg.n_hops + 1]) for i, t in enumerate(sc.node_types)}
         self._x = None
@@ -259,6 +322,13 @@ class SampledBatch:
             else:
                 out[et] = torch.zeros(2, 0, dtype=torch.long, device=dg.device)
         return out
+
+    # layout of layer l (1-based): row-block sizes and bases as python ints
+    def lay_rows(self, l: int, t: int) -> int:
+        return int(self.meta.lay_rows[l - 1][t])
+
+    def lay_src(self, l: int, t: int) -> int:
+        return int(self.meta.lay_src[l - 1][t])
 
     @property
     def n_edges_per_layer(self):
@@ -358,13 +428,15 @@ def gather_rows(src: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def sample_into(dg: DeviceGraph, buf: BatchBuffers, seeds: Optional[torch.Tensor], seed_type: int, stream=None):
+def sample_into(dg: DeviceGraph, buf: BatchBuffers, seeds: Optional[torch.Tensor], seed_type: int, stream=None,
+                record: bool = True):
     st = stream if stream is not None else torch.cuda.current_stream()
     n = 0 if seeds is None else int(seeds.numel())
     rc = _lib.lib().kgw_sample_batch(C.byref(dg.kg), C.byref(buf.c), _ptr(seeds), n, seed_type,
                                      1 if dg.full_graph else 0, C.c_void_p(st.cuda_stream))
     _lib.check(rc, 'kgw_sample_batch')
-    buf.ready.record(st)
+    if record:
+        buf.ready.record(st)
 
 
 def finish_sample(dg: DeviceGraph, buf: BatchBuffers, input_type: str, batch_size: int) -> SampledBatch:
@@ -433,6 +505,40 @@ class NeighborLoader:
         else:
             sample_into(self.dg, buf, seeds, self.seed_type)
         return int(seeds.numel())
+
+    def measure_caps(self, margin: float = 1.03, round_to: int = 64) -> BatchCaps:
+        """Dry pass over every batch of this loader (the batch order is fixed, kgwas.py:93-94): the largest
+        node / edge / chunk counts, plus a safety margin, become the capacities of a static layout."""
+        dg = self.dg
+        sc, L = dg.schema, dg.num_layers
+        node_off = np.zeros((sc.NT, L + 2), dtype=np.int64)
+        edges = np.zeros(L, dtype=np.int64)
+        chunks = np.zeros(L, dtype=np.int64)
+        for b in self:
+            m = b.meta
+            for t in range(sc.NT):
+                for k in range(L + 2):
+                    node_off[t, k] = max(node_off[t, k], int(m.node_off[t][min(k, dg.n_hops + 1)]))
+            for l in range(L):
+                edges[l] = max(edges[l], int(m.n_edges[l]))
+                chunks[l] = max(chunks[l], int(m.n_chunks[l]))
+
+        def up(v, hi=None, exact=False):
+            if exact:
+                return int(v)
+            w = int(-(-int(v * margin + 1) // round_to) * round_to)
+            return min(w, hi) if hi is not None else w
+        seed_t = self.seed_type
+        for t in range(sc.NT):
+            for k in range(L + 2):
+                if k == 0:
+                    node_off[t, k] = 0
+                elif t == seed_t and k == 1:
+                    node_off[t, k] = self.batch_size          # the seeds: exact
+                else:
+                    node_off[t, k] = up(node_off[t, k], hi=dg.n_nodes[t])
+            node_off[t] = np.maximum.accumulate(node_off[t])
+        return BatchCaps(node_off.tolist(), [up(e) for e in edges], [up(c) for c in chunks])
 
     def __iter__(self):
         self._ensure()
