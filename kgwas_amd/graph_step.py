@@ -42,6 +42,16 @@ class GraphTrainStep:
         self.seeds = torch.zeros(self.batch_size, dtype=torch.int64, device=dev)
         self.ld_w = run._ld_weight_vector()
         self.capture_optimizer = capture_optimizer
+        self.world = 1
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                self.world = dist.get_world_size()
+        except Exception:
+            pass
+        if self.world > 1:
+            capture_optimizer = False          # gradients are all-reduced between backward and Adam
+            self.capture_optimizer = False
         self.opt = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay,
                                     capturable=capture_optimizer)
         # device-side statistics accumulated inside the graph: [edges layer 1..L, sampled edges, error mask]
@@ -108,6 +118,11 @@ class GraphTrainStep:
         b = self.batch_size
         self.seeds.copy_(self.ids[i * b:(i + 1) * b])
         self.graph.replay()
+        if not self.capture_optimizer:
+            if self.world > 1:
+                from . import dist as kdist
+                kdist.allreduce_grads(self.model, self.world)
+            self.opt.step()
         return self.loss
 
     def grads_ready(self):

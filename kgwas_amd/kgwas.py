@@ -113,7 +113,9 @@ class KGWAS:
         return loss
 
     def train(self, batch_size=512, num_workers=0, lr=1e-4, weight_decay=5e-4, epoch=10, save_best_model=True,
-              save_name=None, data_to_cuda=False):
+              save_name=None, data_to_cuda=False, use_graph=True):
+        """Same signature and defaults as kgwas/kgwas.py:85-87.  ``use_graph`` (extra, default on): run the
+        training step as one captured HIP graph (kgwas_amd/graph_step.py); off = eager launches, same math."""
         total_epoch = epoch
         if save_name is None:
             save_name = self.exp_name
@@ -123,19 +125,33 @@ class KGWAS:
         rank, world = kdist.rank_world()
         if world > 1:
             kdist.broadcast_params(self.model)
-        optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay)   # kgwas.py:116
+        graph_step = None
+        if use_graph and len(self.train_loader) > 0:
+            from .graph_step import GraphTrainStep
+            graph_step = GraphTrainStep(self, (self.train_loader.input_type, self.train_loader.ids.cpu().numpy()),
+                                        self.train_loader.batch_size, lr=lr, weight_decay=weight_decay)
+            optimizer = graph_step.opt
+        else:
+            optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay)   # kgwas.py:116
         ld_w = self._ld_weight_vector()
         min_val = -1000
         self.best_model = deepcopy(self.model).to(self.device)
         print_sys('Start Training...')
         for ep in range(total_epoch):
             self.model.train()
-            for step, batch in enumerate(self.train_loader):
-                loss = self.train_step(batch, optimizer, ld_w, world)
+            steps = range(graph_step.n_batches) if graph_step is not None else enumerate(self.train_loader)
+            for item in steps:
+                if graph_step is not None:
+                    step, loss = item, graph_step.step(item)
+                else:
+                    step, batch = item
+                    loss = self.train_step(batch, optimizer, ld_w, world)
                 if self.wandb:
                     self.wandb.log({'training_loss': loss.item()})
                 if (step % 500 == 0) and (step >= 500):
                     print_sys('Epoch {} Step {} Train Loss: {:.4f}'.format(ep + 1, step + 1, loss.item()))
+            if graph_step is not None:
+                graph_step.check()
             val_res = evaluate_minibatch_clean(self.val_loader, self.model, self.device)
             val_metrics = compute_metrics(val_res, False, -1, -1, F.mse_loss)
             print_sys('Epoch {}: Validation MSE: {:.4f} Validation Pearson: {:.4f}. '.format(
