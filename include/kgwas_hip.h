@@ -200,6 +200,13 @@ int kgw_linear(const float* X, int64_t ldx, const float* W, int64_t ldw, const f
                const float* mask, int64_t ldm, float* Y, int64_t ldy, int64_t rows, int32_t K, int32_t N,
                int32_t relu, int32_t w_is_kn, kgw_stream_t stream);
 
+/* One Adam step (torch.optim.Adam semantics, weight_decay as L2: kgwas/kgwas.py:116,151) over up to 64
+ * parameter tensors in a single launch.  The pointer arrays are HOST arrays of device pointers (passed to the
+ * kernel by value); step_dev is a device int32 counter incremented by the call (graph-capturable).        */
+int kgw_adam(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+             float* const* exp_avg_sq, const int64_t* numel, int32_t* step_dev, float lr, float beta1,
+             float beta2, float eps, float weight_decay, kgw_stream_t stream);
+
 /* Self-test of the cross-lane reductions used by the aggregate kernels (one wavefront):
  * out_half[l] = sum over l's 32-lane half, out_wave[l] = sum over the wavefront,
  * out_steps[4][64] = the four intra-row DPP butterfly stages.                                  */

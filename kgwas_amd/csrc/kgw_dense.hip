@@ -427,3 +427,70 @@ extern "C" int kgw_linear(const float* X, int64_t ldx, const float* W, int64_t l
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }
+
+// ======================================================================================================
+// kgw_adam: torch.optim.Adam(lr, betas, eps, weight_decay as L2) of kgwas/kgwas.py:116,151 for ALL parameter
+// tensors in one launch (the framework's capturable Adam issues ~100 small launches per step).  Same update
+// order as torch: g += wd*p ; m = lerp(m, g, 1-b1) ; v = v*b2 + (1-b2)*g*g ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).
+// The step counter lives on the device so the call can sit inside a captured HIP graph.
+// ======================================================================================================
+namespace {
+
+constexpr int ADAM_MAX = 64;
+struct AdamTab {
+    float* p[ADAM_MAX]; const float* g[ADAM_MAX]; float* m[ADAM_MAX]; float* v[ADAM_MAX];
+    int64_t off[ADAM_MAX + 1];      // prefix sums of element counts
+    int n;
+};
+
+__global__ void __launch_bounds__(256) k_adam(AdamTab T, int32_t* step, float lr, float b1, float b2, float eps, float wd) {
+    const int t_now = *step + 1;                       // every thread reads the same pre-increment value
+    const float bc1 = 1.0f - powf(b1, (float)t_now);
+    const float bc2 = 1.0f - powf(b2, (float)t_now);
+    const float step_size = lr / bc1;
+    const float bc2_sqrt = sqrtf(bc2);
+    const int64_t total = T.off[T.n];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int lo = 0, hi = T.n;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (T.off[mid] <= i) lo = mid; else hi = mid; }
+        const int64_t j = i - T.off[lo];
+        float p = T.p[lo][j];
+        float g = T.g[lo][j];
+        g = fmaf(wd, p, g);
+        float m = T.m[lo][j], v = T.v[lo][j];
+        m = m + (1.0f - b1) * (g - m);
+        v = v * b2 + (1.0f - b2) * g * g;
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        p = p - step_size * (m / denom);
+        T.m[lo][j] = m; T.v[lo][j] = v; T.p[lo][j] = p;
+    }
+}
+
+__global__ void k_adam_tick(int32_t* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
+
+}  // namespace
+
+extern "C" int kgw_adam(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                        float* const* exp_avg_sq, const int64_t* numel, int32_t* step_dev, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, kgw_stream_t stream_) {
+    if (n_tensors == 0) return KGW_OK;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !step_dev) return KGW_E_NULL;
+    if (n_tensors < 0 || n_tensors > ADAM_MAX) return KGW_E_RANGE;
+    AdamTab T;
+    T.n = n_tensors;
+    T.off[0] = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] < 0) return KGW_E_NULL;
+        T.p[i] = params[i]; T.g[i] = grads[i]; T.m[i] = exp_avg[i]; T.v[i] = exp_avg_sq[i];
+        T.off[i + 1] = T.off[i] + numel[i];
+    }
+    hipStream_t st = (hipStream_t)stream_;
+    int64_t g = (T.off[n_tensors] + 255) / 256;
+    if (g > KGW_GRID) g = KGW_GRID;
+    if (g < 1) g = 1;
+    k_adam<<<(int)g, 256, 0, st>>>(T, step_dev, lr, beta1, beta2, eps, weight_decay);
+    KGW_LAUNCH_CHECK();
+    k_adam_tick<<<1, 64, 0, st>>>(step_dev);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}

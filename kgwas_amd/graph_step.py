@@ -52,8 +52,8 @@ class GraphTrainStep:
         if self.world > 1:
             capture_optimizer = False          # gradients are all-reduced between backward and Adam
             self.capture_optimizer = False
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay,
-                                    capturable=capture_optimizer)
+        from .optim import FusedAdam
+        self.opt = FusedAdam(self.model.parameters(), lr=lr, weight_decay=weight_decay)   # one launch, capturable
         # device-side statistics accumulated inside the graph: [edges layer 1..L, sampled edges, error mask]
         nbytes = C.sizeof(_lib.KgwBatchMeta)
         self._meta_i32 = self.buf.meta.view(torch.int32)
@@ -107,6 +107,7 @@ class GraphTrainStep:
                 for v in st.values():
                     if torch.is_tensor(v):
                         v.zero_()
+            self.opt.step_dev.zero_()
         self.stats.zero_()
         self.opt.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()

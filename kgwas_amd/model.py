@@ -255,14 +255,15 @@ class HeteroGNN(nn.Module):
                     if name not in h or h[name].shape[0] < ns:
                         raise RuntimeError(f'layer {l}: node type {name!r} is a message source but has no '
                                            f'incoming relation to produce its layer-{l - 1} state')
-                    parts.append(h[name][:ns])
+                    parts.append(h[name] if h[name].shape[0] == ns else h[name][:ns])
                 nr = int(m.lay_rows[l - 1][t])
                 if nr:
                     lo, hi = rng[t]
-                    a_parts.append((h[name][:nr] @ V_live[lo:hi].t()).reshape(-1))
+                    hd = h[name] if h[name].shape[0] == nr else h[name][:nr]
+                    a_parts.append((hd @ V_live[lo:hi].t()).reshape(-1))
             H = torch.cat(parts, 0) if len(parts) != 1 else parts[0]
             a_dst = torch.cat(a_parts) if len(a_parts) != 1 else a_parts[0]
-            Z, stat, e_edge = ops.gat_aggregate(batch, l, H, a_dst, U, self.negative_slope, self.temperature)
+            Zt_by_type, stat, e_edge = ops.gat_aggregate(batch, l, H, a_dst, U, self.negative_slope, self.temperature)
             if want_attention:
                 attn.append(ops.edge_alpha(batch, l, stat, e_edge, self.temperature))
             # per-relation linear maps + bias + relation sum + ReLU: one GEMM per destination type
@@ -273,8 +274,7 @@ class HeteroGNN(nn.Module):
                     continue
                 lo, hi = rng[t]
                 R = hi - lo
-                zb = int(m.z_base[l - 1][t])
-                Zt = Z[zb:zb + nr * R].view(nr, R * C)
+                Zt = Zt_by_type[t].view(nr, R * C)
                 h_next[name] = ops.linear_act(Zt, P.w_src_t[lo:hi].reshape(R * C, C), P.bias[lo:hi].sum(0), True)
             h = h_next
         return h, attn

@@ -101,11 +101,24 @@ class _GatAggregate(torch.autograd.Function):
         ctx.save_for_backward(H, U, Z, stat, e_edge)
         ctx.batch, ctx.layer, ctx.neg_slope, ctx.inv_temp = batch, layer, neg_slope, inv_temp
         ctx.mark_non_differentiable(stat, e_edge)
-        return Z[:z_rows], stat, e_edge
+        # one output per destination type (a view of its row block): the caller never slices Z, so autograd never
+        # has to zero-fill + copy a full-size gradient per slice
+        sc = dg.schema
+        outs, spans = [], []
+        for t in range(NT):
+            nr = int(m.lay_rows[layer - 1][t]) * int(sc.R_dst[t])
+            if nr:
+                zb = int(m.z_base[layer - 1][t])
+                outs.append(Z[zb:zb + nr])
+                spans.append((zb, nr))
+        ctx.spans = spans
+        return (stat, e_edge) + tuple(outs)
 
     @staticmethod
-    def backward(ctx, dZ, _dstat, _de):
+    def backward(ctx, _dstat, _de, *dZs):
         H, U, Z, stat, e_edge = ctx.saved_tensors
+        pieces = [d if d is not None else torch.zeros(n, KGW_C, device=H.device) for d, (_, n) in zip(dZs, ctx.spans)]
+        dZ = pieces[0] if len(pieces) == 1 else (torch.cat(pieces, 0) if pieces else None)
         batch, layer = ctx.batch, ctx.layer
         dg, m = batch.dg, batch.meta
         sc = dg.schema
@@ -150,8 +163,23 @@ class _GatAggregate(torch.autograd.Function):
 
 def gat_aggregate(batch, layer: int, H: torch.Tensor, a_dst: torch.Tensor, U: torch.Tensor,
                   neg_slope: float = 0.2, temperature: float = 1.0):
-    """Returns (Z [z_rows,128], stat [z_rows,2] = (row max, denominator), e_edge [n_edges])."""
-    return _GatAggregate.apply(H, a_dst, U, batch, layer, float(neg_slope), 1.0 / float(temperature))
+    """Returns (Z_by_type, stat [z_rows,2] = (row max, denominator), e_edge [n_edges]); ``Z_by_type[t]`` is the
+    [rows_t * R_dst[t], 128] block of destination type t (only types with rows in this layer)."""
+    res = _GatAggregate.apply(H, a_dst, U, batch, layer, float(neg_slope), 1.0 / float(temperature))
+    stat, e_edge, outs = res[0], res[1], res[2:]
+    m, sc = batch.meta, batch.dg.schema
+    zt, k = {}, 0
+    for t in range(sc.NT):
+        if int(m.lay_rows[layer - 1][t]) * int(sc.R_dst[t]):
+            zt[t] = outs[k]; k += 1
+    return zt, stat, e_edge
+
+
+def gat_aggregate_flat(batch, layer, H, a_dst, U, neg_slope=0.2, temperature=1.0):
+    """Same, with the per-type blocks concatenated into Z [z_rows, 128] (tests / callers that want one tensor)."""
+    zt, stat, e_edge = gat_aggregate(batch, layer, H, a_dst, U, neg_slope, temperature)
+    parts = [zt[t] for t in sorted(zt)]
+    return (parts[0] if len(parts) == 1 else torch.cat(parts, 0)), stat, e_edge
 
 
 def edge_alpha(batch, layer: int, stat: torch.Tensor, e_edge: torch.Tensor, temperature: float = 1.0):

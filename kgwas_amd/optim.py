@@ -1,0 +1,62 @@
+"""FusedAdam: torch.optim.Adam(lr, betas, eps, weight_decay) semantics (kgwas/kgwas.py:116) in ONE launch over all
+parameter tensors (kgw_adam), with the step counter on the device so it can sit inside a captured HIP graph."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class FusedAdam:
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params = [p for p in params]
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.state = {}
+        dev = self.params[0].device if self.params else torch.device('cuda')
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.param_groups = [{'params': self.params, 'lr': lr, 'betas': betas, 'eps': eps, 'weight_decay': weight_decay}]
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def _state(self, p):
+        st = self.state.get(p)
+        if st is None:      # like torch: state is created the first time a parameter has a gradient
+            st = {'exp_avg': torch.zeros_like(p, memory_format=torch.preserve_format),
+                  'exp_avg_sq': torch.zeros_like(p, memory_format=torch.preserve_format)}
+            self.state[p] = st
+        return st
+
+    def init_state(self):
+        for p in self.params:
+            if p.requires_grad:
+                self._state(p)
+
+    @torch.no_grad()
+    def step(self):
+        live = [p for p in self.params if p.grad is not None]     # grad None => skipped, exactly like torch
+        if not live:
+            return
+        for i in range(0, len(live), 64):
+            chunk = live[i:i + 64]
+            n = len(chunk)
+            P = (C.c_void_p * n)(); G = (C.c_void_p * n)(); M = (C.c_void_p * n)(); V = (C.c_void_p * n)()
+            N = (C.c_int64 * n)()
+            for k, p in enumerate(chunk):
+                g = p.grad
+                if not (p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32 and g.dtype == torch.float32):
+                    raise _lib.KgwasHipError('FusedAdam needs contiguous fp32 parameters and gradients')
+                st = self._state(p)
+                P[k], G[k], M[k], V[k], N[k] = p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel()
+            # chunks > 0 must not advance the step counter again: only the last call ticks it
+            rc = _lib.lib().kgw_adam(n, P, G, M, V, N, self.step_dev.data_ptr(), self.lr, self.betas[0], self.betas[1],
+                                     self.eps, self.weight_decay, _lib.stream_ptr())
+            _lib.check(rc, 'kgw_adam')
+            if i + 64 < len(live):
+                self.step_dev.sub_(1)

@@ -68,7 +68,7 @@ def test_aggregate_forward_backward(small_kg, edge_case_graph, graph, layer):
     G = torch.randn(z_rows, 128, generator=g)
 
     Hd, ad, Ud = (t.cuda().requires_grad_(True) for t in (H, a_dst, U))
-    Z, stat, e_edge = ops.gat_aggregate(batch, layer, Hd, ad, Ud)
+    Z, stat, e_edge = ops.gat_aggregate_flat(batch, layer, Hd, ad, Ud)
     (Z * G.cuda()).sum().backward()
 
     Ho, ao, Uo = (t.double().requires_grad_(True) for t in (H, a_dst, U))
@@ -94,7 +94,7 @@ def test_temperature_and_slope(edge_case_graph):
     H = torch.randn(int(m.src_base[0][sc.NT]), 128, generator=g)
     a_dst = torch.randn(int(m.z_base[0][sc.NT]), generator=g)
     U = torch.randn(sc.NR, 128, generator=g) * 0.2
-    Z, _, _ = ops.gat_aggregate(batch, 1, H.cuda(), a_dst.cuda(), U.cuda(), neg_slope=0.05, temperature=2.5)
+    Z, _, _ = ops.gat_aggregate_flat(batch, 1, H.cuda(), a_dst.cuda(), U.cuda(), neg_slope=0.05, temperature=2.5)
     Zo = _oracle_layer(batch, 1, H.double(), a_dst.double(), U.double(), slope=0.05, temp=2.5)
     assert_close(Z, Zo, RTOL, ATOL, 'Z (T=2.5, slope=0.05)')
 
@@ -111,7 +111,7 @@ def test_extreme_logits_do_not_overflow(edge_case_graph):
     H[777] *= 40.0                      # one SNP source row with a huge logit inside gene 0's 1500-edge hub row
     a_dst = torch.randn(int(m.z_base[0][sc.NT]), generator=g)
     U = torch.randn(sc.NR, 128, generator=g)
-    Z, stat, e = ops.gat_aggregate(batch, 1, H.cuda(), a_dst.cuda(), U.cuda())
+    Z, stat, e = ops.gat_aggregate_flat(batch, 1, H.cuda(), a_dst.cuda(), U.cuda())
     assert torch.isfinite(Z).all()
     Zo = _oracle_layer(batch, 1, H.double(), a_dst.double(), U.double())
     assert_close(Z, Zo, 2e-4, 1e-4, 'Z with spike')

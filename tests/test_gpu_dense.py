@@ -92,3 +92,23 @@ def test_linear_act_node_matches_autograd():
     assert_close(x.grad, xo.grad, 1e-4, 1e-6, 'dx')
     assert_close(Wt.grad, Wo.grad, 1e-4, 1e-6, 'dWt')
     assert_close(b.grad, bo.grad, 1e-4, 1e-6, 'db')
+
+
+def test_fused_adam_matches_torch_adam():
+    from kgwas_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(2)
+    shapes = [(23, 128, 128), (128,), (128, 20), (1, 128), (6, 128), (3, 5, 7)]
+    pa = [torch.randn(*s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    dead_a = torch.randn(4, 4).cuda().requires_grad_(True)          # never gets a gradient -> never touched
+    dead_b = dead_a.detach().clone().requires_grad_(True)
+    oa = FusedAdam(pa + [dead_a], lr=1e-3, weight_decay=5e-4)
+    ob = torch.optim.Adam(pb + [dead_b], lr=1e-3, weight_decay=5e-4)
+    for it in range(6):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).cuda() * (10.0 if it == 2 else 1.0)
+            a.grad = gr.clone(); b.grad = gr.clone()
+        oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        assert_close(a, b, 2e-6, 1e-7, 'adam param', rel_to_max=0)
+    assert torch.equal(dead_a, dead_b) and int(oa.step_dev) == 6
