@@ -21,7 +21,7 @@ from .sampler import BatchBuffers, NeighborLoader, SampledBatch, sample_into
 
 class GraphTrainStep:
     def __init__(self, run, input_nodes, batch_size: int, lr: float = 1e-4, weight_decay: float = 5e-4,
-                 margin: float = 1.03, capture_optimizer: bool = True):
+                 margin: float = 1.03, capture_optimizer: bool = True, overlap_sampling: bool = None):
         self.run = run
         self.model = run.model
         self.batch_size = int(batch_size)
@@ -37,9 +37,11 @@ class GraphTrainStep:
         self.dg = probe.dg.with_static_caps(self.caps)
         self.seed_type = probe.seed_type
         self.ids = probe.ids
-        self.buf = BatchBuffers(self.dg)
+        # two batch buffers: while the graph trains on one, its side branch samples the NEXT batch into the other
+        self.bufs = [BatchBuffers(self.dg), BatchBuffers(self.dg)]
+        self.buf = self.bufs[0]
         self.meta = self.dg.static_meta()
-        self.seeds = torch.zeros(self.batch_size, dtype=torch.int64, device=dev)
+        self.seeds = torch.zeros(self.batch_size, dtype=torch.int64, device=dev)        # seeds sampled by the side branch
         self.ld_w = run._ld_weight_vector()
         self.capture_optimizer = capture_optimizer
         self.world = 1
@@ -50,27 +52,36 @@ class GraphTrainStep:
         except Exception:
             pass
         if self.world > 1:
-            capture_optimizer = False          # gradients are all-reduced between backward and Adam
-            self.capture_optimizer = False
+            self.capture_optimizer = False       # gradients are all-reduced between backward and Adam
         from .optim import FusedAdam
         self.opt = FusedAdam(self.model.parameters(), lr=lr, weight_decay=weight_decay)   # one launch, capturable
         # device-side statistics accumulated inside the graph: [edges layer 1..L, sampled edges, error mask]
-        nbytes = C.sizeof(_lib.KgwBatchMeta)
-        self._meta_i32 = self.buf.meta.view(torch.int32)
         base = _lib.KgwBatchMeta
+        self._meta_i32 = [b.meta.view(torch.int32) for b in self.bufs]
         self._idx = torch.tensor([base.n_edges.offset // 4 + l for l in range(L)] +
                                  [base.edge_end.offset // 4 + self.dg.n_hops - 1, base.error.offset // 4],
                                  dtype=torch.long, device=dev)
         self.stats = torch.zeros(L + 2, dtype=torch.int64, device=dev)
-        self.loss = None
-        self.graph = None
+        self.loss = [None, None]
+        self.graphs = [None, None]
+        import os
+        if overlap_sampling is None:
+            overlap_sampling = os.environ.get('KGW_OVERLAP_SAMPLING', '0') == '1'
+        self.overlap = overlap_sampling
+        self._side = torch.cuda.Stream(device=dev)
+        self._have = [-1, -1]                      # batch index currently sampled into each buffer
         self._capture()
 
-    # one step on the current stream, static shapes only
-    def _step_body(self):
+    # train on the batch held by bufs[cur]; concurrently sample ``self.seeds`` into bufs[1 - cur]
+    def _step_body(self, cur: int):
         bs = self.batch_size
-        sample_into(self.dg, self.buf, self.seeds, self.seed_type, record=False)
-        batch = SampledBatch(self.dg, self.buf, self.meta, self.input_type, bs, static=True)
+        main = torch.cuda.current_stream()
+        if self.overlap:
+            self._side.wait_stream(main)                               # fork
+            with torch.cuda.stream(self._side):
+                sample_into(self.dg, self.bufs[1 - cur], self.seeds, self.seed_type, record=False)
+        buf = self.bufs[cur]
+        batch = SampledBatch(self.dg, buf, self.meta, self.input_type, bs, static=True)
         self.opt.zero_grad(set_to_none=True)
         out = self.model(batch.x_dict, batch.edge_index_dict, bs)
         n_id = batch.n_id(self.input_type)[:bs].long()
@@ -80,26 +91,37 @@ class GraphTrainStep:
         loss.backward()
         if self.capture_optimizer:
             self.opt.step()
-        vals = self._meta_i32[self._idx].long()
+        vals = self._meta_i32[cur][self._idx].long()
         self.stats[:-1] += vals[:-1]
         self.stats[-1] |= vals[-1]
+        if self.overlap:
+            main.wait_stream(self._side)                               # join
+        else:
+            sample_into(self.dg, self.bufs[1 - cur], self.seeds, self.seed_type, record=False)
         return loss
+
+    def _sample_now(self, which: int, i: int):
+        b = self.batch_size
+        self.seeds.copy_(self.ids[i * b:(i + 1) * b])
+        sample_into(self.dg, self.bufs[which], self.seeds, self.seed_type, record=False)
+        self._have[which] = i
 
     def _capture(self):
         # warm-up on a side stream (allocator pools, one-time kernel attributes, Adam state), then undo its effect
         params = [p for p in self.model.parameters()]
         snap = [p.detach().clone() for p in params]
-        self.seeds.copy_(self.ids[:self.batch_size])
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for _ in range(3):
-                self._step_body()
+            self._sample_now(0, 0)
+            for k in range(4):
+                self._step_body(k % 2)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        err = int(self.buf.read_meta().error)
-        if err:
-            raise _lib.KgwasHipError(f'static layout does not fit the sampler buffers (error mask {err})')
+        for b in self.bufs:
+            err = int(b.read_meta().error)
+            if err:
+                raise _lib.KgwasHipError(f'static layout does not fit the sampler buffers (error mask {err})')
         with torch.no_grad():
             for p, q in zip(params, snap):
                 p.copy_(q)
@@ -110,21 +132,31 @@ class GraphTrainStep:
             self.opt.step_dev.zero_()
         self.stats.zero_()
         self.opt.zero_grad(set_to_none=True)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = self._step_body()
+        for cur in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.loss[cur] = self._step_body(cur)
+            self.graphs[cur] = g
+        self._have = [-1, -1]
 
     def step(self, i: int):
-        """Train on batch ``i`` of the loader's fixed order; returns the (device, float64) loss tensor."""
+        """Train on batch ``i`` of the loader's fixed order (and pre-sample batch i+1); returns the (device,
+        float64) loss tensor."""
+        cur = i % 2
+        if self._have[cur] != i:                 # first call / non-sequential access: sample it now
+            self._sample_now(cur, i)
+        nxt = (i + 1) % self.n_batches
         b = self.batch_size
-        self.seeds.copy_(self.ids[i * b:(i + 1) * b])
-        self.graph.replay()
+        self.seeds.copy_(self.ids[nxt * b:(nxt + 1) * b])
+        self.graphs[cur].replay()
+        self._have[1 - cur] = nxt
+        self._have[cur] = -1
         if not self.capture_optimizer:
             if self.world > 1:
                 from . import dist as kdist
                 kdist.allreduce_grads(self.model, self.world)
             self.opt.step()
-        return self.loss
+        return self.loss[cur]
 
     def grads_ready(self):
         return [p.grad for p in self.model.parameters() if p.grad is not None]
