@@ -108,12 +108,17 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}')
     assert torch.cuda.is_available(), 'bench.py needs a ROCm GPU'
+    local_rank %= torch.cuda.device_count()      # (single-GPU boxes: KGW_DIST_BACKEND=gloo lets 2 ranks share cuda:0 for a dry run)
     torch.cuda.set_device(local_rank)
     dev = f'cuda:{local_rank}'
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device(dev))
+        backend = os.environ.get('KGW_DIST_BACKEND', 'nccl')          # "nccl" == RCCL over xGMI on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
 
     from kgwas_amd import dist as kdist
     from kgwas_amd import ops

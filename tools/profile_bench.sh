@@ -12,9 +12,10 @@ out = sys.argv[1]
 rows = list(csv.DictReader(open(out + '/r_kernel_stats.csv')))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 ncalls = sum(int(r['Calls']) for r in rows)
-print('kernel time total %.1f ms, %d launches  (23 steps + setup) -> %.2f ms/step, %d launches/step' % (tot / 1e6, ncalls, tot / 1e6 / 23, ncalls // 23))
-for r in rows[:22]:
-    print('%-64s calls %5s tot %7.2f ms avg %8.1f us %5.1f%%' % (r['Name'].replace('(anonymous namespace)::', '')[:64], r['Calls'], float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3, float(r['Percentage'])))
+nstep = max([int(r['Calls']) for r in rows if 'k_adam(' in r['Name']] + [0]) or 23
+print('kernel time total %.1f ms, %d launches; %d optimizer steps executed (incl. warm-ups; the caps pre-pass adds sampler-only work)' % (tot / 1e6, ncalls, nstep))
+for r in rows[:32]:
+    print('%-60s calls/step %6.1f  us/step %8.1f  avg %8.1f us %5.1f%%' % (r['Name'].replace('(anonymous namespace)::', '')[:60], int(r['Calls']) / nstep, float(r['TotalDurationNs']) / 1e3 / nstep, float(r['AverageNs']) / 1e3, float(r['Percentage'])))
 try:
     d = json.loads(open(out + '/bench.json').read().strip().splitlines()[-1])
     print('bench under profiler: ms/step %.2f value %.3g roofline frac %.3f' % (d['ms_per_step'], d['value'], d['roofline']['frac']))
