@@ -12,6 +12,7 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    torch.set_num_threads(min(16, torch.get_num_threads()))   # CPU oracle: more threads only add fork/join cost
     config.addinivalue_line('markers', 'gpu: needs a ROCm GPU (MI355X); run with -m gpu')
 
 

@@ -186,3 +186,62 @@ def test_end_to_end_train_api(tiny_kg):
     assert {'P_weighted', 'KGWAS_P'} <= set(res.columns)
     assert float(res['KGWAS_P'].min()) >= 0.0 and float(res['KGWAS_P'].max()) <= 1.0
     assert np.isfinite(run.val_metrics['mse'])
+
+
+def test_validation_pearson_matches_oracle_after_training(small_kg):
+    """north_star: val-set Pearson r of the MI355X path within 1e-3 of the reference restatement trained with
+    identical init / data / batch order (one epoch of kgwas/kgwas.py:126-164 on the small synthetic KG; the HIP
+    side runs the captured-graph step, the oracle the unpruned fp64 reference computation)."""
+    from scipy.stats import pearsonr
+    from kgwas_amd.graph_step import GraphTrainStep
+    from kgwas_amd.kgwas import KGWAS
+    from kgwas_amd.utils import evaluate_minibatch_clean
+    from oracle.sampler_np import FullNeighborSamplerNP
+    bs = 64
+    torch.set_num_threads(min(16, torch.get_num_threads()))      # the CPU oracle degrades badly when oversubscribed
+    run = KGWAS(small_kg, device='cuda:0', seed=21)
+    run.initialize_model()
+    oracle = oracle_from_product(run.model, dtype=torch.float64)
+    ids = np.asarray(small_kg.train_input_nodes[1])
+    nb = min(len(ids) // bs, 32)
+    ids = ids[:nb * bs]
+    lr, wd = 1e-3, 5e-4
+    gs = GraphTrainStep(run, ('SNP', ids), bs, lr=lr, weight_decay=wd)
+    run.model.train()
+    for i in range(nb):
+        gs.step(i)
+    gs.check()
+    # oracle: same batches, same order, torch Adam
+    g = small_kg.data
+    smp = FullNeighborSamplerNP(g.edge_index_dict, g.num_nodes_dict, 2)
+    opt = torch.optim.Adam(oracle.parameters(), lr=lr, weight_decay=wd)
+    y_all = g['SNP'].y.double()
+    w_all = run._ld_weight_vector().cpu()
+    for i in range(nb):
+        seeds = ids[i * bs:(i + 1) * bs]
+        n_id, ei = smp.sample('SNP', seeds)
+        x = {t: g[t].x[n_id[t]].double() for t in g.node_types}
+        opt.zero_grad()
+        weighted_mse(oracle(x, ei, bs), y_all[n_id['SNP'][:bs]], w_all[n_id['SNP'][:bs]]).backward()
+        opt.step()
+    # validation predictions of both on the val split
+    from kgwas_amd.sampler import NeighborLoader
+    val_ids = np.asarray(small_kg.val_input_nodes[1])[:192]
+    res = evaluate_minibatch_clean(NeighborLoader(g, [-1, -1], ('SNP', val_ids), batch_size=bs, device='cuda:0'),
+                                   run.model, 'cuda:0')
+    preds_o = []
+    with torch.no_grad():
+        for i in range(0, len(val_ids), bs):
+            seeds = val_ids[i:i + bs]
+            n_id, ei = smp.sample('SNP', seeds)
+            x = {t: g[t].x[n_id[t]].double() for t in g.node_types}
+            preds_o.append(oracle(x, ei, len(seeds)).reshape(-1))
+    pred_o = torch.cat(preds_o).numpy()
+    truth = y_all[torch.as_tensor(val_ids)].numpy()
+    assert np.allclose(res['truth'], truth.astype(np.float32))
+    r_hip = pearsonr(res['pred'], res['truth'])[0]
+    r_ref = pearsonr(pred_o, truth)[0]
+    assert np.std(pred_o) > 0 and np.isfinite(r_hip)
+    assert abs(r_hip - r_ref) < 1e-3, (r_hip, r_ref)
+    rel = float(np.linalg.norm(res['pred'] - pred_o) / max(np.linalg.norm(pred_o), 1e-12))
+    assert rel < 2e-2, f'relative L2 difference of the validation predictions {rel:.3e} (r_hip {r_hip:.5f}, r_ref {r_ref:.5f})'
