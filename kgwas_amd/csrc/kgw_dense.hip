@@ -284,7 +284,9 @@ extern "C" int kgw_tn_gemm(const float* A, int64_t lda, int32_t M, const float* 
     hipStream_t st = (hipStream_t)stream_;
     const bool a4 = (M % 4 == 0) && (lda % 4 == 0) && aligned16(A) && M >= 128;
     const bool b4 = (N % 4 == 0) && (ldb % 4 == 0) && aligned16(B) && N >= 128;
-    if (a4 && b4) return launch_tn<4, 4>(A, lda, M, B, ldb, N, rows, C, ldc, colsum_a, workspace, workspace_floats, st);
+    // the 128x128 accumulator pays a fixed ~25 us block epilogue (64 KB per block through LDS): worth it only for
+    // very tall inputs; shorter ones split N over blockIdx.z with 128x32 accumulators instead
+    if (a4 && b4 && rows >= 65536) return launch_tn<4, 4>(A, lda, M, B, ldb, N, rows, C, ldc, colsum_a, workspace, workspace_floats, st);
     if (a4)       return launch_tn<4, 1>(A, lda, M, B, ldb, N, rows, C, ldc, colsum_a, workspace, workspace_floats, st);
     if (b4)       return launch_tn<1, 4>(A, lda, M, B, ldb, N, rows, C, ldc, colsum_a, workspace, workspace_floats, st);
     return launch_tn<1, 1>(A, lda, M, B, ldb, N, rows, C, ldc, colsum_a, workspace, workspace_floats, st);

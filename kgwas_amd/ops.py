@@ -195,7 +195,7 @@ def edge_alpha(batch, layer: int, stat: torch.Tensor, e_edge: torch.Tensor, temp
 # ------------------------------------------------------------------------------------------------------
 # dense helpers on the split-K MFMA kernel (kgw_tn_gemm)
 # ------------------------------------------------------------------------------------------------------
-_TN_MIN_ROWS = 4096       # below this a library GEMM is fine
+_TN_MIN_ROWS = 1024       # below this a library GEMM is fine
 
 
 def tn_gemm(A: torch.Tensor, B: torch.Tensor, colsum: bool = False):
