@@ -207,6 +207,19 @@ int kgw_adam(int32_t n_tensors, float* const* params, const float* const* grads,
              float* const* exp_avg_sq, const int64_t* numel, int32_t* step_dev, float lr, float beta1,
              float beta2, float eps, float weight_decay, kgw_stream_t stream);
 
+/* Attention vectors of all relations of a layer (kgwas/conv.py:138-151 reduced to what the path consumes):
+ * U_full[r] = W_src^T att_src for every relation id r the layer computes (live_of_rel[r] = its index i in the
+ * packed parameter arrays, -1 => row of zeros), V[i] = W_dst^T att_dst (bip_pos[i] >= 0: index into w_dst_t) or
+ * W_src^T att_dst (same-type relation).  Packed weights are transposed: w_*_t[i][k][c] = W_i[c][k], C = 128.
+ * _bwd: gradients of the packed parameters from (dU_full, dV); every output element is written.          */
+int kgw_relvec_fwd(int32_t n_rels_total, const int32_t* live_of_rel, const int32_t* bip_pos, const float* w_src_t,
+                   const float* w_dst_t, const float* att_src, const float* att_dst, float* U_full, float* V,
+                   kgw_stream_t stream);
+int kgw_relvec_bwd(int32_t n_live, const int32_t* rel_ids, const int32_t* bip_pos, const float* w_src_t,
+                   const float* w_dst_t, const float* att_src, const float* att_dst, const float* dU_full,
+                   const float* dV, float* dw_src_t, float* dw_dst_t, float* datt_src, float* datt_dst,
+                   kgw_stream_t stream);
+
 /* Self-test of the cross-lane reductions used by the aggregate kernels (one wavefront):
  * out_half[l] = sum over l's 32-lane half, out_wave[l] = sum over the wavefront,
  * out_steps[4][64] = the four intra-row DPP butterfly stages.                                  */

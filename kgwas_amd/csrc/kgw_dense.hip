@@ -496,3 +496,103 @@ extern "C" int kgw_adam(int32_t n_tensors, float* const* params, const float* co
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }
+
+// ======================================================================================================
+// kgw_relvec: the attention vectors of every relation of a layer in one launch.
+//   u_r = W_src^T att_src , v_r = W_dst^T att_dst (W_src^T att_dst for same-type relations)   conv.py:138-151
+// Weights are stored transposed/packed: wT[i][k][c] = W_i[c][k].  Forward: U_full[r] (zeros for relations the
+// layer does not compute) and V[i].  Backward: d wT, d att from (dU_full, dV).
+// ======================================================================================================
+namespace {
+
+__global__ void __launch_bounds__(128) k_relvec_fwd(int NR, const int32_t* __restrict__ live_of_rel,
+                                                    const int32_t* __restrict__ bip_pos, const float* __restrict__ wsT,
+                                                    const float* __restrict__ wdT, const float* __restrict__ att_src,
+                                                    const float* __restrict__ att_dst, float* __restrict__ U_full,
+                                                    float* __restrict__ V) {
+    __shared__ float as[KGW_C], ad[KGW_C];
+    const int r = blockIdx.x, k = threadIdx.x;
+    const int i = live_of_rel[r];
+    if (i < 0) { U_full[(int64_t)r * KGW_C + k] = 0.f; return; }
+    as[k] = att_src[(int64_t)i * KGW_C + k];
+    ad[k] = att_dst[(int64_t)i * KGW_C + k];
+    __syncthreads();
+    const int j = bip_pos[i];
+    const float4* ws = (const float4*)(wsT + ((int64_t)i * KGW_C + k) * KGW_C);
+    const float4* wd = j >= 0 ? (const float4*)(wdT + ((int64_t)j * KGW_C + k) * KGW_C) : ws;
+    float u = 0.f, v = 0.f;
+#pragma unroll 8
+    for (int c4 = 0; c4 < KGW_C / 4; ++c4) {
+        const float4 a = ws[c4], b = wd[c4];
+        u = fmaf(a.x, as[4 * c4], fmaf(a.y, as[4 * c4 + 1], fmaf(a.z, as[4 * c4 + 2], fmaf(a.w, as[4 * c4 + 3], u))));
+        v = fmaf(b.x, ad[4 * c4], fmaf(b.y, ad[4 * c4 + 1], fmaf(b.z, ad[4 * c4 + 2], fmaf(b.w, ad[4 * c4 + 3], v))));
+    }
+    U_full[(int64_t)r * KGW_C + k] = u;
+    V[(int64_t)i * KGW_C + k] = v;
+}
+
+// one block per live relation i; thread c owns column c of the [k][c] matrices
+__global__ void __launch_bounds__(128) k_relvec_bwd(const int32_t* __restrict__ rel_ids, const int32_t* __restrict__ bip_pos,
+                                                    const float* __restrict__ wsT, const float* __restrict__ wdT,
+                                                    const float* __restrict__ att_src, const float* __restrict__ att_dst,
+                                                    const float* __restrict__ dU_full, const float* __restrict__ dV,
+                                                    float* __restrict__ dwsT, float* __restrict__ dwdT,
+                                                    float* __restrict__ datt_src, float* __restrict__ datt_dst) {
+    __shared__ float du[KGW_C], dv[KGW_C];
+    const int i = blockIdx.x, c = threadIdx.x;
+    const int r = rel_ids[i], j = bip_pos[i];
+    du[c] = dU_full[(int64_t)r * KGW_C + c];
+    dv[c] = dV[(int64_t)i * KGW_C + c];
+    __syncthreads();
+    const float as = att_src[(int64_t)i * KGW_C + c], ad = att_dst[(int64_t)i * KGW_C + c];
+    const float* ws = wsT + (int64_t)i * KGW_C * KGW_C;
+    float* dws = dwsT + (int64_t)i * KGW_C * KGW_C;
+    float gs = 0.f, gd = 0.f;
+    if (j >= 0) {
+        const float* wd = wdT + (int64_t)j * KGW_C * KGW_C;
+        float* dwd = dwdT + (int64_t)j * KGW_C * KGW_C;
+#pragma unroll 4
+        for (int k = 0; k < KGW_C; ++k) {
+            gs = fmaf(ws[k * KGW_C + c], du[k], gs);
+            gd = fmaf(wd[k * KGW_C + c], dv[k], gd);
+            dws[k * KGW_C + c] = du[k] * as;
+            dwd[k * KGW_C + c] = dv[k] * ad;
+        }
+    } else {
+#pragma unroll 4
+        for (int k = 0; k < KGW_C; ++k) {
+            const float w = ws[k * KGW_C + c];
+            gs = fmaf(w, du[k], gs);
+            gd = fmaf(w, dv[k], gd);
+            dws[k * KGW_C + c] = fmaf(du[k], as, dv[k] * ad);
+        }
+    }
+    datt_src[(int64_t)i * KGW_C + c] = gs;
+    datt_dst[(int64_t)i * KGW_C + c] = gd;
+}
+
+}  // namespace
+
+extern "C" int kgw_relvec_fwd(int32_t n_rels_total, const int32_t* live_of_rel, const int32_t* bip_pos, const float* w_src_t,
+                              const float* w_dst_t, const float* att_src, const float* att_dst, float* U_full, float* V,
+                              kgw_stream_t stream_) {
+    if (n_rels_total <= 0) return KGW_OK;
+    if (!live_of_rel || !bip_pos || !w_src_t || !att_src || !att_dst || !U_full || !V) return KGW_E_NULL;
+    k_relvec_fwd<<<n_rels_total, 128, 0, (hipStream_t)stream_>>>(n_rels_total, live_of_rel, bip_pos, w_src_t, w_dst_t,
+                                                                 att_src, att_dst, U_full, V);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+extern "C" int kgw_relvec_bwd(int32_t n_live, const int32_t* rel_ids, const int32_t* bip_pos, const float* w_src_t,
+                              const float* w_dst_t, const float* att_src, const float* att_dst, const float* dU_full,
+                              const float* dV, float* dw_src_t, float* dw_dst_t, float* datt_src, float* datt_dst,
+                              kgw_stream_t stream_) {
+    if (n_live <= 0) return KGW_OK;
+    if (!rel_ids || !bip_pos || !w_src_t || !att_src || !att_dst || !dU_full || !dV || !dw_src_t || !datt_src || !datt_dst)
+        return KGW_E_NULL;
+    k_relvec_bwd<<<n_live, 128, 0, (hipStream_t)stream_>>>(rel_ids, bip_pos, w_src_t, w_dst_t, att_src, att_dst, dU_full, dV,
+                                                           dw_src_t, dw_dst_t, datt_src, datt_dst);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}

@@ -84,6 +84,7 @@ class RelationPack(nn.Module):
 
     def __init__(self, edge_types: List[EdgeType], rel_ids: List[int], C: int):
         super().__init__()
+        self.n_rels_total = len(edge_types)
         self.rel_ids = list(rel_ids)
         self.rel_types = [edge_types[r] for r in rel_ids]
         n = len(rel_ids)
@@ -99,6 +100,15 @@ class RelationPack(nn.Module):
         self.bias = nn.Parameter(torch.zeros(n, C))
         self.register_buffer('rel_ids_t', torch.tensor(rel_ids, dtype=torch.long), persistent=False)
         self.register_buffer('bip_t', torch.tensor(bip, dtype=torch.long), persistent=False)
+        # int32 tables of the HIP kernels: relation id of each packed slot, packed slot of each relation id (-1 =
+        # not in this pack), index into w_dst_t of each packed slot (-1 = same-type relation)
+        live_of = [-1] * len(edge_types)
+        for i, r in enumerate(rel_ids):
+            live_of[r] = i
+        self.register_buffer('rel_ids_i32', torch.tensor(rel_ids, dtype=torch.int32), persistent=False)
+        self.register_buffer('live_of_rel_i32', torch.tensor(live_of, dtype=torch.int32), persistent=False)
+        self.register_buffer('bip_pos_i32', torch.tensor([self.bip_pos.get(i, -1) for i in range(n)], dtype=torch.int32),
+                             persistent=False)
 
     # reference-named view of one tensor of relation slot i (value or gradient)
     def get(self, i: int, field: str, grad: bool = False):
@@ -240,13 +250,8 @@ class HeteroGNN(nn.Module):
         for l in range(1, self.num_layers + 1):
             P: RelationPack = self.live_packs[l - 1]
             rng = self._dst_range[l - 1]
-            # u_r = W_src^T att_src ; v_r = W_dst^T att_dst (W_src^T att_dst for same-type relations)
-            U_live = torch.bmm(P.w_src_t, P.att_src.unsqueeze(-1)).squeeze(-1)
-            V_live = torch.bmm(P.w_src_t, P.att_dst.unsqueeze(-1)).squeeze(-1)
-            if P.bip:
-                Vd = torch.bmm(P.w_dst_t, P.att_dst.index_select(0, P.bip_t).unsqueeze(-1)).squeeze(-1)
-                V_live = V_live.index_copy(0, P.bip_t, Vd)
-            U = torch.zeros(sc.NR, C, device=dev).index_copy(0, P.rel_ids_t, U_live)
+            # u_r = W_src^T att_src ; v_r = W_dst^T att_dst (W_src^T att_dst for same-type relations): one launch
+            U, V_live = ops.rel_vectors(P)
             # layer input, type-major (src_base) ; destination-side attention terms a_d[i, r]
             parts, a_parts = [], []
             for t, name in enumerate(sc.node_types):
@@ -266,16 +271,10 @@ class HeteroGNN(nn.Module):
             Zt_by_type, stat, e_edge = ops.gat_aggregate(batch, l, H, a_dst, U, self.negative_slope, self.temperature)
             if want_attention:
                 attn.append(ops.edge_alpha(batch, l, stat, e_edge, self.temperature))
-            # per-relation linear maps + bias + relation sum + ReLU: one GEMM per destination type
-            h_next = {}
-            for t, name in enumerate(sc.node_types):
-                nr = int(m.lay_rows[l - 1][t])
-                if not nr:
-                    continue
-                lo, hi = rng[t]
-                R = hi - lo
-                Zt = Zt_by_type[t].view(nr, R * C)
-                h_next[name] = ops.linear_act(Zt, P.w_src_t[lo:hi].reshape(R * C, C), P.bias[lo:hi].sum(0), True)
+            # per-relation linear maps + bias + relation sum + ReLU: one GEMM per destination type, one autograd node
+            tys = [t for t in range(sc.NT) if int(m.lay_rows[l - 1][t])]
+            outs = ops.layer_transform(P, [rng[t] for t in tys], [Zt_by_type[t] for t in tys])
+            h_next = {sc.node_types[t]: o for t, o in zip(tys, outs)}
             h = h_next
         return h, attn
 

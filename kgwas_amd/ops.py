@@ -335,3 +335,95 @@ def mlp_tail(h1, W2, b2, W3, b3):
 
 def linear_relu(x, W, b):
     return _LinearReLU.apply(x, W, b)
+
+
+# ------------------------------------------------------------------------------------------------------
+# per-layer parameter plumbing as two autograd nodes (instead of ~60 tiny framework ops per step)
+# ------------------------------------------------------------------------------------------------------
+class _RelVectors(torch.autograd.Function):
+    """(U_full [NR,C], V [n,C]) from the packed relation parameters of a layer -- kgw_relvec_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, w_src_t, w_dst_t, att_src, att_dst, pack):
+        n, C = att_src.shape
+        dev = att_src.device
+        U = torch.empty(pack.n_rels_total, C, device=dev)
+        V = torch.empty(n, C, device=dev)
+        _lib.check(_lib.lib().kgw_relvec_fwd(pack.n_rels_total, _p(pack.live_of_rel_i32), _p(pack.bip_pos_i32), _p(w_src_t),
+                                             _p(w_dst_t) if w_dst_t.numel() else 0, _p(att_src), _p(att_dst), _p(U), _p(V),
+                                             _lib.stream_ptr()), 'kgw_relvec_fwd')
+        ctx.save_for_backward(w_src_t, w_dst_t, att_src, att_dst)
+        ctx.pack = pack
+        return U, V
+
+    @staticmethod
+    def backward(ctx, dU, dV):
+        w_src_t, w_dst_t, att_src, att_dst = ctx.saved_tensors
+        pack = ctx.pack
+        n = att_src.shape[0]
+        dU = dU.contiguous(); dV = dV.contiguous()
+        dws = torch.empty_like(w_src_t)
+        dwd = torch.empty_like(w_dst_t)
+        das = torch.empty_like(att_src)
+        dad = torch.empty_like(att_dst)
+        _lib.check(_lib.lib().kgw_relvec_bwd(n, _p(pack.rel_ids_i32), _p(pack.bip_pos_i32), _p(w_src_t),
+                                             _p(w_dst_t) if w_dst_t.numel() else 0, _p(att_src), _p(att_dst), _p(dU), _p(dV),
+                                             _p(dws), _p(dwd) if dwd.numel() else 0, _p(das), _p(dad), _lib.stream_ptr()),
+                   'kgw_relvec_bwd')
+        return dws, dwd, das, dad, None
+
+
+def rel_vectors(pack):
+    return _RelVectors.apply(pack.w_src_t, pack.w_dst_t, pack.att_src, pack.att_dst, pack)
+
+
+class _LayerTransform(torch.autograd.Function):
+    """h_d = relu([Z[:, r0] | Z[:, r1] | ...] @ [W_r0^T ; W_r1^T ; ...] + sum_r bias_r) for every destination
+    type of a layer (lin_src of kgwas/conv.py:138/142 + bias :190 + HeteroConv sum model.py:74 + ReLU :75).
+    ``spans`` = [(lo, hi)] ranges of the packed relation arrays per given Z block."""
+
+    @staticmethod
+    def forward(ctx, w_src_t, bias, spans, *Zs):
+        C = bias.shape[1]
+        outs, saved = [], []
+        for (lo, hi), Z in zip(spans, Zs):
+            R = hi - lo
+            x = Z.view(-1, R * C)
+            y = linear(x, w_src_t[lo:hi].view(R * C, C), bias[lo:hi].sum(0), relu=True, w_kn=True)
+            outs.append(y)
+            saved += [x, y]
+        ctx.save_for_backward(w_src_t, *saved)
+        ctx.spans = spans
+        ctx.n_bias = bias.shape[0]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dYs):
+        w_src_t = ctx.saved_tensors[0]
+        saved = ctx.saved_tensors[1:]
+        C = w_src_t.shape[-1]
+        covered = sum(hi - lo for lo, hi in ctx.spans)
+        full = covered == w_src_t.shape[0]
+        dW = torch.empty_like(w_src_t) if full else torch.zeros_like(w_src_t)
+        db = torch.empty(ctx.n_bias, C, device=w_src_t.device) if full else torch.zeros(ctx.n_bias, C, device=w_src_t.device)
+        dZs = []
+        for k, ((lo, hi), dy) in enumerate(zip(ctx.spans, dYs)):
+            x, y = saved[2 * k], saved[2 * k + 1]
+            R = hi - lo
+            if dy is None:
+                dW[lo:hi].zero_(); db[lo:hi].zero_(); dZs.append(None)
+                continue
+            dz = torch.ops.aten.threshold_backward(dy.contiguous(), y, 0.0)
+            Wt = w_src_t[lo:hi].view(R * C, C)
+            out = dW[lo:hi].view(R * C, C)
+            if x.shape[0] >= _TN_MIN_ROWS:
+                out.copy_(tn_gemm(x, dz))
+            else:
+                torch.mm(x.t(), dz, out=out)
+            db[lo:hi] = dz.sum(0)
+            dZs.append(linear(dz, Wt).view(-1, C) if ctx.needs_input_grad[3 + k] else None)
+        return (dW, db, None) + tuple(dZs)
+
+
+def layer_transform(pack, spans, Zs):
+    return _LayerTransform.apply(pack.w_src_t, pack.bias, spans, *Zs)
