@@ -337,7 +337,10 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, 
             if (lane < Rs) P.da_src[tb + lane] = 0.f;
             continue;
         }
-        const int p0 = P.t_ptr[tb], p1 = P.t_ptr[tb + Rs];
+        // all Rs + 1 row pointers of this source in ONE load (lane k holds t_ptr[tb + k]); the per-slot logic below
+        // works on shuffles of it instead of a chain of dependent scalar loads
+        const int tpv = (lane <= Rs) ? P.t_ptr[tb + lane] : 0;
+        const int p0 = __shfl(tpv, 0, 64), p1 = __shfl(tpv, Rs, 64);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         float dasv = 0.f;                                    // lane k holds d a_src of slot k
         for (int pb = p0; pb < p1; pb += 64) {
@@ -353,7 +356,7 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, 
             }
             // per-slot sums of d pre-activation (entries of one source are grouped by slot)
             for (int k = 0; k < Rs; ++k) {
-                const int s0 = P.t_ptr[tb + k], s1 = P.t_ptr[tb + k + 1];
+                const int s0 = __shfl(tpv, k, 64), s1 = __shfl(tpv, k + 1, 64);
                 if (s1 <= pb || s0 >= pb + nb || s0 == s1) continue;
                 const int pos = pb + lane;
                 const float v = (lane < nb && pos >= s0 && pos < s1) ? dp : 0.f;
