@@ -15,6 +15,7 @@
 // are balanced at ~5 TB/s.  Waves of a block are summed through LDS, blocks through a partial buffer and a
 // second kernel in a fixed order: no atomics, deterministic.
 #include "kgw_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -414,6 +415,166 @@ __global__ void __launch_bounds__(256, 2) k_linear(LinArgs a) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------
+// K <= 128, N <= 128 (every Linear of the feature MLPs, forward and dX): persistent 8-wavefront blocks keep
+// the weight matrix RESIDENT in LDS (staged once per block) and stream 256-row X tiles through a second LDS
+// buffer in K-chunks of KC, the next chunk prefetched into registers while the MFMAs of the current one run.
+// MFMA step kp of a chunk multiplies k = lk*(KC/2) + kp (a permutation of the K order -- the sum is the same
+// set of products), so each lane's operands are CONTIGUOUS in LDS: one ds_read_b128 feeds four MFMA steps
+// (5 LDS reads per 16 MFMAs instead of 20).  Row strides of 4 mod 64 floats keep those reads conflict free.
+// Epilogue: accumulators -> the wavefront's own 32 rows of the X buffer -> full-row float4 stores.
+// ------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int WST = 132;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int KC, bool WKN>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_linear_wres(LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int XST = KC + 4;
+    float* Wl = lds;                       // [128 n][WST]
+    float* Xs = lds + 128 * WST;           // [256 rows][XST]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int nch = (a.K + KC - 1) / KC;   // 1 or 2 chunks (K <= 128)
+    // stage W once (zero outside [N, K])
+    for (int idx = tid; idx < 128 * 32; idx += 512) {
+        if (!WKN) {
+            const int n = idx >> 5, k4 = (idx & 31) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < a.N && k4 < a.K) v = *(const float4*)(a.W + (int64_t)n * a.ldw + k4);
+            *(float4*)(Wl + n * WST + k4) = v;
+        } else {
+            const int k = idx >> 5, n4 = (idx & 31) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < a.K && n4 < a.N) v = *(const float4*)(a.W + (int64_t)k * a.ldw + n4);
+            Wl[(n4 + 0) * WST + k] = v.x; Wl[(n4 + 1) * WST + k] = v.y;
+            Wl[(n4 + 2) * WST + k] = v.z; Wl[(n4 + 3) * WST + k] = v.w;
+        }
+    }
+    const int64_t ntiles = (a.rows + 255) / 256;
+    constexpr int F4 = 256 * KC / 4 / 512;             // float4 per thread per chunk (8 for KC=64, 4 for KC=32)
+    f32x4 xr[F4];
+#define KGW_FETCH(TILE, CH)                                                                            \
+    _Pragma("unroll") for (int j = 0; j < F4; ++j) {                                                   \
+        const int idx = tid + 512 * j;                                                                 \
+        const int row = idx / (KC / 4), kq = (idx % (KC / 4)) * 4;                                     \
+        int64_t r = (TILE) * 256 + row;                                                                \
+        if (r >= a.rows) r = a.rows - 1;           /* clamped rows: outputs never stored */           \
+        int k = (CH) * KC + kq;                                                                        \
+        if (k > a.K - 4) k = a.K - 4;              /* beyond K the staged weights are zero */         \
+        xr[j] = *(const f32x4*)(a.X + r * a.ldx + k);                                                   \
+    }
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) { KGW_FETCH(tile, 0) }
+    const float* wb = Wl + li * WST + lk * (KC / 2);
+    float* slice = Xs + wave * 32 * XST;               // this wavefront's 32 rows
+    const float* xa = slice + li * XST + lk * (KC / 2);
+    constexpr int Q = KC / 8;                          // groups of four MFMA steps per chunk
+    for (; tile < ntiles; tile += gridDim.x) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        for (int ch = 0; ch < nch; ++ch) {
+            __syncthreads();                            // previous chunk / epilogue done (and W staged, first time)
+#pragma unroll
+            for (int j = 0; j < F4; ++j) {
+                const int idx = tid + 512 * j;
+                *(f32x4*)(Xs + (idx / (KC / 4)) * XST + (idx % (KC / 4)) * 4) = xr[j];
+            }
+            __syncthreads();
+            // prefetch the next chunk (same tile or the block's next tile) while computing
+            {
+                const bool same = ch + 1 < nch;
+                const int64_t nt = same ? tile : tile + gridDim.x;
+                const int nc = same ? ch + 1 : 0;
+                if (nt < ntiles) { KGW_FETCH(nt, nc) }
+            }
+            const float* wk = wb + ch * KC;
+            f32x4 af[2], bf[2][4];
+            af[0] = *(const f32x4*)xa;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bf[0][t] = *(const f32x4*)(wk + t * 32 * WST);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int cur = q & 1;
+                if (q + 1 < Q) {
+                    af[cur ^ 1] = *(const f32x4*)(xa + 4 * (q + 1));
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) bf[cur ^ 1][t] = *(const f32x4*)(wk + t * 32 * WST + 4 * (q + 1));
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur].x, bf[cur][t].x, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur].y, bf[cur][t].y, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur].z, bf[cur][t].z, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur].w, bf[cur][t].w, acc[t], 0, 0, 0);
+            }
+        }
+        // epilogue through the wavefront's own rows of Xs (nobody else touches them before the next barrier)
+        constexpr int CP = (KC >= 64) ? 64 : 32;        // columns per pass
+        constexpr int LR = CP / 4;                      // lanes per output row
+        constexpr int RP = 64 / LR;                     // rows per store instruction
+        const int64_t rbase = tile * 256 + wave * 32;
+#pragma unroll
+        for (int pass = 0; pass < 128 / CP; ++pass) {
+            if (pass * CP >= a.N) continue;
+#pragma unroll
+            for (int tt = 0; tt < CP / 32; ++tt) {
+                const int t = pass * (CP / 32) + tt;
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    slice[((e & 3) + 8 * (e >> 2) + 4 * lk) * XST + tt * 32 + li] = acc[t][e];
+            }
+            const int c = (lane % LR) * 4, col = pass * CP + c;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias && col < a.N) bv = *(const float4*)(a.bias + col);
+#pragma unroll
+            for (int it = 0; it < 32 / RP; ++it) {
+                const int row = it * RP + lane / LR;
+                float4 v = *(const float4*)(slice + row * XST + c);
+                const int64_t rr = rbase + row;
+                if (rr < a.rows && col < a.N) {
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (a.mask) {
+                        const float4 m = *(const float4*)(a.mask + rr * a.ldm + col);
+                        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+                        v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                    }
+                    *(float4*)(a.Y + rr * a.ldy + col) = v;
+                }
+            }
+        }
+    }
+}
+
+#undef KGW_FETCH
+
+template <int KC, bool WKN>
+int launch_wres(const LinArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)(128 * WST + 256 * (KC + 4)) * sizeof(float);
+    auto kern = k_linear_wres<KC, WKN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        KGW_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    int64_t ntiles = (a.rows + 255) / 256;
+    int grid = (int)(ntiles < 256 ? ntiles : 256);
+    kern<<<grid, 512, lds, st>>>(a);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+}  // namespace
+
 extern "C" int kgw_linear(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias,
                           const float* mask, int64_t ldm, float* Y, int64_t ldy, int64_t rows, int32_t K,
                           int32_t N, int32_t relu, int32_t w_is_kn, kgw_stream_t stream_) {
@@ -424,6 +585,13 @@ extern "C" int kgw_linear(const float* X, int64_t ldx, const float* W, int64_t l
     if ((K & 3) || (ldx & 3) || (ldw & 3) || !aligned16(X) || !aligned16(W)) return KGW_E_UNSUPPORTED;
     if (w_is_kn && (N & 3)) return KGW_E_UNSUPPORTED;
     LinArgs a{X, ldx, W, ldw, bias, mask, ldm, Y, ldy, rows, K, N, relu, w_is_kn};
+    static const int64_t wres_min = getenv("KGW_WRES_MIN_ROWS") ? atoll(getenv("KGW_WRES_MIN_ROWS")) : 32768;
+    if (K <= 128 && N <= 128 && rows >= wres_min && (N & 3) == 0 && (ldy & 3) == 0 && aligned16(Y) && aligned16(bias) &&
+        (!mask || ((ldm & 3) == 0 && aligned16(mask)))) {           // weight-resident persistent kernel (tall inputs)
+        hipStream_t st = (hipStream_t)stream_;
+        if (w_is_kn) return K <= 32 ? launch_wres<32, true>(a, st) : launch_wres<64, true>(a, st);
+        return K <= 32 ? launch_wres<32, false>(a, st) : launch_wres<64, false>(a, st);
+    }
     dim3 grid((unsigned)((rows + LBM - 1) / LBM), (unsigned)((N + LBN - 1) / LBN));
     k_linear<<<grid, 256, 0, (hipStream_t)stream_>>>(a);
     KGW_LAUNCH_CHECK();

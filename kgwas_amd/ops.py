@@ -237,8 +237,9 @@ def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask
     ok = (X.dtype == torch.float32 and X.stride(1) == 1 and W.stride(1) == 1 and K % 4 == 0 and K <= _LIN_MAX_K
           and X.stride(0) % 4 == 0 and W.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0
           and (not w_kn or N % 4 == 0) and (mask is None or mask.stride(1) == 1)
-          # one 128x128 block per CU-slot and no split over K: short-and-wide problems stay on the library
-          and (rows >= 8192 or rows * K <= (1 << 19)))
+          # 128-row tiles, no split over K: problems with few row tiles stay on the library unless the output is
+          # wide enough to fill the chip with column tiles
+          and (rows >= 8192 or (N >= 1024 and K <= 256)))
     if not ok:
         Y = X @ (W if w_kn else W.t())
         if bias is not None:
