@@ -357,45 +357,60 @@ __global__ void __launch_bounds__(KGW_BLK) k_relabel(SampArgs A, int h) {
 }
 
 // ---- per-layer layout tables -------------------------------------------------------------------
-__global__ void k_layer_tables(SampArgs A) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void __launch_bounds__(64) k_layer_tables(SampArgs A) {
+    // one lane per (layer, node type); prefix sums over the <= KGW_MAX_TYPES types of a layer through LDS
+    __shared__ int s_lr[KGW_MAX_LAYERS][KGW_MAX_TYPES], s_ls[KGW_MAX_LAYERS][KGW_MAX_TYPES];
     const KgwGraph& G = A.G;
     KgwBatchMeta* M = A.B.meta;
-    const int L = G.n_layers;
-    // nodes first seen at the last hop keep node_off[.][n_hops+1]; fill the tail for uniform indexing
-    for (int l = 1; l <= L; ++l) {
-        const int hd = min(L - l, G.n_hops - 1);   // destination rows: hops <= hd
-        int zb = 0, sb = 0, tb = 0;
-        for (int t = 0; t < G.n_types; ++t) {
-            bool dst_live = false, src_live = false;
-            for (int r = 0; r < G.n_rels; ++r) {
-                if (!G.rel_live[l - 1][r]) continue;
-                dst_live |= (G.rel_dst[r] == t);
-                src_live |= (G.rel_src[r] == t);
-            }
-            const int nr = dst_live ? M->node_off[t][hd + 1] : 0;
-            const int ns = src_live ? M->node_off[t][hd + 2] : 0;
-            // row-block sizes of the layout: the batch's own counts, or fixed capacities (graph capture)
-            int lr = nr, ls = ns;
-            if (G.static_layout) {
-                lr = dst_live ? G.cap_rows[l - 1][t] : 0;
-                ls = src_live ? G.cap_src[l - 1][t] : 0;
-                if (nr > lr || ns > ls) M->error |= 32;
-            }
-            M->n_rows[l - 1][t] = nr;
-            M->lay_rows[l - 1][t] = lr;
-            M->z_base[l - 1][t] = zb;  zb += lr * G.R_dst[t];
-            M->n_src[l - 1][t] = ns;
-            M->lay_src[l - 1][t] = ls;
-            M->src_base[l - 1][t] = sb; sb += ls;
-            M->t_base[l - 1][t] = tb;  tb += ls * G.R_src[t];
+    const int L = G.n_layers, NT = G.n_types;
+    const int l = threadIdx.x / KGW_MAX_TYPES + 1, t = threadIdx.x % KGW_MAX_TYPES;
+    const bool on = (l <= L) && (t < NT) && threadIdx.x < KGW_MAX_LAYERS * KGW_MAX_TYPES;
+    int hd = 0, nr = 0, ns = 0, lr = 0, ls = 0, err = 0;
+    if (on) {
+        hd = min(L - l, G.n_hops - 1);             // destination rows: hops <= hd
+        bool dst_live = false, src_live = false;
+        for (int r = 0; r < G.n_rels; ++r) {
+            if (!G.rel_live[l - 1][r]) continue;
+            dst_live |= (G.rel_dst[r] == t);
+            src_live |= (G.rel_src[r] == t);
         }
-        M->z_base[l - 1][G.n_types] = zb;
-        M->src_base[l - 1][G.n_types] = sb;
-        M->t_base[l - 1][G.n_types] = tb;
-        M->n_chunks[l - 1] = M->chunk_end[hd];
-        M->n_edges[l - 1] = M->edge_end[hd];
-        if ((int64_t)tb > A.B.trow_cap) M->error |= 16;
+        nr = dst_live ? M->node_off[t][hd + 1] : 0;
+        ns = src_live ? M->node_off[t][hd + 2] : 0;
+        // row-block sizes of the layout: the batch's own counts, or fixed capacities (graph capture)
+        lr = nr; ls = ns;
+        if (G.static_layout) {
+            lr = dst_live ? G.cap_rows[l - 1][t] : 0;
+            ls = src_live ? G.cap_src[l - 1][t] : 0;
+            if (nr > lr || ns > ls) err |= 32;
+        }
+        s_lr[l - 1][t] = lr;
+        s_ls[l - 1][t] = ls;
+    }
+    __syncthreads();
+    if (on) {
+        int zb = 0, sb = 0, tb = 0;
+        for (int q = 0; q < t; ++q) {
+            zb += s_lr[l - 1][q] * G.R_dst[q];
+            sb += s_ls[l - 1][q];
+            tb += s_ls[l - 1][q] * G.R_src[q];
+        }
+        M->n_rows[l - 1][t] = nr;
+        M->lay_rows[l - 1][t] = lr;
+        M->z_base[l - 1][t] = zb;
+        M->n_src[l - 1][t] = ns;
+        M->lay_src[l - 1][t] = ls;
+        M->src_base[l - 1][t] = sb;
+        M->t_base[l - 1][t] = tb;
+        if (t == NT - 1) {
+            zb += lr * G.R_dst[t]; sb += ls; tb += ls * G.R_src[t];
+            M->z_base[l - 1][NT] = zb;
+            M->src_base[l - 1][NT] = sb;
+            M->t_base[l - 1][NT] = tb;
+            M->n_chunks[l - 1] = M->chunk_end[hd];
+            M->n_edges[l - 1] = M->edge_end[hd];
+            if ((int64_t)tb > A.B.trow_cap) err |= 16;
+        }
+        if (err) atomicOr(&M->error, err);
     }
 }
 
@@ -407,6 +422,8 @@ __global__ void k_t_begin(SampArgs A, int l) {
     M->cur[1] = M->error ? 0 : M->t_base[l - 1][A.G.n_types];
 }
 
+// One wavefront per chunk (chunks of the benchmark graph average ~100 edges: the lanes are busy; a
+// lane-per-chunk variant measured 2-4x slower because only n_chunks/64 wavefronts had work).
 template <bool FILL>
 __global__ void __launch_bounds__(KGW_BLK) k_t_pass(SampArgs A, int l) {
     const KgwGraph& G = A.G;
