@@ -430,12 +430,15 @@ constexpr int WST = 132;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int KC, bool WKN>
+// RT = rows per tile: 256 (each wavefront 32 rows x all 128 columns) for tall inputs; 64 (2 row groups x 4 column
+// groups of 32) for mid-size inputs, so that 8k-32k rows still spread over every CU.
+template <int KC, bool WKN, int RT>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_linear_wres(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int XST = KC + 4;
     float* Wl = lds;                       // [128 n][WST]
-    float* Xs = lds + 128 * WST;           // [256 rows][XST]
+    float* Xs = lds + 128 * WST;           // [RT rows][XST]
+    constexpr int WRG = RT / 32, WCG = 8 / WRG, CT = 4 / WCG;   // wave grid (rows x column groups), col tiles per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lk = lane >> 5;
     const int nch = (a.K + KC - 1) / KC;   // 1 or 2 chunks (K <= 128)
@@ -454,14 +457,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             Wl[(n4 + 2) * WST + k] = v.z; Wl[(n4 + 3) * WST + k] = v.w;
         }
     }
-    const int64_t ntiles = (a.rows + 255) / 256;
-    constexpr int F4 = 256 * KC / 4 / 512;             // float4 per thread per chunk (8 for KC=64, 4 for KC=32)
+    const int64_t ntiles = (a.rows + RT - 1) / RT;
+    constexpr int F4 = RT * KC / 4 / 512;              // float4 per thread per chunk
     f32x4 xr[F4];
 #define KGW_FETCH(TILE, CH)                                                                            \
     _Pragma("unroll") for (int j = 0; j < F4; ++j) {                                                   \
         const int idx = tid + 512 * j;                                                                 \
         const int row = idx / (KC / 4), kq = (idx % (KC / 4)) * 4;                                     \
-        int64_t r = (TILE) * 256 + row;                                                                \
+        int64_t r = (TILE) * RT + row;                                                                 \
         if (r >= a.rows) r = a.rows - 1;           /* clamped rows: outputs never stored */           \
         int k = (CH) * KC + kq;                                                                        \
         if (k > a.K - 4) k = a.K - 4;              /* beyond K the staged weights are zero */         \
@@ -469,14 +472,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     int64_t tile = blockIdx.x;
     if (tile < ntiles) { KGW_FETCH(tile, 0) }
-    const float* wb = Wl + li * WST + lk * (KC / 2);
-    float* slice = Xs + wave * 32 * XST;               // this wavefront's 32 rows
+    const int rg = wave % WRG, cg = wave / WRG;
+    const float* wb = Wl + (cg * CT * 32 + li) * WST + lk * (KC / 2);
+    float* slice = Xs + rg * 32 * XST;                 // this wavefront's 32 rows (private when WCG == 1)
     const float* xa = slice + li * XST + lk * (KC / 2);
     constexpr int Q = KC / 8;                          // groups of four MFMA steps per chunk
     for (; tile < ntiles; tile += gridDim.x) {
-        f32x16 acc[4];
+        f32x16 acc[CT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < CT; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
         for (int ch = 0; ch < nch; ++ch) {
@@ -495,33 +499,34 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 if (nt < ntiles) { KGW_FETCH(nt, nc) }
             }
             const float* wk = wb + ch * KC;
-            f32x4 af[2], bf[2][4];
+            f32x4 af[2], bf[2][CT];
             af[0] = *(const f32x4*)xa;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bf[0][t] = *(const f32x4*)(wk + t * 32 * WST);
+            for (int t = 0; t < CT; ++t) bf[0][t] = *(const f32x4*)(wk + t * 32 * WST);
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
                 const int cur = q & 1;
                 if (q + 1 < Q) {
                     af[cur ^ 1] = *(const f32x4*)(xa + 4 * (q + 1));
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) bf[cur ^ 1][t] = *(const f32x4*)(wk + t * 32 * WST + 4 * (q + 1));
+                    for (int t = 0; t < CT; ++t) bf[cur ^ 1][t] = *(const f32x4*)(wk + t * 32 * WST + 4 * (q + 1));
                 }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur].x, bf[cur][t].x, acc[t], 0, 0, 0);
+                for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur].x, bf[cur][t].x, acc[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur].y, bf[cur][t].y, acc[t], 0, 0, 0);
+                for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur].y, bf[cur][t].y, acc[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur].z, bf[cur][t].z, acc[t], 0, 0, 0);
+                for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur].z, bf[cur][t].z, acc[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur].w, bf[cur][t].w, acc[t], 0, 0, 0);
+                for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur].w, bf[cur][t].w, acc[t], 0, 0, 0);
             }
         }
+        if constexpr (WCG == 1) {
         // epilogue through the wavefront's own rows of Xs (nobody else touches them before the next barrier)
         constexpr int CP = (KC >= 64) ? 64 : 32;        // columns per pass
         constexpr int LR = CP / 4;                      // lanes per output row
         constexpr int RP = 64 / LR;                     // rows per store instruction
-        const int64_t rbase = tile * 256 + wave * 32;
+        const int64_t rbase = tile * RT + rg * 32;
 #pragma unroll
         for (int pass = 0; pass < 128 / CP; ++pass) {
             if (pass * CP >= a.N) continue;
@@ -552,21 +557,48 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
             }
         }
+        } else {
+        // the A rows are shared by WCG wavefronts: store straight from the accumulators (32 lanes = one 128-B
+        // row segment); all mask loads are issued before the first store
+        static_assert(CT == 1 || WCG == 1, "direct epilogue handles one column tile per wavefront");
+        const int col = cg * 32 + li;
+        const int64_t rbase = tile * RT + rg * 32 + 4 * lk;
+        if (col < a.N) {
+            const float bv = a.bias ? a.bias[col] : 0.f;
+            float mv[16];
+            if (a.mask) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    int64_t rr = rbase + (e & 3) + 8 * (e >> 2);
+                    if (rr >= a.rows) rr = a.rows - 1;
+                    mv[e] = a.mask[rr * a.ldm + col];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t rr = rbase + (e & 3) + 8 * (e >> 2);
+                float v = acc[0][e] + bv;
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (a.mask) v = mv[e] > 0.f ? v : 0.f;
+                if (rr < a.rows) a.Y[rr * a.ldy + col] = v;
+            }
+        }
+        }
     }
 }
 
 #undef KGW_FETCH
 
-template <int KC, bool WKN>
+template <int KC, bool WKN, int RT>
 int launch_wres(const LinArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)(128 * WST + 256 * (KC + 4)) * sizeof(float);
-    auto kern = k_linear_wres<KC, WKN>;
+    const size_t lds = (size_t)(128 * WST + RT * (KC + 4)) * sizeof(float);
+    auto kern = k_linear_wres<KC, WKN, RT>;
     static bool attr_set = false;
     if (!attr_set) {
         KGW_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    int64_t ntiles = (a.rows + 255) / 256;
+    int64_t ntiles = (a.rows + RT - 1) / RT;
     int grid = (int)(ntiles < 256 ? ntiles : 256);
     kern<<<grid, 512, lds, st>>>(a);
     KGW_LAUNCH_CHECK();
@@ -585,12 +617,17 @@ extern "C" int kgw_linear(const float* X, int64_t ldx, const float* W, int64_t l
     if ((K & 3) || (ldx & 3) || (ldw & 3) || !aligned16(X) || !aligned16(W)) return KGW_E_UNSUPPORTED;
     if (w_is_kn && (N & 3)) return KGW_E_UNSUPPORTED;
     LinArgs a{X, ldx, W, ldw, bias, mask, ldm, Y, ldy, rows, K, N, relu, w_is_kn};
-    static const int64_t wres_min = getenv("KGW_WRES_MIN_ROWS") ? atoll(getenv("KGW_WRES_MIN_ROWS")) : 32768;
+    static const int64_t wres_min = getenv("KGW_WRES_MIN_ROWS") ? atoll(getenv("KGW_WRES_MIN_ROWS")) : 4096;
+    static const int64_t wres_tall = getenv("KGW_WRES_TALL_ROWS") ? atoll(getenv("KGW_WRES_TALL_ROWS")) : 32768;
     if (K <= 128 && N <= 128 && rows >= wres_min && (N & 3) == 0 && (ldy & 3) == 0 && aligned16(Y) && aligned16(bias) &&
         (!mask || ((ldm & 3) == 0 && aligned16(mask)))) {           // weight-resident persistent kernel (tall inputs)
         hipStream_t st = (hipStream_t)stream_;
-        if (w_is_kn) return K <= 32 ? launch_wres<32, true>(a, st) : launch_wres<64, true>(a, st);
-        return K <= 32 ? launch_wres<32, false>(a, st) : launch_wres<64, false>(a, st);
+        if (rows >= wres_tall) {
+            if (w_is_kn) return K <= 32 ? launch_wres<32, true, 256>(a, st) : launch_wres<64, true, 256>(a, st);
+            return K <= 32 ? launch_wres<32, false, 256>(a, st) : launch_wres<64, false, 256>(a, st);
+        }
+        if (w_is_kn) return K <= 32 ? launch_wres<32, true, 64>(a, st) : launch_wres<64, true, 64>(a, st);
+        return K <= 32 ? launch_wres<32, false, 64>(a, st) : launch_wres<64, false, 64>(a, st);
     }
     dim3 grid((unsigned)((rows + LBM - 1) / LBM), (unsigned)((N + LBN - 1) / LBN));
     k_linear<<<grid, 256, 0, (hipStream_t)stream_>>>(a);

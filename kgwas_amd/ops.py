@@ -239,7 +239,7 @@ def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask
           and (not w_kn or N % 4 == 0) and (mask is None or mask.stride(1) == 1)
           # 128-row tiles, no split over K: problems with few row tiles stay on the library unless the output is
           # wide enough to fill the chip with column tiles
-          and (rows >= 8192 or (N >= 1024 and K <= 256)))
+          and (rows >= 8192 or (N >= 1024 and K <= 256) or (rows >= 4096 and K <= 128 and N <= 128)))
     if not ok:
         Y = X @ (W if w_kn else W.t())
         if bias is not None:
