@@ -148,7 +148,7 @@ typedef struct KgwLayerArgs {
     float* part_da;                /* [n_chunks]                                               */
     const int32_t* t_ptr; const int32_t* t_edge; const int32_t* t_zrow;
     float* dH;                     /* [n_src_rows][128]                                        */
-    float* da_src;                 /* [t rows] d a_src per (source row, relation slot)         */
+    float* da_src;                 /* [n_src_rows][(n_rels+3)&~3] d a_src per (source row, relation id) */
 } KgwLayerArgs;
 
 /* ---- entry points ------------------------------------------------------------------------ */
@@ -191,6 +191,15 @@ int64_t kgw_tn_gemm_workspace_floats(int64_t rows, int32_t M, int32_t N);
 int kgw_tn_gemm(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
                 int64_t rows, float* C, int64_t ldc, float* colsum_a, float* workspace,
                 int64_t workspace_floats, kgw_stream_t stream);
+/* Same product with two output options that let the gradient land where the caller keeps it (no copy / reduce
+ * launches afterwards): c_transposed != 0 stores C^T, i.e. element (m,n) at C[n*ldc + m] (the packed per-relation
+ * weights are kept transposed, [in, out]); colsum_a is written colsum_repeat times, copy q at
+ * colsum_a + q*colsum_ld (the bias gradient of every relation summed into one destination type is the same
+ * vector: HeteroConv sum, kgwas/model.py:74).                                                              */
+int kgw_tn_gemm_ex(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
+                   int64_t rows, float* C, int64_t ldc, int32_t c_transposed, float* colsum_a,
+                   int32_t colsum_repeat, int64_t colsum_ld, float* workspace, int64_t workspace_floats,
+                   kgw_stream_t stream);
 
 /* Y[rows,N] = act(X[rows,K] * Wop + bias) * (mask > 0): the Linear layers of the path on fp32 MFMA.
  * w_is_kn = 0: W is [N,K] (nn.Linear / PyG Linear forward, kgwas/model.py:13-21,50; kgwas/conv.py:138,142);

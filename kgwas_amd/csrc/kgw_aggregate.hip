@@ -40,6 +40,9 @@ struct LayerTab {
     int32_t type_t_base[KGW_MAX_TYPES + 1];
     int32_t type_R_src[KGW_MAX_TYPES];
     int32_t rel_of_slot[KGW_MAX_TYPES][KGW_MAX_RELS / 2];   // relation id of (source type, slot)
+    int8_t rel_src_type[KGW_MAX_RELS];                      // source type of relation r
+    int8_t rel_slot_src[KGW_MAX_RELS];                      // its slot among the relations of that source type
+    int32_t ld_da;                                          // row stride of da_src (n_rels rounded up to 4)
 };
 
 struct AggPtrs {
@@ -334,7 +337,7 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, 
         const int tb = T.type_t_base[ty] + j * Rs;
         if (j >= P.meta->n_src[P.layer - 1][ty]) {          // padding row of a static layout: no gradient
             if (half == 0) ((float4*)(P.dH + (int64_t)u * KGW_C))[hl] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (lane < Rs) P.da_src[tb + lane] = 0.f;
+            if (lane < T.ld_da) P.da_src[(int64_t)u * T.ld_da + lane] = 0.f;
             continue;
         }
         // all Rs + 1 row pointers of this source in ONE load (lane k holds t_ptr[tb + k]); the per-slot logic below
@@ -384,7 +387,13 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, 
             }
         }
         if (half == 0) ((float4*)(P.dH + (int64_t)u * KGW_C))[hl] = acc;
-        if (lane < Rs) P.da_src[tb + lane] = dasv;
+        // d a_src row of this source, one column per RELATION ID (zero for relations of other source types): the
+        // caller gets d u_r = sum_j d a_src[j, r] * H[j] for all relations as ONE tall-skinny product
+        {
+            const bool mine = lane < T.n_rels && T.rel_src_type[lane] == ty;
+            const float v = __shfl(dasv, mine ? T.rel_slot_src[lane] : 0, 64);
+            if (lane < T.ld_da) P.da_src[(int64_t)u * T.ld_da + lane] = mine ? v : 0.f;
+        }
     }
 }
 
@@ -416,6 +425,7 @@ int build_tab(const KgwLayerArgs* a, LayerTab* T) {
     if (G->n_rels > KGW_MAX_RELS || G->n_types > KGW_MAX_TYPES) return KGW_E_RANGE;
     T->n_rels = G->n_rels;
     T->n_types = G->n_types;
+    T->ld_da = (G->n_rels + 3) & ~3;
     for (int r = 0; r < G->n_rels; ++r) {
         const int s = G->rel_src[r], d = G->rel_dst[r];
         T->src_base[r] = M->src_base[l - 1][s];
@@ -424,6 +434,8 @@ int build_tab(const KgwLayerArgs* a, LayerTab* T) {
         T->live[r] = G->rel_live[l - 1][r];
         if (G->rel_slot_src[r] >= KGW_MAX_RELS / 2) return KGW_E_RANGE;
         T->rel_of_slot[s][G->rel_slot_src[r]] = r;
+        T->rel_src_type[r] = (int8_t)s;
+        T->rel_slot_src[r] = (int8_t)G->rel_slot_src[r];
     }
     for (int t = 0; t <= G->n_types; ++t) {
         T->type_src_base[t] = M->src_base[l - 1][t];

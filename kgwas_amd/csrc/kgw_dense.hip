@@ -183,8 +183,8 @@ __global__ void __launch_bounds__(256, 1) k_tn_gemm(const float* __restrict__ A,
 // Block = 64 fragment elements x 4 groups of row-blocks; every thread keeps 8 loads in flight.
 template <int MT, int NT>
 __global__ void __launch_bounds__(256) k_tn_reduce(const float* __restrict__ ws, const float* __restrict__ ws_colsum,
-                                                   int nblk, int gy, int M, int N, float* __restrict__ C, int64_t ldc,
-                                                   float* __restrict__ colsum) {
+                                                   int nblk, int gy, int M, int N, float* __restrict__ C, int64_t c_rs,
+                                                   int64_t c_cs, float* __restrict__ colsum, int cs_rep, int64_t cs_ld) {
     constexpr int FRAG = MT * NT * 16 * 64;
     __shared__ float sm[256];
     const int by = blockIdx.y, bz = blockIdx.z;
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) k_tn_reduce(const float* __restrict__ ws,
         const int ti = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);     // row of the 32x32 tile
         const int tj = lane & 31;                                     // column of the tile
         const int m = m0 + MT * ti + ta, n = n0 + NT * tj + tb;
-        if (m < M && n < N) C[(int64_t)m * ldc + n] = s;
+        if (m < M && n < N) C[(int64_t)m * c_rs + (int64_t)n * c_cs] = s;
     }
     if (colsum && bz == 0 && blockIdx.x == 0) {
         // 32*MT columns x (256 / (32*MT)) groups of row-blocks, 4 loads in flight per thread, fixed order
@@ -229,14 +229,16 @@ __global__ void __launch_bounds__(256) k_tn_reduce(const float* __restrict__ ws,
         if (gq == 0) {
             float t = 0.f;
             for (int q = 0; q < NG; ++q) t += sm[q * NC + c];
-            if (m0 + c < M) colsum[m0 + c] = t;
+            if (m0 + c < M)
+                for (int q = 0; q < cs_rep; ++q) colsum[(int64_t)q * cs_ld + m0 + c] = t;
         }
     }
 }
 
 template <int MT, int NT>
 int launch_tn(const float* A, int64_t lda, int M, const float* B, int64_t ldb, int N, int64_t rows, float* C,
-              int64_t ldc, float* colsum, float* ws, int64_t ws_floats, hipStream_t st) {
+              int64_t ldc, bool c_t, float* colsum, int cs_rep, int64_t cs_ld, float* ws, int64_t ws_floats,
+              hipStream_t st) {
     constexpr int FRAG = MT * NT * 16 * 64;
     const int gy = (M + 32 * MT - 1) / (32 * MT), gz = (N + 32 * NT - 1) / (32 * NT);
     // one block per CU at most; at least 64 rows per wavefront
@@ -259,7 +261,8 @@ int launch_tn(const float* A, int64_t lda, int M, const float* B, int64_t ldb, i
     }
     kern<<<dim3((unsigned)nblk, gy, gz), 256, lds_bytes, st>>>(A, lda, M, B, ldb, N, rows, rpw, ws, ws_cs);
     KGW_LAUNCH_CHECK();
-    k_tn_reduce<MT, NT><<<dim3(FRAG / 64, gy, gz), 256, 0, st>>>(ws, ws_cs, (int)nblk, gy, M, N, C, ldc, colsum);
+    k_tn_reduce<MT, NT><<<dim3(FRAG / 64, gy, gz), 256, 0, st>>>(ws, ws_cs, (int)nblk, gy, M, N, C, c_t ? 1 : ldc,
+                                                                 c_t ? ldc : 1, colsum, cs_rep, cs_ld);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }
@@ -277,20 +280,30 @@ extern "C" int64_t kgw_tn_gemm_workspace_floats(int64_t rows, int M, int N) {
     return nblk * gy1 * gz1 * 1024 + nblk * gy1 * 32 + 4096;   // 1024 floats per 32x32 tile per row-block
 }
 
-extern "C" int kgw_tn_gemm(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
-                           int64_t rows, float* C, int64_t ldc, float* colsum_a, float* workspace,
-                           int64_t workspace_floats, kgw_stream_t stream_) {
+extern "C" int kgw_tn_gemm_ex(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
+                              int64_t rows, float* C, int64_t ldc, int32_t c_transposed, float* colsum_a,
+                              int32_t colsum_repeat, int64_t colsum_ld, float* workspace, int64_t workspace_floats,
+                              kgw_stream_t stream_) {
     if (!A || !B || !C || !workspace) return KGW_E_NULL;
-    if (M <= 0 || N <= 0 || rows <= 0 || lda < M || ldb < N || ldc < N) return KGW_E_RANGE;
+    if (M <= 0 || N <= 0 || rows <= 0 || lda < M || ldb < N || ldc < (c_transposed ? M : N)) return KGW_E_RANGE;
+    if (colsum_a && (colsum_repeat < 1 || (colsum_repeat > 1 && colsum_ld < M))) return KGW_E_RANGE;
     hipStream_t st = (hipStream_t)stream_;
+    const bool ct = c_transposed != 0;
+    const int rep = colsum_a ? colsum_repeat : 0;
     const bool a4 = (M % 4 == 0) && (lda % 4 == 0) && aligned16(A) && M >= 128;
     const bool b4 = (N % 4 == 0) && (ldb % 4 == 0) && aligned16(B) && N >= 128;
     // the 128x128 accumulator pays a fixed ~25 us block epilogue (64 KB per block through LDS): worth it only for
     // very tall inputs; shorter ones split N over blockIdx.z with 128x32 accumulators instead
-    if (a4 && b4 && rows >= 65536) return launch_tn<4, 4>(A, lda, M, B, ldb, N, rows, C, ldc, colsum_a, workspace, workspace_floats, st);
-    if (a4)       return launch_tn<4, 1>(A, lda, M, B, ldb, N, rows, C, ldc, colsum_a, workspace, workspace_floats, st);
-    if (b4)       return launch_tn<1, 4>(A, lda, M, B, ldb, N, rows, C, ldc, colsum_a, workspace, workspace_floats, st);
-    return launch_tn<1, 1>(A, lda, M, B, ldb, N, rows, C, ldc, colsum_a, workspace, workspace_floats, st);
+    if (a4 && b4 && rows >= 65536) return launch_tn<4, 4>(A, lda, M, B, ldb, N, rows, C, ldc, ct, colsum_a, rep, colsum_ld, workspace, workspace_floats, st);
+    if (a4)       return launch_tn<4, 1>(A, lda, M, B, ldb, N, rows, C, ldc, ct, colsum_a, rep, colsum_ld, workspace, workspace_floats, st);
+    if (b4)       return launch_tn<1, 4>(A, lda, M, B, ldb, N, rows, C, ldc, ct, colsum_a, rep, colsum_ld, workspace, workspace_floats, st);
+    return launch_tn<1, 1>(A, lda, M, B, ldb, N, rows, C, ldc, ct, colsum_a, rep, colsum_ld, workspace, workspace_floats, st);
+}
+
+extern "C" int kgw_tn_gemm(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
+                           int64_t rows, float* C, int64_t ldc, float* colsum_a, float* workspace,
+                           int64_t workspace_floats, kgw_stream_t stream_) {
+    return kgw_tn_gemm_ex(A, lda, M, B, ldb, N, rows, C, ldc, 0, colsum_a, 1, M, workspace, workspace_floats, stream_);
 }
 
 // ======================================================================================================

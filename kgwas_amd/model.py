@@ -268,12 +268,13 @@ class HeteroGNN(nn.Module):
                     a_parts.append((hd @ V_live[lo:hi].t()).reshape(-1))
             H = torch.cat(parts, 0) if len(parts) != 1 else parts[0]
             a_dst = torch.cat(a_parts) if len(a_parts) != 1 else a_parts[0]
-            Zt_by_type, stat, e_edge = ops.gat_aggregate(batch, l, H, a_dst, U, self.negative_slope, self.temperature)
+            Z, stat, e_edge = ops.gat_aggregate(batch, l, H, a_dst, U, self.negative_slope, self.temperature)
             if want_attention:
                 attn.append(ops.edge_alpha(batch, l, stat, e_edge, self.temperature))
             # per-relation linear maps + bias + relation sum + ReLU: one GEMM per destination type, one autograd node
             tys = [t for t in range(sc.NT) if int(m.lay_rows[l - 1][t])]
-            outs = ops.layer_transform(P, [rng[t] for t in tys], [Zt_by_type[t] for t in tys])
+            blocks = [(rng[t][0], rng[t][1], int(m.z_base[l - 1][t]), int(m.lay_rows[l - 1][t])) for t in tys]
+            outs = ops.layer_transform(P, Z, blocks)
             h_next = {sc.node_types[t]: o for t, o in zip(tys, outs)}
             h = h_next
         return h, attn

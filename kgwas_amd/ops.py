@@ -101,24 +101,11 @@ class _GatAggregate(torch.autograd.Function):
         ctx.save_for_backward(H, U, Z, stat, e_edge)
         ctx.batch, ctx.layer, ctx.neg_slope, ctx.inv_temp = batch, layer, neg_slope, inv_temp
         ctx.mark_non_differentiable(stat, e_edge)
-        # one output per destination type (a view of its row block): the caller never slices Z, so autograd never
-        # has to zero-fill + copy a full-size gradient per slice
-        sc = dg.schema
-        outs, spans = [], []
-        for t in range(NT):
-            nr = int(m.lay_rows[layer - 1][t]) * int(sc.R_dst[t])
-            if nr:
-                zb = int(m.z_base[layer - 1][t])
-                outs.append(Z[zb:zb + nr])
-                spans.append((zb, nr))
-        ctx.spans = spans
-        return (stat, e_edge) + tuple(outs)
+        return stat, e_edge, Z[:z_rows]
 
     @staticmethod
-    def backward(ctx, _dstat, _de, *dZs):
+    def backward(ctx, _dstat, _de, dZ):
         H, U, Z, stat, e_edge = ctx.saved_tensors
-        pieces = [d if d is not None else torch.zeros(n, KGW_C, device=H.device) for d, (_, n) in zip(dZs, ctx.spans)]
-        dZ = pieces[0] if len(pieces) == 1 else (torch.cat(pieces, 0) if pieces else None)
         batch, layer = ctx.batch, ctx.layer
         dg, m = batch.dg, batch.meta
         sc = dg.schema
@@ -134,7 +121,8 @@ class _GatAggregate(torch.autograd.Function):
         da_dst = torch.zeros(max(z_rows, 1), device=dev)
         part_da = torch.empty(max(n_chunks, 1), device=dev)
         dH = torch.empty(max(n_src, 1), KGW_C, device=dev)
-        da_src = torch.empty(max(t_rows, 1), device=dev)
+        ld_da = (sc.NR + 3) & ~3
+        da_src = torch.empty(max(n_src, 1), ld_da, device=dev)    # [source row, relation id]
         a = _layer_args(batch, layer, ctx.neg_slope, ctx.inv_temp)
         a.H, a.U, a.Z, a.stat, a.e_edge = _p(H), _p(U), _p(Z), _p(stat), _p(e_edge)
         a.dZ, a.adp, a.da_dst, a.part_da = _p(dZf), _p(adp), _p(da_dst), _p(part_da)
@@ -146,40 +134,24 @@ class _GatAggregate(torch.autograd.Function):
         ev = TIMER.bracket('bwd_src', layer, n_edges, z_rows, n_src)
         _lib.check(L.kgw_gat_aggregate_bwd_src(C.byref(a), _lib.stream_ptr()), 'kgw_gat_aggregate_bwd_src')
         TIMER.close(ev)
-        # d u_r = sum_j d a_src[j, r] * H_s[j]   (a_s = <H_s[j], u_r>)
-        dU = torch.zeros_like(U)
-        for t in range(NT):
-            ns, Rs = int(m.lay_src[layer - 1][t]), int(sc.R_src[t])
-            if ns == 0 or Rs == 0:
-                continue
-            tb, sb = int(m.t_base[layer - 1][t]), int(m.src_base[layer - 1][t])
-            blk = da_src[tb:tb + ns * Rs].view(ns, Rs)
-            Hs = H[sb:sb + ns]
-            # index tensors live on the device (a python list would be uploaded synchronously -- illegal while a
-            # HIP graph is being captured)
-            dU.index_copy_(0, dg.rels_by_src_t[t], tn_gemm(blk, Hs) if ns >= _TN_MIN_ROWS else blk.t() @ Hs)
+        # d u_r = sum_j d a_src[j, r] * H[j]   (a_s = <H[j], u_r>): all relations in one tall-skinny product
+        if n_src:
+            dU = tn_gemm(da_src[:n_src, :sc.NR], H[:n_src])
+        else:
+            dU = torch.zeros_like(U)
         return dH[:n_src], da_dst[:z_rows], dU, None, None, None, None
 
 
 def gat_aggregate(batch, layer: int, H: torch.Tensor, a_dst: torch.Tensor, U: torch.Tensor,
                   neg_slope: float = 0.2, temperature: float = 1.0):
-    """Returns (Z_by_type, stat [z_rows,2] = (row max, denominator), e_edge [n_edges]); ``Z_by_type[t]`` is the
-    [rows_t * R_dst[t], 128] block of destination type t (only types with rows in this layer)."""
-    res = _GatAggregate.apply(H, a_dst, U, batch, layer, float(neg_slope), 1.0 / float(temperature))
-    stat, e_edge, outs = res[0], res[1], res[2:]
-    m, sc = batch.meta, batch.dg.schema
-    zt, k = {}, 0
-    for t in range(sc.NT):
-        if int(m.lay_rows[layer - 1][t]) * int(sc.R_dst[t]):
-            zt[t] = outs[k]; k += 1
-    return zt, stat, e_edge
+    """Returns (Z [z_rows,128], stat [z_rows,2] = (row max, denominator), e_edge [n_edges]); Z is type-major:
+    the block of destination type t starts at row ``meta.z_base[layer-1][t]`` and holds ``lay_rows * R_dst[t]``
+    rows ([row, relation slot, 128])."""
+    stat, e_edge, Z = _GatAggregate.apply(H, a_dst, U, batch, layer, float(neg_slope), 1.0 / float(temperature))
+    return Z, stat, e_edge
 
 
-def gat_aggregate_flat(batch, layer, H, a_dst, U, neg_slope=0.2, temperature=1.0):
-    """Same, with the per-type blocks concatenated into Z [z_rows, 128] (tests / callers that want one tensor)."""
-    zt, stat, e_edge = gat_aggregate(batch, layer, H, a_dst, U, neg_slope, temperature)
-    parts = [zt[t] for t in sorted(zt)]
-    return (parts[0] if len(parts) == 1 else torch.cat(parts, 0)), stat, e_edge
+gat_aggregate_flat = gat_aggregate
 
 
 def edge_alpha(batch, layer: int, stat: torch.Tensor, e_edge: torch.Tensor, temperature: float = 1.0):
@@ -198,9 +170,12 @@ def edge_alpha(batch, layer: int, stat: torch.Tensor, e_edge: torch.Tensor, temp
 _TN_MIN_ROWS = 1024       # below this a library GEMM is fine
 
 
-def tn_gemm(A: torch.Tensor, B: torch.Tensor, colsum: bool = False):
+def tn_gemm(A: torch.Tensor, B: torch.Tensor, colsum: bool = False, out: torch.Tensor = None,
+            transpose_out: bool = False, colsum_out: torch.Tensor = None):
     """C = A^T @ B for tall row-major A [rows, M], B [rows, N] (fp32, inner stride 1); optionally also the
-    column sums of A.  Deterministic split-K on fp32 MFMA."""
+    column sums of A.  Deterministic split-K on fp32 MFMA.  ``out``: write C (or C^T with ``transpose_out``) into
+    this row-major 2-D view instead of a new tensor; ``colsum_out`` [q, M]: write the column sums into each of its
+    q rows."""
     assert A.dim() == 2 and B.dim() == 2 and A.shape[0] == B.shape[0]
     assert A.dtype == torch.float32 and B.dtype == torch.float32
     if A.stride(1) != 1:
@@ -210,25 +185,35 @@ def tn_gemm(A: torch.Tensor, B: torch.Tensor, colsum: bool = False):
     rows, M = A.shape
     N = B.shape[1]
     dev = A.device
-    C_ = torch.empty(M, N, device=dev)
-    cs = torch.empty(M, device=dev) if colsum else None
+    if out is None:
+        out = torch.empty((N, M) if transpose_out else (M, N), device=dev)
+    assert out.shape == ((N, M) if transpose_out else (M, N)) and out.stride(1) == 1
+    cs = None
+    rep, cs_ld = 1, M
+    if colsum_out is not None:
+        assert colsum_out.dim() == 2 and colsum_out.shape[1] == M and colsum_out.stride(1) == 1
+        cs, rep, cs_ld = colsum_out, colsum_out.shape[0], colsum_out.stride(0)
+    elif colsum:
+        cs = torch.empty(M, device=dev)
     if rows == 0:
-        C_.zero_()
+        out.zero_()
         if cs is not None:
             cs.zero_()
-        return (C_, cs) if colsum else C_
+        return (out, cs) if (colsum or colsum_out is not None) else out
     L = _lib.lib()
     nws = int(L.kgw_tn_gemm_workspace_floats(rows, M, N))
     ws = torch.empty(nws, device=dev)
-    _lib.check(L.kgw_tn_gemm(_p(A), A.stride(0), M, _p(B), B.stride(0), N, rows, _p(C_), N, _p(cs), _p(ws), nws,
-                             _lib.stream_ptr()), 'kgw_tn_gemm')
-    return (C_, cs) if colsum else C_
+    _lib.check(L.kgw_tn_gemm_ex(_p(A), A.stride(0), M, _p(B), B.stride(0), N, rows, _p(out), out.stride(0),
+                                1 if transpose_out else 0, _p(cs), rep, cs_ld, _p(ws), nws, _lib.stream_ptr()),
+               'kgw_tn_gemm_ex')
+    return (out, cs) if (colsum or colsum_out is not None) else out
 
 
 _LIN_MAX_K = 2304        # wider reductions (the 5120 / 57742-wide gene layer) go to the library GEMM
 
 
-def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask=None, w_kn: bool = False):
+def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask=None, w_kn: bool = False,
+           out: torch.Tensor = None):
     """Y = act(X @ Wop + bias) * (mask > 0) on the fp32-MFMA kernel (kgw_linear); Wop = W^T for W [N,K]
     (nn.Linear forward) or W for W [K,N] (w_kn: the dX product).  Shapes the kernel does not take
     (K or leading dimensions not multiples of 4, very wide K) run on the library GEMM with identical math."""
@@ -241,6 +226,8 @@ def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask
           # wide enough to fill the chip with column tiles
           and (rows >= 8192 or (N >= 1024 and K <= 256) or (rows >= 4096 and K <= 128 and N <= 128)))
     if not ok:
+        if out is not None and bias is None and not relu and mask is None:
+            return torch.mm(X, W if w_kn else W.t(), out=out)
         Y = X @ (W if w_kn else W.t())
         if bias is not None:
             Y = Y + bias
@@ -248,11 +235,15 @@ def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask
             Y = torch.relu_(Y)
         if mask is not None:
             Y = Y * (mask > 0)
+        if out is not None:
+            out.copy_(Y)
+            return out
         return Y
-    Y = torch.empty(rows, N, device=X.device)
+    Y = torch.empty(rows, N, device=X.device) if out is None else out
+    assert Y.shape == (rows, N) and Y.stride(1) == 1
     if rows:
         _lib.check(_lib.lib().kgw_linear(_p(X), X.stride(0), _p(W), W.stride(0), _p(bias), _p(mask),
-                                         mask.stride(0) if mask is not None else 0, _p(Y), N, rows, K, N,
+                                         mask.stride(0) if mask is not None else 0, _p(Y), Y.stride(0), rows, K, N,
                                          1 if relu else 0, 1 if w_kn else 0, _lib.stream_ptr()), 'kgw_linear')
     return Y
 
@@ -381,50 +372,53 @@ def rel_vectors(pack):
 class _LayerTransform(torch.autograd.Function):
     """h_d = relu([Z[:, r0] | Z[:, r1] | ...] @ [W_r0^T ; W_r1^T ; ...] + sum_r bias_r) for every destination
     type of a layer (lin_src of kgwas/conv.py:138/142 + bias :190 + HeteroConv sum model.py:74 + ReLU :75).
-    ``spans`` = [(lo, hi)] ranges of the packed relation arrays per given Z block."""
+    ``Z`` is the aggregate's type-major output; ``blocks`` = [(lo, hi, z0, rows)]: relations [lo, hi) of the packed
+    arrays feed the destination type whose block starts at Z row z0 and has ``rows`` destination rows."""
 
     @staticmethod
-    def forward(ctx, w_src_t, bias, spans, *Zs):
+    def forward(ctx, w_src_t, bias, Z, blocks):
         C = bias.shape[1]
-        outs, saved = [], []
-        for (lo, hi), Z in zip(spans, Zs):
+        outs, ys = [], []
+        for lo, hi, z0, rows in blocks:
             R = hi - lo
-            x = Z.view(-1, R * C)
+            x = Z[z0:z0 + rows * R].view(rows, R * C)
             y = linear(x, w_src_t[lo:hi].view(R * C, C), bias[lo:hi].sum(0), relu=True, w_kn=True)
             outs.append(y)
-            saved += [x, y]
-        ctx.save_for_backward(w_src_t, *saved)
-        ctx.spans = spans
+            ys.append(y)
+        ctx.save_for_backward(w_src_t, Z, *ys)
+        ctx.blocks = blocks
         ctx.n_bias = bias.shape[0]
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *dYs):
-        w_src_t = ctx.saved_tensors[0]
-        saved = ctx.saved_tensors[1:]
+        w_src_t, Z = ctx.saved_tensors[:2]
+        ys = ctx.saved_tensors[2:]
         C = w_src_t.shape[-1]
-        covered = sum(hi - lo for lo, hi in ctx.spans)
-        full = covered == w_src_t.shape[0]
+        blocks = ctx.blocks
+        covered = sum(hi - lo for lo, hi, _, _ in blocks)
+        full = covered == w_src_t.shape[0] and all(d is not None for d in dYs)
+        dev = w_src_t.device
         dW = torch.empty_like(w_src_t) if full else torch.zeros_like(w_src_t)
-        db = torch.empty(ctx.n_bias, C, device=w_src_t.device) if full else torch.zeros(ctx.n_bias, C, device=w_src_t.device)
-        dZs = []
-        for k, ((lo, hi), dy) in enumerate(zip(ctx.spans, dYs)):
-            x, y = saved[2 * k], saved[2 * k + 1]
-            R = hi - lo
-            if dy is None:
-                dW[lo:hi].zero_(); db[lo:hi].zero_(); dZs.append(None)
+        db = torch.empty(ctx.n_bias, C, device=dev) if full else torch.zeros(ctx.n_bias, C, device=dev)
+        need_dz = ctx.needs_input_grad[2]
+        z_rows = Z.shape[0]
+        z_cov = sum(rows * (hi - lo) for lo, hi, _, rows in blocks)
+        dZ = None
+        if need_dz:
+            dZ = torch.empty_like(Z) if (z_cov == z_rows and all(d is not None for d in dYs)) else torch.zeros_like(Z)
+        for k, ((lo, hi, z0, rows), dy) in enumerate(zip(blocks, dYs)):
+            if dy is None or rows == 0:
                 continue
-            dz = torch.ops.aten.threshold_backward(dy.contiguous(), y, 0.0)
-            Wt = w_src_t[lo:hi].view(R * C, C)
-            out = dW[lo:hi].view(R * C, C)
-            if x.shape[0] >= _TN_MIN_ROWS:
-                out.copy_(tn_gemm(x, dz))
-            else:
-                torch.mm(x.t(), dz, out=out)
-            db[lo:hi] = dz.sum(0)
-            dZs.append(linear(dz, Wt).view(-1, C) if ctx.needs_input_grad[3 + k] else None)
-        return (dW, db, None) + tuple(dZs)
+            R = hi - lo
+            x = Z[z0:z0 + rows * R].view(rows, R * C)
+            dz = torch.ops.aten.threshold_backward(dy.contiguous(), ys[k], 0.0)
+            # dWt = x^T dz lands transposed in place (the pack keeps [in, out]); db = colsum(dz) for each relation
+            tn_gemm(dz, x, out=dW[lo:hi].view(R * C, C), transpose_out=True, colsum_out=db[lo:hi])
+            if need_dz:
+                linear(dz, w_src_t[lo:hi].view(R * C, C), out=dZ[z0:z0 + rows * R].view(rows, R * C))
+        return dW, db, dZ, None
 
 
-def layer_transform(pack, spans, Zs):
-    return _LayerTransform.apply(pack.w_src_t, pack.bias, spans, *Zs)
+def layer_transform(pack, Z, blocks):
+    return _LayerTransform.apply(pack.w_src_t, pack.bias, Z, blocks)

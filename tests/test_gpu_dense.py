@@ -37,6 +37,23 @@ def test_tn_gemm_strided_inputs_and_determinism():
     assert_close(C1, A.double().t() @ B.double(), 1e-5, 1e-6, 'strided', rel_to_max=2e-6)
 
 
+def test_tn_gemm_transposed_output_and_repeated_colsum():
+    """kgw_tn_gemm_ex: C^T written into a strided view, column sums replicated into q rows."""
+    from kgwas_amd import ops
+    g = torch.Generator().manual_seed(4)
+    for rows in (700, 40000):
+        A = torch.randn(rows, 128, generator=g).cuda()
+        B = torch.randn(rows, 384, generator=g).cuda()
+        big = torch.full((5, 128, 128), 7.0).cuda()               # pack-like [n, k, c]; relations 1..3 are the target
+        db = torch.full((5, 128), 7.0).cuda()
+        ops.tn_gemm(A, B, out=big[1:4].view(384, 128), transpose_out=True, colsum_out=db[1:4])
+        ref = B.double().t() @ A.double()
+        assert_close(big[1:4].reshape(384, 128), ref, 1e-5, 1e-6, 'C^T', rel_to_max=2e-6)
+        for q in (1, 2, 3):
+            assert_close(db[q], A.double().sum(0), 1e-5, 1e-5, 'colsum copy', rel_to_max=2e-6)
+        assert float(big[0].min()) == 7.0 and float(big[4].max()) == 7.0 and float(db[0].min()) == 7.0 and float(db[4].max()) == 7.0
+
+
 def test_mlp_nodes_match_autograd():
     from kgwas_amd import ops
     g = torch.Generator().manual_seed(1)
