@@ -135,7 +135,9 @@ typedef struct KgwLayerArgs {
     const int32_t* multi;  int64_t multi_cap;
     const int32_t* col_local;
     const float* H;                /* [n_src_rows][128] layer input, type-major (src_base)     */
-    const float* a_dst;            /* [z rows]  <h_dst[i], W_dst^T att_dst> per (row, relation) */
+    const float* a_dst;            /* [z rows]  <h_dst[i], W_dst^T att_dst> per (row, relation); read only if V == NULL */
+    const float* V;                /* [n_rels][128]  v_r = W_dst^T att_dst: a_dst is computed in-kernel from the
+                                      destination node's own row of H (every destination type has a block in H)  */
     const float* U;                /* [n_rels][128]  u_r = W_src^T att_src                     */
     float* Z;                      /* [z rows][128]  sum_j alpha_ij h_src[j]  (pre-zeroed)      */
     float* stat;                   /* [z rows][2]    (row max, denominator)                    */
@@ -148,7 +150,8 @@ typedef struct KgwLayerArgs {
     float* part_da;                /* [n_chunks]                                               */
     const int32_t* t_ptr; const int32_t* t_edge; const int32_t* t_zrow;
     float* dH;                     /* [n_src_rows][128]                                        */
-    float* da_src;                 /* [n_src_rows][(n_rels+3)&~3] d a_src per (source row, relation id) */
+    float* da_src;                 /* [n_src_rows][2*ld], ld = (n_rels+3)&~3: columns [0,ld) d a_src, [ld,2ld) d a_dst
+                                      of the node, one column per relation id (n_rels <= 32)            */
 } KgwLayerArgs;
 
 /* ---- entry points ------------------------------------------------------------------------ */
@@ -220,14 +223,16 @@ int kgw_adam(int32_t n_tensors, float* const* params, const float* const* grads,
  * U_full[r] = W_src^T att_src for every relation id r the layer computes (live_of_rel[r] = its index i in the
  * packed parameter arrays, -1 => row of zeros), V[i] = W_dst^T att_dst (bip_pos[i] >= 0: index into w_dst_t) or
  * W_src^T att_dst (same-type relation).  Packed weights are transposed: w_*_t[i][k][c] = W_i[c][k], C = 128.
+ * v_by_rel != 0: V / dV are [n_rels_total][128] indexed by relation id like U_full (zero rows for relations the
+ * layer does not compute) -- the form kgw_gat_aggregate_* consume.
  * _bwd: gradients of the packed parameters from (dU_full, dV); every output element is written.          */
 int kgw_relvec_fwd(int32_t n_rels_total, const int32_t* live_of_rel, const int32_t* bip_pos, const float* w_src_t,
                    const float* w_dst_t, const float* att_src, const float* att_dst, float* U_full, float* V,
-                   kgw_stream_t stream);
+                   int32_t v_by_rel, kgw_stream_t stream);
 int kgw_relvec_bwd(int32_t n_live, const int32_t* rel_ids, const int32_t* bip_pos, const float* w_src_t,
                    const float* w_dst_t, const float* att_src, const float* att_dst, const float* dU_full,
                    const float* dV, float* dw_src_t, float* dw_dst_t, float* datt_src, float* datt_dst,
-                   kgw_stream_t stream);
+                   int32_t v_by_rel, kgw_stream_t stream);
 
 /* Self-test of the cross-lane reductions used by the aggregate kernels (one wavefront):
  * out_half[l] = sum over l's 32-lane half, out_wave[l] = sum over the wavefront,

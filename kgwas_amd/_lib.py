@@ -89,7 +89,7 @@ class KgwLayerArgs(C.Structure):
         ('neg_slope', C.c_float), ('inv_temp', C.c_float),
         ('graph_host', C.c_void_p), ('meta_host', C.c_void_p), ('meta_dev', C.c_void_p),
         ('chunks', C.c_void_p), ('multi', C.c_void_p), ('multi_cap', C.c_int64),
-        ('col_local', C.c_void_p), ('H', C.c_void_p), ('a_dst', C.c_void_p), ('U', C.c_void_p),
+        ('col_local', C.c_void_p), ('H', C.c_void_p), ('a_dst', C.c_void_p), ('V', C.c_void_p), ('U', C.c_void_p),
         ('Z', C.c_void_p), ('stat', C.c_void_p), ('e_edge', C.c_void_p), ('part', C.c_void_p),
         ('dZ', C.c_void_p), ('adp', C.c_void_p), ('da_dst', C.c_void_p), ('part_da', C.c_void_p),
         ('t_ptr', C.c_void_p), ('t_edge', C.c_void_p), ('t_zrow', C.c_void_p),
@@ -142,8 +142,8 @@ def lib():
                              C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     L.kgw_adam.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
-    L.kgw_relvec_fwd.argtypes = [C.c_int32] + [C.c_void_p] * 9
-    L.kgw_relvec_bwd.argtypes = [C.c_int32] + [C.c_void_p] * 13
+    L.kgw_relvec_fwd.argtypes = [C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]
+    L.kgw_relvec_bwd.argtypes = [C.c_int32] + [C.c_void_p] * 12 + [C.c_int32, C.c_void_p]
     L.kgw_tn_gemm.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
                               C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     L.kgw_tn_gemm_ex.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,

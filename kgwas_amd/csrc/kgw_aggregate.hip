@@ -39,10 +39,18 @@ struct LayerTab {
     int32_t type_src_base[KGW_MAX_TYPES + 1];
     int32_t type_t_base[KGW_MAX_TYPES + 1];
     int32_t type_R_src[KGW_MAX_TYPES];
-    int32_t rel_of_slot[KGW_MAX_TYPES][KGW_MAX_RELS / 2];   // relation id of (source type, slot)
+    int8_t rel_of_slot[KGW_MAX_TYPES][KGW_MAX_RELS / 2];    // relation id of (source type, slot)
     int8_t rel_src_type[KGW_MAX_RELS];                      // source type of relation r
     int8_t rel_slot_src[KGW_MAX_RELS];                      // its slot among the relations of that source type
-    int32_t ld_da;                                          // row stride of da_src (n_rels rounded up to 4)
+    int32_t ld_da;                                          // n_rels rounded up to 4; da_src rows are 2*ld_da wide
+    // destination-side view (in-kernel a_d = <h_dst, v_r>): the rows of a destination type are the first rows of
+    // its own block of H
+    int32_t dst_hbase[KGW_MAX_RELS];                        // first H row of the relation's DESTINATION type
+    int8_t rel_dst_type[KGW_MAX_RELS];
+    int8_t rel_slot_dst[KGW_MAX_RELS];
+    int8_t rel_of_dslot[KGW_MAX_TYPES][KGW_MAX_RELS / 2];   // relation id of (destination type, slot)
+    int32_t type_z_base[KGW_MAX_TYPES];
+    int32_t type_R_dst[KGW_MAX_TYPES];
 };
 
 struct AggPtrs {
@@ -50,6 +58,7 @@ struct AggPtrs {
     const int32_t* col_local;
     const float* H;
     const float* a_dst;
+    const float* V;               // [n_rels][128] v_r (nullable: then a_dst is read)
     const float* U;
     float* Z;
     float* stat;
@@ -132,7 +141,14 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_fwd(LayerTab T, AggPtrs P, floa
         const int r = ck.rel;
         if (!T.live[r]) continue;
         const int zrow = T.z0[r] + ck.row * T.zstride[r];
-        const float ad = P.a_dst[zrow];
+        float ad;
+        if (P.V) {          // a_d = <h_dst[row], v_r> (conv.py:150-151 re-associated), both halves compute it
+            const float4 hd4 = ((const float4*)(P.H + ((int64_t)T.dst_hbase[r] + ck.row) * KGW_C))[hl];
+            const float4 v4 = ((const float4*)(P.V + (int64_t)r * KGW_C))[hl];
+            ad = kgw_half_allsum(dot4(hd4, v4));
+        } else {
+            ad = P.a_dst[zrow];
+        }
         const float4 u4 = ((const float4*)(P.U + (int64_t)r * KGW_C))[hl];
         const float4* Hb4 = (const float4*)(P.H + (int64_t)T.src_base[r] * KGW_C);
         float m = NEG_BIG, s = 0.f;
@@ -337,7 +353,7 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, 
         const int tb = T.type_t_base[ty] + j * Rs;
         if (j >= P.meta->n_src[P.layer - 1][ty]) {          // padding row of a static layout: no gradient
             if (half == 0) ((float4*)(P.dH + (int64_t)u * KGW_C))[hl] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (lane < T.ld_da) P.da_src[(int64_t)u * T.ld_da + lane] = 0.f;
+            if (lane < 2 * T.ld_da) P.da_src[(int64_t)u * 2 * T.ld_da + lane] = 0.f;
             continue;
         }
         // all Rs + 1 row pointers of this source in ONE load (lane k holds t_ptr[tb + k]); the per-slot logic below
@@ -386,13 +402,33 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, 
                 }
             }
         }
+        // destination side of the same node: a_d[i, r] = <h[i], v_r> sends d a_d back into h[i]
+        const int Rd = T.type_R_dst[ty];
+        const bool is_dst = P.V && Rd > 0 && j < P.meta->n_rows[P.layer - 1][ty];
+        const int zb = T.type_z_base[ty] + j * Rd;
+        if (is_dst) {
+            const float dav = (lane < Rd) ? P.da_dst[zb + lane] : 0.f;
+            for (int k = 0; k < Rd; ++k) {
+                const float dk = __shfl(dav, k, 64);
+                if (dk != 0.f) {
+                    const int r = T.rel_of_dslot[ty][k];
+                    const float4 v4 = ((const float4*)(P.V + (int64_t)r * KGW_C))[hl];
+                    fma4(acc, dk, v4);
+                }
+            }
+        }
         if (half == 0) ((float4*)(P.dH + (int64_t)u * KGW_C))[hl] = acc;
-        // d a_src row of this source, one column per RELATION ID (zero for relations of other source types): the
-        // caller gets d u_r = sum_j d a_src[j, r] * H[j] for all relations as ONE tall-skinny product
+        // [d a_src | d a_dst] row of this node, one column per RELATION ID (zero for relations of other types): the
+        // caller gets d u_r = sum_j d a_src[j, r] H[j] and d v_r = sum_i d a_dst[i, r] H[i] for all relations as
+        // ONE tall-skinny product over H
         {
+            const int ld = T.ld_da;
             const bool mine = lane < T.n_rels && T.rel_src_type[lane] == ty;
             const float v = __shfl(dasv, mine ? T.rel_slot_src[lane] : 0, 64);
-            if (lane < T.ld_da) P.da_src[(int64_t)u * T.ld_da + lane] = mine ? v : 0.f;
+            float w = 0.f;
+            const int c = lane - ld;
+            if (is_dst && c >= 0 && c < T.n_rels && T.rel_dst_type[c] == ty) w = P.da_dst[zb + T.rel_slot_dst[c]];
+            if (lane < 2 * ld) P.da_src[(int64_t)u * 2 * ld + lane] = (lane < ld) ? (mine ? v : 0.f) : w;
         }
     }
 }
@@ -426,6 +462,7 @@ int build_tab(const KgwLayerArgs* a, LayerTab* T) {
     T->n_rels = G->n_rels;
     T->n_types = G->n_types;
     T->ld_da = (G->n_rels + 3) & ~3;
+    if (2 * T->ld_da > 64) return KGW_E_UNSUPPORTED;          // one wavefront-wide store per source row
     for (int r = 0; r < G->n_rels; ++r) {
         const int s = G->rel_src[r], d = G->rel_dst[r];
         T->src_base[r] = M->src_base[l - 1][s];
@@ -433,21 +470,30 @@ int build_tab(const KgwLayerArgs* a, LayerTab* T) {
         T->zstride[r] = G->R_dst[d];
         T->live[r] = G->rel_live[l - 1][r];
         if (G->rel_slot_src[r] >= KGW_MAX_RELS / 2) return KGW_E_RANGE;
-        T->rel_of_slot[s][G->rel_slot_src[r]] = r;
+        if (G->rel_slot_dst[r] >= KGW_MAX_RELS / 2) return KGW_E_RANGE;
+        T->rel_of_slot[s][G->rel_slot_src[r]] = (int8_t)r;
         T->rel_src_type[r] = (int8_t)s;
         T->rel_slot_src[r] = (int8_t)G->rel_slot_src[r];
+        T->rel_dst_type[r] = (int8_t)d;
+        T->rel_slot_dst[r] = (int8_t)G->rel_slot_dst[r];
+        T->rel_of_dslot[d][G->rel_slot_dst[r]] = (int8_t)r;
+        T->dst_hbase[r] = M->src_base[l - 1][d];
     }
     for (int t = 0; t <= G->n_types; ++t) {
         T->type_src_base[t] = M->src_base[l - 1][t];
         T->type_t_base[t] = M->t_base[l - 1][t];
-        if (t < G->n_types) T->type_R_src[t] = G->R_src[t];
+        if (t < G->n_types) {
+            T->type_R_src[t] = G->R_src[t];
+            T->type_R_dst[t] = G->R_dst[t];
+            T->type_z_base[t] = M->z_base[l - 1][t];
+        }
     }
     return KGW_OK;
 }
 
 AggPtrs build_ptrs(const KgwLayerArgs* a) {
     AggPtrs P;
-    P.chunks = a->chunks; P.col_local = a->col_local; P.H = a->H; P.a_dst = a->a_dst; P.U = a->U;
+    P.chunks = a->chunks; P.col_local = a->col_local; P.H = a->H; P.a_dst = a->a_dst; P.V = a->V; P.U = a->U;
     P.Z = a->Z; P.stat = a->stat; P.e_edge = a->e_edge; P.part = a->part; P.dZ = a->dZ; P.adp = a->adp;
     P.da_dst = a->da_dst; P.part_da = a->part_da; P.t_ptr = a->t_ptr; P.t_edge = a->t_edge;
     P.t_zrow = a->t_zrow; P.dH = a->dH; P.da_src = a->da_src; P.multi = a->multi; P.multi_cap = a->multi_cap;
@@ -467,7 +513,7 @@ inline int grid_for_waves(int64_t n_waves) {
 extern "C" int kgw_gat_aggregate_fwd(const KgwLayerArgs* a, kgw_stream_t stream_) {
     if (!a) return KGW_E_NULL;
     if (a->n_chunks == 0) return KGW_OK;
-    if (!a->chunks || !a->col_local || !a->H || !a->a_dst || !a->U || !a->Z || !a->stat || !a->e_edge || !a->part ||
+    if (!a->chunks || !a->col_local || !a->H || (!a->a_dst && !a->V) || !a->U || !a->Z || !a->stat || !a->e_edge || !a->part ||
         !a->meta_dev)
         return KGW_E_NULL;
     LayerTab T;

@@ -727,11 +727,15 @@ __global__ void __launch_bounds__(128) k_relvec_fwd(int NR, const int32_t* __res
                                                     const int32_t* __restrict__ bip_pos, const float* __restrict__ wsT,
                                                     const float* __restrict__ wdT, const float* __restrict__ att_src,
                                                     const float* __restrict__ att_dst, float* __restrict__ U_full,
-                                                    float* __restrict__ V) {
+                                                    float* __restrict__ V, int v_by_rel) {
     __shared__ float as[KGW_C], ad[KGW_C];
     const int r = blockIdx.x, k = threadIdx.x;
     const int i = live_of_rel[r];
-    if (i < 0) { U_full[(int64_t)r * KGW_C + k] = 0.f; return; }
+    if (i < 0) {
+        U_full[(int64_t)r * KGW_C + k] = 0.f;
+        if (v_by_rel) V[(int64_t)r * KGW_C + k] = 0.f;
+        return;
+    }
     as[k] = att_src[(int64_t)i * KGW_C + k];
     ad[k] = att_dst[(int64_t)i * KGW_C + k];
     __syncthreads();
@@ -746,7 +750,7 @@ __global__ void __launch_bounds__(128) k_relvec_fwd(int NR, const int32_t* __res
         v = fmaf(b.x, ad[4 * c4], fmaf(b.y, ad[4 * c4 + 1], fmaf(b.z, ad[4 * c4 + 2], fmaf(b.w, ad[4 * c4 + 3], v))));
     }
     U_full[(int64_t)r * KGW_C + k] = u;
-    V[(int64_t)i * KGW_C + k] = v;
+    V[(int64_t)(v_by_rel ? r : i) * KGW_C + k] = v;
 }
 
 // one block per live relation i; thread c owns column c of the [k][c] matrices
@@ -755,12 +759,13 @@ __global__ void __launch_bounds__(128) k_relvec_bwd(const int32_t* __restrict__ 
                                                     const float* __restrict__ att_src, const float* __restrict__ att_dst,
                                                     const float* __restrict__ dU_full, const float* __restrict__ dV,
                                                     float* __restrict__ dwsT, float* __restrict__ dwdT,
-                                                    float* __restrict__ datt_src, float* __restrict__ datt_dst) {
+                                                    float* __restrict__ datt_src, float* __restrict__ datt_dst,
+                                                    int v_by_rel) {
     __shared__ float du[KGW_C], dv[KGW_C];
     const int i = blockIdx.x, c = threadIdx.x;
     const int r = rel_ids[i], j = bip_pos[i];
     du[c] = dU_full[(int64_t)r * KGW_C + c];
-    dv[c] = dV[(int64_t)i * KGW_C + c];
+    dv[c] = dV[(int64_t)(v_by_rel ? r : i) * KGW_C + c];
     __syncthreads();
     const float as = att_src[(int64_t)i * KGW_C + c], ad = att_dst[(int64_t)i * KGW_C + c];
     const float* ws = wsT + (int64_t)i * KGW_C * KGW_C;
@@ -793,11 +798,11 @@ __global__ void __launch_bounds__(128) k_relvec_bwd(const int32_t* __restrict__ 
 
 extern "C" int kgw_relvec_fwd(int32_t n_rels_total, const int32_t* live_of_rel, const int32_t* bip_pos, const float* w_src_t,
                               const float* w_dst_t, const float* att_src, const float* att_dst, float* U_full, float* V,
-                              kgw_stream_t stream_) {
+                              int32_t v_by_rel, kgw_stream_t stream_) {
     if (n_rels_total <= 0) return KGW_OK;
     if (!live_of_rel || !bip_pos || !w_src_t || !att_src || !att_dst || !U_full || !V) return KGW_E_NULL;
     k_relvec_fwd<<<n_rels_total, 128, 0, (hipStream_t)stream_>>>(n_rels_total, live_of_rel, bip_pos, w_src_t, w_dst_t,
-                                                                 att_src, att_dst, U_full, V);
+                                                                 att_src, att_dst, U_full, V, v_by_rel);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }
@@ -805,12 +810,12 @@ extern "C" int kgw_relvec_fwd(int32_t n_rels_total, const int32_t* live_of_rel, 
 extern "C" int kgw_relvec_bwd(int32_t n_live, const int32_t* rel_ids, const int32_t* bip_pos, const float* w_src_t,
                               const float* w_dst_t, const float* att_src, const float* att_dst, const float* dU_full,
                               const float* dV, float* dw_src_t, float* dw_dst_t, float* datt_src, float* datt_dst,
-                              kgw_stream_t stream_) {
+                              int32_t v_by_rel, kgw_stream_t stream_) {
     if (n_live <= 0) return KGW_OK;
     if (!rel_ids || !bip_pos || !w_src_t || !att_src || !att_dst || !dU_full || !dV || !dw_src_t || !datt_src || !datt_dst)
         return KGW_E_NULL;
     k_relvec_bwd<<<n_live, 128, 0, (hipStream_t)stream_>>>(rel_ids, bip_pos, w_src_t, w_dst_t, att_src, att_dst, dU_full, dV,
-                                                           dw_src_t, dw_dst_t, datt_src, datt_dst);
+                                                           dw_src_t, dw_dst_t, datt_src, datt_dst, v_by_rel);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }

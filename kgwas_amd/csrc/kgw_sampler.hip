@@ -374,6 +374,9 @@ __global__ void __launch_bounds__(64) k_layer_tables(SampArgs A) {
             dst_live |= (G.rel_dst[r] == t);
             src_live |= (G.rel_src[r] == t);
         }
+        // a destination type always has a block in the layer input too (its rows are the destination-side
+        // operand of the attention logits), even when no live relation leaves it
+        src_live |= dst_live;
         nr = dst_live ? M->node_off[t][hd + 1] : 0;
         ns = src_live ? M->node_off[t][hd + 2] : 0;
         // row-block sizes of the layout: the batch's own counts, or fixed capacities (graph capture)

@@ -251,24 +251,18 @@ class HeteroGNN(nn.Module):
             P: RelationPack = self.live_packs[l - 1]
             rng = self._dst_range[l - 1]
             # u_r = W_src^T att_src ; v_r = W_dst^T att_dst (W_src^T att_dst for same-type relations): one launch
-            U, V_live = ops.rel_vectors(P)
-            # layer input, type-major (src_base) ; destination-side attention terms a_d[i, r]
-            parts, a_parts = [], []
+            U, V = ops.rel_vectors(P)
+            # layer input, type-major (src_base): every type that sends or receives messages in this layer
+            parts = []
             for t, name in enumerate(sc.node_types):
                 ns = int(m.lay_src[l - 1][t])
                 if ns:
                     if name not in h or h[name].shape[0] < ns:
-                        raise RuntimeError(f'layer {l}: node type {name!r} is a message source but has no '
+                        raise RuntimeError(f'layer {l}: node type {name!r} takes part in the layer but has no '
                                            f'incoming relation to produce its layer-{l - 1} state')
                     parts.append(h[name] if h[name].shape[0] == ns else h[name][:ns])
-                nr = int(m.lay_rows[l - 1][t])
-                if nr:
-                    lo, hi = rng[t]
-                    hd = h[name] if h[name].shape[0] == nr else h[name][:nr]
-                    a_parts.append((hd @ V_live[lo:hi].t()).reshape(-1))
             H = torch.cat(parts, 0) if len(parts) != 1 else parts[0]
-            a_dst = torch.cat(a_parts) if len(a_parts) != 1 else a_parts[0]
-            Z, stat, e_edge = ops.gat_aggregate(batch, l, H, a_dst, U, self.negative_slope, self.temperature)
+            Z, stat, e_edge = ops.gat_aggregate(batch, l, H, U, V, self.negative_slope, self.temperature)
             if want_attention:
                 attn.append(ops.edge_alpha(batch, l, stat, e_edge, self.temperature))
             # per-relation linear maps + bias + relation sum + ReLU: one GEMM per destination type, one autograd node

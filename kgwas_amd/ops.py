@@ -1,7 +1,7 @@
 """autograd bridge to the fused attention-aggregate kernels (include/kgwas_hip.h).
 
-``gat_aggregate(batch, layer, H, a_dst, U)`` is, for every live relation r=(s,rel,d) of the layer at once,
-    e_ij  = leaky_relu(<H_s[j], U[r]> + a_dst[i, r])          kgwas/conv.py:150-152,205,217
+``gat_aggregate(batch, layer, H, U, V)`` is, for every live relation r=(s,rel,d) of the layer at once,
+    e_ij  = leaky_relu(<H_s[j], U[r]> + <H_d[i], V[r]>)       kgwas/conv.py:150-152,205,217
     alpha = softmax over the in-edges of destination i        kgwas/conv.py:223
     Z[i, r, :] = sum_j alpha_ij H_s[j, :]                     kgwas/conv.py:227-228,182
 with hand-written backward (dst-major + src-major HIP passes, no atomics)."""
@@ -76,16 +76,16 @@ def _layer_args(batch, layer: int, neg_slope: float, inv_temp: float) -> KgwLaye
 
 class _GatAggregate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, H, a_dst, U, batch, layer, neg_slope, inv_temp):
+    def forward(ctx, H, U, V, batch, layer, neg_slope, inv_temp):
         dg, m = batch.dg, batch.meta
         NT = dg.schema.NT
         z_rows = int(m.z_base[layer - 1][NT])
         n_edges = int(m.n_edges[layer - 1])
         n_chunks = int(m.n_chunks[layer - 1])
         n_src = int(m.src_base[layer - 1][NT])
-        H = H.contiguous(); a_dst = a_dst.contiguous(); U = U.contiguous()
+        H = H.contiguous(); U = U.contiguous(); V = V.contiguous()
         assert H.dtype == torch.float32 and H.shape == (n_src, KGW_C), (H.shape, n_src)
-        assert a_dst.numel() == z_rows and U.shape == (dg.schema.NR, KGW_C)
+        assert U.shape == (dg.schema.NR, KGW_C) and V.shape == U.shape
         dev = H.device
         Z = torch.zeros(max(z_rows, 1), KGW_C, device=dev)
         stat = torch.zeros(max(z_rows, 1), 2, device=dev)
@@ -93,19 +93,19 @@ class _GatAggregate(torch.autograd.Function):
         any_multi = batch.static or any(int(m.multi_cnt[h]) for h in range(dg.n_hops))
         part = torch.empty(max(n_chunks, 1) * PART_STRIDE if any_multi else 4, device=dev)
         a = _layer_args(batch, layer, neg_slope, inv_temp)
-        a.H, a.a_dst, a.U = _p(H), _p(a_dst), _p(U)
+        a.H, a.V, a.U = _p(H), _p(V), _p(U)
         a.Z, a.stat, a.e_edge, a.part = _p(Z), _p(stat), _p(e_edge), _p(part)
         ev = TIMER.bracket('fwd', layer, n_edges, z_rows, n_src)
         _lib.check(_lib.lib().kgw_gat_aggregate_fwd(C.byref(a), _lib.stream_ptr()), 'kgw_gat_aggregate_fwd')
         TIMER.close(ev)
-        ctx.save_for_backward(H, U, Z, stat, e_edge)
+        ctx.save_for_backward(H, U, V, Z, stat, e_edge)
         ctx.batch, ctx.layer, ctx.neg_slope, ctx.inv_temp = batch, layer, neg_slope, inv_temp
         ctx.mark_non_differentiable(stat, e_edge)
         return stat, e_edge, Z[:z_rows]
 
     @staticmethod
     def backward(ctx, _dstat, _de, dZ):
-        H, U, Z, stat, e_edge = ctx.saved_tensors
+        H, U, V, Z, stat, e_edge = ctx.saved_tensors
         batch, layer = ctx.batch, ctx.layer
         dg, m = batch.dg, batch.meta
         sc = dg.schema
@@ -122,9 +122,9 @@ class _GatAggregate(torch.autograd.Function):
         part_da = torch.empty(max(n_chunks, 1), device=dev)
         dH = torch.empty(max(n_src, 1), KGW_C, device=dev)
         ld_da = (sc.NR + 3) & ~3
-        da_src = torch.empty(max(n_src, 1), ld_da, device=dev)    # [source row, relation id]
+        da_src = torch.empty(max(n_src, 1), 2 * ld_da, device=dev)   # [node row, (d a_src | d a_dst) by relation id]
         a = _layer_args(batch, layer, ctx.neg_slope, ctx.inv_temp)
-        a.H, a.U, a.Z, a.stat, a.e_edge = _p(H), _p(U), _p(Z), _p(stat), _p(e_edge)
+        a.H, a.U, a.V, a.Z, a.stat, a.e_edge = _p(H), _p(U), _p(V), _p(Z), _p(stat), _p(e_edge)
         a.dZ, a.adp, a.da_dst, a.part_da = _p(dZf), _p(adp), _p(da_dst), _p(part_da)
         a.dH, a.da_src = _p(dH), _p(da_src)
         L = _lib.lib()
@@ -134,20 +134,24 @@ class _GatAggregate(torch.autograd.Function):
         ev = TIMER.bracket('bwd_src', layer, n_edges, z_rows, n_src)
         _lib.check(L.kgw_gat_aggregate_bwd_src(C.byref(a), _lib.stream_ptr()), 'kgw_gat_aggregate_bwd_src')
         TIMER.close(ev)
-        # d u_r = sum_j d a_src[j, r] * H[j]   (a_s = <H[j], u_r>): all relations in one tall-skinny product
+        # d u_r = sum_j d a_src[j, r] H[j], d v_r = sum_i d a_dst[i, r] H[i]: all relations, both sides, as ONE
+        # tall-skinny product over H
         if n_src:
-            dU = tn_gemm(da_src[:n_src, :sc.NR], H[:n_src])
+            dUV = tn_gemm(da_src[:n_src], H[:n_src])
+            dU, dV = dUV[:sc.NR], dUV[ld_da:ld_da + sc.NR]
         else:
-            dU = torch.zeros_like(U)
-        return dH[:n_src], da_dst[:z_rows], dU, None, None, None, None
+            dU, dV = torch.zeros_like(U), torch.zeros_like(V)
+        return dH[:n_src], dU, dV, None, None, None, None
 
 
-def gat_aggregate(batch, layer: int, H: torch.Tensor, a_dst: torch.Tensor, U: torch.Tensor,
+def gat_aggregate(batch, layer: int, H: torch.Tensor, U: torch.Tensor, V: torch.Tensor,
                   neg_slope: float = 0.2, temperature: float = 1.0):
-    """Returns (Z [z_rows,128], stat [z_rows,2] = (row max, denominator), e_edge [n_edges]); Z is type-major:
-    the block of destination type t starts at row ``meta.z_base[layer-1][t]`` and holds ``lay_rows * R_dst[t]``
-    rows ([row, relation slot, 128])."""
-    stat, e_edge, Z = _GatAggregate.apply(H, a_dst, U, batch, layer, float(neg_slope), 1.0 / float(temperature))
+    """Z[i, r] = sum_j softmax_j(leaky_relu(<H_src[j], u_r> + <H_dst[i], v_r>) / T) H_src[j] for every live relation
+    of the layer.  H [n_src_rows,128]: layer input, type-major (``meta.src_base``; a destination node is row i of
+    its own type's block); U, V [n_rels,128] by relation id.  Returns (Z [z_rows,128], stat [z_rows,2] =
+    (row max, denominator), e_edge [n_edges]); Z is type-major: the block of destination type t starts at row
+    ``meta.z_base[layer-1][t]`` and holds ``lay_rows * R_dst[t]`` rows ([row, relation slot, 128])."""
+    stat, e_edge, Z = _GatAggregate.apply(H, U, V, batch, layer, float(neg_slope), 1.0 / float(temperature))
     return Z, stat, e_edge
 
 
@@ -333,17 +337,17 @@ def linear_relu(x, W, b):
 # per-layer parameter plumbing as two autograd nodes (instead of ~60 tiny framework ops per step)
 # ------------------------------------------------------------------------------------------------------
 class _RelVectors(torch.autograd.Function):
-    """(U_full [NR,C], V [n,C]) from the packed relation parameters of a layer -- kgw_relvec_fwd / _bwd."""
+    """(U [NR,C], V [NR,C]), rows by relation id, from the packed relation parameters of a layer -- kgw_relvec_fwd / _bwd."""
 
     @staticmethod
     def forward(ctx, w_src_t, w_dst_t, att_src, att_dst, pack):
         n, C = att_src.shape
         dev = att_src.device
         U = torch.empty(pack.n_rels_total, C, device=dev)
-        V = torch.empty(n, C, device=dev)
+        V = torch.empty(pack.n_rels_total, C, device=dev)        # by relation id, like U
         _lib.check(_lib.lib().kgw_relvec_fwd(pack.n_rels_total, _p(pack.live_of_rel_i32), _p(pack.bip_pos_i32), _p(w_src_t),
                                              _p(w_dst_t) if w_dst_t.numel() else 0, _p(att_src), _p(att_dst), _p(U), _p(V),
-                                             _lib.stream_ptr()), 'kgw_relvec_fwd')
+                                             1, _lib.stream_ptr()), 'kgw_relvec_fwd')
         ctx.save_for_backward(w_src_t, w_dst_t, att_src, att_dst)
         ctx.pack = pack
         return U, V
@@ -360,7 +364,7 @@ class _RelVectors(torch.autograd.Function):
         dad = torch.empty_like(att_dst)
         _lib.check(_lib.lib().kgw_relvec_bwd(n, _p(pack.rel_ids_i32), _p(pack.bip_pos_i32), _p(w_src_t),
                                              _p(w_dst_t) if w_dst_t.numel() else 0, _p(att_src), _p(att_dst), _p(dU), _p(dV),
-                                             _p(dws), _p(dwd) if dwd.numel() else 0, _p(das), _p(dad), _lib.stream_ptr()),
+                                             _p(dws), _p(dwd) if dwd.numel() else 0, _p(das), _p(dad), 1, _lib.stream_ptr()),
                    'kgw_relvec_bwd')
         return dws, dwd, das, dad, None
 

@@ -136,7 +136,7 @@ class DeviceGraph:
             zb = sb = tb = 0
             for t in range(sc.NT):
                 dst_live = any(int(sc.dst_type[r]) == t for r in live)
-                src_live = any(int(sc.src_type[r]) == t for r in live)
+                src_live = any(int(sc.src_type[r]) == t for r in live) or dst_live   # (k_layer_tables: same rule)
                 lr = int(g.cap_rows[l - 1][t]) if dst_live else 0
                 ls = int(g.cap_src[l - 1][t]) if src_live else 0
                 m.lay_rows[l - 1][t], m.lay_src[l - 1][t] = lr, ls

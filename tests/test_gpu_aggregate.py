@@ -23,8 +23,9 @@ def _batch(data, L, n_seeds=48, seed=0, full=False):
     return next(iter(NeighborLoader(data, [-1] * L, ('SNP', ids), batch_size=n_seeds, device='cuda:0')))
 
 
-def _oracle_layer(batch, layer, H, a_dst, U, slope=0.2, temp=1.0):
-    """fp64 CPU: Z[zrow] = sum_j softmax_j(leaky_relu(<H_s[j],u_r> + a_dst[zrow]) / T) H_s[j]."""
+def _oracle_layer(batch, layer, H, V, U, slope=0.2, temp=1.0):
+    """fp64 CPU: Z[zrow] = sum_j softmax_j(leaky_relu(<H_s[j],u_r> + <H_d[i],v_r>) / T) H_s[j]  (conv.py:144-228 with
+    the attention projections re-associated: a_s = <x W_src^T, att_src> = <x, W_src^T att_src>)."""
     dg, m = batch.dg, batch.meta
     sc = dg.schema
     ei = {k: v.cpu() for k, v in batch.edge_index_dict.items()}
@@ -43,7 +44,9 @@ def _oracle_layer(batch, layer, H, a_dst, U, slope=0.2, temp=1.0):
         Hs = H[int(m.src_base[layer - 1][s]):int(m.src_base[layer - 1][s]) + int(m.n_src[layer - 1][s])]
         zrow = int(m.z_base[layer - 1][d]) + dst * int(sc.R_dst[d]) + int(sc.slot_dst[r])
         a_s = Hs @ U[r]
-        logit = torch.nn.functional.leaky_relu(a_s[src] + a_dst[zrow], slope)
+        Hd = H[int(m.src_base[layer - 1][d]):int(m.src_base[layer - 1][d]) + nr]     # destination rows: head of their type's block
+        a_d = Hd @ V[r]
+        logit = torch.nn.functional.leaky_relu(a_s[src] + a_d[dst], slope)
         # softmax grouped by destination row of THIS relation
         alpha = segment_softmax(logit / temp, dst, nr)
         Z.index_add_(0, zrow, alpha.unsqueeze(-1) * Hs[src])
@@ -63,23 +66,25 @@ def test_aggregate_forward_backward(small_kg, edge_case_graph, graph, layer):
     z_rows = int(m.z_base[layer - 1][sc.NT])
     assert n_src > 0 and z_rows > 0
     H = torch.randn(n_src, 128, generator=g)
-    a_dst = torch.randn(z_rows, generator=g)
+    V = torch.randn(sc.NR, 128, generator=g) * 0.2
     U = torch.randn(sc.NR, 128, generator=g) * 0.2
     G = torch.randn(z_rows, 128, generator=g)
 
-    Hd, ad, Ud = (t.cuda().requires_grad_(True) for t in (H, a_dst, U))
-    Z, stat, e_edge = ops.gat_aggregate_flat(batch, layer, Hd, ad, Ud)
+    Hd, Vd, Ud = (t.cuda().requires_grad_(True) for t in (H, V, U))
+    Z, stat, e_edge = ops.gat_aggregate(batch, layer, Hd, Ud, Vd)
     (Z * G.cuda()).sum().backward()
 
-    Ho, ao, Uo = (t.double().requires_grad_(True) for t in (H, a_dst, U))
-    Zo = _oracle_layer(batch, layer, Ho, ao, Uo)
+    Ho, Vo, Uo = (t.double().requires_grad_(True) for t in (H, V, U))
+    Zo = _oracle_layer(batch, layer, Ho, Vo, Uo)
     (Zo * G.double()).sum().backward()
 
     assert_close(Z, Zo.detach(), RTOL, ATOL, 'Z')
     assert_close(Hd.grad, Ho.grad, RTOL, 2e-5, 'dH')
-    assert_close(ad.grad, ao.grad, RTOL, 2e-5, 'd a_dst')
     live = [r for r in range(sc.NR) if dg.kg.rel_live[layer - 1][r]]
     assert_close(Ud.grad[live], Uo.grad[live], RTOL, 1e-4, 'dU')
+    assert_close(Vd.grad[live], Vo.grad[live], RTOL, 1e-4, 'dV')
+    dead = [r for r in range(sc.NR) if not dg.kg.rel_live[layer - 1][r]]
+    assert float(Ud.grad[dead].abs().sum()) == 0.0 and float(Vd.grad[dead].abs().sum()) == 0.0
     # softmax rows sum to one wherever a row has edges
     alpha = ops.edge_alpha(batch, layer, stat, e_edge)
     assert torch.isfinite(alpha).all() and float(alpha.min()) >= 0.0
@@ -92,10 +97,10 @@ def test_temperature_and_slope(edge_case_graph):
     m, sc = batch.meta, batch.dg.schema
     g = torch.Generator().manual_seed(3)
     H = torch.randn(int(m.src_base[0][sc.NT]), 128, generator=g)
-    a_dst = torch.randn(int(m.z_base[0][sc.NT]), generator=g)
+    V = torch.randn(sc.NR, 128, generator=g) * 0.2
     U = torch.randn(sc.NR, 128, generator=g) * 0.2
-    Z, _, _ = ops.gat_aggregate_flat(batch, 1, H.cuda(), a_dst.cuda(), U.cuda(), neg_slope=0.05, temperature=2.5)
-    Zo = _oracle_layer(batch, 1, H.double(), a_dst.double(), U.double(), slope=0.05, temp=2.5)
+    Z, _, _ = ops.gat_aggregate(batch, 1, H.cuda(), U.cuda(), V.cuda(), neg_slope=0.05, temperature=2.5)
+    Zo = _oracle_layer(batch, 1, H.double(), V.double(), U.double(), slope=0.05, temp=2.5)
     assert_close(Z, Zo, RTOL, ATOL, 'Z (T=2.5, slope=0.05)')
 
 
@@ -109,9 +114,9 @@ def test_extreme_logits_do_not_overflow(edge_case_graph):
     n_src = int(m.src_base[0][sc.NT])
     H = torch.randn(n_src, 128, generator=g)
     H[777] *= 40.0                      # one SNP source row with a huge logit inside gene 0's 1500-edge hub row
-    a_dst = torch.randn(int(m.z_base[0][sc.NT]), generator=g)
+    V = torch.randn(sc.NR, 128, generator=g) * 0.1
     U = torch.randn(sc.NR, 128, generator=g)
-    Z, stat, e = ops.gat_aggregate_flat(batch, 1, H.cuda(), a_dst.cuda(), U.cuda())
+    Z, stat, e = ops.gat_aggregate(batch, 1, H.cuda(), U.cuda(), V.cuda())
     assert torch.isfinite(Z).all()
-    Zo = _oracle_layer(batch, 1, H.double(), a_dst.double(), U.double())
+    Zo = _oracle_layer(batch, 1, H.double(), V.double(), U.double())
     assert_close(Z, Zo, 2e-4, 1e-4, 'Z with spike')
