@@ -234,6 +234,14 @@ int kgw_relvec_bwd(int32_t n_live, const int32_t* rel_ids, const int32_t* bip_po
                    const float* dV, float* dw_src_t, float* dw_dst_t, float* datt_src, float* datt_dst,
                    int32_t v_by_rel, kgw_stream_t stream);
 
+/* LD-score weighted MSE over the seed rows (kgwas/kgwas.py:139-145): loss = mean_i w[n_id[i]] * (pred[i] - y[n_id[i]])^2,
+ * float32 residual / square, float64 weight and mean; _bwd: dpred[i] = grad_loss * d loss / d pred[i].
+ * y [N] float32 labels and w [N] float64 weights are indexed by GLOBAL node id, n_id [n] = the seeds' global ids. */
+int kgw_wmse_fwd(const float* pred, const int32_t* n_id, const float* y, const double* w, int32_t n,
+                 double* loss, kgw_stream_t stream);
+int kgw_wmse_bwd(const float* pred, const int32_t* n_id, const float* y, const double* w, int32_t n,
+                 const double* grad_loss, float* dpred, kgw_stream_t stream);
+
 /* Self-test of the cross-lane reductions used by the aggregate kernels (one wavefront):
  * out_half[l] = sum over l's 32-lane half, out_wave[l] = sum over the wavefront,
  * out_steps[4][64] = the four intra-row DPP butterfly stages.                                  */

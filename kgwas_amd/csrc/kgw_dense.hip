@@ -716,6 +716,63 @@ extern "C" int kgw_adam(int32_t n_tensors, float* const* params, const float* co
 }
 
 // ======================================================================================================
+// kgw_wmse: LD-score weighted MSE of the seed predictions, loss = mean(w[n_id] * (pred - y[n_id])^2) in float64
+// (kgwas/kgwas.py:139-145: float32 residual and square, float64 weight, float64 mean), and its gradient.
+// One block; fixed-order reduction.
+// ======================================================================================================
+namespace {
+
+__global__ void __launch_bounds__(256) k_wmse_fwd(const float* __restrict__ pred, const int32_t* __restrict__ n_id,
+                                                  const float* __restrict__ y, const double* __restrict__ w, int n,
+                                                  double* __restrict__ loss) {
+    __shared__ double sm[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int g = n_id[i];
+        const float d = pred[i] - y[g];
+        acc += w[g] * (double)(d * d);
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = sm[0] / (double)n;
+}
+
+__global__ void __launch_bounds__(256) k_wmse_bwd(const float* __restrict__ pred, const int32_t* __restrict__ n_id,
+                                                  const float* __restrict__ y, const double* __restrict__ w, int n,
+                                                  const double* __restrict__ gloss, float* __restrict__ dpred) {
+    const double g0 = gloss[0] / (double)n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int g = n_id[i];
+        const float d = pred[i] - y[g];
+        dpred[i] = (float)(g0 * w[g]) * (2.0f * d);        // the float64 product meets the float32 square here
+    }
+}
+
+}  // namespace
+
+extern "C" int kgw_wmse_fwd(const float* pred, const int32_t* n_id, const float* y, const double* w, int32_t n,
+                            double* loss, kgw_stream_t stream_) {
+    if (!pred || !n_id || !y || !w || !loss) return KGW_E_NULL;
+    if (n <= 0) return KGW_E_RANGE;
+    k_wmse_fwd<<<1, 256, 0, (hipStream_t)stream_>>>(pred, n_id, y, w, n, loss);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+extern "C" int kgw_wmse_bwd(const float* pred, const int32_t* n_id, const float* y, const double* w, int32_t n,
+                            const double* grad_loss, float* dpred, kgw_stream_t stream_) {
+    if (!pred || !n_id || !y || !w || !grad_loss || !dpred) return KGW_E_NULL;
+    if (n <= 0) return KGW_E_RANGE;
+    k_wmse_bwd<<<(n + 255) / 256, 256, 0, (hipStream_t)stream_>>>(pred, n_id, y, w, n, grad_loss, dpred);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+// ======================================================================================================
 // kgw_relvec: the attention vectors of every relation of a layer in one launch.
 //   u_r = W_src^T att_src , v_r = W_dst^T att_dst (W_src^T att_dst for same-type relations)   conv.py:138-151
 // Weights are stored transposed/packed: wT[i][k][c] = W_i[c][k].  Forward: U_full[r] (zeros for relations the

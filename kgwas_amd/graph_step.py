@@ -15,7 +15,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, ops
 from .sampler import BatchBuffers, NeighborLoader, SampledBatch, sample_into
 
 
@@ -84,10 +84,7 @@ class GraphTrainStep:
         batch = SampledBatch(self.dg, buf, self.meta, self.input_type, bs, static=True)
         self.opt.zero_grad(set_to_none=True)
         out = self.model(batch.x_dict, batch.edge_index_dict, bs)
-        n_id = batch.n_id(self.input_type)[:bs].long()
-        y = self.dg.y[self.input_type][n_id]
-        w = self.ld_w[n_id]
-        loss = torch.mean(w * (out.reshape(-1) - y) ** 2)            # float64, kgwas.py:145
+        loss = ops.weighted_mse(out.reshape(-1), batch.n_id(self.input_type), self.dg.y[self.input_type], self.ld_w)   # kgwas.py:139-145
         loss.backward()
         if self.capture_optimizer:
             self.opt.step()

@@ -22,6 +22,7 @@ import torch
 import torch.nn.functional as F
 
 from . import dist as kdist
+from . import ops
 from .model import HeteroGNN
 from .sampler import NeighborLoader
 from .utils import compute_metrics, evaluate_minibatch_clean, load_pretrained, print_sys, save_model
@@ -102,10 +103,8 @@ class KGWAS:
         bs = batch['SNP'].batch_size
         out = self.model(batch.x_dict, batch.edge_index_dict, bs)
         pred = out.reshape(-1)
-        n_id = batch.n_id('SNP')[:bs].long()
-        y = batch.dg.y['SNP'][n_id]
-        w = ld_w[n_id]
-        loss = torch.mean(w * (pred - y) ** 2)                       # float64, kgwas.py:145
+        # mean(ld_weight * (pred - y)**2) in float64 (kgwas.py:139-145), labels / weights looked up by the seeds' ids
+        loss = ops.weighted_mse(pred, batch.n_id('SNP'), batch.dg.y['SNP'], ld_w)
         loss.backward()
         if world > 1:
             kdist.allreduce_grads(self.model, world)

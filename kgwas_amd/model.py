@@ -68,12 +68,16 @@ class SimpleMLP(nn.Module):
         """relu(FC_hidden(x)) -- one autograd node; weight gradient on the split-K MFMA kernel."""
         return ops.linear_relu(x, self.FC_hidden.weight, self.FC_hidden.bias)
 
-    def tail(self, h1):
+    def tail(self, h1, out=None):
         """FC_output(relu(FC_hidden2(h1))) -- one autograd node."""
-        return ops.mlp_tail(h1, self.FC_hidden2.weight, self.FC_hidden2.bias, self.FC_output.weight, self.FC_output.bias)
+        return ops.mlp_tail(h1, self.FC_hidden2.weight, self.FC_hidden2.bias, self.FC_output.weight, self.FC_output.bias,
+                            out)
 
-    def forward(self, x):
-        return self.tail(self.first(x))
+    def forward(self, x, out=None):
+        if x.requires_grad:
+            return self.tail(self.first(x), out)
+        return ops.mlp3(x, self.FC_hidden.weight, self.FC_hidden.bias, self.FC_hidden2.weight, self.FC_hidden2.bias,
+                        self.FC_output.weight, self.FC_output.bias, out)
 
 
 class RelationPack(nn.Module):
@@ -105,6 +109,7 @@ class RelationPack(nn.Module):
         live_of = [-1] * len(edge_types)
         for i, r in enumerate(rel_ids):
             live_of[r] = i
+        self._sel_cache = {}                       # relation-sum selectors of ops.layer_transform, by block layout
         self.register_buffer('rel_ids_i32', torch.tensor(rel_ids, dtype=torch.int32), persistent=False)
         self.register_buffer('live_of_rel_i32', torch.tensor(live_of, dtype=torch.int32), persistent=False)
         self.register_buffer('bip_pos_i32', torch.tensor([self.bip_pos.get(i, -1) for i in range(n)], dtype=torch.int32),
@@ -209,7 +214,7 @@ class HeteroGNN(nn.Module):
             return self.go_feat_mlp
         raise KeyError(f'no feature MLP for node type {t!r} (kgwas/model.py:56-60)')
 
-    def _embed(self, batch: SampledBatch, x_dict, t: str):
+    def _embed(self, batch: SampledBatch, x_dict, t: str, out=None):
         """Feature MLP of the sampled nodes of type t (model.py:56-60).  When most of a type is in the batch
         and its features are wide (the 5120 / 57742-wide gene matrix), the first Linear runs on the RESIDENT
         matrix and the 128-wide result is sliced, instead of slicing 20 KB rows first: same values, the
@@ -219,29 +224,47 @@ class HeteroGNN(nn.Module):
         n = batch.n_nodes[t]
         if n == 0:
             return torch.zeros(0, self.hidden, device=self.lin.weight.device)
+        if out is not None and out.n != n:
+            out = None
         lazy = getattr(x_dict, 'kgw_batch', None) is batch and t in dg.x
         if lazy and not dg.full_graph:
             X = dg.x[t]
             if X.shape[1] >= 512 and 2 * n > X.shape[0]:
-                return mlp.tail(mlp.first(X).index_select(0, batch.n_id(t)))
-        return mlp(x_dict[t])
+                return mlp.tail(mlp.first(X).index_select(0, batch.n_id(t)), out)
+        return mlp(x_dict[t], out)
 
-    def _embed_all(self, batch: SampledBatch, x_dict):
+    def _layer_input(self, batch: SampledBatch, l: int):
+        """Preallocated type-major input matrix of layer l and one RowBlock per node type that has rows in it."""
+        m, sc = batch.meta, self.schema
+        total = int(m.src_base[l - 1][sc.NT])
+        buf = torch.empty(max(total, 1), self.hidden, device=self.lin.weight.device)
+        blocks = {name: ops.RowBlock(buf, int(m.src_base[l - 1][t]), int(m.lay_src[l - 1][t]))
+                  for t, name in enumerate(sc.node_types) if int(m.lay_src[l - 1][t])}
+        return buf, blocks
+
+    def _embed_all(self, batch: SampledBatch, x_dict, blocks=None):
         """All feature MLPs (model.py:56-60).  The three GO types share ``go_feat_mlp`` (model.py:58-60): their
-        rows go through it as ONE matrix."""
+        rows go through it as ONE matrix.  ``blocks``: RowBlocks of the first layer's input to write into."""
         h = {}
+        blocks = blocks or {}
         go = [t for t in self.node_types if t in GO_TYPES and t in x_dict and batch.n_nodes.get(t, x_dict[t].shape[0]) > 0]
         if len(go) > 1:
             xs = [x_dict[t] for t in go]
-            out = self.go_feat_mlp(torch.cat(xs, 0))
-            for t, piece in zip(go, torch.split(out, [x.shape[0] for x in xs], 0)):
+            ns = [x.shape[0] for x in xs]
+            out = None
+            bl = [blocks.get(t) for t in go]
+            if all(b is not None and b.n == n for b, n in zip(bl, ns)) and \
+                    all(bl[k + 1].lo == bl[k].lo + bl[k].n for k in range(len(bl) - 1)):
+                out = ops.RowBlock(bl[0].buf, bl[0].lo, sum(ns))          # the GO blocks are adjacent: one output
+            y = self.go_feat_mlp(torch.cat(xs, 0), out)
+            for t, piece in zip(go, torch.split(y, ns, 0)):
                 h[t] = piece
         for t in self.node_types:
             if t in x_dict and t not in h:
-                h[t] = self._embed(batch, x_dict, t)
+                h[t] = self._embed(batch, x_dict, t, blocks.get(t))
         return h
 
-    def _fused_layers(self, batch: SampledBatch, h: Dict[str, torch.Tensor], want_attention=False):
+    def _fused_layers(self, batch: SampledBatch, h: Dict[str, torch.Tensor], want_attention=False, hbuf=None):
         sc = self.schema
         m = batch.meta
         C = self.hidden
@@ -253,7 +276,7 @@ class HeteroGNN(nn.Module):
             # u_r = W_src^T att_src ; v_r = W_dst^T att_dst (W_src^T att_dst for same-type relations): one launch
             U, V = ops.rel_vectors(P)
             # layer input, type-major (src_base): every type that sends or receives messages in this layer
-            parts = []
+            parts, spans = [], []
             for t, name in enumerate(sc.node_types):
                 ns = int(m.lay_src[l - 1][t])
                 if ns:
@@ -261,14 +284,18 @@ class HeteroGNN(nn.Module):
                         raise RuntimeError(f'layer {l}: node type {name!r} takes part in the layer but has no '
                                            f'incoming relation to produce its layer-{l - 1} state')
                     parts.append(h[name] if h[name].shape[0] == ns else h[name][:ns])
-            H = torch.cat(parts, 0) if len(parts) != 1 else parts[0]
+                    spans.append((int(m.src_base[l - 1][t]), ns))
+            if hbuf is None:
+                hbuf, _ = self._layer_input(batch, l)
+            H = ops.join_blocks(hbuf, spans, parts) if len(parts) != 1 or parts[0].shape[0] != hbuf.shape[0] else parts[0]
             Z, stat, e_edge = ops.gat_aggregate(batch, l, H, U, V, self.negative_slope, self.temperature)
             if want_attention:
                 attn.append(ops.edge_alpha(batch, l, stat, e_edge, self.temperature))
             # per-relation linear maps + bias + relation sum + ReLU: one GEMM per destination type, one autograd node
             tys = [t for t in range(sc.NT) if int(m.lay_rows[l - 1][t])]
             blocks = [(rng[t][0], rng[t][1], int(m.z_base[l - 1][t]), int(m.lay_rows[l - 1][t])) for t in tys]
-            outs = ops.layer_transform(P, Z, blocks)
+            hbuf, nxt = self._layer_input(batch, l + 1) if l < self.num_layers else (None, {})
+            outs = ops.layer_transform(P, Z, blocks, [nxt.get(sc.node_types[t]) for t in tys])
             h_next = {sc.node_types[t]: o for t, o in zip(tys, outs)}
             h = h_next
         return h, attn
@@ -278,8 +305,9 @@ class HeteroGNN(nn.Module):
         batch: Optional[SampledBatch] = getattr(x_dict, 'kgw_batch', None) or getattr(edge_index_dict, 'kgw_batch', None)
         if batch is None:
             batch = self._block_from_coo(x_dict, edge_index_dict)
-        h = self._embed_all(batch, x_dict)
-        h, attn = self._fused_layers(batch, h, want_attention=return_attention_weights)
+        hbuf, blocks = self._layer_input(batch, 1)
+        h = self._embed_all(batch, x_dict, blocks)
+        h, attn = self._fused_layers(batch, h, want_attention=return_attention_weights, hbuf=hbuf)
         snp = h['SNP']
         out = self.lin(snp)[:batch_size]
         if return_h:                                            # model.py:78-79

@@ -232,9 +232,11 @@ def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask
     if not ok:
         if out is not None and bias is None and not relu and mask is None:
             return torch.mm(X, W if w_kn else W.t(), out=out)
-        Y = X @ (W if w_kn else W.t())
-        if bias is not None:
-            Y = Y + bias
+        Wop = W if w_kn else W.t()
+        if mask is None and out is not None:
+            Y = torch.addmm(bias, X, Wop, out=out) if bias is not None else torch.mm(X, Wop, out=out)
+            return torch.relu_(Y) if relu else Y
+        Y = torch.addmm(bias, X, Wop) if bias is not None else X @ Wop
         if relu:
             Y = torch.relu_(Y)
         if mask is not None:
@@ -257,9 +259,9 @@ class _MLPTail(torch.autograd.Function):
     forward and for dX (ReLU mask fused in the epilogue), split-K MFMA kernel for the weight / bias gradients."""
 
     @staticmethod
-    def forward(ctx, h1, W2, b2, W3, b3):
+    def forward(ctx, h1, W2, b2, W3, b3, out=None):
         h2 = linear(h1, W2, b2, relu=True)
-        y = linear(h2, W3, b3)
+        y = linear(h2, W3, b3, out=out.view() if out is not None else None)
         ctx.save_for_backward(h1, h2, W2, W3)
         return y
 
@@ -271,7 +273,75 @@ class _MLPTail(torch.autograd.Function):
         dh2 = linear(dy, W3, mask=h2, w_kn=True)                 # (dy @ W3) * (h2 > 0)
         dW2, db2 = linear_weight_grad(dh2, h1)
         dh1 = linear(dh2, W2, w_kn=True) if ctx.needs_input_grad[0] else None
-        return dh1, dW2, db2, dW3, db3
+        return dh1, dW2, db2, dW3, db3, None
+
+
+class RowBlock:
+    """Rows [lo, lo+n) of a preallocated activation matrix: a node that is handed one writes its output there (the
+    next layer's type-major input is then assembled without a concatenation copy)."""
+
+    def __init__(self, buf: torch.Tensor, lo: int, n: int):
+        self.buf, self.lo, self.n = buf, int(lo), int(n)
+
+    def view(self):
+        # an ALIAS of the rows, not an autograd view of ``buf``: blocks are written independently of each other and
+        # view/in-place version tracking across them would (rightly, in general) refuse that
+        b = self.buf
+        t = torch.empty(0, dtype=b.dtype, device=b.device)
+        return t.set_(b.untyped_storage(), b.storage_offset() + self.lo * b.stride(0), (self.n,) + tuple(b.shape[1:]),
+                      b.stride())
+
+
+class _JoinBlocks(torch.autograd.Function):
+    """The type-major layer input from its per-type blocks; blocks already written in place (RowBlock outputs) cost
+    nothing, others are copied.  Backward hands each block its rows of dH as a view."""
+
+    @staticmethod
+    def forward(ctx, holder, spans, *parts):
+        buf = holder.buf
+        for (lo, n), p in zip(spans, parts):
+            dst = buf[lo:lo + n]
+            if p.data_ptr() != dst.data_ptr() or p.stride(0) != buf.stride(0):
+                dst.copy_(p)
+        ctx.spans = spans
+        return holder.view()
+
+    @staticmethod
+    def backward(ctx, dH):
+        return (None, None) + tuple(dH[lo:lo + n] for lo, n in ctx.spans)
+
+
+def join_blocks(buf: torch.Tensor, spans, parts):
+    return _JoinBlocks.apply(RowBlock(buf, 0, buf.shape[0]), tuple(spans), *parts)
+
+
+class _MLP3(torch.autograd.Function):
+    """SimpleMLP (kgwas/model.py:17-21) on a feature matrix that needs no gradient, as ONE autograd node: three
+    MFMA Linear launches forward; backward = two dX launches with the ReLU masks fused in their epilogues and three
+    split-K weight-gradient launches (no stand-alone ReLU-backward / bias-sum kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, W3, b3, out):
+        h1 = linear(x, W1, b1, relu=True)
+        h2 = linear(h1, W2, b2, relu=True)
+        y = linear(h2, W3, b3, out=out.view() if out is not None else None)
+        ctx.save_for_backward(x, h1, h2, W2, W3)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h1, h2, W2, W3 = ctx.saved_tensors
+        dy = dy.contiguous()
+        dW3, db3 = linear_weight_grad(dy, h2)
+        dh2 = linear(dy, W3, mask=h2, w_kn=True)                 # (dy @ W3) * (h2 > 0)
+        dW2, db2 = linear_weight_grad(dh2, h1)
+        dh1 = linear(dh2, W2, mask=h1, w_kn=True)                # (dh2 @ W2) * (h1 > 0)
+        dW1, db1 = linear_weight_grad(dh1, x)
+        return None, dW1, db1, dW2, db2, dW3, db3, None
+
+
+def mlp3(x, W1, b1, W2, b2, W3, b3, out=None):
+    return _MLP3.apply(x, W1, b1, W2, b2, W3, b3, out)
 
 
 class _LinearReLU(torch.autograd.Function):
@@ -325,8 +395,8 @@ def linear_weight_grad(dY: torch.Tensor, X: torch.Tensor):
     return dY.t().mm(X), dY.sum(0)
 
 
-def mlp_tail(h1, W2, b2, W3, b3):
-    return _MLPTail.apply(h1, W2, b2, W3, b3)
+def mlp_tail(h1, W2, b2, W3, b3, out=None):
+    return _MLPTail.apply(h1, W2, b2, W3, b3, out)
 
 
 def linear_relu(x, W, b):
@@ -380,13 +450,16 @@ class _LayerTransform(torch.autograd.Function):
     arrays feed the destination type whose block starts at Z row z0 and has ``rows`` destination rows."""
 
     @staticmethod
-    def forward(ctx, w_src_t, bias, Z, blocks):
+    def forward(ctx, w_src_t, bias, Z, blocks, sel, out_blocks):
         C = bias.shape[1]
         outs, ys = [], []
-        for lo, hi, z0, rows in blocks:
+        bsum = torch.mm(sel, bias)                      # [n blocks, C]: bias of every relation into a type, summed
+        for k, (lo, hi, z0, rows) in enumerate(blocks):
             R = hi - lo
             x = Z[z0:z0 + rows * R].view(rows, R * C)
-            y = linear(x, w_src_t[lo:hi].view(R * C, C), bias[lo:hi].sum(0), relu=True, w_kn=True)
+            ob = out_blocks[k] if out_blocks is not None else None
+            y = linear(x, w_src_t[lo:hi].view(R * C, C), bsum[k], relu=True, w_kn=True,
+                       out=ob.view() if ob is not None and ob.n == rows else None)
             outs.append(y)
             ys.append(y)
         ctx.save_for_backward(w_src_t, Z, *ys)
@@ -421,8 +494,49 @@ class _LayerTransform(torch.autograd.Function):
             tn_gemm(dz, x, out=dW[lo:hi].view(R * C, C), transpose_out=True, colsum_out=db[lo:hi])
             if need_dz:
                 linear(dz, w_src_t[lo:hi].view(R * C, C), out=dZ[z0:z0 + rows * R].view(rows, R * C))
-        return dW, db, dZ, None
+        return dW, db, dZ, None, None, None
 
 
-def layer_transform(pack, Z, blocks):
-    return _LayerTransform.apply(pack.w_src_t, pack.bias, Z, blocks)
+def layer_transform(pack, Z, blocks, out_blocks=None):
+    """``blocks`` = [(lo, hi, z0, rows)] (see _LayerTransform); ``out_blocks``: optional RowBlock per block to write
+    the outputs into."""
+    key = tuple((lo, hi) for lo, hi, _, _ in blocks)
+    sel = pack._sel_cache.get(key)
+    if sel is None:
+        sel = torch.zeros(len(blocks), pack.bias.shape[0], device=pack.bias.device)
+        for k, (lo, hi) in enumerate(key):
+            sel[k, lo:hi] = 1.0
+        pack._sel_cache[key] = sel
+    return _LayerTransform.apply(pack.w_src_t, pack.bias, Z, blocks, sel, out_blocks)
+
+
+# ------------------------------------------------------------------------------------------------------
+# LD-score weighted loss of a step (kgwas/kgwas.py:139-145) as one node
+# ------------------------------------------------------------------------------------------------------
+class _WeightedMSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, n_id, y_all, w_all):
+        pred = pred.contiguous()
+        n = pred.numel()
+        assert pred.dtype == torch.float32 and n_id.dtype == torch.int32 and n_id.numel() >= n
+        assert y_all.dtype == torch.float32 and w_all.dtype == torch.float64
+        loss = torch.empty((), dtype=torch.float64, device=pred.device)
+        _lib.check(_lib.lib().kgw_wmse_fwd(_p(pred), _p(n_id), _p(y_all), _p(w_all), n, _p(loss), _lib.stream_ptr()),
+                   'kgw_wmse_fwd')
+        ctx.save_for_backward(pred, n_id, y_all, w_all)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        pred, n_id, y_all, w_all = ctx.saved_tensors
+        gloss = gloss.contiguous().to(torch.float64)
+        dpred = torch.empty_like(pred)
+        _lib.check(_lib.lib().kgw_wmse_bwd(_p(pred), _p(n_id), _p(y_all), _p(w_all), pred.numel(), _p(gloss), _p(dpred),
+                                           _lib.stream_ptr()), 'kgw_wmse_bwd')
+        return dpred, None, None, None
+
+
+def weighted_mse(pred, n_id, y_all, w_all):
+    """mean(w_all[n_id] * (pred - y_all[n_id])**2) (float64) for the first ``pred.numel()`` entries of ``n_id``
+    (int32 global ids of the seeds); y_all float32 [N], w_all float64 [N]."""
+    return _WeightedMSE.apply(pred, n_id, y_all, w_all)

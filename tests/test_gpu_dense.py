@@ -139,3 +139,23 @@ def test_fused_adam_matches_torch_adam():
     for a, b in zip(pa, pb):
         assert_close(a, b, 2e-6, 1e-7, 'adam param', rel_to_max=0)
     assert torch.equal(dead_a, dead_b) and int(oa.step_dev) == 6
+
+
+def test_weighted_mse_matches_reference_expression():
+    """kgw_wmse_fwd / _bwd vs the reference's expression, kgwas/kgwas.py:139-145 (float32 residual, float64 weights)."""
+    from kgwas_amd import ops
+    g = torch.Generator().manual_seed(8)
+    N, n = 5000, 512
+    y_all = torch.rand(N, generator=g)
+    w_all = torch.rand(N, generator=g, dtype=torch.float64) * 3
+    n_id = torch.randperm(N, generator=g)[:700].to(torch.int32)          # longer than the batch: only the head is used
+    pred = torch.rand(n, generator=g).cuda().requires_grad_(True)
+    loss = ops.weighted_mse(pred, n_id.cuda(), y_all.cuda(), w_all.cuda())
+    (loss * 1.7).backward()
+    po = pred.detach().cpu().requires_grad_(True)
+    ids = n_id[:n].long()
+    lo = torch.mean(w_all[ids] * (po - y_all[ids]) ** 2)
+    (lo * 1.7).backward()
+    assert loss.dtype == torch.float64
+    assert abs(float(loss) - float(lo)) <= 1e-12 + 1e-9 * abs(float(lo))
+    assert_close(pred.grad, po.grad, 1e-6, 1e-9, 'd pred')
