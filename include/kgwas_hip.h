@@ -31,6 +31,9 @@ extern "C" {
 #define KGW_TILE         1024         /* scan tile; per-type node regions are padded to this  */
 #define KGW_C            128          /* hidden width (gnn_hidden_dim, kgwas/kgwas.py:52)     */
 
+#define KGW_F_RAW_WEIGHTS 1           /* KgwLayerArgs.flags: no softmax (the reference's attention export,
+                                         kgwas/utils.py:446-461 with return_raw_attention_weights)      */
+
 #define KGW_OK           0
 #define KGW_E_NULL      -1
 #define KGW_E_RANGE     -2
@@ -128,6 +131,8 @@ typedef struct KgwLayerArgs {
                                       actual counts from meta_dev) ; multi lists of dst hops [0,n_multi_hops) */
     int32_t n_src_rows;            /* rows of H / dH in the layout (src_base[n_types])         */
     float   neg_slope, inv_temp;   /* LeakyReLU slope (0.2), 1/temperature (1)                 */
+    int32_t flags;                 /* KGW_F_RAW_WEIGHTS: forward weights messages by the raw logits   */
+    int32_t pad_;
     const KgwGraph* graph_host;    /* host copy, passed by value to the kernels               */
     const KgwBatchMeta* meta_host; /* host struct holding the LAYOUT (z_base, src_base, t_base, lay_*) */
     const KgwBatchMeta* meta_dev;  /* device struct written by kgw_sample_batch (actual counts)        */

@@ -86,7 +86,7 @@ class KgwBatchBuf(C.Structure):
 class KgwLayerArgs(C.Structure):
     _fields_ = [
         ('layer', C.c_int32), ('n_chunks', C.c_int32), ('n_multi_hops', C.c_int32), ('n_src_rows', C.c_int32),
-        ('neg_slope', C.c_float), ('inv_temp', C.c_float),
+        ('neg_slope', C.c_float), ('inv_temp', C.c_float), ('flags', C.c_int32), ('pad_', C.c_int32),
         ('graph_host', C.c_void_p), ('meta_host', C.c_void_p), ('meta_dev', C.c_void_p),
         ('chunks', C.c_void_p), ('multi', C.c_void_p), ('multi_cap', C.c_int64),
         ('col_local', C.c_void_p), ('H', C.c_void_p), ('a_dst', C.c_void_p), ('V', C.c_void_p), ('U', C.c_void_p),

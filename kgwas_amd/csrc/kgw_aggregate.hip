@@ -77,6 +77,7 @@ struct AggPtrs {
     int64_t multi_cap;
     const KgwBatchMeta* meta;     // device: actual counts of the batch
     int layer;
+    int raw;                      // forward: raw-logit weights (attention export)
 };
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
@@ -97,7 +98,10 @@ __device__ __forceinline__ KgwChunk load_chunk(const KgwChunk* chunks, int c) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int G>
+// RAW: the messages are weighted by the leaky_relu logits themselves, no softmax -- what the reference's
+// attention export computes (conv.py:221-223 skips the softmax under return_raw_attention_weights and
+// message() :227-228 multiplies by that alpha; kgwas/utils.py:446-461).
+template <int G, bool RAW>
 __device__ __forceinline__ void fwd_group(const float4* __restrict__ Hb4, int colv, int q0, int hn, int nb,
                                           int half, int hl, const float4& u4, float ad, float slope,
                                           float inv_temp, float& m, float& s, float4& acc, float& ev) {
@@ -118,8 +122,14 @@ __device__ __forceinline__ void fwd_group(const float4* __restrict__ Hb4, int co
         float d = kgw_half_allsum(dot4(x[p], u4)) + ad;
         d = d > 0.f ? d : d * slope;
         ev = (hl == q0 + p) ? d : ev;              // lane (half, hl) keeps the logit of edge half*hn+hl
+        if (RAW) { t[p] = valid[p] ? d : 0.f; continue; }
         t[p] = valid[p] ? d * inv_temp : -INFINITY;
         mb = fmaxf(mb, t[p]);
+    }
+    if (RAW) {
+#pragma unroll
+        for (int p = 0; p < G; ++p) fma4(acc, t[p], x[p]);
+        return;
     }
     const float mn = fmaxf(m, mb);
     const float sc = __expf(m - mn);
@@ -132,6 +142,7 @@ __device__ __forceinline__ void fwd_group(const float4* __restrict__ Hb4, int co
     }
 }
 
+template <bool RAW>
 __global__ void __launch_bounds__(KGW_BLK) k_agg_fwd(LayerTab T, AggPtrs P, float slope, float inv_temp) {
     const int lane = kgw_lane(), half = lane >> 5, hl = lane & 31;
     const int nw = gridDim.x * 4;
@@ -161,23 +172,23 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_fwd(LayerTab T, AggPtrs P, floa
             float ev = 0.f;
             for (int q0 = 0; q0 < hn;) {
                 const int rem = hn - q0;
-                if (rem > 4)      { fwd_group<8>(Hb4, colv, q0, hn, nb, half, hl, u4, ad, slope, inv_temp, m, s, acc, ev); q0 += 8; }
-                else if (rem > 2) { fwd_group<4>(Hb4, colv, q0, hn, nb, half, hl, u4, ad, slope, inv_temp, m, s, acc, ev); q0 += 4; }
-                else              { fwd_group<2>(Hb4, colv, q0, hn, nb, half, hl, u4, ad, slope, inv_temp, m, s, acc, ev); q0 += 2; }
+                if (rem > 4)      { fwd_group<8, RAW>(Hb4, colv, q0, hn, nb, half, hl, u4, ad, slope, inv_temp, m, s, acc, ev); q0 += 8; }
+                else if (rem > 2) { fwd_group<4, RAW>(Hb4, colv, q0, hn, nb, half, hl, u4, ad, slope, inv_temp, m, s, acc, ev); q0 += 4; }
+                else              { fwd_group<2, RAW>(Hb4, colv, q0, hn, nb, half, hl, u4, ad, slope, inv_temp, m, s, acc, ev); q0 += 2; }
             }
             const int i = half * hn + hl;
             if (hl < hn && i < nb) P.e_edge[ck.e0 + b + i] = ev;
         }
         // merge the two half-wave states
         const float mo = kgw_xhalf(m);
-        const float M = fmaxf(m, mo);
-        const float f = __expf(m - M);
+        const float M = RAW ? 0.f : fmaxf(m, mo);
+        const float f = RAW ? 1.f : __expf(m - M);
         s *= f; scale4(acc, f);
-        const float S = s + kgw_xhalf(s);
+        const float S = RAW ? 1.f : s + kgw_xhalf(s);
         acc.x += kgw_xhalf(acc.x); acc.y += kgw_xhalf(acc.y);
         acc.z += kgw_xhalf(acc.z); acc.w += kgw_xhalf(acc.w);
         if (ck.nch == 1) {
-            const float den = S + 1e-16f;
+            const float den = RAW ? 1.f : S + 1e-16f;
             const float inv = 1.0f / den;
             if (half == 0) {
                 scale4(acc, inv);
@@ -223,7 +234,8 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_fwd_combine(LayerTab T, AggPtrs
             const float2 a = ((const float2*)(pr + 4))[lane];
             acc.x = fmaf(a.x, f, acc.x); acc.y = fmaf(a.y, f, acc.y);
         }
-        const float den = S + 1e-16f, inv = 1.0f / den;
+        // (raw mode: every partial carries max 0 and sum 1, so f == 1 above and the sum of partials is the result)
+        const float den = P.raw ? 1.f : S + 1e-16f, inv = 1.0f / den;
         ((float2*)(P.Z + (int64_t)zrow * KGW_C))[lane] = make_float2(acc.x * inv, acc.y * inv);
         if (lane == 0) { P.stat[2 * (int64_t)zrow] = M; P.stat[2 * (int64_t)zrow + 1] = den; }
     }
@@ -493,7 +505,7 @@ int build_tab(const KgwLayerArgs* a, LayerTab* T) {
 
 AggPtrs build_ptrs(const KgwLayerArgs* a) {
     AggPtrs P;
-    P.chunks = a->chunks; P.col_local = a->col_local; P.H = a->H; P.a_dst = a->a_dst; P.V = a->V; P.U = a->U;
+    P.chunks = a->chunks; P.col_local = a->col_local; P.H = a->H; P.a_dst = a->a_dst; P.V = a->V; P.U = a->U; P.raw = (a->flags & KGW_F_RAW_WEIGHTS) ? 1 : 0;
     P.Z = a->Z; P.stat = a->stat; P.e_edge = a->e_edge; P.part = a->part; P.dZ = a->dZ; P.adp = a->adp;
     P.da_dst = a->da_dst; P.part_da = a->part_da; P.t_ptr = a->t_ptr; P.t_edge = a->t_edge;
     P.t_zrow = a->t_zrow; P.dH = a->dH; P.da_src = a->da_src; P.multi = a->multi; P.multi_cap = a->multi_cap;
@@ -521,7 +533,8 @@ extern "C" int kgw_gat_aggregate_fwd(const KgwLayerArgs* a, kgw_stream_t stream_
     if (rc) return rc;
     AggPtrs P = build_ptrs(a);
     hipStream_t st = (hipStream_t)stream_;
-    k_agg_fwd<<<grid_for_waves(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
+    if (P.raw) k_agg_fwd<true><<<grid_for_waves(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
+    else       k_agg_fwd<false><<<grid_for_waves(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
     KGW_LAUNCH_CHECK();
     if (a->multi && a->multi_cap > 0) {     // hub rows: the number of multi-chunk segments is read on the device
         for (int h = 0; h < a->n_multi_hops; ++h) {

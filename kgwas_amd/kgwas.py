@@ -25,7 +25,8 @@ from . import dist as kdist
 from . import ops
 from .model import HeteroGNN
 from .sampler import NeighborLoader
-from .utils import compute_metrics, evaluate_minibatch_clean, load_pretrained, print_sys, save_model
+from .utils import (compute_metrics, evaluate_minibatch_clean, get_network_weight, load_pretrained, print_sys,
+                    save_model)
 
 
 class KGWAS:
@@ -174,6 +175,16 @@ class KGWAS:
         infer_res = evaluate_minibatch_clean(self.infer_loader, self.best_model, self.device)
         self.data.lr_uni['pred'] = infer_res['pred']                 # kgwas.py:191
         self._postprocess(save_name, save_best_model and rank == 0)
+
+    def get_network_weight(self):
+        """The graph-side half of kgwas/kgwas.py:268-273: per-edge raw attention weights of the best model."""
+        return get_network_weight(self, self.data)
+
+    def get_disease_critical_network(self, *args, **kwargs):
+        """kgwas/kgwas.py:268-273 goes on to `generate_viz` (MAGMA binary, plots): outside this build's scope
+        (SURVEY.md 8); the network weights it starts from are `get_network_weight()`."""
+        raise NotImplementedError('only the attention export is built: use KGWAS.get_network_weight(); generate_viz '
+                                  '(external MAGMA binary + plotting, kgwas/utils.py:496-) is out of scope')
 
     def _postprocess(self, save_name, save_best_model):
         """kgwas.py:192-212: prediction-weighted p-values (Storey-Tibshirani pi0 per prediction-quantile bin,

@@ -320,6 +320,67 @@ class HeteroGNN(nn.Module):
         return self.ReLU(out)                                   # model.py:86
 
     # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def raw_attention_full_graph(self, graph: HeteroGraph, device=None):
+        """Per layer, per relation: (edge_index [2,E] global ids, raw attention [E]) over the WHOLE graph, the way
+        the reference's export computes them (kgwas/utils.py:437-461): every relation of every layer takes part,
+        the attention is leaky_relu(alpha_j + alpha_i) without softmax (conv.py:217-223 under
+        return_raw_attention_weights), the layer output fed to the next layer is the sum of messages weighted by
+        those raw values (conv.py:227-228) plus bias, summed over relations, and -- unlike HeteroGNN.forward -- NO
+        ReLU is applied between the layers (utils.py:460)."""
+        from .sampler import BatchBuffers, DeviceGraph, finish_sample, sample_into
+        dev = torch.device(device) if device is not None else self.lin.weight.device
+        sc = self.schema
+        dg = DeviceGraph.get(graph, self.num_layers, dev, full_graph=True).with_all_relations_live()
+        buf = BatchBuffers(dg)
+        sample_into(dg, buf, None, 0)
+        batch = finish_sample(dg, buf, sc.node_types[0], dg.n_nodes[0])
+        m = batch.meta
+        h = self._embed_all(batch, batch.x_dict)
+        ei = batch.edge_index_dict                         # full graph: local ids are the global ids
+        seg_ptr = buf.seg_ptr
+        C = self.hidden
+        layers = []
+        for l in range(1, self.num_layers + 1):
+            U = torch.zeros(sc.NR, C, device=dev)
+            V = torch.zeros(sc.NR, C, device=dev)
+            for pack in (self.live_packs[l - 1], self.dead_packs[l - 1]):
+                if len(pack.rel_ids):
+                    u, v = ops.rel_vectors(pack)           # rows of the pack's relations, zeros elsewhere
+                    U += u; V += v
+            parts = []
+            for t, name in enumerate(sc.node_types):
+                ns = int(m.lay_src[l - 1][t])
+                if ns:
+                    if name not in h or h[name].shape[0] < ns:
+                        raise RuntimeError(f'layer {l}: node type {name!r} has no layer-{l - 1} state')
+                    parts.append(h[name][:ns])
+            H = torch.cat(parts, 0)
+            Z, _, e_edge = ops.gat_aggregate(batch, l, H, U, V, self.negative_slope, self.temperature, raw_weights=True)
+            att = OrderedDict()
+            for r, et in enumerate(self.edge_types):
+                a, b = int(m.seg_off[0][r]), int(m.seg_off[0][r + 1])
+                e0, e1 = (int(seg_ptr[a]), int(seg_ptr[b])) if b > a else (0, 0)
+                att[et] = (ei[et], e_edge[e0:e1])
+            layers.append(att)
+            h_next = {}
+            for t, name in enumerate(sc.node_types):
+                n, R = int(m.lay_rows[l - 1][t]), int(sc.R_dst[t])
+                if n == 0 or R == 0:
+                    continue
+                z0 = int(m.z_base[l - 1][t])
+                x = Z[z0:z0 + n * R].view(n, R * C)
+                ws, bs = [], 0
+                for r in sc.rels_by_dst[t]:                # slot order of the Z columns
+                    which, i = self._slot[l - 1][r]
+                    pack = self.live_packs[l - 1] if which == 'live' else self.dead_packs[l - 1]
+                    ws.append(pack.w_src_t[i])
+                    bs = bs + pack.bias[i]
+                h_next[name] = torch.addmm(bs, x, torch.cat(ws, 0))          # no ReLU here (utils.py:460)
+            h = h_next
+        return layers
+
+    # ------------------------------------------------------------------------------------------
     def _block_from_coo(self, x_dict, edge_index_dict) -> SampledBatch:
         """Plain (x_dict, edge_index_dict) inputs: every row of every type is computed in every layer,
         exactly like the reference on a PyG batch / the full graph (kgwas/utils.py:446-461)."""

@@ -76,7 +76,7 @@ def _layer_args(batch, layer: int, neg_slope: float, inv_temp: float) -> KgwLaye
 
 class _GatAggregate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, H, U, V, batch, layer, neg_slope, inv_temp):
+    def forward(ctx, H, U, V, batch, layer, neg_slope, inv_temp, raw_weights=False):
         dg, m = batch.dg, batch.meta
         NT = dg.schema.NT
         z_rows = int(m.z_base[layer - 1][NT])
@@ -94,6 +94,8 @@ class _GatAggregate(torch.autograd.Function):
         part = torch.empty(max(n_chunks, 1) * PART_STRIDE if any_multi else 4, device=dev)
         a = _layer_args(batch, layer, neg_slope, inv_temp)
         a.H, a.V, a.U = _p(H), _p(V), _p(U)
+        a.flags = 1 if raw_weights else 0          # KGW_F_RAW_WEIGHTS
+        ctx.raw_weights = raw_weights
         a.Z, a.stat, a.e_edge, a.part = _p(Z), _p(stat), _p(e_edge), _p(part)
         ev = TIMER.bracket('fwd', layer, n_edges, z_rows, n_src)
         _lib.check(_lib.lib().kgw_gat_aggregate_fwd(C.byref(a), _lib.stream_ptr()), 'kgw_gat_aggregate_fwd')
@@ -105,6 +107,8 @@ class _GatAggregate(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, _dstat, _de, dZ):
+        if ctx.raw_weights:
+            raise RuntimeError('raw-logit aggregation (attention export) is inference only')
         H, U, V, Z, stat, e_edge = ctx.saved_tensors
         batch, layer = ctx.batch, ctx.layer
         dg, m = batch.dg, batch.meta
@@ -141,17 +145,19 @@ class _GatAggregate(torch.autograd.Function):
             dU, dV = dUV[:sc.NR], dUV[ld_da:ld_da + sc.NR]
         else:
             dU, dV = torch.zeros_like(U), torch.zeros_like(V)
-        return dH[:n_src], dU, dV, None, None, None, None
+        return dH[:n_src], dU, dV, None, None, None, None, None
 
 
 def gat_aggregate(batch, layer: int, H: torch.Tensor, U: torch.Tensor, V: torch.Tensor,
-                  neg_slope: float = 0.2, temperature: float = 1.0):
+                  neg_slope: float = 0.2, temperature: float = 1.0, raw_weights: bool = False):
     """Z[i, r] = sum_j softmax_j(leaky_relu(<H_src[j], u_r> + <H_dst[i], v_r>) / T) H_src[j] for every live relation
     of the layer.  H [n_src_rows,128]: layer input, type-major (``meta.src_base``; a destination node is row i of
     its own type's block); U, V [n_rels,128] by relation id.  Returns (Z [z_rows,128], stat [z_rows,2] =
     (row max, denominator), e_edge [n_edges]); Z is type-major: the block of destination type t starts at row
-    ``meta.z_base[layer-1][t]`` and holds ``lay_rows * R_dst[t]`` rows ([row, relation slot, 128])."""
-    stat, e_edge, Z = _GatAggregate.apply(H, U, V, batch, layer, float(neg_slope), 1.0 / float(temperature))
+    ``meta.z_base[layer-1][t]`` and holds ``lay_rows * R_dst[t]`` rows ([row, relation slot, 128]).
+    ``raw_weights``: Z[i, r] = sum_j e_ij H_src[j] with e the leaky_relu logits, no softmax (inference only; what
+    the reference's attention export propagates, kgwas/utils.py:446-461 + conv.py:221-228)."""
+    stat, e_edge, Z = _GatAggregate.apply(H, U, V, batch, layer, float(neg_slope), 1.0 / float(temperature), raw_weights)
     return Z, stat, e_edge
 
 

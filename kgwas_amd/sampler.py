@@ -126,6 +126,20 @@ class DeviceGraph:
         dg.caps = caps
         return dg
 
+    def with_all_relations_live(self) -> "DeviceGraph":
+        """Same resident graph with EVERY relation computed in EVERY layer (no structural pruning): what plain
+        inference over all node types needs (the attention export, kgwas/utils.py:437-461)."""
+        import copy
+        dg = copy.copy(self)
+        g = KgwGraph()
+        C.memmove(C.addressof(g), C.addressof(self.kg), C.sizeof(KgwGraph))
+        for l in range(self.num_layers):
+            for r in range(self.schema.NR):
+                g.rel_live[l][r] = 1
+        dg.kg = g
+        dg.live_rel = [None] + [list(range(self.schema.NR)) for _ in range(self.num_layers)]
+        return dg
+
     def static_meta(self) -> KgwBatchMeta:
         """Host-side KgwBatchMeta holding the LAYOUT of a static-caps graph (same formulas as the device's
         k_layer_tables); the counts of a particular batch stay on the device."""

@@ -80,3 +80,33 @@ def ldsc_regression_weights(ld, w_ld, N, M, hsq, intercept=None, ii=None):
     het_w = 1.0 / (2 * np.square(intercept + np.multiply(c, ld)))
     oc_w = 1.0 / w_ld
     return np.multiply(het_w, oc_w)
+
+
+def get_network_weight(run, data):
+    """kgwas/utils.py:437-494: raw attention weight of every edge of the knowledge graph at every layer, from the
+    best model, as a DataFrame [h_idx, t_idx, weight, h_type, rel_type, t_type, layer] (duplicates of
+    (h_idx, t_idx, rel_type, layer) dropped).  The reference runs its modified HeteroConv on the CPU; here the
+    whole-graph pass runs on the fused kernels (HeteroGNN.raw_attention_full_graph)."""
+    import pandas as pd
+    model = getattr(run, 'best_model', None) or run.model
+    print('Retrieving weights...')
+    was_training = model.training
+    model.eval()
+    layers = model.raw_attention_full_graph(data.data, run.device)
+    model.train(was_training)
+    print('Aggregating across node types...')
+    frames = []
+    node_types = list(data.data.node_types)
+    for k, att in enumerate(layers):
+        for node_type in node_types:                                     # utils.py:469-474 iteration order
+            for et, (ei, w) in att.items():
+                if et[2] != node_type:
+                    continue
+                ei = ei.cpu().numpy()
+                df = pd.DataFrame({'h_idx': ei[0].astype(np.float64), 't_idx': ei[1].astype(np.float64),
+                                   'weight': w.cpu().numpy().astype(np.float64)})
+                df['h_type'], df['rel_type'], df['t_type'], df['layer'] = et[0], et[1], et[2], f'l{k + 1}'
+                frames.append(df)
+    cols = ['h_idx', 't_idx', 'weight', 'h_type', 'rel_type', 't_type', 'layer']
+    df_all = pd.concat(frames)[cols] if frames else pd.DataFrame(columns=cols)
+    return df_all.drop_duplicates(['h_idx', 't_idx', 'rel_type', 'layer'])

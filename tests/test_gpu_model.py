@@ -245,3 +245,46 @@ def test_validation_pearson_matches_oracle_after_training(small_kg):
     assert abs(r_hip - r_ref) < 1e-3, (r_hip, r_ref)
     rel = float(np.linalg.norm(res['pred'] - pred_o) / max(np.linalg.norm(pred_o), 1e-12))
     assert rel < 2e-2, f'relative L2 difference of the validation predictions {rel:.3e} (r_hip {r_hip:.5f}, r_ref {r_ref:.5f})'
+
+
+def test_network_weight_export_matches_reference_procedure(small_kg):
+    """Row f-2: KGWAS.get_network_weight() (kgwas/utils.py:437-494) vs the same procedure on the fp64 oracle: MLPs,
+    then every HeteroConv with raw (un-normalised) attention returned AND propagated, no ReLU between layers."""
+    from kgwas_amd.kgwas import KGWAS
+    from oracle.gat_oracle import GO_TYPES
+    run = KGWAS(small_kg, device='cuda:0', seed=5)
+    run.initialize_model()
+    with torch.no_grad():                       # make bias / dead relations non-trivial
+        for p in run.model.parameters():
+            if p.dim() == 2 and p.shape[-1] == 128 and float(p.abs().sum()) == 0.0:
+                p.uniform_(-0.1, 0.1)
+    run.best_model = run.model
+    df = run.get_network_weight()
+    assert list(df.columns) == ['h_idx', 't_idx', 'weight', 'h_type', 'rel_type', 't_type', 'layer']
+    assert set(df.layer.unique()) == {'l1', 'l2'}
+
+    g = small_kg.data
+    o = oracle_from_product(run.model)
+    with torch.no_grad():
+        x = {t: g[t].x.double() for t in g.node_types}
+        x['SNP'] = o.snp_feat_mlp(x['SNP']); x['Gene'] = o.gene_feat_mlp(x['Gene'])
+        for t in GO_TYPES:
+            x[t] = o.go_feat_mlp(x[t])
+        ei = {et: g[et].edge_index for et in g.edge_types}
+        n_checked = 0
+        for k, conv in enumerate(o.convs):
+            x, att = conv(x, ei, return_attention_weights=True, raw=True)          # utils.py:452-460 (no relu)
+            for et, a in att.items():
+                sub = df[(df.layer == f'l{k + 1}') & (df.h_type == et[0]) & (df.rel_type == et[1]) & (df.t_type == et[2])]
+                e = ei[et].numpy()
+                # the reference drops duplicate (h, t) pairs per relation and layer: compare on unique pairs
+                key_ref = e[0].astype(np.int64) * (1 << 32) + e[1]
+                _, first = np.unique(key_ref, return_index=True)
+                ref = dict(zip(key_ref[first].tolist(), a.reshape(-1).numpy()[first].tolist()))
+                key_my = sub.h_idx.values.astype(np.int64) * (1 << 32) + sub.t_idx.values.astype(np.int64)
+                assert len(key_my) == len(ref) and set(key_my.tolist()) == set(ref)
+                mine = torch.tensor(sub.weight.values)
+                want = torch.tensor([ref[q] for q in key_my.tolist()])
+                assert_close(mine, want, 2e-4, 1e-5, f'raw attention l{k + 1} {et}', rel_to_max=1e-5)
+                n_checked += len(ref)
+    assert n_checked > 0
