@@ -118,6 +118,8 @@ typedef struct KgwBatchBuf {
     int32_t* t_edge[KGW_MAX_LAYERS];  /* [edge_cap] local edge id of each entry                */
     int32_t* t_zrow[KGW_MAX_LAYERS];  /* [edge_cap] Z row (dst row * R_dst + slot) of the entry */
     int32_t* scan_tmp;     /* [2 * (max(seg_cap, node_cap, trow_cap) / KGW_TILE + 2)]          */
+    int32_t* t_tmp;        /* [4 * edge_cap], 16-B aligned: unsorted (edge, Z row, src-major row, 0) entries: the atomic cursor
+                              fill lands here, a rank pass writes them in ascending edge order         */
     KgwBatchMeta* meta;    /* device                                                           */
     KgwBatchMeta* meta_host; /* pinned host mirror (async D2H at the end of sampling)          */
     int64_t seg_cap, edge_cap, chunk_cap, multi_cap, trow_cap, scan_cap;

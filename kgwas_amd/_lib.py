@@ -77,7 +77,7 @@ class KgwBatchBuf(C.Structure):
         ('chunks', C.c_void_p), ('multi', C.c_void_p),
         ('t_cnt', C.c_void_p * KGW_MAX_LAYERS), ('t_ptr', C.c_void_p * KGW_MAX_LAYERS),
         ('t_edge', C.c_void_p * KGW_MAX_LAYERS), ('t_zrow', C.c_void_p * KGW_MAX_LAYERS),
-        ('scan_tmp', C.c_void_p), ('meta', C.c_void_p), ('meta_host', C.c_void_p),
+        ('scan_tmp', C.c_void_p), ('t_tmp', C.c_void_p), ('meta', C.c_void_p), ('meta_host', C.c_void_p),
         ('seg_cap', C.c_int64), ('edge_cap', C.c_int64), ('chunk_cap', C.c_int64),
         ('multi_cap', C.c_int64), ('trow_cap', C.c_int64), ('scan_cap', C.c_int64),
     ]

@@ -423,6 +423,7 @@ __global__ void k_t_begin(SampArgs A, int l) {
     KgwBatchMeta* M = A.B.meta;
     M->cur[0] = 0;
     M->cur[1] = M->error ? 0 : M->t_base[l - 1][A.G.n_types];
+    M->cur[5] = 0;                                   // length of k_t_rank's work list of long rows
 }
 
 // One wavefront per chunk (chunks of the benchmark graph average ~100 edges: the lanes are busy; a
@@ -450,14 +451,85 @@ __global__ void __launch_bounds__(KGW_BLK) k_t_pass(SampArgs A, int l) {
             if (!FILL) {
                 atomicAdd(&cnt[trow], 1);
             } else {
+                // position inside the row in ARRIVAL order (atomic cursor): staged, then k_t_rank puts the row in
+                // ascending edge order so that the backward's summation order is the same run to run
                 const int pos = A.B.t_ptr[l - 1][trow] + atomicSub(&cnt[trow], 1) - 1;
-                A.B.t_edge[l - 1][pos] = e;
-                A.B.t_zrow[l - 1][pos] = zrow;
+                ((int4*)A.B.t_tmp)[pos] = make_int4(e, zrow, trow, 0);
             }
         }
     }
 }
 
+// Final (deterministic) order of the src-major rows: ascending edge id inside every row.  The rank of a staged
+// entry = #entries of its row with a smaller edge id (edge ids are unique).
+//   k_t_rank      one lane per staged entry; rows of <= T_BIG entries are ranked by a short loop over the row's
+//                 staged keys (L1-resident: neighbouring lanes read the same keys); longer rows are put on a work
+//                 list by the lane that owns their first entry;
+//   k_t_rank_big  one block per listed row, keys staged in LDS and compared four per ds_read_b128 (rows above
+//                 T_LDS entries, which only whole-graph blocks have: plain memory loop).
+// On the benchmark graph 99 % of the rows have <= 40 entries but the 0.1 % above 64 hold most of sum(n^2).
+constexpr int T_BIG = 64, T_LDS = 4096;
+
+__global__ void __launch_bounds__(KGW_BLK) k_t_rank(SampArgs A, int l) {
+    KgwBatchMeta* M = A.B.meta;
+    if (M->error) return;
+    const int n = M->cur[4];                       // entries of this layer (total of the histogram scan)
+    const int4* tmp = (const int4*)A.B.t_tmp;
+    const int32_t* tp = A.B.t_ptr[l - 1];
+    int32_t* big = A.B.t_cnt[l - 1];               // histogram scratch is free again: work list of long rows
+    for (int p = blockIdx.x * KGW_BLK + threadIdx.x; p < n; p += gridDim.x * KGW_BLK) {
+        const int4 me = tmp[p];
+        const int e = me.x, trow = me.z;
+        const int s0 = tp[trow], s1 = tp[trow + 1];
+        if (s1 - s0 > T_BIG) {
+            if (p == s0) big[atomicAdd(&M->cur[5], 1)] = trow;
+            continue;
+        }
+        int rank = 0;
+        if (s1 - s0 > 1)
+            for (int q = s0; q < s1; ++q) rank += (tmp[q].x < e) ? 1 : 0;
+        A.B.t_edge[l - 1][s0 + rank] = e;
+        A.B.t_zrow[l - 1][s0 + rank] = me.y;
+    }
+}
+
+__global__ void __launch_bounds__(KGW_BLK) k_t_rank_big(SampArgs A, int l) {
+    __shared__ __attribute__((aligned(16))) int keys[T_LDS];
+    const KgwBatchMeta* M = A.B.meta;
+    if (M->error) return;
+    const int nbig = M->cur[5];
+    const int4* tmp = (const int4*)A.B.t_tmp;
+    const int32_t* tp = A.B.t_ptr[l - 1];
+    const int32_t* big = A.B.t_cnt[l - 1];
+    for (int b = blockIdx.x; b < nbig; b += gridDim.x) {
+        const int trow = big[b];
+        const int s0 = tp[trow], len = tp[trow + 1] - s0;
+        const bool in_lds = len <= T_LDS;
+        const int len4 = (len + 3) & ~3;
+        __syncthreads();
+        if (in_lds)
+            for (int i = threadIdx.x; i < len4; i += KGW_BLK) keys[i] = (i < len) ? tmp[s0 + i].x : 0x7fffffff;
+        __syncthreads();
+        for (int i = threadIdx.x; i < len; i += KGW_BLK) {
+            const int4 me = tmp[s0 + i];
+            int rank = 0;
+            if (in_lds) {
+#pragma unroll 4
+                for (int q = 0; q < len4; q += 4) {
+                    const int4 k4 = *(const int4*)(keys + q);
+                    rank += (k4.x < me.x) + (k4.y < me.x) + (k4.z < me.x) + (k4.w < me.x);
+                }
+            } else {
+                for (int q = 0; q < len; ++q) rank += (tmp[s0 + q].x < me.x) ? 1 : 0;
+            }
+            A.B.t_edge[l - 1][s0 + rank] = me.x;
+            A.B.t_zrow[l - 1][s0 + rank] = me.y;
+        }
+    }
+}
+
+// the work list lives in the histogram array, which the next sampling call expects zeroed only up to its own fill:
+// nothing to restore (kgw_sample_batch clears t_cnt before every use)
 __global__ void k_t_end(SampArgs A, int l) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     A.B.meta->t_entries[l - 1] = A.B.meta->cur[4];
@@ -517,7 +589,7 @@ extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, c
     KGW_LAUNCH_CHECK();
 
     for (int l = 1; l <= graph->n_layers; ++l) {
-        if (!buf->t_cnt[l - 1] || !buf->t_ptr[l - 1] || !buf->t_edge[l - 1] || !buf->t_zrow[l - 1])
+        if (!buf->t_cnt[l - 1] || !buf->t_ptr[l - 1] || !buf->t_edge[l - 1] || !buf->t_zrow[l - 1] || !buf->t_tmp)
             return KGW_E_NULL;
         { int rc = fill_i32(buf->t_cnt[l - 1], 0, buf->trow_cap + 1, st); if (rc) return rc; }
         k_t_begin<<<1, 64, 0, st>>>(A, l);
@@ -527,6 +599,8 @@ extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, c
         k_scan_apply<1><<<KGW_GRID, KGW_BLK, 0, st>>>(buf->t_cnt[l - 1], nullptr, buf->t_ptr[l - 1],
                                                       nullptr, buf->meta, buf->scan_tmp);
         k_t_pass<true><<<KGW_GRID, KGW_BLK, 0, st>>>(A, l);
+        k_t_rank<<<KGW_GRID, KGW_BLK, 0, st>>>(A, l);
+        k_t_rank_big<<<KGW_GRID, KGW_BLK, 0, st>>>(A, l);
         k_t_end<<<1, 64, 0, st>>>(A, l);
         KGW_LAUNCH_CHECK();
     }

@@ -211,6 +211,7 @@ class BatchBuffers:
         self.t_zrow = [torch.empty(dg.edge_cap + 1, **i32) for _ in range(L)]
         self.scan_cap = 2 * (max(dg.seg_cap, dg.node_slots, dg.trow_cap) // KGW_TILE + 4)
         self.scan_tmp = torch.empty(self.scan_cap, **i32)
+        self.t_tmp = torch.empty(4 * (dg.edge_cap + 1), **i32)
         nbytes = C.sizeof(KgwBatchMeta)
         self.meta = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         self.meta_host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
@@ -223,6 +224,7 @@ class BatchBuffers:
             b.t_cnt[l] = self.t_cnt[l].data_ptr(); b.t_ptr[l] = self.t_ptr[l].data_ptr()
             b.t_edge[l] = self.t_edge[l].data_ptr(); b.t_zrow[l] = self.t_zrow[l].data_ptr()
         b.scan_tmp, b.meta, b.meta_host = self.scan_tmp.data_ptr(), self.meta.data_ptr(), self.meta_host.data_ptr()
+        b.t_tmp = self.t_tmp.data_ptr()
         b.seg_cap, b.edge_cap, b.chunk_cap = dg.seg_cap, dg.edge_cap, dg.chunk_cap
         b.multi_cap, b.trow_cap, b.scan_cap = dg.multi_cap, dg.trow_cap, self.scan_cap
         self.c = b
@@ -231,7 +233,7 @@ class BatchBuffers:
 
     def tensors(self):
         return [self.g2l, self.n_id, self.seg_deg, self.seg_nch, self.seg_ptr, self.seg_chptr, self.col_local,
-                self.chunks, self.multi, self.scan_tmp, self.meta] + self.t_cnt + self.t_ptr + self.t_edge + self.t_zrow
+                self.chunks, self.multi, self.scan_tmp, self.t_tmp, self.meta] + self.t_cnt + self.t_ptr + self.t_edge + self.t_zrow
 
     def record_stream(self, stream):
         """The buffers were allocated on the consumer's stream but are written on the sampler's side stream:

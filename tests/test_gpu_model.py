@@ -288,3 +288,25 @@ def test_network_weight_export_matches_reference_procedure(small_kg):
                 assert_close(mine, want, 2e-4, 1e-5, f'raw attention l{k + 1} {et}', rel_to_max=1e-5)
                 n_checked += len(ref)
     assert n_checked > 0
+
+
+def test_gradients_are_bit_reproducible(small_kg):
+    """Same batch, same parameters, two independent sample + forward + backward passes: every gradient is bitwise
+    identical (no atomics in the arithmetic; the sampler's src-major rows are put in a fixed order)."""
+    from kgwas_amd.kgwas import KGWAS
+    run = KGWAS(small_kg, device='cuda:0', seed=3)
+    run.initialize_model()
+    ld_w = run._ld_weight_vector()
+    ids = np.asarray(small_kg.train_input_nodes[1][:256])
+    grads = []
+    for _ in range(2):
+        batch = next(iter(_loader(small_kg.data, ids, 256)))
+        run.model.zero_grad(set_to_none=True)
+        out = run.model(batch.x_dict, batch.edge_index_dict, 256)
+        from kgwas_amd import ops
+        loss = ops.weighted_mse(out.reshape(-1), batch.n_id('SNP'), batch.dg.y['SNP'], ld_w)
+        loss.backward()
+        grads.append([p.grad.clone() for p in run.model.parameters() if p.grad is not None])
+    assert len(grads[0]) == len(grads[1]) > 0
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)

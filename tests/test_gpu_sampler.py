@@ -119,6 +119,11 @@ def test_block_structures_are_consistent(small_kg, edge_case_graph, which):
         assert np.all(tptr[trow] <= pos) and np.all(pos < tptr[trow + 1])
         assert np.array_equal(tz, zb[dst_t] + row * sc.R_dst[dst_t] + sc.slot_dst[rel])
         assert ne <= n_edges_all
+        # deterministic order: inside every src-major row the entries ascend by edge id (the atomic cursor of the
+        # fill only decides staging slots; k_t_rank fixes the final order)
+        row_of = np.repeat(np.arange(t_rows), np.diff(tptr))
+        same = row_of[1:] == row_of[:-1]
+        assert np.all(tedge[1:][same] > tedge[:-1][same])
 
 
 def test_full_graph_block(edge_case_graph):
