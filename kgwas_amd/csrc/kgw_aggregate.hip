@@ -372,6 +372,8 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, 
         // works on shuffles of it instead of a chain of dependent scalar loads
         const int tpv = (lane <= Rs) ? P.t_ptr[tb + lane] : 0;
         const int p0 = __shfl(tpv, 0, 64), p1 = __shfl(tpv, Rs, 64);
+        const int tpn = __shfl_down(tpv, 1, 64);
+        const unsigned long long slots = __ballot(lane < Rs && tpn > tpv);      // bit k: slot k has entries
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         float dasv = 0.f;                                    // lane k holds d a_src of slot k
         for (int pb = p0; pb < p1; pb += 64) {
@@ -385,10 +387,12 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, 
                 const float2 a2 = ((const float2*)P.adp)[te];
                 al = a2.x; dp = a2.y;
             }
-            // per-slot sums of d pre-activation (entries of one source are grouped by slot)
-            for (int k = 0; k < Rs; ++k) {
+            // per-slot sums of d pre-activation (entries of one source are grouped by slot); only slots that have
+            // entries are visited (most sources use 1-3 of their slots)
+            for (unsigned long long left = slots; left; left &= left - 1) {
+                const int k = __builtin_ctzll(left);
                 const int s0 = __shfl(tpv, k, 64), s1 = __shfl(tpv, k + 1, 64);
-                if (s1 <= pb || s0 >= pb + nb || s0 == s1) continue;
+                if (s1 <= pb || s0 >= pb + nb) continue;
                 const int pos = pb + lane;
                 const float v = (lane < nb && pos >= s0 && pos < s1) ? dp : 0.f;
                 const float sk = kgw_wave_allsum(v);
@@ -405,7 +409,8 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, 
         acc.z += kgw_xhalf(acc.z); acc.w += kgw_xhalf(acc.w);
         if (p1 > p0) {
             // d a_src flows back into h_src through a_s = <h_src, u_r>
-            for (int k = 0; k < Rs; ++k) {
+            for (unsigned long long left = slots; left; left &= left - 1) {
+                const int k = __builtin_ctzll(left);
                 const float dk = __shfl(dasv, k, 64);
                 if (dk != 0.f) {
                     const int r = T.rel_of_slot[ty][k];
