@@ -231,7 +231,7 @@ def main():
         d = summ[('fwd', 1)]
         ach = algorithmic_bytes_fwd(d['edges'], d['z_rows']) / (d['ms'] * 1e-3) / 1e9
         roof = {'kernel': 'k_agg_fwd (layer-1 attention aggregate, forward)',
-                'timing': 'HIP events around each launch on its stream, eager pass over the timed batches',
+                'timing': 'hipEvent pair recorded by the C ABI immediately around the k_agg_fwd launch on its stream (KgwLayerArgs.ev_before/ev_after), eager pass over the timed batches',
                 'bound': 'hbm', 'achieved': ach,
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                 'bytes_per_launch': algorithmic_bytes_fwd(d['edges'], d['z_rows']) / d['n'],

@@ -157,6 +157,10 @@ typedef struct KgwLayerArgs {
     float* part_da;                /* [n_chunks]                                               */
     const int32_t* t_ptr; const int32_t* t_edge; const int32_t* t_zrow;
     float* dH;                     /* [n_src_rows][128]                                        */
+    /* optional profiling hooks (NULL = off): hipEvent_t handles owned by the caller, recorded on `stream`
+     * immediately before and after the MAIN kernel of the call (k_agg_fwd / k_agg_bwd_dst / k_agg_bwd_src), i.e.
+     * excluding the small combine launches for hub rows -- bench.py's per-kernel roofline timing */
+    void* ev_before; void* ev_after;
     float* da_src;                 /* [n_src_rows][2*ld], ld = (n_rels+3)&~3: columns [0,ld) d a_src, [ld,2ld) d a_dst
                                       of the node, one column per relation id (n_rels <= 32)            */
 } KgwLayerArgs;

@@ -93,7 +93,7 @@ class KgwLayerArgs(C.Structure):
         ('Z', C.c_void_p), ('stat', C.c_void_p), ('e_edge', C.c_void_p), ('part', C.c_void_p),
         ('dZ', C.c_void_p), ('adp', C.c_void_p), ('da_dst', C.c_void_p), ('part_da', C.c_void_p),
         ('t_ptr', C.c_void_p), ('t_edge', C.c_void_p), ('t_zrow', C.c_void_p),
-        ('dH', C.c_void_p), ('da_src', C.c_void_p),
+        ('dH', C.c_void_p), ('ev_before', C.c_void_p), ('ev_after', C.c_void_p), ('da_src', C.c_void_p),
     ]
 
 

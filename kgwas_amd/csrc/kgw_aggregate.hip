@@ -538,9 +538,11 @@ extern "C" int kgw_gat_aggregate_fwd(const KgwLayerArgs* a, kgw_stream_t stream_
     if (rc) return rc;
     AggPtrs P = build_ptrs(a);
     hipStream_t st = (hipStream_t)stream_;
+    if (a->ev_before) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_before, st));
     if (P.raw) k_agg_fwd<true><<<grid_for_waves(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
     else       k_agg_fwd<false><<<grid_for_waves(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
     KGW_LAUNCH_CHECK();
+    if (a->ev_after) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_after, st));
     if (a->multi && a->multi_cap > 0) {     // hub rows: the number of multi-chunk segments is read on the device
         for (int h = 0; h < a->n_multi_hops; ++h) {
             k_agg_fwd_combine<<<grid_for_waves(a->multi_cap < 1024 ? a->multi_cap : 1024), KGW_BLK, 0, st>>>(T, P, h);
@@ -561,8 +563,10 @@ extern "C" int kgw_gat_aggregate_bwd_dst(const KgwLayerArgs* a, kgw_stream_t str
     if (rc) return rc;
     AggPtrs P = build_ptrs(a);
     hipStream_t st = (hipStream_t)stream_;
+    if (a->ev_before) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_before, st));
     k_agg_bwd_dst<<<grid_for_waves(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
     KGW_LAUNCH_CHECK();
+    if (a->ev_after) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_after, st));
     if (a->multi && a->multi_cap > 0) {
         for (int h = 0; h < a->n_multi_hops; ++h) {
             k_agg_bwd_combine<<<grid_for_waves(a->multi_cap < 1024 ? a->multi_cap : 1024), KGW_BLK, 0, st>>>(T, P, h);
@@ -581,8 +585,10 @@ extern "C" int kgw_gat_aggregate_bwd_src(const KgwLayerArgs* a, kgw_stream_t str
     int rc = build_tab(a, &T);
     if (rc) return rc;
     AggPtrs P = build_ptrs(a);
+    if (a->ev_before) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_before, (hipStream_t)stream_));
     k_agg_bwd_src<<<grid_for_waves(a->n_src_rows), KGW_BLK, 0, (hipStream_t)stream_>>>(T, P, a->n_src_rows);
     KGW_LAUNCH_CHECK();
+    if (a->ev_after) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_after, (hipStream_t)stream_));
     return KGW_OK;
 }
 

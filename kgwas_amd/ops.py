@@ -20,33 +20,44 @@ def _p(t):
 
 
 class KernelTimer:
-    """Optional HIP-event bracketing of the aggregate launches on the stream they are enqueued on
-    (bench.py's live roofline measurement).  Disabled by default: no events, no overhead."""
+    """Optional HIP-event timing of the main aggregate kernels (bench.py's live roofline measurement): raw
+    hipEvent_t pairs handed to the C ABI (KgwLayerArgs.ev_before / ev_after), which records them on the launch
+    stream immediately around k_agg_fwd / k_agg_bwd_dst / k_agg_bwd_src.  Disabled by default: no events."""
 
     def __init__(self):
         self.enabled = False
         self.records = []      # (tag, layer, start_event, end_event, n_edges, z_rows, n_src)
+        self._hip = None
+        self._pool = []
 
-    def bracket(self, tag, layer, n_edges, z_rows, n_src):
+    def _event(self):
+        if self._hip is None:
+            self._hip = C.CDLL('libamdhip64.so')
+            self._hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+            self._hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        ev = C.c_void_p()
+        rc = self._hip.hipEventCreate(C.byref(ev))
+        if rc:
+            raise _lib.KgwasHipError(f'hipEventCreate failed ({rc})')
+        return ev
+
+    def attach(self, a: KgwLayerArgs, tag, layer, n_edges, z_rows, n_src):
         if not self.enabled:
-            return None
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev1 = torch.cuda.Event(enable_timing=True)
-        ev0.record(torch.cuda.current_stream())
-        self.records.append((tag, layer, ev0, ev1, n_edges, z_rows, n_src))
-        return ev1
-
-    @staticmethod
-    def close(ev1):
-        if ev1 is not None:
-            ev1.record(torch.cuda.current_stream())
+            return
+        e0, e1 = self._event(), self._event()
+        a.ev_before, a.ev_after = e0, e1
+        self.records.append((tag, layer, e0, e1, n_edges, z_rows, n_src))
 
     def summary(self):
         """{(tag, layer): dict(n, ms_total, edges, z_rows, n_src)} -- call after a device sync."""
         out = {}
         for tag, layer, e0, e1, ne, zr, ns in self.records:
+            ms = C.c_float()
+            rc = self._hip.hipEventElapsedTime(C.byref(ms), e0, e1)
+            if rc:
+                raise _lib.KgwasHipError(f'hipEventElapsedTime failed ({rc})')
             d = out.setdefault((tag, layer), dict(n=0, ms=0.0, edges=0, z_rows=0, n_src=0))
-            d['n'] += 1; d['ms'] += e0.elapsed_time(e1); d['edges'] += ne; d['z_rows'] += zr; d['n_src'] += ns
+            d['n'] += 1; d['ms'] += ms.value; d['edges'] += ne; d['z_rows'] += zr; d['n_src'] += ns
         return out
 
 
@@ -97,9 +108,8 @@ class _GatAggregate(torch.autograd.Function):
         a.flags = 1 if raw_weights else 0          # KGW_F_RAW_WEIGHTS
         ctx.raw_weights = raw_weights
         a.Z, a.stat, a.e_edge, a.part = _p(Z), _p(stat), _p(e_edge), _p(part)
-        ev = TIMER.bracket('fwd', layer, n_edges, z_rows, n_src)
+        TIMER.attach(a, 'fwd', layer, n_edges, z_rows, n_src)
         _lib.check(_lib.lib().kgw_gat_aggregate_fwd(C.byref(a), _lib.stream_ptr()), 'kgw_gat_aggregate_fwd')
-        TIMER.close(ev)
         ctx.save_for_backward(H, U, V, Z, stat, e_edge)
         ctx.batch, ctx.layer, ctx.neg_slope, ctx.inv_temp = batch, layer, neg_slope, inv_temp
         ctx.mark_non_differentiable(stat, e_edge)
@@ -132,12 +142,10 @@ class _GatAggregate(torch.autograd.Function):
         a.dZ, a.adp, a.da_dst, a.part_da = _p(dZf), _p(adp), _p(da_dst), _p(part_da)
         a.dH, a.da_src = _p(dH), _p(da_src)
         L = _lib.lib()
-        ev = TIMER.bracket('bwd_dst', layer, n_edges, z_rows, n_src)
+        TIMER.attach(a, 'bwd_dst', layer, n_edges, z_rows, n_src)
         _lib.check(L.kgw_gat_aggregate_bwd_dst(C.byref(a), _lib.stream_ptr()), 'kgw_gat_aggregate_bwd_dst')
-        TIMER.close(ev)
-        ev = TIMER.bracket('bwd_src', layer, n_edges, z_rows, n_src)
+        TIMER.attach(a, 'bwd_src', layer, n_edges, z_rows, n_src)
         _lib.check(L.kgw_gat_aggregate_bwd_src(C.byref(a), _lib.stream_ptr()), 'kgw_gat_aggregate_bwd_src')
-        TIMER.close(ev)
         # d u_r = sum_j d a_src[j, r] H[j], d v_r = sum_i d a_dst[i, r] H[i]: all relations, both sides, as ONE
         # tall-skinny product over H
         if n_src:
