@@ -37,16 +37,30 @@ def _grads(model):
     return [p.grad for p in model.parameters() if p.grad is not None]
 
 
-def allreduce_grads(model, world: int):
-    """Average the parameter gradients over ranks: one flat bucket, one all-reduce."""
-    grads = _grads(model)
-    if not grads:
+def allreduce_flat(flat: torch.Tensor, world: int):
+    """Average ``flat`` over the ranks in place: ONE collective (RCCL's AVG where the backend has it)."""
+    if world <= 1:
         return
-    flat = torch._utils._flatten_dense_tensors(grads)
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat.div_(world)
-    for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
-        g.copy_(f)
+    if dist.get_backend() == 'nccl':
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+    else:                                            # gloo (CPU tests) has no AVG
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world)
+
+
+def allreduce_grads(model, world: int):
+    """Average the parameter gradients over ranks: one flat bucket, one all-reduce.  The averaged gradients are
+    handed back as VIEWS of the bucket (``p.grad`` re-pointed: no copy-back launch per parameter)."""
+    params = [p for p in model.parameters() if p.grad is not None]
+    if not params:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    allreduce_flat(flat, world)
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.grad = flat[off:off + n].view_as(p)
+        off += n
 
 
 def broadcast_params(model, src: int = 0):

@@ -63,6 +63,8 @@ class GraphTrainStep:
                                  dtype=torch.long, device=dev)
         self.stats = torch.zeros(L + 2, dtype=torch.int64, device=dev)
         self.loss = [None, None]
+        self._flat = None                         # multi-rank: gradient bucket + {param: view}
+        self._flat_grads = None
         self.graphs = [None, None]
         import os
         if overlap_sampling is None:
@@ -88,6 +90,16 @@ class GraphTrainStep:
         loss.backward()
         if self.capture_optimizer:
             self.opt.step()
+        elif self.world > 1:
+            # gradients of all live tensors into ONE persistent bucket (the all-reduce and Adam run on it after the replay)
+            live = [p for p in self.model.parameters() if p.grad is not None]
+            if self._flat is None:
+                self._flat = torch.empty(sum(p.numel() for p in live), device=self.seeds.device)
+                self._flat_grads, off = {}, 0
+                for p in live:
+                    self._flat_grads[p] = self._flat[off:off + p.numel()].view_as(p)
+                    off += p.numel()
+            torch.cat([p.grad.reshape(-1) for p in live], out=self._flat)
         vals = self._meta_i32[cur][self._idx].long()
         self.stats[:-1] += vals[:-1]
         self.stats[-1] |= vals[-1]
@@ -151,8 +163,10 @@ class GraphTrainStep:
         if not self.capture_optimizer:
             if self.world > 1:
                 from . import dist as kdist
-                kdist.allreduce_grads(self.model, self.world)
-            self.opt.step()
+                kdist.allreduce_flat(self._flat, self.world)          # one RCCL collective over the bucket
+                self.opt.step(self._flat_grads)
+            else:
+                self.opt.step()
         return self.loss[cur]
 
     def grads_ready(self):

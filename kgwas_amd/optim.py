@@ -39,8 +39,13 @@ class FusedAdam:
                 self._state(p)
 
     @torch.no_grad()
-    def step(self):
-        live = [p for p in self.params if p.grad is not None]     # grad None => skipped, exactly like torch
+    def step(self, grads=None):
+        """``grads``: optional {parameter: gradient tensor} to use instead of ``p.grad`` (the all-reduced bucket's
+        views in the multi-GPU step); parameters missing from it are skipped."""
+        if grads is not None:
+            live = [p for p in self.params if p in grads]
+        else:
+            live = [p for p in self.params if p.grad is not None]     # grad None => skipped, exactly like torch
         if not live:
             return
         for i in range(0, len(live), 64):
@@ -49,7 +54,7 @@ class FusedAdam:
             P = (C.c_void_p * n)(); G = (C.c_void_p * n)(); M = (C.c_void_p * n)(); V = (C.c_void_p * n)()
             N = (C.c_int64 * n)()
             for k, p in enumerate(chunk):
-                g = p.grad
+                g = grads[p] if grads is not None else p.grad
                 if not (p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32 and g.dtype == torch.float32):
                     raise _lib.KgwasHipError('FusedAdam needs contiguous fp32 parameters and gradients')
                 st = self._state(p)
