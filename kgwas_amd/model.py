@@ -64,9 +64,9 @@ class SimpleMLP(nn.Module):
         self.FC_output = nn.Linear(hidden_dim, output_dim)
         self.ReLU = nn.ReLU()
 
-    def first(self, x):
+    def first(self, x, fixed_shape=False):
         """relu(FC_hidden(x)) -- one autograd node; weight gradient on the split-K MFMA kernel."""
-        return ops.linear_relu(x, self.FC_hidden.weight, self.FC_hidden.bias)
+        return ops.linear_relu(x, self.FC_hidden.weight, self.FC_hidden.bias, fixed_shape)
 
     def tail(self, h1, out=None):
         """FC_output(relu(FC_hidden2(h1))) -- one autograd node."""
@@ -230,7 +230,7 @@ class HeteroGNN(nn.Module):
         if lazy and not dg.full_graph:
             X = dg.x[t]
             if X.shape[1] >= 512 and 2 * n > X.shape[0]:
-                return mlp.tail(mlp.first(X).index_select(0, batch.n_id(t)), out)
+                return mlp.tail(mlp.first(X, fixed_shape=True).index_select(0, batch.n_id(t)), out)
         return mlp(x_dict[t], out)
 
     def _layer_input(self, batch: SampledBatch, l: int):

@@ -8,6 +8,7 @@ with hand-written backward (dst-major + src-major HIP passes, no atomics)."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -17,6 +18,40 @@ from ._lib import KGW_C, PART_STRIDE, KgwLayerArgs
 
 def _p(t):
     return t.data_ptr() if t is not None else 0
+
+
+class _TunedLibraryGemm:
+    """Scope for the few LIBRARY GEMMs whose shape is the same every step (the 5120-wide first gene layer on the
+    resident feature matrix and its weight gradient): PyTorch's TunableOp picks the fastest hipBLASLt / rocBLAS
+    solution for that shape the first time it is seen (a few seconds, during warm-up) instead of the default
+    heuristic's -- 1.2-1.4x on these two products.  Off outside the scope, so batch-dependent shapes never tune."""
+
+    def __init__(self):
+        self.on = os.environ.get('KGW_TUNABLE_GEMM', '1') == '1'
+        self._ready = False
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        import torch.cuda.tunable as tn
+        if not self._ready:
+            # results are kept per device under the temp dir: the next process starts from the same choice
+            tn.set_filename(os.path.join(os.environ.get('KGW_CACHE_DIR', '/tmp'), 'kgwas_amd_tunableop.csv'), True)
+            tn.set_max_tuning_duration(200)          # ms per candidate solution
+            tn.set_max_tuning_iterations(20)
+            self._ready = True
+        tn.enable(True)
+        tn.tuning_enable(True)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            import torch.cuda.tunable as tn
+            tn.enable(False)
+        return False
+
+
+_TUNED = _TunedLibraryGemm()
 
 
 class KernelTimer:
@@ -231,7 +266,7 @@ _LIN_MAX_K = 2304        # wider reductions (the 5120 / 57742-wide gene layer) g
 
 
 def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask=None, w_kn: bool = False,
-           out: torch.Tensor = None):
+           out: torch.Tensor = None, fixed_shape: bool = False):
     """Y = act(X @ Wop + bias) * (mask > 0) on the fp32-MFMA kernel (kgw_linear); Wop = W^T for W [N,K]
     (nn.Linear forward) or W for W [K,N] (w_kn: the dX product).  Shapes the kernel does not take
     (K or leading dimensions not multiples of 4, very wide K) run on the library GEMM with identical math."""
@@ -247,6 +282,10 @@ def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask
         if out is not None and bias is None and not relu and mask is None:
             return torch.mm(X, W if w_kn else W.t(), out=out)
         Wop = W if w_kn else W.t()
+        if fixed_shape and mask is None and out is None:          # same shape every step: tuned library solution
+            with _TUNED:
+                Y = torch.addmm(bias, X, Wop) if bias is not None else X @ Wop
+            return torch.relu_(Y) if relu else Y
         if mask is None and out is not None:
             Y = torch.addmm(bias, X, Wop, out=out) if bias is not None else torch.mm(X, Wop, out=out)
             return torch.relu_(Y) if relu else Y
@@ -362,18 +401,19 @@ class _LinearReLU(torch.autograd.Function):
     """h = relu(x W^T + b) with the weight gradient on the split-K kernel; x gets a gradient only if asked."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
-        h = linear(x, W, b, relu=True)
+    def forward(ctx, x, W, b, fixed_shape=False):
+        h = linear(x, W, b, relu=True, fixed_shape=fixed_shape)
         ctx.save_for_backward(x, h, W)
+        ctx.fixed_shape = fixed_shape
         return h
 
     @staticmethod
     def backward(ctx, dh):
         x, h, W = ctx.saved_tensors
         dz = torch.ops.aten.threshold_backward(dh.contiguous(), h, 0.0)      # dh * (h > 0), one launch
-        dW, db = linear_weight_grad(dz, x)
+        dW, db = linear_weight_grad(dz, x, ctx.fixed_shape)
         dx = linear(dz, W, w_kn=True) if ctx.needs_input_grad[0] else None
-        return dx, dW, db
+        return dx, dW, db, None
 
 
 class _LinearAct(torch.autograd.Function):
@@ -401,11 +441,14 @@ def linear_act(x, Wt, b, relu=True):
     return _LinearAct.apply(x, Wt, b, relu)
 
 
-def linear_weight_grad(dY: torch.Tensor, X: torch.Tensor):
+def linear_weight_grad(dY: torch.Tensor, X: torch.Tensor, fixed_shape: bool = False):
     """(dW [out,in], db [out]) of Y = X W^T + b given dY [rows,out], X [rows,in]."""
     rows, K = X.shape
     if rows >= _TN_MIN_ROWS and K <= 1024:
         return tn_gemm(dY, X, colsum=True)
+    if fixed_shape:
+        with _TUNED:
+            return dY.t().mm(X), dY.sum(0)
     return dY.t().mm(X), dY.sum(0)
 
 
@@ -413,8 +456,10 @@ def mlp_tail(h1, W2, b2, W3, b3, out=None):
     return _MLPTail.apply(h1, W2, b2, W3, b3, out)
 
 
-def linear_relu(x, W, b):
-    return _LinearReLU.apply(x, W, b)
+def linear_relu(x, W, b, fixed_shape=False):
+    """``fixed_shape``: x is a resident matrix (same shape every step) -- lets a library-routed product use the
+    tuned solution."""
+    return _LinearReLU.apply(x, W, b, fixed_shape)
 
 
 # ------------------------------------------------------------------------------------------------------

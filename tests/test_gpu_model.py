@@ -310,3 +310,30 @@ def test_gradients_are_bit_reproducible(small_kg):
     assert len(grads[0]) == len(grads[1]) > 0
     for a, b in zip(*grads):
         assert torch.equal(a, b)
+
+
+def test_wide_gene_features_take_the_resident_first_layer(tmp_path):
+    """Gene features >= 512 wide and most genes in the batch: the first Linear runs on the RESIDENT matrix (no x[n_id]
+    copy of 20 KB rows) through the library GEMM with the tuned fixed-shape solution; same values / gradients as the
+    oracle on the sliced features."""
+    from kgwas_amd.kgwas_data import KGWAS_Data
+    kg = KGWAS_Data.from_synthetic(scale=0.002, seed=4, feat_dims={'Gene': 640}, data_path=str(tmp_path))
+    data = kg.data
+    dims = (kg.snp_init_dim_size, kg.gene_init_dim_size, kg.go_init_dim_size)
+    assert dims[1] == 640
+    model = _model(data, dims, L=2)
+    ids = np.random.default_rng(0).choice(data['SNP'].x.shape[0], size=256, replace=False)
+    batch = next(iter(_loader(data, ids, 256)))
+    assert 2 * batch.n_nodes['Gene'] > data['Gene'].x.shape[0], 'test graph should put most genes in the batch'
+    out = model(batch.x_dict, batch.edge_index_dict, 256)
+    y = torch.rand(256, dtype=torch.float64); w = torch.rand(256, dtype=torch.float64) + 0.5
+    weighted_mse(out, y.cuda(), w.cuda()).backward()
+    oracle = oracle_from_product(model)
+    x, ei = batch_cpu(batch)
+    out_o = oracle(x, ei, 256)
+    weighted_mse(out_o, y, w).backward()
+    assert_close(out, out_o.detach(), RTOL, ATOL, 'pred')
+    go = grads_by_name(oracle)
+    for name, g in grads_by_name(model).items():
+        if 'gene_feat_mlp' in name:
+            assert_close(g, go[name], RTOL, max(ATOL, 1e-4 * float(go[name].abs().max())), f'grad {name}')
