@@ -553,21 +553,30 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             const int c = (lane % LR) * 4, col = pass * CP + c;
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.bias && col < a.N) bv = *(const float4*)(a.bias + col);
+            // all mask rows of the pass are requested before the first store: a load between two stores would make
+            // every store wait for the previous one (vmcnt counts both)
+            float4 mk[32 / RP];
+            if (a.mask) {
+#pragma unroll
+                for (int it = 0; it < 32 / RP; ++it) {
+                    int64_t rr = rbase + it * RP + lane / LR;
+                    if (rr >= a.rows) rr = a.rows - 1;
+                    mk[it] = *(const float4*)(a.mask + rr * a.ldm + (col < a.N ? col : 0));
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < 32 / RP; ++it) mk[it] = make_float4(1.f, 1.f, 1.f, 1.f);
+            }
 #pragma unroll
             for (int it = 0; it < 32 / RP; ++it) {
                 const int row = it * RP + lane / LR;
                 float4 v = *(const float4*)(slice + row * XST + c);
                 const int64_t rr = rbase + row;
-                if (rr < a.rows && col < a.N) {
-                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (a.mask) {
-                        const float4 m = *(const float4*)(a.mask + rr * a.ldm + col);
-                        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
-                        v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
-                    }
-                    *(float4*)(a.Y + rr * a.ldy + col) = v;
-                }
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                v.x = mk[it].x > 0.f ? v.x : 0.f; v.y = mk[it].y > 0.f ? v.y : 0.f;
+                v.z = mk[it].z > 0.f ? v.z : 0.f; v.w = mk[it].w > 0.f ? v.w : 0.f;
+                if (rr < a.rows && col < a.N) *(float4*)(a.Y + rr * a.ldy + col) = v;
             }
         }
         } else {
