@@ -209,19 +209,22 @@ int kgw_tn_gemm(const float* A, int64_t lda, int32_t M, const float* B, int64_t 
  * launches afterwards): c_transposed != 0 stores C^T, i.e. element (m,n) at C[n*ldc + m] (the packed per-relation
  * weights are kept transposed, [in, out]); colsum_a is written colsum_repeat times, copy q at
  * colsum_a + q*colsum_ld (the bias gradient of every relation summed into one destination type is the same
- * vector: HeteroConv sum, kgwas/model.py:74).                                                              */
+ * vector: HeteroConv sum, kgwas/model.py:74).  rows_dev (nullable, device int32): actual row count <= rows (static
+ * capacity of a captured step); only those rows are read.                                                   */
 int kgw_tn_gemm_ex(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
                    int64_t rows, float* C, int64_t ldc, int32_t c_transposed, float* colsum_a,
                    int32_t colsum_repeat, int64_t colsum_ld, float* workspace, int64_t workspace_floats,
-                   kgw_stream_t stream);
+                   const int32_t* rows_dev, kgw_stream_t stream);
 
 /* Y[rows,N] = act(X[rows,K] * Wop + bias) * (mask > 0): the Linear layers of the path on fp32 MFMA.
  * w_is_kn = 0: W is [N,K] (nn.Linear / PyG Linear forward, kgwas/model.py:13-21,50; kgwas/conv.py:138,142);
  * w_is_kn = 1: W is [K,N] (the dX = dY * W product of their backward).  bias, mask may be NULL; relu 0/1.
- * K, ldx, ldw (and N when w_is_kn) must be multiples of 4, X and W 16-byte aligned, else KGW_E_UNSUPPORTED. */
+ * K, ldx, ldw (and N when w_is_kn) must be multiples of 4, X and W 16-byte aligned, else KGW_E_UNSUPPORTED.
+ * rows_dev (nullable, device int32): the number of rows the batch really has when `rows` is the static capacity of a
+ * captured step (KgwBatchMeta.n_src / n_rows entry): rows [*rows_dev, rows) are not computed, Y gets zeros there. */
 int kgw_linear(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias,
                const float* mask, int64_t ldm, float* Y, int64_t ldy, int64_t rows, int32_t K, int32_t N,
-               int32_t relu, int32_t w_is_kn, kgw_stream_t stream);
+               int32_t relu, int32_t w_is_kn, const int32_t* rows_dev, kgw_stream_t stream);
 
 /* One Adam step (torch.optim.Adam semantics, weight_decay as L2: kgwas/kgwas.py:116,151) over up to 64
  * parameter tensors in a single launch.  The pointer arrays are HOST arrays of device pointers (passed to the

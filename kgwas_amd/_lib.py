@@ -139,7 +139,8 @@ def lib():
     L.kgw_tn_gemm_workspace_floats.restype = C.c_int64
     L.kgw_tn_gemm_workspace_floats.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     L.kgw_linear.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
-                             C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+                             C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                             C.c_void_p]
     L.kgw_adam.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
     L.kgw_relvec_fwd.argtypes = [C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]
@@ -148,7 +149,7 @@ def lib():
                               C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     L.kgw_tn_gemm_ex.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
                                  C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
-                                 C.c_int64, C.c_void_p]
+                                 C.c_int64, C.c_void_p, C.c_void_p]
     L.kgw_wmse_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_void_p, C.c_void_p]
     L.kgw_wmse_bwd.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L

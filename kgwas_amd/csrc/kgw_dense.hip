@@ -71,7 +71,7 @@ template <int MT, int NT>
 __global__ void __launch_bounds__(256, 1) k_tn_gemm(const float* __restrict__ A, int64_t lda, int M,
                                                     const float* __restrict__ B, int64_t ldb, int N, int64_t rows,
                                                     int64_t rows_per_wave, float* __restrict__ ws,
-                                                    float* __restrict__ ws_colsum) {
+                                                    float* __restrict__ ws_colsum, const int32_t* __restrict__ rows_dev) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = lane >> 5, i = lane & 31;
@@ -79,7 +79,12 @@ __global__ void __launch_bounds__(256, 1) k_tn_gemm(const float* __restrict__ A,
     const int ca = m0 + MT * i, cb = n0 + NT * i;
     const int cas = ca < M ? ca : 0, cbs = cb < N ? cb : 0;
     const int64_t wg = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t r0 = wg * rows_per_wave;
+    if (rows_dev) {                     // actual row count of the batch (<= the static capacity `rows`): re-split evenly
+        const int64_t re = min(rows, (int64_t)max(*rows_dev, 0));
+        rows = re;
+        rows_per_wave = ((re + (int64_t)gridDim.x * 4 - 1) / ((int64_t)gridDim.x * 4) + 1) & ~(int64_t)1;
+    }
+    const int64_t r0 = min(rows, wg * rows_per_wave);
     const int64_t r1 = min(rows, r0 + rows_per_wave);
 
     f32x16 acc[MT][NT];
@@ -238,7 +243,7 @@ __global__ void __launch_bounds__(256) k_tn_reduce(const float* __restrict__ ws,
 template <int MT, int NT>
 int launch_tn(const float* A, int64_t lda, int M, const float* B, int64_t ldb, int N, int64_t rows, float* C,
               int64_t ldc, bool c_t, float* colsum, int cs_rep, int64_t cs_ld, float* ws, int64_t ws_floats,
-              hipStream_t st) {
+              const int32_t* rows_dev, hipStream_t st) {
     constexpr int FRAG = MT * NT * 16 * 64;
     const int gy = (M + 32 * MT - 1) / (32 * MT), gz = (N + 32 * NT - 1) / (32 * NT);
     // one block per CU at most; at least 64 rows per wavefront
@@ -259,7 +264,7 @@ int launch_tn(const float* A, int64_t lda, int M, const float* B, int64_t ldb, i
         KGW_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
     }
-    kern<<<dim3((unsigned)nblk, gy, gz), 256, lds_bytes, st>>>(A, lda, M, B, ldb, N, rows, rpw, ws, ws_cs);
+    kern<<<dim3((unsigned)nblk, gy, gz), 256, lds_bytes, st>>>(A, lda, M, B, ldb, N, rows, rpw, ws, ws_cs, rows_dev);
     KGW_LAUNCH_CHECK();
     k_tn_reduce<MT, NT><<<dim3(FRAG / 64, gy, gz), 256, 0, st>>>(ws, ws_cs, (int)nblk, gy, M, N, C, c_t ? 1 : ldc,
                                                                  c_t ? ldc : 1, colsum, cs_rep, cs_ld);
@@ -283,7 +288,7 @@ extern "C" int64_t kgw_tn_gemm_workspace_floats(int64_t rows, int M, int N) {
 extern "C" int kgw_tn_gemm_ex(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
                               int64_t rows, float* C, int64_t ldc, int32_t c_transposed, float* colsum_a,
                               int32_t colsum_repeat, int64_t colsum_ld, float* workspace, int64_t workspace_floats,
-                              kgw_stream_t stream_) {
+                              const int32_t* rows_dev, kgw_stream_t stream_) {
     if (!A || !B || !C || !workspace) return KGW_E_NULL;
     if (M <= 0 || N <= 0 || rows <= 0 || lda < M || ldb < N || ldc < (c_transposed ? M : N)) return KGW_E_RANGE;
     if (colsum_a && (colsum_repeat < 1 || (colsum_repeat > 1 && colsum_ld < M))) return KGW_E_RANGE;
@@ -294,16 +299,16 @@ extern "C" int kgw_tn_gemm_ex(const float* A, int64_t lda, int32_t M, const floa
     const bool b4 = (N % 4 == 0) && (ldb % 4 == 0) && aligned16(B) && N >= 128;
     // the 128x128 accumulator pays a fixed ~25 us block epilogue (64 KB per block through LDS): worth it only for
     // very tall inputs; shorter ones split N over blockIdx.z with 128x32 accumulators instead
-    if (a4 && b4 && rows >= 65536) return launch_tn<4, 4>(A, lda, M, B, ldb, N, rows, C, ldc, ct, colsum_a, rep, colsum_ld, workspace, workspace_floats, st);
-    if (a4)       return launch_tn<4, 1>(A, lda, M, B, ldb, N, rows, C, ldc, ct, colsum_a, rep, colsum_ld, workspace, workspace_floats, st);
-    if (b4)       return launch_tn<1, 4>(A, lda, M, B, ldb, N, rows, C, ldc, ct, colsum_a, rep, colsum_ld, workspace, workspace_floats, st);
-    return launch_tn<1, 1>(A, lda, M, B, ldb, N, rows, C, ldc, ct, colsum_a, rep, colsum_ld, workspace, workspace_floats, st);
+    if (a4 && b4 && rows >= 65536) return launch_tn<4, 4>(A, lda, M, B, ldb, N, rows, C, ldc, ct, colsum_a, rep, colsum_ld, workspace, workspace_floats, rows_dev, st);
+    if (a4)       return launch_tn<4, 1>(A, lda, M, B, ldb, N, rows, C, ldc, ct, colsum_a, rep, colsum_ld, workspace, workspace_floats, rows_dev, st);
+    if (b4)       return launch_tn<1, 4>(A, lda, M, B, ldb, N, rows, C, ldc, ct, colsum_a, rep, colsum_ld, workspace, workspace_floats, rows_dev, st);
+    return launch_tn<1, 1>(A, lda, M, B, ldb, N, rows, C, ldc, ct, colsum_a, rep, colsum_ld, workspace, workspace_floats, rows_dev, st);
 }
 
 extern "C" int kgw_tn_gemm(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
                            int64_t rows, float* C, int64_t ldc, float* colsum_a, float* workspace,
                            int64_t workspace_floats, kgw_stream_t stream_) {
-    return kgw_tn_gemm_ex(A, lda, M, B, ldb, N, rows, C, ldc, 0, colsum_a, 1, M, workspace, workspace_floats, stream_);
+    return kgw_tn_gemm_ex(A, lda, M, B, ldb, N, rows, C, ldc, 0, colsum_a, 1, M, workspace, workspace_floats, nullptr, stream_);
 }
 
 // ======================================================================================================
@@ -327,9 +332,37 @@ struct LinArgs {
     float* Y; int64_t ldy;
     int64_t rows; int K, N;
     int relu, w_kn;
+    const int32_t* rows_dev;   // device: actual row count (<= rows); rows beyond it are written as zeros
 };
 
-__global__ void __launch_bounds__(256, 2) k_linear(LinArgs a) {
+// rows the batch really has; the rest of the static capacity is padding: not computed, written as zeros
+__device__ __forceinline__ int64_t lin_rows_eff(const LinArgs& a) {
+    if (!a.rows_dev) return a.rows;
+    const int64_t r = *a.rows_dev;
+    return r < 0 ? 0 : (r < a.rows ? r : a.rows);
+}
+
+__device__ __forceinline__ void lin_zero_padding(const LinArgs& a, int64_t rows_eff, int64_t tid, int64_t nthreads) {
+    const int64_t npad = a.rows - rows_eff;
+    if (npad <= 0) return;
+    if ((a.N & 3) == 0 && (a.ldy & 3) == 0 && ((uintptr_t)a.Y & 15) == 0) {
+        const int n4 = a.N >> 2;
+        for (int64_t q = tid; q < npad * n4; q += nthreads)
+            *(float4*)(a.Y + (rows_eff + q / n4) * a.ldy + (q % n4) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        for (int64_t q = tid; q < npad * a.N; q += nthreads) a.Y[(rows_eff + q / a.N) * a.ldy + q % a.N] = 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) k_linear(LinArgs a_) {
+    LinArgs a = a_;
+    {
+        const int64_t re = lin_rows_eff(a_);
+        lin_zero_padding(a_, re, ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x,
+                         (int64_t)gridDim.x * gridDim.y * 256);
+        a.rows = re;
+        if ((int64_t)blockIdx.x * LBM >= re) return;
+    }
     __shared__ float Xs[LBM * LPAD];
     __shared__ float Ws[LBN * LPAD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -446,8 +479,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // RT = rows per tile: 256 (each wavefront 32 rows x all 128 columns) for tall inputs; 64 (2 row groups x 4 column
 // groups of 32) for mid-size inputs, so that 8k-32k rows still spread over every CU.
 template <int KC, bool WKN, int RT>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_linear_wres(LinArgs a) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_linear_wres(LinArgs a_) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    LinArgs a = a_;
+    {
+        const int64_t re = lin_rows_eff(a_);
+        lin_zero_padding(a_, re, (int64_t)blockIdx.x * 512 + threadIdx.x, (int64_t)gridDim.x * 512);
+        a.rows = re;
+        if ((int64_t)blockIdx.x * RT >= re) return;      // (before any barrier: the whole block leaves)
+    }
     constexpr int XST = KC + 4;
     float* Wl = lds;                       // [128 n][WST]
     float* Xs = lds + 128 * WST;           // [RT rows][XST]
@@ -631,14 +671,14 @@ int launch_wres(const LinArgs& a, hipStream_t st) {
 
 extern "C" int kgw_linear(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias,
                           const float* mask, int64_t ldm, float* Y, int64_t ldy, int64_t rows, int32_t K,
-                          int32_t N, int32_t relu, int32_t w_is_kn, kgw_stream_t stream_) {
+                          int32_t N, int32_t relu, int32_t w_is_kn, const int32_t* rows_dev, kgw_stream_t stream_) {
     if (rows == 0) return KGW_OK;
     if (!X || !W || !Y) return KGW_E_NULL;
     if (rows < 0 || K <= 0 || N <= 0) return KGW_E_RANGE;
     // float4 tiles: leading dimensions and K (N for the [K,N] form) must be multiples of 4, bases 16-B aligned
     if ((K & 3) || (ldx & 3) || (ldw & 3) || !aligned16(X) || !aligned16(W)) return KGW_E_UNSUPPORTED;
     if (w_is_kn && (N & 3)) return KGW_E_UNSUPPORTED;
-    LinArgs a{X, ldx, W, ldw, bias, mask, ldm, Y, ldy, rows, K, N, relu, w_is_kn};
+    LinArgs a{X, ldx, W, ldw, bias, mask, ldm, Y, ldy, rows, K, N, relu, w_is_kn, rows_dev};
     static const int64_t wres_min = getenv("KGW_WRES_MIN_ROWS") ? atoll(getenv("KGW_WRES_MIN_ROWS")) : 4096;
     static const int64_t wres_tall = getenv("KGW_WRES_TALL_ROWS") ? atoll(getenv("KGW_WRES_TALL_ROWS")) : 32768;
     if (K <= 128 && N <= 128 && rows >= wres_min && (N & 3) == 0 && (ldy & 3) == 0 && aligned16(Y) && aligned16(bias) &&

@@ -73,11 +73,11 @@ class SimpleMLP(nn.Module):
         return ops.mlp_tail(h1, self.FC_hidden2.weight, self.FC_hidden2.bias, self.FC_output.weight, self.FC_output.bias,
                             out)
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, rows_dev=None):
         if x.requires_grad:
             return self.tail(self.first(x), out)
         return ops.mlp3(x, self.FC_hidden.weight, self.FC_hidden.bias, self.FC_hidden2.weight, self.FC_hidden2.bias,
-                        self.FC_output.weight, self.FC_output.bias, out)
+                        self.FC_output.weight, self.FC_output.bias, out, rows_dev)
 
 
 class RelationPack(nn.Module):
@@ -231,7 +231,8 @@ class HeteroGNN(nn.Module):
             X = dg.x[t]
             if X.shape[1] >= 512 and 2 * n > X.shape[0]:
                 return mlp.tail(mlp.first(X, fixed_shape=True).index_select(0, batch.n_id(t)), out)
-        return mlp(x_dict[t], out)
+        # static layout: the row block is padded to its capacity; the kernels skip the padding (count on the device)
+        return mlp(x_dict[t], out, batch.rows_dev(t) if n == batch.lay_src(1, dg.schema.type_id[t]) else None)
 
     def _layer_input(self, batch: SampledBatch, l: int):
         """Preallocated type-major input matrix of layer l and one RowBlock per node type that has rows in it."""

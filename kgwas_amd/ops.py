@@ -224,7 +224,7 @@ _TN_MIN_ROWS = 1024       # below this a library GEMM is fine
 
 
 def tn_gemm(A: torch.Tensor, B: torch.Tensor, colsum: bool = False, out: torch.Tensor = None,
-            transpose_out: bool = False, colsum_out: torch.Tensor = None):
+            transpose_out: bool = False, colsum_out: torch.Tensor = None, rows_dev: torch.Tensor = None):
     """C = A^T @ B for tall row-major A [rows, M], B [rows, N] (fp32, inner stride 1); optionally also the
     column sums of A.  Deterministic split-K on fp32 MFMA.  ``out``: write C (or C^T with ``transpose_out``) into
     this row-major 2-D view instead of a new tensor; ``colsum_out`` [q, M]: write the column sums into each of its
@@ -257,19 +257,41 @@ def tn_gemm(A: torch.Tensor, B: torch.Tensor, colsum: bool = False, out: torch.T
     nws = int(L.kgw_tn_gemm_workspace_floats(rows, M, N))
     ws = torch.empty(nws, device=dev)
     _lib.check(L.kgw_tn_gemm_ex(_p(A), A.stride(0), M, _p(B), B.stride(0), N, rows, _p(out), out.stride(0),
-                                1 if transpose_out else 0, _p(cs), rep, cs_ld, _p(ws), nws, _lib.stream_ptr()),
+                                1 if transpose_out else 0, _p(cs), rep, cs_ld, _p(ws), nws, _p(rows_dev), _lib.stream_ptr()),
                'kgw_tn_gemm_ex')
     return (out, cs) if (colsum or colsum_out is not None) else out
+
+
+def _library_linear(X, W, bias, relu, mask, w_kn, out, fixed_shape):
+    Wop = W if w_kn else W.t()
+    if fixed_shape and mask is None and out is None:          # same shape every step: tuned library solution
+        with _TUNED:
+            Y = torch.addmm(bias, X, Wop) if bias is not None else X @ Wop
+        return torch.relu_(Y) if relu else Y
+    if mask is None and out is not None:
+        Y = torch.addmm(bias, X, Wop, out=out) if bias is not None else torch.mm(X, Wop, out=out)
+        return torch.relu_(Y) if relu else Y
+    Y = torch.addmm(bias, X, Wop) if bias is not None else X @ Wop
+    if relu:
+        Y = torch.relu_(Y)
+    if mask is not None:
+        Y = Y * (mask > 0)
+    if out is not None:
+        out.copy_(Y)
+        return out
+    return Y
 
 
 _LIN_MAX_K = 2304        # wider reductions (the 5120 / 57742-wide gene layer) go to the library GEMM
 
 
 def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask=None, w_kn: bool = False,
-           out: torch.Tensor = None, fixed_shape: bool = False):
+           out: torch.Tensor = None, fixed_shape: bool = False, rows_dev: torch.Tensor = None):
     """Y = act(X @ Wop + bias) * (mask > 0) on the fp32-MFMA kernel (kgw_linear); Wop = W^T for W [N,K]
     (nn.Linear forward) or W for W [K,N] (w_kn: the dX product).  Shapes the kernel does not take
-    (K or leading dimensions not multiples of 4, very wide K) run on the library GEMM with identical math."""
+    (K or leading dimensions not multiples of 4, very wide K) run on the library GEMM with identical math.
+    ``rows_dev``: device int32 holding the number of rows that are real when X is padded to a static capacity (a
+    captured step): the kernel skips the padding rows and writes zeros there."""
     rows, K = X.shape
     N = W.shape[1] if w_kn else W.shape[0]
     ok = (X.dtype == torch.float32 and X.stride(1) == 1 and W.stride(1) == 1 and K % 4 == 0 and K <= _LIN_MAX_K
@@ -279,31 +301,16 @@ def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask
           # wide enough to fill the chip with column tiles
           and (rows >= 8192 or (N >= 1024 and K <= 256) or (rows >= 4096 and K <= 128 and N <= 128)))
     if not ok:
-        if out is not None and bias is None and not relu and mask is None:
-            return torch.mm(X, W if w_kn else W.t(), out=out)
-        Wop = W if w_kn else W.t()
-        if fixed_shape and mask is None and out is None:          # same shape every step: tuned library solution
-            with _TUNED:
-                Y = torch.addmm(bias, X, Wop) if bias is not None else X @ Wop
-            return torch.relu_(Y) if relu else Y
-        if mask is None and out is not None:
-            Y = torch.addmm(bias, X, Wop, out=out) if bias is not None else torch.mm(X, Wop, out=out)
-            return torch.relu_(Y) if relu else Y
-        Y = torch.addmm(bias, X, Wop) if bias is not None else X @ Wop
-        if relu:
-            Y = torch.relu_(Y)
-        if mask is not None:
-            Y = Y * (mask > 0)
-        if out is not None:
-            out.copy_(Y)
-            return out
+        Y = _library_linear(X, W, bias, relu, mask, w_kn, out, fixed_shape)
+        if rows_dev is not None:          # padding rows of a static layout: zeros, whatever the inputs held there
+            Y.masked_fill_((torch.arange(rows, device=Y.device) >= rows_dev).unsqueeze(1), 0.0)
         return Y
     Y = torch.empty(rows, N, device=X.device) if out is None else out
     assert Y.shape == (rows, N) and Y.stride(1) == 1
     if rows:
         _lib.check(_lib.lib().kgw_linear(_p(X), X.stride(0), _p(W), W.stride(0), _p(bias), _p(mask),
                                          mask.stride(0) if mask is not None else 0, _p(Y), Y.stride(0), rows, K, N,
-                                         1 if relu else 0, 1 if w_kn else 0, _lib.stream_ptr()), 'kgw_linear')
+                                         1 if relu else 0, 1 if w_kn else 0, _p(rows_dev), _lib.stream_ptr()), 'kgw_linear')
     return Y
 
 
@@ -374,27 +381,29 @@ class _MLP3(torch.autograd.Function):
     split-K weight-gradient launches (no stand-alone ReLU-backward / bias-sum kernels)."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, W3, b3, out):
-        h1 = linear(x, W1, b1, relu=True)
-        h2 = linear(h1, W2, b2, relu=True)
-        y = linear(h2, W3, b3, out=out.view() if out is not None else None)
+    def forward(ctx, x, W1, b1, W2, b2, W3, b3, out, rows_dev):
+        h1 = linear(x, W1, b1, relu=True, rows_dev=rows_dev)
+        h2 = linear(h1, W2, b2, relu=True, rows_dev=rows_dev)
+        y = linear(h2, W3, b3, out=out.view() if out is not None else None, rows_dev=rows_dev)
         ctx.save_for_backward(x, h1, h2, W2, W3)
+        ctx.rows_dev = rows_dev
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, h1, h2, W2, W3 = ctx.saved_tensors
+        rd = ctx.rows_dev
         dy = dy.contiguous()
-        dW3, db3 = linear_weight_grad(dy, h2)
-        dh2 = linear(dy, W3, mask=h2, w_kn=True)                 # (dy @ W3) * (h2 > 0)
-        dW2, db2 = linear_weight_grad(dh2, h1)
-        dh1 = linear(dh2, W2, mask=h1, w_kn=True)                # (dh2 @ W2) * (h1 > 0)
-        dW1, db1 = linear_weight_grad(dh1, x)
-        return None, dW1, db1, dW2, db2, dW3, db3, None
+        dW3, db3 = linear_weight_grad(dy, h2, rows_dev=rd)
+        dh2 = linear(dy, W3, mask=h2, w_kn=True, rows_dev=rd)    # (dy @ W3) * (h2 > 0)
+        dW2, db2 = linear_weight_grad(dh2, h1, rows_dev=rd)
+        dh1 = linear(dh2, W2, mask=h1, w_kn=True, rows_dev=rd)   # (dh2 @ W2) * (h1 > 0)
+        dW1, db1 = linear_weight_grad(dh1, x, rows_dev=rd)
+        return None, dW1, db1, dW2, db2, dW3, db3, None, None
 
 
-def mlp3(x, W1, b1, W2, b2, W3, b3, out=None):
-    return _MLP3.apply(x, W1, b1, W2, b2, W3, b3, out)
+def mlp3(x, W1, b1, W2, b2, W3, b3, out=None, rows_dev=None):
+    return _MLP3.apply(x, W1, b1, W2, b2, W3, b3, out, rows_dev)
 
 
 class _LinearReLU(torch.autograd.Function):
@@ -441,11 +450,11 @@ def linear_act(x, Wt, b, relu=True):
     return _LinearAct.apply(x, Wt, b, relu)
 
 
-def linear_weight_grad(dY: torch.Tensor, X: torch.Tensor, fixed_shape: bool = False):
+def linear_weight_grad(dY: torch.Tensor, X: torch.Tensor, fixed_shape: bool = False, rows_dev: torch.Tensor = None):
     """(dW [out,in], db [out]) of Y = X W^T + b given dY [rows,out], X [rows,in]."""
     rows, K = X.shape
     if rows >= _TN_MIN_ROWS and K <= 1024:
-        return tn_gemm(dY, X, colsum=True)
+        return tn_gemm(dY, X, colsum=True, rows_dev=rows_dev)
     if fixed_shape:
         with _TUNED:
             return dY.t().mm(X), dY.sum(0)

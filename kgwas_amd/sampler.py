@@ -346,6 +346,15 @@ class SampledBatch:
     def lay_src(self, l: int, t: int) -> int:
         return int(self.meta.lay_src[l - 1][t])
 
+    def rows_dev(self, t: str):
+        """Static layout only: 1-element int32 device view of the number of rows of type t the batch really has in
+        the first layer's input (KgwBatchMeta.n_src[0][t], written by the sampler); None for exact-size batches."""
+        if not self.static:
+            return None
+        i = self.dg.schema.type_id[t]
+        off = KgwBatchMeta.n_src.offset // 4 + i
+        return self.buf.meta.view(torch.int32)[off:off + 1]
+
     @property
     def n_edges_per_layer(self):
         return [int(self.meta.n_edges[l]) for l in range(self.dg.num_layers)]

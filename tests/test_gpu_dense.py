@@ -159,3 +159,26 @@ def test_weighted_mse_matches_reference_expression():
     assert loss.dtype == torch.float64
     assert abs(float(loss) - float(lo)) <= 1e-12 + 1e-9 * abs(float(lo))
     assert_close(pred.grad, po.grad, 1e-6, 1e-9, 'd pred')
+
+
+@pytest.mark.parametrize('rows,real', [(137000, 120017), (20000, 13001), (6000, 0), (3000, 2999)])
+def test_rows_dev_skips_padding_rows(rows, real):
+    """Static-capacity inputs: kgw_linear / kgw_tn_gemm_ex read the real row count from the device, compute only
+    those rows, and kgw_linear writes zeros into the padding rows (garbage there must not leak anywhere)."""
+    from kgwas_amd import ops
+    g = torch.Generator().manual_seed(rows)
+    X = torch.randn(rows, 128, generator=g).cuda()
+    X[real:] = float('nan')                                   # padding rows hold garbage
+    W = (torch.randn(128, 128, generator=g) * 0.2).cuda(); b = torch.randn(128, generator=g).cuda()
+    Mk = torch.randn(rows, 128, generator=g).cuda()
+    cnt = torch.tensor([real], dtype=torch.int32).cuda()
+    for kn in (False, True):
+        Y = torch.full((rows, 128), 7.0).cuda()
+        ops.linear(X, W, b, relu=True, mask=Mk, w_kn=kn, out=Y, rows_dev=cnt)
+        ref = torch.relu(X[:real].double() @ (W.double() if kn else W.double().t()) + b.double()) * (Mk[:real].double() > 0)
+        assert_close(Y[:real], ref, 1e-5, 1e-6, 'linear rows_dev', rel_to_max=2e-6)
+        assert float(Y[real:].abs().sum()) == 0.0
+    B = torch.randn(rows, 20, generator=g).cuda()
+    Cm, cs = ops.tn_gemm(X, B, colsum=True, rows_dev=cnt)
+    assert_close(Cm, X[:real].double().t() @ B[:real].double(), 1e-5, 1e-5, 'tn rows_dev', rel_to_max=2e-6)
+    assert_close(cs, X[:real].double().sum(0), 1e-5, 1e-5, 'colsum rows_dev', rel_to_max=2e-6)
