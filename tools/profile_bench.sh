@@ -14,7 +14,10 @@ tot = sum(float(r['TotalDurationNs']) for r in rows)
 ncalls = sum(int(r['Calls']) for r in rows)
 nstep = max([int(r['Calls']) for r in rows if 'k_adam(' in r['Name']] + [0]) or 23
 print('kernel time total %.1f ms, %d launches; %d optimizer steps executed (incl. warm-ups; the caps pre-pass adds sampler-only work)' % (tot / 1e6, ncalls, nstep))
-for r in rows[:32]:
+# kernels of the step itself: launched at least once per optimizer step (leaves out the one-off library tuning runs)
+step_rows = [r for r in rows if int(r['Calls']) >= nstep]
+print('kernels launched every step: %.2f ms / step' % (sum(float(r['TotalDurationNs']) for r in step_rows) / 1e6 / nstep))
+for r in step_rows[:36]:
     print('%-60s calls/step %6.1f  us/step %8.1f  avg %8.1f us %5.1f%%' % (r['Name'].replace('(anonymous namespace)::', '')[:60], int(r['Calls']) / nstep, float(r['TotalDurationNs']) / 1e3 / nstep, float(r['AverageNs']) / 1e3, float(r['Percentage'])))
 try:
     d = json.loads(open(out + '/bench.json').read().strip().splitlines()[-1])
