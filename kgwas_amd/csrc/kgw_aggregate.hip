@@ -352,12 +352,11 @@ __device__ __forceinline__ void src_group(const float4* __restrict__ dZ4, int tz
     for (int p = 0; p < G; ++p) fma4(acc, w[p], x[p]);
 }
 
-__global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, int n_src_rows) {
+// one wavefront, one source row (rows with many entries; rows whose neighbour cannot be paired)
+__device__ __forceinline__ void bwd_src_one_row(const LayerTab& T, const AggPtrs& P, int u) {
     const int lane = kgw_lane(), half = lane >> 5, hl = lane & 31;
-    const int nw = gridDim.x * 4;
     const float4* dZ4 = (const float4*)P.dZ;
-    for (int u0 = blockIdx.x * 4 + (threadIdx.x >> 6); u0 < n_src_rows; u0 += nw) {
-        const int u = __builtin_amdgcn_readfirstlane(u0);
+    {
         int ty = 0;
         while (ty + 1 < T.n_types && u >= T.type_src_base[ty + 1]) ++ty;
         const int j = u - T.type_src_base[ty];
@@ -366,7 +365,7 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, 
         if (j >= P.meta->n_src[P.layer - 1][ty]) {          // padding row of a static layout: no gradient
             if (half == 0) ((float4*)(P.dH + (int64_t)u * KGW_C))[hl] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (lane < 2 * T.ld_da) P.da_src[(int64_t)u * 2 * T.ld_da + lane] = 0.f;
-            continue;
+            return;
         }
         // all Rs + 1 row pointers of this source in ONE load (lane k holds t_ptr[tb + k]); the per-slot logic below
         // works on shuffles of it instead of a chain of dependent scalar loads
@@ -447,6 +446,116 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, 
             if (is_dst && c >= 0 && c < T.n_rels && T.rel_dst_type[c] == ty) w = P.da_dst[zb + T.rel_slot_dst[c]];
             if (lane < 2 * ld) P.da_src[(int64_t)u * 2 * ld + lane] = (lane < ld) ? (mine ? v : 0.f) : w;
         }
+    }
+}
+
+
+// Two source rows per wavefront, one per 32-lane half.  Most source rows are SNPs with one to three entries: a
+// whole wavefront per row spends its (VALU-issue bound) instructions on two live lanes.  Here lane hl of a half
+// owns entry hl of ITS row during the gather / per-slot phase and float4 hl of the row's 128-float dH during the
+// accumulation; per-slot sums are 32-lane reductions (DPP + one permlane16 swap).  Taken when both rows are real, of
+// the same node type and have at most 32 entries each.
+__device__ __forceinline__ bool bwd_src_row_pair(const LayerTab& T, const AggPtrs& P, int u) {
+    const int lane = kgw_lane(), half = lane >> 5, hl = lane & 31, hb = half << 5;
+    int ty = 0;
+    while (ty + 1 < T.n_types && u >= T.type_src_base[ty + 1]) ++ty;
+    if (u + 1 >= T.type_src_base[ty + 1]) return false;                  // the neighbour is of another type
+    const int j0 = u - T.type_src_base[ty];
+    const int n_real = P.meta->n_src[P.layer - 1][ty];
+    if (j0 + 1 >= n_real) return false;                                   // padding involved: single-row path
+    const int Rs = T.type_R_src[ty];
+    if (Rs >= 32) return false;
+    const int j = j0 + half, uh = u + half;
+    const int tb = T.type_t_base[ty] + j * Rs;
+    const int tpv = (hl <= Rs) ? P.t_ptr[tb + hl] : 0;
+    const int p0 = __shfl(tpv, hb, 64), p1 = __shfl(tpv, hb + Rs, 64);
+    const int n = p1 - p0;
+    if (__ballot(n > 32)) return false;
+    const int tpn = __shfl_down(tpv, 1, 64);
+    const unsigned long long bal = __ballot(hl < Rs && tpn > tpv);
+    const unsigned slots_any = (unsigned)(bal | (bal >> 32));              // slots used by either row
+    int te = 0, tz = 0;
+    float al = 0.f, dp = 0.f;
+    if (hl < n) {
+        te = P.t_edge[p0 + hl];
+        tz = P.t_zrow[p0 + hl];
+        const float2 a2 = ((const float2*)P.adp)[te];
+        al = a2.x; dp = a2.y;
+    }
+    // per-slot sums of d pre-activation, each half over its own row
+    float dasv = 0.f;                                                      // lane hl == k of a half: d a_src of slot k
+    for (unsigned left = slots_any; left; left &= left - 1) {
+        const int k = __builtin_ctz(left);
+        const int s0 = __shfl(tpv, hb + k, 64), s1 = __shfl(tpv, hb + k + 1, 64);
+        const int pos = p0 + hl;
+        const float v = (hl < n && pos >= s0 && pos < s1) ? dp : 0.f;
+        const float sk = kgw_half_allsum(v);
+        dasv += (hl == k) ? sk : 0.f;
+    }
+    // dH row = sum over the row's entries of alpha * dZ[z row], four entries in flight
+    const float4* dZ4 = (const float4*)P.dZ;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nmax = max(__shfl(n, 0, 64), __shfl(n, 32, 64));
+    for (int i0 = 0; i0 < nmax; i0 += 4) {
+        float4 x[4];
+        float w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q;
+            const bool valid = i < n;
+            const int z = __shfl(tz, hb + (valid ? i : 0), 64);
+            const float a = __shfl(al, hb + (valid ? i : 0), 64);
+            w[q] = valid ? a : 0.f;
+            x[q] = dZ4[(int64_t)z * 32 + hl];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fma4(acc, w[q], x[q]);
+    }
+    // d a_src flows back into h_src through a_s = <h_src, u_r>
+    for (unsigned left = slots_any; left; left &= left - 1) {
+        const int k = __builtin_ctz(left);
+        const float dk = __shfl(dasv, hb + k, 64);
+        const int r = T.rel_of_slot[ty][k];
+        const float4 u4 = ((const float4*)(P.U + (int64_t)r * KGW_C))[hl];
+        fma4(acc, dk, u4);
+    }
+    // destination side of the same node
+    const int Rd = T.type_R_dst[ty];
+    const bool is_dst = P.V && Rd > 0 && j < P.meta->n_rows[P.layer - 1][ty];
+    const int zb = T.type_z_base[ty] + j * Rd;
+    if (__ballot(is_dst)) {
+        const float dav = (is_dst && hl < Rd) ? P.da_dst[zb + hl] : 0.f;
+        for (int k = 0; k < Rd; ++k) {
+            const float dk = __shfl(dav, hb + k, 64);
+            if (__ballot(dk != 0.f)) {
+                const int r = T.rel_of_dslot[ty][k];
+                const float4 v4 = ((const float4*)(P.V + (int64_t)r * KGW_C))[hl];
+                fma4(acc, dk, v4);
+            }
+        }
+    }
+    ((float4*)(P.dH + (int64_t)uh * KGW_C))[hl] = acc;
+    // [d a_src | d a_dst] row, one column per relation id; each half writes its own row, two columns per lane
+    {
+        const int ld = T.ld_da;
+        const bool mine = hl < T.n_rels && T.rel_src_type[hl] == ty;
+        const float v = __shfl(dasv, hb + (mine ? T.rel_slot_src[hl] : 0), 64);
+        float w = 0.f;
+        if (is_dst && hl < T.n_rels && T.rel_dst_type[hl] == ty) w = P.da_dst[zb + T.rel_slot_dst[hl]];
+        float* row = P.da_src + (int64_t)uh * 2 * ld;
+        if (hl < ld) { row[hl] = mine ? v : 0.f; row[ld + hl] = w; }
+    }
+    return true;
+}
+
+__global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, int n_src_rows) {
+    const int nw = gridDim.x * 4;
+    // a wavefront takes source rows two at a time
+    for (int u0 = 2 * (blockIdx.x * 4 + (threadIdx.x >> 6)); u0 < n_src_rows; u0 += 2 * nw) {
+        const int u = __builtin_amdgcn_readfirstlane(u0);
+        if (u + 1 < n_src_rows && bwd_src_row_pair(T, P, u)) continue;
+        bwd_src_one_row(T, P, u);
+        if (u + 1 < n_src_rows) bwd_src_one_row(T, P, u + 1);
     }
 }
 
