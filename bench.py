@@ -169,7 +169,8 @@ def main():
 
         def do_step(i):
             gs.step(i)
-        mode = 'one HIP graph per step (sampling + fwd + bwd' + (' + Adam)' if gs.capture_optimizer else '), RCCL all-reduce + Adam eager')
+        mode = ('HIP graphs: step graph (fwd + bwd' + (' + Adam)' if gs.capture_optimizer else '), RCCL all-reduce + Adam eager') +
+                (' with the next batch sampled by a second graph on a side stream' if gs.twin else ', sampling inside it'))
     setup_s = time.time() - t0
 
     for i in range(args.warmup):
