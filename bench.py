@@ -214,6 +214,9 @@ def main():
         torch.distributed.all_reduce(tot, op=torch.distributed.ReduceOp.SUM)
         elapsed = float(tmax[0]); edges_kernel, edges_ref, seeds = (float(x) for x in tot)
 
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
     summ = ops.TIMER.summary()
@@ -244,7 +247,7 @@ def main():
             except Exception:
                 pass
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed at N = 1 only
         cpu = cpu_baseline(data, bs)
     ms = elapsed / args.steps * 1e3
     out = {
