@@ -822,6 +822,130 @@ extern "C" int kgw_wmse_bwd(const float* pred, const int32_t* n_id, const float*
 }
 
 // ======================================================================================================
+// kgw_readout_wmse: read-out Linear(128 -> 1) (+ ReLU) of the seed rows (kgwas/model.py:86) fused with the
+// LD-score weighted MSE (kgwas/kgwas.py:139-145).  One block: wavefront w takes seeds w, w+4, ...; partial sums are
+// combined in a fixed order.  _bwd also produces the gradients of the read-out weight / bias and dH (zero for the
+// rows beyond the seeds).
+// ======================================================================================================
+namespace {
+
+// Both kernels: one wavefront per seed, four per block; per-seed / per-block partial results go to a scratch buffer
+// and the LAST block to finish (ticket counter, self-resetting) folds them in index order -- parallel across the
+// chip, yet a fixed summation order.
+__global__ void __launch_bounds__(256) k_readout_wmse_fwd(const float* __restrict__ H, const float* __restrict__ wl,
+                                                          const float* __restrict__ bl, const int32_t* __restrict__ n_id,
+                                                          const float* __restrict__ y, const double* __restrict__ w, int n,
+                                                          int relu, float* __restrict__ pred, double* __restrict__ loss,
+                                                          double* __restrict__ terms, int32_t* __restrict__ ticket) {
+    __shared__ double sm[256];
+    __shared__ int last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    if (i < n) {
+        const float2 w2 = ((const float2*)wl)[lane];
+        const float2 h2 = ((const float2*)(H + (int64_t)i * KGW_C))[lane];
+        float p = kgw_wave_allsum(fmaf(h2.x, w2.x, h2.y * w2.y)) + bl[0];
+        if (relu) p = fmaxf(p, 0.f);
+        if (lane == 0) {
+            const int g = n_id[i];
+            const float d = p - y[g];
+            pred[i] = p;
+            terms[i] = w[g] * (double)(d * d);
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    double acc = 0.0;
+    for (int q = threadIdx.x; q < n; q += 256) acc += __builtin_nontemporal_load(terms + q);
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { loss[0] = sm[0] / (double)n; *ticket = 0; }
+}
+
+__global__ void __launch_bounds__(256) k_readout_wmse_bwd(const float* __restrict__ H, const float* __restrict__ wl,
+                                                          const float* __restrict__ pred, const int32_t* __restrict__ n_id,
+                                                          const float* __restrict__ y, const double* __restrict__ w, int n,
+                                                          int64_t rows, int relu, const double* __restrict__ gloss,
+                                                          float* __restrict__ dH, float* __restrict__ dwl,
+                                                          float* __restrict__ dbl, float* __restrict__ part,
+                                                          int32_t* __restrict__ ticket) {
+    __shared__ float sw[4][KGW_C + 1];
+    __shared__ int last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    float2 dw = make_float2(0.f, 0.f);
+    float dp = 0.f;
+    if (i < n) {
+        const float2 w2 = ((const float2*)wl)[lane];
+        const int g = n_id[i];
+        const float p = pred[i];
+        dp = (float)(gloss[0] / (double)n * w[g]) * (2.0f * (p - y[g]));
+        if (relu && !(p > 0.f)) dp = 0.f;
+        const float2 h2 = ((const float2*)(H + i * KGW_C))[lane];
+        ((float2*)(dH + i * KGW_C))[lane] = make_float2(dp * w2.x, dp * w2.y);
+        dw = make_float2(dp * h2.x, dp * h2.y);
+    } else if (i < rows) {
+        ((float2*)(dH + i * KGW_C))[lane] = make_float2(0.f, 0.f);
+    }
+    sw[wave][2 * lane] = dw.x; sw[wave][2 * lane + 1] = dw.y;
+    if (lane == 0) sw[wave][KGW_C] = dp;
+    __syncthreads();
+    if (threadIdx.x <= KGW_C) {                    // block partial: 128 weight columns + the bias term
+        const int c = threadIdx.x;
+        part[(int64_t)blockIdx.x * (KGW_C + 1) + c] = (sw[0][c] + sw[1][c]) + (sw[2][c] + sw[3][c]);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const int nb = (n + 3) / 4;                     // blocks that held seeds
+    if (threadIdx.x <= KGW_C) {
+        const int c = threadIdx.x;
+        float acc = 0.f;
+        for (int q = 0; q < nb; ++q) acc += __builtin_nontemporal_load(part + (int64_t)q * (KGW_C + 1) + c);
+        if (c < KGW_C) dwl[c] = acc; else dbl[0] = acc;
+    }
+    if (threadIdx.x == 0) *ticket = 0;
+}
+
+}  // namespace
+
+extern "C" int kgw_readout_wmse_fwd(const float* H, const float* w_lin, const float* b_lin, const int32_t* n_id,
+                                    const float* y, const double* w, int32_t n, int32_t relu, float* pred,
+                                    double* loss, double* scratch, int32_t* ticket, kgw_stream_t stream_) {
+    if (!H || !w_lin || !b_lin || !n_id || !y || !w || !pred || !loss || !scratch || !ticket) return KGW_E_NULL;
+    if (n <= 0) return KGW_E_RANGE;
+    k_readout_wmse_fwd<<<(n + 3) / 4, 256, 0, (hipStream_t)stream_>>>(H, w_lin, b_lin, n_id, y, w, n, relu, pred, loss,
+                                                                       scratch, ticket);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+extern "C" int kgw_readout_wmse_bwd(const float* H, const float* w_lin, const float* pred, const int32_t* n_id,
+                                    const float* y, const double* w, int32_t n, int64_t rows, int32_t relu,
+                                    const double* grad_loss, float* dH, float* dw_lin, float* db_lin, float* scratch,
+                                    int32_t* ticket, kgw_stream_t stream_) {
+    if (!H || !w_lin || !pred || !n_id || !y || !w || !grad_loss || !dH || !dw_lin || !db_lin || !scratch || !ticket)
+        return KGW_E_NULL;
+    if (n <= 0 || rows < n) return KGW_E_RANGE;
+    k_readout_wmse_bwd<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream_>>>(H, w_lin, pred, n_id, y, w, n, rows, relu,
+                                                                                     grad_loss, dH, dw_lin, db_lin, scratch,
+                                                                                     ticket);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+// ======================================================================================================
 // kgw_relvec: the attention vectors of every relation of a layer in one launch.
 //   u_r = W_src^T att_src , v_r = W_dst^T att_dst (W_src^T att_dst for same-type relations)   conv.py:138-151
 // Weights are stored transposed/packed: wT[i][k][c] = W_i[c][k].  Forward: U_full[r] (zeros for relations the

@@ -93,8 +93,8 @@ class GraphTrainStep:
         buf = self.bufs[cur]
         batch = SampledBatch(self.dg, buf, self.meta, self.input_type, bs, static=True)
         self.opt.zero_grad(set_to_none=True)
-        out = self.model(batch.x_dict, batch.edge_index_dict, bs)
-        loss = ops.weighted_mse(out.reshape(-1), batch.n_id(self.input_type), self.dg.y[self.input_type], self.ld_w)   # kgwas.py:139-145
+        loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id(self.input_type),
+                                          self.dg.y[self.input_type], self.ld_w)          # kgwas.py:137-145
         loss.backward()
         if self.capture_optimizer:
             self.opt.step()

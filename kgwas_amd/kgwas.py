@@ -102,10 +102,8 @@ class KGWAS:
         """kgwas.py:130-151 for one batch; returns the (float64) loss tensor, no host sync."""
         optimizer.zero_grad(set_to_none=True)
         bs = batch['SNP'].batch_size
-        out = self.model(batch.x_dict, batch.edge_index_dict, bs)
-        pred = out.reshape(-1)
-        # mean(ld_weight * (pred - y)**2) in float64 (kgwas.py:139-145), labels / weights looked up by the seeds' ids
-        loss = ops.weighted_mse(pred, batch.n_id('SNP'), batch.dg.y['SNP'], ld_w)
+        # forward + mean(ld_weight * (pred - y)**2) in float64 (kgwas.py:137-145); labels / weights by the seeds' ids
+        loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id('SNP'), batch.dg.y['SNP'], ld_w)
         loss.backward()
         if world > 1:
             kdist.allreduce_grads(self.model, world)

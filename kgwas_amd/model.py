@@ -320,6 +320,21 @@ class HeteroGNN(nn.Module):
             return out
         return self.ReLU(out)                                   # model.py:86
 
+    def forward_loss(self, x_dict, edge_index_dict, batch_size, n_id, y_all, w_all):
+        """The training step's forward (kgwas/kgwas.py:137-145): HeteroGNN.forward followed by
+        mean(w_all[n_id] * (pred - y_all[n_id])**2), with the read-out Linear + ReLU (model.py:86) and the loss fused
+        into one node.  Returns (loss [float64 scalar], pred [batch_size])."""
+        batch: Optional[SampledBatch] = getattr(x_dict, 'kgw_batch', None) or getattr(edge_index_dict, 'kgw_batch', None)
+        if batch is None:
+            batch = self._block_from_coo(x_dict, edge_index_dict)
+        if self.lin.out_features != 1:
+            raise NotImplementedError('the fused read-out + loss is for out_channels == 1 (kgwas/kgwas.py:52)')
+        hbuf, blocks = self._layer_input(batch, 1)
+        h = self._embed_all(batch, x_dict, blocks)
+        h, _ = self._fused_layers(batch, h, hbuf=hbuf)
+        return ops.readout_weighted_mse(h['SNP'], self.lin.weight, self.lin.bias, n_id, y_all, w_all, batch_size,
+                                        relu=not self.no_relu)
+
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def raw_attention_full_graph(self, graph: HeteroGraph, device=None):

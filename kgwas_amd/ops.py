@@ -608,3 +608,55 @@ def weighted_mse(pred, n_id, y_all, w_all):
     """mean(w_all[n_id] * (pred - y_all[n_id])**2) (float64) for the first ``pred.numel()`` entries of ``n_id``
     (int32 global ids of the seeds); y_all float32 [N], w_all float64 [N]."""
     return _WeightedMSE.apply(pred, n_id, y_all, w_all)
+
+
+_TICKETS = {}
+
+
+def _ticket(dev):
+    """Persistent zero-initialised int32 per device: the arrival counter of the read-out kernels (they reset it)."""
+    k = str(dev)
+    if k not in _TICKETS:
+        _TICKETS[k] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return _TICKETS[k]
+
+
+class _ReadoutWeightedMSE(torch.autograd.Function):
+    """loss = mean(w[n_id] * ([relu](H[:n] @ w_lin^T + b_lin) - y[n_id])**2): the read-out Linear(128 -> 1) of the seed
+    rows (kgwas/model.py:86) and the weighted MSE (kgwas/kgwas.py:139-145) as one node, two launches per step."""
+
+    @staticmethod
+    def forward(ctx, H, w_lin, b_lin, n_id, y_all, w_all, n, relu):
+        H = H.contiguous()
+        assert H.dtype == torch.float32 and H.shape[1] == KGW_C and H.shape[0] >= n and w_lin.numel() == KGW_C
+        assert n_id.dtype == torch.int32 and y_all.dtype == torch.float32 and w_all.dtype == torch.float64
+        dev = H.device
+        pred = torch.empty(n, device=dev)
+        loss = torch.empty((), dtype=torch.float64, device=dev)
+        terms = torch.empty(n, dtype=torch.float64, device=dev)
+        _lib.check(_lib.lib().kgw_readout_wmse_fwd(_p(H), _p(w_lin), _p(b_lin), _p(n_id), _p(y_all), _p(w_all), n,
+                                                   1 if relu else 0, _p(pred), _p(loss), _p(terms), _p(_ticket(dev)),
+                                                   _lib.stream_ptr()), 'kgw_readout_wmse_fwd')
+        ctx.save_for_backward(H, w_lin, pred, n_id, y_all, w_all)
+        ctx.n, ctx.relu = n, relu
+        ctx.mark_non_differentiable(pred)
+        return loss, pred
+
+    @staticmethod
+    def backward(ctx, gloss, _gpred):
+        H, w_lin, pred, n_id, y_all, w_all = ctx.saved_tensors
+        gloss = gloss.contiguous().to(torch.float64)
+        dH = torch.empty_like(H)
+        dw = torch.empty_like(w_lin)
+        db = torch.empty(1, device=H.device)
+        part = torch.empty(((H.shape[0] + 3) // 4) * (KGW_C + 1), device=H.device)
+        _lib.check(_lib.lib().kgw_readout_wmse_bwd(_p(H), _p(w_lin), _p(pred), _p(n_id), _p(y_all), _p(w_all), ctx.n,
+                                                   H.shape[0], 1 if ctx.relu else 0, _p(gloss), _p(dH), _p(dw), _p(db),
+                                                   _p(part), _p(_ticket(H.device)), _lib.stream_ptr()),
+                   'kgw_readout_wmse_bwd')
+        return dH, dw, db, None, None, None, None, None
+
+
+def readout_weighted_mse(H, w_lin, b_lin, n_id, y_all, w_all, n: int, relu: bool = True):
+    """Returns (loss float64 scalar, pred float32 [n]); ``w_lin`` [1,128] / ``b_lin`` [1] = HeteroGNN.lin."""
+    return _ReadoutWeightedMSE.apply(H, w_lin, b_lin, n_id, y_all, w_all, int(n), bool(relu))

@@ -337,3 +337,31 @@ def test_wide_gene_features_take_the_resident_first_layer(tmp_path):
     for name, g in grads_by_name(model).items():
         if 'gene_feat_mlp' in name:
             assert_close(g, go[name], RTOL, max(ATOL, 1e-4 * float(go[name].abs().max())), f'grad {name}')
+
+
+@pytest.mark.parametrize('no_relu', [False, True])
+def test_fused_readout_loss_equals_forward_plus_loss(small_kg, no_relu):
+    """HeteroGNN.forward_loss (read-out Linear + ReLU + LD-weighted MSE as one node) == forward() followed by the
+    reference's loss expression (kgwas/kgwas.py:137-145), values and every gradient."""
+    data = small_kg.data
+    dims = (small_kg.snp_init_dim_size, small_kg.gene_init_dim_size, small_kg.go_init_dim_size)
+    model = _model(data, dims, L=2, no_relu=no_relu)
+    ids = np.random.default_rng(2).choice(data['SNP'].x.shape[0], size=96, replace=False)
+    batch = next(iter(_loader(data, ids, 96)))
+    g = torch.Generator().manual_seed(0)
+    w_all = (torch.rand(data['SNP'].x.shape[0], generator=g, dtype=torch.float64) + 0.5).cuda()
+    y_all = batch.dg.y['SNP']
+    loss, pred = model.forward_loss(batch.x_dict, batch.edge_index_dict, 96, batch.n_id('SNP'), y_all, w_all)
+    loss.backward()
+    g1 = {n: t.clone() for n, t in grads_by_name(model).items() if t is not None}
+    model.zero_grad(set_to_none=True)
+    out = model(batch.x_dict, batch.edge_index_dict, 96)
+    n_id = batch.n_id('SNP')[:96].long()
+    loss2 = torch.mean(w_all[n_id] * (out.reshape(-1) - y_all[n_id]) ** 2)
+    loss2.backward()
+    g2 = {n: t for n, t in grads_by_name(model).items() if t is not None}
+    assert_close(pred, out.reshape(-1).detach(), 1e-6, 1e-7, 'pred')
+    assert abs(float(loss) - float(loss2)) <= 1e-9 + 1e-6 * abs(float(loss2))
+    assert set(g1) == set(g2)
+    for n in g1:
+        assert_close(g1[n], g2[n], 1e-4, 1e-7, 'grad ' + n, rel_to_max=1e-5)
