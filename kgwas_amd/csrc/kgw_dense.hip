@@ -911,8 +911,15 @@ __global__ void __launch_bounds__(256) k_readout_wmse_bwd(const float* __restric
     const int nb = (n + 3) / 4;                     // blocks that held seeds
     if (threadIdx.x <= KGW_C) {
         const int c = threadIdx.x;
-        float acc = 0.f;
-        for (int q = 0; q < nb; ++q) acc += __builtin_nontemporal_load(part + (int64_t)q * (KGW_C + 1) + c);
+        // eight independent partial sums (loads in flight together), combined in a fixed order
+        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int q = 0;
+        for (; q + 8 <= nb; q += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a8[k] += __builtin_nontemporal_load(part + (int64_t)(q + k) * (KGW_C + 1) + c);
+        }
+        for (int k = 0; q < nb; ++q, ++k) a8[k] += __builtin_nontemporal_load(part + (int64_t)q * (KGW_C + 1) + c);
+        const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
         if (c < KGW_C) dwl[c] = acc; else dbl[0] = acc;
     }
     if (threadIdx.x == 0) *ticket = 0;

@@ -16,7 +16,9 @@ nstep = max([int(r['Calls']) for r in rows if 'k_adam(' in r['Name']] + [0]) or 
 print('kernel time total %.1f ms, %d launches; %d optimizer steps executed (incl. warm-ups; the caps pre-pass adds sampler-only work)' % (tot / 1e6, ncalls, nstep))
 # kernels of the step itself: launched at least once per optimizer step (leaves out the one-off library tuning runs)
 step_rows = [r for r in rows if int(r['Calls']) >= nstep]
-print('kernels launched every step: %.2f ms / step' % (sum(float(r['TotalDurationNs']) for r in step_rows) / 1e6 / nstep))
+SAMP = ('k_fill_i32', 'k_init', 'k_hop_', 'k_seg_deg', 'k_scan_', 'k_fill_chunks', 'k_mark', 'k_count_pending', 'k_assign', 'k_relabel', 'k_layer_tables', 'k_t_', 'k_meta_to_host')
+is_s = lambda r: any(t in r['Name'] for t in SAMP)
+print('kernels launched every step: %.2f ms / step; of which sampler (incl. the caps pre-pass share) %.2f, %d + %d launches / step' % (sum(float(r['TotalDurationNs']) for r in step_rows) / 1e6 / nstep, sum(float(r['TotalDurationNs']) for r in step_rows if is_s(r)) / 1e6 / nstep, sum(int(r['Calls']) for r in step_rows if not is_s(r)) / nstep, sum(int(r['Calls']) for r in step_rows if is_s(r)) / nstep))
 for r in step_rows[:36]:
     print('%-60s calls/step %6.1f  us/step %8.1f  avg %8.1f us %5.1f%%' % (r['Name'].replace('(anonymous namespace)::', '')[:60], int(r['Calls']) / nstep, float(r['TotalDurationNs']) / 1e3 / nstep, float(r['AverageNs']) / 1e3, float(r['Percentage'])))
 try:
