@@ -213,7 +213,8 @@ __device__ __forceinline__ float wave_allsum_slow(float v) {
 }
 
 // one wavefront per multi-chunk segment: merge partial (max, sum, acc)
-__global__ void __launch_bounds__(KGW_BLK) k_agg_fwd_combine(LayerTab T, AggPtrs P, int hop) {
+__global__ void __launch_bounds__(KGW_BLK) k_agg_fwd_combine(LayerTab T, AggPtrs P, int n_hops) {
+  for (int hop = 0; hop < n_hops; ++hop) {     // (one launch for the multi-chunk lists of every destination hop)
     const int lane = kgw_lane();
     const int nw = gridDim.x * 4;
     const int n_multi = P.meta->multi_cnt[hop];
@@ -239,6 +240,7 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_fwd_combine(LayerTab T, AggPtrs
         ((float2*)(P.Z + (int64_t)zrow * KGW_C))[lane] = make_float2(acc.x * inv, acc.y * inv);
         if (lane == 0) { P.stat[2 * (int64_t)zrow] = M; P.stat[2 * (int64_t)zrow + 1] = den; }
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -313,7 +315,8 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_dst(LayerTab T, AggPtrs P, 
     }
 }
 
-__global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_combine(LayerTab T, AggPtrs P, int hop) {
+__global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_combine(LayerTab T, AggPtrs P, int n_hops) {
+  for (int hop = 0; hop < n_hops; ++hop) {     // (one launch for the multi-chunk lists of every destination hop)
     const int lane = kgw_lane();
     const int nw = gridDim.x * 4;
     const int n_multi = P.meta->multi_cnt[hop];
@@ -328,6 +331,7 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_combine(LayerTab T, AggPtrs
         s = wave_allsum_slow(s);
         if (lane == 0) P.da_dst[zrow] = s;
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -653,10 +657,8 @@ extern "C" int kgw_gat_aggregate_fwd(const KgwLayerArgs* a, kgw_stream_t stream_
     KGW_LAUNCH_CHECK();
     if (a->ev_after) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_after, st));
     if (a->multi && a->multi_cap > 0) {     // hub rows: the number of multi-chunk segments is read on the device
-        for (int h = 0; h < a->n_multi_hops; ++h) {
-            k_agg_fwd_combine<<<grid_for_waves(a->multi_cap < 1024 ? a->multi_cap : 1024), KGW_BLK, 0, st>>>(T, P, h);
-            KGW_LAUNCH_CHECK();
-        }
+        k_agg_fwd_combine<<<grid_for_waves(a->multi_cap < 1024 ? a->multi_cap : 1024), KGW_BLK, 0, st>>>(T, P, a->n_multi_hops);
+        KGW_LAUNCH_CHECK();
     }
     return KGW_OK;
 }
@@ -677,10 +679,8 @@ extern "C" int kgw_gat_aggregate_bwd_dst(const KgwLayerArgs* a, kgw_stream_t str
     KGW_LAUNCH_CHECK();
     if (a->ev_after) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_after, st));
     if (a->multi && a->multi_cap > 0) {
-        for (int h = 0; h < a->n_multi_hops; ++h) {
-            k_agg_bwd_combine<<<grid_for_waves(a->multi_cap < 1024 ? a->multi_cap : 1024), KGW_BLK, 0, st>>>(T, P, h);
-            KGW_LAUNCH_CHECK();
-        }
+        k_agg_bwd_combine<<<grid_for_waves(a->multi_cap < 1024 ? a->multi_cap : 1024), KGW_BLK, 0, st>>>(T, P, a->n_multi_hops);
+        KGW_LAUNCH_CHECK();
     }
     return KGW_OK;
 }

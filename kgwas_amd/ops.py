@@ -145,6 +145,7 @@ class _GatAggregate(torch.autograd.Function):
         a.Z, a.stat, a.e_edge, a.part = _p(Z), _p(stat), _p(e_edge), _p(part)
         TIMER.attach(a, 'fwd', layer, n_edges, z_rows, n_src)
         _lib.check(_lib.lib().kgw_gat_aggregate_fwd(C.byref(a), _lib.stream_ptr()), 'kgw_gat_aggregate_fwd')
+        ctx.set_materialize_grads(False)          # no zero tensors for the (non-differentiable) stat / e_edge outputs
         ctx.save_for_backward(H, U, V, Z, stat, e_edge)
         ctx.batch, ctx.layer, ctx.neg_slope, ctx.inv_temp = batch, layer, neg_slope, inv_temp
         ctx.mark_non_differentiable(stat, e_edge)
@@ -154,6 +155,8 @@ class _GatAggregate(torch.autograd.Function):
     def backward(ctx, _dstat, _de, dZ):
         if ctx.raw_weights:
             raise RuntimeError('raw-logit aggregation (attention export) is inference only')
+        if dZ is None:
+            return (None,) * 8
         H, U, V, Z, stat, e_edge = ctx.saved_tensors
         batch, layer = ctx.batch, ctx.layer
         dg, m = batch.dg, batch.meta
@@ -640,10 +643,13 @@ class _ReadoutWeightedMSE(torch.autograd.Function):
         ctx.save_for_backward(H, w_lin, pred, n_id, y_all, w_all)
         ctx.n, ctx.relu = n, relu
         ctx.mark_non_differentiable(pred)
+        ctx.set_materialize_grads(False)
         return loss, pred
 
     @staticmethod
     def backward(ctx, gloss, _gpred):
+        if gloss is None:
+            return (None,) * 8
         H, w_lin, pred, n_id, y_all, w_all = ctx.saved_tensors
         gloss = gloss.contiguous().to(torch.float64)
         dH = torch.empty_like(H)
