@@ -33,6 +33,8 @@ extern "C" {
 
 #define KGW_F_RAW_WEIGHTS 1           /* KgwLayerArgs.flags: no softmax (the reference's attention export,
                                          kgwas/utils.py:446-461 with return_raw_attention_weights)      */
+#define KGW_F_RELU_INPUT  2           /* bwd_src: H is the output of a ReLU (model.py:75) whose backward is folded
+                                         into this pass: dH *= (H > 0)                                   */
 
 #define KGW_OK           0
 #define KGW_E_NULL      -1
@@ -258,7 +260,8 @@ int kgw_wmse_bwd(const float* pred, const int32_t* n_id, const float* y, const d
 
 /* The training step's tail as two launches: read-out pred[i] = [relu](<H[i], w_lin> + b_lin) of the n seed rows
  * (HeteroGNN.lin, kgwas/model.py:50,83-86; hidden 128 -> 1) fused with the weighted MSE above; _bwd writes dH [rows][128]
- * (zero beyond the seeds), d w_lin [128] and d b_lin [1].  One wavefront per seed; partial results go to `scratch`
+ * (zero beyond the seeds), d w_lin [128] and d b_lin [1].  `relu` bit 0: ReLU on pred; bit 1 (_bwd): H is itself a ReLU
+ * output whose backward is folded in (dH *= H > 0).  One wavefront per seed; partial results go to `scratch`
  * (_fwd: n doubles; _bwd: ceil(rows/4) * 129 floats) and the last block to finish folds them in index order
  * (deterministic); `ticket` is a device int32 that must be 0 before the first call and is reset by every call.     */
 int kgw_readout_wmse_fwd(const float* H, const float* w_lin, const float* b_lin, const int32_t* n_id,
@@ -268,6 +271,12 @@ int kgw_readout_wmse_bwd(const float* H, const float* w_lin, const float* pred, 
                          const float* y, const double* w, int32_t n, int64_t rows, int32_t relu,
                          const double* grad_loss, float* dH, float* dw_lin, float* db_lin, float* scratch,
                          int32_t* ticket, kgw_stream_t stream);
+
+/* out[c] = sum over rows of X[r][c], X [rows][128] (the bias gradient of a Linear whose weight gradient runs on the
+ * library GEMM); scratch: kgw_colsum128_scratch_floats(rows) floats; ticket as for kgw_readout_wmse_*.          */
+int64_t kgw_colsum128_scratch_floats(int64_t rows);
+int kgw_colsum128(const float* X, int64_t ldx, int64_t rows, float* out, float* scratch, int32_t* ticket,
+                  kgw_stream_t stream);
 
 /* Self-test of the cross-lane reductions used by the aggregate kernels (one wavefront):
  * out_half[l] = sum over l's 32-lane half, out_wave[l] = sum over the wavefront,

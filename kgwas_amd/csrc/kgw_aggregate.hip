@@ -78,6 +78,7 @@ struct AggPtrs {
     const KgwBatchMeta* meta;     // device: actual counts of the batch
     int layer;
     int raw;                      // forward: raw-logit weights (attention export)
+    int relu_in;                  // bwd_src: dH *= (H > 0)
 };
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
@@ -437,6 +438,11 @@ __device__ __forceinline__ void bwd_src_one_row(const LayerTab& T, const AggPtrs
                 }
             }
         }
+        if (P.relu_in) {
+            const float4 h4 = ((const float4*)(P.H + (int64_t)u * KGW_C))[hl];
+            acc.x = h4.x > 0.f ? acc.x : 0.f; acc.y = h4.y > 0.f ? acc.y : 0.f;
+            acc.z = h4.z > 0.f ? acc.z : 0.f; acc.w = h4.w > 0.f ? acc.w : 0.f;
+        }
         if (half == 0) ((float4*)(P.dH + (int64_t)u * KGW_C))[hl] = acc;
         // [d a_src | d a_dst] row of this node, one column per RELATION ID (zero for relations of other types): the
         // caller gets d u_r = sum_j d a_src[j, r] H[j] and d v_r = sum_i d a_dst[i, r] H[i] for all relations as
@@ -538,6 +544,11 @@ __device__ __forceinline__ bool bwd_src_row_pair(const LayerTab& T, const AggPtr
             }
         }
     }
+    if (P.relu_in) {
+        const float4 h4 = ((const float4*)(P.H + (int64_t)uh * KGW_C))[hl];
+        acc.x = h4.x > 0.f ? acc.x : 0.f; acc.y = h4.y > 0.f ? acc.y : 0.f;
+        acc.z = h4.z > 0.f ? acc.z : 0.f; acc.w = h4.w > 0.f ? acc.w : 0.f;
+    }
     ((float4*)(P.dH + (int64_t)uh * KGW_C))[hl] = acc;
     // [d a_src | d a_dst] row, one column per relation id; each half writes its own row, two columns per lane
     {
@@ -623,7 +634,7 @@ int build_tab(const KgwLayerArgs* a, LayerTab* T) {
 
 AggPtrs build_ptrs(const KgwLayerArgs* a) {
     AggPtrs P;
-    P.chunks = a->chunks; P.col_local = a->col_local; P.H = a->H; P.a_dst = a->a_dst; P.V = a->V; P.U = a->U; P.raw = (a->flags & KGW_F_RAW_WEIGHTS) ? 1 : 0;
+    P.chunks = a->chunks; P.col_local = a->col_local; P.H = a->H; P.a_dst = a->a_dst; P.V = a->V; P.U = a->U; P.raw = (a->flags & KGW_F_RAW_WEIGHTS) ? 1 : 0; P.relu_in = (a->flags & KGW_F_RELU_INPUT) ? 1 : 0;
     P.Z = a->Z; P.stat = a->stat; P.e_edge = a->e_edge; P.part = a->part; P.dZ = a->dZ; P.adp = a->adp;
     P.da_dst = a->da_dst; P.part_da = a->part_da; P.t_ptr = a->t_ptr; P.t_edge = a->t_edge;
     P.t_zrow = a->t_zrow; P.dH = a->dH; P.da_src = a->da_src; P.multi = a->multi; P.multi_cap = a->multi_cap;

@@ -265,7 +265,8 @@ class HeteroGNN(nn.Module):
                 h[t] = self._embed(batch, x_dict, t, blocks.get(t))
         return h
 
-    def _fused_layers(self, batch: SampledBatch, h: Dict[str, torch.Tensor], want_attention=False, hbuf=None):
+    def _fused_layers(self, batch: SampledBatch, h: Dict[str, torch.Tensor], want_attention=False, hbuf=None,
+                      last_premasked=False):
         sc = self.schema
         m = batch.meta
         C = self.hidden
@@ -289,14 +290,16 @@ class HeteroGNN(nn.Module):
             if hbuf is None:
                 hbuf, _ = self._layer_input(batch, l)
             H = ops.join_blocks(hbuf, spans, parts) if len(parts) != 1 or parts[0].shape[0] != hbuf.shape[0] else parts[0]
-            Z, stat, e_edge = ops.gat_aggregate(batch, l, H, U, V, self.negative_slope, self.temperature)
+            # (from layer 2 on, H is the previous layer's ReLU output: its backward is folded into this node's)
+            Z, stat, e_edge = ops.gat_aggregate(batch, l, H, U, V, self.negative_slope, self.temperature, relu_input=l > 1)
             if want_attention:
                 attn.append(ops.edge_alpha(batch, l, stat, e_edge, self.temperature))
             # per-relation linear maps + bias + relation sum + ReLU: one GEMM per destination type, one autograd node
             tys = [t for t in range(sc.NT) if int(m.lay_rows[l - 1][t])]
             blocks = [(rng[t][0], rng[t][1], int(m.z_base[l - 1][t]), int(m.lay_rows[l - 1][t])) for t in tys]
             hbuf, nxt = self._layer_input(batch, l + 1) if l < self.num_layers else (None, {})
-            outs = ops.layer_transform(P, Z, blocks, [nxt.get(sc.node_types[t]) for t in tys])
+            outs = ops.layer_transform(P, Z, blocks, [nxt.get(sc.node_types[t]) for t in tys],
+                                       premasked=(l < self.num_layers) or last_premasked)
             h_next = {sc.node_types[t]: o for t, o in zip(tys, outs)}
             h = h_next
         return h, attn
@@ -331,9 +334,9 @@ class HeteroGNN(nn.Module):
             raise NotImplementedError('the fused read-out + loss is for out_channels == 1 (kgwas/kgwas.py:52)')
         hbuf, blocks = self._layer_input(batch, 1)
         h = self._embed_all(batch, x_dict, blocks)
-        h, _ = self._fused_layers(batch, h, hbuf=hbuf)
+        h, _ = self._fused_layers(batch, h, hbuf=hbuf, last_premasked=True)
         return ops.readout_weighted_mse(h['SNP'], self.lin.weight, self.lin.bias, n_id, y_all, w_all, batch_size,
-                                        relu=not self.no_relu)
+                                        relu=not self.no_relu, h_is_relu=True)
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -122,7 +122,7 @@ def _layer_args(batch, layer: int, neg_slope: float, inv_temp: float) -> KgwLaye
 
 class _GatAggregate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, H, U, V, batch, layer, neg_slope, inv_temp, raw_weights=False):
+    def forward(ctx, H, U, V, batch, layer, neg_slope, inv_temp, raw_weights=False, relu_input=False):
         dg, m = batch.dg, batch.meta
         NT = dg.schema.NT
         z_rows = int(m.z_base[layer - 1][NT])
@@ -142,6 +142,7 @@ class _GatAggregate(torch.autograd.Function):
         a.H, a.V, a.U = _p(H), _p(V), _p(U)
         a.flags = 1 if raw_weights else 0          # KGW_F_RAW_WEIGHTS
         ctx.raw_weights = raw_weights
+        ctx.relu_input = relu_input
         a.Z, a.stat, a.e_edge, a.part = _p(Z), _p(stat), _p(e_edge), _p(part)
         TIMER.attach(a, 'fwd', layer, n_edges, z_rows, n_src)
         _lib.check(_lib.lib().kgw_gat_aggregate_fwd(C.byref(a), _lib.stream_ptr()), 'kgw_gat_aggregate_fwd')
@@ -156,7 +157,7 @@ class _GatAggregate(torch.autograd.Function):
         if ctx.raw_weights:
             raise RuntimeError('raw-logit aggregation (attention export) is inference only')
         if dZ is None:
-            return (None,) * 8
+            return (None,) * 9
         H, U, V, Z, stat, e_edge = ctx.saved_tensors
         batch, layer = ctx.batch, ctx.layer
         dg, m = batch.dg, batch.meta
@@ -179,6 +180,7 @@ class _GatAggregate(torch.autograd.Function):
         a.H, a.U, a.V, a.Z, a.stat, a.e_edge = _p(H), _p(U), _p(V), _p(Z), _p(stat), _p(e_edge)
         a.dZ, a.adp, a.da_dst, a.part_da = _p(dZf), _p(adp), _p(da_dst), _p(part_da)
         a.dH, a.da_src = _p(dH), _p(da_src)
+        a.flags = 2 if ctx.relu_input else 0       # KGW_F_RELU_INPUT: fold the ReLU that produced H into dH
         L = _lib.lib()
         TIMER.attach(a, 'bwd_dst', layer, n_edges, z_rows, n_src)
         _lib.check(L.kgw_gat_aggregate_bwd_dst(C.byref(a), _lib.stream_ptr()), 'kgw_gat_aggregate_bwd_dst')
@@ -191,19 +193,24 @@ class _GatAggregate(torch.autograd.Function):
             dU, dV = dUV[:sc.NR], dUV[ld_da:ld_da + sc.NR]
         else:
             dU, dV = torch.zeros_like(U), torch.zeros_like(V)
-        return dH[:n_src], dU, dV, None, None, None, None, None
+        return dH[:n_src], dU, dV, None, None, None, None, None, None
 
 
 def gat_aggregate(batch, layer: int, H: torch.Tensor, U: torch.Tensor, V: torch.Tensor,
-                  neg_slope: float = 0.2, temperature: float = 1.0, raw_weights: bool = False):
+                  neg_slope: float = 0.2, temperature: float = 1.0, raw_weights: bool = False,
+                  relu_input: bool = False):
     """Z[i, r] = sum_j softmax_j(leaky_relu(<H_src[j], u_r> + <H_dst[i], v_r>) / T) H_src[j] for every live relation
     of the layer.  H [n_src_rows,128]: layer input, type-major (``meta.src_base``; a destination node is row i of
     its own type's block); U, V [n_rels,128] by relation id.  Returns (Z [z_rows,128], stat [z_rows,2] =
     (row max, denominator), e_edge [n_edges]); Z is type-major: the block of destination type t starts at row
     ``meta.z_base[layer-1][t]`` and holds ``lay_rows * R_dst[t]`` rows ([row, relation slot, 128]).
     ``raw_weights``: Z[i, r] = sum_j e_ij H_src[j] with e the leaky_relu logits, no softmax (inference only; what
-    the reference's attention export propagates, kgwas/utils.py:446-461 + conv.py:221-228)."""
-    stat, e_edge, Z = _GatAggregate.apply(H, U, V, batch, layer, float(neg_slope), 1.0 / float(temperature), raw_weights)
+    the reference's attention export propagates, kgwas/utils.py:446-461 + conv.py:221-228).
+    ``relu_input``: every row of H is the output of a ReLU (the previous layer, model.py:75) and the node that
+    produced it expects its incoming gradient ALREADY multiplied by (H > 0): the source-side backward does it while
+    writing dH (see layer_transform's ``premasked``)."""
+    stat, e_edge, Z = _GatAggregate.apply(H, U, V, batch, layer, float(neg_slope), 1.0 / float(temperature), raw_weights,
+                                          relu_input)
     return Z, stat, e_edge
 
 
@@ -269,12 +276,21 @@ def _library_linear(X, W, bias, relu, mask, w_kn, out, fixed_shape):
     Wop = W if w_kn else W.t()
     if fixed_shape and mask is None and out is None:          # same shape every step: tuned library solution
         with _TUNED:
+            if bias is not None and relu:
+                return torch._addmm_activation(bias, X, Wop)          # bias + ReLU in the GEMM epilogue
             Y = torch.addmm(bias, X, Wop) if bias is not None else X @ Wop
         return torch.relu_(Y) if relu else Y
-    if mask is None and out is not None:
+    if bias is not None and relu and X.is_cuda:
+        Y = torch._addmm_activation(bias, X, Wop, out=out) if (out is not None and mask is None) else \
+            torch._addmm_activation(bias, X, Wop)
+        if mask is None:
+            return Y
+        relu = False
+    elif mask is None and out is not None:
         Y = torch.addmm(bias, X, Wop, out=out) if bias is not None else torch.mm(X, Wop, out=out)
         return torch.relu_(Y) if relu else Y
-    Y = torch.addmm(bias, X, Wop) if bias is not None else X @ Wop
+    else:
+        Y = torch.addmm(bias, X, Wop) if bias is not None else X @ Wop
     if relu:
         Y = torch.relu_(Y)
     if mask is not None:
@@ -460,8 +476,21 @@ def linear_weight_grad(dY: torch.Tensor, X: torch.Tensor, fixed_shape: bool = Fa
         return tn_gemm(dY, X, colsum=True, rows_dev=rows_dev)
     if fixed_shape:
         with _TUNED:
-            return dY.t().mm(X), dY.sum(0)
-    return dY.t().mm(X), dY.sum(0)
+            return dY.t().mm(X), colsum(dY)
+    return dY.t().mm(X), colsum(dY)
+
+
+def colsum(X: torch.Tensor):
+    """Column sums of a [rows,128] fp32 matrix on kgw_colsum128 (deterministic); other shapes: the framework's sum."""
+    if not (X.dim() == 2 and X.shape[1] == KGW_C and X.dtype == torch.float32 and X.stride(1) == 1 and X.shape[0] > 0
+            and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0 and X.is_cuda):
+        return X.sum(0)
+    L = _lib.lib()
+    out = torch.empty(KGW_C, device=X.device)
+    part = torch.empty(int(L.kgw_colsum128_scratch_floats(X.shape[0])), device=X.device)
+    _lib.check(L.kgw_colsum128(_p(X), X.stride(0), X.shape[0], _p(out), _p(part), _p(_ticket(X.device)), _lib.stream_ptr()),
+               'kgw_colsum128')
+    return out
 
 
 def mlp_tail(h1, W2, b2, W3, b3, out=None):
@@ -521,7 +550,7 @@ class _LayerTransform(torch.autograd.Function):
     arrays feed the destination type whose block starts at Z row z0 and has ``rows`` destination rows."""
 
     @staticmethod
-    def forward(ctx, w_src_t, bias, Z, blocks, sel, out_blocks):
+    def forward(ctx, w_src_t, bias, Z, blocks, sel, out_blocks, premasked=False):
         C = bias.shape[1]
         outs, ys = [], []
         bsum = torch.mm(sel, bias)                      # [n blocks, C]: bias of every relation into a type, summed
@@ -536,6 +565,7 @@ class _LayerTransform(torch.autograd.Function):
         ctx.save_for_backward(w_src_t, Z, *ys)
         ctx.blocks = blocks
         ctx.n_bias = bias.shape[0]
+        ctx.premasked = premasked
         return tuple(outs)
 
     @staticmethod
@@ -560,17 +590,20 @@ class _LayerTransform(torch.autograd.Function):
                 continue
             R = hi - lo
             x = Z[z0:z0 + rows * R].view(rows, R * C)
-            dz = torch.ops.aten.threshold_backward(dy.contiguous(), ys[k], 0.0)
+            # (premasked: the consumer of y already multiplied its gradient by (y > 0))
+            dz = dy.contiguous() if ctx.premasked else torch.ops.aten.threshold_backward(dy.contiguous(), ys[k], 0.0)
             # dWt = x^T dz lands transposed in place (the pack keeps [in, out]); db = colsum(dz) for each relation
             tn_gemm(dz, x, out=dW[lo:hi].view(R * C, C), transpose_out=True, colsum_out=db[lo:hi])
             if need_dz:
                 linear(dz, w_src_t[lo:hi].view(R * C, C), out=dZ[z0:z0 + rows * R].view(rows, R * C))
-        return dW, db, dZ, None, None, None
+        return dW, db, dZ, None, None, None, None
 
 
-def layer_transform(pack, Z, blocks, out_blocks=None):
+def layer_transform(pack, Z, blocks, out_blocks=None, premasked=False):
     """``blocks`` = [(lo, hi, z0, rows)] (see _LayerTransform); ``out_blocks``: optional RowBlock per block to write
-    the outputs into."""
+    the outputs into; ``premasked``: whoever consumes the outputs folds this node's ReLU backward into its own
+    backward kernel (gat_aggregate(relu_input=True) / readout_weighted_mse(h_is_relu=True)), so no stand-alone
+    threshold launch runs here."""
     key = tuple((lo, hi) for lo, hi, _, _ in blocks)
     sel = pack._sel_cache.get(key)
     if sel is None:
@@ -578,7 +611,7 @@ def layer_transform(pack, Z, blocks, out_blocks=None):
         for k, (lo, hi) in enumerate(key):
             sel[k, lo:hi] = 1.0
         pack._sel_cache[key] = sel
-    return _LayerTransform.apply(pack.w_src_t, pack.bias, Z, blocks, sel, out_blocks)
+    return _LayerTransform.apply(pack.w_src_t, pack.bias, Z, blocks, sel, out_blocks, premasked)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -629,7 +662,7 @@ class _ReadoutWeightedMSE(torch.autograd.Function):
     rows (kgwas/model.py:86) and the weighted MSE (kgwas/kgwas.py:139-145) as one node, two launches per step."""
 
     @staticmethod
-    def forward(ctx, H, w_lin, b_lin, n_id, y_all, w_all, n, relu):
+    def forward(ctx, H, w_lin, b_lin, n_id, y_all, w_all, n, relu, h_is_relu=False):
         H = H.contiguous()
         assert H.dtype == torch.float32 and H.shape[1] == KGW_C and H.shape[0] >= n and w_lin.numel() == KGW_C
         assert n_id.dtype == torch.int32 and y_all.dtype == torch.float32 and w_all.dtype == torch.float64
@@ -641,7 +674,7 @@ class _ReadoutWeightedMSE(torch.autograd.Function):
                                                    1 if relu else 0, _p(pred), _p(loss), _p(terms), _p(_ticket(dev)),
                                                    _lib.stream_ptr()), 'kgw_readout_wmse_fwd')
         ctx.save_for_backward(H, w_lin, pred, n_id, y_all, w_all)
-        ctx.n, ctx.relu = n, relu
+        ctx.n, ctx.relu, ctx.h_is_relu = n, relu, h_is_relu
         ctx.mark_non_differentiable(pred)
         ctx.set_materialize_grads(False)
         return loss, pred
@@ -649,7 +682,7 @@ class _ReadoutWeightedMSE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, _gpred):
         if gloss is None:
-            return (None,) * 8
+            return (None,) * 9
         H, w_lin, pred, n_id, y_all, w_all = ctx.saved_tensors
         gloss = gloss.contiguous().to(torch.float64)
         dH = torch.empty_like(H)
@@ -657,12 +690,13 @@ class _ReadoutWeightedMSE(torch.autograd.Function):
         db = torch.empty(1, device=H.device)
         part = torch.empty(((H.shape[0] + 3) // 4) * (KGW_C + 1), device=H.device)
         _lib.check(_lib.lib().kgw_readout_wmse_bwd(_p(H), _p(w_lin), _p(pred), _p(n_id), _p(y_all), _p(w_all), ctx.n,
-                                                   H.shape[0], 1 if ctx.relu else 0, _p(gloss), _p(dH), _p(dw), _p(db),
-                                                   _p(part), _p(_ticket(H.device)), _lib.stream_ptr()),
+                                                   H.shape[0], (1 if ctx.relu else 0) | (2 if ctx.h_is_relu else 0), _p(gloss),
+                                                   _p(dH), _p(dw), _p(db), _p(part), _p(_ticket(H.device)), _lib.stream_ptr()),
                    'kgw_readout_wmse_bwd')
-        return dH, dw, db, None, None, None, None, None
+        return dH, dw, db, None, None, None, None, None, None
 
 
-def readout_weighted_mse(H, w_lin, b_lin, n_id, y_all, w_all, n: int, relu: bool = True):
-    """Returns (loss float64 scalar, pred float32 [n]); ``w_lin`` [1,128] / ``b_lin`` [1] = HeteroGNN.lin."""
-    return _ReadoutWeightedMSE.apply(H, w_lin, b_lin, n_id, y_all, w_all, int(n), bool(relu))
+def readout_weighted_mse(H, w_lin, b_lin, n_id, y_all, w_all, n: int, relu: bool = True, h_is_relu: bool = False):
+    """Returns (loss float64 scalar, pred float32 [n]); ``w_lin`` [1,128] / ``b_lin`` [1] = HeteroGNN.lin.
+    ``h_is_relu``: see layer_transform's ``premasked``."""
+    return _ReadoutWeightedMSE.apply(H, w_lin, b_lin, n_id, y_all, w_all, int(n), bool(relu), bool(h_is_relu))
