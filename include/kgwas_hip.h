@@ -190,6 +190,11 @@ int kgw_gat_aggregate_fwd(const KgwLayerArgs* args, kgw_stream_t stream);
 int kgw_gat_aggregate_bwd_dst(const KgwLayerArgs* args, kgw_stream_t stream);
 int kgw_gat_aggregate_bwd_src(const KgwLayerArgs* args, kgw_stream_t stream);
 
+/* Running totals over the batches of a captured training loop: stats[l] += edges aggregated by layer l+1 (l < n_layers),
+ * stats[n_layers] += edges sampled, stats[n_layers+1] |= KgwBatchMeta.error.  stats: n_layers + 2 device int64.   */
+int kgw_accumulate_stats(const KgwBatchMeta* meta_dev, int32_t n_layers, int32_t n_hops, int64_t* stats,
+                         kgw_stream_t stream);
+
 /* Replaces: the index_select feature slicing of the loader (x[n_id], kgwas/kgwas.py:135).      */
 int kgw_gather_rows(const float* src, const int32_t* ids, int64_t n_rows, int32_t width,
                     float* dst, kgw_stream_t stream);

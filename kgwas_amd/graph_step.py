@@ -108,9 +108,8 @@ class GraphTrainStep:
                     self._flat_grads[p] = self._flat[off:off + p.numel()].view_as(p)
                     off += p.numel()
             torch.cat([p.grad.reshape(-1) for p in live], out=self._flat)
-        vals = self._meta_i32[cur][self._idx].long()
-        self.stats[:-1] += vals[:-1]
-        self.stats[-1] |= vals[-1]
+        _lib.check(_lib.lib().kgw_accumulate_stats(buf.meta.data_ptr(), self.run.gnn_num_layers, self.dg.n_hops,
+                                                   self.stats.data_ptr(), _lib.stream_ptr()), 'kgw_accumulate_stats')
         if self.overlap:
             main.wait_stream(self._side)                               # join
         elif not self.twin:

@@ -250,15 +250,27 @@ class HeteroGNN(nn.Module):
         blocks = blocks or {}
         go = [t for t in self.node_types if t in GO_TYPES and t in x_dict and batch.n_nodes.get(t, x_dict[t].shape[0]) > 0]
         if len(go) > 1:
-            xs = [x_dict[t] for t in go]
-            ns = [x.shape[0] for x in xs]
+            lazy = getattr(x_dict, 'kgw_batch', None) is batch and all(t in batch.dg.x for t in go) and \
+                len({batch.dg.x[t].shape[1] for t in go}) == 1
+            if lazy:            # gather the three types' rows straight into one matrix (no concatenation copy)
+                ns = [batch.n_nodes[t] for t in go]
+                xg = torch.empty(sum(ns), batch.dg.x[go[0]].shape[1], device=self.lin.weight.device)
+                off = 0
+                for t, n in zip(go, ns):
+                    gather_rows(batch.dg.x[t], batch.n_id(t), out=xg[off:off + n])
+                    off += n
+                xs = None
+            else:
+                xs = [x_dict[t] for t in go]
+                ns = [x.shape[0] for x in xs]
+                xg = torch.cat(xs, 0)
             out = None
             bl = [blocks.get(t) for t in go]
             if all(b is not None and b.n == n for b, n in zip(bl, ns)) and \
                     all(bl[k + 1].lo == bl[k].lo + bl[k].n for k in range(len(bl) - 1)):
                 out = ops.RowBlock(bl[0].buf, bl[0].lo, sum(ns))          # the GO blocks are adjacent: one output
-            y = self.go_feat_mlp(torch.cat(xs, 0), out)
-            for t, piece in zip(go, torch.split(y, ns, 0)):
+            y = self.go_feat_mlp(xg, out)
+            for t, piece in zip(go, ops.split_rows(y, ns)):
                 h[t] = piece
         for t in self.node_types:
             if t in x_dict and t not in h:

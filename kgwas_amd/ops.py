@@ -133,8 +133,12 @@ class _GatAggregate(torch.autograd.Function):
         assert H.dtype == torch.float32 and H.shape == (n_src, KGW_C), (H.shape, n_src)
         assert U.shape == (dg.schema.NR, KGW_C) and V.shape == U.shape
         dev = H.device
-        Z = torch.zeros(max(z_rows, 1), KGW_C, device=dev)
-        stat = torch.zeros(max(z_rows, 1), 2, device=dev)
+        # Z, stat and the backward's d a_dst all start from zero (rows without edges are never visited): one fill
+        zr = max(z_rows, 1)
+        zbuf = torch.zeros(zr * (KGW_C + 3), device=dev)
+        Z = zbuf[:zr * KGW_C].view(zr, KGW_C)
+        stat = zbuf[zr * KGW_C:zr * (KGW_C + 2)].view(zr, 2)
+        ctx.da_dst = zbuf[zr * (KGW_C + 2):]
         e_edge = torch.empty(max(n_edges, 1), device=dev)
         any_multi = batch.static or any(int(m.multi_cnt[h]) for h in range(dg.n_hops))
         part = torch.empty(max(n_chunks, 1) * PART_STRIDE if any_multi else 4, device=dev)
@@ -171,7 +175,9 @@ class _GatAggregate(torch.autograd.Function):
         dev = H.device
         dZf = dZ.contiguous() if z_rows else torch.zeros(1, KGW_C, device=dev)
         adp = torch.empty(max(n_edges, 1), 2, device=dev)
-        da_dst = torch.zeros(max(z_rows, 1), device=dev)
+        da_dst, ctx.da_dst = ctx.da_dst, None            # zeroed with Z in forward; consumed once
+        if da_dst is None:
+            da_dst = torch.zeros(max(z_rows, 1), device=dev)
         part_da = torch.empty(max(n_chunks, 1), device=dev)
         dH = torch.empty(max(n_src, 1), KGW_C, device=dev)
         ld_da = (sc.NR + 3) & ~3
@@ -388,6 +394,42 @@ class _JoinBlocks(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dH):
         return (None, None) + tuple(dH[lo:lo + n] for lo, n in ctx.spans)
+
+
+class _SplitRows(torch.autograd.Function):
+    """torch.split along rows whose backward does not concatenate when the incoming gradients already are adjacent
+    row blocks of one tensor (the slices _JoinBlocks hands back): it returns that tensor's rows as they lie."""
+
+    @staticmethod
+    def forward(ctx, y, sizes):
+        ctx.sizes = sizes
+        ctx.set_materialize_grads(False)
+        outs, off = [], 0
+        for n in sizes:
+            outs.append(RowBlock(y, off, n).view())
+            off += n
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        sizes = ctx.sizes
+        if all(g is not None for g in gs):
+            g0 = gs[0]
+            adj, ptr = g0.is_contiguous(), g0.data_ptr()
+            for g, n in zip(gs, sizes):
+                adj = adj and g.is_contiguous() and g.data_ptr() == ptr and g.untyped_storage().data_ptr() == g0.untyped_storage().data_ptr()
+                ptr += n * g.shape[1] * g.element_size()
+            if adj:
+                total = sum(sizes)
+                t = torch.empty(0, dtype=g0.dtype, device=g0.device)
+                return t.set_(g0.untyped_storage(), g0.storage_offset(), (total, g0.shape[1]), (g0.shape[1], 1)), None
+        first = next(g for g in gs if g is not None)
+        parts = [g if g is not None else torch.zeros(n, first.shape[1], device=first.device) for g, n in zip(gs, sizes)]
+        return torch.cat(parts, 0), None
+
+
+def split_rows(y: torch.Tensor, sizes):
+    return _SplitRows.apply(y, tuple(int(n) for n in sizes))
 
 
 def join_blocks(buf: torch.Tensor, spans, parts):

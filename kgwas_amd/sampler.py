@@ -443,10 +443,12 @@ class LazyEdgeIndexDict(BatchDict):
         self._build(); return dict.items(self)
 
 
-def gather_rows(src: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
-    """out[i] = src[ids[i]] via kgw_gather_rows (ids int32)."""
+def gather_rows(src: torch.Tensor, ids: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """out[i] = src[ids[i]] via kgw_gather_rows (ids int32); ``out``: contiguous [n, width] destination."""
     n, w = int(ids.numel()), int(src.shape[1])
-    out = torch.empty(n, w, dtype=torch.float32, device=src.device)
+    if out is None:
+        out = torch.empty(n, w, dtype=torch.float32, device=src.device)
+    assert out.shape == (n, w) and out.is_contiguous()
     if n:
         _lib.check(_lib.lib().kgw_gather_rows(_ptr(src), _ptr(ids), n, w, _ptr(out), _lib.stream_ptr()),
                    'kgw_gather_rows')
