@@ -1032,9 +1032,27 @@ __global__ void __launch_bounds__(128) k_relvec_fwd(int NR, const int32_t* __res
                                                     const int32_t* __restrict__ bip_pos, const float* __restrict__ wsT,
                                                     const float* __restrict__ wdT, const float* __restrict__ att_src,
                                                     const float* __restrict__ att_dst, float* __restrict__ U_full,
-                                                    float* __restrict__ V, int v_by_rel) {
+                                                    float* __restrict__ V, int v_by_rel, int n_live,
+                                                    const float* __restrict__ bias, const int32_t* __restrict__ blk_of_live,
+                                                    int n_blk, float* __restrict__ bsum) {
     __shared__ float as[KGW_C], ad[KGW_C];
     const int r = blockIdx.x, k = threadIdx.x;
+    if (r == NR) {          // extra block: bias of every relation into a destination type, summed in packed order
+        float acc[KGW_MAX_TYPES];
+#pragma unroll
+        for (int b = 0; b < KGW_MAX_TYPES; ++b) acc[b] = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < n_live; ++i) {                 // independent loads: all in flight together
+            const float v = bias[(int64_t)i * KGW_C + k];
+            const int bi = blk_of_live[i];
+#pragma unroll
+            for (int b = 0; b < KGW_MAX_TYPES; ++b) acc[b] += (bi == b) ? v : 0.f;
+        }
+#pragma unroll
+        for (int b = 0; b < KGW_MAX_TYPES; ++b)
+            if (b < n_blk) bsum[(int64_t)b * KGW_C + k] = acc[b];
+        return;
+    }
     const int i = live_of_rel[r];
     if (i < 0) {
         U_full[(int64_t)r * KGW_C + k] = 0.f;
@@ -1103,11 +1121,14 @@ __global__ void __launch_bounds__(128) k_relvec_bwd(const int32_t* __restrict__ 
 
 extern "C" int kgw_relvec_fwd(int32_t n_rels_total, const int32_t* live_of_rel, const int32_t* bip_pos, const float* w_src_t,
                               const float* w_dst_t, const float* att_src, const float* att_dst, float* U_full, float* V,
-                              int32_t v_by_rel, kgw_stream_t stream_) {
+                              int32_t v_by_rel, int32_t n_live, const float* bias, const int32_t* blk_of_live,
+                              int32_t n_blk, float* bias_sum, kgw_stream_t stream_) {
     if (n_rels_total <= 0) return KGW_OK;
     if (!live_of_rel || !bip_pos || !w_src_t || !att_src || !att_dst || !U_full || !V) return KGW_E_NULL;
-    k_relvec_fwd<<<n_rels_total, 128, 0, (hipStream_t)stream_>>>(n_rels_total, live_of_rel, bip_pos, w_src_t, w_dst_t,
-                                                                 att_src, att_dst, U_full, V, v_by_rel);
+    const bool with_bias = bias && blk_of_live && bias_sum && n_blk > 0 && n_blk <= KGW_MAX_TYPES;
+    k_relvec_fwd<<<n_rels_total + (with_bias ? 1 : 0), 128, 0, (hipStream_t)stream_>>>(
+        n_rels_total, live_of_rel, bip_pos, w_src_t, w_dst_t, att_src, att_dst, U_full, V, v_by_rel, n_live, bias,
+        blk_of_live, n_blk, bias_sum);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }

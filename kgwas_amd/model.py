@@ -287,8 +287,12 @@ class HeteroGNN(nn.Module):
         for l in range(1, self.num_layers + 1):
             P: RelationPack = self.live_packs[l - 1]
             rng = self._dst_range[l - 1]
-            # u_r = W_src^T att_src ; v_r = W_dst^T att_dst (W_src^T att_dst for same-type relations): one launch
-            U, V = ops.rel_vectors(P)
+            # destination blocks of the layer: one per node type that receives messages
+            tys = [t for t in range(sc.NT) if int(m.lay_rows[l - 1][t])]
+            blocks = [(rng[t][0], rng[t][1], int(m.z_base[l - 1][t]), int(m.lay_rows[l - 1][t])) for t in tys]
+            # u_r = W_src^T att_src ; v_r = W_dst^T att_dst (W_src^T att_dst for same-type relations) and the summed
+            # bias of every destination block: one launch
+            U, V, bsum = ops.rel_vectors(P, blocks)
             # layer input, type-major (src_base): every type that sends or receives messages in this layer
             parts, spans = [], []
             for t, name in enumerate(sc.node_types):
@@ -307,11 +311,9 @@ class HeteroGNN(nn.Module):
             if want_attention:
                 attn.append(ops.edge_alpha(batch, l, stat, e_edge, self.temperature))
             # per-relation linear maps + bias + relation sum + ReLU: one GEMM per destination type, one autograd node
-            tys = [t for t in range(sc.NT) if int(m.lay_rows[l - 1][t])]
-            blocks = [(rng[t][0], rng[t][1], int(m.z_base[l - 1][t]), int(m.lay_rows[l - 1][t])) for t in tys]
             hbuf, nxt = self._layer_input(batch, l + 1) if l < self.num_layers else (None, {})
             outs = ops.layer_transform(P, Z, blocks, [nxt.get(sc.node_types[t]) for t in tys],
-                                       premasked=(l < self.num_layers) or last_premasked)
+                                       premasked=(l < self.num_layers) or last_premasked, bias_sum=bsum)
             h_next = {sc.node_types[t]: o for t, o in zip(tys, outs)}
             h = h_next
         return h, attn

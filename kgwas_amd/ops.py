@@ -552,21 +552,33 @@ class _RelVectors(torch.autograd.Function):
     """(U [NR,C], V [NR,C]), rows by relation id, from the packed relation parameters of a layer -- kgw_relvec_fwd / _bwd."""
 
     @staticmethod
-    def forward(ctx, w_src_t, w_dst_t, att_src, att_dst, pack):
+    def forward(ctx, w_src_t, w_dst_t, att_src, att_dst, pack, blk_of_live, n_blk):
         n, C = att_src.shape
         dev = att_src.device
         U = torch.empty(pack.n_rels_total, C, device=dev)
         V = torch.empty(pack.n_rels_total, C, device=dev)        # by relation id, like U
+        bsum = torch.empty(max(n_blk, 1), C, device=dev) if blk_of_live is not None else None
         _lib.check(_lib.lib().kgw_relvec_fwd(pack.n_rels_total, _p(pack.live_of_rel_i32), _p(pack.bip_pos_i32), _p(w_src_t),
                                              _p(w_dst_t) if w_dst_t.numel() else 0, _p(att_src), _p(att_dst), _p(U), _p(V),
-                                             1, _lib.stream_ptr()), 'kgw_relvec_fwd')
+                                             1, n, _p(pack.bias.detach()) if bsum is not None else 0, _p(blk_of_live),
+                                             n_blk if bsum is not None else 0, _p(bsum), _lib.stream_ptr()), 'kgw_relvec_fwd')
         ctx.save_for_backward(w_src_t, w_dst_t, att_src, att_dst)
         ctx.pack = pack
-        return U, V
+        ctx.set_materialize_grads(False)
+        if bsum is None:
+            return U, V
+        ctx.mark_non_differentiable(bsum)
+        return U, V, bsum
 
     @staticmethod
-    def backward(ctx, dU, dV):
+    def backward(ctx, dU, dV, _dbsum=None):
         w_src_t, w_dst_t, att_src, att_dst = ctx.saved_tensors
+        if dU is None and dV is None:
+            return (None,) * 7
+        if dU is None:
+            dU = torch.zeros(ctx.pack.n_rels_total, att_src.shape[1], device=att_src.device)
+        if dV is None:
+            dV = torch.zeros(ctx.pack.n_rels_total, att_src.shape[1], device=att_src.device)
         pack = ctx.pack
         n = att_src.shape[0]
         dU = dU.contiguous(); dV = dV.contiguous()
@@ -578,11 +590,28 @@ class _RelVectors(torch.autograd.Function):
                                              _p(w_dst_t) if w_dst_t.numel() else 0, _p(att_src), _p(att_dst), _p(dU), _p(dV),
                                              _p(dws), _p(dwd) if dwd.numel() else 0, _p(das), _p(dad), 1, _lib.stream_ptr()),
                    'kgw_relvec_bwd')
-        return dws, dwd, das, dad, None
+        return dws, dwd, das, dad, None, None, None
 
 
-def rel_vectors(pack):
-    return _RelVectors.apply(pack.w_src_t, pack.w_dst_t, pack.att_src, pack.att_dst, pack)
+def _block_key(blocks):
+    return tuple((lo, hi) for lo, hi, *_ in blocks)
+
+
+def rel_vectors(pack, blocks=None):
+    """(U, V) by relation id; with ``blocks`` (the layer_transform block list, [(lo, hi, ...)]) also the summed bias
+    of every block, [n blocks, C] (no gradient flows through it: layer_transform produces d bias itself)."""
+    if blocks is None:
+        return _RelVectors.apply(pack.w_src_t, pack.w_dst_t, pack.att_src, pack.att_dst, pack, None, 0)
+    key = ('blk',) + _block_key(blocks)
+    tab = pack._sel_cache.get(key)
+    if tab is None:
+        blk = [-1] * pack.bias.shape[0]
+        for b, (lo, hi) in enumerate(key[1:]):
+            for i in range(lo, hi):
+                blk[i] = b
+        tab = torch.tensor(blk, dtype=torch.int32, device=pack.bias.device)
+        pack._sel_cache[key] = tab
+    return _RelVectors.apply(pack.w_src_t, pack.w_dst_t, pack.att_src, pack.att_dst, pack, tab, len(blocks))
 
 
 class _LayerTransform(torch.autograd.Function):
@@ -592,10 +621,10 @@ class _LayerTransform(torch.autograd.Function):
     arrays feed the destination type whose block starts at Z row z0 and has ``rows`` destination rows."""
 
     @staticmethod
-    def forward(ctx, w_src_t, bias, Z, blocks, sel, out_blocks, premasked=False):
+    def forward(ctx, w_src_t, bias, Z, blocks, bsum, out_blocks, premasked=False):
         C = bias.shape[1]
         outs, ys = [], []
-        bsum = torch.mm(sel, bias)                      # [n blocks, C]: bias of every relation into a type, summed
+        # bsum [n blocks, C]: bias of every relation into a type, summed (rel_vectors computes it in its launch)
         for k, (lo, hi, z0, rows) in enumerate(blocks):
             R = hi - lo
             x = Z[z0:z0 + rows * R].view(rows, R * C)
@@ -641,19 +670,21 @@ class _LayerTransform(torch.autograd.Function):
         return dW, db, dZ, None, None, None, None
 
 
-def layer_transform(pack, Z, blocks, out_blocks=None, premasked=False):
+def layer_transform(pack, Z, blocks, out_blocks=None, premasked=False, bias_sum=None):
     """``blocks`` = [(lo, hi, z0, rows)] (see _LayerTransform); ``out_blocks``: optional RowBlock per block to write
     the outputs into; ``premasked``: whoever consumes the outputs folds this node's ReLU backward into its own
     backward kernel (gat_aggregate(relu_input=True) / readout_weighted_mse(h_is_relu=True)), so no stand-alone
-    threshold launch runs here."""
-    key = tuple((lo, hi) for lo, hi, _, _ in blocks)
-    sel = pack._sel_cache.get(key)
-    if sel is None:
-        sel = torch.zeros(len(blocks), pack.bias.shape[0], device=pack.bias.device)
-        for k, (lo, hi) in enumerate(key):
-            sel[k, lo:hi] = 1.0
-        pack._sel_cache[key] = sel
-    return _LayerTransform.apply(pack.w_src_t, pack.bias, Z, blocks, sel, out_blocks, premasked)
+    threshold launch runs here; ``bias_sum``: per-block summed bias from rel_vectors(pack, blocks)."""
+    if bias_sum is None:
+        key = _block_key(blocks)
+        sel = pack._sel_cache.get(key)
+        if sel is None:
+            sel = torch.zeros(len(blocks), pack.bias.shape[0], device=pack.bias.device)
+            for k, (lo, hi) in enumerate(key):
+                sel[k, lo:hi] = 1.0
+            pack._sel_cache[key] = sel
+        bias_sum = torch.mm(sel, pack.bias.detach())
+    return _LayerTransform.apply(pack.w_src_t, pack.bias, Z, blocks, bias_sum, out_blocks, premasked)
 
 
 # ------------------------------------------------------------------------------------------------------
