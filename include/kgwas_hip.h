@@ -280,12 +280,6 @@ int kgw_readout_wmse_bwd(const float* H, const float* w_lin, const float* pred, 
                          const double* grad_loss, float* dH, float* dw_lin, float* db_lin, float* scratch,
                          int32_t* ticket, kgw_stream_t stream);
 
-/* out[c] = sum over rows of X[r][c], X [rows][128] (the bias gradient of a Linear whose weight gradient runs on the
- * library GEMM); scratch: kgw_colsum128_scratch_floats(rows) floats; ticket as for kgw_readout_wmse_*.          */
-int64_t kgw_colsum128_scratch_floats(int64_t rows);
-int kgw_colsum128(const float* X, int64_t ldx, int64_t rows, float* out, float* scratch, int32_t* ticket,
-                  kgw_stream_t stream);
-
 /* Self-test of the cross-lane reductions used by the aggregate kernels (one wavefront):
  * out_half[l] = sum over l's 32-lane half, out_wave[l] = sum over the wavefront,
  * out_steps[4][64] = the four intra-row DPP butterfly stages.                                  */

@@ -100,7 +100,7 @@ class KgwLayerArgs(C.Structure):
 EXPORTS = ['kgw_version', 'kgw_status_string', 'kgw_struct_sizes', 'kgw_sample_batch',
            'kgw_gat_aggregate_fwd', 'kgw_gat_aggregate_bwd_dst', 'kgw_gat_aggregate_bwd_src',
            'kgw_gather_rows', 'kgw_edge_alpha', 'kgw_debug_reduce', 'kgw_tn_gemm', 'kgw_tn_gemm_ex', 'kgw_tn_gemm_workspace_floats',
-           'kgw_linear', 'kgw_adam', 'kgw_relvec_fwd', 'kgw_relvec_bwd', 'kgw_wmse_fwd', 'kgw_wmse_bwd', 'kgw_readout_wmse_fwd', 'kgw_readout_wmse_bwd', 'kgw_colsum128', 'kgw_colsum128_scratch_floats', 'kgw_accumulate_stats']
+           'kgw_linear', 'kgw_adam', 'kgw_relvec_fwd', 'kgw_relvec_bwd', 'kgw_wmse_fwd', 'kgw_wmse_bwd', 'kgw_readout_wmse_fwd', 'kgw_readout_wmse_bwd', 'kgw_accumulate_stats']
 
 _lib = None
 
@@ -155,9 +155,6 @@ def lib():
     L.kgw_wmse_bwd.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.kgw_readout_wmse_fwd.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_int32] + [C.c_void_p] * 5
     L.kgw_readout_wmse_bwd.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_int64, C.c_int32] + [C.c_void_p] * 7
-    L.kgw_colsum128_scratch_floats.restype = C.c_int64
-    L.kgw_colsum128_scratch_floats.argtypes = [C.c_int64]
-    L.kgw_colsum128.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.kgw_accumulate_stats.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     _lib = L
     return L

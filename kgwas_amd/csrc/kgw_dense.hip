@@ -956,71 +956,6 @@ extern "C" int kgw_readout_wmse_bwd(const float* H, const float* w_lin, const fl
 }
 
 // ======================================================================================================
-// kgw_colsum128: out[c] = sum_r X[r][c] for a [rows,128] matrix (bias gradients of library-routed Linear layers).
-// Blocks sum row slabs, the last block to finish folds the per-block partials in index order (deterministic).
-// ======================================================================================================
-namespace {
-
-__global__ void __launch_bounds__(256) k_colsum128(const float* __restrict__ X, int64_t ldx, int64_t rows,
-                                                   float* __restrict__ out, float* __restrict__ part,
-                                                   int32_t* __restrict__ ticket) {
-    __shared__ float sm[8][KGW_C];
-    __shared__ int last;
-    const int c4 = threadIdx.x & 31, g = threadIdx.x >> 5;           // 32 lanes x float4 = one row, 8 rows per pass
-    const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
-    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(rows, r0 + per);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t r = r0 + g; r < r1; r += 8) {
-        const float4 v = ((const float4*)(X + r * ldx))[c4];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    ((float4*)sm[g])[c4] = acc;
-    __syncthreads();
-    if (threadIdx.x < KGW_C) {
-        const int c = threadIdx.x;
-        part[(int64_t)blockIdx.x * KGW_C + c] = ((sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c])) + ((sm[4][c] + sm[5][c]) + (sm[6][c] + sm[7][c]));
-    }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    if (threadIdx.x < KGW_C) {
-        const int c = threadIdx.x, nb = gridDim.x;
-        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int q = 0;
-        for (; q + 8 <= nb; q += 8) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) a8[k] += __builtin_nontemporal_load(part + (int64_t)(q + k) * KGW_C + c);
-        }
-        for (int k = 0; q < nb; ++q, ++k) a8[k] += __builtin_nontemporal_load(part + (int64_t)q * KGW_C + c);
-        out[c] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
-    }
-    if (threadIdx.x == 0) *ticket = 0;
-}
-
-}  // namespace
-
-extern "C" int64_t kgw_colsum128_scratch_floats(int64_t rows) {
-    int64_t nb = (rows + 255) / 256;
-    if (nb > 256) nb = 256;
-    if (nb < 1) nb = 1;
-    return nb * KGW_C;
-}
-
-extern "C" int kgw_colsum128(const float* X, int64_t ldx, int64_t rows, float* out, float* scratch, int32_t* ticket,
-                             kgw_stream_t stream_) {
-    if (!X || !out || !scratch || !ticket) return KGW_E_NULL;
-    if (rows <= 0 || ldx < KGW_C || (ldx & 3) || !aligned16(X)) return KGW_E_RANGE;
-    int64_t nb = (rows + 255) / 256;
-    if (nb > 256) nb = 256;
-    k_colsum128<<<(unsigned)nb, 256, 0, (hipStream_t)stream_>>>(X, ldx, rows, out, scratch, ticket);
-    KGW_LAUNCH_CHECK();
-    return KGW_OK;
-}
-
-// ======================================================================================================
 // kgw_relvec: the attention vectors of every relation of a layer in one launch.
 //   u_r = W_src^T att_src , v_r = W_dst^T att_dst (W_src^T att_dst for same-type relations)   conv.py:138-151
 // Weights are stored transposed/packed: wT[i][k][c] = W_i[c][k].  Forward: U_full[r] (zeros for relations the

@@ -182,14 +182,3 @@ def test_rows_dev_skips_padding_rows(rows, real):
     Cm, cs = ops.tn_gemm(X, B, colsum=True, rows_dev=cnt)
     assert_close(Cm, X[:real].double().t() @ B[:real].double(), 1e-5, 1e-5, 'tn rows_dev', rel_to_max=2e-6)
     assert_close(cs, X[:real].double().sum(0), 1e-5, 1e-5, 'colsum rows_dev', rel_to_max=2e-6)
-
-
-@pytest.mark.parametrize('rows', [1, 255, 20032, 200001])
-def test_colsum128(rows):
-    from kgwas_amd import ops
-    g = torch.Generator().manual_seed(rows)
-    big = torch.randn(rows, 160, generator=g).cuda()
-    X = big[:, :128]                                           # row stride 160
-    a = ops.colsum(X); b = ops.colsum(X)
-    assert torch.equal(a, b)                                   # fixed order
-    assert_close(a, X.double().sum(0), 1e-5, 1e-5, 'colsum', rel_to_max=2e-6)
