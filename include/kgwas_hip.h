@@ -270,15 +270,15 @@ int kgw_wmse_bwd(const float* pred, const int32_t* n_id, const float* y, const d
  * (HeteroGNN.lin, kgwas/model.py:50,83-86; hidden 128 -> 1) fused with the weighted MSE above; _bwd writes dH [rows][128]
  * (zero beyond the seeds), d w_lin [128] and d b_lin [1].  `relu` bit 0: ReLU on pred; bit 1 (_bwd): H is itself a ReLU
  * output whose backward is folded in (dH *= H > 0).  One wavefront per seed; partial results go to `scratch`
- * (_fwd: n doubles; _bwd: ceil(rows/4) * 129 floats) and the last block to finish folds them in index order
- * (deterministic); `ticket` is a device int32 that must be 0 before the first call and is reset by every call.     */
+ * (_fwd: n doubles; _bwd: ceil(rows/4) * 129 floats) and a second single-block launch folds them in index order
+ * (deterministic).                                                                                              */
 int kgw_readout_wmse_fwd(const float* H, const float* w_lin, const float* b_lin, const int32_t* n_id,
                          const float* y, const double* w, int32_t n, int32_t relu, float* pred, double* loss,
-                         double* scratch, int32_t* ticket, kgw_stream_t stream);
+                         double* scratch, kgw_stream_t stream);
 int kgw_readout_wmse_bwd(const float* H, const float* w_lin, const float* pred, const int32_t* n_id,
                          const float* y, const double* w, int32_t n, int64_t rows, int32_t relu,
                          const double* grad_loss, float* dH, float* dw_lin, float* db_lin, float* scratch,
-                         int32_t* ticket, kgw_stream_t stream);
+                         kgw_stream_t stream);
 
 /* Self-test of the cross-lane reductions used by the aggregate kernels (one wavefront):
  * out_half[l] = sum over l's 32-lane half, out_wave[l] = sum over the wavefront,

@@ -153,8 +153,8 @@ def lib():
                                  C.c_int64, C.c_void_p, C.c_void_p]
     L.kgw_wmse_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_void_p, C.c_void_p]
     L.kgw_wmse_bwd.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
-    L.kgw_readout_wmse_fwd.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_int32] + [C.c_void_p] * 5
-    L.kgw_readout_wmse_bwd.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_int64, C.c_int32] + [C.c_void_p] * 7
+    L.kgw_readout_wmse_fwd.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_int32] + [C.c_void_p] * 4
+    L.kgw_readout_wmse_bwd.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_int64, C.c_int32] + [C.c_void_p] * 6
     L.kgw_accumulate_stats.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     _lib = L
     return L

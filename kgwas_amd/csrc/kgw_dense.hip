@@ -829,56 +829,47 @@ extern "C" int kgw_wmse_bwd(const float* pred, const int32_t* n_id, const float*
 // ======================================================================================================
 namespace {
 
-// Both kernels: one wavefront per seed, four per block; per-seed / per-block partial results go to a scratch buffer
-// and the LAST block to finish (ticket counter, self-resetting) folds them in index order -- parallel across the
-// chip, yet a fixed summation order.
+// One wavefront per seed, four per block; per-seed / per-block partial results go to a scratch buffer and a second,
+// single-block launch folds them in index order -- parallel across the chip, yet a fixed summation order.  (A
+// "last block folds" hand-off inside one launch was tried: its device-scope fence cost more than the second launch.)
 __global__ void __launch_bounds__(256) k_readout_wmse_fwd(const float* __restrict__ H, const float* __restrict__ wl,
                                                           const float* __restrict__ bl, const int32_t* __restrict__ n_id,
                                                           const float* __restrict__ y, const double* __restrict__ w, int n,
-                                                          int relu, float* __restrict__ pred, double* __restrict__ loss,
-                                                          double* __restrict__ terms, int32_t* __restrict__ ticket) {
-    __shared__ double sm[256];
-    __shared__ int last;
+                                                          int relu, float* __restrict__ pred, double* __restrict__ terms) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wave;
-    if (i < n) {
-        const float2 w2 = ((const float2*)wl)[lane];
-        const float2 h2 = ((const float2*)(H + (int64_t)i * KGW_C))[lane];
-        float p = kgw_wave_allsum(fmaf(h2.x, w2.x, h2.y * w2.y)) + bl[0];
-        if (relu) p = fmaxf(p, 0.f);
-        if (lane == 0) {
-            const int g = n_id[i];
-            const float d = p - y[g];
-            pred[i] = p;
-            terms[i] = w[g] * (double)(d * d);
-        }
+    if (i >= n) return;
+    const float2 w2 = ((const float2*)wl)[lane];
+    const float2 h2 = ((const float2*)(H + (int64_t)i * KGW_C))[lane];
+    float p = kgw_wave_allsum(fmaf(h2.x, w2.x, h2.y * w2.y)) + bl[0];
+    if (relu) p = fmaxf(p, 0.f);
+    if (lane == 0) {
+        const int g = n_id[i];
+        const float d = p - y[g];
+        pred[i] = p;
+        terms[i] = w[g] * (double)(d * d);
     }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
+}
+
+__global__ void __launch_bounds__(256) k_fold_f64(const double* __restrict__ terms, int n, double* __restrict__ out) {
+    __shared__ double sm[256];
     double acc = 0.0;
-    for (int q = threadIdx.x; q < n; q += 256) acc += __builtin_nontemporal_load(terms + q);
+    for (int q = threadIdx.x; q < n; q += 256) acc += terms[q];
     sm[threadIdx.x] = acc;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { loss[0] = sm[0] / (double)n; *ticket = 0; }
+    if (threadIdx.x == 0) out[0] = sm[0] / (double)n;
 }
 
 __global__ void __launch_bounds__(256) k_readout_wmse_bwd(const float* __restrict__ H, const float* __restrict__ wl,
                                                           const float* __restrict__ pred, const int32_t* __restrict__ n_id,
                                                           const float* __restrict__ y, const double* __restrict__ w, int n,
                                                           int64_t rows, int relu, const double* __restrict__ gloss,
-                                                          float* __restrict__ dH, float* __restrict__ dwl,
-                                                          float* __restrict__ dbl, float* __restrict__ part,
-                                                          int32_t* __restrict__ ticket) {
+                                                          float* __restrict__ dH, float* __restrict__ part) {
     __shared__ float sw[4][KGW_C + 1];
-    __shared__ int last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + wave;
     float2 dw = make_float2(0.f, 0.f);
@@ -898,6 +889,7 @@ __global__ void __launch_bounds__(256) k_readout_wmse_bwd(const float* __restric
     } else if (i < rows) {
         ((float2*)(dH + i * KGW_C))[lane] = make_float2(0.f, 0.f);
     }
+    if ((int64_t)blockIdx.x * 4 >= n) return;            // blocks without seeds hold no partial
     sw[wave][2 * lane] = dw.x; sw[wave][2 * lane + 1] = dw.y;
     if (lane == 0) sw[wave][KGW_C] = dp;
     __syncthreads();
@@ -905,38 +897,41 @@ __global__ void __launch_bounds__(256) k_readout_wmse_bwd(const float* __restric
         const int c = threadIdx.x;
         part[(int64_t)blockIdx.x * (KGW_C + 1) + c] = (sw[0][c] + sw[1][c]) + (sw[2][c] + sw[3][c]);
     }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    const int nb = (n + 3) / 4;                     // blocks that held seeds
-    if (threadIdx.x <= KGW_C) {
-        const int c = threadIdx.x;
-        // eight independent partial sums (loads in flight together), combined in a fixed order
-        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int q = 0;
-        for (; q + 8 <= nb; q += 8) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) a8[k] += __builtin_nontemporal_load(part + (int64_t)(q + k) * (KGW_C + 1) + c);
+}
+
+// d w_lin [128] and d b_lin from the per-block partials [nb][129]: 129 columns x 7 row groups of one block, fixed order
+__global__ void __launch_bounds__(1024) k_readout_fold(const float* __restrict__ part, int nb, float* __restrict__ dwl,
+                                                       float* __restrict__ dbl) {
+    __shared__ float sm[7][KGW_C + 1];
+    const int c = threadIdx.x % (KGW_C + 1), g = threadIdx.x / (KGW_C + 1);
+    if (g < 7) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int q = g;
+        for (; q + 21 < nb; q += 28) {
+            a0 += part[(int64_t)q * (KGW_C + 1) + c];        a1 += part[(int64_t)(q + 7) * (KGW_C + 1) + c];
+            a2 += part[(int64_t)(q + 14) * (KGW_C + 1) + c]; a3 += part[(int64_t)(q + 21) * (KGW_C + 1) + c];
         }
-        for (int k = 0; q < nb; ++q, ++k) a8[k] += __builtin_nontemporal_load(part + (int64_t)q * (KGW_C + 1) + c);
-        const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
-        if (c < KGW_C) dwl[c] = acc; else dbl[0] = acc;
+        for (; q < nb; q += 7) a0 += part[(int64_t)q * (KGW_C + 1) + c];
+        sm[g][c] = (a0 + a1) + (a2 + a3);
     }
-    if (threadIdx.x == 0) *ticket = 0;
+    __syncthreads();
+    if (g == 0) {
+        const float t = ((sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c])) + ((sm[4][c] + sm[5][c]) + sm[6][c]);
+        if (c < KGW_C) dwl[c] = t; else dbl[0] = t;
+    }
 }
 
 }  // namespace
 
 extern "C" int kgw_readout_wmse_fwd(const float* H, const float* w_lin, const float* b_lin, const int32_t* n_id,
                                     const float* y, const double* w, int32_t n, int32_t relu, float* pred,
-                                    double* loss, double* scratch, int32_t* ticket, kgw_stream_t stream_) {
-    if (!H || !w_lin || !b_lin || !n_id || !y || !w || !pred || !loss || !scratch || !ticket) return KGW_E_NULL;
+                                    double* loss, double* scratch, kgw_stream_t stream_) {
+    if (!H || !w_lin || !b_lin || !n_id || !y || !w || !pred || !loss || !scratch) return KGW_E_NULL;
     if (n <= 0) return KGW_E_RANGE;
-    k_readout_wmse_fwd<<<(n + 3) / 4, 256, 0, (hipStream_t)stream_>>>(H, w_lin, b_lin, n_id, y, w, n, relu, pred, loss,
-                                                                       scratch, ticket);
+    hipStream_t st = (hipStream_t)stream_;
+    k_readout_wmse_fwd<<<(n + 3) / 4, 256, 0, st>>>(H, w_lin, b_lin, n_id, y, w, n, relu, pred, scratch);
+    KGW_LAUNCH_CHECK();
+    k_fold_f64<<<1, 256, 0, st>>>(scratch, n, loss);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }
@@ -944,13 +939,15 @@ extern "C" int kgw_readout_wmse_fwd(const float* H, const float* w_lin, const fl
 extern "C" int kgw_readout_wmse_bwd(const float* H, const float* w_lin, const float* pred, const int32_t* n_id,
                                     const float* y, const double* w, int32_t n, int64_t rows, int32_t relu,
                                     const double* grad_loss, float* dH, float* dw_lin, float* db_lin, float* scratch,
-                                    int32_t* ticket, kgw_stream_t stream_) {
-    if (!H || !w_lin || !pred || !n_id || !y || !w || !grad_loss || !dH || !dw_lin || !db_lin || !scratch || !ticket)
+                                    kgw_stream_t stream_) {
+    if (!H || !w_lin || !pred || !n_id || !y || !w || !grad_loss || !dH || !dw_lin || !db_lin || !scratch)
         return KGW_E_NULL;
     if (n <= 0 || rows < n) return KGW_E_RANGE;
-    k_readout_wmse_bwd<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream_>>>(H, w_lin, pred, n_id, y, w, n, rows, relu,
-                                                                                     grad_loss, dH, dw_lin, db_lin, scratch,
-                                                                                     ticket);
+    hipStream_t st = (hipStream_t)stream_;
+    k_readout_wmse_bwd<<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(H, w_lin, pred, n_id, y, w, n, rows, relu, grad_loss, dH,
+                                                                    scratch);
+    KGW_LAUNCH_CHECK();
+    k_readout_fold<<<1, 1024, 0, st>>>(scratch, (n + 3) / 4, dw_lin, db_lin);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }

@@ -713,17 +713,6 @@ def weighted_mse(pred, n_id, y_all, w_all):
     return _WeightedMSE.apply(pred, n_id, y_all, w_all)
 
 
-_TICKETS = {}
-
-
-def _ticket(dev):
-    """Persistent zero-initialised int32 per device: the arrival counter of the read-out kernels (they reset it)."""
-    k = str(dev)
-    if k not in _TICKETS:
-        _TICKETS[k] = torch.zeros(1, dtype=torch.int32, device=dev)
-    return _TICKETS[k]
-
-
 class _ReadoutWeightedMSE(torch.autograd.Function):
     """loss = mean(w[n_id] * ([relu](H[:n] @ w_lin^T + b_lin) - y[n_id])**2): the read-out Linear(128 -> 1) of the seed
     rows (kgwas/model.py:86) and the weighted MSE (kgwas/kgwas.py:139-145) as one node, two launches per step."""
@@ -738,8 +727,8 @@ class _ReadoutWeightedMSE(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float64, device=dev)
         terms = torch.empty(n, dtype=torch.float64, device=dev)
         _lib.check(_lib.lib().kgw_readout_wmse_fwd(_p(H), _p(w_lin), _p(b_lin), _p(n_id), _p(y_all), _p(w_all), n,
-                                                   1 if relu else 0, _p(pred), _p(loss), _p(terms), _p(_ticket(dev)),
-                                                   _lib.stream_ptr()), 'kgw_readout_wmse_fwd')
+                                                   1 if relu else 0, _p(pred), _p(loss), _p(terms), _lib.stream_ptr()),
+                   'kgw_readout_wmse_fwd')
         ctx.save_for_backward(H, w_lin, pred, n_id, y_all, w_all)
         ctx.n, ctx.relu, ctx.h_is_relu = n, relu, h_is_relu
         ctx.mark_non_differentiable(pred)
@@ -758,7 +747,7 @@ class _ReadoutWeightedMSE(torch.autograd.Function):
         part = torch.empty(((H.shape[0] + 3) // 4) * (KGW_C + 1), device=H.device)
         _lib.check(_lib.lib().kgw_readout_wmse_bwd(_p(H), _p(w_lin), _p(pred), _p(n_id), _p(y_all), _p(w_all), ctx.n,
                                                    H.shape[0], (1 if ctx.relu else 0) | (2 if ctx.h_is_relu else 0), _p(gloss),
-                                                   _p(dH), _p(dw), _p(db), _p(part), _p(_ticket(H.device)), _lib.stream_ptr()),
+                                                   _p(dH), _p(dw), _p(db), _p(part), _lib.stream_ptr()),
                    'kgw_readout_wmse_bwd')
         return dH, dw, db, None, None, None, None, None, None
 
