@@ -56,11 +56,6 @@ class GraphTrainStep:
         from .optim import FusedAdam
         self.opt = FusedAdam(self.model.parameters(), lr=lr, weight_decay=weight_decay)   # one launch, capturable
         # device-side statistics accumulated inside the graph: [edges layer 1..L, sampled edges, error mask]
-        base = _lib.KgwBatchMeta
-        self._meta_i32 = [b.meta.view(torch.int32) for b in self.bufs]
-        self._idx = torch.tensor([base.n_edges.offset // 4 + l for l in range(L)] +
-                                 [base.edge_end.offset // 4 + self.dg.n_hops - 1, base.error.offset // 4],
-                                 dtype=torch.long, device=dev)
         self.stats = torch.zeros(L + 2, dtype=torch.int64, device=dev)
         self.loss = [None, None]
         self._flat = None                         # multi-rank: gradient bucket + {param: view}
