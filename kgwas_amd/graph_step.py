@@ -201,3 +201,100 @@ class GraphTrainStep:
         if err:
             raise _lib.KgwasHipError(f'a batch exceeded the static capacities (error mask {err}); raise `margin`')
         return [int(v) for v in self.stats[:-1]]
+
+
+class GraphEvalStep:
+    """Forward-only twin of GraphTrainStep for the evaluation / inference loops (kgwas/utils.py:20-39 driven by the
+    val / test / infer loaders of kgwas/kgwas.py:104-113): one captured forward graph per buffer parity, the next
+    batch sampled by its own graph on a side stream.  The loaders keep partial last batches (drop_last=False): the
+    id list is padded to a whole number of batches with ids from its head (distinct from the tail's) and the padded
+    outputs are dropped."""
+
+    def __init__(self, model, graph, num_layers: int, input_nodes, batch_size: int, device, margin: float = 1.03):
+        self.model = model
+        self.batch_size = bs = int(batch_size)
+        dev = torch.device(device)
+        self.input_type, ids = input_nodes
+        ids = np.asarray(ids.cpu() if torch.is_tensor(ids) else ids, dtype=np.int64).reshape(-1)
+        self.n = len(ids)
+        if self.n < 2 * bs:
+            raise ValueError('too few evaluation nodes for the captured path')
+        self.n_batches = (self.n + bs - 1) // bs
+        pad = self.n_batches * bs - self.n
+        ids_p = np.concatenate([ids, ids[:pad]])
+        probe = NeighborLoader(graph, [-1] * num_layers, (self.input_type, ids_p), batch_size=bs, drop_last=True,
+                               device=dev, prefetch=False)
+        self.caps = probe.measure_caps(margin)
+        self.dg = probe.dg.with_static_caps(self.caps)
+        self.seed_type = probe.seed_type
+        self.ids = probe.ids
+        self.bufs = [BatchBuffers(self.dg), BatchBuffers(self.dg)]
+        self.meta = self.dg.static_meta()
+        self.seeds = torch.zeros(bs, dtype=torch.int64, device=dev)
+        self.out = torch.zeros(self.n_batches * bs, device=dev)
+        self.pred = [None, None]
+        self.graphs = [None, None]
+        self.sample_graphs = [None, None]
+        self._side = torch.cuda.Stream(device=dev)
+        self._sampled = [torch.cuda.Event(), torch.cuda.Event()]
+        self._capture()
+
+    def _forward(self, cur: int):
+        batch = SampledBatch(self.dg, self.bufs[cur], self.meta, self.input_type, self.batch_size, static=True)
+        with torch.no_grad():
+            return self.model(batch.x_dict, batch.edge_index_dict, self.batch_size).reshape(-1)
+
+    def _sample_now(self, which: int, i: int):
+        b = self.batch_size
+        self.seeds.copy_(self.ids[i * b:(i + 1) * b])
+        sample_into(self.dg, self.bufs[which], self.seeds, self.seed_type, record=False)
+
+    def _capture(self):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for k in range(3):
+                self._sample_now(k % 2, 0)
+                self._forward(k % 2)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        for b in self.bufs:
+            err = int(b.read_meta().error)
+            if err:
+                raise _lib.KgwasHipError(f'static layout does not fit the sampler buffers (error mask {err})')
+        for cur in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.pred[cur] = self._forward(cur)
+            self.graphs[cur] = g
+            gs = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gs, stream=self._side):
+                sample_into(self.dg, self.bufs[cur], self.seeds, self.seed_type, record=False)
+            self.sample_graphs[cur] = gs
+
+    def run(self) -> torch.Tensor:
+        """Predictions of every input node, in input order (device tensor [n])."""
+        b, main = self.batch_size, torch.cuda.current_stream()
+        self._sample_now(0, 0)
+        err = torch.zeros(1, dtype=torch.int32, device=self.out.device)
+        meta_err = [bf.meta.view(torch.int32)[_lib.KgwBatchMeta.error.offset // 4:][:1] for bf in self.bufs]
+        pending = [False, False]
+        for i in range(self.n_batches):
+            cur = i % 2
+            if i + 1 < self.n_batches:
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    self.seeds.copy_(self.ids[(i + 1) * b:(i + 2) * b])
+                    self.sample_graphs[1 - cur].replay()
+                    self._sampled[1 - cur].record(self._side)
+                pending[1 - cur] = True
+            if pending[cur]:
+                main.wait_event(self._sampled[cur])
+                pending[cur] = False
+            self.graphs[cur].replay()
+            self.out[i * b:(i + 1) * b].copy_(self.pred[cur])
+            err |= meta_err[cur]
+        torch.cuda.synchronize()
+        if int(err):
+            raise _lib.KgwasHipError(f'a batch exceeded the static capacities (error mask {int(err)}); raise `margin`')
+        return self.out[:self.n]

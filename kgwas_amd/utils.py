@@ -26,9 +26,31 @@ def load_dict(path):
 
 def evaluate_minibatch_clean(loader, model, device):
     """kgwas/utils.py:20-39: eval-mode forward over a loader; returns {'pred', 'truth'} numpy arrays.
-    Differences by design: wrapped in no_grad (the reference builds and frees autograd graphs), and
-    predictions stay on the GPU until the end (one D2H copy instead of one per batch)."""
+    Differences by design: wrapped in no_grad (the reference builds and frees autograd graphs), predictions stay on
+    the GPU until the end (one D2H copy instead of one per batch), and -- for this package's own NeighborLoader on a
+    ROCm device -- the per-batch forward is a captured HIP graph (kgwas_amd/graph_step.py::GraphEvalStep; set
+    KGW_EVAL_EAGER=1 to issue the launches one by one instead: same kernels, same values)."""
     model.eval()
+    from .sampler import NeighborLoader
+    if isinstance(loader, NeighborLoader) and torch.device(device).type == 'cuda' and \
+            os.environ.get('KGW_EVAL_EAGER', '0') != '1' and len(loader) > 0:
+        cache = loader.__dict__.setdefault('_graph_eval', {})
+        ge = cache.get(id(model))
+        if ge is None:
+            try:
+                from .graph_step import GraphEvalStep
+                # (a drop_last loader -- the reference's val loader, kgwas.py:102-103 -- never sees its tail)
+                ids = loader.ids[:len(loader) * loader.batch_size] if loader.drop_last else loader.ids
+                ge = GraphEvalStep(model, loader.data, loader.num_layers, (loader.input_type, ids), loader.batch_size, device)
+                ge.eval_ids = ids
+            except ValueError:
+                ge = False                       # too few nodes for a padded static layout: eager path below
+            cache.clear()
+            cache[id(model)] = ge
+        if ge:
+            pred = ge.run()
+            truth = loader.dg.y[loader.input_type][ge.eval_ids]
+            return {'pred': pred.float().cpu().numpy(), 'truth': truth.float().cpu().numpy()}
     preds, truths = [], []
     with torch.no_grad():
         for batch in loader:

@@ -75,3 +75,24 @@ def test_static_capacity_overflow_is_reported(small_kg):
         overflow = True
     caps_equal = gs2.caps.node_off == gs.caps.node_off
     assert overflow or caps_equal
+
+
+@pytest.mark.parametrize('drop_last', [False, True])
+def test_graph_eval_equals_eager_eval(small_kg, drop_last, monkeypatch):
+    """evaluate_minibatch_clean through the captured forward (GraphEvalStep) == the eager per-batch loop, including
+    the partial last batch of a drop_last=False loader."""
+    from kgwas_amd.kgwas import KGWAS
+    from kgwas_amd.sampler import NeighborLoader
+    from kgwas_amd.utils import evaluate_minibatch_clean
+    run = KGWAS(small_kg, device='cuda:0', seed=4)
+    run.initialize_model()
+    ids = np.asarray(small_kg.test_input_nodes[1])[:64 * 5 + 17]
+    mk = lambda: NeighborLoader(small_kg.data, [-1, -1], ('SNP', ids), batch_size=64, drop_last=drop_last, device='cuda:0')
+    a = evaluate_minibatch_clean(mk(), run.model, 'cuda:0')
+    monkeypatch.setenv('KGW_EVAL_EAGER', '1')
+    b = evaluate_minibatch_clean(mk(), run.model, 'cuda:0')
+    n = (len(ids) // 64) * 64 if drop_last else len(ids)
+    assert len(ids) % 64 != 0 and len(ids) >= 3 * 64
+    assert a['pred'].shape == b['pred'].shape == (n,)
+    assert np.array_equal(a['truth'], b['truth'])
+    np.testing.assert_allclose(a['pred'], b['pred'], rtol=1e-5, atol=1e-6)
