@@ -54,8 +54,22 @@ class KGWAS_Data:
 
     # ---------------------------------------------------------------------------------------------
     def load_kg(self, snp_init_emb='enformer', go_init_emb='random', gene_init_emb='esm', sample_edges=False,
-                sample_ratio=1, seed=1):
+                sample_ratio=1, seed=1, cache=True):
+        """kgwas/kgwas_data.py:112-273.  ``cache`` (extra): keep / reuse the converted graph under
+        ``<data_path>/cell_kg/kgwas_amd_cache/<options>`` (kgwas_amd/ingest.py): later loads map contiguous arrays
+        instead of unpickling dicts and sorting 21 M edges."""
         dp = self.data_path
+        opts = {'snp_init_emb': snp_init_emb, 'go_init_emb': go_init_emb, 'gene_init_emb': gene_init_emb,
+                'sample_edges': bool(sample_edges), 'sample_ratio': float(sample_ratio), 'seed': int(seed)}
+        cache_dir = os.path.join(dp, 'cell_kg', 'kgwas_amd_cache',
+                                 '_'.join(str(v) for v in opts.values()).replace('.', 'p'))
+        if cache:
+            from . import ingest
+            meta = ingest.read_meta(cache_dir)
+            if meta is not None and meta.get('options') == opts:
+                print('--loading KG (cached)---')
+                ingest.load(self, cache_dir)
+                return
         net = os.path.join(dp, 'cell_kg/network')
         for f in ('node_idx2id.pkl', 'edge_index.pkl', 'node_id2idx.pkl'):
             if not os.path.exists(os.path.join(net, f)):
@@ -91,6 +105,11 @@ class KGWAS_Data:
                 ei = ei[:, perm]
             edges[tuple(et)] = ei
         self._finish_graph(data, edges)
+        if cache:
+            try:
+                ingest.convert(self, cache_dir, opts)
+            except OSError as e:                     # read-only data directory: run without a cache
+                print(f'KG cache not written: {e}')
 
     def _finish_graph(self, data: HeteroGraph, edges):
         nn_ = data.num_nodes_dict

@@ -60,7 +60,11 @@ class DeviceGraph:
         seg_cap = edge_cap = chunk_cap = multi_cap = 0
         ro = co = 0
         for r, et in enumerate(sc.edge_types):
-            rp, col = build_csr(data[et].edge_index, self.n_nodes[sc.src_type[r]], self.n_nodes[sc.dst_type[r]])
+            cached = data._extra.get('csr', {}).get(tuple(et)) if hasattr(data, '_extra') else None
+            if cached is not None:                    # kgwas_amd/ingest.py: CSR straight from the on-disk cache
+                rp, col = np.asarray(cached[0]), np.asarray(cached[1])
+            else:
+                rp, col = build_csr(data[et].edge_index, self.n_nodes[sc.src_type[r]], self.n_nodes[sc.dst_type[r]])
             if rp[-1] >= 2 ** 31:
                 raise ValueError('relation too large for int32 row pointers')
             deg = np.diff(rp)

@@ -160,3 +160,20 @@ def test_loader_contract(small_kg):
     assert [bb['SNP'].batch_size for bb in b] == [64, 64, 64, 8]
     xd = next(iter(a)).x_dict
     assert set(xd.keys()) == set(data.node_types)
+
+
+def test_loader_on_cached_graph_equals_direct(tiny_kg, tmp_path):
+    """kgwas_amd/ingest.py: a DeviceGraph fed from the on-disk CSR cache samples exactly what one built from COO does."""
+    from kgwas_amd import ingest
+    from kgwas_amd.kgwas_data import KGWAS_Data
+    cache = ingest.convert(tiny_kg, str(tmp_path / 'cache'))
+    other = ingest.load(KGWAS_Data(str(tmp_path / 'dp')), cache)
+    ids = np.random.default_rng(5).choice(tiny_kg.data['SNP'].x.shape[0], size=32, replace=False)
+    a = next(iter(_loader(tiny_kg.data, ids, 32, L=2)))
+    b = next(iter(_loader(other.data, ids, 32, L=2)))
+    for t in tiny_kg.data.node_types:
+        assert torch.equal(a.n_id(t), b.n_id(t))
+        assert torch.equal(a.x_dict[t], b.x_dict[t])
+    ea, eb = a.edge_index_dict, b.edge_index_dict
+    for et in ea:
+        assert torch.equal(ea[et], eb[et])
