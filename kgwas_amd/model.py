@@ -147,6 +147,40 @@ class RelationPack(nn.Module):
                 getattr(self, field)[i].copy_(value)
 
 
+class SagePack(nn.Module):
+    """Parameters of a list of SAGEConv((-1,-1), C) relations of one layer, packed (kgwas/model.py:38; PyG SAGEConv:
+    aggr='mean', root_weight=True): ``w_l_t[i]`` = lin_l.weight^T ([in, out]) and ``bias[i]`` = lin_l.bias act on the
+    mean of the neighbours, ``w_r_t[i]`` = lin_r.weight^T (no bias) on the destination node itself.  Same field
+    plumbing as RelationPack (``get`` / ``set`` by reference name)."""
+
+    FIELDS = ('lin_l.weight', 'lin_l.bias', 'lin_r.weight')
+
+    def __init__(self, edge_types: List[EdgeType], rel_ids: List[int], C: int):
+        super().__init__()
+        self.n_rels_total = len(edge_types)
+        self.rel_ids = list(rel_ids)
+        n = len(rel_ids)
+        a = 1.0 / math.sqrt(C)                     # nn.Linear's default (kaiming_uniform a=sqrt(5)) bound for fan_in = C
+        self.w_l_t = nn.Parameter(_uniform_(torch.empty(n, C, C), a))
+        self.bias = nn.Parameter(_uniform_(torch.empty(n, C), a))
+        self.w_r_t = nn.Parameter(_uniform_(torch.empty(n, C, C), a))
+        self._sel_cache = {}
+
+    def get(self, i: int, field: str, grad: bool = False):
+        p = {'lin_l.weight': self.w_l_t, 'lin_l.bias': self.bias, 'lin_r.weight': self.w_r_t}[field]
+        t = p.grad if grad else p.detach()
+        if t is None:
+            return None
+        return t[i] if field == 'lin_l.bias' else t[i].t()
+
+    def set(self, i: int, field: str, value: torch.Tensor):
+        with torch.no_grad():
+            if field == 'lin_l.bias':
+                self.bias[i].copy_(value)
+            else:
+                (self.w_l_t if field == 'lin_l.weight' else self.w_r_t)[i].copy_(value.t())
+
+
 class HeteroGNN(nn.Module):
     """kgwas/model.py:24-86 (same ctor / forward signature).  ``pyg_data`` only needs ``.edge_types``
     and ``.node_types``."""
@@ -154,9 +188,11 @@ class HeteroGNN(nn.Module):
     def __init__(self, pyg_data, hidden_channels, out_channels, num_layers, gnn_backbone, gnn_aggr,
                  snp_init_dim_size, gene_init_dim_size, go_init_dim_size, gat_num_head, no_relu=False):
         super().__init__()
-        if gnn_backbone != 'GAT':
-            raise NotImplementedError(f"backbone {gnn_backbone!r}: only 'GAT' (the reference default, "
-                                      "kgwas.py:52) runs on the fused MI355X path")
+        if gnn_backbone not in ('GAT', 'SAGE'):
+            raise NotImplementedError(f"backbone {gnn_backbone!r}: 'GAT' (the reference default, kgwas.py:52) and 'SAGE' "
+                                      "run on the fused MI355X path; GCNConv / SGConv cannot take the bipartite "
+                                      "relations HeteroConv hands them (kgwas/model.py:44-46)")
+        self.backbone = gnn_backbone
         if gnn_aggr != 'sum':
             raise NotImplementedError("gnn_aggr: only 'sum' (the reference default) is fused")
         if hidden_channels != 128:
@@ -171,6 +207,7 @@ class HeteroGNN(nn.Module):
         self.num_layers = num_layers
         self.hidden = hidden_channels
         self.negative_slope, self.temperature = 0.2, 1.0          # conv.py:43,50 defaults (model.py:40-42)
+        self.rel_fields = REL_FIELDS if gnn_backbone == 'GAT' else SagePack.FIELDS
         self.live_rel, self.live_types = sc.live_relations(num_layers, 'SNP')
         self.live_packs = nn.ModuleList()
         self.dead_packs = nn.ModuleList()
@@ -180,8 +217,9 @@ class HeteroGNN(nn.Module):
             live = set(self.live_rel[l])
             order = [r for t in range(sc.NT) for r in sc.rels_by_dst[t] if r in live]   # grouped by dst type
             dead = [r for r in range(sc.NR) if r not in live]
-            self.live_packs.append(RelationPack(self.edge_types, order, hidden_channels))
-            self.dead_packs.append(RelationPack(self.edge_types, dead, hidden_channels))
+            Pack = RelationPack if gnn_backbone == 'GAT' else SagePack
+            self.live_packs.append(Pack(self.edge_types, order, hidden_channels))
+            self.dead_packs.append(Pack(self.edge_types, dead, hidden_channels))
             slot = {r: ('live', i) for i, r in enumerate(order)}
             slot.update({r: ('dead', i) for i, r in enumerate(dead)})
             self._slot.append(slot)
@@ -277,8 +315,52 @@ class HeteroGNN(nn.Module):
                 h[t] = self._embed(batch, x_dict, t, blocks.get(t))
         return h
 
+    def _sage_layers(self, batch: SampledBatch, h: Dict[str, torch.Tensor], hbuf=None):
+        """SAGE backbone (kgwas/model.py:38,74-75): out_d = relu(sum_r [lin_l^r(mean_{j->i} h_s[j]) + lin_r^r(h_d[i])]).
+        The neighbour mean IS the attention aggregate with all logits equal: the same kernels run with zero attention
+        vectors (alpha = 1/deg; rows without in-edges stay zero like PyG's mean), forward and backward; the root
+        term is one more product per destination type with the relation-summed lin_r."""
+        sc, m, C = self.schema, batch.meta, self.hidden
+        dev = self.lin.weight.device
+        zeros = torch.zeros(sc.NR, C, device=dev)
+        for l in range(1, self.num_layers + 1):
+            P: SagePack = self.live_packs[l - 1]
+            rng = self._dst_range[l - 1]
+            parts, spans = [], []
+            for t, name in enumerate(sc.node_types):
+                ns = int(m.lay_src[l - 1][t])
+                if ns:
+                    if name not in h or h[name].shape[0] < ns:
+                        raise RuntimeError(f'layer {l}: node type {name!r} takes part in the layer but has no '
+                                           f'incoming relation to produce its layer-{l - 1} state')
+                    parts.append(h[name] if h[name].shape[0] == ns else h[name][:ns])
+                    spans.append((int(m.src_base[l - 1][t]), ns))
+            if hbuf is None:
+                hbuf, _ = self._layer_input(batch, l)
+            H = ops.join_blocks(hbuf, spans, parts) if len(parts) != 1 or parts[0].shape[0] != hbuf.shape[0] else parts[0]
+            hbuf = None
+            Z, _, _ = ops.gat_aggregate(batch, l, H, zeros, zeros, self.negative_slope, self.temperature)
+            h_next = {}
+            for t, name in enumerate(sc.node_types):
+                rows = int(m.lay_rows[l - 1][t])
+                if not rows:
+                    continue
+                lo, hi = rng[t]
+                R = hi - lo
+                z0 = int(m.z_base[l - 1][t])
+                x = Z[z0:z0 + rows * R].view(rows, R * C)
+                y = ops.linear_act(x, P.w_l_t[lo:hi].reshape(R * C, C), P.bias[lo:hi].sum(0), relu=False)
+                y = y + h[name][:rows] @ P.w_r_t[lo:hi].sum(0)            # root term: sum_r lin_r^r(h_d[i])
+                h_next[name] = torch.relu(y)
+            h = h_next
+        return h, []
+
     def _fused_layers(self, batch: SampledBatch, h: Dict[str, torch.Tensor], want_attention=False, hbuf=None,
                       last_premasked=False):
+        if self.backbone == 'SAGE':
+            if want_attention:
+                raise NotImplementedError('attention weights exist for the GAT backbone only (kgwas/model.py:65-72)')
+            return self._sage_layers(batch, h, hbuf)
         sc = self.schema
         m = batch.meta
         C = self.hidden
@@ -348,9 +430,10 @@ class HeteroGNN(nn.Module):
             raise NotImplementedError('the fused read-out + loss is for out_channels == 1 (kgwas/kgwas.py:52)')
         hbuf, blocks = self._layer_input(batch, 1)
         h = self._embed_all(batch, x_dict, blocks)
-        h, _ = self._fused_layers(batch, h, hbuf=hbuf, last_premasked=True)
+        gat = self.backbone == 'GAT'
+        h, _ = self._fused_layers(batch, h, hbuf=hbuf, last_premasked=gat)
         return ops.readout_weighted_mse(h['SNP'], self.lin.weight, self.lin.bias, n_id, y_all, w_all, batch_size,
-                                        relu=not self.no_relu, h_is_relu=True)
+                                        relu=not self.no_relu, h_is_relu=gat)
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -362,6 +445,8 @@ class HeteroGNN(nn.Module):
         those raw values (conv.py:227-228) plus bias, summed over relations, and -- unlike HeteroGNN.forward -- NO
         ReLU is applied between the layers (utils.py:460)."""
         from .sampler import BatchBuffers, DeviceGraph, finish_sample, sample_into
+        if self.backbone != 'GAT':
+            raise NotImplementedError('attention weights exist for the GAT backbone only (kgwas/utils.py:437-461)')
         dev = torch.device(device) if device is not None else self.lin.weight.device
         sc = self.schema
         dg = DeviceGraph.get(graph, self.num_layers, dev, full_graph=True).with_all_relations_live()
@@ -433,7 +518,7 @@ class HeteroGNN(nn.Module):
             for r, et in enumerate(self.edge_types):
                 which, i = self._slot[l][r]
                 pack = self.live_packs[l] if which == 'live' else self.dead_packs[l]
-                for f in REL_FIELDS:
+                for f in self.rel_fields:
                     yield f'convs.{l}.convs.{edge_key(et)}.{f}', pack.get(i, f, grad)
 
     def named_reference_tensors(self, grad: bool = False) -> "OrderedDict[str, Optional[torch.Tensor]]":
@@ -464,7 +549,7 @@ class HeteroGNN(nn.Module):
         want = {}
         for l in range(self.num_layers):
             for r, et in enumerate(self.edge_types):
-                for f in REL_FIELDS:
+                for f in self.rel_fields:
                     want[f'convs.{l}.convs.{edge_key(et)}.{f}'] = (l, r, f)
         rest = OrderedDict()
         seen = set()

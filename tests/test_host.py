@@ -113,10 +113,18 @@ def test_model_state_dict_uses_reference_keys(tiny_kg):
     with pytest.raises(RuntimeError):
         m2.load_state_dict({k: v for k, v in sd.items() if 'lin.bias' not in k})
     # unsupported reference options fail loudly instead of silently doing something else
-    for kw in (dict(gnn_backbone='SAGE'), dict(gnn_aggr='mean'), dict(gat_num_head=2)):
+    for kw in (dict(gnn_backbone='GCN'), dict(gnn_backbone='SGC'), dict(gnn_aggr='mean'), dict(gat_num_head=2)):
         args = dict(gnn_backbone='GAT', gnn_aggr='sum', gat_num_head=1); args.update(kw)
         with pytest.raises(NotImplementedError):
             HeteroGNN(tiny_kg.data, 128, 1, 2, args['gnn_backbone'], args['gnn_aggr'], 20, 40, 128, args['gat_num_head'])
+    # the SAGE backbone (kgwas/model.py:38) is built: its checkpoints carry PyG SAGEConv's keys
+    ms = HeteroGNN(tiny_kg.data, 128, 1, 2, 'SAGE', 'sum', 20, 40, 128, 1)
+    ks = list(ms.state_dict())
+    assert 'convs.0.convs.SNP__ABC__Gene.lin_l.weight' in ks and 'convs.0.convs.SNP__ABC__Gene.lin_l.bias' in ks and \
+        'convs.1.convs.SNP__ABC__Gene.lin_r.weight' in ks and not any('att_' in k for k in ks)
+    ms2 = HeteroGNN(tiny_kg.data, 128, 1, 2, 'SAGE', 'sum', 20, 40, 128, 1)
+    ms2.load_state_dict(ms.state_dict())
+    assert all(torch.equal(a, b) for a, b in zip(ms.state_dict().values(), ms2.state_dict().values()))
 
 
 def test_shard_batches_partitions_every_batch():
