@@ -193,8 +193,11 @@ class HeteroGNN(nn.Module):
                                       "run on the fused MI355X path; GCNConv / SGConv cannot take the bipartite "
                                       "relations HeteroConv hands them (kgwas/model.py:44-46)")
         self.backbone = gnn_backbone
-        if gnn_aggr != 'sum':
-            raise NotImplementedError("gnn_aggr: only 'sum' (the reference default) is fused")
+        if gnn_aggr not in ('sum', 'mean', 'min', 'max'):
+            raise NotImplementedError(f"gnn_aggr {gnn_aggr!r}: 'sum' (the reference default, fused), 'mean', 'min' and 'max' are "
+                                      "built; 'cat' widens the hidden state to R*128 and breaks the reference's own "
+                                      "read-out (kgwas/model.py:50), like gat_num_head > 1")
+        self.aggr = gnn_aggr
         if hidden_channels != 128:
             raise NotImplementedError('the fused kernels are specialised for gnn_hidden_dim=128')
         if gat_num_head != 1:
@@ -315,6 +318,13 @@ class HeteroGNN(nn.Module):
                 h[t] = self._embed(batch, x_dict, t, blocks.get(t))
         return h
 
+    def _combine_relations(self, o: torch.Tensor) -> torch.Tensor:
+        """HeteroConv(aggr) over the relation axis of per-relation outputs o [R, rows, C] (PyG hetero_conv.group:
+        stack + reduce; kgwas/model.py:47): used for 'min' / 'max', which cannot be folded into one GEMM."""
+        if o.shape[0] == 1:
+            return o[0]
+        return getattr(torch, self.aggr)(o, dim=0).values
+
     def _sage_layers(self, batch: SampledBatch, h: Dict[str, torch.Tensor], hbuf=None):
         """SAGE backbone (kgwas/model.py:38,74-75): out_d = relu(sum_r [lin_l^r(mean_{j->i} h_s[j]) + lin_r^r(h_d[i])]).
         The neighbour mean IS the attention aggregate with all logits equal: the same kernels run with zero attention
@@ -348,9 +358,17 @@ class HeteroGNN(nn.Module):
                 lo, hi = rng[t]
                 R = hi - lo
                 z0 = int(m.z_base[l - 1][t])
+                if self.aggr in ('min', 'max'):
+                    zr = Z[z0:z0 + rows * R].view(rows, R, C).transpose(0, 1)                    # [R, rows, C]
+                    o = torch.baddbmm(P.bias[lo:hi].unsqueeze(1), zr, P.w_l_t[lo:hi]) + \
+                        torch.matmul(h[name][:rows].unsqueeze(0), P.w_r_t[lo:hi])
+                    h_next[name] = torch.relu(self._combine_relations(o))
+                    continue
                 x = Z[z0:z0 + rows * R].view(rows, R * C)
                 y = ops.linear_act(x, P.w_l_t[lo:hi].reshape(R * C, C), P.bias[lo:hi].sum(0), relu=False)
                 y = y + h[name][:rows] @ P.w_r_t[lo:hi].sum(0)            # root term: sum_r lin_r^r(h_d[i])
+                if self.aggr == 'mean':
+                    y = y * (1.0 / R)
                 h_next[name] = torch.relu(y)
             h = h_next
         return h, []
@@ -388,14 +406,34 @@ class HeteroGNN(nn.Module):
             if hbuf is None:
                 hbuf, _ = self._layer_input(batch, l)
             H = ops.join_blocks(hbuf, spans, parts) if len(parts) != 1 or parts[0].shape[0] != hbuf.shape[0] else parts[0]
-            # (from layer 2 on, H is the previous layer's ReLU output: its backward is folded into this node's)
-            Z, stat, e_edge = ops.gat_aggregate(batch, l, H, U, V, self.negative_slope, self.temperature, relu_input=l > 1)
+            # (from layer 2 on, H is the previous layer's ReLU output: with the fused transform its backward is folded
+            # into this node's)
+            fused = self.aggr in ('sum', 'mean')
+            Z, stat, e_edge = ops.gat_aggregate(batch, l, H, U, V, self.negative_slope, self.temperature,
+                                                relu_input=(l > 1 and fused))
             if want_attention:
                 attn.append(ops.edge_alpha(batch, l, stat, e_edge, self.temperature))
+            if not fused:
+                # 'min' / 'max' over relations: per-relation outputs (lin_src + bias, conv.py:138-190) as one batched
+                # product per destination type, then the reduction over the relation axis and the ReLU (model.py:74-75)
+                hbuf = None
+                outs = []
+                for (lo, hi, z0, rows) in blocks:
+                    R = hi - lo
+                    zr = Z[z0:z0 + rows * R].view(rows, R, C).transpose(0, 1)
+                    o = torch.baddbmm(P.bias[lo:hi].unsqueeze(1), zr, P.w_src_t[lo:hi])
+                    outs.append(torch.relu(self._combine_relations(o)))
+                h = {sc.node_types[t]: o for t, o in zip(tys, outs)}
+                continue
             # per-relation linear maps + bias + relation sum + ReLU: one GEMM per destination type, one autograd node
             hbuf, nxt = self._layer_input(batch, l + 1) if l < self.num_layers else (None, {})
             outs = ops.layer_transform(P, Z, blocks, [nxt.get(sc.node_types[t]) for t in tys],
                                        premasked=(l < self.num_layers) or last_premasked, bias_sum=bsum)
+            if self.aggr == 'mean':
+                # mean over the relations of a destination type = the sum scaled by 1/R; relu(s/R) = relu(s)/R, and the
+                # positive scale commutes with the folded ReLU masks
+                hbuf = None
+                outs = [o * (1.0 / (hi - lo)) for o, (lo, hi, _, _) in zip(outs, blocks)]
             h_next = {sc.node_types[t]: o for t, o in zip(tys, outs)}
             h = h_next
         return h, attn
@@ -430,7 +468,7 @@ class HeteroGNN(nn.Module):
             raise NotImplementedError('the fused read-out + loss is for out_channels == 1 (kgwas/kgwas.py:52)')
         hbuf, blocks = self._layer_input(batch, 1)
         h = self._embed_all(batch, x_dict, blocks)
-        gat = self.backbone == 'GAT'
+        gat = self.backbone == 'GAT' and self.aggr in ('sum', 'mean')
         h, _ = self._fused_layers(batch, h, hbuf=hbuf, last_premasked=gat)
         return ops.readout_weighted_mse(h['SNP'], self.lin.weight, self.lin.bias, n_id, y_all, w_all, batch_size,
                                         relu=not self.no_relu, h_is_relu=gat)
@@ -447,6 +485,8 @@ class HeteroGNN(nn.Module):
         from .sampler import BatchBuffers, DeviceGraph, finish_sample, sample_into
         if self.backbone != 'GAT':
             raise NotImplementedError('attention weights exist for the GAT backbone only (kgwas/utils.py:437-461)')
+        if self.aggr != 'sum':
+            raise NotImplementedError("the attention export is built for gnn_aggr='sum' (the reference default)")
         dev = torch.device(device) if device is not None else self.lin.weight.device
         sc = self.schema
         dg = DeviceGraph.get(graph, self.num_layers, dev, full_graph=True).with_all_relations_live()

@@ -19,10 +19,10 @@ pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-4, 1e-5
 
 
-def _model(data, dims, seed=0, L=2, backbone='GAT', **kw):
+def _model(data, dims, seed=0, L=2, backbone='GAT', aggr='sum', **kw):
     from kgwas_amd.model import HeteroGNN
     torch.manual_seed(seed)
-    m = HeteroGNN(data, 128, 1, L, backbone, 'sum', dims[0], dims[1], dims[2], 1, **kw).cuda()
+    m = HeteroGNN(data, 128, 1, L, backbone, aggr, dims[0], dims[1], dims[2], 1, **kw).cuda()
     # biases start at zero in the reference (conv.py:120); randomise so their path is exercised
     with torch.no_grad():
         for pack in list(m.live_packs) + list(m.dead_packs):
@@ -412,3 +412,44 @@ def test_sage_backbone_matches_reference_restatement(small_kg, edge_case_graph, 
     l2, pred = model.forward_loss(batch.x_dict, batch.edge_index_dict, 40, batch.n_id('SNP'), batch.dg.y['SNP'], w_all)
     l2.backward()
     assert_close(pred, out.reshape(-1).detach(), 1e-6, 1e-7, 'forward_loss pred')
+
+
+@pytest.mark.parametrize('backbone,aggr', [('GAT', 'mean'), ('GAT', 'max'), ('GAT', 'min'), ('SAGE', 'mean'), ('SAGE', 'max')])
+def test_relation_aggregation_modes_match_reference_restatement(edge_case_graph, backbone, aggr):
+    """gnn_aggr in {mean, min, max} (HeteroConv(aggr), kgwas/model.py:47; README options): 'mean' rides the fused sum
+    path (scaled by 1/R), 'min' / 'max' reduce per-relation outputs; prediction, loss and every gradient vs the oracle,
+    through forward() and through the fused training forward."""
+    data, d = edge_case_graph
+    dims = (d['SNP'], d['Gene'], 16)
+    model = _model(data, dims, L=2, backbone=backbone, aggr=aggr)
+    ids = np.random.default_rng(3).choice(data['SNP'].x.shape[0], size=48, replace=False)
+    batch = next(iter(_loader(data, ids, 48)))
+    y_all = batch.dg.y['SNP']
+    w_all = (torch.rand(data['SNP'].x.shape[0], generator=torch.Generator().manual_seed(1), dtype=torch.float64) + 0.5).cuda()
+    n_id = batch.n_id('SNP')[:48].long()
+    oracle = oracle_from_product(model)
+    x, ei = batch_cpu(batch)
+    out_o = oracle(x, ei, 48)
+    loss_o = torch.mean(w_all[n_id].cpu() * (out_o.reshape(-1) - y_all[n_id].cpu().double()) ** 2)
+    loss_o.backward()
+    go = grads_by_name(oracle)
+    for fused in (False, True):
+        model.zero_grad(set_to_none=True)
+        if fused:
+            loss, pred = model.forward_loss(batch.x_dict, batch.edge_index_dict, 48, batch.n_id('SNP'), y_all, w_all)
+        else:
+            out = model(batch.x_dict, batch.edge_index_dict, 48)
+            pred = out.reshape(-1)
+            loss = torch.mean(w_all[n_id] * (pred - y_all[n_id]) ** 2)
+        loss.backward()
+        assert_close(pred, out_o.reshape(-1).detach(), RTOL, ATOL, f'pred fused={fused}')
+        assert_close(loss.detach(), loss_o.detach(), RTOL, ATOL, 'loss')
+        n = 0
+        for name, g in grads_by_name(model).items():
+            ref = go[name]
+            if g is None:
+                assert ref is None or float(ref.abs().max()) == 0.0, name
+                continue
+            n += 1
+            assert_close(g, ref, RTOL, max(ATOL, 1e-4 * float(ref.abs().max())), f'grad {name} fused={fused}')
+        assert n > 10

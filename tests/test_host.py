@@ -113,7 +113,7 @@ def test_model_state_dict_uses_reference_keys(tiny_kg):
     with pytest.raises(RuntimeError):
         m2.load_state_dict({k: v for k, v in sd.items() if 'lin.bias' not in k})
     # unsupported reference options fail loudly instead of silently doing something else
-    for kw in (dict(gnn_backbone='GCN'), dict(gnn_backbone='SGC'), dict(gnn_aggr='mean'), dict(gat_num_head=2)):
+    for kw in (dict(gnn_backbone='GCN'), dict(gnn_backbone='SGC'), dict(gnn_aggr='cat'), dict(gat_num_head=2)):
         args = dict(gnn_backbone='GAT', gnn_aggr='sum', gat_num_head=1); args.update(kw)
         with pytest.raises(NotImplementedError):
             HeteroGNN(tiny_kg.data, 128, 1, 2, args['gnn_backbone'], args['gnn_aggr'], 20, 40, 128, args['gat_num_head'])
