@@ -97,6 +97,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--scale', type=float, default=1.0, help='SynthKG scale (1.0 = reference size)')
     ap.add_argument('--batch-size', type=int, default=512)
+    ap.add_argument('--mode', default='fast', choices=['fast', 'full'],
+                    help="feature widths: 'fast' 20/5120/128 (BASELINE.json configs[1], the default) or 'full' 70/57742/128 (configs[4])")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--eager', action='store_true', help='issue every launch from the host instead of replaying one HIP graph per step')
@@ -129,7 +131,7 @@ def main():
     t0 = time.time()
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):        # stdout carries exactly one JSON line
-        data = KGWAS_Data.from_synthetic(scale=args.scale, seed=1, mode='fast', gwas_kind='causal',
+        data = KGWAS_Data.from_synthetic(scale=args.scale, seed=1, mode=args.mode, gwas_kind='causal',
                                          data_path=f'/tmp/kgwas_bench_{rank}')
     run = KGWAS(data, device=dev, seed=1)
     run.initialize_model()
@@ -255,9 +257,11 @@ def main():
         'value': edges_kernel / elapsed, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'SynthKG-fast full KG (784256 SNP / 20032 Gene / ~20.6M directed edges; features '
-                               '20/5120/128) + causal-simulation GWAS seed=1, batch 512 seeds per GPU, 2-layer GAT-128, '
-                               'Adam(1e-4, wd 5e-4) -- BASELINE.json configs[1]',
+        'config': {'workload': ('SynthKG-fast full KG (784256 SNP / 20032 Gene / ~20.6M directed edges; features '
+                                '20/5120/128) + causal-simulation GWAS seed=1, batch 512 seeds per GPU, 2-layer GAT-128, '
+                                'Adam(1e-4, wd 5e-4) -- BASELINE.json configs[1]') if args.mode == 'fast' else
+                               ('SynthKG-full: same graph, full-mode feature widths 70/57742/128 -- BASELINE.json configs[4] '
+                                'on one GPU, not the headline configuration'),
                    'scale': args.scale, 'batch_size_per_gpu': bs, 'parallelism': f'seed-dp{world}', 'execution': mode,
                    'edges_per_step_kernel': edges_kernel / args.steps / world,
                    'edges_per_step_reference_equivalent': edges_ref / args.steps / world,
