@@ -242,6 +242,10 @@ def main():
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                 'bytes_per_launch': algorithmic_bytes_fwd(d['edges'], d['z_rows']) / d['n'],
                 'avg_launch_ms': d['ms'] / d['n'], 'traffic': None}
+        # rocprofv3 --stats averages ALL launches of the kernel name (layer 1: ~1 M edges, layer 2: ~2 k edges) together:
+        # the figure to compare with profiles/*kernel_stats*.csv
+        allf = [v for (tag, _), v in summ.items() if tag == 'fwd']
+        roof['avg_ms_all_launches_of_this_kernel_name'] = sum(v['ms'] for v in allf) / max(1, sum(v['n'] for v in allf))
         pmc = os.path.join(ROOT, 'profiles', 'pmc_agg_fwd.json')
         if os.path.exists(pmc):
             try:

@@ -501,21 +501,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lk = lane >> 5;
     const int nch = (a.K + KC - 1) / KC;   // 1 or 2 chunks (K <= 128)
-    // stage W once (zero outside [N, K])
-    for (int idx = tid; idx < 128 * 32; idx += 512) {
-        if (!WKN) {
-            const int n = idx >> 5, k4 = (idx & 31) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < a.N && k4 < a.K) v = *(const float4*)(a.W + (int64_t)n * a.ldw + k4);
-            *(float4*)(Wl + n * WST + k4) = v;
-        } else {
-            const int k = idx >> 5, n4 = (idx & 31) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < a.K && n4 < a.N) v = *(const float4*)(a.W + (int64_t)k * a.ldw + n4);
-            Wl[(n4 + 0) * WST + k] = v.x; Wl[(n4 + 1) * WST + k] = v.y;
-            Wl[(n4 + 2) * WST + k] = v.z; Wl[(n4 + 3) * WST + k] = v.w;
-        }
-    }
+    // the first X chunk is requested before the weights are staged: both latencies overlap
     const int64_t ntiles = (a.rows + RT - 1) / RT;
     constexpr int F4 = RT * KC / 4 / 512;              // float4 per thread per chunk
     f32x4 xr[F4];
@@ -531,6 +517,21 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     int64_t tile = blockIdx.x;
     if (tile < ntiles) { KGW_FETCH(tile, 0) }
+    // stage W once (zero outside [N, K])
+    for (int idx = tid; idx < 128 * 32; idx += 512) {
+        if (!WKN) {
+            const int n = idx >> 5, k4 = (idx & 31) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < a.N && k4 < a.K) v = *(const float4*)(a.W + (int64_t)n * a.ldw + k4);
+            *(float4*)(Wl + n * WST + k4) = v;
+        } else {
+            const int k = idx >> 5, n4 = (idx & 31) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < a.K && n4 < a.N) v = *(const float4*)(a.W + (int64_t)k * a.ldw + n4);
+            Wl[(n4 + 0) * WST + k] = v.x; Wl[(n4 + 1) * WST + k] = v.y;
+            Wl[(n4 + 2) * WST + k] = v.z; Wl[(n4 + 3) * WST + k] = v.w;
+        }
+    }
     const int rg = wave % WRG, cg = wave / WRG;
     const float* wb = Wl + (cg * CT * 32 + li) * WST + lk * (KC / 2);
     float* slice = Xs + rg * 32 * XST;                 // this wavefront's 32 rows (private when WCG == 1)
