@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import torch
 
@@ -33,21 +34,28 @@ class _TunedLibraryGemm:
     def __enter__(self):
         if not self.on:
             return self
-        import torch.cuda.tunable as tn
-        if not self._ready:
-            # results are kept per device under the temp dir: the next process starts from the same choice
-            tn.set_filename(os.path.join(os.environ.get('KGW_CACHE_DIR', '/tmp'), 'kgwas_amd_tunableop.csv'), True)
-            tn.set_max_tuning_duration(200)          # ms per candidate solution
-            tn.set_max_tuning_iterations(20)
-            self._ready = True
-        tn.enable(True)
-        tn.tuning_enable(True)
+        try:
+            import torch.cuda.tunable as tn
+            if not self._ready:
+                # results are kept per device under the temp dir: the next process starts from the same choice
+                tn.set_filename(os.path.join(os.environ.get('KGW_CACHE_DIR', '/tmp'), 'kgwas_amd_tunableop.csv'), True)
+                tn.set_max_tuning_duration(200)          # ms per candidate solution
+                tn.set_max_tuning_iterations(20)
+                self._ready = True
+            tn.enable(True)
+            tn.tuning_enable(True)
+        except Exception as e:                           # tuning is an optimisation: never let it take the step down
+            print(f'kgwas_amd: TunableOp unavailable ({e}); using the default library GEMM', file=sys.stderr)
+            self.on = False
         return self
 
     def __exit__(self, *exc):
         if self.on:
-            import torch.cuda.tunable as tn
-            tn.enable(False)
+            try:
+                import torch.cuda.tunable as tn
+                tn.enable(False)
+            except Exception:
+                self.on = False
         return False
 
 
