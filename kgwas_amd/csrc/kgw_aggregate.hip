@@ -391,15 +391,28 @@ __device__ __forceinline__ void bwd_src_one_row(const LayerTab& T, const AggPtrs
                 const float2 a2 = ((const float2*)P.adp)[te];
                 al = a2.x; dp = a2.y;
             }
-            // per-slot sums of d pre-activation (entries of one source are grouped by slot); only slots that have
-            // entries are visited (most sources use 1-3 of their slots)
+            // per-slot sums of d pre-activation (entries of one source are grouped by slot): ONE segmented inclusive scan
+            // over the 64 lanes (six shuffle steps, fixed tree) instead of a full-wave reduction per slot; the segment
+            // heads come from the row pointers with scalar work only, and each slot's total is read at its last lane
+            unsigned long long heads = 1ull;
             for (unsigned long long left = slots; left; left &= left - 1) {
                 const int k = __builtin_ctzll(left);
-                const int s0 = __shfl(tpv, k, 64), s1 = __shfl(tpv, k + 1, 64);
+                const int s0 = __builtin_amdgcn_readlane(tpv, k);
+                if (s0 > pb && s0 < pb + nb) heads |= 1ull << (s0 - pb);
+            }
+            float sv = (lane < nb) ? dp : 0.f;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const float o = __shfl_up(sv, d, 64);
+                const bool open = lane >= d && ((heads >> (lane - d + 1)) & ((1ull << d) - 1ull)) == 0ull;
+                sv += open ? o : 0.f;
+            }
+            for (unsigned long long left = slots; left; left &= left - 1) {
+                const int k = __builtin_ctzll(left);
+                const int s0 = __builtin_amdgcn_readlane(tpv, k), s1 = __builtin_amdgcn_readlane(tpv, k + 1);
                 if (s1 <= pb || s0 >= pb + nb) continue;
-                const int pos = pb + lane;
-                const float v = (lane < nb && pos >= s0 && pos < s1) ? dp : 0.f;
-                const float sk = kgw_wave_allsum(v);
+                const int last = min(s1, pb + nb) - 1 - pb;
+                const float sk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sv), last));
                 dasv += (lane == k) ? sk : 0.f;
             }
             for (int q0 = 0; q0 < hn;) {
