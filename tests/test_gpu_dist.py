@@ -1,0 +1,96 @@
+"""-m gpu, world_size 2 (both ranks on cuda:0, gloo collectives): the multi-rank step of the product path --
+GraphTrainStep with the gradient bucket filled inside the captured graph, one all-reduce over the bucket, FusedAdam on
+the bucket's views (kgwas_amd/graph_step.py, dist.py) -- against a single-process computation of the same two steps
+(gradients of the two ranks' batches averaged by hand, same optimiser)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+BS, STEPS = 32, 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_run(seed=11):
+    from kgwas_amd.kgwas import KGWAS
+    from kgwas_amd.kgwas_data import KGWAS_Data
+    data = KGWAS_Data.from_synthetic(scale=0.01, seed=1, feat_dims={'Gene': 96}, data_path=f'/tmp/kgwas_gpudist_{os.getpid()}')
+    run = KGWAS(data, device='cuda:0', seed=seed)
+    run.initialize_model()
+    return data, run
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from kgwas_amd import dist as kdist
+        from kgwas_amd.graph_step import GraphTrainStep
+        torch.cuda.set_device(0)
+        data, run = _make_run()
+        kdist.broadcast_params(run.model)
+        ids = np.asarray(data.train_input_nodes[1])[:BS * world * (STEPS + 1)]
+        mine = ids.reshape(-1, world, BS)[:, rank].reshape(-1)          # this rank's batch of every step
+        gs = GraphTrainStep(run, ('SNP', mine), BS, lr=1e-3, weight_decay=5e-4)
+        assert gs.world == world and not gs.capture_optimizer
+        for i in range(STEPS):
+            gs.step(i)
+        gs.check()
+        torch.save({k: v.detach().cpu() for k, v in run.model.named_reference_tensors().items()},
+                   os.path.join(out_dir, f'rank{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_graph_step_equals_hand_averaged_single_process(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method='spawn')
+    r0 = torch.load(os.path.join(tmp_path, 'rank0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'rank1.pt'))
+    assert r0.keys() == r1.keys()
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), f'{k}: ranks diverged'       # same all-reduced gradients, same Adam step
+
+    # single process: the same steps with the two ranks' gradients averaged by hand
+    from kgwas_amd.optim import FusedAdam
+    from kgwas_amd.sampler import NeighborLoader
+    data, run = _make_run()
+    ld_w = run._ld_weight_vector()
+    ids = np.asarray(data.train_input_nodes[1])[:BS * world * (STEPS + 1)].reshape(-1, world, BS)
+    opt = FusedAdam(run.model.parameters(), lr=1e-3, weight_decay=5e-4)
+    params = [p for p in run.model.parameters()]
+    for i in range(STEPS):
+        acc = None
+        for r in range(world):
+            batch = next(iter(NeighborLoader(data.data, [-1, -1], ('SNP', ids[i, r]), batch_size=BS, device='cuda:0')))
+            run.model.zero_grad(set_to_none=True)
+            loss, _ = run.model.forward_loss(batch.x_dict, batch.edge_index_dict, BS, batch.n_id('SNP'), batch.dg.y['SNP'], ld_w)
+            loss.backward()
+            g = [None if p.grad is None else p.grad.clone() for p in params]
+            acc = g if acc is None else [a if b is None else (b if a is None else a + b) for a, b in zip(acc, g)]
+        for p, a in zip(params, acc):
+            p.grad = None if a is None else a / world
+        opt.step()
+    ref = {k: v.detach().cpu() for k, v in run.model.named_reference_tensors().items()}
+    changed = 0
+    for k in ref:
+        d = (r0[k].double() - ref[k].double()).abs().max()
+        scale = ref[k].double().abs().max().clamp(min=1e-6)
+        assert float(d) <= 2e-5 * float(scale) + 2e-6, (k, float(d))
+        changed += 1
+    assert changed > 20
