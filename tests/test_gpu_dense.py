@@ -182,3 +182,45 @@ def test_rows_dev_skips_padding_rows(rows, real):
     Cm, cs = ops.tn_gemm(X, B, colsum=True, rows_dev=cnt)
     assert_close(Cm, X[:real].double().t() @ B[:real].double(), 1e-5, 1e-5, 'tn rows_dev', rel_to_max=2e-6)
     assert_close(cs, X[:real].double().sum(0), 1e-5, 1e-5, 'colsum rows_dev', rel_to_max=2e-6)
+
+
+@pytest.mark.parametrize('n,rows,relu,h_is_relu', [(5, 9, True, False), (512, 512, True, True), (33, 40, False, True), (1, 1, True, False)])
+def test_readout_weighted_mse_matches_autograd(n, rows, relu, h_is_relu):
+    """kgw_readout_wmse_fwd / _bwd (read-out Linear(128->1) [+ReLU] + weighted MSE, kgwas/model.py:86 +
+    kgwas/kgwas.py:139-145) vs the same expression in fp64 autograd; ragged sizes; optional folded ReLU mask on dH."""
+    from kgwas_amd import ops
+    g = torch.Generator().manual_seed(n * 7 + rows)
+    N = 300 + rows
+    H = torch.randn(rows, 128, generator=g)
+    if h_is_relu:
+        H = torch.relu(H)
+    wl = torch.randn(1, 128, generator=g) * 0.2; bl = torch.randn(1, generator=g)
+    y_all = torch.rand(N, generator=g); w_all = torch.rand(N, generator=g, dtype=torch.float64) + 0.1
+    n_id = torch.randperm(N, generator=g)[:rows].to(torch.int32)
+    Hd, wd, bd = (t.cuda().requires_grad_(True) for t in (H, wl, bl))
+    loss, pred = ops.readout_weighted_mse(Hd, wd, bd, n_id.cuda(), y_all.cuda(), w_all.cuda(), n, relu=relu, h_is_relu=h_is_relu)
+    (loss * 0.7).backward()
+    Ho, wo, bo = (t.double().requires_grad_(True) for t in (H, wl, bl))
+    p = (Ho[:n] @ wo.t() + bo).reshape(-1)
+    if relu:
+        p = torch.relu(p)
+    ids = n_id[:n].long()
+    lo = torch.mean(w_all[ids] * (p - y_all[ids].double()) ** 2)
+    (lo * 0.7).backward()
+    assert_close(pred, p.detach(), 1e-5, 1e-6, 'pred')
+    assert abs(float(loss) - float(lo)) <= 1e-9 + 2e-6 * abs(float(lo))
+    ref_dH = Ho.grad * (H.double() > 0) if h_is_relu else Ho.grad          # the folded mask of the producing ReLU
+    assert_close(Hd.grad, ref_dH, 1e-4, 1e-7, 'dH', rel_to_max=1e-5)
+    assert float(Hd.grad[n:].abs().sum()) == 0.0
+    assert_close(wd.grad, wo.grad, 1e-4, 1e-7, 'd lin.weight', rel_to_max=1e-5)
+    assert_close(bd.grad, bo.grad, 1e-4, 1e-7, 'd lin.bias', rel_to_max=1e-5)
+
+
+@pytest.mark.parametrize('rows,M,N', [(1, 128, 128), (63, 128, 20), (3, 6, 128), (257, 64, 128), (1000, 128, 2176)])
+def test_tn_gemm_small_and_ragged_row_counts(rows, M, N):
+    from kgwas_amd import ops
+    g = torch.Generator().manual_seed(rows + M + N)
+    A = torch.randn(rows, M, generator=g).cuda(); B = torch.randn(rows, N, generator=g).cuda()
+    C_, cs = ops.tn_gemm(A, B, colsum=True)
+    assert_close(C_, A.double().t() @ B.double(), 1e-5, 1e-6, 'C', rel_to_max=2e-6)
+    assert_close(cs, A.double().sum(0), 1e-5, 1e-6, 'colsum', rel_to_max=2e-6)
