@@ -143,6 +143,45 @@ __device__ __forceinline__ void fwd_group(const float4* __restrict__ Hb4, int co
     }
 }
 
+// Eight edges per half with the transposed reduction (kgw_half_reduce8): the lane with (hl & 7) == p owns edge q0 + p --
+// its logit, its softmax weight -- and hands the weight to the other lanes of its 8-lane group with one swizzle.
+template <bool RAW>
+__device__ __forceinline__ void fwd_group8(const float4* __restrict__ Hb4, int colv, int q0, int hn, int nb,
+                                           int half, int hl, const float4& u4, float ad, float slope,
+                                           float inv_temp, float& m, float& s, float4& acc, float& ev) {
+    float4 x[8];
+    float part[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int q = q0 + p, i = half * hn + q;
+        const bool ok = (q < hn) && (i < nb);
+        const int cj = __shfl(colv, ok ? i : 0, 64);
+        x[p] = Hb4[(int64_t)cj * 32 + hl];
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) part[p] = dot4(x[p], u4);
+    const int pm = hl & 7, qm = q0 + pm;
+    const bool valid = (qm < hn) && (half * hn + qm < nb);
+    float d = kgw_half_reduce8(part, hl) + ad;                 // logit of edge q0 + (hl & 7)
+    d = d > 0.f ? d : d * slope;
+    ev = ((hl >> 3) == (q0 >> 3) && hl == qm) ? d : ev;        // lane (half, q) keeps the logit of edge half*hn + q
+    float w;
+    if (RAW) {
+        w = valid ? d : 0.f;
+    } else {
+        const float t = valid ? d * inv_temp : -INFINITY;
+        const float mn = fmaxf(m, kgw_max8(t));
+        const float sc = __expf(m - mn);
+        s *= sc; scale4(acc, sc); m = mn;
+        w = __expf(t - mn);                                     // 0 for invalid edges (t = -inf, mn finite: m starts at NEG_BIG)
+        s += kgw_sum8(w);
+    }
+    fma4(acc, kgw_bcast8<0>(w), x[0]); fma4(acc, kgw_bcast8<1>(w), x[1]);
+    fma4(acc, kgw_bcast8<2>(w), x[2]); fma4(acc, kgw_bcast8<3>(w), x[3]);
+    fma4(acc, kgw_bcast8<4>(w), x[4]); fma4(acc, kgw_bcast8<5>(w), x[5]);
+    fma4(acc, kgw_bcast8<6>(w), x[6]); fma4(acc, kgw_bcast8<7>(w), x[7]);
+}
+
 template <bool RAW>
 __global__ void __launch_bounds__(KGW_BLK) k_agg_fwd(LayerTab T, AggPtrs P, float slope, float inv_temp) {
     const int lane = kgw_lane(), half = lane >> 5, hl = lane & 31;
@@ -173,7 +212,7 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_fwd(LayerTab T, AggPtrs P, floa
             float ev = 0.f;
             for (int q0 = 0; q0 < hn;) {
                 const int rem = hn - q0;
-                if (rem > 4)      { fwd_group<8, RAW>(Hb4, colv, q0, hn, nb, half, hl, u4, ad, slope, inv_temp, m, s, acc, ev); q0 += 8; }
+                if (rem > 4)      { fwd_group8<RAW>(Hb4, colv, q0, hn, nb, half, hl, u4, ad, slope, inv_temp, m, s, acc, ev); q0 += 8; }
                 else if (rem > 2) { fwd_group<4, RAW>(Hb4, colv, q0, hn, nb, half, hl, u4, ad, slope, inv_temp, m, s, acc, ev); q0 += 4; }
                 else              { fwd_group<2, RAW>(Hb4, colv, q0, hn, nb, half, hl, u4, ad, slope, inv_temp, m, s, acc, ev); q0 += 2; }
             }
