@@ -315,6 +315,37 @@ __device__ __forceinline__ void bwd_group(const float4* __restrict__ Hb4, int co
     }
 }
 
+// Eight edges per half, transposed reduction (see fwd_group8): the lane with (hl & 7) == p owns edge q0 + p.  `dsum`
+// here collects only the lane's OWN edges; the caller folds the 8 residues once per chunk (kgw_sum8).
+__device__ __forceinline__ void bwd_group8(const float4* __restrict__ Hb4, int colv, float evin, int q0, int hn,
+                                           int nb, int half, int hl, const float4& dz4, float cdot, float M,
+                                           float inv_den, float slope, float inv_temp, float& av, float& dv,
+                                           float& dsum_own) {
+    float4 x[8];
+    float part[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int q = q0 + p, i = half * hn + q;
+        const bool ok = (q < hn) && (i < nb);
+        const int cj = __shfl(colv, ok ? i : 0, 64);
+        x[p] = Hb4[(int64_t)cj * 32 + hl];
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) part[p] = dot4(x[p], dz4);
+    const int pm = hl & 7, qm = q0 + pm;
+    const bool valid = (qm < hn) && (half * hn + qm < nb);
+    const float e = __shfl(evin, half * 32 + (qm & 31), 64);     // logit kept by lane (half, q)
+    const float t = valid ? e : -INFINITY;
+    const float dalpha = kgw_half_reduce8(part, hl);
+    const float alpha = __expf(t * inv_temp - M) * inv_den;
+    const float dlogit = alpha * (dalpha - cdot);
+    const float dpre = dlogit * inv_temp * (t > 0.f ? 1.0f : slope);
+    const bool mine = (hl == qm);
+    av = mine ? alpha : av;
+    dv = mine ? dpre : dv;
+    dsum_own += (hl < 8) ? dpre : 0.f;          // one copy per edge: the 8 residues of the first 8-lane group
+}
+
 __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_dst(LayerTab T, AggPtrs P, float slope, float inv_temp) {
     const int lane = kgw_lane(), half = lane >> 5, hl = lane & 31;
     const int nw = gridDim.x * 4;
@@ -330,7 +361,7 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_dst(LayerTab T, AggPtrs P, 
         const float M = P.stat[2 * (int64_t)zrow];
         const float inv_den = 1.0f / P.stat[2 * (int64_t)zrow + 1];
         const float4* Hb4 = (const float4*)(P.H + (int64_t)T.src_base[r] * KGW_C);
-        float dsum = 0.f;
+        float dsum = 0.f, dsum_own = 0.f;
         const int n = ck.e1 - ck.e0;
         for (int b = 0; b < n; b += 64) {
             const int nb = min(64, n - b);
@@ -342,12 +373,13 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_dst(LayerTab T, AggPtrs P, 
             float av = 0.f, dv = 0.f;
             for (int q0 = 0; q0 < hn;) {
                 const int rem = hn - q0;
-                if (rem > 4)      { bwd_group<8>(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum); q0 += 8; }
+                if (rem > 4)      { bwd_group8(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own); q0 += 8; }
                 else if (rem > 2) { bwd_group<4>(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum); q0 += 4; }
                 else              { bwd_group<2>(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum); q0 += 2; }
             }
             if (mine) ((float2*)P.adp)[ck.e0 + b + i] = make_float2(av, dv);
         }
+        dsum += kgw_sum8(dsum_own);                            // lanes 0..7 of each half: the edges handled 8 at a time
         const float tot = dsum + kgw_xhalf(dsum);
         if (lane == 0) {
             if (ck.nch == 1) P.da_dst[zrow] = tot; else P.part_da[c] = tot;
