@@ -285,6 +285,9 @@ int kgw_readout_wmse_bwd(const float* H, const float* w_lin, const float* pred, 
  * out_steps[4][64] = the four intra-row DPP butterfly stages.                                  */
 int kgw_debug_reduce(const float* in, float* out_half, float* out_wave, float* out_steps,
                      kgw_stream_t stream);
+/* Self-test of the transposed 8-way reduction primitives (kgw_common.h): in [64][8]; out [6][64] = half_reduce8,
+ * max8, sum8, bcast8<3>, xor4, xor8 of (in[lane][*] resp. in[lane][0]).                                          */
+int kgw_debug_reduce8(const float* in, float* out, kgw_stream_t stream);
 
 #ifdef __cplusplus
 }

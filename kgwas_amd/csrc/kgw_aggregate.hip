@@ -857,6 +857,27 @@ __global__ void k_debug_reduce(const float* in, float* out_half, float* out_wave
 }
 }  // namespace
 
+namespace {
+__global__ void k_debug_reduce8(const float* in, float* out) {
+    const int lane = threadIdx.x, hl = lane & 31;
+    float v[8];
+    for (int p = 0; p < 8; ++p) v[p] = in[lane * 8 + p];
+    out[lane] = kgw_half_reduce8(v, hl);              // lane with (hl & 7) == p: sum over its half of v[p]
+    out[64 + lane] = kgw_max8(in[lane * 8]);          // over the lanes of the 8-lane group
+    out[128 + lane] = kgw_sum8(in[lane * 8]);
+    out[192 + lane] = kgw_bcast8<3>(in[lane * 8]);    // value of lane (lane & ~7) | 3
+    out[256 + lane] = kgw_xor4(in[lane * 8]);
+    out[320 + lane] = kgw_xor8(in[lane * 8]);
+}
+}  // namespace
+
+extern "C" int kgw_debug_reduce8(const float* in, float* out, kgw_stream_t stream_) {
+    if (!in || !out) return KGW_E_NULL;
+    k_debug_reduce8<<<1, 64, 0, (hipStream_t)stream_>>>(in, out);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
 extern "C" int kgw_debug_reduce(const float* in, float* out_half, float* out_wave, float* out_steps,
                                 kgw_stream_t stream_) {
     if (!in || !out_half || !out_wave || !out_steps) return KGW_E_NULL;
