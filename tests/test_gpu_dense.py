@@ -87,7 +87,11 @@ def test_mlp_nodes_match_autograd():
                                          (4097, 128, 20, True), (3000, 128, 260, False),
                                          # mid-size inputs: the 64-row-tile weight-resident variant
                                          (20033, 128, 128, False), (13001, 128, 128, True), (9000, 20, 128, False),
-                                         (5000, 96, 64, False), (40001, 96, 100, True)])
+                                         (5000, 96, 64, False), (40001, 96, 100, True),
+                                         # tall 128 x 128: the weights-in-registers variant (both weight layouts,
+                                         # whole tiles only / a ragged last tile / fewer tiles than wavefronts)
+                                         (120003, 128, 128, True), (32768, 128, 128, False), (40001, 128, 128, True),
+                                         (262144 + 17, 128, 128, False)])
 def test_linear_kernel_matches_fp64(rows, K, N, kn):
     from kgwas_amd import ops
     g = torch.Generator().manual_seed(rows + K)
