@@ -198,6 +198,19 @@ int kgw_accumulate_stats(const KgwBatchMeta* meta_dev, int32_t n_layers, int32_t
 /* Replaces: the index_select feature slicing of the loader (x[n_id], kgwas/kgwas.py:135).      */
 int kgw_gather_rows(const float* src, const int32_t* ids, int64_t n_rows, int32_t width,
                     float* dst, kgw_stream_t stream);
+/* The same for up to 8 (src, ids, dst) jobs of one row width in a single launch (the three GO node
+ * types' features go through one shared MLP as one matrix, kgwas/model.py:58-60).               */
+int kgw_gather_rows_multi(int32_t n_jobs, const float* const* src, const int32_t* const* ids,
+                          const int64_t* n_rows, int32_t width, float* const* dst, kgw_stream_t stream);
+
+/* Backward of "rows n_id of relu(X W^T + b) computed on the RESIDENT feature matrix" (the wide gene layer,
+ * kgwas/model.py:17-19 applied before the x[n_id] slicing of kgwas/kgwas.py:135): for every row of the resident
+ * matrix dz[row] = g[g2l[row]] * (h[row] > 0) (zero where g2l[row] < 0: node not in the batch) and
+ * colsum[c] = sum_row dz[row][c] (the bias gradient).  g [n_batch][128], h / dz [n_rows][128], g2l [n_rows];
+ * workspace: kgw_scatter_relu_rows_workspace_floats(n_rows) floats.  Two launches, deterministic.        */
+int64_t kgw_scatter_relu_rows_workspace_floats(int64_t n_rows);
+int kgw_scatter_relu_rows(const float* g, const int32_t* g2l, const float* h, int64_t n_rows, float* dz,
+                          float* colsum, float* workspace, kgw_stream_t stream);
 
 /* alpha_e = exp(e - max)/den per local edge of one layer (attention export,
  * kgwas/conv.py:192-196; kgwas/utils.py:446-461).                                             */

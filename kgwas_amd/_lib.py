@@ -99,7 +99,7 @@ class KgwLayerArgs(C.Structure):
 
 EXPORTS = ['kgw_version', 'kgw_status_string', 'kgw_struct_sizes', 'kgw_sample_batch',
            'kgw_gat_aggregate_fwd', 'kgw_gat_aggregate_bwd_dst', 'kgw_gat_aggregate_bwd_src',
-           'kgw_gather_rows', 'kgw_edge_alpha', 'kgw_debug_reduce', 'kgw_debug_reduce8', 'kgw_tn_gemm', 'kgw_tn_gemm_ex', 'kgw_tn_gemm_workspace_floats',
+           'kgw_gather_rows', 'kgw_gather_rows_multi', 'kgw_scatter_relu_rows', 'kgw_scatter_relu_rows_workspace_floats', 'kgw_edge_alpha', 'kgw_debug_reduce', 'kgw_debug_reduce8', 'kgw_tn_gemm', 'kgw_tn_gemm_ex', 'kgw_tn_gemm_workspace_floats',
            'kgw_linear', 'kgw_adam', 'kgw_relvec_fwd', 'kgw_relvec_bwd', 'kgw_wmse_fwd', 'kgw_wmse_bwd', 'kgw_readout_wmse_fwd', 'kgw_readout_wmse_bwd', 'kgw_accumulate_stats']
 
 _lib = None
@@ -134,6 +134,11 @@ def lib():
     for name in ('kgw_gat_aggregate_fwd', 'kgw_gat_aggregate_bwd_dst', 'kgw_gat_aggregate_bwd_src'):
         getattr(L, name).argtypes = [C.POINTER(KgwLayerArgs), C.c_void_p]
     L.kgw_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+    L.kgw_scatter_relu_rows_workspace_floats.restype = C.c_int64
+    L.kgw_scatter_relu_rows_workspace_floats.argtypes = [C.c_int64]
+    L.kgw_scatter_relu_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.kgw_gather_rows_multi.argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32,
+                                        C.POINTER(C.c_void_p), C.c_void_p]
     L.kgw_edge_alpha.argtypes = [C.POINTER(KgwLayerArgs), C.c_void_p, C.c_void_p]
     L.kgw_debug_reduce.argtypes = [C.c_void_p] * 5
     L.kgw_debug_reduce8.argtypes = [C.c_void_p] * 3

@@ -892,6 +892,73 @@ extern "C" int kgw_linear(const float* X, int64_t ldx, const float* W, int64_t l
 }
 
 // ======================================================================================================
+// kgw_scatter_relu_rows: backward of "rows ids of relu(X W^T + b) computed on a RESIDENT matrix" (the 5120-wide gene
+// layer runs on all N genes and the batch takes its rows): dz[row] = g[g2l[row]] * (h[row] > 0) for every row of the
+// resident matrix (zero where the node is not in the batch), and colsum[c] = sum_row dz[row][c] -- the framework's
+// zero fill + index_add + ReLU mask + column reduction (5 launches) in 2.  Deterministic (fixed partial layout).
+// ======================================================================================================
+namespace {
+__global__ void __launch_bounds__(256) k_scatter_relu_rows(const float* __restrict__ g, const int32_t* __restrict__ g2l,
+                                                           const float* __restrict__ h, int64_t n_rows,
+                                                           float* __restrict__ dz, float* __restrict__ part) {
+    __shared__ float4 red[8][32];
+    const int r8 = threadIdx.x >> 5, c4 = threadIdx.x & 31;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t r = (int64_t)blockIdx.x * 8 + r8; r < n_rows; r += (int64_t)gridDim.x * 8) {
+        const int pos = g2l[r];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pos >= 0) {
+            const float4 gv = ((const float4*)g)[(int64_t)pos * 32 + c4];
+            const float4 hv = ((const float4*)h)[r * 32 + c4];
+            v.x = hv.x > 0.f ? gv.x : 0.f; v.y = hv.y > 0.f ? gv.y : 0.f;
+            v.z = hv.z > 0.f ? gv.z : 0.f; v.w = hv.w > 0.f ? gv.w : 0.f;
+        }
+        ((float4*)dz)[r * 32 + c4] = v;
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    red[r8][c4] = acc;
+    __syncthreads();
+    if (r8 == 0) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { const float4 o = red[k][c4]; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+        ((float4*)part)[(int64_t)blockIdx.x * 32 + c4] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(128) k_colsum_fold(const float* __restrict__ part, int nblk, float* __restrict__ out) {
+    const int c = threadIdx.x;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 4 <= nblk; b += 4) {                       // four independent loads in flight
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += part[(int64_t)(b + k) * 128 + c];
+    }
+    for (; b < nblk; ++b) s[0] += part[(int64_t)b * 128 + c];
+    out[c] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+}  // namespace
+
+extern "C" int64_t kgw_scatter_relu_rows_workspace_floats(int64_t n_rows) {
+    int64_t nblk = (n_rows + 7) / 8;
+    if (nblk > 512) nblk = 512;
+    return (nblk > 0 ? nblk : 1) * 128;
+}
+
+extern "C" int kgw_scatter_relu_rows(const float* g, const int32_t* g2l, const float* h, int64_t n_rows, float* dz,
+                                     float* colsum, float* workspace, kgw_stream_t stream_) {
+    if (!g2l || !h || !dz || !colsum || !workspace) return KGW_E_NULL;
+    if (n_rows <= 0) return KGW_E_RANGE;
+    if (!aligned16(h) || !aligned16(dz) || !aligned16(workspace) || (g && !aligned16(g))) return KGW_E_UNSUPPORTED;
+    int64_t nblk = (n_rows + 7) / 8;
+    if (nblk > 512) nblk = 512;
+    k_scatter_relu_rows<<<(int)nblk, 256, 0, (hipStream_t)stream_>>>(g, g2l, h, n_rows, dz, workspace);
+    KGW_LAUNCH_CHECK();
+    k_colsum_fold<<<1, 128, 0, (hipStream_t)stream_>>>(workspace, (int)nblk, colsum);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+// ======================================================================================================
 // kgw_adam: torch.optim.Adam(lr, betas, eps, weight_decay as L2) of kgwas/kgwas.py:116,151 for ALL parameter
 // tensors in one launch (the framework's capturable Adam issues ~100 small launches per step).  Same update
 // order as torch: g += wd*p ; m = lerp(m, g, 1-b1) ; v = v*b2 + (1-b2)*g*g ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).

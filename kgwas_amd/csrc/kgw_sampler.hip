@@ -632,27 +632,41 @@ extern "C" int kgw_accumulate_stats(const KgwBatchMeta* meta_dev, int32_t n_laye
 
 // ---- x[n_id] feature slicing ---------------------------------------------------------------------
 namespace {
-__global__ void __launch_bounds__(KGW_BLK) k_gather_rows(const float* __restrict__ src,
-                                                         const int32_t* __restrict__ ids, int64_t n_rows,
-                                                         int width, float* __restrict__ dst) {
-    // one wavefront per row; float4 when the row width allows, else scalar
-    const int lane = kgw_lane();
-    const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nw = (int64_t)gridDim.x * 4;
-    if ((width & 3) == 0) {
-        const int w4 = width >> 2;
-        for (int64_t r = w0; r < n_rows; r += nw) {
-            const float4* s = (const float4*)(src + (int64_t)ids[r] * width);
-            float4* d = (float4*)(dst + r * width);
-            for (int k = lane; k < w4; k += 64) d[k] = s[k];
-        }
-    } else {
-        for (int64_t r = w0; r < n_rows; r += nw) {
-            const float* s = src + (int64_t)ids[r] * width;
-            float* d = dst + r * width;
-            for (int k = lane; k < width; k += 64) d[k] = s[k];
-        }
+constexpr int GATHER_MAX_JOBS = 8;
+struct GatherJobs {
+    const float* src[GATHER_MAX_JOBS];
+    const int32_t* ids[GATHER_MAX_JOBS];
+    float* dst[GATHER_MAX_JOBS];
+    int64_t first[GATHER_MAX_JOBS + 1];      // prefix sums of the jobs' element counts (float4s, or floats if width % 4)
+    int n;
+};
+
+// dst_j[i] = src_j[ids_j[i]] for up to eight (src, ids, dst) jobs of one row width in ONE launch.  Threads run over the
+// flattened (row, float4-of-the-row) space, so narrow rows (the 20-float SNP features: 5 float4) still fill every lane.
+template <int VEC>
+__global__ void __launch_bounds__(KGW_BLK) k_gather_rows(GatherJobs J, int wv) {
+    const int64_t total = J.first[J.n];
+    for (int64_t e = (int64_t)blockIdx.x * KGW_BLK + threadIdx.x; e < total; e += (int64_t)gridDim.x * KGW_BLK) {
+        int j = 0;
+        while (j + 1 < J.n && e >= J.first[j + 1]) ++j;
+        const int64_t k = e - J.first[j];
+        const int64_t r = k / wv;
+        const int c = (int)(k - r * wv);
+        const int64_t s = (int64_t)J.ids[j][r] * wv + c;
+        if (VEC == 4) ((float4*)J.dst[j])[k] = ((const float4*)J.src[j])[s];
+        else J.dst[j][k] = J.src[j][s];
     }
+}
+
+int launch_gather(const GatherJobs& J, int width, hipStream_t st) {
+    const int64_t total = J.first[J.n];
+    if (total == 0) return KGW_OK;
+    int64_t grid = (total + KGW_BLK - 1) / KGW_BLK;
+    if (grid > KGW_GRID * 8) grid = KGW_GRID * 8;
+    if ((width & 3) == 0) k_gather_rows<4><<<(int)grid, KGW_BLK, 0, st>>>(J, width >> 2);
+    else k_gather_rows<1><<<(int)grid, KGW_BLK, 0, st>>>(J, width);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
 }
 }  // namespace
 
@@ -661,9 +675,28 @@ extern "C" int kgw_gather_rows(const float* src, const int32_t* ids, int64_t n_r
     if (n_rows == 0) return KGW_OK;
     if (!src || !ids || !dst) return KGW_E_NULL;
     if (width <= 0 || n_rows < 0) return KGW_E_RANGE;
-    int grid = (int)((n_rows + 3) / 4);
-    if (grid > KGW_GRID * 4) grid = KGW_GRID * 4;
-    k_gather_rows<<<grid, KGW_BLK, 0, (hipStream_t)stream_>>>(src, ids, n_rows, width, dst);
-    KGW_LAUNCH_CHECK();
-    return KGW_OK;
+    if ((width & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15)) return KGW_E_UNSUPPORTED;
+    GatherJobs J{};
+    J.src[0] = src; J.ids[0] = ids; J.dst[0] = dst; J.n = 1;
+    J.first[0] = 0; J.first[1] = n_rows * ((width & 3) ? width : width >> 2);
+    return launch_gather(J, width, (hipStream_t)stream_);
+}
+
+extern "C" int kgw_gather_rows_multi(int32_t n_jobs, const float* const* src, const int32_t* const* ids,
+                                     const int64_t* n_rows, int32_t width, float* const* dst, kgw_stream_t stream_) {
+    if (n_jobs == 0) return KGW_OK;
+    if (!src || !ids || !n_rows || !dst) return KGW_E_NULL;
+    if (n_jobs < 0 || n_jobs > GATHER_MAX_JOBS || width <= 0) return KGW_E_RANGE;
+    GatherJobs J{};
+    J.n = 0; J.first[0] = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        if (n_rows[j] < 0) return KGW_E_RANGE;
+        if (n_rows[j] == 0) continue;
+        if (!src[j] || !ids[j] || !dst[j]) return KGW_E_NULL;
+        if ((width & 3) == 0 && (((uintptr_t)src[j] | (uintptr_t)dst[j]) & 15)) return KGW_E_UNSUPPORTED;
+        J.src[J.n] = src[j]; J.ids[J.n] = ids[j]; J.dst[J.n] = dst[j];
+        J.first[J.n + 1] = J.first[J.n] + n_rows[j] * ((width & 3) ? width : width >> 2);
+        ++J.n;
+    }
+    return launch_gather(J, width, (hipStream_t)stream_);
 }

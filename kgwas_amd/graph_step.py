@@ -58,6 +58,7 @@ class GraphTrainStep:
         # device-side statistics accumulated inside the graph: [edges layer 1..L, sampled edges, error mask]
         self.stats = torch.zeros(L + 2, dtype=torch.int64, device=dev)
         self.loss = [None, None]
+        self._unit = torch.ones((), dtype=torch.float64, device=dev)
         self._flat = None                         # multi-rank: gradient bucket + {param: view}
         self._flat_grads = None
         self.graphs = [None, None]
@@ -90,7 +91,7 @@ class GraphTrainStep:
         self.opt.zero_grad(set_to_none=True)
         loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id(self.input_type),
                                           self.dg.y[self.input_type], self.ld_w)          # kgwas.py:137-145
-        loss.backward()
+        loss.backward(gradient=self._unit)                             # (a resident 1.0: no ones_like fill per step)
         if self.capture_optimizer:
             self.opt.step()
         elif self.world > 1:

@@ -36,7 +36,7 @@ import torch.nn as nn
 
 from . import ops
 from .graph import GraphSchema, HeteroGraph
-from .sampler import SampledBatch, gather_rows, sample_full_graph
+from .sampler import SampledBatch, gather_rows_multi, sample_full_graph
 
 EdgeType = Tuple[str, str, str]
 GO_TYPES = ('CellularComponent', 'BiologicalProcess', 'MolecularFunction')
@@ -271,7 +271,9 @@ class HeteroGNN(nn.Module):
         if lazy and not dg.full_graph:
             X = dg.x[t]
             if X.shape[1] >= 512 and 2 * n > X.shape[0]:
-                return mlp.tail(mlp.first(X, fixed_shape=True).index_select(0, batch.n_id(t)), out)
+                i = dg.schema.type_id[t]
+                g2l = batch.buf.g2l[dg.node_base[i]:dg.node_base[i] + X.shape[0]]
+                return mlp.tail(ops.resident_linear_relu_rows(X, mlp.FC_hidden.weight, mlp.FC_hidden.bias, batch.n_id(t), g2l), out)
         # static layout: the row block is padded to its capacity; the kernels skip the padding (count on the device)
         return mlp(x_dict[t], out, batch.rows_dev(t) if n == batch.lay_src(1, dg.schema.type_id[t]) else None)
 
@@ -289,17 +291,20 @@ class HeteroGNN(nn.Module):
         rows go through it as ONE matrix.  ``blocks``: RowBlocks of the first layer's input to write into."""
         h = {}
         blocks = blocks or {}
-        go = [t for t in self.node_types if t in GO_TYPES and t in x_dict and batch.n_nodes.get(t, x_dict[t].shape[0]) > 0]
+        # (n_nodes first: touching a lazy x_dict entry would gather that type's rows a second time)
+        go = [t for t in self.node_types if t in GO_TYPES and t in x_dict and
+              (batch.n_nodes[t] if t in batch.n_nodes else x_dict[t].shape[0]) > 0]
         if len(go) > 1:
             lazy = getattr(x_dict, 'kgw_batch', None) is batch and all(t in batch.dg.x for t in go) and \
                 len({batch.dg.x[t].shape[1] for t in go}) == 1
             if lazy:            # gather the three types' rows straight into one matrix (no concatenation copy)
                 ns = [batch.n_nodes[t] for t in go]
                 xg = torch.empty(sum(ns), batch.dg.x[go[0]].shape[1], device=self.lin.weight.device)
-                off = 0
+                off, jobs = 0, []
                 for t, n in zip(go, ns):
-                    gather_rows(batch.dg.x[t], batch.n_id(t), out=xg[off:off + n])
+                    jobs.append((batch.dg.x[t], batch.n_id(t), xg[off:off + n]))
                     off += n
+                gather_rows_multi(jobs)                       # one launch for the three types
                 xs = None
             else:
                 xs = [x_dict[t] for t in go]

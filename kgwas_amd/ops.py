@@ -494,6 +494,43 @@ class _LinearReLU(torch.autograd.Function):
         return dx, dW, db, None
 
 
+class _ResidentLinearReLURows(torch.autograd.Function):
+    """rows ``ids`` of relu(X W^T + b) where X is a RESIDENT feature matrix (the 5120 / 57742-wide gene features): the
+    product runs on all of X (same shape every step -> tuned library GEMM) and the batch takes its rows -- no x[n_id]
+    copy of 20 KB rows (kgwas/kgwas.py:135).  ``g2l`` [N] int32: local index of each row of X in the batch, -1 = not
+    sampled (the inverse of ``ids``, kept by the sampler).  Backward: kgw_scatter_relu_rows builds the dense dz (zero
+    rows for unsampled nodes, ReLU mask applied) and the bias gradient in two launches; dW is one library GEMM."""
+
+    @staticmethod
+    def forward(ctx, X, W, b, ids, g2l):
+        h = linear(X, W, b, relu=True, fixed_shape=True)
+        n = int(ids.numel())
+        out = torch.empty(n, h.shape[1], device=h.device)
+        if n:
+            _lib.check(_lib.lib().kgw_gather_rows(_p(h), _p(ids), n, h.shape[1], _p(out), _lib.stream_ptr()), 'kgw_gather_rows')
+        ctx.save_for_backward(X, h, g2l)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        X, h, g2l = ctx.saved_tensors
+        g = g.contiguous()
+        N = h.shape[0]
+        assert h.shape[1] == KGW_C and g2l.numel() == N and g2l.dtype == torch.int32
+        dz = torch.empty_like(h)
+        db = torch.empty(KGW_C, device=h.device)
+        ws = torch.empty(int(_lib.lib().kgw_scatter_relu_rows_workspace_floats(N)), device=h.device)
+        _lib.check(_lib.lib().kgw_scatter_relu_rows(_p(g), _p(g2l), _p(h), N, _p(dz), _p(db), _p(ws), _lib.stream_ptr()),
+                   'kgw_scatter_relu_rows')
+        with _TUNED:
+            dW = dz.t().mm(X)
+        return None, dW, db, None, None
+
+
+def resident_linear_relu_rows(X, W, b, ids, g2l):
+    return _ResidentLinearReLURows.apply(X, W, b, ids, g2l)
+
+
 class _LinearAct(torch.autograd.Function):
     """y = [relu](x W^T + b) for W given TRANSPOSED as Wt [K,N] (the packed per-relation weights) -- the
     transform GEMM of a layer: per-relation lin_src + bias + relation sum (+ ReLU) in one launch."""

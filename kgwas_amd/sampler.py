@@ -459,6 +459,22 @@ def gather_rows(src: torch.Tensor, ids: torch.Tensor, out: torch.Tensor = None) 
     return out
 
 
+def gather_rows_multi(jobs) -> None:
+    """``jobs``: up to 8 (src [N_j, w], ids int32 [n_j], out [n_j, w] contiguous) triples of one row width w:
+    out_j[i] = src_j[ids_j[i]] for all of them in ONE launch (kgw_gather_rows_multi)."""
+    jobs = [(s, i, o) for s, i, o in jobs if int(i.numel())]
+    if not jobs:
+        return
+    w = int(jobs[0][0].shape[1])
+    n = len(jobs)
+    S = (C.c_void_p * n)(); I = (C.c_void_p * n)(); O = (C.c_void_p * n)(); N = (C.c_int64 * n)()
+    for k, (s, i, o) in enumerate(jobs):
+        assert s.dtype == torch.float32 and s.is_contiguous() and i.dtype == torch.int32 and int(s.shape[1]) == w
+        assert o.shape == (int(i.numel()), w) and o.is_contiguous()
+        S[k], I[k], O[k], N[k] = _ptr(s).value, _ptr(i).value, _ptr(o).value, int(i.numel())
+    _lib.check(_lib.lib().kgw_gather_rows_multi(n, S, I, N, w, O, _lib.stream_ptr()), 'kgw_gather_rows_multi')
+
+
 def sample_into(dg: DeviceGraph, buf: BatchBuffers, seeds: Optional[torch.Tensor], seed_type: int, stream=None,
                 record: bool = True):
     st = stream if stream is not None else torch.cuda.current_stream()

@@ -228,3 +228,42 @@ def test_tn_gemm_small_and_ragged_row_counts(rows, M, N):
     C_, cs = ops.tn_gemm(A, B, colsum=True)
     assert_close(C_, A.double().t() @ B.double(), 1e-5, 1e-6, 'C', rel_to_max=2e-6)
     assert_close(cs, A.double().sum(0), 1e-5, 1e-6, 'colsum', rel_to_max=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_all,n_batch', [(20032, 13000), (1000, 1000), (37, 0), (9, 5)])
+def test_scatter_relu_rows_matches_index_add(n_all, n_batch):
+    """kgw_scatter_relu_rows == zeros.index_add(ids, g) * (h > 0) and its column sums (the backward of the resident
+    first gene layer), bit for bit on the scatter and to fp32 rounding on the sums."""
+    from kgwas_amd import _lib
+    gen = torch.Generator().manual_seed(n_all)
+    ids = torch.randperm(n_all, generator=gen)[:n_batch].to(torch.int32)
+    g2l = torch.full((n_all,), -1, dtype=torch.int32)
+    g2l[ids.long()] = torch.arange(n_batch, dtype=torch.int32)
+    g = torch.randn(max(n_batch, 1), 128, generator=gen)[:n_batch].contiguous()
+    h = torch.randn(n_all, 128, generator=gen)
+    ref = torch.zeros(n_all, 128).index_add_(0, ids.long(), g) * (h > 0)
+    gd, hd, ld = g.cuda(), h.cuda(), g2l.cuda()
+    dz = torch.full((n_all, 128), 3.0).cuda(); cs = torch.empty(128).cuda()
+    ws = torch.empty(int(_lib.lib().kgw_scatter_relu_rows_workspace_floats(n_all))).cuda()
+    _lib.check(_lib.lib().kgw_scatter_relu_rows(gd.data_ptr() if n_batch else 0, ld.data_ptr(), hd.data_ptr(), n_all, dz.data_ptr(),
+                                                cs.data_ptr(), ws.data_ptr(), _lib.stream_ptr()), 'scatter')
+    assert torch.equal(dz.cpu(), ref)
+    assert_close(cs, ref.double().sum(0), 1e-5, 1e-5, 'colsum', rel_to_max=2e-6)
+
+
+@pytest.mark.gpu
+def test_gather_rows_multi_and_narrow_rows():
+    """kgw_gather_rows (flattened indexing: 20-float rows fill the lanes; odd widths take the scalar path) and the
+    multi-job entry point equal index_select, including empty jobs."""
+    from kgwas_amd.sampler import gather_rows, gather_rows_multi
+    gen = torch.Generator().manual_seed(5)
+    for w, N, n in [(20, 5000, 12345), (128, 300, 1000), (7, 50, 64), (5120, 40, 9)]:
+        src = torch.randn(N, w, generator=gen).cuda()
+        ids = torch.randint(0, N, (n,), generator=gen).to(torch.int32).cuda()
+        assert torch.equal(gather_rows(src, ids), src.index_select(0, ids.long()))
+    srcs = [torch.randn(N, 128, generator=gen).cuda() for N in (100, 7, 3000)]
+    idss = [torch.randint(0, s.shape[0], (n,), generator=gen).to(torch.int32).cuda() for s, n in zip(srcs, (250, 0, 1111))]
+    out = torch.full((250 + 0 + 1111, 128), -1.0).cuda()
+    gather_rows_multi([(srcs[0], idss[0], out[:250]), (srcs[1], idss[1], out[250:250]), (srcs[2], idss[2], out[250:])])
+    assert torch.equal(out, torch.cat([s.index_select(0, i.long()) for s, i in zip(srcs, idss)], 0))
