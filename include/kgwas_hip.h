@@ -222,6 +222,20 @@ int kgw_edge_alpha(const KgwLayerArgs* args, float* alpha_out, kgw_stream_t stre
  * (kgwas/model.py:13-21,50; kgwas/conv.py:82-89,150-151) whose reduction dimension is the number of
  * sampled nodes.  workspace: kgw_tn_gemm_workspace_floats(rows, M, N) floats.                    */
 int64_t kgw_tn_gemm_workspace_floats(int64_t rows, int32_t M, int32_t N);
+/* One product of kgw_tn_gemm_multi: the arguments of kgw_tn_gemm_ex as a record.                  */
+typedef struct KgwTnJob {
+    const float* A; int64_t lda; const float* B; int64_t ldb;
+    int64_t rows;
+    float* C; int64_t ldc;
+    float* colsum_a; int64_t colsum_ld;
+    float* workspace; int64_t workspace_floats;
+    const int32_t* rows_dev;
+    int32_t M, N, c_transposed, colsum_repeat;
+} KgwTnJob;
+/* Up to 4 such products in ONE pair of launches (the weight / bias gradients of the Linears of one
+ * MLP, kgwas/model.py:17-21, become available together at the end of its backward).  Needs even M, N,
+ * lda, ldb and 8-byte aligned A, B (else KGW_E_UNSUPPORTED: use kgw_tn_gemm_ex per product).        */
+int kgw_tn_gemm_multi(int32_t n_jobs, const KgwTnJob* jobs, kgw_stream_t stream);
 int kgw_tn_gemm(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
                 int64_t rows, float* C, int64_t ldc, float* colsum_a, float* workspace,
                 int64_t workspace_floats, kgw_stream_t stream);

@@ -97,9 +97,16 @@ class KgwLayerArgs(C.Structure):
     ]
 
 
+class KgwTnJob(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('lda', C.c_int64), ('B', C.c_void_p), ('ldb', C.c_int64), ('rows', C.c_int64),
+                ('C', C.c_void_p), ('ldc', C.c_int64), ('colsum_a', C.c_void_p), ('colsum_ld', C.c_int64),
+                ('workspace', C.c_void_p), ('workspace_floats', C.c_int64), ('rows_dev', C.c_void_p),
+                ('M', C.c_int32), ('N', C.c_int32), ('c_transposed', C.c_int32), ('colsum_repeat', C.c_int32)]
+
+
 EXPORTS = ['kgw_version', 'kgw_status_string', 'kgw_struct_sizes', 'kgw_sample_batch',
            'kgw_gat_aggregate_fwd', 'kgw_gat_aggregate_bwd_dst', 'kgw_gat_aggregate_bwd_src',
-           'kgw_gather_rows', 'kgw_gather_rows_multi', 'kgw_scatter_relu_rows', 'kgw_scatter_relu_rows_workspace_floats', 'kgw_edge_alpha', 'kgw_debug_reduce', 'kgw_debug_reduce8', 'kgw_tn_gemm', 'kgw_tn_gemm_ex', 'kgw_tn_gemm_workspace_floats',
+           'kgw_gather_rows', 'kgw_gather_rows_multi', 'kgw_scatter_relu_rows', 'kgw_scatter_relu_rows_workspace_floats', 'kgw_edge_alpha', 'kgw_debug_reduce', 'kgw_debug_reduce8', 'kgw_tn_gemm', 'kgw_tn_gemm_ex', 'kgw_tn_gemm_multi', 'kgw_tn_gemm_workspace_floats',
            'kgw_linear', 'kgw_adam', 'kgw_relvec_fwd', 'kgw_relvec_bwd', 'kgw_wmse_fwd', 'kgw_wmse_bwd', 'kgw_readout_wmse_fwd', 'kgw_readout_wmse_bwd', 'kgw_accumulate_stats']
 
 _lib = None
@@ -123,10 +130,10 @@ def lib():
     L.kgw_status_string.restype = C.c_char_p
     L.kgw_status_string.argtypes = [C.c_int]
     L.kgw_struct_sizes.argtypes = [C.POINTER(C.c_int64), C.c_int]
-    sizes = (C.c_int64 * 5)()
-    L.kgw_struct_sizes(sizes, 5)
+    sizes = (C.c_int64 * 6)()
+    L.kgw_struct_sizes(sizes, 6)
     mine = [C.sizeof(KgwGraph), C.sizeof(KgwBatchMeta), C.sizeof(KgwChunk), C.sizeof(KgwBatchBuf),
-            C.sizeof(KgwLayerArgs)]
+            C.sizeof(KgwLayerArgs), C.sizeof(KgwTnJob)]
     if list(sizes) != mine:
         raise KgwasHipError(f'ABI struct size mismatch: library {list(sizes)} vs binding {mine}')
     L.kgw_sample_batch.argtypes = [C.POINTER(KgwGraph), C.POINTER(KgwBatchBuf), C.c_void_p, C.c_int32,
@@ -134,6 +141,7 @@ def lib():
     for name in ('kgw_gat_aggregate_fwd', 'kgw_gat_aggregate_bwd_dst', 'kgw_gat_aggregate_bwd_src'):
         getattr(L, name).argtypes = [C.POINTER(KgwLayerArgs), C.c_void_p]
     L.kgw_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+    L.kgw_tn_gemm_multi.argtypes = [C.c_int32, C.POINTER(KgwTnJob), C.c_void_p]
     L.kgw_scatter_relu_rows_workspace_floats.restype = C.c_int64
     L.kgw_scatter_relu_rows_workspace_floats.argtypes = [C.c_int64]
     L.kgw_scatter_relu_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -824,9 +824,9 @@ extern "C" const char* kgw_status_string(int status) {
 
 extern "C" int kgw_struct_sizes(int64_t* out, int n) {
     if (!out) return KGW_E_NULL;
-    const int64_t v[5] = {(int64_t)sizeof(KgwGraph), (int64_t)sizeof(KgwBatchMeta), (int64_t)sizeof(KgwChunk),
-                          (int64_t)sizeof(KgwBatchBuf), (int64_t)sizeof(KgwLayerArgs)};
-    for (int i = 0; i < n && i < 5; ++i) out[i] = v[i];
+    const int64_t v[6] = {(int64_t)sizeof(KgwGraph), (int64_t)sizeof(KgwBatchMeta), (int64_t)sizeof(KgwChunk),
+                          (int64_t)sizeof(KgwBatchBuf), (int64_t)sizeof(KgwLayerArgs), (int64_t)sizeof(KgwTnJob)};
+    for (int i = 0; i < n && i < 6; ++i) out[i] = v[i];
     return KGW_OK;
 }
 

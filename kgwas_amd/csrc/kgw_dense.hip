@@ -66,23 +66,42 @@ __device__ __forceinline__ void tn_mma(const Stage<MT, NT>& s, f32x16 (&acc)[MT]
     }
 }
 
+// Up to four products of one tiling per launch (the weight gradients of one MLP: same rows, different operands): the
+// x dimension of the grid is the concatenation of the jobs' row blocks.
+constexpr int TN_MAX_JOBS = 4;
+struct TnJob {
+    const float* A; const float* B; float* C; float* colsum; float* ws; float* ws_cs; const int32_t* rows_dev;
+    int64_t lda, ldb, rows, rpw, c_rs, c_cs, cs_ld;
+    int M, N, nblk, blk0, gy, gz, cs_rep, pad_;
+};
+struct TnJobs { TnJob j[TN_MAX_JOBS]; int n; };
+
 // ws layout per block: [MT][NT][16][64] floats (fragment order) ; colsum ws per block: [32*MT]
 template <int MT, int NT>
-__global__ void __launch_bounds__(256, 1) k_tn_gemm(const float* __restrict__ A, int64_t lda, int M,
-                                                    const float* __restrict__ B, int64_t ldb, int N, int64_t rows,
-                                                    int64_t rows_per_wave, float* __restrict__ ws,
-                                                    float* __restrict__ ws_colsum, const int32_t* __restrict__ rows_dev) {
+__global__ void __launch_bounds__(256, 1) k_tn_gemm(TnJobs J) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    int jq = 0;
+    while (jq + 1 < J.n && (int)blockIdx.x >= J.j[jq + 1].blk0) ++jq;
+    const TnJob& T = J.j[jq];
+    if ((int)blockIdx.y >= T.gy || (int)blockIdx.z >= T.gz) return;       // (before any barrier: whole blocks)
+    const float* __restrict__ A = T.A;
+    const float* __restrict__ B = T.B;
+    const int64_t lda = T.lda, ldb = T.ldb;
+    const int M = T.M, N = T.N;
+    int64_t rows = T.rows, rows_per_wave = T.rpw;
+    float* __restrict__ ws = T.ws;
+    float* __restrict__ ws_colsum = T.ws_cs;
+    const int bx = (int)blockIdx.x - T.blk0, nbx = T.nblk;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = lane >> 5, i = lane & 31;
     const int m0 = blockIdx.y * 32 * MT, n0 = blockIdx.z * 32 * NT;
     const int ca = m0 + MT * i, cb = n0 + NT * i;
     const int cas = ca < M ? ca : 0, cbs = cb < N ? cb : 0;
-    const int64_t wg = (int64_t)blockIdx.x * 4 + wave;
-    if (rows_dev) {                     // actual row count of the batch (<= the static capacity `rows`): re-split evenly
-        const int64_t re = min(rows, (int64_t)max(*rows_dev, 0));
+    const int64_t wg = (int64_t)bx * 4 + wave;
+    if (T.rows_dev) {                   // actual row count of the batch (<= the static capacity `rows`): re-split evenly
+        const int64_t re = min(rows, (int64_t)max(*T.rows_dev, 0));
         rows = re;
-        rows_per_wave = ((re + (int64_t)gridDim.x * 4 - 1) / ((int64_t)gridDim.x * 4) + 1) & ~(int64_t)1;
+        rows_per_wave = ((re + (int64_t)nbx * 4 - 1) / ((int64_t)nbx * 4) + 1) & ~(int64_t)1;
     }
     const int64_t r0 = min(rows, wg * rows_per_wave);
     const int64_t r1 = min(rows, r0 + rows_per_wave);
@@ -171,7 +190,7 @@ __global__ void __launch_bounds__(256, 1) k_tn_gemm(const float* __restrict__ A,
             }
     }
     __syncthreads();
-    const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int64_t blk = ((int64_t)blockIdx.z * T.gy + blockIdx.y) * nbx + bx;
     float* out = ws + blk * FRAG;
     for (int f = threadIdx.x * 4; f < FRAG; f += 256 * 4) {
         const float4 x = *(const float4*)(reg0 + f), y = *(const float4*)(reg1 + f);
@@ -180,19 +199,25 @@ __global__ void __launch_bounds__(256, 1) k_tn_gemm(const float* __restrict__ A,
     if (ws_colsum && blockIdx.z == 0 && threadIdx.x < 32 * MT) {
         const int c = threadIdx.x;
         const float t = (cs[c] + cs[2 * 32 * MT + c]) + (cs[32 * MT + c] + cs[3 * 32 * MT + c]);
-        ws_colsum[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 * MT + c] = t;
+        ws_colsum[((int64_t)blockIdx.y * nbx + bx) * 32 * MT + c] = t;
     }
 }
 
 // C[m][n] = sum over row-blocks of the partial fragments (fixed order); also the column sums.
 // Block = 64 fragment elements x 4 groups of row-blocks; every thread keeps 8 loads in flight.
 template <int MT, int NT>
-__global__ void __launch_bounds__(256) k_tn_reduce(const float* __restrict__ ws, const float* __restrict__ ws_colsum,
-                                                   int nblk, int gy, int M, int N, float* __restrict__ C, int64_t c_rs,
-                                                   int64_t c_cs, float* __restrict__ colsum, int cs_rep, int64_t cs_ld) {
+__global__ void __launch_bounds__(256) k_tn_reduce(TnJobs J, int gz_max) {
     constexpr int FRAG = MT * NT * 16 * 64;
     __shared__ float sm[256];
-    const int by = blockIdx.y, bz = blockIdx.z;
+    const TnJob& T = J.j[blockIdx.z / gz_max];
+    const int by = blockIdx.y, bz = blockIdx.z % gz_max;
+    if (by >= T.gy || bz >= T.gz) return;
+    const float* __restrict__ ws = T.ws;
+    const float* __restrict__ ws_colsum = T.ws_cs;
+    const int nblk = T.nblk, gy = T.gy, M = T.M, N = T.N, cs_rep = T.cs_rep;
+    float* __restrict__ C = T.C;
+    float* __restrict__ colsum = T.colsum;
+    const int64_t c_rs = T.c_rs, c_cs = T.c_cs, cs_ld = T.cs_ld;
     const int m0 = by * 32 * MT, n0 = bz * 32 * NT;
     const int fl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int f = blockIdx.x * 64 + fl;
@@ -240,23 +265,41 @@ __global__ void __launch_bounds__(256) k_tn_reduce(const float* __restrict__ ws,
     }
 }
 
+struct TnDesc {      // one product as the C ABI describes it
+    const float* A; int64_t lda; int M; const float* B; int64_t ldb; int N; int64_t rows; float* C; int64_t ldc; bool c_t;
+    float* colsum; int cs_rep; int64_t cs_ld; float* ws; int64_t ws_floats; const int32_t* rows_dev;
+};
+
 template <int MT, int NT>
-int launch_tn(const float* A, int64_t lda, int M, const float* B, int64_t ldb, int N, int64_t rows, float* C,
-              int64_t ldc, bool c_t, float* colsum, int cs_rep, int64_t cs_ld, float* ws, int64_t ws_floats,
-              const int32_t* rows_dev, hipStream_t st) {
+int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st) {
     constexpr int FRAG = MT * NT * 16 * 64;
-    const int gy = (M + 32 * MT - 1) / (32 * MT), gz = (N + 32 * NT - 1) / (32 * NT);
-    // one block per CU at most; at least 64 rows per wavefront
-    int64_t nblk = (rows + 4 * 64 - 1) / (4 * 64);
-    int64_t cap = ((MT * NT <= 4) ? 512 : 256) / ((int64_t)gy * gz);      // (small accumulators: two blocks per CU)
-    if (cap < 1) cap = 1;
-    if (nblk > cap) nblk = cap;
-    if (nblk < 1) nblk = 1;
-    int64_t rpw = (rows + nblk * 4 - 1) / (nblk * 4);
-    rpw = (rpw + 1) & ~(int64_t)1;
-    const int64_t need = nblk * gy * gz * FRAG + nblk * gy * 32 * MT;
-    if (need > ws_floats) return KGW_E_RANGE;
-    float* ws_cs = colsum ? ws + nblk * gy * gz * FRAG : nullptr;
+    TnJobs J{};
+    J.n = n;
+    int blk = 0, gy_max = 0, gz_max = 0;
+    for (int q = 0; q < n; ++q) {
+        const TnDesc& D = d[q];
+        TnJob& T = J.j[q];
+        const int gy = (D.M + 32 * MT - 1) / (32 * MT), gz = (D.N + 32 * NT - 1) / (32 * NT);
+        // one block per CU at most; at least 64 rows per wavefront
+        int64_t nblk = (D.rows + 4 * 64 - 1) / (4 * 64);
+        int64_t cap = ((MT * NT <= 4) ? 512 : 256) / ((int64_t)gy * gz);      // (small accumulators: two blocks per CU)
+        if (cap < 1) cap = 1;
+        if (nblk > cap) nblk = cap;
+        if (nblk < 1) nblk = 1;
+        int64_t rpw = (D.rows + nblk * 4 - 1) / (nblk * 4);
+        rpw = (rpw + 1) & ~(int64_t)1;
+        const int64_t need = nblk * gy * gz * FRAG + nblk * gy * 32 * MT;
+        if (need > D.ws_floats) return KGW_E_RANGE;
+        T.A = D.A; T.B = D.B; T.C = D.C; T.colsum = D.colsum; T.ws = D.ws;
+        T.ws_cs = D.colsum ? D.ws + nblk * gy * gz * FRAG : nullptr;
+        T.rows_dev = D.rows_dev;
+        T.lda = D.lda; T.ldb = D.ldb; T.rows = D.rows; T.rpw = rpw;
+        T.c_rs = D.c_t ? 1 : D.ldc; T.c_cs = D.c_t ? D.ldc : 1; T.cs_ld = D.cs_ld;
+        T.M = D.M; T.N = D.N; T.nblk = (int)nblk; T.blk0 = blk; T.gy = gy; T.gz = gz; T.cs_rep = D.cs_rep;
+        blk += (int)nblk;
+        gy_max = gy > gy_max ? gy : gy_max;
+        gz_max = gz > gz_max ? gz : gz_max;
+    }
     const size_t lds_bytes = (size_t)(2 * FRAG + 4 * 32 * MT) * sizeof(float);
     auto kern = k_tn_gemm<MT, NT>;
     static bool attr_set = false;     // idempotent; a benign race at worst repeats the call
@@ -264,12 +307,19 @@ int launch_tn(const float* A, int64_t lda, int M, const float* B, int64_t ldb, i
         KGW_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
     }
-    kern<<<dim3((unsigned)nblk, gy, gz), 256, lds_bytes, st>>>(A, lda, M, B, ldb, N, rows, rpw, ws, ws_cs, rows_dev);
+    kern<<<dim3((unsigned)blk, gy_max, gz_max), 256, lds_bytes, st>>>(J);
     KGW_LAUNCH_CHECK();
-    k_tn_reduce<MT, NT><<<dim3(FRAG / 64, gy, gz), 256, 0, st>>>(ws, ws_cs, (int)nblk, gy, M, N, C, c_t ? 1 : ldc,
-                                                                 c_t ? ldc : 1, colsum, cs_rep, cs_ld);
+    k_tn_reduce<MT, NT><<<dim3(FRAG / 64, gy_max, gz_max * n), 256, 0, st>>>(J, gz_max);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
+}
+
+template <int MT, int NT>
+int launch_tn(const float* A, int64_t lda, int M, const float* B, int64_t ldb, int N, int64_t rows, float* C,
+              int64_t ldc, bool c_t, float* colsum, int cs_rep, int64_t cs_ld, float* ws, int64_t ws_floats,
+              const int32_t* rows_dev, hipStream_t st) {
+    const TnDesc d{A, lda, M, B, ldb, N, rows, C, ldc, c_t, colsum, cs_rep, cs_ld, ws, ws_floats, rows_dev};
+    return launch_tn_jobs<MT, NT>(&d, 1, st);
 }
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -309,6 +359,25 @@ extern "C" int kgw_tn_gemm_ex(const float* A, int64_t lda, int32_t M, const floa
     if (b2)       return launch_tn<1, 2>(KGW_TN_ARGS);
     return launch_tn<1, 1>(KGW_TN_ARGS);
 #undef KGW_TN_ARGS
+}
+
+extern "C" int kgw_tn_gemm_multi(int32_t n_jobs, const KgwTnJob* jobs, kgw_stream_t stream_) {
+    if (n_jobs == 0) return KGW_OK;
+    if (!jobs) return KGW_E_NULL;
+    if (n_jobs < 0 || n_jobs > TN_MAX_JOBS) return KGW_E_RANGE;
+    TnDesc d[TN_MAX_JOBS];
+    auto aligned8 = [](const void* p) { return ((uintptr_t)p & 7) == 0; };
+    for (int q = 0; q < n_jobs; ++q) {
+        const KgwTnJob& j = jobs[q];
+        if (!j.A || !j.B || !j.C || !j.workspace) return KGW_E_NULL;
+        if (j.M <= 0 || j.N <= 0 || j.rows <= 0 || j.lda < j.M || j.ldb < j.N || j.ldc < (j.c_transposed ? j.M : j.N)) return KGW_E_RANGE;
+        if (j.colsum_a && (j.colsum_repeat < 1 || (j.colsum_repeat > 1 && j.colsum_ld < j.M))) return KGW_E_RANGE;
+        // every job runs on the 64 x 64-per-wavefront tiling: float2 operand loads
+        if ((j.M & 1) || (j.lda & 1) || !aligned8(j.A) || (j.N & 1) || (j.ldb & 1) || !aligned8(j.B)) return KGW_E_UNSUPPORTED;
+        d[q] = TnDesc{j.A, j.lda, j.M, j.B, j.ldb, j.N, j.rows, j.C, j.ldc, j.c_transposed != 0, j.colsum_a,
+                      j.colsum_a ? j.colsum_repeat : 0, j.colsum_ld, j.workspace, j.workspace_floats, j.rows_dev};
+    }
+    return launch_tn_jobs<2, 2>(d, n_jobs, (hipStream_t)stream_);
 }
 
 extern "C" int kgw_tn_gemm(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,

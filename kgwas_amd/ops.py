@@ -286,6 +286,37 @@ def tn_gemm(A: torch.Tensor, B: torch.Tensor, colsum: bool = False, out: torch.T
     return (out, cs) if (colsum or colsum_out is not None) else out
 
 
+def weight_grads(pairs, rows_dev: torch.Tensor = None):
+    """[(dW [out,in], db [out])] of Y = X W^T + b for several (dY [rows,out], X [rows,in]) pairs that are available
+    TOGETHER (the Linears of one MLP at the end of its backward): one kgw_tn_gemm_multi launch pair for all of them
+    instead of one pair each; falls back to per-product calls where the grouped kernel does not apply."""
+    pairs = [(dY if dY.stride(1) == 1 else dY.contiguous(), X if X.stride(1) == 1 else X.contiguous()) for dY, X in pairs]
+    ok = 1 < len(pairs) <= 4 and all(X.shape[0] >= _TN_MIN_ROWS and X.shape[1] <= 1024 and X.shape[1] % 2 == 0 and dY.shape[1] % 2 == 0 and
+                                     X.stride(0) % 2 == 0 and dY.stride(0) % 2 == 0 and X.data_ptr() % 8 == 0 and dY.data_ptr() % 8 == 0
+                                     for dY, X in pairs)
+    if not ok:
+        return [linear_weight_grad(dY, X, rows_dev=rows_dev) for dY, X in pairs]
+    L = _lib.lib()
+    jobs = (_lib.KgwTnJob * len(pairs))()
+    outs, keep = [], []
+    for q, (dY, X) in enumerate(pairs):
+        rows, M = dY.shape
+        N = X.shape[1]
+        dW = torch.empty(M, N, device=dY.device)
+        db = torch.empty(M, device=dY.device)
+        nws = int(L.kgw_tn_gemm_workspace_floats(rows, M, N))
+        ws = torch.empty(nws, device=dY.device)
+        keep.append(ws)
+        j = jobs[q]
+        j.A, j.lda, j.B, j.ldb, j.rows = _p(dY), dY.stride(0), _p(X), X.stride(0), rows
+        j.C, j.ldc, j.colsum_a, j.colsum_ld = _p(dW), N, _p(db), M
+        j.workspace, j.workspace_floats, j.rows_dev = _p(ws), nws, _p(rows_dev)
+        j.M, j.N, j.c_transposed, j.colsum_repeat = M, N, 0, 1
+        outs.append((dW, db))
+    _lib.check(L.kgw_tn_gemm_multi(len(pairs), jobs, _lib.stream_ptr()), 'kgw_tn_gemm_multi')
+    return outs
+
+
 def _library_linear(X, W, bias, relu, mask, w_kn, out, fixed_shape):
     Wop = W if w_kn else W.t()
     if fixed_shape and mask is None and out is None:          # same shape every step: tuned library solution
@@ -362,10 +393,9 @@ class _MLPTail(torch.autograd.Function):
     def backward(ctx, dy):
         h1, h2, W2, W3 = ctx.saved_tensors
         dy = dy.contiguous()
-        dW3, db3 = linear_weight_grad(dy, h2)
         dh2 = linear(dy, W3, mask=h2, w_kn=True)                 # (dy @ W3) * (h2 > 0)
-        dW2, db2 = linear_weight_grad(dh2, h1)
         dh1 = linear(dh2, W2, w_kn=True) if ctx.needs_input_grad[0] else None
+        (dW3, db3), (dW2, db2) = weight_grads([(dy, h2), (dh2, h1)])      # both products in one launch pair
         return dh1, dW2, db2, dW3, db3, None
 
 
@@ -463,11 +493,9 @@ class _MLP3(torch.autograd.Function):
         x, h1, h2, W2, W3 = ctx.saved_tensors
         rd = ctx.rows_dev
         dy = dy.contiguous()
-        dW3, db3 = linear_weight_grad(dy, h2, rows_dev=rd)
         dh2 = linear(dy, W3, mask=h2, w_kn=True, rows_dev=rd)    # (dy @ W3) * (h2 > 0)
-        dW2, db2 = linear_weight_grad(dh2, h1, rows_dev=rd)
         dh1 = linear(dh2, W2, mask=h1, w_kn=True, rows_dev=rd)   # (dh2 @ W2) * (h1 > 0)
-        dW1, db1 = linear_weight_grad(dh1, x, rows_dev=rd)
+        (dW3, db3), (dW2, db2), (dW1, db1) = weight_grads([(dy, h2), (dh2, h1), (dh1, x)], rows_dev=rd)
         return None, dW1, db1, dW2, db2, dW3, db3, None, None
 
 

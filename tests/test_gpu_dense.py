@@ -267,3 +267,25 @@ def test_gather_rows_multi_and_narrow_rows():
     out = torch.full((250 + 0 + 1111, 128), -1.0).cuda()
     gather_rows_multi([(srcs[0], idss[0], out[:250]), (srcs[1], idss[1], out[250:250]), (srcs[2], idss[2], out[250:])])
     assert torch.equal(out, torch.cat([s.index_select(0, i.long()) for s, i in zip(srcs, idss)], 0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,real', [(50001, None), (20000, 13001), (3000, 2999)])
+def test_grouped_weight_gradients_match_fp64(rows, real):
+    """kgw_tn_gemm_multi: the three weight / bias gradients of an MLP (128x128, 128x128, 128x20) in one launch pair
+    == the fp64 products, with and without a device-side row count; bitwise equal to the one-product entry point."""
+    from kgwas_amd import ops
+    g = torch.Generator().manual_seed(rows)
+    dYs = [torch.randn(rows, 128, generator=g).cuda() for _ in range(3)]
+    Xs = [torch.randn(rows, 128, generator=g).cuda(), torch.randn(rows, 128, generator=g).cuda(), torch.randn(rows, 20, generator=g).cuda()]
+    cnt = torch.tensor([real], dtype=torch.int32).cuda() if real is not None else None
+    n = real if real is not None else rows
+    if real is not None:
+        for t in dYs + Xs:
+            t[real:] = float('nan')
+    outs = ops.weight_grads(list(zip(dYs, Xs)), rows_dev=cnt)
+    for (dW, db), dY, X in zip(outs, dYs, Xs):
+        assert_close(dW, dY[:n].double().t() @ X[:n].double(), 1e-5, 1e-5, 'grouped dW', rel_to_max=2e-6)
+        assert_close(db, dY[:n].double().sum(0), 1e-5, 1e-5, 'grouped db', rel_to_max=2e-6)
+    one = ops.tn_gemm(dYs[0], Xs[0], colsum=True, rows_dev=cnt)
+    assert torch.equal(one[0], outs[0][0]) and torch.equal(one[1], outs[0][1])
