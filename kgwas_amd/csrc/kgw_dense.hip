@@ -994,22 +994,31 @@ __global__ void __launch_bounds__(256) k_scatter_relu_rows(const float* __restri
     }
 }
 
-__global__ void __launch_bounds__(128) k_colsum_fold(const float* __restrict__ part, int nblk, float* __restrict__ out) {
-    const int c = threadIdx.x;
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    int b = 0;
-    for (; b + 4 <= nblk; b += 4) {                       // four independent loads in flight
+// 128 columns x 8 groups of partial rows, eight independent loads in flight per thread, fixed order
+__global__ void __launch_bounds__(1024) k_colsum_fold(const float* __restrict__ part, int nblk, float* __restrict__ out) {
+    __shared__ float sm[8][128];
+    const int c = threadIdx.x & 127, gq = threadIdx.x >> 7;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = gq;
+    for (; b + 56 < nblk; b += 64) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] += part[(int64_t)(b + k) * 128 + c];
+        for (int k = 0; k < 8; ++k) s[k] += part[(int64_t)(b + 8 * k) * 128 + c];
     }
-    for (; b < nblk; ++b) s[0] += part[(int64_t)b * 128 + c];
-    out[c] = (s[0] + s[1]) + (s[2] + s[3]);
+    for (int k = 0; b < nblk; b += 8, ++k) s[k & 7] += part[(int64_t)b * 128 + c];
+    sm[gq][c] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (gq == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sm[k][c];
+        out[c] = t;
+    }
 }
 }  // namespace
 
 extern "C" int64_t kgw_scatter_relu_rows_workspace_floats(int64_t n_rows) {
     int64_t nblk = (n_rows + 7) / 8;
-    if (nblk > 512) nblk = 512;
+    if (nblk > 256) nblk = 256;
     return (nblk > 0 ? nblk : 1) * 128;
 }
 
@@ -1019,10 +1028,10 @@ extern "C" int kgw_scatter_relu_rows(const float* g, const int32_t* g2l, const f
     if (n_rows <= 0) return KGW_E_RANGE;
     if (!aligned16(h) || !aligned16(dz) || !aligned16(workspace) || (g && !aligned16(g))) return KGW_E_UNSUPPORTED;
     int64_t nblk = (n_rows + 7) / 8;
-    if (nblk > 512) nblk = 512;
+    if (nblk > 256) nblk = 256;
     k_scatter_relu_rows<<<(int)nblk, 256, 0, (hipStream_t)stream_>>>(g, g2l, h, n_rows, dz, workspace);
     KGW_LAUNCH_CHECK();
-    k_colsum_fold<<<1, 128, 0, (hipStream_t)stream_>>>(workspace, (int)nblk, colsum);
+    k_colsum_fold<<<1, 1024, 0, (hipStream_t)stream_>>>(workspace, (int)nblk, colsum);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }

@@ -291,7 +291,8 @@ def weight_grads(pairs, rows_dev: torch.Tensor = None):
     TOGETHER (the Linears of one MLP at the end of its backward): one kgw_tn_gemm_multi launch pair for all of them
     instead of one pair each; falls back to per-product calls where the grouped kernel does not apply."""
     pairs = [(dY if dY.stride(1) == 1 else dY.contiguous(), X if X.stride(1) == 1 else X.contiguous()) for dY, X in pairs]
-    ok = 1 < len(pairs) <= 4 and all(X.shape[0] >= _TN_MIN_ROWS and X.shape[1] <= 1024 and X.shape[1] % 2 == 0 and dY.shape[1] % 2 == 0 and
+    # (tall products fill the chip on their own: grouping only pays while a product is launch-bound)
+    ok = 1 < len(pairs) <= 4 and all(_TN_MIN_ROWS <= X.shape[0] < 32768 and X.shape[1] <= 1024 and X.shape[1] % 2 == 0 and dY.shape[1] % 2 == 0 and
                                      X.stride(0) % 2 == 0 and dY.stride(0) % 2 == 0 and X.data_ptr() % 8 == 0 and dY.data_ptr() % 8 == 0
                                      for dY, X in pairs)
     if not ok:
@@ -361,9 +362,9 @@ def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask
     ok = (X.dtype == torch.float32 and X.stride(1) == 1 and W.stride(1) == 1 and K % 4 == 0 and K <= _LIN_MAX_K
           and X.stride(0) % 4 == 0 and W.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0
           and (not w_kn or N % 4 == 0) and (mask is None or mask.stride(1) == 1)
-          # 128-row tiles, no split over K: problems with few row tiles stay on the library unless the output is
-          # wide enough to fill the chip with column tiles
-          and (rows >= 8192 or (N >= 1024 and K <= 256) or (rows >= 4096 and K <= 128 and N <= 128)))
+          # 128-row tiles, no split over K: problems with few row tiles stay on the library (measured at 1171 rows,
+          # K = 128, N = 1536 / 2176 -- the dZ product of a layer transform: 9 / 18.5 us there vs 23 / 24 us here)
+          and (rows >= 8192 or (rows >= 4096 and K <= 128 and N <= 128)))
     if not ok:
         Y = _library_linear(X, W, bias, relu, mask, w_kn, out, fixed_shape)
         if rows_dev is not None:          # padding rows of a static layout: zeros, whatever the inputs held there

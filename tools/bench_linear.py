@@ -21,3 +21,7 @@ for rows,K,N in [(1171,2176,128),(512,768,128)]:
     X=torch.randn(rows,K,device='cuda'); W=torch.randn(K,N,device='cuda')
     t1=bench(lambda: ops.linear(X,W,None,w_kn=True)); t2=bench(lambda: X@W)
     print(f'{rows}x{K}x{N} kn: linear {t1:7.1f}  torch {t2:7.1f}')
+for rows,K,N in [(1171,128,2176),(1171,128,1536),(512,128,768)]:
+    X=torch.randn(rows,K,device='cuda'); W=torch.randn(N,K,device='cuda')
+    t1=bench(lambda: ops.linear(X,W,None)); t2=bench(lambda: X@W.t())
+    print(f'{rows}x{K}x{N} nk (layer-transform dX): linear {t1:7.1f}  torch {t2:7.1f}')
