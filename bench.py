@@ -252,6 +252,15 @@ def main():
                 roof['traffic'] = json.load(open(pmc)).get('hbm_bytes_per_launch')
             except Exception:
                 pass
+        if roof['traffic']:
+            # `achieved` follows the contract (ALGORITHMIC bytes / launch time) and can exceed the peak: a source row gathered
+            # by several relations / destination rows is counted every time but fetched from HBM once.  The HBM-side rate
+            # of the same launch, from the PMC traffic:
+            roof['hbm_side_GBs'] = roof['traffic'] / (roof['avg_launch_ms'] * 1e-3) / 1e9
+            roof['hbm_side_frac'] = roof['hbm_side_GBs'] / HBM_PEAK_GBS
+            roof['note'] = ('achieved = algorithmic bytes (SURVEY 8d: 520 B per edge and per segment) / HIP-event time; the PMC '
+                            'counters see less HBM traffic than that (traffic, hbm_side_*): re-used source rows are served by L2 / '
+                            'Infinity Cache')
     cpu = None
     if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed at N = 1 only
         cpu = cpu_baseline(data, bs)

@@ -733,6 +733,19 @@ inline int grid_for_waves(int64_t n_waves) {
     return (int)g;
 }
 
+// Grid of the three main aggregate kernels: up to 8192 blocks (32 k wavefronts), i.e. about one work item (chunk /
+// source-row pair) per wavefront.  Chunks differ in size by two orders of magnitude; with the 2048-block grid-stride
+// launch every wavefront drew ~2 of them and the longest draws set the kernel's tail: measured 74 -> 64 us (k_agg_fwd),
+// 72 -> 65 us (k_agg_bwd_dst), 163 -> 154 us (k_agg_bwd_src).  (32768 blocks: k_agg_bwd_src back to 164 us -- the
+// per-wavefront prologue shows; exactly one resident round -- occupancy x CUs blocks -- : k_agg_fwd 78 us.)
+inline int grid_fine(int64_t n_items) {
+    static const int64_t cap = getenv("KGW_AGG_GRID_CAP") ? atoll(getenv("KGW_AGG_GRID_CAP")) : 8192;
+    int64_t g = (n_items + 3) / 4;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
 }  // namespace
 
 extern "C" int kgw_gat_aggregate_fwd(const KgwLayerArgs* a, kgw_stream_t stream_) {
@@ -747,8 +760,8 @@ extern "C" int kgw_gat_aggregate_fwd(const KgwLayerArgs* a, kgw_stream_t stream_
     AggPtrs P = build_ptrs(a);
     hipStream_t st = (hipStream_t)stream_;
     if (a->ev_before) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_before, st));
-    if (P.raw) k_agg_fwd<true><<<grid_for_waves(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
-    else       k_agg_fwd<false><<<grid_for_waves(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
+    if (P.raw) k_agg_fwd<true><<<grid_fine(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
+    else       k_agg_fwd<false><<<grid_fine(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
     KGW_LAUNCH_CHECK();
     if (a->ev_after) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_after, st));
     if (a->multi && a->multi_cap > 0) {     // hub rows: the number of multi-chunk segments is read on the device
@@ -770,7 +783,7 @@ extern "C" int kgw_gat_aggregate_bwd_dst(const KgwLayerArgs* a, kgw_stream_t str
     AggPtrs P = build_ptrs(a);
     hipStream_t st = (hipStream_t)stream_;
     if (a->ev_before) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_before, st));
-    k_agg_bwd_dst<<<grid_for_waves(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
+    k_agg_bwd_dst<<<grid_fine(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
     KGW_LAUNCH_CHECK();
     if (a->ev_after) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_after, st));
     if (a->multi && a->multi_cap > 0) {
@@ -790,7 +803,7 @@ extern "C" int kgw_gat_aggregate_bwd_src(const KgwLayerArgs* a, kgw_stream_t str
     if (rc) return rc;
     AggPtrs P = build_ptrs(a);
     if (a->ev_before) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_before, (hipStream_t)stream_));
-    k_agg_bwd_src<<<grid_for_waves(a->n_src_rows), KGW_BLK, 0, (hipStream_t)stream_>>>(T, P, a->n_src_rows);
+    k_agg_bwd_src<<<grid_fine((a->n_src_rows + 1) / 2), KGW_BLK, 0, (hipStream_t)stream_>>>(T, P, a->n_src_rows);
     KGW_LAUNCH_CHECK();
     if (a->ev_after) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_after, (hipStream_t)stream_));
     return KGW_OK;
