@@ -548,7 +548,9 @@ __device__ __forceinline__ void bwd_src_one_row(const LayerTab& T, const AggPtrs
 // whole wavefront per row spends its (VALU-issue bound) instructions on two live lanes.  Here lane hl of a half
 // owns entry hl of ITS row during the gather / per-slot phase and float4 hl of the row's 128-float dH during the
 // accumulation; per-slot sums are 32-lane reductions (DPP + one permlane16 swap).  Taken when both rows are real, of
-// the same node type and have at most 32 entries each.
+// the same node type and have at most KGW_PAIR_MAX entries each (processed in blocks of 32 per half): that covers the
+// SNP rows (mean 2 entries) and 99 % of the gene / GO rows (mean ~35, which hold 70 % of all entries).
+constexpr int KGW_PAIR_MAX = 128;
 __device__ __forceinline__ bool bwd_src_row_pair(const LayerTab& T, const AggPtrs& P, int u) {
     const int lane = kgw_lane(), half = lane >> 5, hl = lane & 31, hb = half << 5;
     int ty = 0;
@@ -564,46 +566,52 @@ __device__ __forceinline__ bool bwd_src_row_pair(const LayerTab& T, const AggPtr
     const int tpv = (hl <= Rs) ? P.t_ptr[tb + hl] : 0;
     const int p0 = __shfl(tpv, hb, 64), p1 = __shfl(tpv, hb + Rs, 64);
     const int n = p1 - p0;
-    if (__ballot(n > 32)) return false;
+    if (__ballot(n > KGW_PAIR_MAX)) return false;
     const int tpn = __shfl_down(tpv, 1, 64);
     const unsigned long long bal = __ballot(hl < Rs && tpn > tpv);
     const unsigned slots_any = (unsigned)(bal | (bal >> 32));              // slots used by either row
-    int te = 0, tz = 0;
-    float al = 0.f, dp = 0.f;
-    if (hl < n) {
-        te = P.t_edge[p0 + hl];
-        tz = P.t_zrow[p0 + hl];
-        const float2 a2 = ((const float2*)P.adp)[te];
-        al = a2.x; dp = a2.y;
-    }
-    // per-slot sums of d pre-activation, each half over its own row
-    float dasv = 0.f;                                                      // lane hl == k of a half: d a_src of slot k
-    for (unsigned left = slots_any; left; left &= left - 1) {
-        const int k = __builtin_ctz(left);
-        const int s0 = __shfl(tpv, hb + k, 64), s1 = __shfl(tpv, hb + k + 1, 64);
-        const int pos = p0 + hl;
-        const float v = (hl < n && pos >= s0 && pos < s1) ? dp : 0.f;
-        const float sk = kgw_half_allsum(v);
-        dasv += (hl == k) ? sk : 0.f;
-    }
-    // dH row = sum over the row's entries of alpha * dZ[z row], four entries in flight
     const float4* dZ4 = (const float4*)P.dZ;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int nmax = max(__shfl(n, 0, 64), __shfl(n, 32, 64));
-    for (int i0 = 0; i0 < nmax; i0 += 4) {
-        float4 x[4];
-        float w[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = i0 + q;
-            const bool valid = i < n;
-            const int z = __shfl(tz, hb + (valid ? i : 0), 64);
-            const float a = __shfl(al, hb + (valid ? i : 0), 64);
-            w[q] = valid ? a : 0.f;
-            x[q] = dZ4[(int64_t)z * 32 + hl];
+    float dasv = 0.f;                                                      // lane hl == k of a half: d a_src of slot k
+    const int nall = max(__shfl(n, 0, 64), __shfl(n, 32, 64));
+    // the rows' entries in blocks of 32 per half (gene / GO rows average ~35 entries: two blocks)
+    for (int b0 = 0; b0 < nall; b0 += 32) {
+        const int nb = min(max(n - b0, 0), 32);                            // entries of this half's row in the block
+        int te = 0, tz = 0;
+        float al = 0.f, dp = 0.f;
+        if (hl < nb) {
+            te = P.t_edge[p0 + b0 + hl];
+            tz = P.t_zrow[p0 + b0 + hl];
+            const float2 a2 = ((const float2*)P.adp)[te];
+            al = a2.x; dp = a2.y;
         }
+        // per-slot sums of d pre-activation, each half over its own row (slots that miss the block in both rows skipped)
+        const int pos = p0 + b0 + hl;
+        for (unsigned left = slots_any; left; left &= left - 1) {
+            const int k = __builtin_ctz(left);
+            const int s0 = __shfl(tpv, hb + k, 64), s1 = __shfl(tpv, hb + k + 1, 64);
+            const bool in = hl < nb && pos >= s0 && pos < s1;
+            if (!__ballot(in)) continue;
+            const float sk = kgw_half_allsum(in ? dp : 0.f);
+            dasv += (hl == k) ? sk : 0.f;
+        }
+        // dH row += sum over the block's entries of alpha * dZ[z row], four entries in flight
+        const int nmax = min(nall - b0, 32);
+        for (int i0 = 0; i0 < nmax; i0 += 4) {
+            float4 x[4];
+            float w[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) fma4(acc, w[q], x[q]);
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q;
+                const bool valid = i < nb;
+                const int z = __shfl(tz, hb + (valid ? i : 0), 64);
+                const float a = __shfl(al, hb + (valid ? i : 0), 64);
+                w[q] = valid ? a : 0.f;
+                x[q] = dZ4[(int64_t)z * 32 + hl];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fma4(acc, w[q], x[q]);
+        }
     }
     // d a_src flows back into h_src through a_s = <h_src, u_r>
     for (unsigned left = slots_any; left; left &= left - 1) {
@@ -649,9 +657,12 @@ __device__ __forceinline__ bool bwd_src_row_pair(const LayerTab& T, const AggPtr
 
 __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, int n_src_rows) {
     const int nw = gridDim.x * 4;
-    // a wavefront takes source rows two at a time
-    for (int u0 = 2 * (blockIdx.x * 4 + (threadIdx.x >> 6)); u0 < n_src_rows; u0 += 2 * nw) {
-        const int u = __builtin_amdgcn_readfirstlane(u0);
+    const int npairs = (n_src_rows + 1) >> 1;
+    // a wavefront takes source rows two at a time, LAST rows first: the layout is type-major with the SNPs (short rows,
+    // most of the rows) in front and the genes / GO terms (rows of up to thousands of entries, one wavefront each) at
+    // the end -- the long rows must start at the beginning of the kernel, not in the last round
+    for (int i0 = blockIdx.x * 4 + (threadIdx.x >> 6); i0 < npairs; i0 += nw) {
+        const int u = __builtin_amdgcn_readfirstlane(2 * (npairs - 1 - i0));
         if (u + 1 < n_src_rows && bwd_src_row_pair(T, P, u)) continue;
         bwd_src_one_row(T, P, u);
         if (u + 1 < n_src_rows) bwd_src_one_row(T, P, u + 1);
