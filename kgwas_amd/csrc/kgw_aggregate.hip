@@ -551,7 +551,7 @@ __device__ __forceinline__ void bwd_src_one_row(const LayerTab& T, const AggPtrs
 // the same node type and have at most KGW_PAIR_MAX entries each (processed in blocks of 32 per half): that covers the
 // SNP rows (mean 2 entries) and 99 % of the gene / GO rows (mean ~35, which hold 70 % of all entries).
 constexpr int KGW_PAIR_MAX = 128;
-__device__ __forceinline__ bool bwd_src_row_pair(const LayerTab& T, const AggPtrs& P, int u) {
+__device__ __forceinline__ bool bwd_src_row_pair(const LayerTab& T, const AggPtrs& P, int u, float* wdp) {
     const int lane = kgw_lane(), half = lane >> 5, hl = lane & 31, hb = half << 5;
     int ty = 0;
     while (ty + 1 < T.n_types && u >= T.type_src_base[ty + 1]) ++ty;
@@ -574,44 +574,70 @@ __device__ __forceinline__ bool bwd_src_row_pair(const LayerTab& T, const AggPtr
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float dasv = 0.f;                                                      // lane hl == k of a half: d a_src of slot k
     const int nall = max(__shfl(n, 0, 64), __shfl(n, 32, 64));
-    // the rows' entries in blocks of 32 per half (gene / GO rows average ~35 entries: two blocks)
+    // the rows' entries in blocks of 32 per half (gene / GO rows average ~35 entries: two blocks).  The load chain
+    // entries -> (alpha, d pre-activation) / dZ rows is unrolled across blocks: the NEXT block's entries and this block's
+    // alphas are requested before this block's gathers, and the gathers (which need the Z rows only) before the alphas
+    // are waited for.
+    int te = 0, tz = 0;
+    if (hl < min(n, 32)) {
+        te = P.t_edge[p0 + hl];
+        tz = P.t_zrow[p0 + hl];
+    }
     for (int b0 = 0; b0 < nall; b0 += 32) {
         const int nb = min(max(n - b0, 0), 32);                            // entries of this half's row in the block
-        int te = 0, tz = 0;
-        float al = 0.f, dp = 0.f;
-        if (hl < nb) {
-            te = P.t_edge[p0 + b0 + hl];
-            tz = P.t_zrow[p0 + b0 + hl];
-            const float2 a2 = ((const float2*)P.adp)[te];
-            al = a2.x; dp = a2.y;
+        float2 a2 = make_float2(0.f, 0.f);
+        if (hl < nb) a2 = ((const float2*)P.adp)[te];
+        int te_n = 0, tz_n = 0;
+        if (hl < min(max(n - b0 - 32, 0), 32)) {
+            te_n = P.t_edge[p0 + b0 + 32 + hl];
+            tz_n = P.t_zrow[p0 + b0 + 32 + hl];
         }
-        // per-slot sums of d pre-activation, each half over its own row (slots that miss the block in both rows skipped)
-        const int pos = p0 + b0 + hl;
-        for (unsigned left = slots_any; left; left &= left - 1) {
-            const int k = __builtin_ctz(left);
-            const int s0 = __shfl(tpv, hb + k, 64), s1 = __shfl(tpv, hb + k + 1, 64);
-            const bool in = hl < nb && pos >= s0 && pos < s1;
-            if (!__ballot(in)) continue;
-            const float sk = kgw_half_allsum(in ? dp : 0.f);
-            dasv += (hl == k) ? sk : 0.f;
-        }
-        // dH row += sum over the block's entries of alpha * dZ[z row], four entries in flight
+        // dH row += sum over the block's entries of alpha * dZ[z row], eight (row tails: four) gathers in flight per half
         const int nmax = min(nall - b0, 32);
-        for (int i0 = 0; i0 < nmax; i0 += 4) {
-            float4 x[4];
-            float w[4];
+        int i0 = 0;
+        for (; i0 + 4 < nmax; i0 += 8) {
+            float4 x[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 8; ++q) {
                 const int i = i0 + q;
-                const bool valid = i < nb;
-                const int z = __shfl(tz, hb + (valid ? i : 0), 64);
-                const float a = __shfl(al, hb + (valid ? i : 0), 64);
-                w[q] = valid ? a : 0.f;
+                const int z = __shfl(tz, hb + (i < nb ? i : 0), 64);
                 x[q] = dZ4[(int64_t)z * 32 + hl];
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) fma4(acc, w[q], x[q]);
+            for (int q = 0; q < 8; ++q) {
+                const int i = i0 + q;
+                const float a = __shfl(a2.x, hb + (i < nb ? i : 0), 64);
+                fma4(acc, i < nb ? a : 0.f, x[q]);
+            }
         }
+        for (; i0 < nmax; i0 += 4) {
+            float4 x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q;
+                const int z = __shfl(tz, hb + (i < nb ? i : 0), 64);
+                x[q] = dZ4[(int64_t)z * 32 + hl];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q;
+                const float a = __shfl(a2.x, hb + (i < nb ? i : 0), 64);
+                fma4(acc, i < nb ? a : 0.f, x[q]);
+            }
+        }
+        // per-slot sums of d pre-activation: the block's values go through the wavefront's 64 floats of LDS and lane k
+        // of a half adds up slot k's range of ITS row, entries in ascending order -- all slots in parallel, as many steps
+        // as the longest slot of the block has entries
+        wdp[lane] = (hl < nb) ? a2.y : 0.f;
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (hl < Rs) {
+            const int a = max(tpv - (p0 + b0), 0), b = min(tpn - (p0 + b0), nb);
+            float sk = 0.f;
+            for (int i = a; i < b; ++i) sk += wdp[hb + i];
+            dasv += sk;
+        }
+        __asm__ volatile("" ::: "memory");
+        te = te_n; tz = tz_n;
     }
     // d a_src flows back into h_src through a_s = <h_src, u_r>
     for (unsigned left = slots_any; left; left &= left - 1) {
@@ -656,6 +682,8 @@ __device__ __forceinline__ bool bwd_src_row_pair(const LayerTab& T, const AggPtr
 }
 
 __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, int n_src_rows) {
+    __shared__ float s_dp[KGW_BLK];                           // 64 floats per wavefront (bwd_src_row_pair)
+    float* wdp = s_dp + (threadIdx.x & ~63);
     const int nw = gridDim.x * 4;
     const int npairs = (n_src_rows + 1) >> 1;
     // a wavefront takes source rows two at a time, LAST rows first: the layout is type-major with the SNPs (short rows,
@@ -663,7 +691,7 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, 
     // the end -- the long rows must start at the beginning of the kernel, not in the last round
     for (int i0 = blockIdx.x * 4 + (threadIdx.x >> 6); i0 < npairs; i0 += nw) {
         const int u = __builtin_amdgcn_readfirstlane(2 * (npairs - 1 - i0));
-        if (u + 1 < n_src_rows && bwd_src_row_pair(T, P, u)) continue;
+        if (u + 1 < n_src_rows && bwd_src_row_pair(T, P, u, wdp)) continue;
         bwd_src_one_row(T, P, u);
         if (u + 1 < n_src_rows) bwd_src_one_row(T, P, u + 1);
     }
