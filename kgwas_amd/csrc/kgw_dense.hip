@@ -1048,29 +1048,56 @@ constexpr int ADAM_MAX = 64;
 struct AdamTab {
     float* p[ADAM_MAX]; const float* g[ADAM_MAX]; float* m[ADAM_MAX]; float* v[ADAM_MAX];
     int64_t off[ADAM_MAX + 1];      // prefix sums of element counts
+    int64_t coff[ADAM_MAX + 1];     // prefix sums of 1024-element work units
+    unsigned char vec[ADAM_MAX];    // all four pointers 16-byte aligned: float4 path
     int n;
 };
 
+// Work unit = 1024 consecutive elements of ONE tensor (256 threads x float4); the tensor of a unit is found once per
+// unit with wave-uniform (scalar) comparisons, not per element.
 __global__ void __launch_bounds__(256) k_adam(AdamTab T, int32_t* step, float lr, float b1, float b2, float eps, float wd) {
     const int t_now = *step + 1;                       // every thread reads the same pre-increment value
     const float bc1 = 1.0f - powf(b1, (float)t_now);
     const float bc2 = 1.0f - powf(b2, (float)t_now);
     const float step_size = lr / bc1;
     const float bc2_sqrt = sqrtf(bc2);
-    const int64_t total = T.off[T.n];
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t units = T.coff[T.n];
+    for (int64_t c = blockIdx.x; c < units; c += gridDim.x) {
         int lo = 0, hi = T.n;
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (T.off[mid] <= i) lo = mid; else hi = mid; }
-        const int64_t j = i - T.off[lo];
-        float p = T.p[lo][j];
-        float g = T.g[lo][j];
-        g = fmaf(wd, p, g);
-        float m = T.m[lo][j], v = T.v[lo][j];
-        m = m + (1.0f - b1) * (g - m);
-        v = v * b2 + (1.0f - b2) * g * g;
-        const float denom = sqrtf(v) / bc2_sqrt + eps;
-        p = p - step_size * (m / denom);
-        T.m[lo][j] = m; T.v[lo][j] = v; T.p[lo][j] = p;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (T.coff[mid] <= c) lo = mid; else hi = mid; }
+        const int64_t n = T.off[lo + 1] - T.off[lo];
+        const int64_t j = (c - T.coff[lo]) * 1024 + (int64_t)threadIdx.x * 4;
+        float* __restrict__ P = T.p[lo];
+        const float* __restrict__ G = T.g[lo];
+        float* __restrict__ M = T.m[lo];
+        float* __restrict__ V = T.v[lo];
+        if (j + 4 <= n && T.vec[lo]) {
+            float4 p = *(float4*)(P + j), m = *(float4*)(M + j), v = *(float4*)(V + j);
+            const float4 g0 = *(const float4*)(G + j);
+            float pe[4] = {p.x, p.y, p.z, p.w}, ge[4] = {g0.x, g0.y, g0.z, g0.w}, me[4] = {m.x, m.y, m.z, m.w}, ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g = fmaf(wd, pe[e], ge[e]);
+                me[e] = me[e] + (1.0f - b1) * (g - me[e]);
+                ve[e] = ve[e] * b2 + (1.0f - b2) * g * g;
+                const float denom = sqrtf(ve[e]) / bc2_sqrt + eps;
+                pe[e] = pe[e] - step_size * (me[e] / denom);
+            }
+            *(float4*)(M + j) = make_float4(me[0], me[1], me[2], me[3]);
+            *(float4*)(V + j) = make_float4(ve[0], ve[1], ve[2], ve[3]);
+            *(float4*)(P + j) = make_float4(pe[0], pe[1], pe[2], pe[3]);
+        } else {
+            for (int64_t i = j; i < n && i < j + 4; ++i) {
+                float p = P[i];
+                const float g = fmaf(wd, p, G[i]);
+                float m = M[i], v = V[i];
+                m = m + (1.0f - b1) * (g - m);
+                v = v * b2 + (1.0f - b2) * g * g;
+                const float denom = sqrtf(v) / bc2_sqrt + eps;
+                p = p - step_size * (m / denom);
+                M[i] = m; V[i] = v; P[i] = p;
+            }
+        }
     }
 }
 
@@ -1087,14 +1114,17 @@ extern "C" int kgw_adam(int32_t n_tensors, float* const* params, const float* co
     AdamTab T;
     T.n = n_tensors;
     T.off[0] = 0;
+    T.coff[0] = 0;
     for (int i = 0; i < n_tensors; ++i) {
         if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] < 0) return KGW_E_NULL;
         T.p[i] = params[i]; T.g[i] = grads[i]; T.m[i] = exp_avg[i]; T.v[i] = exp_avg_sq[i];
         T.off[i + 1] = T.off[i] + numel[i];
+        T.coff[i + 1] = T.coff[i] + (numel[i] + 1023) / 1024;
+        T.vec[i] = (((uintptr_t)params[i] | (uintptr_t)grads[i] | (uintptr_t)exp_avg[i] | (uintptr_t)exp_avg_sq[i]) & 15) == 0;
     }
     hipStream_t st = (hipStream_t)stream_;
-    int64_t g = (T.off[n_tensors] + 255) / 256;
-    if (g > KGW_GRID) g = KGW_GRID;
+    int64_t g = T.coff[n_tensors];
+    if (g > 4 * KGW_GRID) g = 4 * KGW_GRID;
     if (g < 1) g = 1;
     k_adam<<<(int)g, 256, 0, st>>>(T, step_dev, lr, beta1, beta2, eps, weight_decay);
     KGW_LAUNCH_CHECK();
