@@ -97,6 +97,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--scale', type=float, default=1.0, help='SynthKG scale (1.0 = reference size)')
     ap.add_argument('--batch-size', type=int, default=512)
+    ap.add_argument('--snp-scale', type=float, default=1.0,
+                    help='multiply the SNP count and the SNP->Gene edges only (12.75 = the ~10 M-SNP full-cohort case of BASELINE.json configs[3]); not the headline workload')
     ap.add_argument('--mode', default='fast', choices=['fast', 'full'],
                     help="feature widths: 'fast' 20/5120/128 (BASELINE.json configs[1], the default) or 'full' 70/57742/128 (configs[4])")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -132,7 +134,7 @@ def main():
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):        # stdout carries exactly one JSON line
         data = KGWAS_Data.from_synthetic(scale=args.scale, seed=1, mode=args.mode, gwas_kind='causal',
-                                         data_path=f'/tmp/kgwas_bench_{rank}')
+                                         data_path=f'/tmp/kgwas_bench_{rank}', snp_scale=args.snp_scale)
     run = KGWAS(data, device=dev, seed=1)
     run.initialize_model()
     if world > 1:
@@ -272,10 +274,15 @@ def main():
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': ('SynthKG-fast full KG (784256 SNP / 20032 Gene / ~20.6M directed edges; features '
                                 '20/5120/128) + causal-simulation GWAS seed=1, batch 512 seeds per GPU, 2-layer GAT-128, '
-                                'Adam(1e-4, wd 5e-4) -- BASELINE.json configs[1]') if args.mode == 'fast' else
+                                'Adam(1e-4, wd 5e-4) -- BASELINE.json configs[1]') if (args.mode == 'fast' and args.snp_scale == 1.0 and args.scale == 1.0) else
+                               (f'SynthKG-fast with scale={args.scale}, snp_scale={args.snp_scale} (see config.graph) -- NOT the headline configuration; '
+                                'snp_scale 12.75 is the ~10 M-SNP full-cohort case of BASELINE.json configs[3] on ONE GPU') if args.mode == 'fast' else
                                ('SynthKG-full: same graph, full-mode feature widths 70/57742/128 -- BASELINE.json configs[4] '
                                 'on one GPU, not the headline configuration'),
-                   'scale': args.scale, 'batch_size_per_gpu': bs, 'parallelism': f'seed-dp{world}', 'execution': mode,
+                   'scale': args.scale, 'snp_scale': args.snp_scale,
+                   'graph': {'nodes': {t: int(data.data[t].x.shape[0]) for t in data.data.node_types},
+                             'directed_edges': int(sum(data.data[et].edge_index.shape[1] for et in data.data.edge_types))},
+                   'batch_size_per_gpu': bs, 'parallelism': f'seed-dp{world}', 'execution': mode,
                    'edges_per_step_kernel': edges_kernel / args.steps / world,
                    'edges_per_step_reference_equivalent': edges_ref / args.steps / world,
                    'reference_equivalent_edges_per_s': edges_ref / elapsed,

@@ -120,12 +120,12 @@ class KGWAS_Data:
 
     @classmethod
     def from_synthetic(cls, scale=1.0, seed=1, mode='fast', data_path='/tmp/kgwas_synth', n_labelled=None,
-                       gwas_kind='causal', sample_size=5000, feat_dims=None, split=True):
+                       gwas_kind='causal', sample_size=5000, feat_dims=None, split=True, snp_scale=1.0):
         """SynthKG + synthetic summary statistics through the same pipeline as the real files."""
         import pandas as pd
         from .synth import FEAT_DIMS, make_synth_edges, make_synth_gwas
         self = cls(data_path)
-        edges, nc = make_synth_edges(scale, seed)
+        edges, nc = make_synth_edges(scale, seed, snp_scale=snp_scale)
         dims = dict(FEAT_DIMS[mode])
         if feat_dims:
             dims.update(feat_dims)

@@ -53,10 +53,13 @@ def _heavy_tail_weights(rng, n, sigma):
     return w / w.sum()
 
 
-def make_synth_edges(scale: float = 1.0, seed: int = 1, node_counts=None):
-    """Original directed COO lists, dict (src, rel, dst) -> int64[2, E], plus node counts."""
+def make_synth_edges(scale: float = 1.0, seed: int = 1, node_counts=None, snp_scale: float = 1.0):
+    """Original directed COO lists, dict (src, rel, dst) -> int64[2, E], plus node counts.  ``snp_scale`` multiplies
+    the SNP count and the SNP->Gene edge counts on top of ``scale`` (a denser genotyping array over the same genes:
+    BASELINE.json's ~10 M-SNP full-cohort case is snp_scale = 12.75)."""
     rng = np.random.default_rng(seed)
-    nc = OrderedDict((k, max(8, int(round(v * scale)))) for k, v in (node_counts or NODE_COUNTS).items())
+    nc = OrderedDict((k, max(8, int(round(v * scale * (snp_scale if k == 'SNP' else 1.0)))))
+                     for k, v in (node_counts or NODE_COUNTS).items())
     n_snp, n_gene = nc['SNP'], nc['Gene']
     edges: "OrderedDict[tuple, np.ndarray]" = OrderedDict()
 
@@ -66,7 +69,7 @@ def make_synth_edges(scale: float = 1.0, seed: int = 1, node_counts=None):
                   2, max(4, n_snp // 50)).astype(np.int64)
     gene_pop = _heavy_tail_weights(rng, n_gene, 1.0)
     for rel, e_full in V2G.items():
-        e = max(4, int(round(e_full * scale)))
+        e = max(4, int(round(e_full * scale * snp_scale)))
         if rel == 'TSS':   # every SNP -> nearest gene centre (exactly one edge per SNP)
             snp = np.arange(n_snp, dtype=np.int64)
             pos = np.searchsorted(centre, snp)
