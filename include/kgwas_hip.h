@@ -125,6 +125,10 @@ typedef struct KgwBatchBuf {
     KgwBatchMeta* meta;    /* device                                                           */
     KgwBatchMeta* meta_host; /* pinned host mirror (async D2H at the end of sampling)          */
     int64_t seg_cap, edge_cap, chunk_cap, multi_cap, trow_cap, scan_cap;
+    int32_t grid_blocks;   /* blocks of the sampler's grid-stride launches; 0 = default (2048: the call has the GPU to
+                              itself).  A sampler replayed BESIDE a training step (second HIP graph on a side stream)
+                              should stay small -- 256 measured best: -4 % step time vs 2048, +0.1 ms sampler time    */
+    int32_t pad_;
 } KgwBatchBuf;
 
 /* One attention-aggregate layer over a sampled batch (kgwas/conv.py:177-190 for every relation

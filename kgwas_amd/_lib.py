@@ -80,6 +80,7 @@ class KgwBatchBuf(C.Structure):
         ('scan_tmp', C.c_void_p), ('t_tmp', C.c_void_p), ('meta', C.c_void_p), ('meta_host', C.c_void_p),
         ('seg_cap', C.c_int64), ('edge_cap', C.c_int64), ('chunk_cap', C.c_int64),
         ('multi_cap', C.c_int64), ('trow_cap', C.c_int64), ('scan_cap', C.c_int64),
+        ('grid_blocks', C.c_int32), ('pad_', C.c_int32),
     ]
 
 

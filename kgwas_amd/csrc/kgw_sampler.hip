@@ -541,6 +541,10 @@ extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, c
                                 int32_t n_seeds, int32_t seed_type, int32_t full_graph,
                                 kgw_stream_t stream_) {
     if (!graph || !buf) return KGW_E_NULL;
+    // grid of the sampler's grid-stride kernels: KgwBatchBuf.grid_blocks (a sampler replayed BESIDE a training step keeps
+    // its launches small), else the whole-GPU default
+    static const int sg_env = getenv("KGW_SAMPLER_GRID") ? atoi(getenv("KGW_SAMPLER_GRID")) : 0;
+    const int SG = sg_env > 0 ? sg_env : (buf->grid_blocks > 0 ? (buf->grid_blocks < KGW_GRID ? buf->grid_blocks : KGW_GRID) : KGW_GRID);
     if (!full_graph && (!seeds || n_seeds <= 0)) return KGW_E_NULL;
     if (graph->n_types < 1 || graph->n_types > KGW_MAX_TYPES || graph->n_rels < 1 ||
         graph->n_rels > KGW_MAX_RELS || graph->n_layers < 1 || graph->n_layers > KGW_MAX_LAYERS ||
@@ -563,26 +567,26 @@ extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, c
 
     for (int h = 0; h < graph->n_hops; ++h) {
         k_hop_begin<<<1, 64, 0, st>>>(A, h);
-        k_seg_deg<<<KGW_GRID, KGW_BLK, 0, st>>>(A, h);
-        k_scan_tiles<2><<<KGW_GRID, KGW_BLK, 0, st>>>(buf->seg_deg, buf->seg_nch, buf->meta, buf->scan_tmp);
+        k_seg_deg<<<SG, KGW_BLK, 0, st>>>(A, h);
+        k_scan_tiles<2><<<SG, KGW_BLK, 0, st>>>(buf->seg_deg, buf->seg_nch, buf->meta, buf->scan_tmp);
         k_scan_top<2><<<1, KGW_BLK, 0, st>>>(buf->scan_tmp, buf->meta, 1);
-        k_scan_apply<2><<<KGW_GRID, KGW_BLK, 0, st>>>(buf->seg_deg, buf->seg_nch, buf->seg_ptr,
+        k_scan_apply<2><<<SG, KGW_BLK, 0, st>>>(buf->seg_deg, buf->seg_nch, buf->seg_ptr,
                                                       buf->seg_chptr, buf->meta, buf->scan_tmp);
         k_hop_mid<<<1, 64, 0, st>>>(A, h);
-        k_fill_chunks<<<KGW_GRID, KGW_BLK, 0, st>>>(A, h);
+        k_fill_chunks<<<SG, KGW_BLK, 0, st>>>(A, h);
         KGW_LAUNCH_CHECK();
         if (!full_graph) {
-            k_mark<<<KGW_GRID, KGW_BLK, 0, st>>>(A, h);
-            k_count_pending<<<KGW_GRID, KGW_BLK, 0, st>>>(A, buf->scan_tmp, ntiles_nodes);
+            k_mark<<<SG, KGW_BLK, 0, st>>>(A, h);
+            k_count_pending<<<SG, KGW_BLK, 0, st>>>(A, buf->scan_tmp, ntiles_nodes);
             k_scan_top_fixed<<<1, KGW_BLK, 0, st>>>(buf->scan_tmp, ntiles_nodes);
-            k_assign<<<KGW_GRID, KGW_BLK, 0, st>>>(A, buf->scan_tmp, ntiles_nodes, h);
+            k_assign<<<SG, KGW_BLK, 0, st>>>(A, buf->scan_tmp, ntiles_nodes, h);
             k_hop_end<<<1, 64, 0, st>>>(A, buf->scan_tmp, h);
         } else {
             // every node is already a seed: hop h+1 adds nothing
             { int rc = fill_i32(buf->scan_tmp, 0, ntiles_nodes + 2, st); if (rc) return rc; }
             k_hop_end<<<1, 64, 0, st>>>(A, buf->scan_tmp, h);
         }
-        k_relabel<<<KGW_GRID, KGW_BLK, 0, st>>>(A, h);
+        k_relabel<<<SG, KGW_BLK, 0, st>>>(A, h);
         KGW_LAUNCH_CHECK();
     }
     k_layer_tables<<<1, 64, 0, st>>>(A);
@@ -593,14 +597,14 @@ extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, c
             return KGW_E_NULL;
         { int rc = fill_i32(buf->t_cnt[l - 1], 0, buf->trow_cap + 1, st); if (rc) return rc; }
         k_t_begin<<<1, 64, 0, st>>>(A, l);
-        k_t_pass<false><<<KGW_GRID, KGW_BLK, 0, st>>>(A, l);
-        k_scan_tiles<1><<<KGW_GRID, KGW_BLK, 0, st>>>(buf->t_cnt[l - 1], nullptr, buf->meta, buf->scan_tmp);
+        k_t_pass<false><<<SG, KGW_BLK, 0, st>>>(A, l);
+        k_scan_tiles<1><<<SG, KGW_BLK, 0, st>>>(buf->t_cnt[l - 1], nullptr, buf->meta, buf->scan_tmp);
         k_scan_top<1><<<1, KGW_BLK, 0, st>>>(buf->scan_tmp, buf->meta, 0);
-        k_scan_apply<1><<<KGW_GRID, KGW_BLK, 0, st>>>(buf->t_cnt[l - 1], nullptr, buf->t_ptr[l - 1],
+        k_scan_apply<1><<<SG, KGW_BLK, 0, st>>>(buf->t_cnt[l - 1], nullptr, buf->t_ptr[l - 1],
                                                       nullptr, buf->meta, buf->scan_tmp);
-        k_t_pass<true><<<KGW_GRID, KGW_BLK, 0, st>>>(A, l);
-        k_t_rank<<<KGW_GRID, KGW_BLK, 0, st>>>(A, l);
-        k_t_rank_big<<<KGW_GRID, KGW_BLK, 0, st>>>(A, l);
+        k_t_pass<true><<<SG, KGW_BLK, 0, st>>>(A, l);
+        k_t_rank<<<SG, KGW_BLK, 0, st>>>(A, l);
+        k_t_rank_big<<<SG, KGW_BLK, 0, st>>>(A, l);
         k_t_end<<<1, 64, 0, st>>>(A, l);
         KGW_LAUNCH_CHECK();
     }

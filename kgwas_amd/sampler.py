@@ -196,7 +196,9 @@ class BatchBuffers:
     """Worst-case sized device buffers of one in-flight batch (sized once; 288 GB of HBM makes
     re-allocation pointless)."""
 
-    def __init__(self, dg: DeviceGraph):
+    def __init__(self, dg: DeviceGraph, grid_blocks: int = 0):
+        """``grid_blocks``: blocks of the sampler's launches into this buffer (0 = whole-GPU default); a sampler that runs
+        BESIDE a training step (GraphTrainStep / GraphEvalStep) passes 256."""
         dev = dg.device
         L = dg.num_layers
         i32 = dict(dtype=torch.int32, device=dev)
@@ -231,6 +233,7 @@ class BatchBuffers:
         b.t_tmp = self.t_tmp.data_ptr()
         b.seg_cap, b.edge_cap, b.chunk_cap = dg.seg_cap, dg.edge_cap, dg.chunk_cap
         b.multi_cap, b.trow_cap, b.scan_cap = dg.multi_cap, dg.trow_cap, self.scan_cap
+        b.grid_blocks = int(grid_blocks)
         self.c = b
         self.ready = torch.cuda.Event()      # sampling finished
         self.released: Optional[torch.cuda.Event] = None   # consumer finished with the previous contents
