@@ -54,10 +54,10 @@ __global__ void __launch_bounds__(KGW_BLK) k_fill_i32(int32_t* __restrict__ p, i
     for (int64_t i = (n4 << 2) + tid; i < n; i += nthr) p[i] = v;
 }
 
-inline int fill_i32(int32_t* p, int32_t v, int64_t n, hipStream_t st) {
+inline int fill_i32(int32_t* p, int32_t v, int64_t n, hipStream_t st, int max_blocks = KGW_GRID) {
     if (n <= 0) return KGW_OK;
     int64_t g = (n / 4 + KGW_BLK - 1) / KGW_BLK;
-    if (g > KGW_GRID) g = KGW_GRID;
+    if (g > max_blocks) g = max_blocks;
     if (g < 1) g = 1;
     k_fill_i32<<<(int)g, KGW_BLK, 0, st>>>(p, v, n);
     hipError_t e = hipGetLastError();
@@ -560,7 +560,7 @@ extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, c
     const int ntiles_nodes = total_slots / KGW_TILE;
     if ((int64_t)ntiles_nodes + 2 > buf->scan_cap) return KGW_E_RANGE;
 
-    { int rc = fill_i32(buf->g2l, -1, total_slots, st); if (rc) return rc; }
+    { int rc = fill_i32(buf->g2l, -1, total_slots, st, SG); if (rc) return rc; }
     { int rc = fill_i32((int32_t*)buf->meta, 0, sizeof(KgwBatchMeta) / sizeof(int32_t), st); if (rc) return rc; }
     k_init<<<full_graph ? KGW_GRID : 64, KGW_BLK, 0, st>>>(A, seeds, n_seeds, seed_type, full_graph);
     KGW_LAUNCH_CHECK();
@@ -583,7 +583,7 @@ extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, c
             k_hop_end<<<1, 64, 0, st>>>(A, buf->scan_tmp, h);
         } else {
             // every node is already a seed: hop h+1 adds nothing
-            { int rc = fill_i32(buf->scan_tmp, 0, ntiles_nodes + 2, st); if (rc) return rc; }
+            { int rc = fill_i32(buf->scan_tmp, 0, ntiles_nodes + 2, st, SG); if (rc) return rc; }
             k_hop_end<<<1, 64, 0, st>>>(A, buf->scan_tmp, h);
         }
         k_relabel<<<SG, KGW_BLK, 0, st>>>(A, h);
@@ -595,7 +595,7 @@ extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, c
     for (int l = 1; l <= graph->n_layers; ++l) {
         if (!buf->t_cnt[l - 1] || !buf->t_ptr[l - 1] || !buf->t_edge[l - 1] || !buf->t_zrow[l - 1] || !buf->t_tmp)
             return KGW_E_NULL;
-        { int rc = fill_i32(buf->t_cnt[l - 1], 0, buf->trow_cap + 1, st); if (rc) return rc; }
+        { int rc = fill_i32(buf->t_cnt[l - 1], 0, buf->trow_cap + 1, st, SG); if (rc) return rc; }
         k_t_begin<<<1, 64, 0, st>>>(A, l);
         k_t_pass<false><<<SG, KGW_BLK, 0, st>>>(A, l);
         k_scan_tiles<1><<<SG, KGW_BLK, 0, st>>>(buf->t_cnt[l - 1], nullptr, buf->meta, buf->scan_tmp);
