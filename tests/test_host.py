@@ -26,10 +26,10 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_abi_struct_sizes_and_argument_checks():
     from kgwas_amd import _lib
     lib = _lib.lib()
-    sizes = (C.c_int64 * 5)()
-    assert lib.kgw_struct_sizes(sizes, 5) == 0
+    sizes = (C.c_int64 * 6)()
+    assert lib.kgw_struct_sizes(sizes, 6) == 0
     assert list(sizes) == [C.sizeof(_lib.KgwGraph), C.sizeof(_lib.KgwBatchMeta), C.sizeof(_lib.KgwChunk),
-                           C.sizeof(_lib.KgwBatchBuf), C.sizeof(_lib.KgwLayerArgs)]
+                           C.sizeof(_lib.KgwBatchBuf), C.sizeof(_lib.KgwLayerArgs), C.sizeof(_lib.KgwTnJob)]
     assert C.sizeof(_lib.KgwChunk) == 32
     # argument errors are reported as negative status codes before any launch
     assert lib.kgw_sample_batch(None, None, None, 0, 0, 0, None) == -1
@@ -38,6 +38,19 @@ def test_abi_struct_sizes_and_argument_checks():
     g = _lib.KgwGraph()
     b = _lib.KgwBatchBuf()
     assert lib.kgw_sample_batch(C.byref(g), C.byref(b), None, 0, 0, 1, None) == -2     # n_types = 0 out of range
+    # the multi-job entry points: nothing to do / null tables / too many jobs / odd shapes -- all before any launch
+    assert lib.kgw_gather_rows_multi(0, None, None, None, 4, None, None) == 0
+    assert lib.kgw_gather_rows_multi(2, None, None, None, 4, None, None) == -1
+    P2, N2 = (C.c_void_p * 9)(), (C.c_int64 * 9)()
+    assert lib.kgw_gather_rows_multi(9, P2, P2, N2, 4, P2, None) == -2
+    assert lib.kgw_tn_gemm_multi(0, None, None) == 0
+    assert lib.kgw_tn_gemm_multi(2, None, None) == -1
+    jobs = (_lib.KgwTnJob * 5)()
+    assert lib.kgw_tn_gemm_multi(5, jobs, None) == -2
+    assert lib.kgw_tn_gemm_multi(1, jobs, None) == -1                                   # null operands
+    assert lib.kgw_scatter_relu_rows(None, None, None, 8, None, None, None, None) == -1
+    assert lib.kgw_scatter_relu_rows_workspace_floats(20032) == 256 * 128
+    assert lib.kgw_tn_gemm_workspace_floats(1000, 128, 128) > 0
 
 
 def test_product_refuses_to_run_without_gpu():
