@@ -892,6 +892,106 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 }
 
+// Same product for FEW row tiles (up to 512: the GO / gene matrices of a batch): with one 32-row tile per wavefront
+// only ntiles of the chip's 1024 SIMDs get work.  Here a wavefront takes one tile x ONE HALF of the output columns
+// (128 MFMAs, 128 registers of W), two wavefronts per SIMD, every task resident at once: no tile loop, no refill.
+template <bool WKN, bool MASK>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_linear_wreg_half(LinArgs a_) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    LinArgs a = a_;
+    {
+        const int64_t re = lin_rows_eff(a_);
+        lin_zero_padding(a_, re, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+        a.rows = re;
+        if ((int64_t)blockIdx.x * 2 * 32 >= re) return;      // (before any barrier: the whole block leaves)
+    }
+    float* Wl = lds;                                         // [128 n][WST], k contiguous; bias behind it
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * 2 + (wave >> 1);
+    const int t0 = (wave & 1) * 2;                            // this wavefront's two 32-column blocks
+    const int64_t row = tile * 32 + li;
+    const bool live = row < a.rows;
+    const int64_t rc = live ? row : a.rows - 1;
+    f32x4 xa[16];
+    {
+        const float* xp = a.X + rc * a.ldx + lk * 64;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xa[q] = *(const f32x4*)(xp + 4 * q);
+    }
+    f32x4 mv[2][4];
+    if (MASK) {
+        const float* mp = a.mask + rc * a.ldm + 4 * lk;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mv[t][g] = *(const f32x4*)(mp + (t0 + t) * 32 + 8 * g);
+    }
+    {   // stage W: all 16 loads of a thread in flight before the first LDS write
+        f32x4 wv[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = tid + 256 * it;
+            if (!WKN) wv[it] = *(const f32x4*)(a.W + (int64_t)(idx >> 5) * a.ldw + (idx & 31) * 4);
+            else wv[it] = *(const f32x4*)(a.W + (int64_t)(idx & 127) * a.ldw + (idx >> 7) * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = tid + 256 * it;
+            if (!WKN) {
+                *(f32x4*)(Wl + (idx >> 5) * WST + (idx & 31) * 4) = wv[it];
+            } else {
+                const int k = idx & 127, n4 = (idx >> 7) * 4;
+                Wl[(n4 + 0) * WST + k] = wv[it].x; Wl[(n4 + 1) * WST + k] = wv[it].y;
+                Wl[(n4 + 2) * WST + k] = wv[it].z; Wl[(n4 + 3) * WST + k] = wv[it].w;
+            }
+        }
+    }
+    if (tid < 128) Wl[128 * WST + tid] = a.bias ? a.bias[tid] : 0.f;
+    __syncthreads();
+    f32x4 bw[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bw[t][q] = *(const f32x4*)(Wl + ((t0 + t) * 32 + li) * WST + lk * 64 + 4 * q);
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[t][q].x, xa[q].x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[t][q].y, xa[q].y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[t][q].z, xa[q].z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[t][q].w, xa[q].w, acc[t], 0, 0, 0);
+    }
+    if (live) {
+        const float* bl = Wl + 128 * WST + 4 * lk;
+        float* yp = a.Y + row * a.ldy + 4 * lk;
+        const float lo = a.relu ? 0.f : -__builtin_inff();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *(const f32x4*)(bl + (t0 + t) * 32 + 8 * g);
+                f32x4 v;
+                v.x = fmaxf(acc[t][4 * g + 0] + b4.x, lo); v.y = fmaxf(acc[t][4 * g + 1] + b4.y, lo);
+                v.z = fmaxf(acc[t][4 * g + 2] + b4.z, lo); v.w = fmaxf(acc[t][4 * g + 3] + b4.w, lo);
+                if (MASK) {
+                    v.x = mv[t][g].x > 0.f ? v.x : 0.f; v.y = mv[t][g].y > 0.f ? v.y : 0.f;
+                    v.z = mv[t][g].z > 0.f ? v.z : 0.f; v.w = mv[t][g].w > 0.f ? v.w : 0.f;
+                }
+                *(f32x4*)(yp + (t0 + t) * 32 + 8 * g) = v;
+            }
+        }
+    }
+}
+
 template <bool WKN>
 int launch_wreg(const LinArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(128 * WST + 128) * sizeof(float);
@@ -901,7 +1001,23 @@ int launch_wreg(const LinArgs& a, hipStream_t st) {
         KGW_HIP(hipFuncSetAttribute((const void*)k_linear_wreg<WKN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const int64_t nblk = ((a.rows + 31) / 32 + 3) / 4;
+    const int64_t ntiles = (a.rows + 31) / 32;
+    static const int64_t half_max = getenv("KGW_WREG_HALF_MAX_TILES") ? atoll(getenv("KGW_WREG_HALF_MAX_TILES")) : 512;
+    // (measured in the step: 1.648 ms with the half-tile kernel up to 512 tiles, 1.653 up to 1024, 1.671 without it)
+    if (ntiles <= half_max) {                                 // few tiles: one (tile, column half) per wavefront, all resident
+        static bool attr_half = false;
+        if (!attr_half) {
+            KGW_HIP(hipFuncSetAttribute((const void*)k_linear_wreg_half<WKN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            KGW_HIP(hipFuncSetAttribute((const void*)k_linear_wreg_half<WKN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_half = true;
+        }
+        const int grid = (int)((ntiles + 1) / 2);
+        if (a.mask) k_linear_wreg_half<WKN, true><<<grid, 256, lds, st>>>(a);
+        else k_linear_wreg_half<WKN, false><<<grid, 256, lds, st>>>(a);
+        KGW_LAUNCH_CHECK();
+        return KGW_OK;
+    }
+    const int64_t nblk = (ntiles + 3) / 4;
     const int grid = (int)(nblk < 256 ? nblk : 256);
     if (a.mask) k_linear_wreg<WKN, true><<<grid, 256, lds, st>>>(a);
     else k_linear_wreg<WKN, false><<<grid, 256, lds, st>>>(a);

@@ -91,7 +91,9 @@ def test_mlp_nodes_match_autograd():
                                          # tall 128 x 128: the weights-in-registers variant (both weight layouts,
                                          # whole tiles only / a ragged last tile / fewer tiles than wavefronts)
                                          (120003, 128, 128, True), (32768, 128, 128, False), (40001, 128, 128, True),
-                                         (262144 + 17, 128, 128, False)])
+                                         (262144 + 17, 128, 128, False),
+                                         # up to 512 row tiles: one (tile, column half) per wavefront
+                                         (16384, 128, 128, False), (4097, 128, 128, True), (16385, 128, 128, True)])
 def test_linear_kernel_matches_fp64(rows, K, N, kn):
     from kgwas_amd import ops
     g = torch.Generator().manual_seed(rows + K)
