@@ -279,11 +279,13 @@ int kgw_adam(int32_t n_tensors, float* const* params, const float* const* grads,
  * layer does not compute) -- the form kgw_gat_aggregate_* consume.
  * Optional (bias != NULL): bias_sum[b] = sum of bias[i] over the packed relations i with blk_of_live[i] == b, the
  * bias of the relation-summed output of destination block b (HeteroConv sum of conv.py:190's bias, model.py:74).
+ * Optional (zero_buf != NULL): zero_floats (multiple of 4) floats at zero_buf are cleared by extra blocks of the same
+ * launch -- the Z / stat / d a_dst workspace of the kgw_gat_aggregate_fwd call that follows (it needs them zeroed).
  * _bwd: gradients of the packed parameters from (dU_full, dV); every output element is written.          */
 int kgw_relvec_fwd(int32_t n_rels_total, const int32_t* live_of_rel, const int32_t* bip_pos, const float* w_src_t,
                    const float* w_dst_t, const float* att_src, const float* att_dst, float* U_full, float* V,
                    int32_t v_by_rel, int32_t n_live, const float* bias, const int32_t* blk_of_live, int32_t n_blk,
-                   float* bias_sum, kgw_stream_t stream);
+                   float* bias_sum, float* zero_buf, int64_t zero_floats, kgw_stream_t stream);
 int kgw_relvec_bwd(int32_t n_live, const int32_t* rel_ids, const int32_t* bip_pos, const float* w_src_t,
                    const float* w_dst_t, const float* att_src, const float* att_dst, const float* dU_full,
                    const float* dV, float* dw_src_t, float* dw_dst_t, float* datt_src, float* datt_dst,

@@ -159,7 +159,7 @@ def lib():
     L.kgw_adam.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
     L.kgw_relvec_fwd.argtypes = [C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
-                                 C.c_void_p, C.c_void_p]
+                                 C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     L.kgw_relvec_bwd.argtypes = [C.c_int32] + [C.c_void_p] * 12 + [C.c_int32, C.c_void_p]
     L.kgw_tn_gemm.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
                               C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]

@@ -1451,9 +1451,16 @@ __global__ void __launch_bounds__(128) k_relvec_fwd(int NR, const int32_t* __res
                                                     const float* __restrict__ att_dst, float* __restrict__ U_full,
                                                     float* __restrict__ V, int v_by_rel, int n_live,
                                                     const float* __restrict__ bias, const int32_t* __restrict__ blk_of_live,
-                                                    int n_blk, float* __restrict__ bsum) {
+                                                    int n_blk, float* __restrict__ bsum, int n_main,
+                                                    float* __restrict__ zero_buf, int64_t zero_f4) {
     __shared__ float as[KGW_C], ad[KGW_C];
     const int r = blockIdx.x, k = threadIdx.x;
+    if (r >= n_main) {      // extra blocks: clear the aggregate's workspace (Z, stat, d a_dst) in this launch
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t i = (int64_t)(r - n_main) * 128 + k; i < zero_f4; i += (int64_t)(gridDim.x - n_main) * 128)
+            ((float4*)zero_buf)[i] = z4;
+        return;
+    }
     if (r == NR) {          // extra block: bias of every relation into a destination type, summed in packed order
         float acc[KGW_MAX_TYPES];
 #pragma unroll
@@ -1539,13 +1546,18 @@ __global__ void __launch_bounds__(128) k_relvec_bwd(const int32_t* __restrict__ 
 extern "C" int kgw_relvec_fwd(int32_t n_rels_total, const int32_t* live_of_rel, const int32_t* bip_pos, const float* w_src_t,
                               const float* w_dst_t, const float* att_src, const float* att_dst, float* U_full, float* V,
                               int32_t v_by_rel, int32_t n_live, const float* bias, const int32_t* blk_of_live,
-                              int32_t n_blk, float* bias_sum, kgw_stream_t stream_) {
+                              int32_t n_blk, float* bias_sum, float* zero_buf, int64_t zero_floats, kgw_stream_t stream_) {
     if (n_rels_total <= 0) return KGW_OK;
     if (!live_of_rel || !bip_pos || !w_src_t || !att_src || !att_dst || !U_full || !V) return KGW_E_NULL;
+    if (zero_buf && ((zero_floats & 3) || zero_floats < 0 || !aligned16(zero_buf))) return KGW_E_UNSUPPORTED;
     const bool with_bias = bias && blk_of_live && bias_sum && n_blk > 0 && n_blk <= KGW_MAX_TYPES;
-    k_relvec_fwd<<<n_rels_total + (with_bias ? 1 : 0), 128, 0, (hipStream_t)stream_>>>(
+    const int n_main = n_rels_total + (with_bias ? 1 : 0);
+    const int64_t zero_f4 = zero_buf ? zero_floats / 4 : 0;
+    int64_t zblk = (zero_f4 + 128 * 8 - 1) / (128 * 8);          // ~8 float4 per thread
+    if (zblk > 2048) zblk = 2048;
+    k_relvec_fwd<<<n_main + (int)zblk, 128, 0, (hipStream_t)stream_>>>(
         n_rels_total, live_of_rel, bip_pos, w_src_t, w_dst_t, att_src, att_dst, U_full, V, v_by_rel, n_live, bias,
-        blk_of_live, n_blk, bias_sum);
+        blk_of_live, n_blk, bias_sum, n_main, zero_buf, zero_f4);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }

@@ -397,7 +397,9 @@ class HeteroGNN(nn.Module):
             blocks = [(rng[t][0], rng[t][1], int(m.z_base[l - 1][t]), int(m.lay_rows[l - 1][t])) for t in tys]
             # u_r = W_src^T att_src ; v_r = W_dst^T att_dst (W_src^T att_dst for same-type relations) and the summed
             # bias of every destination block: one launch
-            U, V, bsum = ops.rel_vectors(P, blocks)
+            # ... and the zero fill of the aggregate's workspace rides in the same launch
+            zws = ops.aggregate_workspace(batch, l, self.lin.weight.device)
+            U, V, bsum = ops.rel_vectors(P, blocks, zero=zws)
             # layer input, type-major (src_base): every type that sends or receives messages in this layer
             parts, spans = [], []
             for t, name in enumerate(sc.node_types):
@@ -415,7 +417,7 @@ class HeteroGNN(nn.Module):
             # into this node's)
             fused = self.aggr in ('sum', 'mean')
             Z, stat, e_edge = ops.gat_aggregate(batch, l, H, U, V, self.negative_slope, self.temperature,
-                                                relu_input=(l > 1 and fused))
+                                                relu_input=(l > 1 and fused), zbuf=zws)
             if want_attention:
                 attn.append(ops.edge_alpha(batch, l, stat, e_edge, self.temperature))
             if not fused:

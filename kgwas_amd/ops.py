@@ -130,7 +130,7 @@ def _layer_args(batch, layer: int, neg_slope: float, inv_temp: float) -> KgwLaye
 
 class _GatAggregate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, H, U, V, batch, layer, neg_slope, inv_temp, raw_weights=False, relu_input=False):
+    def forward(ctx, H, U, V, batch, layer, neg_slope, inv_temp, raw_weights=False, relu_input=False, zbuf=None):
         dg, m = batch.dg, batch.meta
         NT = dg.schema.NT
         z_rows = int(m.z_base[layer - 1][NT])
@@ -143,10 +143,13 @@ class _GatAggregate(torch.autograd.Function):
         dev = H.device
         # Z, stat and the backward's d a_dst all start from zero (rows without edges are never visited): one fill
         zr = max(z_rows, 1)
-        zbuf = torch.zeros(zr * (KGW_C + 3), device=dev)
+        if zbuf is None:
+            zbuf = torch.zeros(zr * (KGW_C + 3), device=dev)
+        else:                                       # cleared by the caller (rel_vectors did it in its launch)
+            assert zbuf.dtype == torch.float32 and zbuf.is_contiguous() and zbuf.numel() >= zr * (KGW_C + 3)
         Z = zbuf[:zr * KGW_C].view(zr, KGW_C)
         stat = zbuf[zr * KGW_C:zr * (KGW_C + 2)].view(zr, 2)
-        ctx.da_dst = zbuf[zr * (KGW_C + 2):]
+        ctx.da_dst = zbuf[zr * (KGW_C + 2):zr * (KGW_C + 3)]
         e_edge = torch.empty(max(n_edges, 1), device=dev)
         any_multi = batch.static or any(int(m.multi_cnt[h]) for h in range(dg.n_hops))
         part = torch.empty(max(n_chunks, 1) * PART_STRIDE if any_multi else 4, device=dev)
@@ -169,7 +172,7 @@ class _GatAggregate(torch.autograd.Function):
         if ctx.raw_weights:
             raise RuntimeError('raw-logit aggregation (attention export) is inference only')
         if dZ is None:
-            return (None,) * 9
+            return (None,) * 10
         H, U, V, Z, stat, e_edge = ctx.saved_tensors
         batch, layer = ctx.batch, ctx.layer
         dg, m = batch.dg, batch.meta
@@ -207,12 +210,19 @@ class _GatAggregate(torch.autograd.Function):
             dU, dV = dUV[:sc.NR], dUV[ld_da:ld_da + sc.NR]
         else:
             dU, dV = torch.zeros_like(U), torch.zeros_like(V)
-        return dH[:n_src], dU, dV, None, None, None, None, None, None
+        return dH[:n_src], dU, dV, None, None, None, None, None, None, None
+
+
+def aggregate_workspace(batch, layer: int, device) -> torch.Tensor:
+    """UNINITIALISED Z / stat / d a_dst workspace of ``gat_aggregate(batch, layer, ...)``: hand it to ``rel_vectors(...,
+    zero=ws)`` (which clears it in its own launch) and then to ``gat_aggregate(..., zbuf=ws)``."""
+    zr = max(int(batch.meta.z_base[layer - 1][batch.dg.schema.NT]), 1)
+    return torch.empty(zr * (KGW_C + 3) + (-(zr * (KGW_C + 3))) % 4, device=device)
 
 
 def gat_aggregate(batch, layer: int, H: torch.Tensor, U: torch.Tensor, V: torch.Tensor,
                   neg_slope: float = 0.2, temperature: float = 1.0, raw_weights: bool = False,
-                  relu_input: bool = False):
+                  relu_input: bool = False, zbuf: torch.Tensor = None):
     """Z[i, r] = sum_j softmax_j(leaky_relu(<H_src[j], u_r> + <H_dst[i], v_r>) / T) H_src[j] for every live relation
     of the layer.  H [n_src_rows,128]: layer input, type-major (``meta.src_base``; a destination node is row i of
     its own type's block); U, V [n_rels,128] by relation id.  Returns (Z [z_rows,128], stat [z_rows,2] =
@@ -222,9 +232,9 @@ def gat_aggregate(batch, layer: int, H: torch.Tensor, U: torch.Tensor, V: torch.
     the reference's attention export propagates, kgwas/utils.py:446-461 + conv.py:221-228).
     ``relu_input``: every row of H is the output of a ReLU (the previous layer, model.py:75) and the node that
     produced it expects its incoming gradient ALREADY multiplied by (H > 0): the source-side backward does it while
-    writing dH (see layer_transform's ``premasked``)."""
+    writing dH (see layer_transform's ``premasked``).  ``zbuf``: an ``aggregate_workspace`` that is ALREADY zero."""
     stat, e_edge, Z = _GatAggregate.apply(H, U, V, batch, layer, float(neg_slope), 1.0 / float(temperature), raw_weights,
-                                          relu_input)
+                                          relu_input, zbuf)
     return Z, stat, e_edge
 
 
@@ -620,8 +630,10 @@ class _RelVectors(torch.autograd.Function):
     """(U [NR,C], V [NR,C]), rows by relation id, from the packed relation parameters of a layer -- kgw_relvec_fwd / _bwd."""
 
     @staticmethod
-    def forward(ctx, w_src_t, w_dst_t, att_src, att_dst, pack, blk_of_live, n_blk):
+    def forward(ctx, w_src_t, w_dst_t, att_src, att_dst, pack, blk_of_live, n_blk, zero=None):
         n, C = att_src.shape
+        if zero is not None:
+            assert zero.dtype == torch.float32 and zero.is_contiguous() and zero.numel() % 4 == 0
         dev = att_src.device
         U = torch.empty(pack.n_rels_total, C, device=dev)
         V = torch.empty(pack.n_rels_total, C, device=dev)        # by relation id, like U
@@ -629,7 +641,8 @@ class _RelVectors(torch.autograd.Function):
         _lib.check(_lib.lib().kgw_relvec_fwd(pack.n_rels_total, _p(pack.live_of_rel_i32), _p(pack.bip_pos_i32), _p(w_src_t),
                                              _p(w_dst_t) if w_dst_t.numel() else 0, _p(att_src), _p(att_dst), _p(U), _p(V),
                                              1, n, _p(pack.bias.detach()) if bsum is not None else 0, _p(blk_of_live),
-                                             n_blk if bsum is not None else 0, _p(bsum), _lib.stream_ptr()), 'kgw_relvec_fwd')
+                                             n_blk if bsum is not None else 0, _p(bsum), _p(zero), zero.numel() if zero is not None else 0,
+                                             _lib.stream_ptr()), 'kgw_relvec_fwd')
         ctx.save_for_backward(w_src_t, w_dst_t, att_src, att_dst)
         ctx.pack = pack
         ctx.set_materialize_grads(False)
@@ -642,7 +655,7 @@ class _RelVectors(torch.autograd.Function):
     def backward(ctx, dU, dV, _dbsum=None):
         w_src_t, w_dst_t, att_src, att_dst = ctx.saved_tensors
         if dU is None and dV is None:
-            return (None,) * 7
+            return (None,) * 8
         if dU is None:
             dU = torch.zeros(ctx.pack.n_rels_total, att_src.shape[1], device=att_src.device)
         if dV is None:
@@ -658,18 +671,19 @@ class _RelVectors(torch.autograd.Function):
                                              _p(w_dst_t) if w_dst_t.numel() else 0, _p(att_src), _p(att_dst), _p(dU), _p(dV),
                                              _p(dws), _p(dwd) if dwd.numel() else 0, _p(das), _p(dad), 1, _lib.stream_ptr()),
                    'kgw_relvec_bwd')
-        return dws, dwd, das, dad, None, None, None
+        return dws, dwd, das, dad, None, None, None, None
 
 
 def _block_key(blocks):
     return tuple((lo, hi) for lo, hi, *_ in blocks)
 
 
-def rel_vectors(pack, blocks=None):
+def rel_vectors(pack, blocks=None, zero=None):
     """(U, V) by relation id; with ``blocks`` (the layer_transform block list, [(lo, hi, ...)]) also the summed bias
-    of every block, [n blocks, C] (no gradient flows through it: layer_transform produces d bias itself)."""
+    of every block, [n blocks, C] (no gradient flows through it: layer_transform produces d bias itself).
+    ``zero``: a float32 buffer to clear in the same launch (``aggregate_workspace``: the zero fill the aggregate needs)."""
     if blocks is None:
-        return _RelVectors.apply(pack.w_src_t, pack.w_dst_t, pack.att_src, pack.att_dst, pack, None, 0)
+        return _RelVectors.apply(pack.w_src_t, pack.w_dst_t, pack.att_src, pack.att_dst, pack, None, 0, zero)
     key = ('blk',) + _block_key(blocks)
     tab = pack._sel_cache.get(key)
     if tab is None:
@@ -679,7 +693,7 @@ def rel_vectors(pack, blocks=None):
                 blk[i] = b
         tab = torch.tensor(blk, dtype=torch.int32, device=pack.bias.device)
         pack._sel_cache[key] = tab
-    return _RelVectors.apply(pack.w_src_t, pack.w_dst_t, pack.att_src, pack.att_dst, pack, tab, len(blocks))
+    return _RelVectors.apply(pack.w_src_t, pack.w_dst_t, pack.att_src, pack.att_dst, pack, tab, len(blocks), zero)
 
 
 class _LayerTransform(torch.autograd.Function):
