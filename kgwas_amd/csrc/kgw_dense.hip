@@ -808,6 +808,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     // registers of lane (j, h) are then FOUR CONSECUTIVE output columns 32 t + 8 g + 4 h .. + 3 of row j, so the epilogue
     // is 16 float4 stores (and 16 float4 mask loads) per tile instead of 64 scalar ones
     const float* bl = Wl + 128 * WST + 4 * lk;             // bias staged behind W
+    const float lo = a.relu ? 0.f : -__builtin_inff();
     for (; tile < ntiles; tile += nw) {
         f32x16 acc[4];
 #pragma unroll
@@ -860,10 +861,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #undef KGW_WREG_STEP
             // the next tile's float4s, in place, half a row (one 128-B line per lane) at a time: the eight loads of a line
             // are issued back to back so that the line is fetched from L2 once
-            if ((q & 7) == 7) {
+            if (q == 7) {
                 __builtin_amdgcn_sched_barrier(0);           // (keeps the refill below its registers' last use)
 #pragma unroll
-                for (int qq = q - 7; qq <= q; ++qq) xa[qq] = *(const f32x4*)(xn + 4 * qq);
+                for (int qq = 0; qq < 8; ++qq) xa[qq] = *(const f32x4*)(xn + 4 * qq);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -879,7 +880,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     f32x4 v;
                     v.x = acc[t][4 * g + 0] + b4.x; v.y = acc[t][4 * g + 1] + b4.y;
                     v.z = acc[t][4 * g + 2] + b4.z; v.w = acc[t][4 * g + 3] + b4.w;
-                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    v.x = fmaxf(v.x, lo); v.y = fmaxf(v.y, lo); v.z = fmaxf(v.z, lo); v.w = fmaxf(v.w, lo);   // (ReLU without a branch per store)
                     if (MASK) {
                         const unsigned m4 = mb[t >> 1] >> (((t & 1) << 4) + 4 * g);
                         v.x = (m4 & 1u) ? v.x : 0.f; v.y = (m4 & 2u) ? v.y : 0.f;
@@ -889,6 +890,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 }
             }
         }
+        // the second half row of the next tile is requested AFTER this tile's stores: the wait for it (step 8 of the next
+        // tile, in-order vmcnt) then has only loads behind it, not the stores
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qq = 8; qq < 16; ++qq) xa[qq] = *(const f32x4*)(xn + 4 * qq);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
