@@ -746,7 +746,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 // straight from global memory into the other operand
 // -- lane (i, h) owns the contiguous half row X[r0 + i][64 h .. 64 h + 63], the K order being permuted so that MFMA
 // step s multiplies k = 64 h + s -- and refills the tile in place with the wavefront's NEXT tile, half a row (eight
-// float4 = one 128-B line per lane) at a time right after that half's last use (the loads have ~8 k cycles to land).  No LDS traffic, no barrier and
+// float4 = one 128-B line per lane) at a time: the first half right after its last use, the second after the tile's
+// stores (the loads have ~8 k cycles to land either way).  No LDS traffic, no barrier and
 // no waitcnt on a fresh load inside the MFMA stream: the matrix pipe sees 256 back-to-back MFMAs per tile over four
 // independent accumulators.  ReLU-mask rows (dX) are fetched 16 at a time under the MFMAs and kept as bits.
 // ------------------------------------------------------------------------------------------------------
