@@ -618,6 +618,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     float* slice = Xs + rg * 32 * XST;                 // this wavefront's 32 rows (private when WCG == 1)
     const float* xa = slice + li * XST + lk * (KC / 2);
     constexpr int Q = KC / 8;                          // groups of four MFMA steps per chunk
+    const float relu_lo = a.relu ? 0.f : -__builtin_inff();
     for (; tile < ntiles; tile += gridDim.x) {
         f32x16 acc[CT];
 #pragma unroll
@@ -701,7 +702,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 float4 v = *(const float4*)(slice + row * XST + c);
                 const int64_t rr = rbase + row;
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                v.x = fmaxf(v.x, relu_lo); v.y = fmaxf(v.y, relu_lo); v.z = fmaxf(v.z, relu_lo); v.w = fmaxf(v.w, relu_lo);   // (no branch between stores)
                 v.x = mk[it].x > 0.f ? v.x : 0.f; v.y = mk[it].y > 0.f ? v.y : 0.f;
                 v.z = mk[it].z > 0.f ? v.z : 0.f; v.w = mk[it].w > 0.f ? v.w : 0.f;
                 if (rr < a.rows && col < a.N) *(float4*)(a.Y + rr * a.ldy + col) = v;
@@ -727,8 +728,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int64_t rr = rbase + (e & 3) + 8 * (e >> 2);
-                float v = acc[0][e] + bv;
-                if (a.relu) v = fmaxf(v, 0.f);
+                float v = fmaxf(acc[0][e] + bv, relu_lo);
                 if (a.mask) v = mv[e] > 0.f ? v : 0.f;
                 if (rr < a.rows) a.Y[rr * a.ldy + col] = v;
             }
