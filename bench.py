@@ -106,6 +106,12 @@ def main():
     ap.add_argument('--eager', action='store_true', help='issue every launch from the host instead of replaying one HIP graph per step')
     args = ap.parse_args()
 
+    # stdout carries EXACTLY one JSON line: everything else that writes to file descriptor 1 (native libraries included --
+    # a collective backend announcing its peers, a BLAS tuner) goes to stderr until the line is printed
+    sys.stdout.flush()
+    _stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -291,7 +297,9 @@ def main():
                    'setup_s': setup_s},
         'roofline': roof, 'cpu_baseline': cpu, 'breakdown': breakdown,
     }
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.dup2(_stdout_fd, 1)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
