@@ -64,10 +64,21 @@ def allreduce_grads(model, world: int):
 
 
 def broadcast_params(model, src: int = 0):
-    tensors = [p.data for p in model.parameters()] + [b.data for b in model.buffers()]
-    if not tensors:
-        return
-    flat = torch._utils._flatten_dense_tensors(tensors)
-    dist.broadcast(flat, src)
-    for t, f in zip(tensors, torch._utils._unflatten_dense_tensors(flat, tensors)):
-        t.copy_(f)
+    """Rank ``src``'s parameters (and persistent floating-point buffers) to every rank, one flat bucket per dtype.  The
+    non-persistent int32 / int64 index tables of the relation packs are structural -- identical on every rank by
+    construction -- and are NOT sent (flattening them with the float parameters would round-trip them through fp32)."""
+    skip = set()
+    for mod in model.modules():
+        for name in getattr(mod, '_non_persistent_buffers_set', ()):
+            b = mod._buffers.get(name)
+            if b is not None:
+                skip.add(id(b))
+    tensors = [p.data for p in model.parameters()] + [b.data for b in model.buffers() if id(b) not in skip]
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for group in by_dtype.values():
+        flat = torch._utils._flatten_dense_tensors(group)
+        dist.broadcast(flat, src)
+        for t, f in zip(group, torch._utils._unflatten_dense_tensors(flat, group)):
+            t.copy_(f)

@@ -29,15 +29,28 @@ import torch
 
 from .graph import HeteroGraph, build_csr
 
-CACHE_VERSION = 1
+CACHE_VERSION = 2
+
+
+def source_fingerprint(paths) -> dict:
+    """{path: [size, mtime_ns]} of the files a cache was converted from: a cache whose sources changed is stale."""
+    out = {}
+    for p in paths:
+        if p and os.path.exists(p):
+            st = os.stat(p)
+            out[p] = [int(st.st_size), int(st.st_mtime_ns)]
+    return out
 
 
 def _fname(kind: str, key: str) -> str:
     return f'{kind}_{key}.npy'
 
 
-def convert(kg_data, cache_dir: str, options: dict = None) -> str:
-    """Write the cache for a loaded ``KGWAS_Data`` (after ``load_kg`` / ``from_synthetic``).  Returns ``cache_dir``."""
+def convert(kg_data, cache_dir: str, options: dict = None, sources: dict = None) -> str:
+    """Write the cache for a loaded ``KGWAS_Data`` (after ``load_kg`` / ``from_synthetic``).  Returns ``cache_dir``.
+    ``sources``: ``source_fingerprint`` of the files the graph was read from (kept in meta.json; ``load_kg`` rejects
+    the cache when it no longer matches)."""
+    import pickle
     data: HeteroGraph = kg_data.data
     os.makedirs(cache_dir, exist_ok=True)
     node_types = list(data.node_types)
@@ -58,7 +71,17 @@ def convert(kg_data, cache_dir: str, options: dict = None) -> str:
             'edge_types': [list(e) for e in edge_types], 'num_edges': n_edges,
             'feat_dims': {'snp': int(kg_data.snp_init_dim_size), 'gene': int(kg_data.gene_init_dim_size),
                           'go': int(kg_data.go_init_dim_size)},
-            'options': dict(options or {})}
+            'options': dict(options or {}), 'sources': dict(sources or {})}
+    # the id maps exactly as the reference's pickles hold them (key types, alias keys of node_id2idx.pkl that idx2id
+    # lacks): a cached load must resolve GWAS ids like the first, uncached one
+    maps = {}
+    for name in ('idx2id', 'id2idx'):
+        m = getattr(kg_data, name, None)
+        if isinstance(m, dict) and all(isinstance(v, dict) for v in m.values()):
+            maps[name] = m
+    if len(maps) == 2:
+        with open(os.path.join(cache_dir, 'idmaps.pkl'), 'wb') as f:
+            pickle.dump(maps, f, protocol=pickle.HIGHEST_PROTOCOL)
     with open(os.path.join(cache_dir, 'meta.json'), 'w') as f:
         json.dump(meta, f, indent=1)
     return cache_dir
@@ -124,6 +147,12 @@ def load(kg_data, cache_dir: str, mmap: bool = True):
         data[et].edge_index = torch.from_numpy(np.stack([np.asarray(col, dtype=np.int64), dst]))
     data._extra['csr'] = csr
     kg_data.data = data
+    mp = os.path.join(cache_dir, 'idmaps.pkl')
+    if os.path.exists(mp):                       # the original maps, key types and aliases intact
+        import pickle
+        with open(mp, 'rb') as f:
+            maps = pickle.load(f)
+        idx2id, id2idx = maps['idx2id'], maps['id2idx']
     kg_data.idx2id, kg_data.id2idx = idx2id, id2idx
     kg_data.snp_init_dim_size = meta['feat_dims']['snp']
     kg_data.gene_init_dim_size = meta['feat_dims']['gene']

@@ -197,6 +197,9 @@ class KGWAS:
         scale_factor = find_closest_x(lr_uni_to_save)
         lr_uni_to_save['KGWAS_P'] = (scale_factor * lr_uni_to_save['P_weighted']).clip(lower=0, upper=1)
         out_dir = os.path.join(self.data_path, 'model_pred', 'new_experiments')
+        self.kgwas_res = lr_uni_to_save
+        if kdist.rank_world()[0] != 0:          # multi-GPU: every rank holds the results, rank 0 alone writes the files
+            return
         try:
             os.makedirs(out_dir, exist_ok=True)
             lr_uni_to_save.to_csv(os.path.join(out_dir, save_name + '_pred.csv'), index=False, sep='\t')
@@ -205,4 +208,3 @@ class KGWAS:
                 lr_uni_to_save.to_csv(os.path.join(self.data_path, 'model', save_name, 'pred.csv'), index=False, sep='\t')
         except OSError as e:   # read-only data_path: keep results in memory
             print_sys(f'could not write predictions: {e}')
-        self.kgwas_res = lr_uni_to_save

@@ -33,6 +33,9 @@ _GENE_EMB = {'random': (None, 128), 'esm': ('cell_kg/node_emb/gene_emb/esm_feat.
              'pops': ('cell_kg/node_emb/gene_emb/pops_feat.pkl', 57742),
              'pops_expression': ('cell_kg/node_emb/gene_emb/pops_expression_feat.pkl', 40546)}
 _GO_EMB = {'random': (None, 128), 'biogpt': ('cell_kg/node_emb/program_emb/biogpt_feat.pkl', 1600)}
+# traits fitted with PLINK's logistic model when sub-sampled to <= 3000 individuals (kgwas_data.py:375,434)
+_BINARY_PHENOS = ('body_BALDING1', 'cancer_BREAST', 'disease_ALLERGY_ECZEMA_DIAGNOSED', 'disease_HYPOTHYROIDISM_SELF_REP',
+                  'other_MORNINGPERSON', 'pigment_SUNBURN')
 
 
 def _feature_matrix(node_map, feat, dim, gen):
@@ -63,14 +66,20 @@ class KGWAS_Data:
                 'sample_edges': bool(sample_edges), 'sample_ratio': float(sample_ratio), 'seed': int(seed)}
         cache_dir = os.path.join(dp, 'cell_kg', 'kgwas_amd_cache',
                                  '_'.join(str(v) for v in opts.values()).replace('.', 'p'))
+        net = os.path.join(dp, 'cell_kg/network')
+        src_files = [os.path.join(net, f) for f in ('node_idx2id.pkl', 'edge_index.pkl', 'node_id2idx.pkl')]
+        for table, name in ((_SNP_EMB, snp_init_emb), (_GENE_EMB, gene_init_emb), (_GO_EMB, go_init_emb)):
+            if name in table and table[name][0]:
+                src_files.append(os.path.join(dp, table[name][0]))
         if cache:
             from . import ingest
             meta = ingest.read_meta(cache_dir)
-            if meta is not None and meta.get('options') == opts:
+            # (a cache converted from other files -- size / mtime of the pickles changed -- is stale: rebuild it)
+            if meta is not None and meta.get('options') == opts and \
+                    meta.get('sources') == ingest.source_fingerprint(src_files):
                 print('--loading KG (cached)---')
                 ingest.load(self, cache_dir)
                 return
-        net = os.path.join(dp, 'cell_kg/network')
         for f in ('node_idx2id.pkl', 'edge_index.pkl', 'node_id2idx.pkl'):
             if not os.path.exists(os.path.join(net, f)):
                 raise FileNotFoundError(f'{os.path.join(net, f)} missing (no network access to download the '
@@ -107,7 +116,7 @@ class KGWAS_Data:
         self._finish_graph(data, edges)
         if cache:
             try:
-                ingest.convert(self, cache_dir, opts)
+                ingest.convert(self, cache_dir, opts, ingest.source_fingerprint(src_files))
             except OSError as e:                     # read-only data directory: run without a cache
                 print(f'KG cache not written: {e}')
 
@@ -207,8 +216,7 @@ class KGWAS_Data:
     def load_gwas_subsample(self, pheno, sample_size, seed):
         import pandas as pd
         self.sample_size, self.pheno = sample_size, pheno
-        binary = pheno in ['body_BALDING1', 'cancer_BREAST', 'disease_ALLERGY_ECZEMA_DIAGNOSED',
-                           'disease_HYPOTHYROIDISM_SELF_REP', 'other_MORNINGPERSON', 'pigment_SUNBURN']
+        binary = pheno in _BINARY_PHENOS
         sub = os.path.join(self.data_path, 'subsample_gwas')
         if sample_size > 3000:
             lr_uni = pd.read_csv(os.path.join(sub, f'{pheno}_fastgwa_full_{sample_size}_{seed}.fastGWA'), sep='\t')
@@ -245,17 +253,22 @@ class KGWAS_Data:
         self.ldsc_weight = w
         self.rs_id_to_ldsc_weight = dict(zip(lr_uni.ID.values, w))
         if label == 'chi':
+            # branch order of kgwas_data.py:431-446: pre-computed chi; Z_STAT for the binary traits run through PLINK's
+            # logistic model (sample_size <= 3000); BETA/SE; else the P column -- NaN labels become 0 in every branch
             if 'chi' in lr_uni.columns.values:
                 lr_uni['y'] = lr_uni['chi'].values
+            elif getattr(self, 'pheno', None) in _BINARY_PHENOS and getattr(self, 'sample_size', 1 << 30) <= 3000:
+                lr_uni['y'] = lr_uni['Z_STAT'].values ** 2
+                lr_uni['y'] = lr_uni.y.fillna(0)
             elif ('BETA' in lr_uni.columns.values) and ('SE' in lr_uni.columns.values):
                 lr_uni['y'] = ((lr_uni['BETA'] / lr_uni['SE']).values ** 2)
-                lr_uni['y'] = lr_uni.y.fillna(0)
-            elif 'Z_STAT' in lr_uni.columns.values:
-                lr_uni['y'] = lr_uni['Z_STAT'].values ** 2
                 lr_uni['y'] = lr_uni.y.fillna(0)
             else:
                 from scipy.stats import chi2
                 lr_uni['y'] = chi2.ppf(1 - lr_uni['P'].values, 1)
+                lr_uni['y'] = lr_uni.y.fillna(0)
+        elif label == 'residual-w-ld':                                # kgwas_data.py:449-450
+            lr_uni['y'] = (lr_uni['BETA'] / lr_uni['SE']).values ** 2
         id2idx = self.id2idx['SNP']
         self.all_ids = np.array([id2idx[i] for i in lr_uni.ID.values], dtype=np.int64)
         self.y = lr_uni.y.values
@@ -264,6 +277,8 @@ class KGWAS_Data:
     def prepare_split(self, test_set_fraction_data=0.05):
         """kgwas_data.py:522-545: sklearn train_test_split twice (5 % test, then 5 % of the rest val)."""
         from sklearn.model_selection import train_test_split
+        if not np.isfinite(np.asarray(self.y, dtype=np.float64)).all():
+            raise ValueError('non-finite GWAS labels: one NaN label turns the loss, and through Adam every parameter, into NaN')
         train_val_ids, test_ids, y_train_val, y_test = train_test_split(
             self.all_ids, self.y, test_size=test_set_fraction_data, random_state=self.seed)
         train_ids, val_ids, y_train, y_val = train_test_split(

@@ -447,22 +447,31 @@ class HeteroGNN(nn.Module):
 
     def forward(self, x_dict, edge_index_dict, batch_size, genotype=None, return_h=False,
                 return_attention_weights=False):
+        if return_attention_weights and not return_h:           # model.py:65-72,80-81 (mean attention per layer)
+            return self._forward_with_attention(x_dict, edge_index_dict, batch_size)
         batch: Optional[SampledBatch] = getattr(x_dict, 'kgw_batch', None) or getattr(edge_index_dict, 'kgw_batch', None)
         if batch is None:
             batch = self._block_from_coo(x_dict, edge_index_dict)
         hbuf, blocks = self._layer_input(batch, 1)
         h = self._embed_all(batch, x_dict, blocks)
-        h, attn = self._fused_layers(batch, h, want_attention=return_attention_weights, hbuf=hbuf)
+        h, attn = self._fused_layers(batch, h, hbuf=hbuf)
         snp = h['SNP']
         out = self.lin(snp)[:batch_size]
         if return_h:                                            # model.py:78-79
             return self.ReLU(out), snp[:batch_size]
-        if return_attention_weights:                            # model.py:80-81 (mean attention per layer)
-            self.last_attention = attn
-            return self.ReLU(out), [a.mean() if a.numel() else a.sum() for a in attn]
         if self.no_relu:                                        # model.py:83-84
             return out
         return self.ReLU(out)                                   # model.py:86
+
+    @torch.no_grad()
+    def hot_path_attention(self, batch: SampledBatch):
+        """Per layer, the softmax attention weight of every edge the TRAINING path aggregates (live relations, hop-pruned
+        destination rows; local edge order of ``batch``) -- what the fused kernels actually use, as opposed to the
+        reference-shaped ``forward(return_attention_weights=True)`` which runs all relations over all rows."""
+        hbuf, blocks = self._layer_input(batch, 1)
+        h = self._embed_all(batch, batch.x_dict, blocks)
+        _, attn = self._fused_layers(batch, h, want_attention=True, hbuf=hbuf)
+        return attn
 
     def forward_loss(self, x_dict, edge_index_dict, batch_size, n_id, y_all, w_all):
         """The training step's forward (kgwas/kgwas.py:137-145): HeteroGNN.forward followed by
@@ -481,6 +490,51 @@ class HeteroGNN(nn.Module):
                                         relu=not self.no_relu, h_is_relu=gat)
 
     # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _forward_all_relations(self, batch: SampledBatch, raw: bool):
+        """Both layers over EVERY relation and every row of a full-graph block (no structural pruning), the way the
+        reference runs a batch (kgwas/model.py:64-75): returns (final x_dict, [per layer: per-edge attention of the whole
+        block, local edge order]).  ``raw``: the export's variant (kgwas/utils.py:446-461) -- raw leaky_relu logits as
+        message weights (conv.py:221-228) and no ReLU between the layers (utils.py:460)."""
+        sc, m, C = self.schema, batch.meta, self.hidden
+        dev = self.lin.weight.device
+        h = self._embed_all(batch, batch.x_dict)
+        per_layer = []
+        for l in range(1, self.num_layers + 1):
+            U = torch.zeros(sc.NR, C, device=dev)
+            V = torch.zeros(sc.NR, C, device=dev)
+            for pack in (self.live_packs[l - 1], self.dead_packs[l - 1]):
+                if len(pack.rel_ids):
+                    u, v = ops.rel_vectors(pack)           # rows of the pack's relations, zeros elsewhere
+                    U += u; V += v
+            parts = []
+            for t, name in enumerate(sc.node_types):
+                ns = int(m.lay_src[l - 1][t])
+                if ns:
+                    if name not in h or h[name].shape[0] < ns:
+                        raise RuntimeError(f'layer {l}: node type {name!r} has no layer-{l - 1} state')
+                    parts.append(h[name][:ns])
+            H = torch.cat(parts, 0)
+            Z, stat, e_edge = ops.gat_aggregate(batch, l, H, U, V, self.negative_slope, self.temperature, raw_weights=raw)
+            per_layer.append(e_edge if raw else ops.edge_alpha(batch, l, stat, e_edge, self.temperature))
+            h_next = {}
+            for t, name in enumerate(sc.node_types):
+                n, R = int(m.lay_rows[l - 1][t]), int(sc.R_dst[t])
+                if n == 0 or R == 0:
+                    continue
+                z0 = int(m.z_base[l - 1][t])
+                x = Z[z0:z0 + n * R].view(n, R * C)
+                ws, bs = [], 0
+                for r in sc.rels_by_dst[t]:                # slot order of the Z columns
+                    which, i = self._slot[l - 1][r]
+                    pack = self.live_packs[l - 1] if which == 'live' else self.dead_packs[l - 1]
+                    ws.append(pack.w_src_t[i])
+                    bs = bs + pack.bias[i]
+                y = torch.addmm(bs, x, torch.cat(ws, 0))
+                h_next[name] = y if raw else torch.relu(y)                   # model.py:75 / no ReLU at utils.py:460
+            h = h_next
+        return h, per_layer
+
     @torch.no_grad()
     def raw_attention_full_graph(self, graph: HeteroGraph, device=None):
         """Per layer, per relation: (edge_index [2,E] global ids, raw attention [E]) over the WHOLE graph, the way
@@ -501,49 +555,48 @@ class HeteroGNN(nn.Module):
         sample_into(dg, buf, None, 0)
         batch = finish_sample(dg, buf, sc.node_types[0], dg.n_nodes[0])
         m = batch.meta
-        h = self._embed_all(batch, batch.x_dict)
+        _, per_layer = self._forward_all_relations(batch, raw=True)
         ei = batch.edge_index_dict                         # full graph: local ids are the global ids
         seg_ptr = buf.seg_ptr
-        C = self.hidden
         layers = []
-        for l in range(1, self.num_layers + 1):
-            U = torch.zeros(sc.NR, C, device=dev)
-            V = torch.zeros(sc.NR, C, device=dev)
-            for pack in (self.live_packs[l - 1], self.dead_packs[l - 1]):
-                if len(pack.rel_ids):
-                    u, v = ops.rel_vectors(pack)           # rows of the pack's relations, zeros elsewhere
-                    U += u; V += v
-            parts = []
-            for t, name in enumerate(sc.node_types):
-                ns = int(m.lay_src[l - 1][t])
-                if ns:
-                    if name not in h or h[name].shape[0] < ns:
-                        raise RuntimeError(f'layer {l}: node type {name!r} has no layer-{l - 1} state')
-                    parts.append(h[name][:ns])
-            H = torch.cat(parts, 0)
-            Z, _, e_edge = ops.gat_aggregate(batch, l, H, U, V, self.negative_slope, self.temperature, raw_weights=True)
+        for e_edge in per_layer:
             att = OrderedDict()
             for r, et in enumerate(self.edge_types):
                 a, b = int(m.seg_off[0][r]), int(m.seg_off[0][r + 1])
                 e0, e1 = (int(seg_ptr[a]), int(seg_ptr[b])) if b > a else (0, 0)
                 att[et] = (ei[et], e_edge[e0:e1])
             layers.append(att)
-            h_next = {}
-            for t, name in enumerate(sc.node_types):
-                n, R = int(m.lay_rows[l - 1][t]), int(sc.R_dst[t])
-                if n == 0 or R == 0:
-                    continue
-                z0 = int(m.z_base[l - 1][t])
-                x = Z[z0:z0 + n * R].view(n, R * C)
-                ws, bs = [], 0
-                for r in sc.rels_by_dst[t]:                # slot order of the Z columns
-                    which, i = self._slot[l - 1][r]
-                    pack = self.live_packs[l - 1] if which == 'live' else self.dead_packs[l - 1]
-                    ws.append(pack.w_src_t[i])
-                    bs = bs + pack.bias[i]
-                h_next[name] = torch.addmm(bs, x, torch.cat(ws, 0))          # no ReLU here (utils.py:460)
-            h = h_next
         return layers
+
+    @torch.no_grad()
+    def _forward_with_attention(self, x_dict, edge_index_dict, batch_size):
+        """forward(return_attention_weights=True) (kgwas/model.py:65-72,80-81): the reference runs EVERY edge type over
+        every edge of the batch in both layers and returns the mean attention of all of them per layer, so this path
+        does too -- the batch's subgraph as a full block with all relations live, no hop pruning (inference only)."""
+        from .sampler import BatchBuffers, DeviceGraph, finish_sample, sample_into
+        if self.backbone != 'GAT':
+            raise NotImplementedError('attention weights exist for the GAT backbone only (kgwas/model.py:65-72)')
+        if self.aggr != 'sum':
+            raise NotImplementedError("attention weights are built for gnn_aggr='sum' (the reference default)")
+        dev = next(iter(x_dict.values())).device if len(x_dict) else self.lin.weight.device
+        g = HeteroGraph()
+        for t in self.node_types:
+            if t in x_dict:
+                g[t].x = x_dict[t]
+            else:
+                g[t].num_nodes_ = 0
+        for et in self.edge_types:
+            ei = edge_index_dict.get(et)
+            g[et].edge_index = ei if ei is not None else torch.zeros(2, 0, dtype=torch.long)
+        dg = DeviceGraph(g, self.num_layers, dev, full_graph=True).with_all_relations_live()
+        buf = BatchBuffers(dg)
+        sample_into(dg, buf, None, 0)
+        sc = self.schema
+        batch = finish_sample(dg, buf, sc.node_types[0], dg.n_nodes[0])
+        h, per_layer = self._forward_all_relations(batch, raw=False)
+        self.last_attention = per_layer
+        out = self.ReLU(self.lin(h['SNP']))[:batch_size]
+        return out, [a.mean() if a.numel() else a.sum() for a in per_layer]
 
     # ------------------------------------------------------------------------------------------
     def _block_from_coo(self, x_dict, edge_index_dict) -> SampledBatch:

@@ -74,10 +74,9 @@ def test_attention_weights_of_every_segment_sum_to_one(full_run):
     ids = np.asarray(run.data.train_input_nodes[1][BS:2 * BS])
     batch = next(iter(_loader(run, ids)))
     run.model.eval()
-    with torch.no_grad():
-        run.model(batch.x_dict, batch.edge_index_dict, BS, return_attention_weights=True)
+    attention = run.model.hot_path_attention(batch)
     seg_ptr = batch.buf.seg_ptr.long()
-    for l, alpha in enumerate(run.model.last_attention, start=1):
+    for l, alpha in enumerate(attention, start=1):
         E = int(alpha.numel())
         assert E == batch.n_edges_per_layer[l - 1] and E > 0
         # layer l aggregates the segments of hops 0 .. L - l (hop-major segment and edge order)

@@ -117,9 +117,13 @@ def test_return_h_no_relu_attention(edge_case_graph):
         model.no_relu = oracle.no_relu = True
         assert_close(model(batch.x_dict, batch.edge_index_dict, 32), oracle(x, ei, 32), RTOL, ATOL, 'no_relu')
         model.no_relu = oracle.no_relu = False
+        # model.py:65-72: the mean attention over ALL edge types and ALL edges of the batch, per layer
         p2, att = model(batch.x_dict, batch.edge_index_dict, 32, return_attention_weights=True)
+        p2o, atto = oracle(x, ei, 32, return_attention_weights=True)
         assert_close(p2, po, RTOL, ATOL, 'pred(attention)')
-        assert len(att) == 2 and all(torch.isfinite(a) for a in att)
+        assert len(att) == len(atto) == 2
+        for l, (a, ao) in enumerate(zip(att, atto)):
+            assert abs(float(a) - float(ao)) <= 1e-5 * abs(float(ao)) + 1e-7, (l, float(a), float(ao))
 
 
 def test_training_steps_track_the_reference(small_kg):
