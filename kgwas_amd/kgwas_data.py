@@ -129,12 +129,27 @@ class KGWAS_Data:
 
     @classmethod
     def from_synthetic(cls, scale=1.0, seed=1, mode='fast', data_path='/tmp/kgwas_synth', n_labelled=None,
-                       gwas_kind='causal', sample_size=5000, feat_dims=None, split=True, snp_scale=1.0):
-        """SynthKG + synthetic summary statistics through the same pipeline as the real files."""
+                       gwas_kind='causal', sample_size=None, feat_dims=None, split=True, snp_scale=1.0,
+                       sample_edges=False, sample_ratio=1.0):
+        """SynthKG + synthetic summary statistics through the same pipeline as the real files.
+        ``gwas_kind`` mirrors the reference's four label sources (BASELINE.json configs): 'causal' / 'null' = the
+        simulations of load_simulation_gwas (N = 5000, kgwas_data.py:275-294), 'subsample' = load_gwas_subsample
+        (N = ``sample_size``, default 10000, :367-389), 'full_cohort' = load_full_gwas (N = 387113, :341-365).
+        ``sample_edges`` / ``sample_ratio``: load_kg's edge thinning (:261-268) -- int(E * ratio) edges of every ORIGINAL
+        relation, seeded permutation, before ToUndirected + AddSelfLoops."""
         import pandas as pd
         from .synth import FEAT_DIMS, make_synth_edges, make_synth_gwas
         self = cls(data_path)
+        if sample_size is None:
+            sample_size = {'subsample': 10000, 'full_cohort': 387113}.get(gwas_kind, 5000)
         edges, nc = make_synth_edges(scale, seed, snp_scale=snp_scale)
+        if sample_edges:
+            gen_e = torch.Generator().manual_seed(seed)
+            for et in list(edges.keys()):
+                ei = edges[et]
+                k = int(ei.shape[1] * sample_ratio)
+                perm = torch.randperm(ei.shape[1], generator=gen_e)[:k].numpy()
+                edges[et] = ei[:, perm]
         dims = dict(FEAT_DIMS[mode])
         if feat_dims:
             dims.update(feat_dims)
@@ -157,7 +172,7 @@ class KGWAS_Data:
         self.idx2id['SNP'] = _IdentityMap(n_snp, 'rs')
         self.id2idx['SNP'] = _IdentityMap(n_snp, 'rs', inverse=True)
         self.sample_size = sample_size
-        self.pheno = 'synthetic'
+        self.pheno = {'causal': 'simulation', 'null': 'simulation'}.get(gwas_kind, 'synthetic_' + gwas_kind)
         self.seed = seed
         self.process_gwas_file()
         if split:

@@ -127,7 +127,9 @@ def make_synth_gwas(n_snp: int, n_labelled: int, seed: int = 1, kind: str = 'cau
     n_labelled = min(n_labelled, n_snp)
     ids = np.sort(rng.choice(n_snp, size=n_labelled, replace=False))
     z = rng.standard_normal(n_labelled)
-    if kind == 'causal':
+    if kind not in ('causal', 'null', 'subsample', 'full_cohort'):
+        raise ValueError(f'gwas kind {kind!r}')
+    if kind != 'null':         # 'subsample' / 'full_cohort': the same causal architecture seen at another cohort size
         k = min(n_causal, n_labelled)
         causal = rng.choice(n_labelled, size=k, replace=False)
         z[causal] += rng.standard_normal(k) * np.sqrt(0.3 * sample_size / max(k, 1)) * 3.0

@@ -1,6 +1,5 @@
-"""-m gpu: the path at BASELINE.json's FULL size (configs[1]: SynthKG-fast, 784 256 SNPs / 20 032 genes / ~20.6 M
-directed edges, 512-seed batches), where the CPU oracle would take minutes per batch: checked through
-size-independent properties of the domain instead --
+"""-m gpu: the path at BASELINE.json's FULL size, on EVERY configuration BASELINE.json names -- where the CPU oracle would
+take minutes per batch, checked through size-independent properties of the domain instead:
 
 * full-neighbour sampling: every sampled destination row carries its WHOLE in-neighbourhood (segment sizes == CSR
   degrees), local ids are a bijection onto the sampled global ids, seeds come first;
@@ -9,6 +8,15 @@ size-independent properties of the domain instead --
 * linearity / determinism of the backward pass: grad(2 * loss) == 2 * grad(loss) bit for bit (power-of-two scale),
   two runs give bitwise identical gradients;
 * the captured HIP-graph step reproduces the eager step's losses on the same batches.
+
+Configurations (the graph generator and label sources are kgwas_amd/synth.py + KGWAS_Data.from_synthetic; what differs
+between them in the reference is cited there):
+  c1  configs[1]  full fast-mode KG + causal-simulation GWAS (the benchmark workload)
+  c2  configs[2]  full fast-mode KG + sub-sampled cohort, sample_size = 10000       (kgwas_data.py:367-389)
+  c3  configs[3]  ~10 M SNPs (snp_scale 12.75) + full-cohort labels, N = 387113     (kgwas_data.py:341-365), one GPU
+  c4  configs[4]  full-mode feature widths 70 / 57742 / 128                          (kgwas_data.py:161-167,237-244)
+  c0  configs[0]  sample_edges=True, sample_ratio=0.01 + null simulation            (kgwas_data.py:261-268,275-294):
+                  batches with EMPTY node types and isolated seeds; here the oracle is fast enough to follow the training.
 """
 import numpy as np
 import pytest
@@ -20,17 +28,34 @@ pytestmark = pytest.mark.gpu
 
 BS = 512
 
+CONFIGS = {
+    'c1_fast_causal': dict(gwas_kind='causal'),
+    'c2_fast_subsample10k': dict(gwas_kind='subsample', sample_size=10000),
+    'c3_snp10m_full_cohort': dict(gwas_kind='full_cohort', snp_scale=12.75),
+    'c4_full_mode_widths': dict(gwas_kind='causal', mode='full'),
+    'c0_thinned_null': dict(gwas_kind='null', sample_edges=True, sample_ratio=0.01),
+}
 
-@pytest.fixture(scope='module')
-def full_run():
+
+@pytest.fixture(scope='module', params=list(CONFIGS))
+def full_run(request):
     from kgwas_amd.kgwas import KGWAS
     from kgwas_amd.kgwas_data import KGWAS_Data
-    data = KGWAS_Data.from_synthetic(scale=1.0, seed=1, mode='fast', gwas_kind='causal', data_path='/tmp/kgwas_synth_full_test')
+    kw = dict(CONFIGS[request.param])
+    kw.setdefault('mode', 'fast')
+    data = KGWAS_Data.from_synthetic(scale=1.0, seed=1, data_path=f'/tmp/kgwas_synth_full_test_{request.param}', **kw)
     run = KGWAS(data, device='cuda:0', seed=1)
     run.initialize_model()
-    n = {t: int(x.shape[0]) for t, x in ((t, data.data[t].x) for t in data.data.node_types)}
-    assert n['SNP'] == 784256 and n['Gene'] == 20032
-    return run
+    run.cfg_name = request.param
+    n = {t: int(data.data[t].x.shape[0]) for t in data.data.node_types}
+    assert n['Gene'] == 20032 and n['SNP'] == (9999264 if 'snp10m' in request.param else 784256)
+    widths = (data.snp_init_dim_size, data.gene_init_dim_size, data.go_init_dim_size)
+    assert widths == ((70, 57742, 128) if kw['mode'] == 'full' else (20, 5120, 128))
+    assert data.sample_size == {'c2_fast_subsample10k': 10000, 'c3_snp10m_full_cohort': 387113}.get(request.param, 5000)
+    yield run
+    data.data._extra.pop('_device_graphs', None)
+    del run, data
+    torch.cuda.empty_cache()
 
 
 def _loader(run, ids, bs=BS):
@@ -153,3 +178,77 @@ def test_graph_step_reproduces_eager_losses_at_full_size(full_run):
         le = float(run_e.train_step(next(it), opt, ld_w))
         assert np.isfinite(lg) and abs(lg - le) <= 1e-4 * abs(le) + 1e-7, (i, lg, le)
     gs.check()
+
+
+def test_config0_hip_training_tracks_the_cpu_restatement(full_run):
+    """configs[0] end to end on the HIP path: the thinned KG gives batches of mostly isolated seeds and EMPTY node types;
+    five Adam steps follow the CPU restatement trained on the same batches (per-step loss rtol 1e-4), then one whole
+    epoch runs through KGWAS.train with its validation / test / inference passes and the p-value post-processing."""
+    run = full_run
+    if run.cfg_name != 'c0_thinned_null':
+        pytest.skip('the oracle follows the training only on the thinned graph')
+    from kgwas_amd.kgwas import KGWAS
+    from oracle.gat_oracle import weighted_mse
+    from oracle.sampler_np import FullNeighborSamplerNP
+    from tests.helpers import oracle_from_product
+    data = run.data
+    g = data.data
+    run2 = KGWAS(data, device='cuda:0', seed=5)
+    run2.initialize_model()
+    oracle = oracle_from_product(run2.model, dtype=torch.float64)
+    opt = torch.optim.Adam(run2.model.parameters(), lr=1e-4, weight_decay=5e-4)
+    opt_o = torch.optim.Adam(oracle.parameters(), lr=1e-4, weight_decay=5e-4)
+    ld_w = run2._ld_weight_vector()
+    ids = np.asarray(data.train_input_nodes[1][:5 * BS])
+    smp = FullNeighborSamplerNP(g.edge_index_dict, g.num_nodes_dict, 2)
+    run2.model.train()
+    it = iter(_loader(run2, ids))
+    empty = 0
+    for i in range(5):
+        batch = next(it)
+        empty += sum(1 for t in g.node_types if batch.n_nodes[t] == 0)
+        loss = float(run2.train_step(batch, opt, ld_w))
+        seeds = ids[i * BS:(i + 1) * BS]
+        n_id, ei = smp.sample('SNP', seeds)
+        x = {k: g[k].x[v].double() for k, v in n_id.items()}
+        opt_o.zero_grad()
+        out = oracle(x, ei, BS)
+        s = torch.as_tensor(n_id['SNP'][:BS])
+        lo = weighted_mse(out, g['SNP'].y[s].double(), ld_w.cpu()[s])
+        lo.backward()
+        opt_o.step()
+        assert abs(loss - float(lo.detach())) <= 1e-4 * abs(float(lo.detach())) + 1e-7, (i, loss, float(lo.detach()))
+    # a batch of ISOLATED seeds only (most SNPs of the thinned graph have no edge at all): every other node type is empty,
+    # no relation has an edge -- the prediction is the read-out of the biases, the step must still run and agree
+    indeg = np.zeros(g['SNP'].x.shape[0], dtype=np.int64)
+    for et in g.edge_types:
+        if et[2] == 'SNP':
+            indeg += np.bincount(g[et].edge_index[1].numpy(), minlength=len(indeg))
+    iso = np.asarray(data.train_input_nodes[1])
+    iso = iso[indeg[iso] == 0][:BS]
+    assert len(iso) == BS
+    batch = next(iter(_loader(run2, iso)))
+    assert all(batch.n_nodes[t] == 0 for t in g.node_types if t != 'SNP') and batch.n_nodes['SNP'] == BS
+    assert sum(batch.n_edges_per_layer) == 0
+    loss = float(run2.train_step(batch, opt, ld_w))
+    x = {k: g[k].x[torch.as_tensor(iso if k == 'SNP' else np.zeros(0, dtype=np.int64))].double() for k in g.node_types}
+    ei = {et: torch.zeros(2, 0, dtype=torch.long) for et in g.edge_types}
+    opt_o.zero_grad()
+    s = torch.as_tensor(iso)
+    lo = weighted_mse(oracle(x, ei, BS), g['SNP'].y[s].double(), ld_w.cpu()[s])
+    assert abs(loss - float(lo.detach())) <= 1e-4 * abs(float(lo.detach())) + 1e-7, (loss, float(lo.detach()))
+    run2.train(batch_size=BS, epoch=1, save_best_model=False, save_name='cfg0')
+    res = run2.kgwas_res
+    assert len(res) == len(data.lr_uni) and np.isfinite(res['pred'].values).all()
+    assert {'P_weighted', 'KGWAS_P'} <= set(res.columns)
+    p = res['KGWAS_P'].values
+    assert np.isfinite(p).all() and p.min() >= 0.0 and p.max() <= 1.0
+    # the post-processing (kgwas.py:192-212) applied to the predictions reproduces the stored columns
+    from kgwas_amd.eval_utils import find_closest_x, storey_ribshirani_integrate
+    import pandas as pd
+    df = pd.DataFrame({'P': res['P'].values, 'abs_pred': np.abs(res['pred'].values)})
+    pw = storey_ribshirani_integrate(df, column='abs_pred', num_bins=500)
+    assert np.allclose(np.asarray(pw, dtype=np.float64), res['P_weighted'].values.astype(np.float64), rtol=1e-12, atol=0)
+    scale = find_closest_x(pd.DataFrame({'P': res['P'].values, 'P_weighted': pw}))
+    assert np.allclose(np.clip(scale * np.asarray(pw, dtype=np.float64), 0, 1), p, rtol=1e-12, atol=0)
+    assert np.isfinite(run2.val_metrics['pearsonr']) and np.isfinite(run2.test_metrics['mse'])
