@@ -44,10 +44,11 @@ def algorithmic_bytes_bwd(n_edges, z_rows, n_src):
     return 1048 * n_edges + 520 * (z_rows + n_src)
 
 
-def cpu_baseline(data, batch_size, budget_s=25.0, max_steps=2):
+def cpu_baseline(data, batch_size, budget_s=40.0, warmup=3, max_steps=20):
     """Reference PyG CPU path, restated (oracle/): numpy full-neighbour sampler + x[n_id] slicing + unpruned
-    2-layer HeteroGNN forward/backward + Adam, all host cores.  Bounded sample: as many steps as fit in
-    ~budget_s (at least 1 after 1 warm-up)."""
+    2-layer HeteroGNN forward/backward + Adam, on this box's host cores.  SURVEY.md 8d asks for >= 20 steps after 3
+    warm-ups; at ~2.5 s per step that is a minute of CPU work, so the timed part stops at ``budget_s`` seconds and the
+    line says how many steps fitted."""
     from oracle.gat_oracle import HeteroGNNOracle, weighted_mse
     from oracle.sampler_np import FullNeighborSamplerNP
     # more threads than ~16 only add OpenMP fork/join cost on these small scatter ops (256 threads: 355 s/step
@@ -55,19 +56,17 @@ def cpu_baseline(data, batch_size, budget_s=25.0, max_steps=2):
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     g = data.data
-    t0 = time.time()
     smp = FullNeighborSamplerNP(g.edge_index_dict, g.num_nodes_dict, 2)
     torch.manual_seed(1)
     model = HeteroGNNOracle(g.edge_types, 128, 1, 2, 'GAT', 'sum', data.snp_init_dim_size, data.gene_init_dim_size,
                             data.go_init_dim_size, 1)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-4)
-    setup_s = time.time() - t0
     ids = np.asarray(data.train_input_nodes[1])
     y_all = g['SNP'].y
     w_all = torch.zeros(g['SNP'].x.shape[0], dtype=torch.float64)
     w_all[torch.from_numpy(np.asarray(data.all_ids))] = torch.from_numpy(np.asarray(data.ldsc_weight))
     times, edges = [], []
-    for step in range(max_steps + 1):
+    for step in range(warmup + max_steps):
         seeds = ids[step * batch_size:(step + 1) * batch_size]
         t = time.time()
         n_id, ei = smp.sample('SNP', seeds)
@@ -78,16 +77,122 @@ def cpu_baseline(data, batch_size, budget_s=25.0, max_steps=2):
         loss.backward()
         opt.step()
         dt = time.time() - t
-        if step > 0:
+        if step >= warmup:
             times.append(dt)
             edges.append(2 * sum(int(v.shape[1]) for v in ei.values()))      # both layers touch every sampled edge
-        if step > 0 and sum(times) + dt > budget_s:
-            break
+            if sum(times) + dt > budget_s:
+                break
     tot_t = sum(times)
     return {'value': sum(edges) / tot_t, 'unit': 'edges/s', 'cores': cores, 'kind': 'port',
-            's_per_step': tot_t / len(times),
-            'sample': f'{len(times)} training steps (after 1 warm-up) of batch {batch_size} on the same SynthKG-fast '
-                      f'batches; unpruned (both layers over every sampled edge) like PyG; torch threads={cores}'}
+            's_per_step': tot_t / len(times), 'steps': len(times), 'warmup': warmup,
+            'sample': f'{len(times)} training steps after {warmup} warm-ups (SURVEY 8d asks for 20; the timed part is cut at '
+                      f'{budget_s:.0f} s of CPU work) of batch {batch_size} on the same SynthKG-fast batches; unpruned (both layers '
+                      f'over every sampled edge) like PyG; torch threads={cores} of {os.cpu_count()} host cores'}
+
+
+# --------------------------------------------------------------------------------------------------------------
+# HBM-side traffic of the aggregate kernels, measured IN THIS RUN: tools/pmc_probe.py under rocprofv3, one pass per
+# counter group (MI355X_MICROARCH.md, HBM / rocprofv3 PMC slots: FETCH_SIZE and WRITE_SIZE cannot share a pass)
+# --------------------------------------------------------------------------------------------------------------
+PMC_GROUPS = (('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE']),
+              ('cache', ['TCC_HIT_sum', 'TCC_MISS_sum', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CU_CYCLES', 'GRBM_GUI_ACTIVE']))
+
+
+def _pmc_rows(csv_path):
+    import csv
+    rows = list(csv.DictReader(open(csv_path)))
+    out = {}
+    for i, r in enumerate(rows):
+        name = r.get('Kernel_Name', '').replace('(anonymous namespace)::', '').replace('void ', '')
+        did = int(r.get('Dispatch_Id', i) or i)
+        out.setdefault((did, name), {})[r['Counter_Name']] = float(r['Counter_Value'])
+    return [(did, name, c) for (did, name), c in sorted(out.items())]
+
+
+def run_pmc_passes(args, outdir, timeout_s=300):
+    """Returns (summary dict, error string or None).  Every pass is a fresh process: `rocprofv3 --pmc <group>
+    --kernel-trace -- python tools/pmc_probe.py`; counters are attributed per dispatch by kernel name and order."""
+    import shutil
+    import subprocess
+    if shutil.which('rocprofv3') is None:
+        return None, 'rocprofv3 not on PATH'
+    os.makedirs(outdir, exist_ok=True)
+    probe = os.path.join(ROOT, 'tools', 'pmc_probe.py')
+    env = dict(os.environ, TMPDIR='/tmp')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    per = {}
+    notes = []
+    for tag, counters in PMC_GROUPS:
+        pj = os.path.join(outdir, f'{tag}_probe.json')
+        cmd = ['rocprofv3', '--pmc', *counters, '--kernel-trace', '--output-format', 'csv', '-d', outdir, '-o', tag, '--',
+               sys.executable, probe, '--out', pj, '--batch-size', str(args.batch_size), '--scale', str(args.scale),
+               '--snp-scale', str(args.snp_scale), '--mode', args.mode, '--big-batch', str(args.big_batch)]
+        try:
+            with open(os.path.join(outdir, f'{tag}.log'), 'w') as lf:
+                rc = subprocess.run(cmd, cwd='/tmp', env=env, stdout=lf, stderr=subprocess.STDOUT, timeout=timeout_s).returncode
+        except Exception as e:                                   # timeout, missing binary, ...
+            notes.append(f'{tag}: {type(e).__name__}')
+            continue
+        cp = os.path.join(outdir, f'{tag}_counter_collection.csv')
+        if rc != 0 or not os.path.exists(cp) or not os.path.exists(pj):
+            notes.append(f'{tag}: rocprofv3 exit {rc}')
+            continue
+        rows = _pmc_rows(cp)
+        probe_info = json.load(open(pj))
+        # calibration = the k_gather_rows dispatch with the largest value of the pass's first counter
+        cal = [(c.get(counters[0], 0.0), did) for did, name, c in rows if name.startswith('k_gather_rows')]
+        if not cal:
+            notes.append(f'{tag}: no calibration dispatch')
+            continue
+        cal_val, cal_id = max(cal)
+        per[tag] = {'rows': [(did, name, c) for did, name, c in rows if did > cal_id], 'cal': dict(next(c for d, n, c in rows if d == cal_id)),
+                    'probe': probe_info}
+    if 'fetch' not in per or 'write' not in per:
+        return None, '; '.join(notes) or 'counter passes incomplete'
+    info = per['fetch']['probe']
+    n_small = sum(1 for s_ in info['steps'] if s_['batch_size'] == args.batch_size)
+    corr_f = info['calibration']['read_bytes'] / max(per['fetch']['cal'].get('FETCH_SIZE', 0.0) * 1024.0, 1.0)
+    corr_w = info['calibration']['write_bytes'] / max(per['write']['cal'].get('WRITE_SIZE', 0.0) * 1024.0, 1.0)
+
+    def layer1(tag, kernel, counter):
+        """per step, the layer-1 dispatch of `kernel` = the larger of the step's two (layer 1, layer 2) dispatches"""
+        vals = [c.get(counter, 0.0) for _, name, c in per[tag]['rows'] if name.startswith(kernel)]
+        return [max(vals[i:i + 2]) for i in range(0, len(vals) - 1, 2)]
+    summ = {'fetch_correction': corr_f, 'write_correction': corr_w,
+            'calibration': {'kernel': 'k_gather_rows, identity ids, %d rows x 512 B (1 GiB >> the 256 MiB Infinity Cache)' % info['calibration']['rows'],
+                            'FETCH_SIZE_KB_raw': per['fetch']['cal'].get('FETCH_SIZE'), 'WRITE_SIZE_KB_raw': per['write']['cal'].get('WRITE_SIZE'),
+                            'known_read_bytes': info['calibration']['read_bytes'], 'known_write_bytes': info['calibration']['write_bytes']},
+            'kernels': {}, 'notes': notes}
+    for kernel in ('k_agg_fwd<false>', 'k_agg_bwd_dst', 'k_agg_bwd_src'):
+        f = layer1('fetch', kernel, 'FETCH_SIZE'); w = layer1('write', kernel, 'WRITE_SIZE')
+        ent = {}
+        for which, sl in (('batch', slice(0, n_small)), ('big_batch', slice(n_small, None))):
+            ff, ww = f[sl], w[sl]
+            if not ff or not ww:
+                continue
+            fb = float(np.median(ff)) * 1024.0 * corr_f
+            wb = float(np.median(ww)) * 1024.0 * corr_w
+            ent[which] = {'fetch_bytes': fb, 'write_bytes': wb, 'bytes': fb + wb, 'FETCH_SIZE_KB_raw': float(np.median(ff)),
+                          'WRITE_SIZE_KB_raw': float(np.median(ww)), 'dispatches': len(ff)}
+            if 'cache' in per:
+                h = layer1('cache', kernel, 'TCC_HIT_sum')[sl]; m_ = layer1('cache', kernel, 'TCC_MISS_sum')[sl]
+                if h and m_ and (np.median(h) + np.median(m_)) > 0:
+                    ent[which]['l2_hit_rate'] = float(np.median(h) / (np.median(h) + np.median(m_)))
+        summ['kernels'][kernel] = ent
+    # layer shapes of the probe's batches (for the compulsory / algorithmic byte counts of the same launches)
+    summ['probe_layers'] = {'batch': [s_['layers'][0] for s_ in info['steps'] if s_['batch_size'] == args.batch_size],
+                            'big_batch': [s_['layers'][0] for s_ in info['steps'] if s_['batch_size'] != args.batch_size]}
+    if 'cache' in per:                                            # MFMA pipe occupancy of the dense kernels
+        mf = {}
+        for _, name, c in per['cache']['rows']:
+            if name.startswith(('k_linear', 'k_tn_gemm', 'k_small_m', 'Cijk_')) and c.get('GRBM_GUI_ACTIVE', 0) > 0:
+                key = name.split('(')[0][:48]
+                d = mf.setdefault(key, {'mfma_busy_cycles': 0.0, 'gui_active_cycles': 0.0, 'dispatches': 0})
+                d['mfma_busy_cycles'] += c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0); d['gui_active_cycles'] += c['GRBM_GUI_ACTIVE']; d['dispatches'] += 1
+        summ['mfma'] = mf
+    json.dump(summ, open(os.path.join(outdir, 'summary.json'), 'w'), indent=1)
+    return summ, None
 
 
 def main():
@@ -101,8 +206,17 @@ def main():
                     help='multiply the SNP count and the SNP->Gene edges only (12.75 = the ~10 M-SNP full-cohort case of BASELINE.json configs[3]); not the headline workload')
     ap.add_argument('--mode', default='fast', choices=['fast', 'full'],
                     help="feature widths: 'fast' 20/5120/128 (BASELINE.json configs[1], the default) or 'full' 70/57742/128 (configs[4])")
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help="N > 1: 'weak' = every rank trains on its own --batch-size seeds per step (default); 'strong' = one "
+                         "--batch-size batch per step split over the ranks, what KGWAS.train does (kgwas_amd/kgwas.py)")
+    ap.add_argument('--parallelism', default='seed', choices=['seed', 'shard'],
+                    help="'seed' = seed-data-parallel, graph replicated (SURVEY 8e-i); 'shard' = SNP rows sharded by id range, "
+                         "Gene / GO replicated, partial-softmax exchange (SURVEY 8e-ii, north_star); implies strong scaling")
+    ap.add_argument('--big-batch', type=int, default=4096, help='seeds per batch of the second roofline measurement (working set > Infinity Cache)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 counter passes (roofline.traffic = null)')
+    ap.add_argument('--no-epoch', action='store_true', help='skip the measured epoch (956 training steps + validation pass)')
     ap.add_argument('--eager', action='store_true', help='issue every launch from the host instead of replaying one HIP graph per step')
     args = ap.parse_args()
 
@@ -129,6 +243,8 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device(dev))
         else:
             dist.init_process_group(backend)
+    shard = args.parallelism == 'shard'
+    strong = shard or args.scaling == 'strong'
 
     from kgwas_amd import dist as kdist
     from kgwas_amd import ops
@@ -149,12 +265,23 @@ def main():
     bs = args.batch_size
     need = (args.steps + args.warmup) * bs
     ids = np.asarray(data.train_input_nodes[1])
-    # weak scaling: rank r trains on batches r, r+world, ... of the reference's fixed batch order
     nb = len(ids) // bs
-    mine = ids[:nb * bs].reshape(nb, bs)[rank::world].reshape(-1)
-    if len(mine) < need:
-        mine = np.resize(mine, need)
-    mine = mine[:need]
+    if strong:
+        # strong scaling: the reference's own batch order; every rank works on ITS part of each 512-seed batch
+        mine = ids[:nb * bs]
+        if len(mine) < need:
+            mine = np.resize(mine, need)
+        mine = mine[:need]
+        if not shard:
+            mine = kdist.shard_batches(mine, bs, rank, world)
+        bs_rank = bs // world if not shard else bs
+    else:
+        # weak scaling: rank r trains on batches r, r+world, ... of the reference's fixed batch order
+        mine = ids[:nb * bs].reshape(nb, bs)[rank::world].reshape(-1)
+        if len(mine) < need:
+            mine = np.resize(mine, need)
+        mine = mine[:need]
+        bs_rank = bs
     run.model.train()
 
     def sync():
@@ -162,9 +289,19 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    if args.eager:
+    gs = None
+    if shard:
+        from kgwas_amd.shard import ShardedTrainer
+        st_ = ShardedTrainer(run, ('SNP', mine), bs, lr=1e-4, weight_decay=5e-4, use_graph=not args.eager)
+        stats_e = [0, 0]
+
+        def do_step(i):
+            e1, e2 = st_.step(i)
+            stats_e[0] += e1; stats_e[1] += e2
+        mode = st_.describe()
+    elif args.eager:
         opt = torch.optim.Adam(run.model.parameters(), lr=1e-4, weight_decay=5e-4)
-        it = iter(NeighborLoader(data.data, [-1, -1], ('SNP', mine), batch_size=bs, drop_last=True, device=dev))
+        it = iter(NeighborLoader(data.data, [-1, -1], ('SNP', mine), batch_size=bs_rank, drop_last=True, device=dev))
         stats_e = [0, 0]
 
         def do_step(i):
@@ -175,17 +312,16 @@ def main():
         mode = 'eager launches'
     else:
         from kgwas_amd.graph_step import GraphTrainStep
-        gs = GraphTrainStep(run, ('SNP', mine), bs, lr=1e-4, weight_decay=5e-4)
+        gs = GraphTrainStep(run, ('SNP', mine), bs_rank, lr=1e-4, weight_decay=5e-4)
 
         def do_step(i):
             gs.step(i)
-        mode = ('HIP graphs: step graph (fwd + bwd' + (' + Adam)' if gs.capture_optimizer else '), RCCL all-reduce + Adam eager') +
-                (' with the next batch sampled by a second graph on a side stream' if gs.twin else ', sampling inside it'))
+        mode = gs.describe()
     setup_s = time.time() - t0
 
     for i in range(args.warmup):
         do_step(i)
-    if not args.eager:
+    if gs is not None:
         torch.cuda.synchronize()
         gs.stats.zero_()
     else:
@@ -196,16 +332,20 @@ def main():
         do_step(args.warmup + i)
     sync()
     elapsed = time.perf_counter() - t_start
-    seeds = args.steps * bs
-    if args.eager:
-        edges_kernel, edges_ref = stats_e
-    else:
+    seeds = args.steps * (bs if shard else bs_rank)
+    if gs is not None:
         st = gs.check()                       # raises if a batch overflowed the static layout
         edges_kernel, edges_ref = sum(st[:2]), 2 * st[2]
+    else:
+        edges_kernel, edges_ref = stats_e
+    if shard and rank != 0:
+        seeds = 0                             # (every rank works on the same batches: count the seeds once)
 
+    single = world == 1 and not shard
     # kernel-level timing for the roofline: HIP events around the aggregate launches on their stream, in an
     # eager pass over the same batches right after the timed region (events cannot bracket nodes of a replayed graph)
-    if not args.no_kernel_timing:
+    big_summ = {}
+    if not args.no_kernel_timing and single:
         opt_r = torch.optim.Adam(run.model.parameters(), lr=1e-4, weight_decay=5e-4)
         n_r = min(args.steps, 20)
         it_r = iter(NeighborLoader(data.data, [-1, -1], ('SNP', mine[args.warmup * bs:(args.warmup + n_r) * bs]),
@@ -215,6 +355,50 @@ def main():
             run.train_step(next(it_r), opt_r, ld_w, world)
         torch.cuda.synchronize()
         ops.TIMER.enabled = False
+        summ = ops.TIMER.summary()
+        # the same kernels on batches of --big-batch seeds: one launch's working set (~0.3 GB of gathered rows) no longer
+        # fits the 256 MiB Infinity Cache, so the counter traffic of THOSE launches is HBM traffic
+        if args.big_batch and args.big_batch * 3 <= len(ids):
+            ops.TIMER.records.clear()
+            it_b = iter(NeighborLoader(data.data, [-1, -1], ('SNP', ids[args.big_batch:4 * args.big_batch]), batch_size=args.big_batch,
+                                       drop_last=True, device=dev, prefetch=False))
+            ops.TIMER.enabled = True
+            for _ in range(3):
+                bb = next(it_b)
+                for p_ in run.model.parameters():
+                    p_.grad = None
+                loss_b, _ = run.model.forward_loss(bb.x_dict, bb.edge_index_dict, args.big_batch, bb.n_id('SNP'), bb.dg.y['SNP'], ld_w)
+                loss_b.backward()
+            torch.cuda.synchronize()
+            ops.TIMER.enabled = False
+            big_summ = ops.TIMER.summary()
+            del it_b, bb
+    else:
+        summ = {}
+
+    # one measured epoch at reference scale: the 956 training steps of the fixed batch order + the validation pass
+    epoch = None
+    if not args.no_epoch and single and not args.eager and args.scale == 1.0:
+        from kgwas_amd.graph_step import GraphTrainStep
+        from kgwas_amd.utils import evaluate_minibatch_clean
+        run.make_loaders(bs)
+        ge = GraphTrainStep(run, ('SNP', ids), bs, lr=1e-4, weight_decay=5e-4)
+        for i in range(3):
+            ge.step(i)
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        for i in range(ge.n_batches):
+            ge.step(i)
+        ge.check()
+        t_train = time.perf_counter() - te
+        tv = time.perf_counter()
+        val = evaluate_minibatch_clean(run.val_loader, run.model, dev)
+        torch.cuda.synchronize()
+        t_val = time.perf_counter() - tv
+        epoch = {'train_steps': ge.n_batches, 'train_s': t_train, 'val_batches': len(run.val_loader), 'val_s': t_val,
+                 'epoch_s': t_train + t_val, 'note': 'one pass over the 489 839 training SNPs in the reference batch order (kgwas/kgwas.py:129) + '
+                 'the validation pass of kgwas.py:157 (first use: includes capturing its forward graph)'}
+        del ge
 
     stats = torch.tensor([elapsed, float(edges_kernel), float(edges_ref), float(seeds)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -229,71 +413,105 @@ def main():
         torch.distributed.destroy_process_group()
     if rank != 0:
         return
-    summ = ops.TIMER.summary()
-    breakdown, roof = {}, None
-    for (tag, layer), d in sorted(summ.items()):
-        byts = algorithmic_bytes_fwd(d['edges'], d['z_rows']) if tag == 'fwd' else None
+
+    pmc, pmc_err = (None, 'skipped')
+    if not args.no_pmc and single and not args.no_kernel_timing:
+        pmc, pmc_err = run_pmc_passes(args, os.path.join(ROOT, 'gpurun_out', 'bench_pmc'))
+
+    def agg_entry(tag, d):
         entry = {'launches': d['n'], 'avg_ms': d['ms'] / d['n'], 'edges_per_launch': d['edges'] / d['n']}
-        if tag == 'fwd':
-            entry['algorithmic_GBs'] = byts / (d['ms'] * 1e-3) / 1e9
-        elif tag == 'bwd_dst':
-            entry['algorithmic_GBs'] = (528 * d['edges'] + 1028 * d['z_rows']) / (d['ms'] * 1e-3) / 1e9
-        elif tag == 'bwd_src':
-            entry['algorithmic_GBs'] = (528 * d['edges'] + 520 * d['n_src']) / (d['ms'] * 1e-3) / 1e9
-        breakdown[f'agg_{tag}_l{layer}'] = entry
+        alg = {'fwd': algorithmic_bytes_fwd(d['edges'], d['z_rows']), 'bwd_dst': 528 * d['edges'] + 1028 * d['z_rows'],
+               'bwd_src': 528 * d['edges'] + 520 * d['n_src']}[tag]
+        entry['algorithmic_GBs'] = alg / (d['ms'] * 1e-3) / 1e9
+        return entry
+    breakdown = {f'agg_{tag}_l{layer}': agg_entry(tag, d) for (tag, layer), d in sorted(summ.items())}
+    for (tag, layer), d in sorted(big_summ.items()):
+        breakdown[f'agg_{tag}_l{layer}_batch{args.big_batch}'] = agg_entry(tag, d)
+
+    def roofline_of(d, counters, what):
+        """d: TIMER summary of the layer-1 forward launches; counters: run_pmc_passes entry of the same launch shape."""
+        n = d['n']
+        alg = algorithmic_bytes_fwd(d['edges'], d['z_rows']) / n
+        # bytes a launch cannot avoid: every row of the layer input once (all are gathered at least once), the column
+        # index and the logit of every edge once, the Z row + softmax statistics of every segment, the chunk records
+        comp = (512 * d['n_src'] + 8 * d['edges'] + 520 * d['z_rows']) / n
+        ms = d['ms'] / n
+        r = {'kernel': 'k_agg_fwd (layer-1 attention aggregate, forward)', 'workload': what, 'bound': 'hbm',
+             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'avg_launch_ms': ms, 'edges_per_launch': d['edges'] / n,
+             'algorithmic_bytes': alg, 'algorithmic_GBs': alg / ms / 1e6, 'algorithmic_frac': alg / ms / 1e6 / HBM_PEAK_GBS,
+             'compulsory_bytes': comp, 'compulsory_GBs': comp / ms / 1e6,
+             'timing': 'hipEvent pair recorded by the C ABI immediately around the k_agg_fwd launch on its stream (KgwLayerArgs.ev_before/ev_after), eager pass'}
+        if counters:
+            r['traffic'] = counters['bytes']
+            r['traffic_fetch_bytes'], r['traffic_write_bytes'] = counters['fetch_bytes'], counters['write_bytes']
+            r['achieved'] = counters['bytes'] / ms / 1e6
+            r['traffic_over_compulsory'] = counters['bytes'] / comp
+            if 'l2_hit_rate' in counters:
+                r['l2_hit_rate'] = counters['l2_hit_rate']
+            r['achieved_is'] = ('L2-side (fabric) bytes of the launch, FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes made by '
+                                'this run, corrected by the known byte count of a 1 GiB row gather in the same pass, / HIP-event time')
+        else:
+            r['traffic'] = None
+            r['achieved'] = comp / ms / 1e6
+            r['achieved_is'] = 'no counters in this run: compulsory bytes / HIP-event time (a LOWER bound on the traffic rate)'
+        r['frac'] = r['achieved'] / HBM_PEAK_GBS
+        return r
+
+    roof = None
     if ('fwd', 1) in summ:
-        d = summ[('fwd', 1)]
-        ach = algorithmic_bytes_fwd(d['edges'], d['z_rows']) / (d['ms'] * 1e-3) / 1e9
-        roof = {'kernel': 'k_agg_fwd (layer-1 attention aggregate, forward)',
-                'timing': 'hipEvent pair recorded by the C ABI immediately around the k_agg_fwd launch on its stream (KgwLayerArgs.ev_before/ev_after), eager pass over the timed batches',
-                'bound': 'hbm', 'achieved': ach,
-                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                'bytes_per_launch': algorithmic_bytes_fwd(d['edges'], d['z_rows']) / d['n'],
-                'avg_launch_ms': d['ms'] / d['n'], 'traffic': None}
+        ck = (pmc or {}).get('kernels', {}).get('k_agg_fwd<false>', {})
+        roof = roofline_of(summ[('fwd', 1)], ck.get('batch'), f'batch {bs} (the benchmark workload)')
         # rocprofv3 --stats averages ALL launches of the kernel name (layer 1: ~1 M edges, layer 2: ~2 k edges) together:
         # the figure to compare with profiles/*kernel_stats*.csv
         allf = [v for (tag, _), v in summ.items() if tag == 'fwd']
         roof['avg_ms_all_launches_of_this_kernel_name'] = sum(v['ms'] for v in allf) / max(1, sum(v['n'] for v in allf))
-        pmc = os.path.join(ROOT, 'profiles', 'pmc_agg_fwd.json')
-        if os.path.exists(pmc):
-            try:
-                roof['traffic'] = json.load(open(pmc)).get('hbm_bytes_per_launch')
-            except Exception:
-                pass
-        if roof['traffic']:
-            # `achieved` follows the contract (ALGORITHMIC bytes / launch time) and can exceed the peak: a source row gathered
-            # by several relations / destination rows is counted every time but fetched from HBM once.  The HBM-side rate
-            # of the same launch, from the PMC traffic:
-            roof['hbm_side_GBs'] = roof['traffic'] / (roof['avg_launch_ms'] * 1e-3) / 1e9
-            roof['hbm_side_frac'] = roof['hbm_side_GBs'] / HBM_PEAK_GBS
-            roof['note'] = ('achieved = algorithmic bytes (SURVEY 8d: 520 B per edge and per segment) / HIP-event time; the PMC '
-                            'counters see less HBM traffic than that (traffic, hbm_side_*): re-used source rows are served by L2 / '
-                            'Infinity Cache')
+        if ('fwd', 1) in big_summ:
+            roof['beyond_infinity_cache'] = roofline_of(big_summ[('fwd', 1)], ck.get('big_batch'),
+                                                        f'batch {args.big_batch}: the gathered rows of one launch exceed the 256 MiB Infinity Cache, FETCH_SIZE is HBM traffic')
+        if pmc:
+            roof['counter_files'] = 'gpurun_out/bench_pmc/{fetch,write,cache}_counter_collection.csv + summary.json (written by this run)'
+            roof['fetch_correction'], roof['write_correction'] = pmc['fetch_correction'], pmc['write_correction']
+            roof['other_kernels'] = {k: v for k, v in pmc['kernels'].items() if k != 'k_agg_fwd<false>'}
+            if pmc.get('mfma'):
+                # MFMA pipe occupancy of the dense kernels: busy cycles of the matrix pipes / (dispatch cycles x 1024 SIMDs)
+                roof['mfma_util'] = {k: {'busy_over_simd_cycles': v['mfma_busy_cycles'] / max(v['gui_active_cycles'] * 1024.0, 1.0),
+                                         'dispatches': v['dispatches']} for k, v in pmc['mfma'].items()}
+        else:
+            roof['counter_note'] = f'counter passes unavailable: {pmc_err}'
+        hit = roof.get('l2_hit_rate')
+        roof['bounded_by'] = ('at batch %d the launch touches %.0f MB of distinct rows (< 256 MiB Infinity Cache): the fabric-side bytes above are '
+                              'served by L3 + HBM together, so `frac` is an UPPER bound on HBM utilisation; the binding resource is the per-XCD '
+                              'L2 miss path (each of the 8 non-coherent L2s fetches its own copy of a hot row%s); see beyond_infinity_cache for the '
+                              'launch shape where the same counters are HBM bytes' %
+                              (bs, roof['compulsory_bytes'] / 1e6, '' if hit is None else ', L2 hit rate %.2f' % hit))
     cpu = None
     if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed at N = 1 only
         cpu = cpu_baseline(data, bs)
     ms = elapsed / args.steps * 1e3
+    headline = args.mode == 'fast' and args.snp_scale == 1.0 and args.scale == 1.0
+    par = (f'snp-shard{world} (SNP rows by id range, Gene/GO replicated, partial-softmax exchange)' if shard else f'seed-dp{world}')
     out = {
         'metric': 'edges aggregated/sec (full fast-mode KG minibatch training; epoch time in config)',
         'value': edges_kernel / elapsed, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
+        'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': ('SynthKG-fast full KG (784256 SNP / 20032 Gene / ~20.6M directed edges; features '
-                                '20/5120/128) + causal-simulation GWAS seed=1, batch 512 seeds per GPU, 2-layer GAT-128, '
-                                'Adam(1e-4, wd 5e-4) -- BASELINE.json configs[1]') if (args.mode == 'fast' and args.snp_scale == 1.0 and args.scale == 1.0) else
+                                '20/5120/128) + causal-simulation GWAS seed=1, batch 512 seeds %s, 2-layer GAT-128, '
+                                'Adam(1e-4, wd 5e-4) -- BASELINE.json configs[1]' % ('per step, split over the GPUs' if strong else 'per GPU')) if headline else
                                (f'SynthKG-fast with scale={args.scale}, snp_scale={args.snp_scale} (see config.graph) -- NOT the headline configuration; '
-                                'snp_scale 12.75 is the ~10 M-SNP full-cohort case of BASELINE.json configs[3] on ONE GPU') if args.mode == 'fast' else
-                               ('SynthKG-full: same graph, full-mode feature widths 70/57742/128 -- BASELINE.json configs[4] '
-                                'on one GPU, not the headline configuration'),
+                                'snp_scale 12.75 is the ~10 M-SNP full-cohort case of BASELINE.json configs[3]') if args.mode == 'fast' else
+                               ('SynthKG-full: same graph, full-mode feature widths 70/57742/128 -- BASELINE.json configs[4], '
+                                'not the headline configuration'),
                    'scale': args.scale, 'snp_scale': args.snp_scale,
                    'graph': {'nodes': {t: int(data.data[t].x.shape[0]) for t in data.data.node_types},
                              'directed_edges': int(sum(data.data[et].edge_index.shape[1] for et in data.data.edge_types))},
-                   'batch_size_per_gpu': bs, 'parallelism': f'seed-dp{world}', 'execution': mode,
-                   'edges_per_step_kernel': edges_kernel / args.steps / world,
-                   'edges_per_step_reference_equivalent': edges_ref / args.steps / world,
+                   'batch_size_per_gpu': bs_rank, 'global_batch': bs if strong else bs * world, 'parallelism': par, 'execution': mode,
+                   'edges_per_step_kernel': edges_kernel / args.steps / (1 if strong else world),
+                   'edges_per_step_reference_equivalent': edges_ref / args.steps / (1 if strong else world),
                    'reference_equivalent_edges_per_s': edges_ref / elapsed,
                    'seeds_per_s': seeds / elapsed,
-                   'epoch_time_s_956_steps': 956 * ms / 1e3 / world,
+                   'epoch_time_s_956_steps': 956 * ms / 1e3 / (1 if strong else world),
+                   'epoch_measured': epoch,
                    'setup_s': setup_s},
         'roofline': roof, 'cpu_baseline': cpu, 'breakdown': breakdown,
     }

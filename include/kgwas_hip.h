@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define KGW_VERSION      100          /* 0.1.0 */
+#define KGW_VERSION      110          /* 0.1.1 */
 #define KGW_MAX_TYPES    8
 #define KGW_MAX_RELS     64
 #define KGW_MAX_LAYERS   4
@@ -169,6 +169,10 @@ typedef struct KgwLayerArgs {
     void* ev_before; void* ev_after;
     float* da_src;                 /* [n_src_rows][2*ld], ld = (n_rels+3)&~3: columns [0,ld) d a_src, [ld,2ld) d a_dst
                                       of the node, one column per relation id (n_rels <= 32)            */
+    uint64_t partial_rels;         /* forward: bit r set => the segments of relation r are written as PARTIAL online-softmax
+                                      states -- Z = sum_j exp(e_ij - m) h_j (not divided), stat = (m, sum_j exp(e_ij - m)) --
+                                      for the caller to merge across GPUs (SNP-sharded mode: a rank holds only its own SNP
+                                      sources of a SNP->Gene relation; kgw_softmax_merge) before anything reads them   */
 } KgwLayerArgs;
 
 /* ---- entry points ------------------------------------------------------------------------ */
@@ -187,12 +191,37 @@ int kgw_struct_sizes(int64_t* out, int n);
  * kgwas/utils.py:446-461).                                                                    */
 int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, const int64_t* seeds,
                      int32_t n_seeds, int32_t seed_type, int32_t full_graph, kgw_stream_t stream);
+/* The same call in parts [part_begin, part_end] (kgw_sample_batch = parts 0 .. 2*n_hops): hop h is part 2h (its segments
+ * and chunks, and the flag KGW_PENDING = -2 in g2l on every not-yet-sampled source node) and part 2h+1 (flags -> local
+ * ids, relabelled edges); part 2*n_hops = layer tables, src-major structures, meta export.  SNP-sharded multi-GPU mode
+ * (BASELINE.json north_star; no counterpart in the single-device reference, kgwas/kgwas.py:38-39): between parts 2h and
+ * 2h+1 the ranks take the element-wise MIN of the g2l regions of the REPLICATED node types (one RCCL all-reduce of
+ * ~44 k int32), so every rank expands the same Gene / GO frontier although it only sees its own SNP seeds.        */
+int kgw_sample_batch_parts(const KgwGraph* graph, const KgwBatchBuf* buf, const int64_t* seeds,
+                           int32_t n_seeds, int32_t seed_type, int32_t full_graph, int32_t part_begin,
+                           int32_t part_end, kgw_stream_t stream);
 
 /* Replaces: GATConv.edge_update + message + aggregate (kgwas/conv.py:200-228,182) and their
  * autograd for all relations of one layer.                                                    */
 int kgw_gat_aggregate_fwd(const KgwLayerArgs* args, kgw_stream_t stream);
 int kgw_gat_aggregate_bwd_dst(const KgwLayerArgs* args, kgw_stream_t stream);
 int kgw_gat_aggregate_bwd_src(const KgwLayerArgs* args, kgw_stream_t stream);
+
+/* SNP-sharded mode, the exchange step of a layer: the softmax of kgwas/conv.py:223 runs over ALL
+ * in-edges of a destination gene, but a rank only aggregated the edges whose SNP source it owns.
+ * kgw_softmax_pack: record x (132 floats: [0] = m, [1] = s, [4..131] = acc) <- the partial state of segment
+ *   seg_zrow[x] (Z row / stat pair written by kgw_gat_aggregate_fwd under KgwLayerArgs.partial_rels).
+ * kgw_softmax_merge: parts [n_ranks][n_seg][132] (every rank's pack, gathered in rank order) ->
+ *   Z[seg_zrow[x]] = sum_p acc_p e^(m_p - m*) / (sum_p s_p e^(m_p - m*) + 1e-16), stat = (m*, that denominator), with
+ *   m* = max over the ranks that saw an edge (s_p > 0); fixed rank order, so every rank computes the same bits.
+ * kgw_scatter_rows: dst[ids[i]] = src[i] (rows of `width` floats): puts the all-reduced dZ rows of the exchanged segments
+ *   back (the gather is kgw_gather_rows).                                                                          */
+int kgw_softmax_pack(const float* Z, const float* stat, const int32_t* seg_zrow, int64_t n_seg, float* parts,
+                     kgw_stream_t stream);
+int kgw_softmax_merge(const float* parts, int32_t n_ranks, const int32_t* seg_zrow, int64_t n_seg, float* Z,
+                      float* stat, kgw_stream_t stream);
+int kgw_scatter_rows(const float* src, const int32_t* ids, int64_t n_rows, int32_t width, float* dst,
+                     kgw_stream_t stream);
 
 /* Running totals over the batches of a captured training loop: stats[l] += edges aggregated by layer l+1 (l < n_layers),
  * stats[n_layers] += edges sampled, stats[n_layers+1] |= KgwBatchMeta.error.  stats: n_layers + 2 device int64.   */

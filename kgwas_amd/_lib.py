@@ -95,6 +95,7 @@ class KgwLayerArgs(C.Structure):
         ('dZ', C.c_void_p), ('adp', C.c_void_p), ('da_dst', C.c_void_p), ('part_da', C.c_void_p),
         ('t_ptr', C.c_void_p), ('t_edge', C.c_void_p), ('t_zrow', C.c_void_p),
         ('dH', C.c_void_p), ('ev_before', C.c_void_p), ('ev_after', C.c_void_p), ('da_src', C.c_void_p),
+        ('partial_rels', C.c_uint64),
     ]
 
 
@@ -105,7 +106,8 @@ class KgwTnJob(C.Structure):
                 ('M', C.c_int32), ('N', C.c_int32), ('c_transposed', C.c_int32), ('colsum_repeat', C.c_int32)]
 
 
-EXPORTS = ['kgw_version', 'kgw_status_string', 'kgw_struct_sizes', 'kgw_sample_batch',
+EXPORTS = ['kgw_version', 'kgw_status_string', 'kgw_struct_sizes', 'kgw_sample_batch', 'kgw_sample_batch_parts',
+           'kgw_softmax_pack', 'kgw_softmax_merge', 'kgw_scatter_rows',
            'kgw_gat_aggregate_fwd', 'kgw_gat_aggregate_bwd_dst', 'kgw_gat_aggregate_bwd_src',
            'kgw_gather_rows', 'kgw_gather_rows_multi', 'kgw_scatter_relu_rows', 'kgw_scatter_relu_rows_workspace_floats', 'kgw_edge_alpha', 'kgw_debug_reduce', 'kgw_debug_reduce8', 'kgw_tn_gemm', 'kgw_tn_gemm_ex', 'kgw_tn_gemm_multi', 'kgw_tn_gemm_workspace_floats',
            'kgw_linear', 'kgw_adam', 'kgw_relvec_fwd', 'kgw_relvec_bwd', 'kgw_wmse_fwd', 'kgw_wmse_bwd', 'kgw_readout_wmse_fwd', 'kgw_readout_wmse_bwd', 'kgw_accumulate_stats']
@@ -139,6 +141,11 @@ def lib():
         raise KgwasHipError(f'ABI struct size mismatch: library {list(sizes)} vs binding {mine}')
     L.kgw_sample_batch.argtypes = [C.POINTER(KgwGraph), C.POINTER(KgwBatchBuf), C.c_void_p, C.c_int32,
                                    C.c_int32, C.c_int32, C.c_void_p]
+    L.kgw_sample_batch_parts.argtypes = [C.POINTER(KgwGraph), C.POINTER(KgwBatchBuf), C.c_void_p, C.c_int32,
+                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    L.kgw_softmax_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.kgw_softmax_merge.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.kgw_scatter_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     for name in ('kgw_gat_aggregate_fwd', 'kgw_gat_aggregate_bwd_dst', 'kgw_gat_aggregate_bwd_src'):
         getattr(L, name).argtypes = [C.POINTER(KgwLayerArgs), C.c_void_p]
     L.kgw_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]

@@ -51,6 +51,7 @@ struct LayerTab {
     int8_t rel_of_dslot[KGW_MAX_TYPES][KGW_MAX_RELS / 2];   // relation id of (destination type, slot)
     int32_t type_z_base[KGW_MAX_TYPES];
     int32_t type_R_dst[KGW_MAX_TYPES];
+    uint64_t partial;                                       // bit r: relation r leaves PARTIAL softmax states (sharded mode)
 };
 
 struct AggPtrs {
@@ -228,8 +229,10 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_fwd(LayerTab T, AggPtrs P, floa
         acc.x += kgw_xhalf(acc.x); acc.y += kgw_xhalf(acc.y);
         acc.z += kgw_xhalf(acc.z); acc.w += kgw_xhalf(acc.w);
         if (ck.nch == 1) {
-            const float den = RAW ? 1.f : S + 1e-16f;
-            const float inv = 1.0f / den;
+            // partial state (SNP-sharded mode): unnormalised sum and (max, sum of exponentials), merged across ranks later
+            const bool partial = !RAW && ((T.partial >> r) & 1ull);
+            const float den = RAW ? 1.f : (partial ? S : S + 1e-16f);
+            const float inv = partial ? 1.f : 1.0f / den;
             if (half == 0) {
                 scale4(acc, inv);
                 ((float4*)(P.Z + (int64_t)zrow * KGW_C))[hl] = acc;
@@ -276,7 +279,8 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_fwd_combine(LayerTab T, AggPtrs
             acc.x = fmaf(a.x, f, acc.x); acc.y = fmaf(a.y, f, acc.y);
         }
         // (raw mode: every partial carries max 0 and sum 1, so f == 1 above and the sum of partials is the result)
-        const float den = P.raw ? 1.f : S + 1e-16f, inv = 1.0f / den;
+        const bool partial = !P.raw && ((T.partial >> r) & 1ull);
+        const float den = P.raw ? 1.f : (partial ? S : S + 1e-16f), inv = partial ? 1.f : 1.0f / den;
         ((float2*)(P.Z + (int64_t)zrow * KGW_C))[lane] = make_float2(acc.x * inv, acc.y * inv);
         if (lane == 0) { P.stat[2 * (int64_t)zrow] = M; P.stat[2 * (int64_t)zrow + 1] = den; }
     }
@@ -725,6 +729,7 @@ int build_tab(const KgwLayerArgs* a, LayerTab* T) {
     if (G->n_rels > KGW_MAX_RELS || G->n_types > KGW_MAX_TYPES) return KGW_E_RANGE;
     T->n_rels = G->n_rels;
     T->n_types = G->n_types;
+    T->partial = a->partial_rels;
     T->ld_da = (G->n_rels + 3) & ~3;
     if (2 * T->ld_da > 64) return KGW_E_UNSUPPORTED;          // one wavefront-wide store per source row
     for (int r = 0; r < G->n_rels; ++r) {
@@ -857,6 +862,104 @@ extern "C" int kgw_edge_alpha(const KgwLayerArgs* a, float* alpha_out, kgw_strea
     if (rc) return rc;
     AggPtrs P = build_ptrs(a);
     k_edge_alpha<<<grid_for_waves(a->n_chunks), KGW_BLK, 0, (hipStream_t)stream_>>>(T, P, a->inv_temp, alpha_out);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+
+// ---- SNP-sharded mode: merge of partial softmax states across ranks --------------------------------------------
+namespace {
+// one half-wave (32 lanes x float4) per segment
+__global__ void __launch_bounds__(KGW_BLK) k_softmax_pack(const float* __restrict__ Z, const float* __restrict__ stat,
+                                                          const int32_t* __restrict__ seg_zrow, int64_t n_seg,
+                                                          float* __restrict__ parts) {
+    const int hl = threadIdx.x & 31;
+    for (int64_t x = (int64_t)blockIdx.x * (KGW_BLK / 32) + (threadIdx.x >> 5); x < n_seg; x += (int64_t)gridDim.x * (KGW_BLK / 32)) {
+        const int64_t z = seg_zrow[x];
+        float* pr = parts + x * PART_STRIDE;
+        ((float4*)(pr + 4))[hl] = ((const float4*)(Z + z * KGW_C))[hl];
+        if (hl == 0) { pr[0] = stat[2 * z]; pr[1] = stat[2 * z + 1]; pr[2] = 0.f; pr[3] = 0.f; }
+    }
+}
+
+__global__ void __launch_bounds__(KGW_BLK) k_softmax_merge(const float* __restrict__ parts, int n_ranks,
+                                                           const int32_t* __restrict__ seg_zrow, int64_t n_seg,
+                                                           float* __restrict__ Z, float* __restrict__ stat) {
+    const int hl = threadIdx.x & 31;
+    for (int64_t x = (int64_t)blockIdx.x * (KGW_BLK / 32) + (threadIdx.x >> 5); x < n_seg; x += (int64_t)gridDim.x * (KGW_BLK / 32)) {
+        float M = NEG_BIG;
+        for (int p = 0; p < n_ranks; ++p) {
+            const float* pr = parts + ((int64_t)p * n_seg + x) * PART_STRIDE;
+            if (pr[1] > 0.f) M = fmaxf(M, pr[0]);               // ranks without an edge of this segment left (0, 0)
+        }
+        float S = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = 0; p < n_ranks; ++p) {                     // fixed rank order: the same bits on every rank
+            const float* pr = parts + ((int64_t)p * n_seg + x) * PART_STRIDE;
+            const float s = pr[1];
+            if (!(s > 0.f)) continue;
+            const float f = __expf(pr[0] - M);
+            S = fmaf(s, f, S);
+            fma4(acc, f, ((const float4*)(pr + 4))[hl]);
+        }
+        const int64_t z = seg_zrow[x];
+        const bool any = S > 0.f;
+        const float den = any ? S + 1e-16f : 0.f, inv = any ? 1.0f / den : 0.f;
+        scale4(acc, inv);
+        ((float4*)(Z + z * KGW_C))[hl] = acc;
+        if (hl == 0) { stat[2 * z] = any ? M : 0.f; stat[2 * z + 1] = den; }
+    }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(KGW_BLK) k_scatter_rows(const float* __restrict__ src, const int32_t* __restrict__ ids,
+                                                          int64_t total, int wv, float* __restrict__ dst) {
+    for (int64_t e = (int64_t)blockIdx.x * KGW_BLK + threadIdx.x; e < total; e += (int64_t)gridDim.x * KGW_BLK) {
+        const int64_t r = e / wv;
+        const int c = (int)(e - r * wv);
+        const int64_t d = (int64_t)ids[r] * wv + c;
+        if (VEC == 4) ((float4*)dst)[d] = ((const float4*)src)[e];
+        else dst[d] = src[e];
+    }
+}
+}  // namespace
+
+extern "C" int kgw_softmax_pack(const float* Z, const float* stat, const int32_t* seg_zrow, int64_t n_seg, float* parts,
+                                kgw_stream_t stream_) {
+    if (n_seg == 0) return KGW_OK;
+    if (!Z || !stat || !seg_zrow || !parts) return KGW_E_NULL;
+    if (n_seg < 0) return KGW_E_RANGE;
+    int64_t g = (n_seg + KGW_BLK / 32 - 1) / (KGW_BLK / 32);
+    if (g > KGW_GRID) g = KGW_GRID;
+    k_softmax_pack<<<(int)g, KGW_BLK, 0, (hipStream_t)stream_>>>(Z, stat, seg_zrow, n_seg, parts);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+extern "C" int kgw_softmax_merge(const float* parts, int32_t n_ranks, const int32_t* seg_zrow, int64_t n_seg, float* Z,
+                                 float* stat, kgw_stream_t stream_) {
+    if (n_seg == 0) return KGW_OK;
+    if (!parts || !seg_zrow || !Z || !stat) return KGW_E_NULL;
+    if (n_seg < 0 || n_ranks < 1) return KGW_E_RANGE;
+    int64_t g = (n_seg + KGW_BLK / 32 - 1) / (KGW_BLK / 32);
+    if (g > KGW_GRID) g = KGW_GRID;
+    k_softmax_merge<<<(int)g, KGW_BLK, 0, (hipStream_t)stream_>>>(parts, n_ranks, seg_zrow, n_seg, Z, stat);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+extern "C" int kgw_scatter_rows(const float* src, const int32_t* ids, int64_t n_rows, int32_t width, float* dst,
+                                kgw_stream_t stream_) {
+    if (n_rows == 0) return KGW_OK;
+    if (!src || !ids || !dst) return KGW_E_NULL;
+    if (width <= 0 || n_rows < 0) return KGW_E_RANGE;
+    const bool v4 = (width & 3) == 0 && !(((uintptr_t)src | (uintptr_t)dst) & 15);
+    const int wv = v4 ? width >> 2 : width;
+    const int64_t total = n_rows * wv;
+    int64_t g = (total + KGW_BLK - 1) / KGW_BLK;
+    if (g > KGW_GRID * 8) g = KGW_GRID * 8;
+    if (v4) k_scatter_rows<4><<<(int)g, KGW_BLK, 0, (hipStream_t)stream_>>>(src, ids, total, wv, dst);
+    else k_scatter_rows<1><<<(int)g, KGW_BLK, 0, (hipStream_t)stream_>>>(src, ids, total, wv, dst);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }

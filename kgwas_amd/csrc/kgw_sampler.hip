@@ -537,9 +537,15 @@ __global__ void k_t_end(SampArgs A, int l) {
 
 }  // namespace
 
-extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, const int64_t* seeds,
-                                int32_t n_seeds, int32_t seed_type, int32_t full_graph,
-                                kgw_stream_t stream_) {
+// Parts of one sampling call (kgw_sample_batch_parts): hop h contributes part 2h (segments, chunks, and the flags on every
+// not-yet-sampled source node: everything up to and including k_mark) and part 2h + 1 (compaction of the flags into local
+// ids, relabelling of the hop's edges); part 2 * n_hops builds the layer tables and the src-major structures and exports
+// the meta block.  Between part 2h and 2h + 1 the caller may merge the flags of node types that are REPLICATED across
+// ranks (SNP-sharded multi-GPU mode: element-wise MIN over the ranks' g2l regions -- KGW_PENDING = -2 < -1 = unsampled,
+// local ids >= 0 are equal on every rank), so that every rank expands the same replicated frontier at the next hop.
+extern "C" int kgw_sample_batch_parts(const KgwGraph* graph, const KgwBatchBuf* buf, const int64_t* seeds,
+                                      int32_t n_seeds, int32_t seed_type, int32_t full_graph, int32_t part_begin,
+                                      int32_t part_end, kgw_stream_t stream_) {
     if (!graph || !buf) return KGW_E_NULL;
     // grid of the sampler's grid-stride kernels: KgwBatchBuf.grid_blocks (a sampler replayed BESIDE a training step keeps
     // its launches small), else the whole-GPU default
@@ -552,6 +558,8 @@ extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, c
         return KGW_E_RANGE;
     if (!full_graph && (seed_type < 0 || seed_type >= graph->n_types || n_seeds > graph->n_nodes[seed_type]))
         return KGW_E_RANGE;
+    const int last_part = 2 * graph->n_hops;
+    if (part_begin < 0 || part_end > last_part || part_begin > part_end) return KGW_E_RANGE;
     hipStream_t st = (hipStream_t)stream_;
     SampArgs A;
     A.G = *graph;
@@ -560,35 +568,45 @@ extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, c
     const int ntiles_nodes = total_slots / KGW_TILE;
     if ((int64_t)ntiles_nodes + 2 > buf->scan_cap) return KGW_E_RANGE;
 
-    { int rc = fill_i32(buf->g2l, -1, total_slots, st, SG); if (rc) return rc; }
-    { int rc = fill_i32((int32_t*)buf->meta, 0, sizeof(KgwBatchMeta) / sizeof(int32_t), st); if (rc) return rc; }
-    k_init<<<full_graph ? KGW_GRID : 64, KGW_BLK, 0, st>>>(A, seeds, n_seeds, seed_type, full_graph);
-    KGW_LAUNCH_CHECK();
-
-    for (int h = 0; h < graph->n_hops; ++h) {
-        k_hop_begin<<<1, 64, 0, st>>>(A, h);
-        k_seg_deg<<<SG, KGW_BLK, 0, st>>>(A, h);
-        k_scan_tiles<2><<<SG, KGW_BLK, 0, st>>>(buf->seg_deg, buf->seg_nch, buf->meta, buf->scan_tmp);
-        k_scan_top<2><<<1, KGW_BLK, 0, st>>>(buf->scan_tmp, buf->meta, 1);
-        k_scan_apply<2><<<SG, KGW_BLK, 0, st>>>(buf->seg_deg, buf->seg_nch, buf->seg_ptr,
-                                                      buf->seg_chptr, buf->meta, buf->scan_tmp);
-        k_hop_mid<<<1, 64, 0, st>>>(A, h);
-        k_fill_chunks<<<SG, KGW_BLK, 0, st>>>(A, h);
-        KGW_LAUNCH_CHECK();
-        if (!full_graph) {
-            k_mark<<<SG, KGW_BLK, 0, st>>>(A, h);
-            k_count_pending<<<SG, KGW_BLK, 0, st>>>(A, buf->scan_tmp, ntiles_nodes);
-            k_scan_top_fixed<<<1, KGW_BLK, 0, st>>>(buf->scan_tmp, ntiles_nodes);
-            k_assign<<<SG, KGW_BLK, 0, st>>>(A, buf->scan_tmp, ntiles_nodes, h);
-            k_hop_end<<<1, 64, 0, st>>>(A, buf->scan_tmp, h);
-        } else {
-            // every node is already a seed: hop h+1 adds nothing
-            { int rc = fill_i32(buf->scan_tmp, 0, ntiles_nodes + 2, st, SG); if (rc) return rc; }
-            k_hop_end<<<1, 64, 0, st>>>(A, buf->scan_tmp, h);
-        }
-        k_relabel<<<SG, KGW_BLK, 0, st>>>(A, h);
+    if (part_begin == 0) {
+        { int rc = fill_i32(buf->g2l, -1, total_slots, st, SG); if (rc) return rc; }
+        { int rc = fill_i32((int32_t*)buf->meta, 0, sizeof(KgwBatchMeta) / sizeof(int32_t), st); if (rc) return rc; }
+        k_init<<<full_graph ? KGW_GRID : 64, KGW_BLK, 0, st>>>(A, seeds, n_seeds, seed_type, full_graph);
         KGW_LAUNCH_CHECK();
     }
+
+    for (int h = 0; h < graph->n_hops; ++h) {
+        if (2 * h >= part_begin && 2 * h <= part_end) {
+            k_hop_begin<<<1, 64, 0, st>>>(A, h);
+            k_seg_deg<<<SG, KGW_BLK, 0, st>>>(A, h);
+            k_scan_tiles<2><<<SG, KGW_BLK, 0, st>>>(buf->seg_deg, buf->seg_nch, buf->meta, buf->scan_tmp);
+            k_scan_top<2><<<1, KGW_BLK, 0, st>>>(buf->scan_tmp, buf->meta, 1);
+            k_scan_apply<2><<<SG, KGW_BLK, 0, st>>>(buf->seg_deg, buf->seg_nch, buf->seg_ptr,
+                                                          buf->seg_chptr, buf->meta, buf->scan_tmp);
+            k_hop_mid<<<1, 64, 0, st>>>(A, h);
+            k_fill_chunks<<<SG, KGW_BLK, 0, st>>>(A, h);
+            KGW_LAUNCH_CHECK();
+            if (!full_graph) {
+                k_mark<<<SG, KGW_BLK, 0, st>>>(A, h);
+                KGW_LAUNCH_CHECK();
+            }
+        }
+        if (2 * h + 1 >= part_begin && 2 * h + 1 <= part_end) {
+            if (!full_graph) {
+                k_count_pending<<<SG, KGW_BLK, 0, st>>>(A, buf->scan_tmp, ntiles_nodes);
+                k_scan_top_fixed<<<1, KGW_BLK, 0, st>>>(buf->scan_tmp, ntiles_nodes);
+                k_assign<<<SG, KGW_BLK, 0, st>>>(A, buf->scan_tmp, ntiles_nodes, h);
+                k_hop_end<<<1, 64, 0, st>>>(A, buf->scan_tmp, h);
+            } else {
+                // every node is already a seed: hop h+1 adds nothing
+                { int rc = fill_i32(buf->scan_tmp, 0, ntiles_nodes + 2, st, SG); if (rc) return rc; }
+                k_hop_end<<<1, 64, 0, st>>>(A, buf->scan_tmp, h);
+            }
+            k_relabel<<<SG, KGW_BLK, 0, st>>>(A, h);
+            KGW_LAUNCH_CHECK();
+        }
+    }
+    if (part_end < last_part) return KGW_OK;
     k_layer_tables<<<1, 64, 0, st>>>(A);
     KGW_LAUNCH_CHECK();
 
@@ -613,6 +631,14 @@ extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, c
         KGW_LAUNCH_CHECK();
     }
     return KGW_OK;
+}
+
+extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, const int64_t* seeds,
+                                int32_t n_seeds, int32_t seed_type, int32_t full_graph,
+                                kgw_stream_t stream_) {
+    if (!graph) return KGW_E_NULL;
+    if (graph->n_hops < 1 || graph->n_hops > KGW_MAX_LAYERS) return KGW_E_RANGE;
+    return kgw_sample_batch_parts(graph, buf, seeds, n_seeds, seed_type, full_graph, 0, 2 * graph->n_hops, stream_);
 }
 
 // ---- running totals of a captured training loop (one launch instead of index / cast / add / or framework ops) ----

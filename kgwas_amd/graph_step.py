@@ -198,6 +198,10 @@ class GraphTrainStep:
                 self.opt.step()
         return self.loss[cur]
 
+    def describe(self) -> str:
+        return ('HIP graphs: step graph (fwd + bwd' + (' + Adam)' if self.capture_optimizer else '), RCCL all-reduce + Adam eager') +
+                (' with the next batch sampled by a second graph on a side stream' if self.twin else ', sampling inside it'))
+
     def grads_ready(self):
         return [p.grad for p in self.model.parameters() if p.grad is not None]
 
