@@ -473,8 +473,10 @@ def main():
             roof['fetch_correction'], roof['write_correction'] = pmc['fetch_correction'], pmc['write_correction']
             roof['other_kernels'] = {k: v for k, v in pmc['kernels'].items() if k != 'k_agg_fwd<false>'}
             if pmc.get('mfma'):
-                # MFMA pipe occupancy of the dense kernels: busy cycles of the matrix pipes / (dispatch cycles x 1024 SIMDs)
-                roof['mfma_util'] = {k: {'busy_over_simd_cycles': v['mfma_busy_cycles'] / max(v['gui_active_cycles'] * 1024.0, 1.0),
+                # MFMA pipe occupancy of the dense kernels: SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs,
+                # GRBM_GUI_ACTIVE over the 8 XCDs (checked on k_linear_wreg: 1.0 M fp32 32x32x2 MFMAs x 64 cycles = 64 M busy
+                # cycles counted as 61.4 M; 49 us x 2.57 GHz x 8 = 1.01 M GUI cycles) => SIMD-cycles = GUI / 8 x 1024
+                roof['mfma_util'] = {k: {'mfma_busy_over_simd_cycles': v['mfma_busy_cycles'] / max(v['gui_active_cycles'] * 128.0, 1.0),
                                          'dispatches': v['dispatches']} for k, v in pmc['mfma'].items()}
         else:
             roof['counter_note'] = f'counter passes unavailable: {pmc_err}'
