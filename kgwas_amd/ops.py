@@ -160,7 +160,14 @@ class _GatAggregate(torch.autograd.Function):
         ctx.relu_input = relu_input
         a.Z, a.stat, a.e_edge, a.part = _p(Z), _p(stat), _p(e_edge), _p(part)
         TIMER.attach(a, 'fwd', layer, n_edges, z_rows, n_src)
+        # SNP-sharded multi-GPU mode (kgwas_amd/shard.py): relations whose sources this rank holds only in part leave
+        # partial softmax states, merged across the ranks before anything reads Z / stat
+        xchg = getattr(batch, 'exchange', None)
+        if xchg is not None and not raw_weights:
+            a.partial_rels = xchg.mask[layer]
         _lib.check(_lib.lib().kgw_gat_aggregate_fwd(C.byref(a), _lib.stream_ptr()), 'kgw_gat_aggregate_fwd')
+        if xchg is not None and not raw_weights and xchg.mask[layer]:
+            xchg.forward(batch, layer, Z, stat)
         ctx.set_materialize_grads(False)          # no zero tensors for the (non-differentiable) stat / e_edge outputs
         ctx.save_for_backward(H, U, V, Z, stat, e_edge)
         ctx.batch, ctx.layer, ctx.neg_slope, ctx.inv_temp = batch, layer, neg_slope, inv_temp
@@ -185,6 +192,10 @@ class _GatAggregate(torch.autograd.Function):
         t_rows = int(m.t_base[layer - 1][NT])
         dev = H.device
         dZf = dZ.contiguous() if z_rows else torch.zeros(1, KGW_C, device=dev)
+        xchg = getattr(batch, 'exchange', None)
+        if xchg is not None and z_rows and xchg.mask[layer]:
+            # sharded mode: this rank's upstream gradient is partial; its own edges of the exchanged segments need the sum
+            dZf = xchg.backward(batch, layer, dZf)
         adp = torch.empty(max(n_edges, 1), 2, device=dev)
         da_dst, ctx.da_dst = ctx.da_dst, None            # zeroed with Z in forward; consumed once
         if da_dst is None:

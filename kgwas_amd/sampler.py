@@ -279,6 +279,7 @@ class SampledBatch:
         self._x = None
         self._ei = None
         self._views = {}
+        self.exchange = None        # kgwas_amd.shard.ShardExchange in the SNP-sharded multi-GPU mode
 
     # --- PyG-batch duck type -------------------------------------------------------------------
     def to(self, device, *a, **k):

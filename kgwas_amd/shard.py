@@ -1,0 +1,318 @@
+"""SNP-sharded multi-GPU mode (BASELINE.json north_star / configs[3]).
+
+The reference trains on one device (kgwas/kgwas.py:38-39) and has nothing to mirror here; the contract is the
+north_star's: *the SNP nodes shard across the GPUs of one node with Gene / GO replicated, boundary SNP->Gene messages and
+gradients moved via RCCL*.  One process per GPU; rank p owns the SNPs of one contiguous id range (genome order =>
+locality) -- their features, labels, LD weights, the CSR rows of every relation INTO them and the edges of every relation
+OUT of them; genes, GO terms, their relations and all weights are replicated.
+
+All ranks work on the SAME 512-seed batch of the reference's batch order:
+  1. sampling: a rank expands the seeds it owns; after the first hop the ranks merge their gene frontiers (one all-reduce
+     MIN over the ~44 k-entry replicated part of the global->local table, kgw_sample_batch_parts) so that every rank
+     expands the same hop-1 genes in the same local order;
+  2. layer 1 on the hop-1 genes: Gene<-Gene and Gene<-GO relations are computed by every rank (replicated); for a
+     Gene<-SNP relation a rank aggregates only the edges whose SNP source it owns and leaves a PARTIAL online-softmax
+     state (m, s, sum exp(e-m) h) per (gene, relation) (KgwLayerArgs.partial_rels).  The ranks all-gather those states
+     (~3.7 MB per rank: 1.2 k genes x 6 relations x 132 floats) and each merges them in rank order
+     (kgw_softmax_merge) -- the softmax of kgwas/conv.py:223 over ALL in-edges, bit-identical on every rank;
+  3. everything downstream of the merged Z (transform, layer 2 on the rank's own seeds, read-out, loss over the rank's
+     seeds / 512) is local;
+  4. backward: gradients are linear in their upstream gradient, so replicated computations simply run on each rank's
+     PARTIAL upstream gradient (their sum over ranks is the true gradient); the one place that needs the COMPLETE
+     upstream gradient is the sharded aggregation itself -- dZ of the exchanged (gene, relation) segments is all-reduced
+     (SUM, same 3.7 MB) before a rank differentiates its own Gene<-SNP edges against the merged softmax statistics;
+  5. one flat all-reduce (SUM) of the parameter gradients, Adam on every rank (identical updates).
+With P = 1 every collective is the identity and the step is the single-GPU step.
+
+What is and is not saved: the 120 k-row SNP MLP, the SNP-side aggregation and the SNP feature / CSR memory divide by P;
+the gene MLP, the Gene<-Gene / Gene<-GO aggregation (70 % of a batch's edges on the benchmark graph) and the transforms are
+replicated work.  Seed-data-parallel training (kgwas_amd/dist.py) therefore scales better on graphs that fit one GPU;
+this mode is for SNP sets whose features and edges do not (north_star: ~10 M SNPs), and it is the mode the contract names.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import KGW_C, PART_STRIDE
+from .graph import HeteroGraph
+from .sampler import BatchBuffers, DeviceGraph, SampledBatch, _ptr
+
+
+def shard_range(n: int, rank: int, world: int):
+    return n * rank // world, n * (rank + 1) // world
+
+
+def shard_graph(data: HeteroGraph, rank: int, world: int, sharded_type: str = 'SNP'):
+    """Rank-local graph: nodes of ``sharded_type`` restricted to this rank's id range [lo, hi) and renumbered from 0,
+    every other type whole; a relation keeps the edges whose ``sharded_type`` endpoint the rank owns.  Returns
+    (local HeteroGraph, lo, hi)."""
+    n = int(data[sharded_type].num_nodes)
+    lo, hi = shard_range(n, rank, world)
+    g = HeteroGraph()
+    for t in data.node_types:
+        st = data[t]
+        for k, v in st.items():
+            if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == st.num_nodes:
+                g[t][k] = v[lo:hi] if t == sharded_type else v
+            elif k == 'num_nodes_':
+                g[t][k] = (hi - lo) if t == sharded_type else v
+    for et in data.edge_types:
+        s, _, d = et
+        ei = data[et].edge_index
+        ei = ei if torch.is_tensor(ei) else torch.as_tensor(ei)
+        if s == sharded_type and d == sharded_type:
+            if ei.shape[1]:
+                raise NotImplementedError(f'relation {et}: both ends are the sharded type (needs a halo exchange)')
+        elif s == sharded_type:
+            keep = (ei[0] >= lo) & (ei[0] < hi)
+            ei = ei[:, keep].clone()
+            ei[0] -= lo
+        elif d == sharded_type:
+            keep = (ei[1] >= lo) & (ei[1] < hi)
+            ei = ei[:, keep].clone()
+            ei[1] -= lo
+        g[et].edge_index = ei
+    return g, lo, hi
+
+
+class ShardExchange:
+    """The collectives of the sharded mode for one rank-local DeviceGraph (see the module docstring)."""
+
+    def __init__(self, dg: DeviceGraph, sharded_type: str = 'SNP', group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        sc = dg.schema
+        self.sharded = sc.type_id[sharded_type]
+        self.dev = dg.device
+        # replicated node types as contiguous runs of the global->local table
+        runs, t = [], 0
+        while t < sc.NT:
+            if t == self.sharded:
+                t += 1
+                continue
+            u = t
+            while u + 1 < sc.NT and u + 1 != self.sharded:
+                u += 1
+            runs.append((dg.node_base[t], dg.node_base[u + 1]))
+            t = u + 1
+        self.rep_runs = runs
+        # per layer: relations whose source is sharded and whose destination is replicated ("exchange relations")
+        self.mask, self.slots = {}, {}
+        for l in range(1, dg.num_layers + 1):
+            m, by_type = 0, {}
+            for r in dg.live_rel[l]:
+                s, d = int(sc.src_type[r]), int(sc.dst_type[r])
+                if s == self.sharded and d == self.sharded:
+                    raise NotImplementedError('a relation inside the sharded type needs a halo exchange')
+                if s == self.sharded and d != self.sharded:
+                    m |= 1 << r
+                    by_type.setdefault(d, []).append(int(sc.slot_dst[r]))
+            self.mask[l] = m
+            self.slots[l] = {d: torch.tensor(sorted(v), dtype=torch.int32, device=self.dev) for d, v in by_type.items()}
+        self.bytes_moved = 0
+
+    # -- sampling ---------------------------------------------------------------------------------------------------
+    def merge_frontier(self, buf: BatchBuffers):
+        """Union of the ranks' PENDING flags on the replicated node types (KGW_PENDING = -2 < -1 = unsampled)."""
+        if self.world == 1:
+            return
+        for lo, hi in self.rep_runs:
+            dist.all_reduce(buf.g2l[lo:hi], op=dist.ReduceOp.MIN, group=self.group)
+            self.bytes_moved += (hi - lo) * 4
+
+    # -- layer exchange ---------------------------------------------------------------------------------------------
+    def seg_rows(self, batch: SampledBatch, layer: int) -> Optional[torch.Tensor]:
+        """int32 Z rows of the exchanged (destination row, relation) segments of a layer, destination-type major; the
+        destination rows of a replicated type are the same nodes in the same order on every rank."""
+        key = ('xseg', layer)
+        cache = batch.__dict__.setdefault('_xchg_cache', {})
+        if key not in cache:
+            m, sc = batch.meta, batch.dg.schema
+            parts = []
+            for d, slots in sorted(self.slots[layer].items()):
+                rows = int(m.n_rows[layer - 1][d])
+                if rows == 0:
+                    continue
+                R = int(sc.R_dst[d])
+                base = torch.arange(rows, dtype=torch.int32, device=self.dev) * R + int(m.z_base[layer - 1][d])
+                parts.append((base[:, None] + slots[None, :]).reshape(-1))
+            cache[key] = torch.cat(parts) if parts else None
+        return cache[key]
+
+    def forward(self, batch: SampledBatch, layer: int, Z: torch.Tensor, stat: torch.Tensor):
+        """Z / stat hold this rank's partial states on the exchanged segments: replace them, in place, by the merged
+        softmax result over all ranks."""
+        seg = self.seg_rows(batch, layer)
+        if seg is None:
+            return
+        n = int(seg.numel())
+        L = _lib.lib()
+        mine = torch.empty(n * PART_STRIDE, device=self.dev)
+        _lib.check(L.kgw_softmax_pack(_ptr(Z), _ptr(stat), _ptr(seg), n, _ptr(mine), _lib.stream_ptr()), 'kgw_softmax_pack')
+        if self.world > 1:
+            allp = torch.empty(self.world * n * PART_STRIDE, device=self.dev)
+            try:
+                dist.all_gather_into_tensor(allp, mine, group=self.group)
+            except (RuntimeError, NotImplementedError):                       # backends without the flat variant
+                chunks = list(allp.view(self.world, -1).unbind(0))
+                dist.all_gather(chunks, mine, group=self.group)
+            self.bytes_moved += allp.numel() * 4
+        else:
+            allp = mine
+        _lib.check(L.kgw_softmax_merge(_ptr(allp), self.world, _ptr(seg), n, _ptr(Z), _ptr(stat), _lib.stream_ptr()),
+                   'kgw_softmax_merge')
+
+    def backward(self, batch: SampledBatch, layer: int, dZ: torch.Tensor) -> torch.Tensor:
+        """dZ holds this rank's PARTIAL upstream gradient; the exchanged segments need the complete one: sum their rows
+        over the ranks, in place."""
+        seg = self.seg_rows(batch, layer)
+        if seg is None or self.world == 1:
+            return dZ
+        n = int(seg.numel())
+        L = _lib.lib()
+        rows = torch.empty(n, KGW_C, device=self.dev)
+        _lib.check(L.kgw_gather_rows(_ptr(dZ), _ptr(seg), n, KGW_C, _ptr(rows), _lib.stream_ptr()), 'kgw_gather_rows')
+        dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group)
+        self.bytes_moved += rows.numel() * 4
+        _lib.check(L.kgw_scatter_rows(_ptr(rows), _ptr(seg), n, KGW_C, _ptr(dZ), _lib.stream_ptr()), 'kgw_scatter_rows')
+        return dZ
+
+
+def sample_sharded(dg: DeviceGraph, buf: BatchBuffers, seeds: torch.Tensor, seed_type: int, xchg: ShardExchange):
+    """kgw_sample_batch with the frontier merge between the two halves of every hop but the last."""
+    st = torch.cuda.current_stream()
+    L = _lib.lib()
+    n = int(seeds.numel())
+    last = 2 * dg.n_hops
+    begin = 0
+    for h in range(dg.n_hops - 1):
+        _lib.check(L.kgw_sample_batch_parts(C.byref(dg.kg), C.byref(buf.c), _ptr(seeds), n, seed_type, 0, begin, 2 * h,
+                                            C.c_void_p(st.cuda_stream)), 'kgw_sample_batch_parts')
+        xchg.merge_frontier(buf)
+        begin = 2 * h + 1
+    _lib.check(L.kgw_sample_batch_parts(C.byref(dg.kg), C.byref(buf.c), _ptr(seeds), n, seed_type, 0, begin, last,
+                                        C.c_void_p(st.cuda_stream)), 'kgw_sample_batch_parts')
+    buf.ready.record(st)
+
+
+class ShardedTrainer:
+    """Training steps of kgwas/kgwas.py:129-151 in the sharded mode.  ``input_nodes`` = (type, GLOBAL ids in training
+    order): every rank is handed the same list and works on the seeds of each ``batch_size`` batch that it owns."""
+
+    def __init__(self, run, input_nodes, batch_size: int, lr: float = 1e-4, weight_decay: float = 5e-4,
+                 use_graph: bool = False, sharded_type: str = 'SNP', group=None):
+        self.run, self.model = run, run.model
+        self.batch_size = int(batch_size)
+        self.input_type, ids = input_nodes
+        if self.input_type != sharded_type:
+            raise NotImplementedError('seeds must be of the sharded node type')
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        dev = torch.device(run.device)
+        self.dev = dev
+        full = run.data.data
+        self.local, self.lo, self.hi = shard_graph(full, self.rank, self.world, sharded_type)
+        L = run.gnn_num_layers
+        self.dg = DeviceGraph(self.local, L, dev)
+        self.xchg = ShardExchange(self.dg, sharded_type, group)
+        self.seed_type = self.dg.schema.type_id[self.input_type]
+        self.buf = BatchBuffers(self.dg)
+        ids = np.asarray(ids.cpu() if torch.is_tensor(ids) else ids, dtype=np.int64).reshape(-1)
+        self.n_batches = len(ids) // self.batch_size
+        self.local_seeds = []
+        for i in range(self.n_batches):
+            b = ids[i * self.batch_size:(i + 1) * self.batch_size]
+            mine = b[(b >= self.lo) & (b < self.hi)] - self.lo
+            if len(mine) == 0:
+                raise NotImplementedError(f'batch {i}: rank {self.rank} owns none of its seeds (use larger batches or fewer ranks)')
+            self.local_seeds.append(torch.from_numpy(mine).to(dev))
+        self.ld_w = run._ld_weight_vector()[self.lo:self.hi].contiguous()
+        self.y = self.dg.y[self.input_type]
+        from .optim import FusedAdam
+        self.opt = FusedAdam(self.model.parameters(), lr=lr, weight_decay=weight_decay)
+        self.use_graph = False               # (the collectives sit between kernels of a step: issued eagerly)
+        self._flat = None
+        self.last_loss = None
+
+    def describe(self) -> str:
+        return ('eager launches; per step: 1 frontier all-reduce(MIN), 1 all-gather of partial softmax states + 1 all-reduce of '
+                'their dZ per exchanged layer, 1 flat gradient all-reduce (SUM)')
+
+    def sample(self, i: int) -> SampledBatch:
+        seeds = self.local_seeds[i % self.n_batches]
+        sample_sharded(self.dg, self.buf, seeds, self.seed_type, self.xchg)
+        torch.cuda.current_stream().wait_event(self.buf.ready)
+        self.buf.ready.synchronize()
+        meta = self.buf.read_meta()
+        if meta.error:
+            raise _lib.KgwasHipError(f'sampler capacity exceeded (error mask {meta.error})')
+        batch = SampledBatch(self.dg, self.buf, meta, self.input_type, int(seeds.numel()))
+        batch.exchange = self.xchg
+        return batch
+
+    def forward_backward(self, i: int):
+        """Loss contribution of this rank's seeds (their weighted squared errors / batch_size) and its backward."""
+        batch = self.sample(i)
+        n = batch.batch_size
+        for p in self.model.parameters():
+            p.grad = None
+        loss, pred = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, n, batch.n_id(self.input_type), self.y, self.ld_w)
+        part = loss * (n / self.batch_size)                       # mean over the rank's seeds -> its share of the batch mean
+        part.backward()
+        return batch, part.detach(), pred
+
+    def allreduce_grads(self):
+        live = [p for p in self.model.parameters() if p.grad is not None]
+        flat = torch.cat([p.grad.reshape(-1) for p in live])
+        if self.world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.xchg.group)
+            self.xchg.bytes_moved += flat.numel() * 4
+        off = 0
+        for p in live:
+            n = p.numel()
+            p.grad = flat[off:off + n].view_as(p)
+            off += n
+
+    def step(self, i: int):
+        batch, part, _ = self.forward_backward(i)
+        self.allreduce_grads()
+        self.opt.step()
+        self.last_loss = part
+        m = batch.meta
+        return sum(int(m.n_edges[l]) for l in range(self.dg.num_layers)), 2 * int(m.edge_end[self.dg.n_hops - 1])
+
+    @torch.no_grad()
+    def predict(self, ids) -> torch.Tensor:
+        """Predictions of GLOBAL SNP ids ``ids`` (any order, any ownership) in input order, on every rank: batches of
+        ``batch_size``, each rank scores the seeds it owns (sharded forward), the results are summed across ranks."""
+        ids = np.asarray(ids.cpu() if torch.is_tensor(ids) else ids, dtype=np.int64).reshape(-1)
+        out = torch.zeros(len(ids), device=self.dev)
+        was_training = self.model.training
+        self.model.eval()
+        bs = self.batch_size
+        for a in range(0, len(ids), bs):
+            b = ids[a:a + bs]
+            sel = np.nonzero((b >= self.lo) & (b < self.hi))[0]
+            # (a rank without a seed in the batch still takes part in the exchange: it samples an arbitrary owned node)
+            mine = b[sel] - self.lo if len(sel) else np.zeros(1, dtype=np.int64)
+            seeds = torch.from_numpy(np.ascontiguousarray(mine)).to(self.dev)
+            sample_sharded(self.dg, self.buf, seeds, self.seed_type, self.xchg)
+            torch.cuda.current_stream().wait_event(self.buf.ready)
+            self.buf.ready.synchronize()
+            batch = SampledBatch(self.dg, self.buf, self.buf.read_meta(), self.input_type, int(seeds.numel()))
+            batch.exchange = self.xchg
+            p = self.model(batch.x_dict, batch.edge_index_dict, int(seeds.numel())).reshape(-1)
+            if len(sel):
+                out[torch.from_numpy(a + sel).to(self.dev)] = p
+        if self.world > 1:
+            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.xchg.group)
+        if was_training:
+            self.model.train()
+        return out

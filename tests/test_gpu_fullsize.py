@@ -251,4 +251,7 @@ def test_config0_hip_training_tracks_the_cpu_restatement(full_run):
     assert np.allclose(np.asarray(pw, dtype=np.float64), res['P_weighted'].values.astype(np.float64), rtol=1e-12, atol=0)
     scale = find_closest_x(pd.DataFrame({'P': res['P'].values, 'P_weighted': pw}))
     assert np.allclose(np.clip(scale * np.asarray(pw, dtype=np.float64), 0, 1), p, rtol=1e-12, atol=0)
-    assert np.isfinite(run2.val_metrics['pearsonr']) and np.isfinite(run2.test_metrics['mse'])
+    # (GATConv has no root term: an isolated seed's prediction is relu(lin(relu(sum of biases))), the same number for all
+    # of them -- on the 1 %-thinned graph most validation SNPs are isolated, so the Pearson r may be undefined, exactly as
+    # in the reference; the MSEs are finite)
+    assert np.isfinite(run2.val_metrics['mse']) and np.isfinite(run2.test_metrics['mse'])

@@ -1,0 +1,166 @@
+"""-m gpu, world_size 2 and 4 (all ranks on cuda:0, gloo collectives): the SNP-SHARDED mode on the HIP path
+(kgwas_amd/shard.py; SURVEY.md 8e-ii, BASELINE.json north_star / configs[3]) against the single-process run of the same
+batches with the same weights:
+
+* every rank predicts exactly the seeds it owns, and those predictions equal the single-process predictions;
+* the SUM over ranks of the parameter gradients equals the single-process gradient of the 512-style batch loss --
+  for every parameter, including the replicated gene / GO MLPs and the relations whose softmax is split across ranks;
+* after the flat all-reduce + Adam the ranks hold bit-identical parameters, equal to the single-process step;
+* the merged attention statistics equal the single-process ones (partial online-softmax merge, hub gene included).
+The graphs: SynthKG at 1 % scale (hub genes above KGW_CHUNK = 256 in-edges, so multi-chunk partial states are merged
+too) and the hand-made corner-case graph (empty relation, duplicate edges, zero-degree seeds)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+BS, STEPS = 64, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_run(which, seed=11):
+    from kgwas_amd.kgwas import KGWAS
+    from kgwas_amd.kgwas_data import KGWAS_Data
+    if which == 'small':
+        data = KGWAS_Data.from_synthetic(scale=0.01, seed=1, feat_dims={'Gene': 96}, data_path=f'/tmp/kgwas_gpushard_{os.getpid()}')
+    else:
+        from tests.conftest import make_edge_case_graph
+        g, d = make_edge_case_graph()
+        data = KGWAS_Data(f'/tmp/kgwas_gpushard_edge_{os.getpid()}')
+        data.data = g
+        data.snp_init_dim_size, data.gene_init_dim_size, data.go_init_dim_size = d['SNP'], d['Gene'], 16
+        n = int(g['SNP'].x.shape[0])
+        rng = np.random.default_rng(5)
+        data.all_ids = np.arange(n)
+        data.ldsc_weight = 0.5 + rng.random(n)
+        data.train_input_nodes = ('SNP', rng.permutation(n))
+    run = KGWAS(data, device='cuda:0', seed=seed)
+    run.initialize_model()
+    with torch.no_grad():                                   # non-zero relation biases: exercise their path
+        g_ = torch.Generator(device='cpu').manual_seed(3)
+        for pack in list(run.model.live_packs) + list(run.model.dead_packs):
+            pack.bias.copy_(torch.randn(pack.bias.shape, generator=g_) * 0.1)
+    return data, run
+
+
+def _ids(data):
+    return np.asarray(data.train_input_nodes[1])[:BS * (STEPS + 1)]
+
+
+def _worker(rank, world, port, out_dir, which):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from kgwas_amd import dist as kdist
+        from kgwas_amd.shard import ShardedTrainer
+        torch.cuda.set_device(0)
+        data, run = _make_run(which)
+        kdist.broadcast_params(run.model)
+        run.model.train()
+        st = ShardedTrainer(run, ('SNP', _ids(data)), BS, lr=1e-3, weight_decay=5e-4)
+        # step 0 without the optimiser: predictions, loss share, gradients, merged softmax statistics
+        batch, part, pred = st.forward_backward(0)
+        own = (batch.n_id('SNP')[:batch.batch_size].long() + st.lo).cpu()
+        grads = {k: (None if v is None else v.detach().cpu().clone()) for k, v in run.model.named_reference_tensors(grad=True).items()}
+        rec = {'own': own, 'pred': pred.detach().cpu(), 'part': part.cpu(), 'grads': grads, 'lo': st.lo, 'hi': st.hi,
+               'genes_l1': batch.n_id('Gene')[:int(batch.meta.n_rows[0][batch.dg.schema.type_id['Gene']])].cpu()}
+        # then full training steps
+        for i in range(STEPS):
+            st.step(i)
+        rec['params'] = {k: v.detach().cpu() for k, v in run.model.named_reference_tensors().items()}
+        rec['pred_all'] = st.predict(_ids(data)[:3 * BS // 2]).cpu()
+        rec['bytes_moved'] = st.xchg.bytes_moved
+        torch.save(rec, os.path.join(out_dir, f'rank{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('which,world', [('small', 2), ('small', 4), ('edge', 2)])
+def test_sharded_mode_equals_single_process(tmp_path, which, world):
+    port = _free_port()
+    mp.start_processes(_worker, args=(world, port, str(tmp_path), which), nprocs=world, join=True, start_method='spawn')
+    recs = [torch.load(os.path.join(tmp_path, f'rank{r}.pt'), weights_only=False) for r in range(world)]
+
+    from kgwas_amd.optim import FusedAdam
+    from kgwas_amd.sampler import NeighborLoader
+    data, run = _make_run(which)
+    run.model.train()
+    ids = _ids(data)
+    ld_w = run._ld_weight_vector()
+
+    def single(i):
+        batch = next(iter(NeighborLoader(data.data, [-1, -1], ('SNP', ids[i * BS:(i + 1) * BS]), batch_size=BS, device='cuda:0')))
+        run.model.zero_grad(set_to_none=True)
+        loss, pred = run.model.forward_loss(batch.x_dict, batch.edge_index_dict, BS, batch.n_id('SNP'), batch.dg.y['SNP'], ld_w)
+        loss.backward()
+        return batch, loss.detach().cpu(), pred.detach().cpu()
+
+    batch, loss, pred = single(0)
+    # 1. ownership: the ranks' seed sets partition the batch, in batch order inside a rank
+    seeds0 = ids[:BS]
+    got = np.concatenate([r['own'].numpy() for r in recs])
+    assert sorted(got.tolist()) == sorted(seeds0.tolist())
+    pos = {int(s): k for k, s in enumerate(seeds0)}
+    for r in recs:
+        assert all(r['lo'] <= int(s) < r['hi'] for s in r['own'])
+        idx = torch.tensor([pos[int(s)] for s in r['own']])
+        assert torch.allclose(r['pred'].double(), pred[idx].double(), rtol=1e-4, atol=1e-5), 'sharded prediction differs'
+        # every rank expanded the same hop-1 genes, in the same order
+        assert torch.equal(r['genes_l1'], recs[0]['genes_l1'])
+    # 2. loss shares add up to the batch loss
+    total = sum(float(r['part']) for r in recs)
+    assert abs(total - float(loss)) <= 1e-5 * abs(float(loss)) + 1e-8, (total, float(loss))
+    # 3. SUM over ranks of the gradients == single-process gradients
+    ref = {k: (None if v is None else v.detach().cpu()) for k, v in run.model.named_reference_tensors(grad=True).items()}
+    n_live = 0
+    for k, g in ref.items():
+        parts = [r['grads'][k] for r in recs]
+        if g is None:
+            assert all(p is None for p in parts), k
+            continue
+        assert all(p is not None for p in parts), k
+        s = sum(p.double() for p in parts)
+        scale = float(g.double().abs().max())
+        err = float((s - g.double()).abs().max())
+        assert err <= 2e-4 * scale + 1e-6, (k, err, scale)
+        n_live += 1
+    assert n_live > 30
+    # 4. training steps: ranks bit-identical, equal to the single-process steps
+    for k in recs[0]['params']:
+        for r in recs[1:]:
+            assert torch.equal(recs[0]['params'][k], r['params'][k]), f'{k}: ranks diverged'
+    opt = FusedAdam(run.model.parameters(), lr=1e-3, weight_decay=5e-4)
+    for i in range(STEPS):
+        single(i)
+        opt.step()
+    refp = {k: v.detach().cpu() for k, v in run.model.named_reference_tensors().items()}
+    for k in refp:
+        d = float((recs[0]['params'][k].double() - refp[k].double()).abs().max())
+        scale = float(refp[k].double().abs().max())
+        assert d <= 5e-5 * max(scale, 1e-6) + 3e-6, (k, d, scale)
+    # 5. sharded inference over an id list that is not a multiple of the batch size
+    run.model.eval()
+    with torch.no_grad():
+        want = []
+        q = ids[:3 * BS // 2]
+        for a in range(0, len(q), BS):
+            b = next(iter(NeighborLoader(data.data, [-1, -1], ('SNP', q[a:a + BS]), batch_size=len(q[a:a + BS]), device='cuda:0')))
+            want.append(run.model(b.x_dict, b.edge_index_dict, len(q[a:a + BS])).reshape(-1).cpu())
+        want = torch.cat(want)
+    for r in recs:
+        assert torch.allclose(r['pred_all'].double(), want.double(), rtol=1e-4, atol=1e-5)
+    assert recs[0]['bytes_moved'] > 0
