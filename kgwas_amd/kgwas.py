@@ -110,14 +110,63 @@ class KGWAS:
         optimizer.step()
         return loss
 
+    def _train_sharded(self, batch_size, lr, weight_decay, total_epoch, save_best_model, save_name):
+        """kgwas/kgwas.py:85-212 in the SNP-sharded multi-GPU mode (kgwas_amd/shard.py): every rank works on the SAME
+        batches of the reference's order and owns the SNPs of one id range; validation / test / inference predictions are
+        computed shard-wise and summed, so every rank sees the same metrics and keeps the same best model."""
+        from .shard import ShardedTrainer
+        rank, world = kdist.rank_world()
+        if world > 1:
+            kdist.broadcast_params(self.model)
+        st = ShardedTrainer(self, self.data.train_input_nodes, batch_size, lr=lr, weight_decay=weight_decay)
+        y_all = self.data.data['SNP'].y
+
+        def evaluate(ids, model, drop_last=False):
+            ids = np.asarray(ids)
+            if drop_last:                                   # the reference's val loader drops the partial batch (kgwas.py:102-103)
+                ids = ids[:len(ids) // batch_size * batch_size]
+            pred = st.predict(ids, model).cpu().numpy()
+            return {'pred': pred, 'truth': y_all[torch.from_numpy(ids)].numpy()}
+
+        min_val = -1000
+        self.best_model = deepcopy(self.model).to(self.device)
+        print_sys('Start Training (SNP-sharded over %d ranks)...' % world)
+        for ep in range(total_epoch):
+            self.model.train()
+            for step in range(st.n_batches):
+                st.step(step)
+                if (step % 500 == 0) and (step >= 500):
+                    print_sys('Epoch {} Step {} Train Loss (this rank\'s share): {:.4f}'.format(ep + 1, step + 1, float(st.last_loss)))
+            val_metrics = compute_metrics(evaluate(self.data.val_input_nodes[1], self.model, True), False, -1, -1, F.mse_loss)
+            print_sys('Epoch {}: Validation MSE: {:.4f} Validation Pearson: {:.4f}. '.format(
+                ep + 1, val_metrics['mse'], val_metrics['pearsonr']))
+            self.val_metrics = val_metrics
+            if val_metrics['pearsonr'] > min_val:                    # kgwas.py:170-173
+                min_val = val_metrics['pearsonr']
+                self.best_model = deepcopy(self.model)
+        if save_best_model and rank == 0:
+            save_model_path = os.path.join(self.data_path, 'model')
+            save_model(self.best_model, self.config, os.path.join(save_model_path, save_name))
+        self.test_metrics = compute_metrics(evaluate(self.data.test_input_nodes[1], self.best_model), False, -1, -1, F.mse_loss)
+        self.data.lr_uni['pred'] = evaluate(self.data.all_ids, self.best_model)['pred']                  # kgwas.py:189-191
+        self._postprocess(save_name, save_best_model and rank == 0)
+        self.shard_bytes_moved = st.xchg.bytes_moved
+
     def train(self, batch_size=512, num_workers=0, lr=1e-4, weight_decay=5e-4, epoch=10, save_best_model=True,
-              save_name=None, data_to_cuda=False, use_graph=True):
+              save_name=None, data_to_cuda=False, use_graph=True, parallelism='seed'):
         """Same signature and defaults as kgwas/kgwas.py:85-87.  ``use_graph`` (extra, default on): run the
-        training step as one captured HIP graph (kgwas_amd/graph_step.py); off = eager launches, same math."""
+        training step as one captured HIP graph (kgwas_amd/graph_step.py); off = eager launches, same math.
+        ``parallelism`` (extra; matters under torch.distributed): 'seed' = every rank trains on its slice of each batch
+        against a replicated graph (kgwas_amd/dist.py); 'shard' = SNP rows sharded by id range, Gene / GO replicated
+        (kgwas_amd/shard.py, BASELINE.json north_star)."""
         total_epoch = epoch
         if save_name is None:
             save_name = self.exp_name
         self.save_name = save_name
+        if parallelism == 'shard':
+            return self._train_sharded(batch_size, lr, weight_decay, total_epoch, save_best_model, save_name)
+        if parallelism != 'seed':
+            raise ValueError(f"parallelism {parallelism!r}: 'seed' or 'shard'")
         print_sys('Creating data loader...')
         self.make_loaders(batch_size, num_workers)
         rank, world = kdist.rank_world()

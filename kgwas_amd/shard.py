@@ -280,20 +280,49 @@ class ShardedTrainer:
             p.grad = flat[off:off + n].view_as(p)
             off += n
 
+    def _count_edges(self, batch: SampledBatch):
+        """(edges this step's kernels aggregated, edges the reference would touch) counting every edge of the GLOBAL batch
+        once across the ranks: an edge with a sharded endpoint exists on exactly one rank, an edge between replicated
+        types on all of them (counted by rank 0 only)."""
+        m, dg = batch.meta, self.dg
+        sc, L = dg.schema, dg.num_layers
+        sp = self.buf.seg_ptr
+        idx, wk, wr = [], [], []
+        for h in range(dg.n_hops):
+            for r in range(sc.NR):
+                a, b = int(m.seg_off[h][r]), int(m.seg_off[h][r + 1])
+                if b <= a:
+                    continue
+                own = 1 if (self.rank == 0 or self.xchg.sharded in (int(sc.src_type[r]), int(sc.dst_type[r]))) else 0
+                layers = sum(1 for l in range(1, L + 1) if h <= L - l and r in dg.live_rel[l])
+                idx += [a, b]; wk.append(own * layers); wr.append(own * L)
+        if not idx:
+            return 0, 0
+        e = sp[torch.tensor(idx, device=self.dev)].view(-1, 2)
+        cnt = (e[:, 1] - e[:, 0]).cpu().numpy().astype(np.int64)
+        return int((cnt * np.asarray(wk)).sum()), int((cnt * np.asarray(wr)).sum())
+
     def step(self, i: int):
         batch, part, _ = self.forward_backward(i)
         self.allreduce_grads()
         self.opt.step()
         self.last_loss = part
-        m = batch.meta
-        return sum(int(m.n_edges[l]) for l in range(self.dg.num_layers)), 2 * int(m.edge_end[self.dg.n_hops - 1])
+        return self._count_edges(batch)
 
     @torch.no_grad()
-    def predict(self, ids) -> torch.Tensor:
+    def predict(self, ids, model=None) -> torch.Tensor:
         """Predictions of GLOBAL SNP ids ``ids`` (any order, any ownership) in input order, on every rank: batches of
-        ``batch_size``, each rank scores the seeds it owns (sharded forward), the results are summed across ranks."""
+        ``batch_size``, each rank scores the seeds it owns (sharded forward), the results are summed across ranks.
+        ``model``: score with this (replicated) model instead of the one being trained (the best-so-far copy)."""
         ids = np.asarray(ids.cpu() if torch.is_tensor(ids) else ids, dtype=np.int64).reshape(-1)
         out = torch.zeros(len(ids), device=self.dev)
+        trained, self.model = self.model, (model if model is not None else self.model)
+        try:
+            return self._predict(ids, out)
+        finally:
+            self.model = trained
+
+    def _predict(self, ids, out):
         was_training = self.model.training
         self.model.eval()
         bs = self.batch_size

@@ -20,7 +20,7 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 
-BS, STEPS = 64, 2
+BS, STEPS, N_GRAD_BATCHES = 64, 2, 6
 
 
 def _free_port():
@@ -31,7 +31,7 @@ def _free_port():
     return p
 
 
-def _make_run(which, seed=11):
+def _make_run(which, seed=11, random_bias=True, no_relu=False):
     from kgwas_amd.kgwas import KGWAS
     from kgwas_amd.kgwas_data import KGWAS_Data
     if which == 'small':
@@ -48,16 +48,17 @@ def _make_run(which, seed=11):
         data.ldsc_weight = 0.5 + rng.random(n)
         data.train_input_nodes = ('SNP', rng.permutation(n))
     run = KGWAS(data, device='cuda:0', seed=seed)
-    run.initialize_model()
-    with torch.no_grad():                                   # non-zero relation biases: exercise their path
-        g_ = torch.Generator(device='cpu').manual_seed(3)
-        for pack in list(run.model.live_packs) + list(run.model.dead_packs):
-            pack.bias.copy_(torch.randn(pack.bias.shape, generator=g_) * 0.1)
+    run.initialize_model(no_relu=no_relu)
+    if random_bias:
+        with torch.no_grad():                               # non-zero relation biases: exercise their path
+            g_ = torch.Generator(device='cpu').manual_seed(3)
+            for pack in list(run.model.live_packs) + list(run.model.dead_packs):
+                pack.bias.copy_(torch.randn(pack.bias.shape, generator=g_) * 0.1)
     return data, run
 
 
 def _ids(data):
-    return np.asarray(data.train_input_nodes[1])[:BS * (STEPS + 1)]
+    return np.asarray(data.train_input_nodes[1])[:BS * max(STEPS + 1, N_GRAD_BATCHES)]
 
 
 def _worker(rank, world, port, out_dir, which):
@@ -78,6 +79,15 @@ def _worker(rank, world, port, out_dir, which):
         grads = {k: (None if v is None else v.detach().cpu().clone()) for k, v in run.model.named_reference_tensors(grad=True).items()}
         rec = {'own': own, 'pred': pred.detach().cpu(), 'part': part.cpu(), 'grads': grads, 'lo': st.lo, 'hi': st.hi,
                'genes_l1': batch.n_id('Gene')[:int(batch.meta.n_rows[0][batch.dg.schema.type_id['Gene']])].cpu()}
+        # all-reduced gradients of a few more batches at the SAME parameters (isolates the exchange from Adam's
+        # amplification of fp32 noise)
+        rec['summed'] = []
+        for i in range(1, N_GRAD_BATCHES):
+            st.forward_backward(i)
+            st.allreduce_grads()
+            if rank == 0:
+                rec['summed'].append({k: (None if v is None else v.detach().cpu().clone())
+                                      for k, v in run.model.named_reference_tensors(grad=True).items()})
         # then full training steps
         for i in range(STEPS):
             st.step(i)
@@ -139,6 +149,16 @@ def test_sharded_mode_equals_single_process(tmp_path, which, world):
         assert err <= 2e-4 * scale + 1e-6, (k, err, scale)
         n_live += 1
     assert n_live > 30
+    for i, summed in enumerate(recs[0]['summed'], start=1):
+        single(i)
+        refi = {k: (None if v is None else v.detach().cpu()) for k, v in run.model.named_reference_tensors(grad=True).items()}
+        for k, g in refi.items():
+            if g is None:
+                assert summed[k] is None, k
+                continue
+            scale = float(g.double().abs().max())
+            err = float((summed[k].double() - g.double()).abs().max())
+            assert err <= 2e-4 * scale + 1e-6, (i, k, err, scale)
     # 4. training steps: ranks bit-identical, equal to the single-process steps
     for k in recs[0]['params']:
         for r in recs[1:]:
@@ -164,3 +184,38 @@ def test_sharded_mode_equals_single_process(tmp_path, which, world):
     for r in recs:
         assert torch.allclose(r['pred_all'].double(), want.double(), rtol=1e-4, atol=1e-5)
     assert recs[0]['bytes_moved'] > 0
+
+
+def _train_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        # (linear read-out: a ReLU read-out that dies during the epoch would make every prediction 0 and the Pearson r undefined)
+        data, run = _make_run('small', seed=21, random_bias=False, no_relu=True)
+        run.train(batch_size=BS, epoch=1, save_best_model=False, save_name=f'shard{rank}', parallelism='shard')
+        torch.save({'val': run.val_metrics, 'test': run.test_metrics, 'pred': np.asarray(run.kgwas_res['pred'].values),
+                    'kgwas_p': np.asarray(run.kgwas_res['KGWAS_P'].values)}, os.path.join(out_dir, f'train{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_kgwas_train_in_sharded_mode_matches_single_process_training(tmp_path):
+    """KGWAS.train(parallelism='shard') through the reference's API (training epoch, validation with drop_last, test,
+    whole-genome inference, p-values) on 2 ranks vs the single-process eager training: same batches, same SGD steps up
+    to fp32 summation order => validation Pearson within 1e-3 (north_star), predictions within tolerance."""
+    world = 2
+    port = _free_port()
+    mp.start_processes(_train_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method='spawn')
+    r0 = torch.load(os.path.join(tmp_path, 'train0.pt'), weights_only=False)
+    r1 = torch.load(os.path.join(tmp_path, 'train1.pt'), weights_only=False)
+    assert np.array_equal(r0['pred'], r1['pred']) and r0['val']['pearsonr'] == r1['val']['pearsonr']
+    data, run = _make_run('small', seed=21, random_bias=False, no_relu=True)
+    run.train(batch_size=BS, epoch=1, save_best_model=False, save_name='single', use_graph=False)
+    assert np.isfinite(run.val_metrics['pearsonr'])
+    assert abs(float(r0['val']['pearsonr']) - float(run.val_metrics['pearsonr'])) < 1e-3
+    assert abs(float(r0['val']['mse']) - float(run.val_metrics['mse'])) < 1e-3 * float(run.val_metrics['mse'])
+    assert abs(float(r0['test']['mse']) - float(run.test_metrics['mse'])) < 1e-3 * float(run.test_metrics['mse'])
+    ref = np.asarray(run.kgwas_res['pred'].values)
+    assert np.allclose(r0['pred'], ref, rtol=2e-3, atol=2e-4)
