@@ -293,6 +293,18 @@ int kgw_linear(const float* X, int64_t ldx, const float* W, int64_t ldw, const f
                const float* mask, int64_t ldm, float* Y, int64_t ldy, int64_t rows, int32_t K, int32_t N,
                int32_t relu, int32_t w_is_kn, const int32_t* rows_dev, kgw_stream_t stream);
 
+/* The same product for FEW rows when one of K, N is 128 and the other a multiple of 128 -- the per-relation transform
+ * of a layer after aggregate-then-transform, [N_dst, R*128] x [R*128, 128] with N_dst ~ 0.5-1.2 k destination rows of a
+ * 512-seed batch (kgwas/conv.py:138-144 for all relations into one destination type + bias :190 + HeteroConv sum
+ * model.py:74 + ReLU :75), and its dZ twin [N_dst, 128] x [128, R*128]: the long dimension is cut into 128-wide slabs
+ * (= relations); a block keeps its slab's 128 x 128 weights stationary in MFMA operand registers and streams 32-row
+ * tiles through LDS; K slabs are added in order by a second launch (deterministic).  workspace:
+ * kgw_linear_splitk_workspace_floats floats (0 when K == 128).  Other shapes: KGW_E_UNSUPPORTED (use kgw_linear).   */
+int64_t kgw_linear_splitk_workspace_floats(int64_t rows, int32_t K, int32_t N);
+int kgw_linear_splitk(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
+                      int64_t ldy, int64_t rows, int32_t K, int32_t N, int32_t relu, int32_t w_is_kn,
+                      float* workspace, int64_t workspace_floats, const int32_t* rows_dev, kgw_stream_t stream);
+
 /* One Adam step (torch.optim.Adam semantics, weight_decay as L2: kgwas/kgwas.py:116,151) over up to 64
  * parameter tensors in a single launch.  The pointer arrays are HOST arrays of device pointers (passed to the
  * kernel by value); step_dev is a device int32 counter incremented by the call (graph-capturable).        */

@@ -1085,6 +1085,203 @@ extern "C" int kgw_linear(const float* X, int64_t ldx, const float* W, int64_t l
 }
 
 // ======================================================================================================
+// kgw_linear_splitk: Y[rows, N] = act(X[rows, K] * Wop + bias) for FEW rows (hundreds to a few thousand) when one of
+// K, N is 128 and the other a multiple of 128 -- the per-relation transform of a layer after aggregate-then-transform
+// (kgwas/conv.py:138-144 + bias :190 + HeteroConv sum model.py:74 + ReLU :75 as ONE product [N_dst, R*128] x [R*128, 128])
+// and its dZ twin [N_dst, 128] x [128, R*128], at the shapes a 512-seed batch has: ~1.2 k gene rows x R = 17 relations,
+// 512 SNP rows x R = 6.  A 128-row-tile kernel puts such a product on ten workgroups.
+//
+// Here the long dimension is cut into 128-wide SLABS (= relations) and a 4-wavefront block owns (slab, a strided group of
+// 32-row tiles).  The slab's 128 x 128 weight block is STATIONARY IN REGISTERS: wavefront w holds, as MFMA B operands, the
+// 64 values W(k = 64 lk + j, column 32 w + li) of its lanes for the whole block (v_mfma_f32_32x32x2_f32, k order inside
+// the slab permuted so that a lane's A values are contiguous), loaded once -- coalesced for the [K, N] form (the packed
+// per-relation weights).  Row tiles stream through a double-buffered LDS tile (coalesced 512-byte row reads, row stride
+// 132 floats: the ds_read_b128 of the A operand is conflict free), one barrier per tile, 64 MFMAs per wavefront and tile.
+//   K > 128 (forward transform): slab = K range; a block writes its partial [rows, 128] to the workspace and a second
+//     launch adds the slabs in order (deterministic, no atomics) with bias / ReLU;
+//   K == 128 (dZ twin): slab = column range; results are final, written directly.
+// ======================================================================================================
+namespace {
+
+constexpr int SK_LD = 132;      // LDS row stride of the X tile (floats)
+
+struct SplitKArgs {
+    const float* X; int64_t ldx;
+    const float* W; int64_t ldw;
+    const float* bias;
+    float* Y; int64_t ldy;
+    float* ws;                 // [KS][rows][128] partial products (KS > 1)
+    int64_t rows; int K, N;
+    int relu, w_kn;
+    int RT, KS, NS, G;         // row tiles; K slabs; column slabs; row-tile groups per slab
+    const int32_t* rows_dev;
+};
+
+__device__ __forceinline__ int64_t sk_rows_eff(const SplitKArgs& a) {
+    if (!a.rows_dev) return a.rows;
+    const int64_t r = *a.rows_dev;
+    return r < 0 ? 0 : (r < a.rows ? r : a.rows);
+}
+
+template <bool WKN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_linear_splitk(SplitKArgs a) {
+    __shared__ __attribute__((aligned(16))) float Xs[2][32 * SK_LD];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lk = lane >> 5, w = tid >> 6;
+    const bool ksplit = a.KS > 1;
+    const int slab = blockIdx.x, g = blockIdx.y;
+    const int64_t rows_eff = sk_rows_eff(a);
+    const int kx0 = ksplit ? slab * 128 : 0;           // first K column of the X tiles
+    const int n0 = (ksplit ? 0 : slab * 128) + 32 * w; // first output column of this wavefront
+    const int ntile = (int)((rows_eff + 31) / 32);
+    if (g >= ntile) return;
+
+    // B operand, stationary: W(k = kx0 + 64 lk + j, n = n0 + li)
+    float bw[64];
+    if (WKN) {
+        const float* p = a.W + (int64_t)(kx0 + 64 * lk) * a.ldw + n0 + li;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) bw[j] = p[(int64_t)j * a.ldw];
+    } else {
+        const float4* p = (const float4*)(a.W + (int64_t)(n0 + li) * a.ldw + kx0 + 64 * lk);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 v = p[q];
+            bw[4 * q] = v.x; bw[4 * q + 1] = v.y; bw[4 * q + 2] = v.z; bw[4 * q + 3] = v.w;
+        }
+    }
+    // X tile of row tile rt: thread t moves float4 (row = idx / 32, column 4 (idx % 32)), idx = t + 256 i
+    float4 xr[4];
+    auto fetch = [&](int rt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int64_t r = (int64_t)rt * 32 + (idx >> 5);
+            const bool ok = r < rows_eff;
+            const float4 v = *(const float4*)(a.X + (ok ? r : 0) * a.ldx + kx0 + 4 * (idx & 31));
+            xr[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            *(float4*)(&Xs[buf][(idx >> 5) * SK_LD + 4 * (idx & 31)]) = xr[i];
+        }
+    };
+    fetch(g);
+    stage(0);
+    __syncthreads();
+    const float bv = (!ksplit && a.bias) ? a.bias[n0 + li] : 0.f;
+    int buf = 0;
+    for (int rt = g; rt < ntile; rt += a.G, buf ^= 1) {
+        const bool more = rt + a.G < ntile;
+        if (more) fetch(rt + a.G);                         // in flight under the MFMAs below
+        float xa[64];
+        const float4* px = (const float4*)(&Xs[buf][li * SK_LD + 64 * lk]);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 v = px[q];
+            xa[4 * q] = v.x; xa[4 * q + 1] = v.y; xa[4 * q + 2] = v.z; xa[4 * q + 3] = v.w;
+        }
+        // two interleaved accumulators (even / odd k steps): no back-to-back dependent MFMAs
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < 64; j += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j], bw[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j + 1], bw[j + 1], acc1, 0, 0, 0);
+        }
+        // accumulator element e of a lane: row (e & 3) + 8 (e >> 2) + 4 lk, column li
+        const int64_t r0 = (int64_t)rt * 32;
+        if (ksplit) {
+            float* out = a.ws + ((int64_t)slab * a.rows + r0) * 128 + n0 + li;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * lk;
+                if (r0 + row < rows_eff) out[(int64_t)row * 128] = acc0[e] + acc1[e];
+            }
+        } else {
+            float* out = a.Y + r0 * a.ldy + n0 + li;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * lk;
+                if (r0 + row >= rows_eff) continue;
+                float v = acc0[e] + acc1[e] + bv;
+                if (a.relu) v = fmaxf(v, 0.f);
+                out[(int64_t)row * a.ldy] = v;
+            }
+        }
+        if (more) stage(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// K-split: Y = act(sum over slabs of ws + bias); always: rows beyond the batch's own count (static capacity) get zeros
+__global__ void __launch_bounds__(256) k_linear_splitk_finish(SplitKArgs a) {
+    const int64_t rows_eff = sk_rows_eff(a);
+    const int n4 = a.N >> 2;
+    const bool ksplit = a.KS > 1;
+    const int64_t first = ksplit ? 0 : rows_eff;
+    const int64_t total = (a.rows - first) * n4;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int64_t r = first + q / n4;
+        const int c = (int)(q % n4) * 4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rows_eff) {
+            for (int ks = 0; ks < a.KS; ++ks) {
+                const float4 v = *(const float4*)(a.ws + ((int64_t)ks * a.rows + r) * 128 + c);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            if (a.bias) { const float4 b = *(const float4*)(a.bias + c); s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w; }
+            if (a.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+        }
+        *(float4*)(a.Y + r * a.ldy + c) = s;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t kgw_linear_splitk_workspace_floats(int64_t rows, int32_t K, int32_t N) {
+    if (rows <= 0 || K <= 128 || N != 128) return 0;
+    return (int64_t)(K / 128) * rows * 128;
+}
+
+extern "C" int kgw_linear_splitk(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
+                                 int64_t ldy, int64_t rows, int32_t K, int32_t N, int32_t relu, int32_t w_is_kn,
+                                 float* workspace, int64_t workspace_floats, const int32_t* rows_dev,
+                                 kgw_stream_t stream_) {
+    if (rows == 0) return KGW_OK;
+    if (!X || !W || !Y) return KGW_E_NULL;
+    if (rows < 0 || K <= 0 || N <= 0) return KGW_E_RANGE;
+    if ((K & 127) || (N & 127) || (K != 128 && N != 128) || (ldx & 3) || (ldw & 3) || (ldy & 3) || !aligned16(X) ||
+        !aligned16(W) || !aligned16(Y) || (bias && !aligned16(bias)))
+        return KGW_E_UNSUPPORTED;
+    SplitKArgs a{X, ldx, W, ldw, bias, Y, ldy, workspace, rows, K, N, relu, w_is_kn, (int)((rows + 31) / 32),
+                 K / 128, N / 128, 1, rows_dev};
+    const int nslab = a.KS > 1 ? a.KS : a.NS;
+    if (a.KS > 1 && (!workspace || workspace_floats < kgw_linear_splitk_workspace_floats(rows, K, N))) return KGW_E_NULL;
+    // row-tile groups per slab: about two blocks per CU in total, at most one tile... at least one tile per block
+    static const int target = getenv("KGW_SPLITK_BLOCKS") ? atoi(getenv("KGW_SPLITK_BLOCKS")) : 512;
+    int G = (target + nslab - 1) / nslab;
+    if (G > a.RT) G = a.RT;
+    if (G < 1) G = 1;
+    a.G = G;
+    hipStream_t st = (hipStream_t)stream_;
+    dim3 grid((unsigned)nslab, (unsigned)G);
+    if (w_is_kn) k_linear_splitk<true><<<grid, 256, 0, st>>>(a);
+    else k_linear_splitk<false><<<grid, 256, 0, st>>>(a);
+    KGW_LAUNCH_CHECK();
+    if (a.KS > 1 || rows_dev) {
+        int64_t g = (rows * (N / 4) + 255) / 256;
+        if (g > KGW_GRID) g = KGW_GRID;
+        k_linear_splitk_finish<<<(int)g, 256, 0, st>>>(a);
+        KGW_LAUNCH_CHECK();
+    }
+    return KGW_OK;
+}
+
+// ======================================================================================================
 // kgw_scatter_relu_rows: backward of "rows ids of relu(X W^T + b) computed on a RESIDENT matrix" (the 5120-wide gene
 // layer runs on all N genes and the batch takes its rows): dz[row] = g[g2l[row]] * (h[row] > 0) for every row of the
 // resident matrix (zero where the node is not in the batch), and colsum[c] = sum_row dz[row][c] -- the framework's

@@ -369,6 +369,7 @@ def _library_linear(X, W, bias, relu, mask, w_kn, out, fixed_shape):
 
 
 _LIN_MAX_K = 2304        # wider reductions (the 5120 / 57742-wide gene layer) go to the library GEMM
+_SPLITK_MAX_ROWS = int(os.environ.get('KGW_SPLITK_MAX_ROWS', '8192'))     # below: kgw_linear_splitk (0 = off)
 
 
 def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask=None, w_kn: bool = False,
@@ -380,6 +381,22 @@ def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask
     captured step): the kernel skips the padding rows and writes zeros there."""
     rows, K = X.shape
     N = W.shape[1] if w_kn else W.shape[0]
+    # few rows, K and N multiples of 128: the per-relation transform of a layer and its dZ twin at the shapes a 512-seed
+    # batch has (~1.2 k gene rows x 17 relations, 512 SNP rows x 6) -- one wavefront per (row tile, column tile, relation slab)
+    if (0 < rows < _SPLITK_MAX_ROWS and K % 128 == 0 and N % 128 == 0 and (K == 128 or N == 128) and mask is None
+            and X.dtype == torch.float32
+            and X.stride(1) == 1 and W.stride(1) == 1 and X.stride(0) % 4 == 0 and W.stride(0) % 4 == 0
+            and X.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0 and (bias is None or bias.data_ptr() % 16 == 0)
+            and (out is None or (out.stride(1) == 1 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0))):
+        Y = torch.empty(rows, N, device=X.device) if out is None else out
+        assert Y.shape == (rows, N)
+        L = _lib.lib()
+        nws = int(L.kgw_linear_splitk_workspace_floats(rows, K, N))
+        ws = torch.empty(nws, device=X.device) if nws else None
+        _lib.check(L.kgw_linear_splitk(_p(X), X.stride(0), _p(W), W.stride(0), _p(bias), _p(Y), Y.stride(0), rows, K, N,
+                                       1 if relu else 0, 1 if w_kn else 0, _p(ws), nws, _p(rows_dev), _lib.stream_ptr()),
+                   'kgw_linear_splitk')
+        return Y
     ok = (X.dtype == torch.float32 and X.stride(1) == 1 and W.stride(1) == 1 and K % 4 == 0 and K <= _LIN_MAX_K
           and X.stride(0) % 4 == 0 and W.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0
           and (not w_kn or N % 4 == 0) and (mask is None or mask.stride(1) == 1)

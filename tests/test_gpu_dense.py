@@ -291,3 +291,38 @@ def test_grouped_weight_gradients_match_fp64(rows, real):
         assert_close(db, dY[:n].double().sum(0), 1e-5, 1e-5, 'grouped db', rel_to_max=2e-6)
     one = ops.tn_gemm(dYs[0], Xs[0], colsum=True, rows_dev=cnt)
     assert torch.equal(one[0], outs[0][0]) and torch.equal(one[1], outs[0][1])
+
+
+@pytest.mark.parametrize('rows,K,N,kn,real', [(1171, 2176, 128, True, None), (1171, 1536, 128, True, None), (512, 768, 128, True, None),
+                                              (1171, 128, 2176, False, None), (1171, 128, 1536, False, None), (512, 128, 768, False, None),
+                                              (1, 128, 128, True, None), (33, 256, 128, False, None), (1216, 2176, 128, True, 1171),
+                                              (1216, 128, 2176, False, 1171), (8000, 768, 128, True, None), (64, 128, 128, False, 0)])
+def test_splitk_transform_kernel_matches_fp64(rows, K, N, kn, real):
+    """kgw_linear_splitk at the benchmark's transform shapes ([~1.2 k, R*128] x [R*128, 128] forward, its dZ twin) and
+    the corner cases: one row, ragged last tile, padding rows of a static layout (rows_dev), a zero-row batch."""
+    from kgwas_amd import _lib, ops
+    g = torch.Generator().manual_seed(rows + K)
+    X = torch.randn(rows, K, generator=g)
+    W = torch.randn(K, N, generator=g) if kn else torch.randn(N, K, generator=g)
+    b = torch.randn(N, generator=g)
+    X[:, 0] += 2.0
+    rd = None if real is None else torch.tensor([real], dtype=torch.int32).cuda()
+    for relu, bias in ((True, b), (False, None)):
+        Y = ops.linear(X.cuda(), W.cuda(), bias.cuda() if bias is not None else None, relu=relu, w_kn=kn, rows_dev=rd)
+        ref = X.double() @ (W.double() if kn else W.double().t())
+        if bias is not None:
+            ref = ref + bias.double()
+        if relu:
+            ref = ref.relu()
+        if real is not None:
+            ref[real:] = 0.0
+        assert_close(Y, ref, 1e-5, 1e-5, f'splitk {rows}x{K}x{N} kn={kn}', rel_to_max=2e-6)
+    # deterministic (fixed slab order), writes into a strided output block in place
+    out = torch.full((rows, N + 128), 7.0).cuda()
+    Y1 = ops.linear(X.cuda(), W.cuda(), b.cuda(), relu=True, w_kn=kn, out=out[:, :N], rows_dev=rd)
+    Y2 = ops.linear(X.cuda(), W.cuda(), b.cuda(), relu=True, w_kn=kn, rows_dev=rd)
+    assert Y1.data_ptr() == out.data_ptr() and torch.equal(Y1, Y2) and bool((out[:, N:] == 7.0).all())
+    # the C ABI refuses what the kernel does not take
+    L = _lib.lib()
+    assert L.kgw_linear_splitk(X.cuda().data_ptr(), K, W.cuda().data_ptr(), N if kn else K, None, Y2.data_ptr(), N, rows, K + 4, N,
+                               0, 1 if kn else 0, None, 0, None, None) == -3
