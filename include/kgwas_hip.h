@@ -27,7 +27,8 @@ extern "C" {
 #define KGW_MAX_TYPES    8
 #define KGW_MAX_RELS     64
 #define KGW_MAX_LAYERS   4
-#define KGW_CHUNK        256          /* edges per chunk (one wavefront processes one chunk)  */
+#define KGW_CHUNK        128          /* edges per chunk (one wavefront processes one chunk; the longest chunks set
+                                         the aggregate kernels' tail: 256 -> 128 took k_agg_fwd 64 -> 56 us)           */
 #define KGW_TILE         1024         /* scan tile; per-type node regions are padded to this  */
 #define KGW_C            128          /* hidden width (gnn_hidden_dim, kgwas/kgwas.py:52)     */
 
@@ -168,7 +169,13 @@ typedef struct KgwLayerArgs {
      * excluding the small combine launches for hub rows -- bench.py's per-kernel roofline timing */
     void* ev_before; void* ev_after;
     float* da_src;                 /* [n_src_rows][2*ld], ld = (n_rels+3)&~3: columns [0,ld) d a_src, [ld,2ld) d a_dst
-                                      of the node, one column per relation id (n_rels <= 32)            */
+                                      of the node, one column per relation id (n_rels <= KGW_MAX_RELS)  */
+    const int32_t* chunk_perm;     /* optional (NULL = chunk list order): XCD-aware work order of k_agg_fwd / k_agg_bwd_dst.
+                                      Entry p = the chunk wavefront p % 4 of block p / 4 processes, -1 = none; blocks are
+                                      dealt to the 8 XCDs round-robin, so the entries with (p / 4) % 8 == x form the work
+                                      list of XCD x -- built so that an XCD gathers from ONE part of the source rows and its
+                                      private L2 holds that part (kgw_sample_batch writes it; KgwBatchBuf.chunk_perm)      */
+    const int32_t* chunk_perm_len; /* device: number of entries of chunk_perm that are in use                           */
     uint64_t partial_rels;         /* forward: bit r set => the segments of relation r are written as PARTIAL online-softmax
                                       states -- Z = sum_j exp(e_ij - m) h_j (not divided), stat = (m, sum_j exp(e_ij - m)) --
                                       for the caller to merge across GPUs (SNP-sharded mode: a rank holds only its own SNP

@@ -8,7 +8,7 @@ import os
 KGW_MAX_TYPES = 8
 KGW_MAX_RELS = 64
 KGW_MAX_LAYERS = 4
-KGW_CHUNK = 256
+KGW_CHUNK = 128
 KGW_TILE = 1024
 KGW_C = 128
 PART_STRIDE = 132
@@ -95,7 +95,7 @@ class KgwLayerArgs(C.Structure):
         ('dZ', C.c_void_p), ('adp', C.c_void_p), ('da_dst', C.c_void_p), ('part_da', C.c_void_p),
         ('t_ptr', C.c_void_p), ('t_edge', C.c_void_p), ('t_zrow', C.c_void_p),
         ('dH', C.c_void_p), ('ev_before', C.c_void_p), ('ev_after', C.c_void_p), ('da_src', C.c_void_p),
-        ('partial_rels', C.c_uint64),
+        ('chunk_perm', C.c_void_p), ('chunk_perm_len', C.c_void_p), ('partial_rels', C.c_uint64),
     ]
 
 

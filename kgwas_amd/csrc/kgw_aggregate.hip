@@ -77,6 +77,8 @@ struct AggPtrs {
     const int32_t* multi;
     int64_t multi_cap;
     const KgwBatchMeta* meta;     // device: actual counts of the batch
+    const int32_t* perm;          // XCD-aware work order (nullable)
+    const int32_t* perm_len;
     int layer;
     int raw;                      // forward: raw-logit weights (attention export)
     int relu_in;                  // bwd_src: dH *= (H > 0)
@@ -144,14 +146,8 @@ __device__ __forceinline__ void fwd_group(const float4* __restrict__ Hb4, int co
     }
 }
 
-// Eight edges per half with the transposed reduction (kgw_half_reduce8): the lane with (hl & 7) == p owns edge q0 + p --
-// its logit, its softmax weight -- and hands the weight to the other lanes of its 8-lane group with one swizzle.
-template <bool RAW>
-__device__ __forceinline__ void fwd_group8(const float4* __restrict__ Hb4, int colv, int q0, int hn, int nb,
-                                           int half, int hl, const float4& u4, float ad, float slope,
-                                           float inv_temp, float& m, float& s, float4& acc, float& ev) {
-    float4 x[8];
-    float part[8];
+__device__ __forceinline__ void grp8_load(const float4* __restrict__ Hb4, int colv, int q0, int hn, int nb, int half, int hl,
+                                          float4 (&x)[8]) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int q = q0 + p, i = half * hn + q;
@@ -159,6 +155,13 @@ __device__ __forceinline__ void fwd_group8(const float4* __restrict__ Hb4, int c
         const int cj = __shfl(colv, ok ? i : 0, 64);
         x[p] = Hb4[(int64_t)cj * 32 + hl];
     }
+}
+
+template <bool RAW>
+__device__ __forceinline__ void fwd_grp8_compute(const float4 (&x)[8], int q0, int hn, int nb, int half, int hl,
+                                                 const float4& u4, float ad, float slope, float inv_temp, float& m, float& s,
+                                                 float4& acc, float& ev) {
+    float part[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) part[p] = dot4(x[p], u4);
     const int pm = hl & 7, qm = q0 + pm;
@@ -183,12 +186,29 @@ __device__ __forceinline__ void fwd_group8(const float4* __restrict__ Hb4, int c
     fma4(acc, kgw_bcast8<6>(w), x[6]); fma4(acc, kgw_bcast8<7>(w), x[7]);
 }
 
+// Eight edges per half with the transposed reduction (kgw_half_reduce8): the lane with (hl & 7) == p owns edge q0 + p --
+// its logit, its softmax weight -- and hands the weight to the other lanes of its 8-lane group with one swizzle.
 template <bool RAW>
+__device__ __forceinline__ void fwd_group8(const float4* __restrict__ Hb4, int colv, int q0, int hn, int nb,
+                                           int half, int hl, const float4& u4, float ad, float slope,
+                                           float inv_temp, float& m, float& s, float4& acc, float& ev) {
+    float4 x[8];
+    grp8_load(Hb4, colv, q0, hn, nb, half, hl, x);
+    fwd_grp8_compute<RAW>(x, q0, hn, nb, half, hl, u4, ad, slope, inv_temp, m, s, acc, ev);
+}
+
+// PIPE: software pipelining inside a chunk.  A chunk of n edges used to cost one memory round trip for the column ids of
+// every 64 edges plus one per group of 16 rows (a 256-edge chunk of a hub row: 20 dependent round trips, and the longest
+// chunks set the kernel's tail -- halving KGW_CHUNK alone took 64 -> 58 us); with PIPE the next block's column ids and
+// the next group's rows are requested before the current group is reduced.
+template <bool RAW, bool PIPE>
 __global__ void __launch_bounds__(KGW_BLK) k_agg_fwd(LayerTab T, AggPtrs P, float slope, float inv_temp) {
     const int lane = kgw_lane(), half = lane >> 5, hl = lane & 31;
     const int nw = gridDim.x * 4;
-    const int n_chunks = P.meta->n_chunks[P.layer - 1];
-    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < n_chunks; c += nw) {
+    const int n_items = P.perm ? *P.perm_len : P.meta->n_chunks[P.layer - 1];
+    for (int g = blockIdx.x * 4 + (threadIdx.x >> 6); g < n_items; g += nw) {
+        const int c = P.perm ? P.perm[g] : g;
+        if (c < 0) continue;
         const KgwChunk ck = load_chunk(P.chunks, c);
         const int r = ck.rel;
         if (!T.live[r]) continue;
@@ -206,12 +226,38 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_fwd(LayerTab T, AggPtrs P, floa
         float m = NEG_BIG, s = 0.f;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         const int n = ck.e1 - ck.e0;
+        int colv_next = (PIPE && lane < min(64, n)) ? P.col_local[ck.e0 + lane] : 0;
         for (int b = 0; b < n; b += 64) {
             const int nb = min(64, n - b);
             const int hn = (nb + 1) >> 1;
-            const int colv = (lane < nb) ? P.col_local[ck.e0 + b + lane] : 0;
+            int colv;
+            if (PIPE) {
+                colv = colv_next;
+                colv_next = (b + 64 < n && lane < min(64, n - b - 64)) ? P.col_local[ck.e0 + b + 64 + lane] : 0;
+            } else {
+                colv = (lane < nb) ? P.col_local[ck.e0 + b + lane] : 0;
+            }
             float ev = 0.f;
-            for (int q0 = 0; q0 < hn;) {
+            int q0 = 0;
+            if (PIPE && hn > 4) {
+                float4 x0[8], x1[8];
+                grp8_load(Hb4, colv, 0, hn, nb, half, hl, x0);
+                while (true) {
+                    const int q1 = q0 + 8;
+                    const bool more1 = hn - q1 > 4;
+                    if (more1) grp8_load(Hb4, colv, q1, hn, nb, half, hl, x1);
+                    fwd_grp8_compute<RAW>(x0, q0, hn, nb, half, hl, u4, ad, slope, inv_temp, m, s, acc, ev);
+                    q0 = q1;
+                    if (!more1) break;
+                    const int q2 = q1 + 8;
+                    const bool more2 = hn - q2 > 4;
+                    if (more2) grp8_load(Hb4, colv, q2, hn, nb, half, hl, x0);
+                    fwd_grp8_compute<RAW>(x1, q1, hn, nb, half, hl, u4, ad, slope, inv_temp, m, s, acc, ev);
+                    q0 = q2;
+                    if (!more2) break;
+                }
+            }
+            for (; q0 < hn;) {
                 const int rem = hn - q0;
                 if (rem > 4)      { fwd_group8<RAW>(Hb4, colv, q0, hn, nb, half, hl, u4, ad, slope, inv_temp, m, s, acc, ev); q0 += 8; }
                 else if (rem > 2) { fwd_group<4, RAW>(Hb4, colv, q0, hn, nb, half, hl, u4, ad, slope, inv_temp, m, s, acc, ev); q0 += 4; }
@@ -321,19 +367,10 @@ __device__ __forceinline__ void bwd_group(const float4* __restrict__ Hb4, int co
 
 // Eight edges per half, transposed reduction (see fwd_group8): the lane with (hl & 7) == p owns edge q0 + p.  `dsum`
 // here collects only the lane's OWN edges; the caller folds the 8 residues once per chunk (kgw_sum8).
-__device__ __forceinline__ void bwd_group8(const float4* __restrict__ Hb4, int colv, float evin, int q0, int hn,
-                                           int nb, int half, int hl, const float4& dz4, float cdot, float M,
-                                           float inv_den, float slope, float inv_temp, float& av, float& dv,
-                                           float& dsum_own) {
-    float4 x[8];
+__device__ __forceinline__ void bwd_grp8_compute(const float4 (&x)[8], float evin, int q0, int hn, int nb, int half, int hl,
+                                                 const float4& dz4, float cdot, float M, float inv_den, float slope,
+                                                 float inv_temp, float& av, float& dv, float& dsum_own) {
     float part[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int q = q0 + p, i = half * hn + q;
-        const bool ok = (q < hn) && (i < nb);
-        const int cj = __shfl(colv, ok ? i : 0, 64);
-        x[p] = Hb4[(int64_t)cj * 32 + hl];
-    }
 #pragma unroll
     for (int p = 0; p < 8; ++p) part[p] = dot4(x[p], dz4);
     const int pm = hl & 7, qm = q0 + pm;
@@ -350,11 +387,23 @@ __device__ __forceinline__ void bwd_group8(const float4* __restrict__ Hb4, int c
     dsum_own += (hl < 8) ? dpre : 0.f;          // one copy per edge: the 8 residues of the first 8-lane group
 }
 
+__device__ __forceinline__ void bwd_group8(const float4* __restrict__ Hb4, int colv, float evin, int q0, int hn,
+                                           int nb, int half, int hl, const float4& dz4, float cdot, float M,
+                                           float inv_den, float slope, float inv_temp, float& av, float& dv,
+                                           float& dsum_own) {
+    float4 x[8];
+    grp8_load(Hb4, colv, q0, hn, nb, half, hl, x);
+    bwd_grp8_compute(x, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own);
+}
+
+template <bool PIPE>
 __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_dst(LayerTab T, AggPtrs P, float slope, float inv_temp) {
     const int lane = kgw_lane(), half = lane >> 5, hl = lane & 31;
     const int nw = gridDim.x * 4;
-    const int n_chunks = P.meta->n_chunks[P.layer - 1];
-    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < n_chunks; c += nw) {
+    const int n_items = P.perm ? *P.perm_len : P.meta->n_chunks[P.layer - 1];
+    for (int g = blockIdx.x * 4 + (threadIdx.x >> 6); g < n_items; g += nw) {
+        const int c = P.perm ? P.perm[g] : g;
+        if (c < 0) continue;
         const KgwChunk ck = load_chunk(P.chunks, c);
         const int r = ck.rel;
         if (!T.live[r]) continue;
@@ -367,15 +416,50 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_dst(LayerTab T, AggPtrs P, 
         const float4* Hb4 = (const float4*)(P.H + (int64_t)T.src_base[r] * KGW_C);
         float dsum = 0.f, dsum_own = 0.f;
         const int n = ck.e1 - ck.e0;
+        int colv_next = (PIPE && lane < min(64, n)) ? P.col_local[ck.e0 + lane] : 0;
+        float ev_next = 0.f;
+        if (PIPE) {
+            const int nb0 = min(64, n), hn0 = (nb0 + 1) >> 1, i0 = half * hn0 + hl;
+            ev_next = (hl < hn0 && i0 < nb0) ? P.e_edge[ck.e0 + i0] : 0.f;
+        }
         for (int b = 0; b < n; b += 64) {
             const int nb = min(64, n - b);
             const int hn = (nb + 1) >> 1;
-            const int colv = (lane < nb) ? P.col_local[ck.e0 + b + lane] : 0;
             const int i = half * hn + hl;
             const bool mine = (hl < hn) && (i < nb);
-            const float evin = mine ? P.e_edge[ck.e0 + b + i] : 0.f;
+            int colv;
+            float evin;
+            if (PIPE) {
+                colv = colv_next; evin = ev_next;
+                const int nb2 = min(64, n - b - 64), hn2 = (nb2 + 1) >> 1, i2 = half * hn2 + hl;
+                const bool nxt = b + 64 < n;
+                colv_next = (nxt && lane < nb2) ? P.col_local[ck.e0 + b + 64 + lane] : 0;
+                ev_next = (nxt && hl < hn2 && i2 < nb2) ? P.e_edge[ck.e0 + b + 64 + i2] : 0.f;
+            } else {
+                colv = (lane < nb) ? P.col_local[ck.e0 + b + lane] : 0;
+                evin = mine ? P.e_edge[ck.e0 + b + i] : 0.f;
+            }
             float av = 0.f, dv = 0.f;
-            for (int q0 = 0; q0 < hn;) {
+            int q0 = 0;
+            if (PIPE && hn > 4) {
+                float4 x0[8], x1[8];
+                grp8_load(Hb4, colv, 0, hn, nb, half, hl, x0);
+                while (true) {
+                    const int q1 = q0 + 8;
+                    const bool more1 = hn - q1 > 4;
+                    if (more1) grp8_load(Hb4, colv, q1, hn, nb, half, hl, x1);
+                    bwd_grp8_compute(x0, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own);
+                    q0 = q1;
+                    if (!more1) break;
+                    const int q2 = q1 + 8;
+                    const bool more2 = hn - q2 > 4;
+                    if (more2) grp8_load(Hb4, colv, q2, hn, nb, half, hl, x0);
+                    bwd_grp8_compute(x1, evin, q1, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own);
+                    q0 = q2;
+                    if (!more2) break;
+                }
+            }
+            for (; q0 < hn;) {
                 const int rem = hn - q0;
                 if (rem > 4)      { bwd_group8(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own); q0 += 8; }
                 else if (rem > 2) { bwd_group<4>(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum); q0 += 4; }
@@ -444,7 +528,7 @@ __device__ __forceinline__ void bwd_src_one_row(const LayerTab& T, const AggPtrs
         const int tb = T.type_t_base[ty] + j * Rs;
         if (j >= P.meta->n_src[P.layer - 1][ty]) {          // padding row of a static layout: no gradient
             if (half == 0) ((float4*)(P.dH + (int64_t)u * KGW_C))[hl] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (lane < 2 * T.ld_da) P.da_src[(int64_t)u * 2 * T.ld_da + lane] = 0.f;
+            for (int c = lane; c < 2 * T.ld_da; c += 64) P.da_src[(int64_t)u * 2 * T.ld_da + c] = 0.f;
             return;
         }
         // all Rs + 1 row pointers of this source in ONE load (lane k holds t_ptr[tb + k]); the per-slot logic below
@@ -536,13 +620,16 @@ __device__ __forceinline__ void bwd_src_one_row(const LayerTab& T, const AggPtrs
         // caller gets d u_r = sum_j d a_src[j, r] H[j] and d v_r = sum_i d a_dst[i, r] H[i] for all relations as
         // ONE tall-skinny product over H
         {
-            const int ld = T.ld_da;
-            const bool mine = lane < T.n_rels && T.rel_src_type[lane] == ty;
-            const float v = __shfl(dasv, mine ? T.rel_slot_src[lane] : 0, 64);
-            float w = 0.f;
-            const int c = lane - ld;
-            if (is_dst && c >= 0 && c < T.n_rels && T.rel_dst_type[c] == ty) w = P.da_dst[zb + T.rel_slot_dst[c]];
-            if (lane < 2 * ld) P.da_src[(int64_t)u * 2 * ld + lane] = (lane < ld) ? (mine ? v : 0.f) : w;
+            const int ld = T.ld_da;                           // up to 64 relations: a row of up to 128 floats, two per lane
+            for (int c0 = 0; c0 < 2 * ld; c0 += 64) {
+                const int col = c0 + lane;
+                const bool mine = col < T.n_rels && T.rel_src_type[col] == ty;
+                const float v = __shfl(dasv, mine ? T.rel_slot_src[col] : 0, 64);
+                float w = 0.f;
+                const int c = col - ld;
+                if (is_dst && c >= 0 && c < T.n_rels && T.rel_dst_type[c] == ty) w = P.da_dst[zb + T.rel_slot_dst[c]];
+                if (col < 2 * ld) P.da_src[(int64_t)u * 2 * ld + col] = (col < ld) ? (mine ? v : 0.f) : w;
+            }
         }
     }
 }
@@ -675,12 +762,15 @@ __device__ __forceinline__ bool bwd_src_row_pair(const LayerTab& T, const AggPtr
     // [d a_src | d a_dst] row, one column per relation id; each half writes its own row, two columns per lane
     {
         const int ld = T.ld_da;
-        const bool mine = hl < T.n_rels && T.rel_src_type[hl] == ty;
-        const float v = __shfl(dasv, hb + (mine ? T.rel_slot_src[hl] : 0), 64);
-        float w = 0.f;
-        if (is_dst && hl < T.n_rels && T.rel_dst_type[hl] == ty) w = P.da_dst[zb + T.rel_slot_dst[hl]];
         float* row = P.da_src + (int64_t)uh * 2 * ld;
-        if (hl < ld) { row[hl] = mine ? v : 0.f; row[ld + hl] = w; }
+        for (int c0 = 0; c0 < ld; c0 += 32) {                 // (more than 32 relations: a second round)
+            const int col = c0 + hl;
+            const bool mine = col < T.n_rels && T.rel_src_type[col] == ty;
+            const float v = __shfl(dasv, hb + (mine ? T.rel_slot_src[col] : 0), 64);
+            float w = 0.f;
+            if (is_dst && col < T.n_rels && T.rel_dst_type[col] == ty) w = P.da_dst[zb + T.rel_slot_dst[col]];
+            if (col < ld) { row[col] = mine ? v : 0.f; row[ld + col] = w; }
+        }
     }
     return true;
 }
@@ -731,7 +821,6 @@ int build_tab(const KgwLayerArgs* a, LayerTab* T) {
     T->n_types = G->n_types;
     T->partial = a->partial_rels;
     T->ld_da = (G->n_rels + 3) & ~3;
-    if (2 * T->ld_da > 64) return KGW_E_UNSUPPORTED;          // one wavefront-wide store per source row
     for (int r = 0; r < G->n_rels; ++r) {
         const int s = G->rel_src[r], d = G->rel_dst[r];
         T->src_base[r] = M->src_base[l - 1][s];
@@ -767,6 +856,7 @@ AggPtrs build_ptrs(const KgwLayerArgs* a) {
     P.da_dst = a->da_dst; P.part_da = a->part_da; P.t_ptr = a->t_ptr; P.t_edge = a->t_edge;
     P.t_zrow = a->t_zrow; P.dH = a->dH; P.da_src = a->da_src; P.multi = a->multi; P.multi_cap = a->multi_cap;
     P.meta = a->meta_dev; P.layer = a->layer;
+    P.perm = a->chunk_perm_len ? a->chunk_perm : nullptr; P.perm_len = a->chunk_perm_len;
     return P;
 }
 
@@ -787,7 +877,7 @@ inline int grid_fine(int64_t n_items) {
     int64_t g = (n_items + 3) / 4;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
-    return (int)g;
+    return (int)((g + 7) & ~7ll);             // whole rounds over the 8 XCDs: a grid-stride step keeps a block's XCD class
 }
 
 }  // namespace
@@ -804,8 +894,13 @@ extern "C" int kgw_gat_aggregate_fwd(const KgwLayerArgs* a, kgw_stream_t stream_
     AggPtrs P = build_ptrs(a);
     hipStream_t st = (hipStream_t)stream_;
     if (a->ev_before) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_before, st));
-    if (P.raw) k_agg_fwd<true><<<grid_fine(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
-    else       k_agg_fwd<false><<<grid_fine(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
+    // KGW_AGG_PIPE: bit 0 = pipelined k_agg_fwd, bit 1 = pipelined k_agg_bwd_dst.  Measured at KGW_CHUNK = 128 (layer-1
+    // launch of the benchmark): forward 55.5 us plain / 57.5 pipelined (122 VGPRs cost two wavefronts per SIMD), backward
+    // 56.8 plain / 53.2 pipelined => default 2
+    static const int pipe = (getenv("KGW_AGG_PIPE") ? atoi(getenv("KGW_AGG_PIPE")) : 2) & 1;
+    if (P.raw) k_agg_fwd<true, false><<<grid_fine(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
+    else if (pipe) k_agg_fwd<false, true><<<grid_fine(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
+    else       k_agg_fwd<false, false><<<grid_fine(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
     KGW_LAUNCH_CHECK();
     if (a->ev_after) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_after, st));
     if (a->multi && a->multi_cap > 0) {     // hub rows: the number of multi-chunk segments is read on the device
@@ -827,7 +922,9 @@ extern "C" int kgw_gat_aggregate_bwd_dst(const KgwLayerArgs* a, kgw_stream_t str
     AggPtrs P = build_ptrs(a);
     hipStream_t st = (hipStream_t)stream_;
     if (a->ev_before) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_before, st));
-    k_agg_bwd_dst<<<grid_fine(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
+    static const int pipe = (getenv("KGW_AGG_PIPE") ? atoi(getenv("KGW_AGG_PIPE")) : 2) & 2;
+    if (pipe) k_agg_bwd_dst<true><<<grid_fine(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
+    else k_agg_bwd_dst<false><<<grid_fine(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
     KGW_LAUNCH_CHECK();
     if (a->ev_after) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_after, st));
     if (a->multi && a->multi_cap > 0) {

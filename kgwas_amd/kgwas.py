@@ -190,6 +190,8 @@ class KGWAS:
             for item in steps:
                 if graph_step is not None:
                     step, loss = item, graph_step.step(item)
+                    if step % 128 == 127:                    # a batch that outgrew the static layout: stop at once, not at
+                        graph_step.check()                   # the end of the epoch (one stream sync per 128 steps)
                 else:
                     step, batch = item
                     loss = self.train_step(batch, optimizer, ld_w, world)

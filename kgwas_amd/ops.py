@@ -125,6 +125,9 @@ def _layer_args(batch, layer: int, neg_slope: float, inv_temp: float) -> KgwLaye
     a.t_ptr = _p(buf.t_ptr[layer - 1])
     a.t_edge = _p(buf.t_edge[layer - 1])
     a.t_zrow = _p(buf.t_zrow[layer - 1])
+    perm = getattr(batch, 'chunk_perm', None)          # XCD-aware work order of the dst-major kernels (optional)
+    if perm is not None and perm.get(layer) is not None:
+        a.chunk_perm, a.chunk_perm_len = _p(perm[layer][0]), _p(perm[layer][1])
     return a
 
 

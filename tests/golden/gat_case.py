@@ -5,7 +5,7 @@ and numpy / torch version: the committed file holds OUTPUTS (attention, activati
 sampled node / edge sets, transformed edge lists), this module regenerates the INPUTS they belong to.
 
 Graph (corner cases of SURVEY.md 4): 5 node types; three SNP->Gene relations (one with a hub row of 300 in-edges
-> KGW_CHUNK = 256 plus duplicate edges, one regular, one EMPTY), one Gene-Gene relation with pre-existing self-loops,
+> KGW_CHUNK = 128 plus duplicate edges, one regular, one EMPTY), one Gene-Gene relation with pre-existing self-loops,
 three Gene->GO relations; SNPs without any edge (zero-degree seeds).  ``original_edges()`` is what the reference's
 ``edge_index.pkl`` would hold; the reference then applies ToUndirected + AddSelfLoops (kgwas_data.py:271-272).
 """

@@ -457,3 +457,51 @@ def test_relation_aggregation_modes_match_reference_restatement(edge_case_graph,
             n += 1
             assert_close(g, ref, RTOL, max(ATOL, 1e-4 * float(ref.abs().max())), f'grad {name} fused={fused}')
         assert n > 10
+
+
+def test_more_than_32_relations_match_reference_restatement():
+    """42 relations after ToUndirected (12 SNP->Gene, 6 Gene-Gene, 6 Gene->GO + their mirrors): above the 32 relation
+    ids one wavefront-wide store of the source-side backward used to cover."""
+    from collections import OrderedDict
+    from kgwas_amd.graph import HeteroGraph, add_self_loops, to_undirected
+    rng = np.random.default_rng(42)
+    n = OrderedDict([('SNP', 900), ('Gene', 40), ('CellularComponent', 6), ('BiologicalProcess', 9), ('MolecularFunction', 5)])
+    e = OrderedDict()
+    for k in range(12):
+        m = int(rng.integers(30, 400))
+        e[('SNP', f'v2g{k}', 'Gene')] = np.stack([rng.integers(0, 900, m), rng.integers(0, 40, m)])
+    for k in range(6):
+        m = int(rng.integers(20, 120))
+        e[('Gene', f'g2g{k}', 'Gene')] = np.stack([rng.integers(0, 40, m), rng.integers(0, 40, m)])
+    for k, t in enumerate(['CellularComponent', 'BiologicalProcess', 'MolecularFunction'] * 2):
+        m = int(rng.integers(10, 60))
+        e[('Gene', f'g2go{k}', t)] = np.stack([rng.integers(0, 40, m), rng.integers(0, n[t], m)])
+    g = torch.Generator().manual_seed(1)
+    data = HeteroGraph()
+    for t, k in n.items():
+        data[t].x = torch.rand(k, 20 if t == 'SNP' else 24 if t == 'Gene' else 16, generator=g)
+    for et, ei in add_self_loops(to_undirected(e, n), n).items():
+        data[et].edge_index = torch.from_numpy(np.ascontiguousarray(ei))
+    assert len(data.edge_types) == 42
+    model = _model(data, (20, 24, 16), seed=9)
+    ids = rng.choice(900, size=48, replace=False)
+    batch = next(iter(_loader(data, ids, 48)))
+    out = model(batch.x_dict, batch.edge_index_dict, 48)
+    y = torch.rand(48, dtype=torch.float64)
+    w = torch.rand(48, dtype=torch.float64) + 0.5
+    weighted_mse(out, y.cuda(), w.cuda()).backward()
+    oracle = oracle_from_product(model)
+    x, ei = batch_cpu(batch)
+    out_o = oracle(x, ei, 48)
+    weighted_mse(out_o, y, w).backward()
+    assert_close(out, out_o.detach(), RTOL, ATOL, 'pred')
+    go = grads_by_name(oracle)
+    n_live = 0
+    for name, gr in grads_by_name(model).items():
+        ref = go[name]
+        if gr is None:
+            assert ref is None or float(ref.abs().max()) == 0.0, name
+            continue
+        n_live += 1
+        assert_close(gr, ref, RTOL, max(ATOL, 1e-4 * float(ref.abs().max())), f'grad {name}')
+    assert n_live > 100

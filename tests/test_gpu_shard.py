@@ -7,7 +7,7 @@ batches with the same weights:
   for every parameter, including the replicated gene / GO MLPs and the relations whose softmax is split across ranks;
 * after the flat all-reduce + Adam the ranks hold bit-identical parameters, equal to the single-process step;
 * the merged attention statistics equal the single-process ones (partial online-softmax merge, hub gene included).
-The graphs: SynthKG at 1 % scale (hub genes above KGW_CHUNK = 256 in-edges, so multi-chunk partial states are merged
+The graphs: SynthKG at 1 % scale (hub genes above KGW_CHUNK = 128 in-edges, so multi-chunk partial states are merged
 too) and the hand-made corner-case graph (empty relation, duplicate edges, zero-degree seeds)."""
 import os
 import socket
