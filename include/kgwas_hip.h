@@ -170,6 +170,10 @@ typedef struct KgwLayerArgs {
     void* ev_before; void* ev_after;
     float* da_src;                 /* [n_src_rows][2*ld], ld = (n_rels+3)&~3: columns [0,ld) d a_src, [ld,2ld) d a_dst
                                       of the node, one column per relation id (n_rels <= KGW_MAX_RELS)  */
+    const float* logit_bias;       /* optional [n_rels]: constant added to the pre-activation logit of every edge of relation r
+                                      (FC_output folded into the layer-1 relation parameters: the feature MLP's last Linear
+                                      H = h2 T + c enters conv.py:150-152 only through <H, u_r> and <H, v_r>, whose constant
+                                      parts <c_src, u_r> + <c_dst, v_r> land here while T is multiplied into U and V)     */
     const int32_t* chunk_perm;     /* optional (NULL = chunk list order): XCD-aware work order of k_agg_fwd / k_agg_bwd_dst.
                                       Entry p = the chunk wavefront p % 4 of block p / 4 processes, -1 = none; blocks are
                                       dealt to the 8 XCDs round-robin, so the entries with (p / 4) % 8 == x form the work
@@ -311,6 +315,17 @@ int64_t kgw_linear_splitk_workspace_floats(int64_t rows, int32_t K, int32_t N);
 int kgw_linear_splitk(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
                       int64_t ldy, int64_t rows, int32_t K, int32_t N, int32_t relu, int32_t w_is_kn,
                       float* workspace, int64_t workspace_floats, const int32_t* rows_dev, kgw_stream_t stream);
+/* The forward transform (N == 128, K = R*128) with a per-segment constant: Y[i] = act(X[i] W + bias + sum_r ind(i, r)
+ * gamma[r]), ind(i, r) = seg_stat[2 (i R + r) + 1] > 0 -- segment (destination row i, relation slot r) has at least one
+ * edge (its softmax denominator as kgw_gat_aggregate_fwd left it).  With FC_output folded into layer 1 the aggregate
+ * works on the MLP's hidden state h2 and the bias c of the folded Linear re-enters as c W_r wherever the attention
+ * weights of a segment sum to 1, i.e. wherever it is not empty.  gamma [R][128].  kgw_ind_colsum is the backward:
+ * dgamma[r] = sum_i ind(i, r) dY[i]  (one block per relation slot, rows added in order: deterministic).           */
+int kgw_linear_splitk_ind(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
+                          int64_t ldy, int64_t rows, int32_t K, int32_t relu, const float* seg_stat, const float* gamma,
+                          float* workspace, int64_t workspace_floats, const int32_t* rows_dev, kgw_stream_t stream);
+int kgw_ind_colsum(const float* seg_stat, const float* dY, int64_t ldy, int64_t rows, int32_t R, float* dgamma,
+                   kgw_stream_t stream);
 
 /* One Adam step (torch.optim.Adam semantics, weight_decay as L2: kgwas/kgwas.py:116,151) over up to 64
  * parameter tensors in a single launch.  The pointer arrays are HOST arrays of device pointers (passed to the
@@ -338,6 +353,31 @@ int kgw_relvec_bwd(int32_t n_live, const int32_t* rel_ids, const int32_t* bip_po
                    const float* w_dst_t, const float* att_src, const float* att_dst, const float* dU_full,
                    const float* dV, float* dw_src_t, float* dw_dst_t, float* datt_src, float* datt_dst,
                    int32_t v_by_rel, kgw_stream_t stream);
+
+/* FC_output of the feature MLPs folded into the layer-1 relation parameters (exact re-association; no counterpart call in
+ * the reference, which runs SimpleMLP.FC_output, kgwas/model.py:15,21, on every sampled node).  H = h2 T + c with
+ * T = FC_output.weight^T enters GATConv only through <H_j, u_r>, <H_i, v_r> and sum_j alpha_ij H_j (kgwas/conv.py:150-152,
+ * 227-228), so layer 1 runs on h2 with
+ *     U'_r = T_src U_r,  V'_r = T_dst V_r,  kappa_r = <c_src, U_r> + <c_dst, V_r>,  W'_i = T_src W_i^T,  gamma_i = c_src W_i^T
+ * (src / dst: the MLP of the relation's source / destination node type).  n packed relations (slot i = relation id
+ * rel_ids_host[i]) of n_rels; n_mlp <= 4 MLPs.  U, V / U', V' / kappa are indexed by relation id (rows of relations
+ * outside the pack are written as zeros), W_i^T / W'_i / gamma_i by packed slot.  _fwd fills Up, Vp, kappa, Wp, gamma;
+ * _bwd fills dU, dV (feed kgw_relvec_bwd), dws (the fold's share of d W_i^T), d_fc_weight[m], d_fc_bias[m] from dUp, dVp,
+ * dkappa, dWp, dgamma -- every element written, fixed summation order.  *_host arrays are host int32 arrays.          */
+typedef struct KgwFoldArgs {
+    int32_t n, n_rels, n_mlp, pad_;
+    const int32_t* rel_ids_host; const int32_t* src_mlp_host; const int32_t* dst_mlp_host;
+    const float* w_src_t;            /* [n][128][128]                                   */
+    const float* fc_weight[4];       /* FC_output.weight [128 out][128 in] of MLP m     */
+    const float* fc_bias[4];         /* FC_output.bias [128]                            */
+    const float* U; const float* V;  /* [n_rels][128]                                   */
+    float* Up; float* Vp; float* kappa; float* Wp; float* gamma;
+    const float* dUp; const float* dVp; const float* dkappa; const float* dWp; const float* dgamma;
+    float* dU; float* dV; float* dws;
+    float* d_fc_weight[4]; float* d_fc_bias[4];
+} KgwFoldArgs;
+int kgw_fold_fwd(const KgwFoldArgs* args, kgw_stream_t stream);
+int kgw_fold_bwd(const KgwFoldArgs* args, kgw_stream_t stream);
 
 /* LD-score weighted MSE over the seed rows (kgwas/kgwas.py:139-145): loss = mean_i w[n_id[i]] * (pred[i] - y[n_id[i]])^2,
  * float32 residual / square, float64 weight and mean; _bwd: dpred[i] = grad_loss * d loss / d pred[i].

@@ -95,7 +95,7 @@ class KgwLayerArgs(C.Structure):
         ('dZ', C.c_void_p), ('adp', C.c_void_p), ('da_dst', C.c_void_p), ('part_da', C.c_void_p),
         ('t_ptr', C.c_void_p), ('t_edge', C.c_void_p), ('t_zrow', C.c_void_p),
         ('dH', C.c_void_p), ('ev_before', C.c_void_p), ('ev_after', C.c_void_p), ('da_src', C.c_void_p),
-        ('chunk_perm', C.c_void_p), ('chunk_perm_len', C.c_void_p), ('partial_rels', C.c_uint64),
+        ('logit_bias', C.c_void_p), ('chunk_perm', C.c_void_p), ('chunk_perm_len', C.c_void_p), ('partial_rels', C.c_uint64),
     ]
 
 
@@ -106,8 +106,19 @@ class KgwTnJob(C.Structure):
                 ('M', C.c_int32), ('N', C.c_int32), ('c_transposed', C.c_int32), ('colsum_repeat', C.c_int32)]
 
 
+class KgwFoldArgs(C.Structure):
+    _fields_ = [('n', C.c_int32), ('n_rels', C.c_int32), ('n_mlp', C.c_int32), ('pad_', C.c_int32),
+                ('rel_ids_host', C.c_void_p), ('src_mlp_host', C.c_void_p), ('dst_mlp_host', C.c_void_p),
+                ('w_src_t', C.c_void_p), ('fc_weight', C.c_void_p * 4), ('fc_bias', C.c_void_p * 4),
+                ('U', C.c_void_p), ('V', C.c_void_p),
+                ('Up', C.c_void_p), ('Vp', C.c_void_p), ('kappa', C.c_void_p), ('Wp', C.c_void_p), ('gamma', C.c_void_p),
+                ('dUp', C.c_void_p), ('dVp', C.c_void_p), ('dkappa', C.c_void_p), ('dWp', C.c_void_p), ('dgamma', C.c_void_p),
+                ('dU', C.c_void_p), ('dV', C.c_void_p), ('dws', C.c_void_p),
+                ('d_fc_weight', C.c_void_p * 4), ('d_fc_bias', C.c_void_p * 4)]
+
+
 EXPORTS = ['kgw_version', 'kgw_status_string', 'kgw_struct_sizes', 'kgw_sample_batch', 'kgw_sample_batch_parts',
-           'kgw_softmax_pack', 'kgw_softmax_merge', 'kgw_scatter_rows', 'kgw_linear_splitk', 'kgw_linear_splitk_workspace_floats',
+           'kgw_softmax_pack', 'kgw_softmax_merge', 'kgw_scatter_rows', 'kgw_linear_splitk', 'kgw_linear_splitk_workspace_floats', 'kgw_linear_splitk_ind', 'kgw_ind_colsum', 'kgw_fold_fwd', 'kgw_fold_bwd',
            'kgw_gat_aggregate_fwd', 'kgw_gat_aggregate_bwd_dst', 'kgw_gat_aggregate_bwd_src',
            'kgw_gather_rows', 'kgw_gather_rows_multi', 'kgw_scatter_relu_rows', 'kgw_scatter_relu_rows_workspace_floats', 'kgw_edge_alpha', 'kgw_debug_reduce', 'kgw_debug_reduce8', 'kgw_tn_gemm', 'kgw_tn_gemm_ex', 'kgw_tn_gemm_multi', 'kgw_tn_gemm_workspace_floats',
            'kgw_linear', 'kgw_adam', 'kgw_relvec_fwd', 'kgw_relvec_bwd', 'kgw_wmse_fwd', 'kgw_wmse_bwd', 'kgw_readout_wmse_fwd', 'kgw_readout_wmse_bwd', 'kgw_accumulate_stats']
@@ -167,6 +178,11 @@ def lib():
     L.kgw_linear_splitk_workspace_floats.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     L.kgw_linear_splitk.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.kgw_linear_splitk_ind.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                        C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.kgw_ind_colsum.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+    L.kgw_fold_fwd.argtypes = [C.POINTER(KgwFoldArgs), C.c_void_p]
+    L.kgw_fold_bwd.argtypes = [C.POINTER(KgwFoldArgs), C.c_void_p]
     L.kgw_adam.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
     L.kgw_relvec_fwd.argtypes = [C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,

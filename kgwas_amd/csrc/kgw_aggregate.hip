@@ -61,6 +61,7 @@ struct AggPtrs {
     const float* a_dst;
     const float* V;               // [n_rels][128] v_r (nullable: then a_dst is read)
     const float* U;
+    const float* lbias;           // [n_rels] constant of the pre-activation logit (nullable)
     float* Z;
     float* stat;
     float* e_edge;
@@ -221,6 +222,7 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_fwd(LayerTab T, AggPtrs P, floa
         } else {
             ad = P.a_dst[zrow];
         }
+        if (P.lbias) ad += P.lbias[r];
         const float4 u4 = ((const float4*)(P.U + (int64_t)r * KGW_C))[hl];
         const float4* Hb4 = (const float4*)(P.H + (int64_t)T.src_base[r] * KGW_C);
         float m = NEG_BIG, s = 0.f;
@@ -857,6 +859,7 @@ AggPtrs build_ptrs(const KgwLayerArgs* a) {
     P.t_zrow = a->t_zrow; P.dH = a->dH; P.da_src = a->da_src; P.multi = a->multi; P.multi_cap = a->multi_cap;
     P.meta = a->meta_dev; P.layer = a->layer;
     P.perm = a->chunk_perm_len ? a->chunk_perm : nullptr; P.perm_len = a->chunk_perm_len;
+    P.lbias = a->logit_bias;
     return P;
 }
 

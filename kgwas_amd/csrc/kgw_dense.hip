@@ -1115,6 +1115,8 @@ struct SplitKArgs {
     int relu, w_kn;
     int RT, KS, NS, G;         // row tiles; K slabs; column slabs; row-tile groups per slab
     const int32_t* rows_dev;
+    const float* seg_stat;     // optional: (max, denominator) pairs of the KS segments of every row; with gamma [KS][128]
+    const float* gamma;
 };
 
 __device__ __forceinline__ int64_t sk_rows_eff(const SplitKArgs& a) {
@@ -1234,6 +1236,15 @@ __global__ void __launch_bounds__(256) k_linear_splitk_finish(SplitKArgs a) {
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
             if (a.bias) { const float4 b = *(const float4*)(a.bias + c); s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w; }
+            if (a.seg_stat) {         // + gamma[slot] for every non-empty (row, slot) segment, slots in order
+                const float* st = a.seg_stat + 2 * r * a.KS + 1;
+                for (int ks = 0; ks < a.KS; ++ks) {
+                    if (st[2 * ks] > 0.f) {
+                        const float4 gm = *(const float4*)(a.gamma + ks * 128 + c);
+                        s.x += gm.x; s.y += gm.y; s.z += gm.z; s.w += gm.w;
+                    }
+                }
+            }
             if (a.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
         }
         *(float4*)(a.Y + r * a.ldy + c) = s;
@@ -1247,10 +1258,71 @@ extern "C" int64_t kgw_linear_splitk_workspace_floats(int64_t rows, int32_t K, i
     return (int64_t)(K / 128) * rows * 128;
 }
 
+namespace {
+__global__ void __launch_bounds__(256) k_ind_colsum(const float* __restrict__ seg_stat, const float* __restrict__ dY, int64_t ldy,
+                                                    int64_t rows, int R, float* __restrict__ dgamma) {
+    // block = (relation slot r, group of 32 columns); thread = (row phase 0..7, column): rows ph, ph + 8, ... added in order,
+    // four independent loads in flight per thread; the eight phases are folded through LDS in phase order (deterministic)
+    __shared__ float sm[8][32];
+    const int r = blockIdx.x >> 2, c = (blockIdx.x & 3) * 32 + (threadIdx.x & 31), ph = threadIdx.x >> 5;
+    float s = 0.f;
+    int64_t i = ph;
+    for (; i + 24 < rows; i += 32) {
+        float d[4], v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { d[q] = seg_stat[2 * ((i + 8 * q) * R + r) + 1]; v[q] = dY[(i + 8 * q) * ldy + c]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s += d[q] > 0.f ? v[q] : 0.f;
+    }
+    for (; i < rows; i += 8)
+        if (seg_stat[2 * (i * R + r) + 1] > 0.f) s += dY[i * ldy + c];
+    sm[ph][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (ph == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tot += sm[q][threadIdx.x];
+        dgamma[r * 128 + c] = tot;
+    }
+}
+
+int splitk_launch(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy, int64_t rows,
+                  int32_t K, int32_t N, int32_t relu, int32_t w_is_kn, float* workspace, int64_t workspace_floats,
+                  const int32_t* rows_dev, const float* seg_stat, const float* gamma, kgw_stream_t stream_);
+}  // namespace
+
+extern "C" int kgw_ind_colsum(const float* seg_stat, const float* dY, int64_t ldy, int64_t rows, int32_t R, float* dgamma,
+                              kgw_stream_t stream_) {
+    if (R <= 0) return KGW_OK;
+    if (!seg_stat || !dY || !dgamma) return KGW_E_NULL;
+    if (rows < 0) return KGW_E_RANGE;
+    k_ind_colsum<<<4 * R, 256, 0, (hipStream_t)stream_>>>(seg_stat, dY, ldy, rows, R, dgamma);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
 extern "C" int kgw_linear_splitk(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
                                  int64_t ldy, int64_t rows, int32_t K, int32_t N, int32_t relu, int32_t w_is_kn,
                                  float* workspace, int64_t workspace_floats, const int32_t* rows_dev,
                                  kgw_stream_t stream_) {
+    return splitk_launch(X, ldx, W, ldw, bias, Y, ldy, rows, K, N, relu, w_is_kn, workspace, workspace_floats, rows_dev,
+                         nullptr, nullptr, stream_);
+}
+
+extern "C" int kgw_linear_splitk_ind(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
+                                     int64_t ldy, int64_t rows, int32_t K, int32_t relu, const float* seg_stat,
+                                     const float* gamma, float* workspace, int64_t workspace_floats,
+                                     const int32_t* rows_dev, kgw_stream_t stream_) {
+    if (!seg_stat || !gamma) return KGW_E_NULL;
+    if (K <= 128 || !aligned16(gamma)) return KGW_E_UNSUPPORTED;
+    return splitk_launch(X, ldx, W, ldw, bias, Y, ldy, rows, K, 128, relu, 1, workspace, workspace_floats, rows_dev, seg_stat,
+                         gamma, stream_);
+}
+
+namespace {
+int splitk_launch(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy, int64_t rows,
+                  int32_t K, int32_t N, int32_t relu, int32_t w_is_kn, float* workspace, int64_t workspace_floats,
+                  const int32_t* rows_dev, const float* seg_stat, const float* gamma, kgw_stream_t stream_) {
     if (rows == 0) return KGW_OK;
     if (!X || !W || !Y) return KGW_E_NULL;
     if (rows < 0 || K <= 0 || N <= 0) return KGW_E_RANGE;
@@ -1258,7 +1330,7 @@ extern "C" int kgw_linear_splitk(const float* X, int64_t ldx, const float* W, in
         !aligned16(W) || !aligned16(Y) || (bias && !aligned16(bias)))
         return KGW_E_UNSUPPORTED;
     SplitKArgs a{X, ldx, W, ldw, bias, Y, ldy, workspace, rows, K, N, relu, w_is_kn, (int)((rows + 31) / 32),
-                 K / 128, N / 128, 1, rows_dev};
+                 K / 128, N / 128, 1, rows_dev, seg_stat, gamma};
     const int nslab = a.KS > 1 ? a.KS : a.NS;
     if (a.KS > 1 && (!workspace || workspace_floats < kgw_linear_splitk_workspace_floats(rows, K, N))) return KGW_E_NULL;
     // row-tile groups per slab: about two blocks per CU in total, at most one tile... at least one tile per block
@@ -1280,6 +1352,7 @@ extern "C" int kgw_linear_splitk(const float* X, int64_t ldx, const float* W, in
     }
     return KGW_OK;
 }
+}  // namespace
 
 // ======================================================================================================
 // kgw_scatter_relu_rows: backward of "rows ids of relu(X W^T + b) computed on a RESIDENT matrix" (the 5120-wide gene

@@ -1,0 +1,279 @@
+// kgw_fold.hip -- FC_output of the feature MLPs folded into the layer-1 relation parameters (gfx950).
+//
+// A node's feature-MLP output H = h2 T + c (T = FC_output.weight^T, c = FC_output.bias; kgwas/model.py:15,21) enters the
+// first GATConv layer only linearly -- as the message sum_j alpha_ij H_j and through the logit projections <H_j, u_r>,
+// <H_i, v_r> (kgwas/conv.py:150-152,227-228; GATConv has no root term).  So layer 1 can run on the hidden state h2 with
+//      U'_r  = T_src U_r                 V'_r = T_dst V_r                 kappa_r = <c_src, U_r> + <c_dst, V_r>
+//      W'_r  = T_src W_r^T               gamma_r = c_src W_r^T            (the packed [in, out] weights)
+// (src / dst = the MLP of the relation's source / destination node type), which removes a 128 x 128 Linear -- forward, dX and
+// dW -- over EVERY sampled node (~160 k rows per 512-seed batch) for a few 128^3 products per relation.  Exact: the same
+// sums re-associated, like aggregate-then-transform.
+//
+// kgw_fold_fwd:  one launch.  Blocks [0, 4 n): the n products W'_i = T W_i^T on fp32 MFMA, one wavefront per 32 x 32 tile
+//                (operands straight from global memory, both coalesced: the k order inside the product is permuted like
+//                in kgw_linear_splitk).  Blocks [4 n, 4 n + n_rels): one per relation id -- U', V', kappa (zeros for
+//                relations outside the pack) and gamma.
+// kgw_fold_bwd:  one launch, every output element written, fixed summation orders (deterministic):
+//                blocks A [0, 4 n):          d W_i^T (fold part) = T^T dW'_i + c (x) dgamma_i            (MFMA tiles)
+//                blocks B [.., + 16 n_mlp):  d FC_output.weight_m = sum over the relations whose source MLP is m of
+//                                            (dW'_i W_i)^T, eight wavefronts share a tile's relations and add their
+//                                            accumulators through LDS in wavefront order, + the rank-1 terms dU'_i (x) U_i,
+//                                            dV'_i (x) V_i
+//                blocks C [.., + n_rels):    dU_r = T^T dU'_r + dkappa_r c_src,  dV_r likewise   (then kgw_relvec_bwd)
+//                blocks D [.., + n_mlp):     d FC_output.bias_m
+#include "kgw_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int FC = 128;            // hidden width
+constexpr int FOLD_MAX_MLP = 4;
+
+struct FoldTab {                   // by value: scalar loads from the kernarg segment
+    int32_t n, n_rels, n_mlp, pad_;
+    int8_t rel_id[KGW_MAX_RELS];   // relation id of packed slot i
+    int8_t live_of[KGW_MAX_RELS];  // packed slot of relation id r, -1 = not in the pack
+    int8_t src_m[KGW_MAX_RELS];    // MLP of the source / destination node type of packed slot i
+    int8_t dst_m[KGW_MAX_RELS];
+};
+
+struct FoldPtrs {
+    const float* w_src_t;                       // [n][128][128]  W_i^T ([in, out])
+    const float* fcw[FOLD_MAX_MLP];             // FC_output.weight [out c][in k]   (T[k][c] = fcw[c][k])
+    const float* fcb[FOLD_MAX_MLP];             // FC_output.bias [c]
+    const float* U; const float* V;             // [n_rels][128] by relation id (kgw_relvec_fwd)
+    float* Up; float* Vp; float* kappa;         // [n_rels][128], [n_rels][128], [n_rels]
+    float* Wp; float* gamma;                    // [n][128][128], [n][128]
+    const float* dUp; const float* dVp; const float* dkappa; const float* dWp; const float* dgamma;
+    float* dU; float* dV;                       // [n_rels][128]
+    float* dws;                                 // [n][128][128]
+    float* dfcw[FOLD_MAX_MLP]; float* dfcb[FOLD_MAX_MLP];
+};
+
+// 32 x 32 tile of C = A B over K = 128 on one wavefront.  A(m, k) = pa[m * sam + k * sak], B(k, n) = pb[k * sbk + n * sbn]
+// for the tile's rows m = li and columns n = li; MFMA step j multiplies k = 64 lk + j (a permutation of the sum).
+__device__ __forceinline__ void tile_mma(const float* __restrict__ pa, int sam, int sak, const float* __restrict__ pb, int sbk,
+                                         int sbn, int li, int lk, f32x16& acc0, f32x16& acc1) {
+    float a[64], b[64];
+    const float* qa = pa + li * sam + 64 * lk * sak;
+    const float* qb = pb + li * sbn + 64 * lk * sbk;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) { a[j] = qa[j * sak]; b[j] = qb[j * sbk]; }
+    __builtin_amdgcn_sched_barrier(0);            // all loads in flight before the first MFMA waits
+#pragma unroll
+    for (int j = 0; j < 64; j += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j + 1], b[j + 1], acc1, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ float block128_sum(float v, float* sm) {      // sum over threads 0..127 of a 256-thread block
+    const int t = threadIdx.x;
+    if (t < 128) sm[t] = v;
+    __syncthreads();
+    for (int o = 64; o > 0; o >>= 1) {
+        if (t < o) sm[t] += sm[t + o];
+        __syncthreads();
+    }
+    return sm[0];
+}
+
+__global__ void __launch_bounds__(256) k_fold_fwd(FoldTab T, FoldPtrs P) {
+    __shared__ float sm[128];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5, wave = threadIdx.x >> 6;
+    if (b < 4 * T.n) {
+        const int i = b >> 2, tile = (b & 3) * 4 + wave, tm = tile >> 2, tn = tile & 3;
+        const float* fw = P.fcw[T.src_m[i]];
+        const float* w = P.w_src_t + (int64_t)i * FC * FC;
+        // W'[k][o] = sum_c T[k][c] w[c][o];  A(m = k, c) = fcw[c][k], B(c, n = o) = w[c][o]
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+        tile_mma(fw + 32 * tm, 1, FC, w + 32 * tn, FC, 1, li, lk, acc0, acc1);
+        float* out = P.Wp + (int64_t)i * FC * FC + (int64_t)(32 * tm) * FC + 32 * tn + li;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[((e & 3) + 8 * (e >> 2) + 4 * lk) * FC] = acc0[e] + acc1[e];
+        return;
+    }
+    const int r = b - 4 * T.n;
+    const int i = T.live_of[r];
+    const int t = threadIdx.x;
+    if (i < 0) {                                   // relation outside the pack: zero rows (the aggregate reads by relation id)
+        if (t < 128) { P.Up[r * FC + t] = 0.f; P.Vp[r * FC + t] = 0.f; }
+        if (t == 0) P.kappa[r] = 0.f;
+        return;
+    }
+    const int ms = T.src_m[i], md = T.dst_m[i];
+    const float* u = P.U + r * FC;
+    const float* v = P.V + r * FC;
+    float kp = 0.f;
+    if (t < 128) {
+        const float* ws = P.fcw[ms];
+        const float* wd = P.fcw[md];
+        const float* cb = P.fcb[ms];
+        const float* w = P.w_src_t + (int64_t)i * FC * FC;
+        float up = 0.f, vp = 0.f, gm = 0.f;
+        for (int c = 0; c < FC; ++c) {
+            up = fmaf(ws[c * FC + t], u[c], up);          // U'[k = t] = sum_c T[k][c] U[c]
+            vp = fmaf(wd[c * FC + t], v[c], vp);
+            gm = fmaf(cb[c], w[c * FC + t], gm);          // gamma[o = t] = sum_c c[c] w[c][o]
+        }
+        P.Up[r * FC + t] = up; P.Vp[r * FC + t] = vp; P.gamma[i * FC + t] = gm;
+        kp = P.fcb[ms][t] * u[t] + P.fcb[md][t] * v[t];
+    }
+    const float ksum = block128_sum(kp, sm);
+    if (t == 0) P.kappa[r] = ksum;
+}
+
+__global__ void __launch_bounds__(512) k_fold_bwd(FoldTab T, FoldPtrs P) {
+    __shared__ float red[8][32 * 32];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5, wave = threadIdx.x >> 6;
+    const int t = threadIdx.x;
+    const int nA = 2 * T.n, nB = 16 * T.n_mlp, nC = T.n_rels;
+    if (b < nA) {
+        // ---- A: dws[i][h][o] = sum_k T[k][h] dW'[k][o] + c[h] dgamma[o];  A(m = h, k) = fcw[h][k], B(k, n = o) = dW'[k][o]
+        const int i = b >> 1, tile = (b & 1) * 8 + wave, tm = tile >> 2, tn = tile & 3;
+        const int ms = T.src_m[i];
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+        tile_mma(P.fcw[ms] + (int64_t)(32 * tm) * FC, FC, 1, P.dWp + (int64_t)i * FC * FC + 32 * tn, FC, 1, li, lk, acc0, acc1);
+        const float dg = P.dgamma[i * FC + 32 * tn + li];
+        float* out = P.dws + (int64_t)i * FC * FC + (int64_t)(32 * tm) * FC + 32 * tn + li;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * lk;
+            out[row * FC] = acc0[e] + acc1[e] + P.fcb[ms][32 * tm + row] * dg;
+        }
+        return;
+    }
+    if (b < nA + nB) {
+        // ---- B: dfcw_m[h][k] = sum_{i: src_m = m} ( sum_o w_i[h][o] dW'_i[k][o] + U_i[h] dU'_i[k] ) + sum_{i: dst_m = m} V_i[h] dV'_i[k]
+        const int q = b - nA, m = q >> 4, tile = q & 15, tm = tile >> 2, tn = tile & 3;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+        int seen = 0;
+        for (int i = 0; i < T.n; ++i) {                    // the m-th MLP's relations, dealt to the 8 wavefronts in order
+            if (T.src_m[i] != m) continue;
+            if ((seen++ & 7) != wave) continue;
+            // A(m = h, o) = w_i[h][o], B(o, n = k) = dW'_i[k][o]
+            tile_mma(P.w_src_t + (int64_t)i * FC * FC + (int64_t)(32 * tm) * FC, FC, 1,
+                     P.dWp + (int64_t)i * FC * FC + (int64_t)(32 * tn) * FC, 1, FC, li, lk, acc0, acc1);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wave][((e & 3) + 8 * (e >> 2) + 4 * lk) * 32 + li] = acc0[e] + acc1[e];
+        __syncthreads();
+        const int col = t & 31;                            // k inside the tile
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int row = (t >> 5) + 16 * h2;            // h inside the tile
+            float vsum = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) vsum += red[w8][row * 32 + col];
+            const int h = 32 * tm + row, k = 32 * tn + col;
+            for (int i = 0; i < T.n; ++i) {                // rank-1 terms, relation order
+                const int r = T.rel_id[i];
+                if (T.src_m[i] == m) vsum = fmaf(P.U[r * FC + h], P.dUp[r * FC + k], vsum);
+                if (T.dst_m[i] == m) vsum = fmaf(P.V[r * FC + h], P.dVp[r * FC + k], vsum);
+            }
+            P.dfcw[m][h * FC + k] = vsum;
+        }
+        return;
+    }
+    if (b < nA + nB + nC) {
+        // ---- C: dU[r][c] = sum_k T[k][c] dU'[r][k] + dkappa_r c_src[c]   (fcw[c][k]: thread c reads its own row)
+        const int r = b - nA - nB;
+        const int i = T.live_of[r];
+        if (t >= 128) return;
+        if (i < 0) { P.dU[r * FC + t] = 0.f; P.dV[r * FC + t] = 0.f; return; }
+        const int ms = T.src_m[i], md = T.dst_m[i];
+        const float* ws = P.fcw[ms] + t * FC;
+        const float* wd = P.fcw[md] + t * FC;
+        const float* du = P.dUp + r * FC;
+        const float* dv = P.dVp + r * FC;
+        float su = 0.f, sv = 0.f;
+        for (int k = 0; k < FC; k += 4) {
+            const float4 a4 = *(const float4*)(ws + k), b4 = *(const float4*)(wd + k);
+            const float4 u4 = *(const float4*)(du + k), v4 = *(const float4*)(dv + k);
+            su = fmaf(a4.x, u4.x, su); su = fmaf(a4.y, u4.y, su); su = fmaf(a4.z, u4.z, su); su = fmaf(a4.w, u4.w, su);
+            sv = fmaf(b4.x, v4.x, sv); sv = fmaf(b4.y, v4.y, sv); sv = fmaf(b4.z, v4.z, sv); sv = fmaf(b4.w, v4.w, sv);
+        }
+        const float dk = P.dkappa[r];
+        P.dU[r * FC + t] = su + dk * P.fcb[ms][t];
+        P.dV[r * FC + t] = sv + dk * P.fcb[md][t];
+        return;
+    }
+    {
+        // ---- D: dfcb_m[h] = sum_{i: src_m = m} ( sum_o dgamma_i[o] w_i[h][o] + dkappa_i U_i[h] ) + sum_{i: dst_m = m} dkappa_i V_i[h]
+        const int m = b - nA - nB - nC;
+        if (t >= 128) return;
+        float s = 0.f;
+        for (int i = 0; i < T.n; ++i) {
+            const int r = T.rel_id[i];
+            const float dk = P.dkappa[r];
+            if (T.src_m[i] == m) {
+                const float* w = P.w_src_t + (int64_t)i * FC * FC + t * FC;
+                const float* dg = P.dgamma + i * FC;
+                float q = 0.f;
+                for (int o = 0; o < FC; o += 4) {
+                    const float4 w4 = *(const float4*)(w + o), g4 = *(const float4*)(dg + o);
+                    q = fmaf(w4.x, g4.x, q); q = fmaf(w4.y, g4.y, q); q = fmaf(w4.z, g4.z, q); q = fmaf(w4.w, g4.w, q);
+                }
+                s += q + dk * P.U[r * FC + t];
+            }
+            if (T.dst_m[i] == m) s += dk * P.V[r * FC + t];
+        }
+        P.dfcb[m][t] = s;
+    }
+}
+
+int build(const KgwFoldArgs* a, FoldTab* T, FoldPtrs* P) {
+    if (!a) return KGW_E_NULL;
+    if (a->n < 1 || a->n > KGW_MAX_RELS || a->n_rels < a->n || a->n_rels > KGW_MAX_RELS || a->n_mlp < 1 || a->n_mlp > FOLD_MAX_MLP)
+        return KGW_E_RANGE;
+    if (!a->rel_ids_host || !a->src_mlp_host || !a->dst_mlp_host || !a->w_src_t || !a->U || !a->V) return KGW_E_NULL;
+    T->n = a->n; T->n_rels = a->n_rels; T->n_mlp = a->n_mlp; T->pad_ = 0;
+    for (int r = 0; r < KGW_MAX_RELS; ++r) { T->live_of[r] = -1; T->rel_id[r] = 0; T->src_m[r] = 0; T->dst_m[r] = 0; }
+    for (int i = 0; i < a->n; ++i) {
+        const int r = a->rel_ids_host[i], sm = a->src_mlp_host[i], dm = a->dst_mlp_host[i];
+        if (r < 0 || r >= a->n_rels || sm < 0 || sm >= a->n_mlp || dm < 0 || dm >= a->n_mlp) return KGW_E_RANGE;
+        T->rel_id[i] = (int8_t)r; T->live_of[r] = (int8_t)i; T->src_m[i] = (int8_t)sm; T->dst_m[i] = (int8_t)dm;
+    }
+    P->w_src_t = a->w_src_t; P->U = a->U; P->V = a->V;
+    for (int m = 0; m < FOLD_MAX_MLP; ++m) {
+        P->fcw[m] = m < a->n_mlp ? a->fc_weight[m] : nullptr; P->fcb[m] = m < a->n_mlp ? a->fc_bias[m] : nullptr;
+        P->dfcw[m] = m < a->n_mlp ? a->d_fc_weight[m] : nullptr; P->dfcb[m] = m < a->n_mlp ? a->d_fc_bias[m] : nullptr;
+        if (m < a->n_mlp && (!P->fcw[m] || !P->fcb[m])) return KGW_E_NULL;
+    }
+    P->Up = a->Up; P->Vp = a->Vp; P->kappa = a->kappa; P->Wp = a->Wp; P->gamma = a->gamma;
+    P->dUp = a->dUp; P->dVp = a->dVp; P->dkappa = a->dkappa; P->dWp = a->dWp; P->dgamma = a->dgamma;
+    P->dU = a->dU; P->dV = a->dV; P->dws = a->dws;
+    return KGW_OK;
+}
+
+}  // namespace
+
+extern "C" int kgw_fold_fwd(const KgwFoldArgs* a, kgw_stream_t stream_) {
+    FoldTab T; FoldPtrs P;
+    int rc = build(a, &T, &P);
+    if (rc) return rc;
+    if (!P.Up || !P.Vp || !P.kappa || !P.Wp || !P.gamma) return KGW_E_NULL;
+    k_fold_fwd<<<4 * T.n + T.n_rels, 256, 0, (hipStream_t)stream_>>>(T, P);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+extern "C" int kgw_fold_bwd(const KgwFoldArgs* a, kgw_stream_t stream_) {
+    FoldTab T; FoldPtrs P;
+    int rc = build(a, &T, &P);
+    if (rc) return rc;
+    if (!P.dUp || !P.dVp || !P.dkappa || !P.dWp || !P.dgamma || !P.dU || !P.dV || !P.dws) return KGW_E_NULL;
+    for (int m = 0; m < T.n_mlp; ++m)
+        if (!P.dfcw[m] || !P.dfcb[m]) return KGW_E_NULL;
+    k_fold_bwd<<<2 * T.n + 16 * T.n_mlp + T.n_rels + T.n_mlp, 512, 0, (hipStream_t)stream_>>>(T, P);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}

@@ -73,6 +73,16 @@ class SimpleMLP(nn.Module):
         return ops.mlp_tail(h1, self.FC_hidden2.weight, self.FC_hidden2.bias, self.FC_output.weight, self.FC_output.bias,
                             out)
 
+    def tail2(self, h1, out=None):
+        """relu(FC_hidden2(h1)): the MLP without FC_output (folded into layer 1, ops.fold_fc_output)."""
+        return ops.mlp_tail2(h1, self.FC_hidden2.weight, self.FC_hidden2.bias, out)
+
+    def hidden(self, x, out=None, rows_dev=None):
+        """h2 = relu(FC_hidden2(relu(FC_hidden(x)))): the MLP without FC_output (folded into layer 1)."""
+        if x.requires_grad:
+            return self.tail2(self.first(x), out)
+        return ops.mlp2(x, self.FC_hidden.weight, self.FC_hidden.bias, self.FC_hidden2.weight, self.FC_hidden2.bias, out, rows_dev)
+
     def forward(self, x, out=None, rows_dev=None):
         if x.requires_grad:
             return self.tail(self.first(x), out)
@@ -241,6 +251,28 @@ class HeteroGNN(nn.Module):
         self.lin = nn.Linear(hidden_channels, out_channels)
         self.no_relu = no_relu
         self.last_attention = None
+        # FC_output of the feature MLPs folded into the layer-1 relation parameters (ops.fold_fc_output): exact, removes a
+        # 128 x 128 Linear (forward, dX, dW) over every sampled node.  GAT with a relation SUM only: SAGE has a root term and
+        # min / max are not linear in the messages.
+        import os
+        self.fold_fc = gnn_backbone == 'GAT' and gnn_aggr in ('sum', 'mean') and os.environ.get('KGW_FOLD_FC', '1') == '1'
+        if self.fold_fc:
+            mlp_of = {'SNP': 0, 'Gene': 1}
+            order = self.live_packs[0].rel_ids
+            try:
+                sm = [mlp_of.get(self.edge_types[r][0], 2) for r in order]
+                dm = [mlp_of.get(self.edge_types[r][2], 2) for r in order]
+                for r in order:
+                    for t in (self.edge_types[r][0], self.edge_types[r][2]):
+                        self._mlp_for(t)
+            except KeyError:
+                self.fold_fc = False
+            if self.fold_fc:
+                self._fold_used = set(sm) | set(dm)
+                import numpy as np
+                self._fold_tab = (np.asarray(order, dtype=np.int32), np.asarray(sm, dtype=np.int32), np.asarray(dm, dtype=np.int32))
+                self.register_buffer('_fold_src_m', torch.tensor(sm, dtype=torch.long), persistent=False)
+                self.register_buffer('_fold_dst_m', torch.tensor(dm, dtype=torch.long), persistent=False)
         # dead packs never receive gradients; keep them out of autograd entirely
         for p in self.dead_packs.parameters():
             p.requires_grad_(False)
@@ -255,7 +287,7 @@ class HeteroGNN(nn.Module):
             return self.go_feat_mlp
         raise KeyError(f'no feature MLP for node type {t!r} (kgwas/model.py:56-60)')
 
-    def _embed(self, batch: SampledBatch, x_dict, t: str, out=None):
+    def _embed(self, batch: SampledBatch, x_dict, t: str, out=None, fold=False):
         """Feature MLP of the sampled nodes of type t (model.py:56-60).  When most of a type is in the batch
         and its features are wide (the 5120 / 57742-wide gene matrix), the first Linear runs on the RESIDENT
         matrix and the 128-wide result is sliced, instead of slicing 20 KB rows first: same values, the
@@ -273,9 +305,11 @@ class HeteroGNN(nn.Module):
             if X.shape[1] >= 512 and 2 * n > X.shape[0]:
                 i = dg.schema.type_id[t]
                 g2l = batch.buf.g2l[dg.node_base[i]:dg.node_base[i] + X.shape[0]]
-                return mlp.tail(ops.resident_linear_relu_rows(X, mlp.FC_hidden.weight, mlp.FC_hidden.bias, batch.n_id(t), g2l), out)
+                h1 = ops.resident_linear_relu_rows(X, mlp.FC_hidden.weight, mlp.FC_hidden.bias, batch.n_id(t), g2l)
+                return mlp.tail2(h1, out) if fold else mlp.tail(h1, out)
         # static layout: the row block is padded to its capacity; the kernels skip the padding (count on the device)
-        return mlp(x_dict[t], out, batch.rows_dev(t) if n == batch.lay_src(1, dg.schema.type_id[t]) else None)
+        rd = batch.rows_dev(t) if n == batch.lay_src(1, dg.schema.type_id[t]) else None
+        return mlp.hidden(x_dict[t], out, rd) if fold else mlp(x_dict[t], out, rd)
 
     def _layer_input(self, batch: SampledBatch, l: int):
         """Preallocated type-major input matrix of layer l and one RowBlock per node type that has rows in it."""
@@ -286,7 +320,7 @@ class HeteroGNN(nn.Module):
                   for t, name in enumerate(sc.node_types) if int(m.lay_src[l - 1][t])}
         return buf, blocks
 
-    def _embed_all(self, batch: SampledBatch, x_dict, blocks=None):
+    def _embed_all(self, batch: SampledBatch, x_dict, blocks=None, fold=False):
         """All feature MLPs (model.py:56-60).  The three GO types share ``go_feat_mlp`` (model.py:58-60): their
         rows go through it as ONE matrix.  ``blocks``: RowBlocks of the first layer's input to write into."""
         h = {}
@@ -315,12 +349,12 @@ class HeteroGNN(nn.Module):
             if all(b is not None and b.n == n for b, n in zip(bl, ns)) and \
                     all(bl[k + 1].lo == bl[k].lo + bl[k].n for k in range(len(bl) - 1)):
                 out = ops.RowBlock(bl[0].buf, bl[0].lo, sum(ns))          # the GO blocks are adjacent: one output
-            y = self.go_feat_mlp(xg, out)
+            y = self.go_feat_mlp.hidden(xg, out) if fold else self.go_feat_mlp(xg, out)
             for t, piece in zip(go, ops.split_rows(y, ns)):
                 h[t] = piece
         for t in self.node_types:
             if t in x_dict and t not in h:
-                h[t] = self._embed(batch, x_dict, t, blocks.get(t))
+                h[t] = self._embed(batch, x_dict, t, blocks.get(t), fold)
         return h
 
     def _combine_relations(self, o: torch.Tensor) -> torch.Tensor:
@@ -379,7 +413,9 @@ class HeteroGNN(nn.Module):
         return h, []
 
     def _fused_layers(self, batch: SampledBatch, h: Dict[str, torch.Tensor], want_attention=False, hbuf=None,
-                      last_premasked=False):
+                      last_premasked=False, folded=False):
+        """``folded``: h holds the feature MLPs' hidden state h2 (``_embed_all(fold=True)``), not their output: layer 1 runs
+        with FC_output folded into its relation parameters (ops.fold_fc_output)."""
         if self.backbone == 'SAGE':
             if want_attention:
                 raise NotImplementedError('attention weights exist for the GAT backbone only (kgwas/model.py:65-72)')
@@ -416,8 +452,19 @@ class HeteroGNN(nn.Module):
             # (from layer 2 on, H is the previous layer's ReLU output: with the fused transform its backward is folded
             # into this node's)
             fused = self.aggr in ('sum', 'mean')
+            Wp = gam = kap = None
+            if folded and l == 1:
+                # (an MLP no live layer-1 relation touches -- the GO one of a 1-layer model -- stays out of the graph: like
+                # in the reference its parameters get no gradient and Adam skips them)
+                mlps = (self.snp_feat_mlp, self.gene_feat_mlp, self.go_feat_mlp)
+                fc = []
+                for k, mm in enumerate(mlps):
+                    used = k in self._fold_used
+                    fc += [mm.FC_output.weight if used else mm.FC_output.weight.detach(),
+                           mm.FC_output.bias if used else mm.FC_output.bias.detach()]
+                U, V, kap, Wp, gam = ops.fold_fc_output_hip(P, U, V, fc, self._fold_tab)
             Z, stat, e_edge = ops.gat_aggregate(batch, l, H, U, V, self.negative_slope, self.temperature,
-                                                relu_input=(l > 1 and fused), zbuf=zws)
+                                                relu_input=((l > 1 or folded) and fused), zbuf=zws, logit_bias=kap)
             if want_attention:
                 attn.append(ops.edge_alpha(batch, l, stat, e_edge, self.temperature))
             if not fused:
@@ -435,7 +482,8 @@ class HeteroGNN(nn.Module):
             # per-relation linear maps + bias + relation sum + ReLU: one GEMM per destination type, one autograd node
             hbuf, nxt = self._layer_input(batch, l + 1) if l < self.num_layers else (None, {})
             outs = ops.layer_transform(P, Z, blocks, [nxt.get(sc.node_types[t]) for t in tys],
-                                       premasked=(l < self.num_layers) or last_premasked, bias_sum=bsum)
+                                       premasked=(l < self.num_layers) or last_premasked, bias_sum=bsum,
+                                       weight=Wp, gamma=gam, stat=stat if gam is not None else None)
             if self.aggr == 'mean':
                 # mean over the relations of a destination type = the sum scaled by 1/R; relu(s/R) = relu(s)/R, and the
                 # positive scale commutes with the folded ReLU masks
@@ -453,8 +501,8 @@ class HeteroGNN(nn.Module):
         if batch is None:
             batch = self._block_from_coo(x_dict, edge_index_dict)
         hbuf, blocks = self._layer_input(batch, 1)
-        h = self._embed_all(batch, x_dict, blocks)
-        h, attn = self._fused_layers(batch, h, hbuf=hbuf)
+        h = self._embed_all(batch, x_dict, blocks, fold=self.fold_fc)
+        h, attn = self._fused_layers(batch, h, hbuf=hbuf, folded=self.fold_fc)
         snp = h['SNP']
         out = self.lin(snp)[:batch_size]
         if return_h:                                            # model.py:78-79
@@ -469,8 +517,8 @@ class HeteroGNN(nn.Module):
         destination rows; local edge order of ``batch``) -- what the fused kernels actually use, as opposed to the
         reference-shaped ``forward(return_attention_weights=True)`` which runs all relations over all rows."""
         hbuf, blocks = self._layer_input(batch, 1)
-        h = self._embed_all(batch, batch.x_dict, blocks)
-        _, attn = self._fused_layers(batch, h, want_attention=True, hbuf=hbuf)
+        h = self._embed_all(batch, batch.x_dict, blocks, fold=self.fold_fc)
+        _, attn = self._fused_layers(batch, h, want_attention=True, hbuf=hbuf, folded=self.fold_fc)
         return attn
 
     def forward_loss(self, x_dict, edge_index_dict, batch_size, n_id, y_all, w_all):
@@ -483,9 +531,9 @@ class HeteroGNN(nn.Module):
         if self.lin.out_features != 1:
             raise NotImplementedError('the fused read-out + loss is for out_channels == 1 (kgwas/kgwas.py:52)')
         hbuf, blocks = self._layer_input(batch, 1)
-        h = self._embed_all(batch, x_dict, blocks)
+        h = self._embed_all(batch, x_dict, blocks, fold=self.fold_fc)
         gat = self.backbone == 'GAT' and self.aggr in ('sum', 'mean')
-        h, _ = self._fused_layers(batch, h, hbuf=hbuf, last_premasked=gat)
+        h, _ = self._fused_layers(batch, h, hbuf=hbuf, last_premasked=gat, folded=self.fold_fc)
         return ops.readout_weighted_mse(h['SNP'], self.lin.weight, self.lin.bias, n_id, y_all, w_all, batch_size,
                                         relu=not self.no_relu, h_is_relu=gat)
 

@@ -133,7 +133,7 @@ def _layer_args(batch, layer: int, neg_slope: float, inv_temp: float) -> KgwLaye
 
 class _GatAggregate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, H, U, V, batch, layer, neg_slope, inv_temp, raw_weights=False, relu_input=False, zbuf=None):
+    def forward(ctx, H, U, V, batch, layer, neg_slope, inv_temp, raw_weights=False, relu_input=False, zbuf=None, lbias=None):
         dg, m = batch.dg, batch.meta
         NT = dg.schema.NT
         z_rows = int(m.z_base[layer - 1][NT])
@@ -158,6 +158,11 @@ class _GatAggregate(torch.autograd.Function):
         part = torch.empty(max(n_chunks, 1) * PART_STRIDE if any_multi else 4, device=dev)
         a = _layer_args(batch, layer, neg_slope, inv_temp)
         a.H, a.V, a.U = _p(H), _p(V), _p(U)
+        if lbias is not None:
+            lbias = lbias.contiguous()
+            assert lbias.dtype == torch.float32 and lbias.numel() == dg.schema.NR
+            a.logit_bias = _p(lbias)
+        ctx.has_lbias = lbias is not None
         a.flags = 1 if raw_weights else 0          # KGW_F_RAW_WEIGHTS
         ctx.raw_weights = raw_weights
         ctx.relu_input = relu_input
@@ -182,7 +187,7 @@ class _GatAggregate(torch.autograd.Function):
         if ctx.raw_weights:
             raise RuntimeError('raw-logit aggregation (attention export) is inference only')
         if dZ is None:
-            return (None,) * 10
+            return (None,) * 11
         H, U, V, Z, stat, e_edge = ctx.saved_tensors
         batch, layer = ctx.batch, ctx.layer
         dg, m = batch.dg, batch.meta
@@ -224,7 +229,16 @@ class _GatAggregate(torch.autograd.Function):
             dU, dV = dUV[:sc.NR], dUV[ld_da:ld_da + sc.NR]
         else:
             dU, dV = torch.zeros_like(U), torch.zeros_like(V)
-        return dH[:n_src], dU, dV, None, None, None, None, None, None, None
+        dlb = None
+        if ctx.has_lbias:
+            # d(constant of relation r) = sum of d pre-activation over ALL its edges = the column sums of d a_dst
+            dlb = torch.zeros(sc.NR, device=dev)
+            for t in range(NT):
+                rows, R = int(m.lay_rows[layer - 1][t]), int(sc.R_dst[t])
+                if rows and R:
+                    z0 = int(m.z_base[layer - 1][t])
+                    dlb[dg.rels_by_dst_t[t]] = da_dst[z0:z0 + rows * R].view(rows, R).sum(0)
+        return dH[:n_src], dU, dV, None, None, None, None, None, None, None, dlb
 
 
 def aggregate_workspace(batch, layer: int, device) -> torch.Tensor:
@@ -236,7 +250,7 @@ def aggregate_workspace(batch, layer: int, device) -> torch.Tensor:
 
 def gat_aggregate(batch, layer: int, H: torch.Tensor, U: torch.Tensor, V: torch.Tensor,
                   neg_slope: float = 0.2, temperature: float = 1.0, raw_weights: bool = False,
-                  relu_input: bool = False, zbuf: torch.Tensor = None):
+                  relu_input: bool = False, zbuf: torch.Tensor = None, logit_bias: torch.Tensor = None):
     """Z[i, r] = sum_j softmax_j(leaky_relu(<H_src[j], u_r> + <H_dst[i], v_r>) / T) H_src[j] for every live relation
     of the layer.  H [n_src_rows,128]: layer input, type-major (``meta.src_base``; a destination node is row i of
     its own type's block); U, V [n_rels,128] by relation id.  Returns (Z [z_rows,128], stat [z_rows,2] =
@@ -246,9 +260,11 @@ def gat_aggregate(batch, layer: int, H: torch.Tensor, U: torch.Tensor, V: torch.
     the reference's attention export propagates, kgwas/utils.py:446-461 + conv.py:221-228).
     ``relu_input``: every row of H is the output of a ReLU (the previous layer, model.py:75) and the node that
     produced it expects its incoming gradient ALREADY multiplied by (H > 0): the source-side backward does it while
-    writing dH (see layer_transform's ``premasked``).  ``zbuf``: an ``aggregate_workspace`` that is ALREADY zero."""
+    writing dH (see layer_transform's ``premasked``).  ``zbuf``: an ``aggregate_workspace`` that is ALREADY zero.
+    ``logit_bias`` [n_rels]: constant added to the pre-activation logit of every edge of a relation (FC_output folded
+    into layer 1, see fold_fc_output); differentiable."""
     stat, e_edge, Z = _GatAggregate.apply(H, U, V, batch, layer, float(neg_slope), 1.0 / float(temperature), raw_weights,
-                                          relu_input, zbuf)
+                                          relu_input, zbuf, logit_bias)
     return Z, stat, e_edge
 
 
@@ -541,6 +557,55 @@ class _MLP3(torch.autograd.Function):
         return None, dW1, db1, dW2, db2, dW3, db3, None, None
 
 
+class _MLP2(torch.autograd.Function):
+    """h2 = relu(FC_hidden2(relu(FC_hidden(x)))) -- SimpleMLP without its last Linear (kgwas/model.py:18-20), for a
+    feature matrix that needs no gradient.  FC_output is folded into the layer-1 relation parameters (fold_fc_output),
+    and the consumer of h2 (gat_aggregate(relu_input=True)) hands back a gradient ALREADY multiplied by (h2 > 0)."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, out, rows_dev):
+        h1 = linear(x, W1, b1, relu=True, rows_dev=rows_dev)
+        h2 = linear(h1, W2, b2, relu=True, out=out.view() if out is not None else None, rows_dev=rows_dev)
+        ctx.save_for_backward(x, h1, W2)
+        ctx.rows_dev = rows_dev
+        return h2
+
+    @staticmethod
+    def backward(ctx, dh2):
+        x, h1, W2 = ctx.saved_tensors
+        rd = ctx.rows_dev
+        dh2 = dh2.contiguous()
+        dh1 = linear(dh2, W2, mask=h1, w_kn=True, rows_dev=rd)   # (dh2 @ W2) * (h1 > 0)
+        (dW2, db2), (dW1, db1) = weight_grads([(dh2, h1), (dh1, x)], rows_dev=rd)
+        return None, dW1, db1, dW2, db2, None, None
+
+
+def mlp2(x, W1, b1, W2, b2, out=None, rows_dev=None):
+    return _MLP2.apply(x, W1, b1, W2, b2, out, rows_dev)
+
+
+class _MLPTail2(torch.autograd.Function):
+    """h2 = relu(FC_hidden2(h1)) (the folded counterpart of _MLPTail); incoming gradient premasked like _MLP2's."""
+
+    @staticmethod
+    def forward(ctx, h1, W2, b2, out=None):
+        h2 = linear(h1, W2, b2, relu=True, out=out.view() if out is not None else None)
+        ctx.save_for_backward(h1, W2)
+        return h2
+
+    @staticmethod
+    def backward(ctx, dh2):
+        h1, W2 = ctx.saved_tensors
+        dh2 = dh2.contiguous()
+        dh1 = linear(dh2, W2, w_kn=True) if ctx.needs_input_grad[0] else None
+        dW2, db2 = linear_weight_grad(dh2, h1)
+        return dh1, dW2, db2, None
+
+
+def mlp_tail2(h1, W2, b2, out=None):
+    return _MLPTail2.apply(h1, W2, b2, out)
+
+
 def mlp3(x, W1, b1, W2, b2, W3, b3, out=None, rows_dev=None):
     return _MLP3.apply(x, W1, b1, W2, b2, W3, b3, out, rows_dev)
 
@@ -734,7 +799,7 @@ class _LayerTransform(torch.autograd.Function):
     arrays feed the destination type whose block starts at Z row z0 and has ``rows`` destination rows."""
 
     @staticmethod
-    def forward(ctx, w_src_t, bias, Z, blocks, bsum, out_blocks, premasked=False):
+    def forward(ctx, w_src_t, bias, Z, blocks, bsum, out_blocks, premasked=False, gamma=None, stat=None):
         C = bias.shape[1]
         outs, ys = [], []
         # bsum [n blocks, C]: bias of every relation into a type, summed (rel_vectors computes it in its launch)
@@ -742,11 +807,25 @@ class _LayerTransform(torch.autograd.Function):
             R = hi - lo
             x = Z[z0:z0 + rows * R].view(rows, R * C)
             ob = out_blocks[k] if out_blocks is not None else None
-            y = linear(x, w_src_t[lo:hi].view(R * C, C), bsum[k], relu=True, w_kn=True,
-                       out=ob.view() if ob is not None and ob.n == rows else None)
+            out = ob.view() if ob is not None and ob.n == rows else None
+            if gamma is not None and R > 1 and rows:
+                # FC_output folded into this layer: + gamma[r] for every non-empty (row, relation) segment
+                y = torch.empty(rows, C, device=Z.device) if out is None else out
+                L = _lib.lib()
+                nws = int(L.kgw_linear_splitk_workspace_floats(rows, R * C, C))
+                ws = torch.empty(nws, device=Z.device)
+                W = w_src_t[lo:hi].view(R * C, C)
+                _lib.check(L.kgw_linear_splitk_ind(_p(x), x.stride(0), _p(W), W.stride(0), _p(bsum[k]), _p(y), y.stride(0), rows,
+                                                   R * C, 1, stat.data_ptr() + 8 * z0, _p(gamma[lo:hi]), _p(ws), nws, None,
+                                                   _lib.stream_ptr()), 'kgw_linear_splitk_ind')
+            else:
+                y = linear(x, w_src_t[lo:hi].view(R * C, C), bsum[k], relu=False if gamma is not None else True, w_kn=True, out=out)
+                if gamma is not None and rows:      # (single relation into the type: no K split; rare, framework ops)
+                    ind = (stat[z0:z0 + rows * R, 1] > 0).to(y.dtype).view(rows, R)
+                    y = torch.relu_(y.add_(ind @ gamma[lo:hi]))
             outs.append(y)
             ys.append(y)
-        ctx.save_for_backward(w_src_t, Z, *ys)
+        ctx.save_for_backward(w_src_t, Z, gamma, stat, *ys)
         ctx.blocks = blocks
         ctx.n_bias = bias.shape[0]
         ctx.premasked = premasked
@@ -754,8 +833,9 @@ class _LayerTransform(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *dYs):
-        w_src_t, Z = ctx.saved_tensors[:2]
-        ys = ctx.saved_tensors[2:]
+        w_src_t, Z, gamma, stat = ctx.saved_tensors[:4]
+        ys = ctx.saved_tensors[4:]
+        dgamma = torch.zeros_like(gamma) if gamma is not None else None
         C = w_src_t.shape[-1]
         blocks = ctx.blocks
         covered = sum(hi - lo for lo, hi, _, _ in blocks)
@@ -780,10 +860,13 @@ class _LayerTransform(torch.autograd.Function):
             tn_gemm(dz, x, out=dW[lo:hi].view(R * C, C), transpose_out=True, colsum_out=db[lo:hi])
             if need_dz:
                 linear(dz, w_src_t[lo:hi].view(R * C, C), out=dZ[z0:z0 + rows * R].view(rows, R * C))
-        return dW, db, dZ, None, None, None, None
+            if gamma is not None:
+                _lib.check(_lib.lib().kgw_ind_colsum(stat.data_ptr() + 8 * z0, _p(dz), dz.stride(0), rows, R, _p(dgamma[lo:hi]),
+                                                     _lib.stream_ptr()), 'kgw_ind_colsum')
+        return dW, db, dZ, None, None, None, None, dgamma, None
 
 
-def layer_transform(pack, Z, blocks, out_blocks=None, premasked=False, bias_sum=None):
+def layer_transform(pack, Z, blocks, out_blocks=None, premasked=False, bias_sum=None, weight=None, gamma=None, stat=None):
     """``blocks`` = [(lo, hi, z0, rows)] (see _LayerTransform); ``out_blocks``: optional RowBlock per block to write
     the outputs into; ``premasked``: whoever consumes the outputs folds this node's ReLU backward into its own
     backward kernel (gat_aggregate(relu_input=True) / readout_weighted_mse(h_is_relu=True)), so no stand-alone
@@ -797,7 +880,95 @@ def layer_transform(pack, Z, blocks, out_blocks=None, premasked=False, bias_sum=
                 sel[k, lo:hi] = 1.0
             pack._sel_cache[key] = sel
         bias_sum = torch.mm(sel, pack.bias.detach())
-    return _LayerTransform.apply(pack.w_src_t, pack.bias, Z, blocks, bias_sum, out_blocks, premasked)
+    return _LayerTransform.apply(pack.w_src_t if weight is None else weight, pack.bias, Z, blocks, bias_sum, out_blocks, premasked,
+                                 gamma, stat)
+
+
+class _FoldFC(torch.autograd.Function):
+    """fold_fc_output on the HIP kernels (kgw_fold_fwd / kgw_fold_bwd): two launches instead of ~40 framework ops."""
+
+    @staticmethod
+    def forward(ctx, w_src_t, U, V, pack, tab, *fc):
+        n_mlp = len(fc) // 2
+        n, NR = w_src_t.shape[0], U.shape[0]
+        dev = U.device
+        U = U.contiguous(); V = V.contiguous()
+        Up = torch.empty_like(U); Vp = torch.empty_like(V)
+        kappa = torch.empty(NR, device=dev)
+        Wp = torch.empty_like(w_src_t)
+        gamma = torch.empty(n, KGW_C, device=dev)
+        a = _lib.KgwFoldArgs()
+        a.n, a.n_rels, a.n_mlp = n, NR, n_mlp
+        a.rel_ids_host, a.src_mlp_host, a.dst_mlp_host = tab[0].ctypes.data, tab[1].ctypes.data, tab[2].ctypes.data
+        a.w_src_t, a.U, a.V = _p(w_src_t), _p(U), _p(V)
+        for m in range(n_mlp):
+            a.fc_weight[m], a.fc_bias[m] = _p(fc[2 * m]), _p(fc[2 * m + 1])
+        a.Up, a.Vp, a.kappa, a.Wp, a.gamma = _p(Up), _p(Vp), _p(kappa), _p(Wp), _p(gamma)
+        _lib.check(_lib.lib().kgw_fold_fwd(C.byref(a), _lib.stream_ptr()), 'kgw_fold_fwd')
+        ctx.save_for_backward(w_src_t, U, V, *fc)
+        ctx.tab, ctx.n_mlp = tab, n_mlp
+        ctx.set_materialize_grads(False)
+        return Up, Vp, kappa, Wp, gamma
+
+    @staticmethod
+    def backward(ctx, dUp, dVp, dkappa, dWp, dgamma):
+        w_src_t, U, V = ctx.saved_tensors[:3]
+        fc = ctx.saved_tensors[3:]
+        tab, n_mlp = ctx.tab, ctx.n_mlp
+        n, NR = w_src_t.shape[0], U.shape[0]
+        dev = U.device
+
+        def z(g, ref_shape):
+            return g.contiguous() if g is not None else torch.zeros(ref_shape, device=dev)
+        dUp, dVp = z(dUp, U.shape), z(dVp, V.shape)
+        dkappa, dWp, dgamma = z(dkappa, (NR,)), z(dWp, w_src_t.shape), z(dgamma, (n, KGW_C))
+        dU = torch.empty_like(U); dV = torch.empty_like(V)
+        dws = torch.empty_like(w_src_t)
+        dfc = [torch.empty_like(t) for t in fc]
+        a = _lib.KgwFoldArgs()
+        a.n, a.n_rels, a.n_mlp = n, NR, n_mlp
+        a.rel_ids_host, a.src_mlp_host, a.dst_mlp_host = tab[0].ctypes.data, tab[1].ctypes.data, tab[2].ctypes.data
+        a.w_src_t, a.U, a.V = _p(w_src_t), _p(U), _p(V)
+        for m in range(n_mlp):
+            a.fc_weight[m], a.fc_bias[m] = _p(fc[2 * m]), _p(fc[2 * m + 1])
+            a.d_fc_weight[m], a.d_fc_bias[m] = _p(dfc[2 * m]), _p(dfc[2 * m + 1])
+        a.dUp, a.dVp, a.dkappa, a.dWp, a.dgamma = _p(dUp), _p(dVp), _p(dkappa), _p(dWp), _p(dgamma)
+        a.dU, a.dV, a.dws = _p(dU), _p(dV), _p(dws)
+        _lib.check(_lib.lib().kgw_fold_bwd(C.byref(a), _lib.stream_ptr()), 'kgw_fold_bwd')
+        return (dws, dU, dV, None, None) + tuple(dfc)
+
+
+def fold_fc_output_hip(pack, U, V, fc_params, tab):
+    """fold_fc_output on the HIP kernels.  ``fc_params``: [weight_0, bias_0, weight_1, bias_1, ...] = FC_output of the MLPs
+    (nn.Linear layout); ``tab`` = (rel ids, source MLP, destination MLP) of the packed relations as int32 numpy arrays."""
+    return _FoldFC.apply(pack.w_src_t, U, V, pack, tab, *fc_params)
+
+
+def fold_fc_output(pack, U, V, T3, c3, src_m, dst_m):
+    """Fold the last Linear of the feature MLPs, H = h2 T_m + c_m (FC_output, kgwas/model.py:15,21; m = the MLP of the node's
+    type), into the layer-1 relation parameters -- exact, like aggregate-then-transform: H enters GATConv (which has no
+    root term) only linearly, as the message sum_j alpha_ij H_j and through the logit projections <H_j, u_r>, <H_i, v_r>
+    (kgwas/conv.py:150-152,227-228).  With layer 1 running on h2:
+        U'_r = T_src U_r,  V'_r = T_dst V_r,  kappa_r = <c_src, U_r> + <c_dst, V_r>         (logits)
+        W'_r = T_src W_r^T (the packed [in, out] form),  gamma_r = c_src W_r^T                (transform; gamma is added
+        wherever the segment is not empty: sum_j alpha_ij = 1)
+    ``U``, ``V`` [n_rels, C] by relation id (rel_vectors); ``T3`` [n_mlp, C, C] = FC_output.weight^T, ``c3`` [n_mlp, C];
+    ``src_m`` / ``dst_m`` [n] long: MLP index of the source / destination type of every packed relation.
+    Returns (U' [n_rels,C], V' [n_rels,C], kappa [n_rels] by relation id; W' [n,C,C], gamma [n,C] by packed slot)."""
+    ids = pack.rel_ids_t
+    Ui, Vi = U[ids], V[ids]
+    Ts, Td = T3[src_m], T3[dst_m]
+    cs, cd = c3[src_m], c3[dst_m]
+    Wp = torch.bmm(Ts, pack.w_src_t)
+    Up = torch.bmm(Ts, Ui.unsqueeze(-1)).squeeze(-1)
+    Vp = torch.bmm(Td, Vi.unsqueeze(-1)).squeeze(-1)
+    kap = (cs * Ui).sum(-1) + (cd * Vi).sum(-1)
+    gam = torch.bmm(cs.unsqueeze(1), pack.w_src_t).squeeze(1)
+    NR = U.shape[0]
+    Uf = torch.zeros_like(U).index_copy(0, ids, Up)
+    Vf = torch.zeros_like(V).index_copy(0, ids, Vp)
+    kf = torch.zeros(NR, device=U.device, dtype=U.dtype).index_copy(0, ids, kap)
+    return Uf, Vf, kf, Wp, gam
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -88,6 +88,7 @@ class DeviceGraph:
         self.node_slots = self.node_base[-1]
         self.live_rel, self.live_types = sc.live_relations(num_layers, out_type)
         self.rels_by_src_t = [torch.tensor(sc.rels_by_src[t], dtype=torch.long, device=self.device) for t in range(sc.NT)]
+        self.rels_by_dst_t = [torch.tensor(sc.rels_by_dst[t], dtype=torch.long, device=self.device) for t in range(sc.NT)]
 
         g = KgwGraph()
         g.n_types, g.n_rels, g.n_layers, g.n_hops = sc.NT, sc.NR, num_layers, self.n_hops

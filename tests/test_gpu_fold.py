@@ -1,0 +1,117 @@
+"""-m gpu: FC_output folded into the layer-1 relation parameters (kgw_fold_fwd / kgw_fold_bwd, kgw_linear_splitk_ind,
+kgw_ind_colsum, the logit constant of kgw_gat_aggregate_fwd) -- the HIP kernels against the same algebra written with
+framework ops in float64 (ops.fold_fc_output + autograd), and the folded model against the unfolded one.  The folded
+model is what every other parity test (oracle, committed vectors) runs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fold_kernels_match_the_framework_formulation():
+    from kgwas_amd import ops
+    from kgwas_amd.model import RelationPack
+    g = torch.Generator().manual_seed(0)
+    NR, C = 29, 128
+    edge_types = [(f's{r % 3}', f'r{r}', f'd{(r * 2) % 3}') for r in range(NR)]
+    rel_ids = [3, 4, 5, 9, 10, 11, 12, 0, 1, 2, 20, 21, 28]
+    pack = RelationPack(edge_types, rel_ids, C).cuda()
+    n = len(rel_ids)
+    sm = np.array([r % 3 for r in rel_ids], dtype=np.int32)
+    dm = np.array([(r * 2) % 3 for r in rel_ids], dtype=np.int32)
+    tab = (np.asarray(rel_ids, dtype=np.int32), sm, dm)
+    fc = []
+    for m in range(3):
+        fc += [(torch.randn(C, C, generator=g) * 0.1).cuda().requires_grad_(True), (torch.randn(C, generator=g) * 0.1).cuda().requires_grad_(True)]
+    U = torch.randn(NR, C, generator=g).cuda().requires_grad_(True)
+    V = torch.randn(NR, C, generator=g).cuda().requires_grad_(True)
+    outs = ops.fold_fc_output_hip(pack, U, V, fc, tab)
+    # float64 twin with framework ops
+    p64 = RelationPack(edge_types, rel_ids, C).cuda().double()
+    p64.load_state_dict({k: v.double() for k, v in pack.state_dict().items()})
+    U64, V64 = U.detach().double().requires_grad_(True), V.detach().double().requires_grad_(True)
+    fc64 = [t.detach().double().requires_grad_(True) for t in fc]
+    T3 = torch.stack([fc64[2 * m].t() for m in range(3)])
+    c3 = torch.stack([fc64[2 * m + 1] for m in range(3)])
+    ref = ops.fold_fc_output(p64, U64, V64, T3, c3, torch.from_numpy(sm).long().cuda(), torch.from_numpy(dm).long().cuda())
+    names = ('U', 'V', 'kappa', 'W', 'gamma')
+    for nm, a, b in zip(names, outs, ref):
+        assert_close(a, b, 1e-5, 1e-6, f'fold fwd {nm}', rel_to_max=2e-6)
+    ws = [torch.randn(o.shape, generator=g).cuda() for o in outs]
+    sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+    sum((o * w.double()).sum() for o, w in zip(ref, ws)).backward()
+    assert_close(pack.w_src_t.grad, p64.w_src_t.grad, 1e-5, 1e-6, 'd w_src_t', rel_to_max=2e-6)
+    assert_close(U.grad, U64.grad, 1e-5, 1e-6, 'dU', rel_to_max=2e-6)
+    assert_close(V.grad, V64.grad, 1e-5, 1e-6, 'dV', rel_to_max=2e-6)
+    for m in range(3):
+        assert_close(fc[2 * m].grad, fc64[2 * m].grad, 1e-5, 1e-6, f'd FC_output.weight {m}', rel_to_max=2e-6)
+        assert_close(fc[2 * m + 1].grad, fc64[2 * m + 1].grad, 1e-5, 1e-6, f'd FC_output.bias {m}', rel_to_max=2e-6)
+    # rows of relations outside the pack are zero
+    outside = [r for r in range(NR) if r not in rel_ids]
+    assert float(outs[0][outside].abs().max()) == 0.0 and float(outs[2][outside].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('rows,R,real', [(1171, 17, None), (512, 6, None), (40, 2, None)])
+def test_transform_with_segment_constant_and_its_backward(rows, R, real):
+    from kgwas_amd import _lib
+    g = torch.Generator().manual_seed(rows)
+    C = 128
+    X = torch.randn(rows, R * C, generator=g)
+    W = torch.randn(R * C, C, generator=g) * 0.1
+    b = torch.randn(C, generator=g)
+    gamma = torch.randn(R, C, generator=g)
+    den = (torch.rand(rows * R, generator=g) > 0.3).float() * (1.0 + torch.rand(rows * R, generator=g))
+    stat = torch.stack([torch.randn(rows * R, generator=g), den], 1).contiguous()
+    L = _lib.lib()
+    Xc, Wc, bc, gc, sc = X.cuda(), W.cuda(), b.cuda(), gamma.cuda(), stat.cuda()
+    Y = torch.empty(rows, C).cuda()
+    nws = int(L.kgw_linear_splitk_workspace_floats(rows, R * C, C))
+    ws = torch.empty(nws).cuda()
+    _lib.check(L.kgw_linear_splitk_ind(Xc.data_ptr(), R * C, Wc.data_ptr(), C, bc.data_ptr(), Y.data_ptr(), C, rows, R * C, 1,
+                                       sc.data_ptr(), gc.data_ptr(), ws.data_ptr(), nws, None, None), 'splitk_ind')
+    ind = (den > 0).double().view(rows, R)
+    ref = (X.double() @ W.double() + b.double() + ind @ gamma.double()).relu()
+    assert_close(Y, ref, 1e-5, 1e-5, 'transform + segment constant', rel_to_max=2e-6)
+    dY = torch.randn(rows, C, generator=g)
+    dg = torch.empty(R, C).cuda()
+    _lib.check(L.kgw_ind_colsum(sc.data_ptr(), dY.cuda().data_ptr(), C, rows, R, dg.data_ptr(), None), 'ind_colsum')
+    assert_close(dg, ind.t() @ dY.double(), 1e-5, 1e-5, 'd gamma', rel_to_max=2e-6)
+
+
+def test_folded_model_equals_unfolded_model(small_kg):
+    """Same weights, same batch: prediction, loss and every parameter gradient of the folded path equal the unfolded
+    path's (KGW_FOLD_FC=0) to fp32 summation-order tolerance."""
+    from kgwas_amd.kgwas import KGWAS
+    from kgwas_amd.sampler import NeighborLoader
+    res = {}
+    ids = np.asarray(small_kg.train_input_nodes[1][:64])
+    for fold in ('1', '0'):
+        os.environ['KGW_FOLD_FC'] = fold
+        try:
+            run = KGWAS(small_kg, device='cuda:0', seed=3)
+            run.initialize_model()
+        finally:
+            os.environ.pop('KGW_FOLD_FC', None)
+        assert run.model.fold_fc == (fold == '1')
+        with torch.no_grad():
+            for pk in list(run.model.live_packs) + list(run.model.dead_packs):
+                pk.bias.copy_(torch.randn(pk.bias.shape, generator=torch.Generator().manual_seed(1)) * 0.1)
+        batch = next(iter(NeighborLoader(small_kg.data, [-1, -1], ('SNP', ids), batch_size=64, device='cuda:0')))
+        run.model.train()
+        loss, pred = run.model.forward_loss(batch.x_dict, batch.edge_index_dict, 64, batch.n_id('SNP'), batch.dg.y['SNP'],
+                                            run._ld_weight_vector())
+        loss.backward()
+        res[fold] = (float(loss), pred.detach().cpu(), {k: (None if v is None else v.detach().cpu())
+                                                        for k, v in run.model.named_reference_tensors(grad=True).items()})
+    assert abs(res['1'][0] - res['0'][0]) <= 1e-5 * abs(res['0'][0])
+    assert_close(res['1'][1], res['0'][1], 1e-4, 1e-5, 'pred')
+    for k, g0 in res['0'][2].items():
+        g1 = res['1'][2][k]
+        assert (g0 is None) == (g1 is None), k
+        if g0 is not None:
+            assert_close(g1, g0, 1e-4, max(1e-5, 1e-4 * float(g0.abs().max())), f'grad {k}')
