@@ -234,6 +234,12 @@ int kgw_softmax_merge(const float* parts, int32_t n_ranks, const int32_t* seg_zr
 int kgw_scatter_rows(const float* src, const int32_t* ids, int64_t n_rows, int32_t width, float* dst,
                      kgw_stream_t stream);
 
+/* out[r] = sum over the destination rows i of relation r of x[Z row of segment (i, r)] for every relation the layer
+ * computes, 0 for the others (x: one float per segment, e.g. KgwLayerArgs.da_dst).  The gradient of the per-relation
+ * logit constant (KgwLayerArgs.logit_bias) is the sum of d pre-activation over all edges of the relation = this sum of
+ * d a_dst.  One block per relation, fixed reduction tree.                                                          */
+int kgw_relation_sums(const KgwLayerArgs* args, const float* x, float* out, kgw_stream_t stream);
+
 /* Running totals over the batches of a captured training loop: stats[l] += edges aggregated by layer l+1 (l < n_layers),
  * stats[n_layers] += edges sampled, stats[n_layers+1] |= KgwBatchMeta.error.  stats: n_layers + 2 device int64.   */
 int kgw_accumulate_stats(const KgwBatchMeta* meta_dev, int32_t n_layers, int32_t n_hops, int64_t* stats,

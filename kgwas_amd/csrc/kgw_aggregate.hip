@@ -967,6 +967,40 @@ extern "C" int kgw_edge_alpha(const KgwLayerArgs* a, float* alpha_out, kgw_strea
 }
 
 
+// ---- per-relation sums of a per-segment quantity (d logit constant = column sums of d a_dst) ----------------------
+namespace {
+__global__ void __launch_bounds__(256) k_relation_sums(LayerTab T, const KgwBatchMeta* __restrict__ meta, int layer,
+                                                       const float* __restrict__ x, float* __restrict__ out) {
+    __shared__ float sm[256];
+    const int r = blockIdx.x, t = threadIdx.x;
+    float s = 0.f;
+    if (T.live[r]) {
+        const int ty = T.rel_dst_type[r];
+        const int rows = meta->n_rows[layer - 1][ty];
+        const float* p = x + T.z0[r];
+        const int st = T.zstride[r];
+        for (int i = t; i < rows; i += 256) s += p[(int64_t)i * st];
+    }
+    sm[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {            // fixed tree: deterministic
+        if (t < o) sm[t] += sm[t + o];
+        __syncthreads();
+    }
+    if (t == 0) out[r] = sm[0];
+}
+}  // namespace
+
+extern "C" int kgw_relation_sums(const KgwLayerArgs* a, const float* x, float* out, kgw_stream_t stream_) {
+    if (!a || !x || !out || !a->meta_dev) return KGW_E_NULL;
+    LayerTab T;
+    int rc = build_tab(a, &T);
+    if (rc) return rc;
+    k_relation_sums<<<T.n_rels, 256, 0, (hipStream_t)stream_>>>(T, a->meta_dev, a->layer, x, out);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
 // ---- SNP-sharded mode: merge of partial softmax states across ranks --------------------------------------------
 namespace {
 // one half-wave (32 lanes x float4) per segment

@@ -1259,29 +1259,29 @@ extern "C" int64_t kgw_linear_splitk_workspace_floats(int64_t rows, int32_t K, i
 }
 
 namespace {
-__global__ void __launch_bounds__(256) k_ind_colsum(const float* __restrict__ seg_stat, const float* __restrict__ dY, int64_t ldy,
-                                                    int64_t rows, int R, float* __restrict__ dgamma) {
-    // block = (relation slot r, group of 32 columns); thread = (row phase 0..7, column): rows ph, ph + 8, ... added in order,
-    // four independent loads in flight per thread; the eight phases are folded through LDS in phase order (deterministic)
-    __shared__ float sm[8][32];
+__global__ void __launch_bounds__(1024) k_ind_colsum(const float* __restrict__ seg_stat, const float* __restrict__ dY, int64_t ldy,
+                                                     int64_t rows, int R, float* __restrict__ dgamma) {
+    // block = (relation slot r, group of 32 columns); thread = (row phase 0..31, column): rows ph, ph + 32, ... added in
+    // order, four independent loads in flight per thread; the phases are folded through LDS in phase order (deterministic)
+    __shared__ float sm[32][32];
     const int r = blockIdx.x >> 2, c = (blockIdx.x & 3) * 32 + (threadIdx.x & 31), ph = threadIdx.x >> 5;
     float s = 0.f;
     int64_t i = ph;
-    for (; i + 24 < rows; i += 32) {
+    for (; i + 96 < rows; i += 128) {
         float d[4], v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { d[q] = seg_stat[2 * ((i + 8 * q) * R + r) + 1]; v[q] = dY[(i + 8 * q) * ldy + c]; }
+        for (int q = 0; q < 4; ++q) { d[q] = seg_stat[2 * ((i + 32 * q) * R + r) + 1]; v[q] = dY[(i + 32 * q) * ldy + c]; }
 #pragma unroll
         for (int q = 0; q < 4; ++q) s += d[q] > 0.f ? v[q] : 0.f;
     }
-    for (; i < rows; i += 8)
+    for (; i < rows; i += 32)
         if (seg_stat[2 * (i * R + r) + 1] > 0.f) s += dY[i * ldy + c];
     sm[ph][threadIdx.x & 31] = s;
     __syncthreads();
     if (ph == 0) {
         float tot = 0.f;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) tot += sm[q][threadIdx.x];
+        for (int q = 0; q < 32; ++q) tot += sm[q][threadIdx.x];
         dgamma[r * 128 + c] = tot;
     }
 }
@@ -1296,7 +1296,7 @@ extern "C" int kgw_ind_colsum(const float* seg_stat, const float* dY, int64_t ld
     if (R <= 0) return KGW_OK;
     if (!seg_stat || !dY || !dgamma) return KGW_E_NULL;
     if (rows < 0) return KGW_E_RANGE;
-    k_ind_colsum<<<4 * R, 256, 0, (hipStream_t)stream_>>>(seg_stat, dY, ldy, rows, R, dgamma);
+    k_ind_colsum<<<4 * R, 1024, 0, (hipStream_t)stream_>>>(seg_stat, dY, ldy, rows, R, dgamma);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }

@@ -52,13 +52,27 @@ struct FoldPtrs {
 
 // 32 x 32 tile of C = A B over K = 128 on one wavefront.  A(m, k) = pa[m * sam + k * sak], B(k, n) = pb[k * sbk + n * sbn]
 // for the tile's rows m = li and columns n = li; MFMA step j multiplies k = 64 lk + j (a permutation of the sum).
+// AK / BK: the operand is contiguous along k (sak / sbk == 1): the lane's 64 values come as 16 float4 loads.
+template <bool AK, bool BK>
 __device__ __forceinline__ void tile_mma(const float* __restrict__ pa, int sam, int sak, const float* __restrict__ pb, int sbk,
                                          int sbn, int li, int lk, f32x16& acc0, f32x16& acc1) {
     float a[64], b[64];
     const float* qa = pa + li * sam + 64 * lk * sak;
     const float* qb = pb + li * sbn + 64 * lk * sbk;
+    if (AK) {
 #pragma unroll
-    for (int j = 0; j < 64; ++j) { a[j] = qa[j * sak]; b[j] = qb[j * sbk]; }
+        for (int q = 0; q < 16; ++q) { const float4 v = ((const float4*)qa)[q]; a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 64; ++j) a[j] = qa[j * sak];
+    }
+    if (BK) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const float4 v = ((const float4*)qb)[q]; b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 64; ++j) b[j] = qb[j * sbk];
+    }
     __builtin_amdgcn_sched_barrier(0);            // all loads in flight before the first MFMA waits
 #pragma unroll
     for (int j = 0; j < 64; j += 2) {
@@ -90,7 +104,7 @@ __global__ void __launch_bounds__(256) k_fold_fwd(FoldTab T, FoldPtrs P) {
         f32x16 acc0, acc1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
-        tile_mma(fw + 32 * tm, 1, FC, w + 32 * tn, FC, 1, li, lk, acc0, acc1);
+        tile_mma<false, false>(fw + 32 * tm, 1, FC, w + 32 * tn, FC, 1, li, lk, acc0, acc1);
         float* out = P.Wp + (int64_t)i * FC * FC + (int64_t)(32 * tm) * FC + 32 * tn + li;
 #pragma unroll
         for (int e = 0; e < 16; ++e) out[((e & 3) + 8 * (e >> 2) + 4 * lk) * FC] = acc0[e] + acc1[e];
@@ -139,7 +153,7 @@ __global__ void __launch_bounds__(512) k_fold_bwd(FoldTab T, FoldPtrs P) {
         f32x16 acc0, acc1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
-        tile_mma(P.fcw[ms] + (int64_t)(32 * tm) * FC, FC, 1, P.dWp + (int64_t)i * FC * FC + 32 * tn, FC, 1, li, lk, acc0, acc1);
+        tile_mma<true, false>(P.fcw[ms] + (int64_t)(32 * tm) * FC, FC, 1, P.dWp + (int64_t)i * FC * FC + 32 * tn, FC, 1, li, lk, acc0, acc1);
         const float dg = P.dgamma[i * FC + 32 * tn + li];
         float* out = P.dws + (int64_t)i * FC * FC + (int64_t)(32 * tm) * FC + 32 * tn + li;
 #pragma unroll
@@ -160,8 +174,8 @@ __global__ void __launch_bounds__(512) k_fold_bwd(FoldTab T, FoldPtrs P) {
             if (T.src_m[i] != m) continue;
             if ((seen++ & 7) != wave) continue;
             // A(m = h, o) = w_i[h][o], B(o, n = k) = dW'_i[k][o]
-            tile_mma(P.w_src_t + (int64_t)i * FC * FC + (int64_t)(32 * tm) * FC, FC, 1,
-                     P.dWp + (int64_t)i * FC * FC + (int64_t)(32 * tn) * FC, 1, FC, li, lk, acc0, acc1);
+            tile_mma<true, true>(P.w_src_t + (int64_t)i * FC * FC + (int64_t)(32 * tm) * FC, FC, 1,
+                                 P.dWp + (int64_t)i * FC * FC + (int64_t)(32 * tn) * FC, 1, FC, li, lk, acc0, acc1);
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) red[wave][((e & 3) + 8 * (e >> 2) + 4 * lk) * 32 + li] = acc0[e] + acc1[e];
@@ -208,25 +222,28 @@ __global__ void __launch_bounds__(512) k_fold_bwd(FoldTab T, FoldPtrs P) {
     }
     {
         // ---- D: dfcb_m[h] = sum_{i: src_m = m} ( sum_o dgamma_i[o] w_i[h][o] + dkappa_i U_i[h] ) + sum_{i: dst_m = m} dkappa_i V_i[h]
+        // four thread groups take every fourth relation; their partial sums are added in group order
         const int m = b - nA - nB - nC;
-        if (t >= 128) return;
+        const int h = t & 127, grp = t >> 7;
         float s = 0.f;
-        for (int i = 0; i < T.n; ++i) {
+        for (int i = grp; i < T.n; i += 4) {
             const int r = T.rel_id[i];
             const float dk = P.dkappa[r];
             if (T.src_m[i] == m) {
-                const float* w = P.w_src_t + (int64_t)i * FC * FC + t * FC;
+                const float* w = P.w_src_t + (int64_t)i * FC * FC + h * FC;
                 const float* dg = P.dgamma + i * FC;
                 float q = 0.f;
                 for (int o = 0; o < FC; o += 4) {
                     const float4 w4 = *(const float4*)(w + o), g4 = *(const float4*)(dg + o);
                     q = fmaf(w4.x, g4.x, q); q = fmaf(w4.y, g4.y, q); q = fmaf(w4.z, g4.z, q); q = fmaf(w4.w, g4.w, q);
                 }
-                s += q + dk * P.U[r * FC + t];
+                s += q + dk * P.U[r * FC + h];
             }
-            if (T.dst_m[i] == m) s += dk * P.V[r * FC + t];
+            if (T.dst_m[i] == m) s += dk * P.V[r * FC + h];
         }
-        P.dfcb[m][t] = s;
+        red[0][t] = s;
+        __syncthreads();
+        if (t < 128) P.dfcb[m][t] = (red[0][t] + red[0][128 + t]) + (red[0][256 + t] + red[0][384 + t]);
     }
 }
 

@@ -232,12 +232,8 @@ class _GatAggregate(torch.autograd.Function):
         dlb = None
         if ctx.has_lbias:
             # d(constant of relation r) = sum of d pre-activation over ALL its edges = the column sums of d a_dst
-            dlb = torch.zeros(sc.NR, device=dev)
-            for t in range(NT):
-                rows, R = int(m.lay_rows[layer - 1][t]), int(sc.R_dst[t])
-                if rows and R:
-                    z0 = int(m.z_base[layer - 1][t])
-                    dlb[dg.rels_by_dst_t[t]] = da_dst[z0:z0 + rows * R].view(rows, R).sum(0)
+            dlb = torch.empty(sc.NR, device=dev)
+            _lib.check(L.kgw_relation_sums(C.byref(a), _p(da_dst), _p(dlb), _lib.stream_ptr()), 'kgw_relation_sums')
         return dH[:n_src], dU, dV, None, None, None, None, None, None, None, dlb
 
 
