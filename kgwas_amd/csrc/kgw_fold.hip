@@ -18,10 +18,11 @@
 //                blocks B [.., + 16 n_mlp):  d FC_output.weight_m = sum over the relations whose source MLP is m of
 //                                            (dW'_i W_i)^T, eight wavefronts share a tile's relations and add their
 //                                            accumulators through LDS in wavefront order, + the rank-1 terms dU'_i (x) U_i,
-//                                            dV'_i (x) V_i
+//                                            dV'_i (x) V_i; the blocks of column tile 0 also produce d FC_output.bias_m (the
+//                                            A operand w_i is already in their registers)
 //                blocks C [.., + n_rels):    dU_r = T^T dU'_r + dkappa_r c_src,  dV_r likewise   (then kgw_relvec_bwd)
-//                blocks D [.., + n_mlp):     d FC_output.bias_m
 #include "kgw_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -140,13 +141,14 @@ __global__ void __launch_bounds__(256) k_fold_fwd(FoldTab T, FoldPtrs P) {
     if (t == 0) P.kappa[r] = ksum;
 }
 
-__global__ void __launch_bounds__(512) k_fold_bwd(FoldTab T, FoldPtrs P) {
+__global__ void __launch_bounds__(512) k_fold_bwd(FoldTab T, FoldPtrs P, int parts) {
     __shared__ float red[8][32 * 32];
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5, wave = threadIdx.x >> 6;
     const int t = threadIdx.x;
     const int nA = 2 * T.n, nB = 16 * T.n_mlp, nC = T.n_rels;
     if (b < nA) {
+        if (!(parts & 1)) return;
         // ---- A: dws[i][h][o] = sum_k T[k][h] dW'[k][o] + c[h] dgamma[o];  A(m = h, k) = fcw[h][k], B(k, n = o) = dW'[k][o]
         const int i = b >> 1, tile = (b & 1) * 8 + wave, tm = tile >> 2, tn = tile & 3;
         const int ms = T.src_m[i];
@@ -164,41 +166,91 @@ __global__ void __launch_bounds__(512) k_fold_bwd(FoldTab T, FoldPtrs P) {
         return;
     }
     if (b < nA + nB) {
+        if (!(parts & 2)) return;
         // ---- B: dfcw_m[h][k] = sum_{i: src_m = m} ( sum_o w_i[h][o] dW'_i[k][o] + U_i[h] dU'_i[k] ) + sum_{i: dst_m = m} V_i[h] dV'_i[k]
+        //         (column-tile 0 also:) dfcb_m[h] = sum_{i: src_m = m} ( sum_o w_i[h][o] dgamma_i[o] + dkappa_i U_i[h] )
+        //                                          + sum_{i: dst_m = m} dkappa_i V_i[h]
         const int q = b - nA, m = q >> 4, tile = q & 15, tm = tile >> 2, tn = tile & 3;
         f32x16 acc0, acc1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+        float qb = 0.f;                                    // this lane's share of sum_o w_i[h = 32 tm + li][o] dgamma_i[o]
         int seen = 0;
         for (int i = 0; i < T.n; ++i) {                    // the m-th MLP's relations, dealt to the 8 wavefronts in order
             if (T.src_m[i] != m) continue;
             if ((seen++ & 7) != wave) continue;
-            // A(m = h, o) = w_i[h][o], B(o, n = k) = dW'_i[k][o]
-            tile_mma<true, true>(P.w_src_t + (int64_t)i * FC * FC + (int64_t)(32 * tm) * FC, FC, 1,
-                                 P.dWp + (int64_t)i * FC * FC + (int64_t)(32 * tn) * FC, 1, FC, li, lk, acc0, acc1);
+            // A(m = h, o) = w_i[h][o], B(o, n = k) = dW'_i[k][o]: both contiguous along the contraction index o
+            float av[64], bv[64];
+            const float4* qa = (const float4*)(P.w_src_t + (int64_t)i * FC * FC + (int64_t)(32 * tm + li) * FC + 64 * lk);
+            const float4* qk = (const float4*)(P.dWp + (int64_t)i * FC * FC + (int64_t)(32 * tn + li) * FC + 64 * lk);
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                const float4 v = qa[x]; av[4 * x] = v.x; av[4 * x + 1] = v.y; av[4 * x + 2] = v.z; av[4 * x + 3] = v.w;
+                const float4 u = qk[x]; bv[4 * x] = u.x; bv[4 * x + 1] = u.y; bv[4 * x + 2] = u.z; bv[4 * x + 3] = u.w;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 64; j += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j + 1], bv[j + 1], acc1, 0, 0, 0);
+            }
+            if (tn == 0) {                                 // the bias gradient reuses the A operand already in registers
+                const float4* dg = (const float4*)(P.dgamma + i * FC + 64 * lk);
+                float s = 0.f;
+#pragma unroll
+                for (int x = 0; x < 16; ++x) {
+                    const float4 g4 = dg[x];
+                    s = fmaf(av[4 * x], g4.x, s); s = fmaf(av[4 * x + 1], g4.y, s);
+                    s = fmaf(av[4 * x + 2], g4.z, s); s = fmaf(av[4 * x + 3], g4.w, s);
+                }
+                qb += s;
+            }
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) red[wave][((e & 3) + 8 * (e >> 2) + 4 * lk) * 32 + li] = acc0[e] + acc1[e];
+        __shared__ float redb[8][64];
+        redb[wave][lane] = qb;
         __syncthreads();
         const int col = t & 31;                            // k inside the tile
+        float vs[2];
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
             const int row = (t >> 5) + 16 * h2;            // h inside the tile
             float vsum = 0.f;
 #pragma unroll
             for (int w8 = 0; w8 < 8; ++w8) vsum += red[w8][row * 32 + col];
-            const int h = 32 * tm + row, k = 32 * tn + col;
-            for (int i = 0; i < T.n; ++i) {                // rank-1 terms, relation order
+            vs[h2] = vsum;
+        }
+        const int k = 32 * tn + col, h0 = 32 * tm + (t >> 5);
+#pragma unroll 4
+        for (int i = 0; i < T.n; ++i) {                    // rank-1 terms, relation order; loads unconditional (independent)
+            const int r = T.rel_id[i];
+            const float fs = T.src_m[i] == m ? 1.f : 0.f, fd = T.dst_m[i] == m ? 1.f : 0.f;
+            const float du = P.dUp[r * FC + k] * fs, dv = P.dVp[r * FC + k] * fd;
+            vs[0] = fmaf(P.U[r * FC + h0], du, vs[0]);      vs[0] = fmaf(P.V[r * FC + h0], dv, vs[0]);
+            vs[1] = fmaf(P.U[r * FC + h0 + 16], du, vs[1]); vs[1] = fmaf(P.V[r * FC + h0 + 16], dv, vs[1]);
+        }
+        P.dfcw[m][h0 * FC + k] = vs[0];
+        P.dfcw[m][(h0 + 16) * FC + k] = vs[1];
+        if (tn == 0 && t < 32) {                           // bias gradient of rows h = 32 tm + t
+            float s = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) s += redb[w8][t] + redb[w8][32 + t];      // the two k halves of every wavefront
+            const int h = 32 * tm + t;
+#pragma unroll 4
+            for (int i = 0; i < T.n; ++i) {
                 const int r = T.rel_id[i];
-                if (T.src_m[i] == m) vsum = fmaf(P.U[r * FC + h], P.dUp[r * FC + k], vsum);
-                if (T.dst_m[i] == m) vsum = fmaf(P.V[r * FC + h], P.dVp[r * FC + k], vsum);
+                const float dk = P.dkappa[r];
+                s = fmaf(P.U[r * FC + h], T.src_m[i] == m ? dk : 0.f, s);
+                s = fmaf(P.V[r * FC + h], T.dst_m[i] == m ? dk : 0.f, s);
             }
-            P.dfcw[m][h * FC + k] = vsum;
+            P.dfcb[m][h] = s;
         }
         return;
     }
-    if (b < nA + nB + nC) {
+    {
         // ---- C: dU[r][c] = sum_k T[k][c] dU'[r][k] + dkappa_r c_src[c]   (fcw[c][k]: thread c reads its own row)
+        if (!(parts & 4)) return;
         const int r = b - nA - nB;
         const int i = T.live_of[r];
         if (t >= 128) return;
@@ -218,32 +270,6 @@ __global__ void __launch_bounds__(512) k_fold_bwd(FoldTab T, FoldPtrs P) {
         const float dk = P.dkappa[r];
         P.dU[r * FC + t] = su + dk * P.fcb[ms][t];
         P.dV[r * FC + t] = sv + dk * P.fcb[md][t];
-        return;
-    }
-    {
-        // ---- D: dfcb_m[h] = sum_{i: src_m = m} ( sum_o dgamma_i[o] w_i[h][o] + dkappa_i U_i[h] ) + sum_{i: dst_m = m} dkappa_i V_i[h]
-        // four thread groups take every fourth relation; their partial sums are added in group order
-        const int m = b - nA - nB - nC;
-        const int h = t & 127, grp = t >> 7;
-        float s = 0.f;
-        for (int i = grp; i < T.n; i += 4) {
-            const int r = T.rel_id[i];
-            const float dk = P.dkappa[r];
-            if (T.src_m[i] == m) {
-                const float* w = P.w_src_t + (int64_t)i * FC * FC + h * FC;
-                const float* dg = P.dgamma + i * FC;
-                float q = 0.f;
-                for (int o = 0; o < FC; o += 4) {
-                    const float4 w4 = *(const float4*)(w + o), g4 = *(const float4*)(dg + o);
-                    q = fmaf(w4.x, g4.x, q); q = fmaf(w4.y, g4.y, q); q = fmaf(w4.z, g4.z, q); q = fmaf(w4.w, g4.w, q);
-                }
-                s += q + dk * P.U[r * FC + h];
-            }
-            if (T.dst_m[i] == m) s += dk * P.V[r * FC + h];
-        }
-        red[0][t] = s;
-        __syncthreads();
-        if (t < 128) P.dfcb[m][t] = (red[0][t] + red[0][128 + t]) + (red[0][256 + t] + red[0][384 + t]);
     }
 }
 
@@ -290,7 +316,8 @@ extern "C" int kgw_fold_bwd(const KgwFoldArgs* a, kgw_stream_t stream_) {
     if (!P.dUp || !P.dVp || !P.dkappa || !P.dWp || !P.dgamma || !P.dU || !P.dV || !P.dws) return KGW_E_NULL;
     for (int m = 0; m < T.n_mlp; ++m)
         if (!P.dfcw[m] || !P.dfcb[m]) return KGW_E_NULL;
-    k_fold_bwd<<<2 * T.n + 16 * T.n_mlp + T.n_rels + T.n_mlp, 512, 0, (hipStream_t)stream_>>>(T, P);
+    static const int parts = getenv("KGW_FOLD_PARTS") ? atoi(getenv("KGW_FOLD_PARTS")) : 15;   // (timing experiments only)
+    k_fold_bwd<<<2 * T.n + 16 * T.n_mlp + T.n_rels, 512, 0, (hipStream_t)stream_>>>(T, P, parts);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }
