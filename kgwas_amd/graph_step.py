@@ -11,6 +11,7 @@ parameter gradients equal the eager path's (tests/test_gpu_graph.py).
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -59,6 +60,16 @@ class GraphTrainStep:
             pass
         if self.world > 1:
             self.capture_optimizer = False       # gradients are all-reduced between backward and Adam
+        # multi-rank: the backward pass is captured in TWO graphs, cut at the feature MLPs' outputs.  The gradients of the
+        # first half (every relation pack, the read-out, the folded FC_output: ~3.9 MB) are all-reduced on a side stream
+        # while the second half (the MLPs' backward: ~45 % of the backward's time, incl. the 5120-wide gene dW product)
+        # runs; only the MLPs' own bucket (~2.7 MB) is reduced in the open.
+        self.split_backward = self.world > 1 and os.environ.get('KGW_SPLIT_BACKWARD', '1') == '1'
+        self._comm = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        self._ev_a, self._ev_ca = torch.cuda.Event(), torch.cuda.Event()
+        self._flat_a = self._flat_b = None
+        self._cut = [None, None]
+        self.graphs_b = [None, None]
         from .optim import FusedAdam
         self.opt = FusedAdam(self.model.parameters(), lr=lr, weight_decay=weight_decay)   # one launch, capturable
         # device-side statistics accumulated inside the graph: [edges layer 1..L, sampled edges, error mask]
@@ -68,7 +79,6 @@ class GraphTrainStep:
         self._flat = None                         # multi-rank: gradient bucket + {param: view}
         self._flat_grads = None
         self.graphs = [None, None]
-        import os
         if overlap_sampling is None:
             overlap_sampling = os.environ.get('KGW_OVERLAP_SAMPLING', '2')
         # '2' (default): the next batch is sampled by a graph of its own, replayed on a side stream while the step's
@@ -95,11 +105,31 @@ class GraphTrainStep:
         buf = self.bufs[cur]
         batch = SampledBatch(self.dg, buf, self.meta, self.input_type, bs, static=True)
         self.opt.zero_grad(set_to_none=True)
-        loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id(self.input_type),
-                                          self.dg.y[self.input_type], self.ld_w)          # kgwas.py:137-145
-        loss.backward(gradient=self._unit)                             # (a resident 1.0: no ones_like fill per step)
+        if self.split_backward:
+            mlp_out = []
+            loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id(self.input_type),
+                                              self.dg.y[self.input_type], self.ld_w, mlp_out=mlp_out)
+            hs = [h for h in mlp_out if h.requires_grad]
+            late = self._late_params()
+            early = [p for p in self.model.parameters() if p.requires_grad and id(p) not in late]
+            g = torch.autograd.grad(loss, hs + early, grad_outputs=self._unit, allow_unused=True)
+            live = [(p, gi) for p, gi in zip(early, g[len(hs):]) if gi is not None]
+            if self._flat_a is None:
+                self._flat_a = torch.empty(sum(p.numel() for p, _ in live), device=self.seeds.device)
+                self._flat_grads, off = {}, 0
+                for p, _ in live:
+                    self._flat_grads[p] = self._flat_a[off:off + p.numel()].view_as(p)
+                    off += p.numel()
+            torch.cat([gi.reshape(-1) for _, gi in live], out=self._flat_a)
+            self._cut[cur] = (hs, list(g[:len(hs)]))
+        else:
+            loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id(self.input_type),
+                                              self.dg.y[self.input_type], self.ld_w)          # kgwas.py:137-145
+            loss.backward(gradient=self._unit)                         # (a resident 1.0: no ones_like fill per step)
         if self.capture_optimizer:
             self.opt.step()
+        elif self.split_backward:
+            pass                                                       # (second half: _step_body_b)
         elif self.world > 1:
             # gradients of all live tensors into ONE persistent bucket (the all-reduce and Adam run on it after the replay)
             live = [p for p in self.model.parameters() if p.grad is not None]
@@ -118,6 +148,32 @@ class GraphTrainStep:
             sample_into(self.dg, self.bufs[1 - cur], self.seeds, self.seed_type, record=False)
         return loss
 
+    def _late_params(self):
+        """ids of the parameters whose gradients come out of the SECOND half of the split backward: the feature MLPs'
+        Linears that sit before the cut (FC_output too unless it is folded into layer 1)."""
+        m = self.model
+        late = set()
+        for mlp in (m.snp_feat_mlp, m.gene_feat_mlp, m.go_feat_mlp):
+            mods = [mlp.FC_hidden, mlp.FC_hidden2] + ([] if getattr(m, 'fold_fc', False) else [mlp.FC_output])
+            for mod in mods:
+                late.update(id(p) for p in mod.parameters())
+        return late
+
+    def _step_body_b(self, cur: int):
+        """Second half of the split backward: from the feature MLPs' outputs down to their weights."""
+        hs, dhs = self._cut[cur]
+        keep = [(h, d) for h, d in zip(hs, dhs) if d is not None]
+        torch.autograd.backward([h for h, _ in keep], grad_tensors=[d for _, d in keep])
+        late = self._late_params()
+        live = [p for p in self.model.parameters() if id(p) in late and p.grad is not None]
+        if self._flat_b is None:
+            self._flat_b = torch.empty(sum(p.numel() for p in live), device=self.seeds.device)
+            off = 0
+            for p in live:
+                self._flat_grads[p] = self._flat_b[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        torch.cat([p.grad.reshape(-1) for p in live], out=self._flat_b)
+
     def _sample_now(self, which: int, i: int):
         b = self.batch_size
         self.seeds.copy_(self.ids[i * b:(i + 1) * b])
@@ -134,6 +190,8 @@ class GraphTrainStep:
             self._sample_now(0, 0)
             for k in range(4):
                 self._step_body(k % 2)
+                if self.split_backward:
+                    self._step_body_b(k % 2)
                 if self.twin:
                     self._sample_now(1 - k % 2, 0)
         torch.cuda.current_stream().wait_stream(s)
@@ -157,6 +215,11 @@ class GraphTrainStep:
             with torch.cuda.graph(g):
                 self.loss[cur] = self._step_body(cur)
             self.graphs[cur] = g
+            if self.split_backward:
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, pool=g.pool()):
+                    self._step_body_b(cur)
+                self.graphs_b[cur] = gb
             if self.twin:
                 gs = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gs, stream=self._side):
@@ -190,7 +253,19 @@ class GraphTrainStep:
         self._have[1 - cur] = nxt
         self._have[cur] = -1
         if not self.capture_optimizer:
-            if self.world > 1:
+            if self.split_backward:
+                from . import dist as kdist
+                main = torch.cuda.current_stream()
+                self._ev_a.record(main)
+                with torch.cuda.stream(self._comm):                   # first bucket: reduced while the MLPs' backward runs
+                    self._comm.wait_event(self._ev_a)
+                    kdist.allreduce_flat(self._flat_a, self.world)
+                    self._ev_ca.record(self._comm)
+                self.graphs_b[cur].replay()
+                kdist.allreduce_flat(self._flat_b, self.world)        # second bucket: the MLPs' own gradients
+                main.wait_event(self._ev_ca)
+                self.opt.step(self._flat_grads)
+            elif self.world > 1:
                 from . import dist as kdist
                 kdist.allreduce_flat(self._flat, self.world)          # one RCCL collective over the bucket
                 self.opt.step(self._flat_grads)
@@ -199,6 +274,10 @@ class GraphTrainStep:
         return self.loss[cur]
 
     def describe(self) -> str:
+        if self.split_backward:
+            return ('HIP graphs: forward + first half of the backward | second half (feature MLPs); the first half\'s gradient bucket '
+                    'is all-reduced (RCCL) on a side stream under the second graph, the MLPs\' bucket after it, then one Adam launch' +
+                    ('; next batch sampled by a third graph on a side stream' if self.twin else ''))
         return ('HIP graphs: step graph (fwd + bwd' + (' + Adam)' if self.capture_optimizer else '), RCCL all-reduce + Adam eager') +
                 (' with the next batch sampled by a second graph on a side stream' if self.twin else ', sampling inside it'))
 
