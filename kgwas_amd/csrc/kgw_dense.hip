@@ -190,6 +190,30 @@ __global__ void __launch_bounds__(256, 1) k_tn_gemm(TnJobs J) {
             }
     }
     __syncthreads();
+    if (nbx == 1) {
+        // few rows (the layer transforms' weight gradients: ~1 k destination rows): ONE row block per tile, so the block's
+        // sum is the result -- written straight to C (and the column sums), no partial buffer, no second launch
+        float* __restrict__ Cq = T.C;
+        for (int f = threadIdx.x * 4; f < FRAG; f += 256 * 4) {
+            const float4 x = *(const float4*)(reg0 + f), y = *(const float4*)(reg1 + f);
+            const float v[4] = {x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w};
+            const int e = (f >> 6) & 15, tb = (f >> 10) % NT, ta = (f >> 10) / NT;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ln = (f & 63) + q;
+                const int ti = (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5), tj = ln & 31;
+                const int m = m0 + MT * ti + ta, n = n0 + NT * tj + tb;
+                if (m < M && n < N) Cq[(int64_t)m * T.c_rs + (int64_t)n * T.c_cs] = v[q];
+            }
+        }
+        if (T.colsum && blockIdx.z == 0 && threadIdx.x < 32 * MT) {
+            const int c = threadIdx.x;
+            const float t = (cs[c] + cs[2 * 32 * MT + c]) + (cs[32 * MT + c] + cs[3 * 32 * MT + c]);
+            if (m0 + c < M)
+                for (int q = 0; q < T.cs_rep; ++q) T.colsum[(int64_t)q * T.cs_ld + m0 + c] = t;
+        }
+        return;
+    }
     const int64_t blk = ((int64_t)blockIdx.z * T.gy + blockIdx.y) * nbx + bx;
     float* out = ws + blk * FRAG;
     for (int f = threadIdx.x * 4; f < FRAG; f += 256 * 4) {
@@ -212,6 +236,7 @@ __global__ void __launch_bounds__(256) k_tn_reduce(TnJobs J, int gz_max) {
     const TnJob& T = J.j[blockIdx.z / gz_max];
     const int by = blockIdx.y, bz = blockIdx.z % gz_max;
     if (by >= T.gy || bz >= T.gz) return;
+    if (T.nblk == 1) return;                 // single row block: k_tn_gemm wrote C and the column sums itself
     const float* __restrict__ ws = T.ws;
     const float* __restrict__ ws_colsum = T.ws_cs;
     const int nblk = T.nblk, gy = T.gy, M = T.M, N = T.N, cs_rep = T.cs_rep;
@@ -276,6 +301,7 @@ int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st) {
     TnJobs J{};
     J.n = n;
     int blk = 0, gy_max = 0, gz_max = 0;
+    bool all_direct = true;
     for (int q = 0; q < n; ++q) {
         const TnDesc& D = d[q];
         TnJob& T = J.j[q];
@@ -286,6 +312,12 @@ int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st) {
         if (cap < 1) cap = 1;
         if (nblk > cap) nblk = cap;
         if (nblk < 1) nblk = 1;
+        // (forcing ONE row block for up to ~2 k rows to save the second launch was measured and lost: the step went
+        // 1.491 -> 1.501 ms at 640 rows, 1.513 at 2048 -- the serial row loop costs more than the launch; a product that has
+        // a single row block anyway writes its result directly)
+        static const int64_t direct_max = getenv("KGW_TN_DIRECT_ROWS") ? atoll(getenv("KGW_TN_DIRECT_ROWS")) : 0;
+        if (D.rows <= direct_max && (int64_t)gy * gz >= 16) nblk = 1;
+        all_direct = all_direct && nblk == 1;
         int64_t rpw = (D.rows + nblk * 4 - 1) / (nblk * 4);
         rpw = (rpw + 1) & ~(int64_t)1;
         const int64_t need = nblk * gy * gz * FRAG + nblk * gy * 32 * MT;
@@ -309,6 +341,7 @@ int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st) {
     }
     kern<<<dim3((unsigned)blk, gy_max, gz_max), 256, lds_bytes, st>>>(J);
     KGW_LAUNCH_CHECK();
+    if (all_direct) return KGW_OK;                     // every product wrote its result itself
     k_tn_reduce<MT, NT><<<dim3(FRAG / 64, gy_max, gz_max * n), 256, 0, st>>>(J, gz_max);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
