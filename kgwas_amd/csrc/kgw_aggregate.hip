@@ -319,7 +319,24 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_fwd_combine(LayerTab T, AggPtrs
         const float M = wave_allmax(mx);
         float S = 0.f;
         float2 acc = make_float2(0.f, 0.f);
-        for (int c = 0; c < nch; ++c) {
+        int c = 0;
+        for (; c + 4 <= nch; c += 4) {               // four partial records in flight (the loads are independent)
+            const float* pr = P.part + (int64_t)(first + c) * PART_STRIDE;
+            float mq[4], sq[4];
+            float2 aq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                mq[q] = pr[q * PART_STRIDE]; sq[q] = pr[q * PART_STRIDE + 1];
+                aq[q] = ((const float2*)(pr + q * PART_STRIDE + 4))[lane];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {              // (same order as the plain loop: chunk order)
+                const float f = __expf(mq[q] - M);
+                S = fmaf(sq[q], f, S);
+                acc.x = fmaf(aq[q].x, f, acc.x); acc.y = fmaf(aq[q].y, f, acc.y);
+            }
+        }
+        for (; c < nch; ++c) {
             const float* pr = P.part + (int64_t)(first + c) * PART_STRIDE;
             const float f = __expf(pr[0] - M);
             S = fmaf(pr[1], f, S);
