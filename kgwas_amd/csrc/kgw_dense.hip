@@ -1252,6 +1252,80 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 }
 
+// Forward transform in ONE launch (K = R * 128 > 128, N == 128, packed [K, N] weights): a block of EIGHT wavefronts owns a
+// (32-row, 32-column) output tile; wavefront w multiplies the K slabs (= relations) w, w + 8, ... into its own accumulator --
+// the slab's X tile goes through a wavefront-private LDS buffer (coalesced 512-byte row reads, then the per-row operand
+// reads of the MFMA layout; no block barrier: a wavefront's LDS operations execute in order), the weights come straight
+// from global memory (coalesced) -- and the eight accumulators are added through LDS in wavefront order, with bias, the
+// per-segment constants of a folded FC_output and ReLU applied on the way out.  No partial buffer, no second launch.
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_linear_splitk_fused(SplitKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lk = lane >> 5, w = tid >> 6;
+    const int rt = blockIdx.x % a.RT, cb = blockIdx.x / a.RT;
+    const int64_t rows_eff = sk_rows_eff(a);
+    const int64_t r0 = (int64_t)rt * 32;
+    float* my = lds + w * (32 * SK_LD);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    if (r0 < rows_eff) {
+        for (int ks = w; ks < a.KS; ks += 8) {
+            float4 xr[16];
+            float bw[64];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t r = r0 + 2 * q + lk;
+                const bool ok = r < rows_eff;
+                const float4 v = *(const float4*)(a.X + (ok ? r : r0) * a.ldx + ks * 128 + 4 * li);
+                xr[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            const float* pw = a.W + (int64_t)(ks * 128 + 64 * lk) * a.ldw + cb * 32 + li;
+#pragma unroll
+            for (int j = 0; j < 64; ++j) bw[j] = pw[(int64_t)j * a.ldw];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) *(float4*)(&my[(2 * q + lk) * SK_LD + 4 * li]) = xr[q];
+            float xa[64];
+            const float4* px = (const float4*)(&my[li * SK_LD + 64 * lk]);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float4 v = px[q];
+                xa[4 * q] = v.x; xa[4 * q + 1] = v.y; xa[4 * q + 2] = v.z; xa[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 64; j += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j], bw[j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j + 1], bw[j + 1], acc1, 0, 0, 0);
+            }
+        }
+    }
+    // each wavefront's 32 x 32 partial into the head of its own buffer, then the sum in wavefront order
+#pragma unroll
+    for (int e = 0; e < 16; ++e) my[((e & 3) + 8 * (e >> 2) + 4 * lk) * 32 + li] = acc0[e] + acc1[e];
+    __syncthreads();
+    const int col = cb * 32 + (tid & 31);
+    const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = (tid >> 5) + 16 * h;
+        const int64_t r = r0 + row;
+        if (r >= a.rows) continue;
+        float v = 0.f;
+        if (r < rows_eff) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v += lds[q * (32 * SK_LD) + row * 32 + (tid & 31)];
+            v += bv;
+            if (a.seg_stat) {
+                const float* st = a.seg_stat + 2 * r * a.KS + 1;
+                for (int ks = 0; ks < a.KS; ++ks)
+                    if (st[2 * ks] > 0.f) v += a.gamma[ks * 128 + col];
+            }
+            if (a.relu) v = fmaxf(v, 0.f);
+        }
+        a.Y[r * a.ldy + col] = v;
+    }
+}
+
 // K-split: Y = act(sum over slabs of ws + bias); always: rows beyond the batch's own count (static capacity) get zeros
 __global__ void __launch_bounds__(256) k_linear_splitk_finish(SplitKArgs a) {
     const int64_t rows_eff = sk_rows_eff(a);
@@ -1365,6 +1439,18 @@ int splitk_launch(const float* X, int64_t ldx, const float* W, int64_t ldw, cons
     SplitKArgs a{X, ldx, W, ldw, bias, Y, ldy, workspace, rows, K, N, relu, w_is_kn, (int)((rows + 31) / 32),
                  K / 128, N / 128, 1, rows_dev, seg_stat, gamma};
     const int nslab = a.KS > 1 ? a.KS : a.NS;
+    static const int fused = getenv("KGW_SPLITK_FUSED") ? atoi(getenv("KGW_SPLITK_FUSED")) : 1;
+    if (fused && a.KS > 1 && w_is_kn && N == 128) {        // forward transform: one launch
+        const size_t lds_bytes = (size_t)8 * 32 * SK_LD * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            KGW_HIP(hipFuncSetAttribute((const void*)k_linear_splitk_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            attr_set = true;
+        }
+        k_linear_splitk_fused<<<a.RT * 4, 512, lds_bytes, (hipStream_t)stream_>>>(a);
+        KGW_LAUNCH_CHECK();
+        return KGW_OK;
+    }
     if (a.KS > 1 && (!workspace || workspace_floats < kgw_linear_splitk_workspace_floats(rows, K, N))) return KGW_E_NULL;
     // row-tile groups per slab: about two blocks per CU in total, at most one tile... at least one tile per block
     static const int target = getenv("KGW_SPLITK_BLOCKS") ? atoi(getenv("KGW_SPLITK_BLOCKS")) : 512;

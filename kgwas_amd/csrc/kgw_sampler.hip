@@ -613,7 +613,15 @@ extern "C" int kgw_sample_batch_parts(const KgwGraph* graph, const KgwBatchBuf* 
     for (int l = 1; l <= graph->n_layers; ++l) {
         if (!buf->t_cnt[l - 1] || !buf->t_ptr[l - 1] || !buf->t_edge[l - 1] || !buf->t_zrow[l - 1] || !buf->t_tmp)
             return KGW_E_NULL;
-        { int rc = fill_i32(buf->t_cnt[l - 1], 0, buf->trow_cap + 1, st, SG); if (rc) return rc; }
+        // histogram of the src-major rows: only the rows the layer can have need clearing -- with a static layout that is the
+        // capacity of its source blocks (~1.1 M of the 5 M rows the whole graph would need: 16 MB less to write per layer)
+        int64_t trows = buf->trow_cap;
+        if (graph->static_layout) {
+            int64_t tb = 0;
+            for (int t = 0; t < graph->n_types; ++t) tb += (int64_t)graph->cap_src[l - 1][t] * graph->R_src[t];
+            if (tb < trows) trows = tb;
+        }
+        { int rc = fill_i32(buf->t_cnt[l - 1], 0, trows + 1, st, SG); if (rc) return rc; }
         k_t_begin<<<1, 64, 0, st>>>(A, l);
         k_t_pass<false><<<SG, KGW_BLK, 0, st>>>(A, l);
         k_scan_tiles<1><<<SG, KGW_BLK, 0, st>>>(buf->t_cnt[l - 1], nullptr, buf->meta, buf->scan_tmp);

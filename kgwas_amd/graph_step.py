@@ -91,6 +91,8 @@ class GraphTrainStep:
         self._sampled = [torch.cuda.Event(), torch.cuda.Event()]
         self._side = torch.cuda.Stream(device=dev)
         self._have = [-1, -1]                      # batch index currently sampled into each buffer
+        # (timing experiments only: train on stale batches to see what the concurrent sampler costs the step)
+        self._skip_resample = os.environ.get('KGW_SKIP_RESAMPLE', '0') == '1'
         self._twin_pending = [False, False]        # the side stream holds an unfinished sample of this buffer
         self._capture()
 
@@ -240,7 +242,8 @@ class GraphTrainStep:
             self._side.wait_stream(main)          # the previous step (reader of bufs[1 - cur], writer of nothing here) is done
             with torch.cuda.stream(self._side):
                 self.seeds.copy_(self.ids[nxt * b:(nxt + 1) * b])
-                self.sample_graphs[1 - cur].replay()
+                if not self._skip_resample:
+                    self.sample_graphs[1 - cur].replay()
                 self._sampled[1 - cur].record(self._side)
             if self._twin_pending[cur]:
                 main.wait_event(self._sampled[cur])
