@@ -12,11 +12,21 @@ on (configs[1]): SynthKG-fast (784 256 SNPs / 20 032 genes / ~20.6 M directed ed
 in HBM before the timed region starts.
 
 Metric: edges aggregated per second = sum over timed steps, layers and live relations of the edges the
-aggregate kernels actually gather, over wall time (max over ranks); N > 1 is weak scaling (every rank
-trains on its own 512-seed batches, one flat gradient all-reduce per step over RCCL).
-Extra keys: ``roofline`` (layer-1 forward aggregate kernel: algorithmic bytes / HIP-event time vs the
-8 TB/s HBM peak), ``cpu_baseline`` (the CPU oracle = op-for-op PyG restatement, timed on this box's host
-cores on a bounded sample of the same batches), ``breakdown`` (per-kernel event times).
+aggregate kernels actually gather, over wall time (max over ranks).  N > 1: --scaling weak (default: every
+rank trains on its own 512-seed batches) or strong (one 512-seed batch per step split over the ranks, what
+KGWAS.train does); --parallelism seed (default: graph replicated, gradient buckets all-reduced over RCCL,
+the first one under the second half of the backward) or shard (SNP rows sharded, partial-softmax exchange).
+
+Extra keys, all measured by this run:
+  roofline     layer-1 forward aggregate kernel: HIP-event time of the launch; L2-side traffic of the same
+               launch shape from three `rocprofv3 --pmc` passes this script starts over tools/pmc_probe.py
+               (FETCH_SIZE / WRITE_SIZE / TCC hit-miss + MFMA counters; calibrated in the pass on a 1 GiB
+               gather of known byte count); frac = traffic / time / 8 TB/s; compulsory and algorithmic
+               bytes; the same at a batch whose working set exceeds the Infinity Cache; MFMA pipe occupancy
+               of the dense kernels
+  cpu_baseline the CPU oracle (op-for-op PyG restatement) on this box's host cores, 20 steps after 3 warm-ups
+  breakdown    per-kernel event times of the three aggregate kernels
+  config.epoch_measured   one whole epoch (956 steps + validation pass), wall clock
 """
 import argparse
 import json
