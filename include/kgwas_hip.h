@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define KGW_VERSION      110          /* 0.1.1 */
+#define KGW_VERSION      111          /* 0.1.1 */
 #define KGW_MAX_TYPES    8
 #define KGW_MAX_RELS     64
 #define KGW_MAX_LAYERS   4
@@ -65,7 +65,9 @@ typedef struct KgwGraph {
     int32_t static_layout;
     int32_t cap_rows[KGW_MAX_LAYERS][KGW_MAX_TYPES];  /* destination rows of type T in layer l        */
     int32_t cap_src[KGW_MAX_LAYERS][KGW_MAX_TYPES];   /* source rows of type T in layer l             */
-    int32_t pad0_;
+    uint32_t short_types;                 /* bit T: nodes of type T have few out-edges (mean <= 4): kgw_sample_batch marks the
+                                             groups of 8 consecutive source rows of such a type that the backward can process
+                                             8 lanes per row (KgwLayerArgs.oct_flags); a scheduling hint, never a correctness one */
     const int32_t* g_rowptr;              /* per relation N_dst+1 entries, relative to col_off */
     const int32_t* g_col;                 /* global source ids                                */
 } KgwGraph;
@@ -120,8 +122,9 @@ typedef struct KgwBatchBuf {
     int32_t* t_ptr[KGW_MAX_LAYERS];   /* [trow_cap + 1] src-major row pointers                 */
     int32_t* t_edge[KGW_MAX_LAYERS];  /* [edge_cap] local edge id of each entry                */
     int32_t* t_zrow[KGW_MAX_LAYERS];  /* [edge_cap] Z row (dst row * R_dst + slot) of the entry */
+    uint8_t* t_rel[KGW_MAX_LAYERS];   /* [edge_cap] relation id of the entry (optional: NULL = not written)  */
     int32_t* scan_tmp;     /* [2 * (max(seg_cap, node_cap, trow_cap) / KGW_TILE + 2)]          */
-    int32_t* t_tmp;        /* [4 * edge_cap], 16-B aligned: unsorted (edge, Z row, src-major row, 0) entries: the atomic cursor
+    int32_t* t_tmp;        /* [4 * edge_cap], 16-B aligned: unsorted (edge, Z row, src-major row, relation) entries: the atomic cursor
                               fill lands here, a rank pass writes them in ascending edge order         */
     KgwBatchMeta* meta;    /* device                                                           */
     KgwBatchMeta* meta_host; /* pinned host mirror (async D2H at the end of sampling)          */
@@ -184,6 +187,13 @@ typedef struct KgwLayerArgs {
                                       states -- Z = sum_j exp(e_ij - m) h_j (not divided), stat = (m, sum_j exp(e_ij - m)) --
                                       for the caller to merge across GPUs (SNP-sharded mode: a rank holds only its own SNP
                                       sources of a SNP->Gene relation; kgw_softmax_merge) before anything reads them   */
+    const uint8_t* t_rel;          /* optional (NULL = off), backward src pass: relation id of every src-major entry
+                                      (KgwBatchBuf.t_rel) and                                                              */
+    const int32_t* oct_flags;      /* one flag per group of 8 consecutive source rows (row index / 8; KgwBatchBuf.t_cnt[layer-1]
+                                      after kgw_sample_batch): != 0 => the eight rows are real rows of one node type of
+                                      KgwGraph.short_types, none of them a destination row of the layer, each with at most 8
+                                      entries.  Such a group is processed by ONE wavefront, 8 lanes per row, without the per-row
+                                      slot bookkeeping of the general path (the SNP rows: ~2 entries, two thirds of all rows)   */
 } KgwLayerArgs;
 
 /* ---- entry points ------------------------------------------------------------------------ */

@@ -34,7 +34,7 @@ class KgwGraph(C.Structure):
         ('static_layout', C.c_int32),
         ('cap_rows', (C.c_int32 * KGW_MAX_TYPES) * KGW_MAX_LAYERS),
         ('cap_src', (C.c_int32 * KGW_MAX_TYPES) * KGW_MAX_LAYERS),
-        ('pad0_', C.c_int32),
+        ('short_types', C.c_uint32),
         ('g_rowptr', C.c_void_p),
         ('g_col', C.c_void_p),
     ]
@@ -77,6 +77,7 @@ class KgwBatchBuf(C.Structure):
         ('chunks', C.c_void_p), ('multi', C.c_void_p),
         ('t_cnt', C.c_void_p * KGW_MAX_LAYERS), ('t_ptr', C.c_void_p * KGW_MAX_LAYERS),
         ('t_edge', C.c_void_p * KGW_MAX_LAYERS), ('t_zrow', C.c_void_p * KGW_MAX_LAYERS),
+        ('t_rel', C.c_void_p * KGW_MAX_LAYERS),
         ('scan_tmp', C.c_void_p), ('t_tmp', C.c_void_p), ('meta', C.c_void_p), ('meta_host', C.c_void_p),
         ('seg_cap', C.c_int64), ('edge_cap', C.c_int64), ('chunk_cap', C.c_int64),
         ('multi_cap', C.c_int64), ('trow_cap', C.c_int64), ('scan_cap', C.c_int64),
@@ -96,6 +97,7 @@ class KgwLayerArgs(C.Structure):
         ('t_ptr', C.c_void_p), ('t_edge', C.c_void_p), ('t_zrow', C.c_void_p),
         ('dH', C.c_void_p), ('ev_before', C.c_void_p), ('ev_after', C.c_void_p), ('da_src', C.c_void_p),
         ('logit_bias', C.c_void_p), ('chunk_perm', C.c_void_p), ('chunk_perm_len', C.c_void_p), ('partial_rels', C.c_uint64),
+        ('t_rel', C.c_void_p), ('oct_flags', C.c_void_p),
     ]
 
 

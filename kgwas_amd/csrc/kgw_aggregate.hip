@@ -52,6 +52,7 @@ struct LayerTab {
     int32_t type_z_base[KGW_MAX_TYPES];
     int32_t type_R_dst[KGW_MAX_TYPES];
     uint64_t partial;                                       // bit r: relation r leaves PARTIAL softmax states (sharded mode)
+    int32_t oct_rows;                                       // rows [0, oct_rows) (a multiple of 8): node types of the short-row hint
 };
 
 struct AggPtrs {
@@ -73,6 +74,8 @@ struct AggPtrs {
     const int32_t* t_ptr;
     const int32_t* t_edge;
     const int32_t* t_zrow;
+    const uint8_t* t_rel;         // relation id per src-major entry (nullable: no octet path)
+    const int32_t* oct_flags;     // per 8 source rows: processed by the octet path
     float* dH;
     float* da_src;
     const int32_t* multi;
@@ -794,20 +797,129 @@ __device__ __forceinline__ bool bwd_src_row_pair(const LayerTab& T, const AggPtr
     return true;
 }
 
+// Eight consecutive source rows of one node type per wavefront, 8 lanes per row -- the rows of a type whose nodes have a
+// handful of entries (the SNPs of the benchmark graph: ~2; two thirds of all rows).  The pair path above spends a
+// wavefront-iteration -- row pointers, ballots, the per-slot LDS pass, ~340 VALU instructions -- on two such rows.  Here
+// lane e of a row's group owns entry e (at most 8) and float4s e, e+8, e+16, e+24 of the 128-float row; the relation of
+// an entry comes from the sampler (t_rel), so d a_src is "column rel(e) += d pre-activation(e)" and the term through
+// a_src is sum_e dpre_e u_rel(e), entry by entry.  Which octets qualify is decided by the sampler (oct_flags: eight real rows
+// of one short-row type, no destination row -- the seeds have a d a_dst term --, at most 8 entries each).
+__device__ __forceinline__ void bwd_src_octet(const LayerTab& T, const AggPtrs& P, int u0) {
+    const int lane = kgw_lane(), g = lane >> 3, gl = lane & 7, gb = g << 3;
+    int ty = 0;
+    while (ty + 1 < T.n_types && u0 >= T.type_src_base[ty + 1]) ++ty;
+    const int Rs = T.type_R_src[ty];
+    const int tb = T.type_t_base[ty] + (u0 - T.type_src_base[ty]) * Rs;
+    const int pv = (lane <= 8) ? P.t_ptr[tb + lane * Rs] : 0;
+    const int p0 = __shfl(pv, g, 64), n = __shfl(pv, g + 1, 64) - p0;
+    const int u = u0 + g;
+    const float4* dZ4 = (const float4*)P.dZ;
+    const float4* U4 = (const float4*)P.U;
+    int tz = 0, tr = 0;
+    float2 a2 = make_float2(0.f, 0.f);
+    if (gl < n) {
+        const int te = P.t_edge[p0 + gl];
+        tz = P.t_zrow[p0 + gl];
+        tr = P.t_rel[p0 + gl];
+        a2 = ((const float2*)P.adp)[te];
+    }
+    // the node's own row of the layer input only matters as a ReLU mask: requested first, folded into 16 bits as soon as it
+    // lands (the gathers behind it stay in flight)
+    unsigned mk = 0xffffu;
+    float4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool first = true;
+    float4 h4[4];
+    if (P.relu_in) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h4[q] = ((const float4*)(P.H + (int64_t)u * KGW_C))[gl + 8 * q];
+    }
+    // two entries per round: 8 gathers in flight per lane; the (L1-resident) u rows follow one entry at a time
+    for (int i = 0; __ballot(i < n); i += 2) {
+        float4 x[2][4];
+        float al[2], dp[2];
+        int rr[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool on = i + e < n;
+            const int z = __shfl(tz, gb + (on ? i + e : 0), 64);
+            rr[e] = __shfl(tr, gb + (on ? i + e : 0), 64);
+            const float a = __shfl(a2.x, gb + (on ? i + e : 0), 64);
+            const float d = __shfl(a2.y, gb + (on ? i + e : 0), 64);
+            al[e] = on ? a : 0.f; dp[e] = on ? d : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[e][q] = dZ4[(int64_t)z * 32 + gl + 8 * q];
+        }
+        if (first && P.relu_in) {
+            mk = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                mk |= ((h4[q].x > 0.f ? 1u : 0u) | (h4[q].y > 0.f ? 2u : 0u) | (h4[q].z > 0.f ? 4u : 0u) | (h4[q].w > 0.f ? 8u : 0u)) << (4 * q);
+        }
+        first = false;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float4 w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = U4[rr[e] * 32 + gl + 8 * q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { fma4(acc[q], al[e], x[e][q]); fma4(acc[q], dp[e], w[q]); }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 v = acc[q];
+        const unsigned m4 = mk >> (4 * q);
+        v.x = (m4 & 1u) ? v.x : 0.f; v.y = (m4 & 2u) ? v.y : 0.f;
+        v.z = (m4 & 4u) ? v.z : 0.f; v.w = (m4 & 8u) ? v.w : 0.f;
+        ((float4*)(P.dH + (int64_t)u * KGW_C))[gl + 8 * q] = v;
+    }
+    // [d a_src | d a_dst] row: column rel(e) of the first half gets d pre-activation(e) (entries of one relation are
+    // adjacent and added in entry order, like the general path's slot sums); the d a_dst half is zero (no destination row)
+    {
+        const int n4 = T.ld_da >> 1;                              // float4s per row (2 * ld_da floats)
+        float4* row = (float4*)(P.da_src + (int64_t)u * 2 * T.ld_da);
+        for (int k0 = 0; k0 < n4; k0 += 8) {                      // (uniform trip count: the shuffles below need every lane)
+            const int k = k0 + gl;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; __ballot(i < n); ++i) {
+                const bool on = i < n;
+                const int r = __shfl(tr, gb + (on ? i : 0), 64);
+                const float d = __shfl(a2.y, gb + (on ? i : 0), 64);
+                const int c = r - 4 * k;
+                if (on && c >= 0 && c < 4) {
+                    v[0] += c == 0 ? d : 0.f; v[1] += c == 1 ? d : 0.f;
+                    v[2] += c == 2 ? d : 0.f; v[3] += c == 3 ? d : 0.f;
+                }
+            }
+            if (k < n4) row[k] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, int n_src_rows) {
     __shared__ float s_dp[KGW_BLK];                           // 64 floats per wavefront (bwd_src_row_pair)
     float* wdp = s_dp + (threadIdx.x & ~63);
     const int nw = gridDim.x * 4;
+    // A wavefront takes source rows two at a time, LAST rows first: the layout is type-major with the SNPs (short rows,
+    // most of the rows) in front and the genes / GO terms (longer rows) at the end -- the long rows must start at the
+    // beginning of the kernel, not in its last round.  Pairs inside an octet that the sampler flagged for the short path
+    // are skipped here and taken by the second loop, whose octets are dealt from the LAST wavefront down: with about
+    // one pair per wavefront the low-numbered wavefronts hold the gene / GO pairs, the high-numbered ones only skipped.
+    // (Two plain loops on purpose: with the octet path inside the pair loop, or an inner loop over an unflagged octet's
+    // pairs, the general path's code got worse -- scalar-register spills -- and the kernel slower than without octets.)
     const int npairs = (n_src_rows + 1) >> 1;
-    // a wavefront takes source rows two at a time, LAST rows first: the layout is type-major with the SNPs (short rows,
-    // most of the rows) in front and the genes / GO terms (rows of up to thousands of entries, one wavefront each) at
-    // the end -- the long rows must start at the beginning of the kernel, not in the last round
-    for (int i0 = blockIdx.x * 4 + (threadIdx.x >> 6); i0 < npairs; i0 += nw) {
+    const int w0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int i0 = w0; i0 < npairs; i0 += nw) {
         const int u = __builtin_amdgcn_readfirstlane(2 * (npairs - 1 - i0));
+        if (u < T.oct_rows && P.oct_flags[u >> 3]) continue;
         if (u + 1 < n_src_rows && bwd_src_row_pair(T, P, u, wdp)) continue;
         bwd_src_one_row(T, P, u);
         if (u + 1 < n_src_rows) bwd_src_one_row(T, P, u + 1);
     }
+    for (int o = nw - 1 - w0; o < (T.oct_rows >> 3); o += nw)
+        if (P.oct_flags[o]) bwd_src_octet(T, P, 8 * o);
 }
 
 // alpha per local edge (attention export)
@@ -865,6 +977,12 @@ int build_tab(const KgwLayerArgs* a, LayerTab* T) {
             T->type_z_base[t] = M->z_base[l - 1][t];
         }
     }
+    // rows [0, oct_rows): the leading node types that carry the short-row hint -- their octets are looked up in oct_flags
+    {
+        int t = 0;
+        while (t < G->n_types && ((G->short_types >> t) & 1u)) ++t;
+        T->oct_rows = (a->t_rel && a->oct_flags) ? (T->type_src_base[t] & ~7) : 0;
+    }
     return KGW_OK;
 }
 
@@ -873,7 +991,7 @@ AggPtrs build_ptrs(const KgwLayerArgs* a) {
     P.chunks = a->chunks; P.col_local = a->col_local; P.H = a->H; P.a_dst = a->a_dst; P.V = a->V; P.U = a->U; P.raw = (a->flags & KGW_F_RAW_WEIGHTS) ? 1 : 0; P.relu_in = (a->flags & KGW_F_RELU_INPUT) ? 1 : 0;
     P.Z = a->Z; P.stat = a->stat; P.e_edge = a->e_edge; P.part = a->part; P.dZ = a->dZ; P.adp = a->adp;
     P.da_dst = a->da_dst; P.part_da = a->part_da; P.t_ptr = a->t_ptr; P.t_edge = a->t_edge;
-    P.t_zrow = a->t_zrow; P.dH = a->dH; P.da_src = a->da_src; P.multi = a->multi; P.multi_cap = a->multi_cap;
+    P.t_zrow = a->t_zrow; P.t_rel = a->t_rel; P.oct_flags = a->oct_flags; P.dH = a->dH; P.da_src = a->da_src; P.multi = a->multi; P.multi_cap = a->multi_cap;
     P.meta = a->meta_dev; P.layer = a->layer;
     P.perm = a->chunk_perm_len ? a->chunk_perm : nullptr; P.perm_len = a->chunk_perm_len;
     P.lbias = a->logit_bias;

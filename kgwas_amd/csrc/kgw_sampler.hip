@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(KGW_BLK) k_t_pass(SampArgs A, int l) {
                 // position inside the row in ARRIVAL order (atomic cursor): staged, then k_t_rank puts the row in
                 // ascending edge order so that the backward's summation order is the same run to run
                 const int pos = A.B.t_ptr[l - 1][trow] + atomicSub(&cnt[trow], 1) - 1;
-                ((int4*)A.B.t_tmp)[pos] = make_int4(e, zrow, trow, 0);
+                ((int4*)A.B.t_tmp)[pos] = make_int4(e, zrow, trow, r);
             }
         }
     }
@@ -490,6 +490,7 @@ __global__ void __launch_bounds__(KGW_BLK) k_t_rank(SampArgs A, int l) {
             for (int q = s0; q < s1; ++q) rank += (tmp[q].x < e) ? 1 : 0;
         A.B.t_edge[l - 1][s0 + rank] = e;
         A.B.t_zrow[l - 1][s0 + rank] = me.y;
+        if (A.B.t_rel[l - 1]) A.B.t_rel[l - 1][s0 + rank] = (uint8_t)me.w;
     }
 }
 
@@ -524,15 +525,42 @@ __global__ void __launch_bounds__(KGW_BLK) k_t_rank_big(SampArgs A, int l) {
             }
             A.B.t_edge[l - 1][s0 + rank] = me.x;
             A.B.t_zrow[l - 1][s0 + rank] = me.y;
+            if (A.B.t_rel[l - 1]) A.B.t_rel[l - 1][s0 + rank] = (uint8_t)me.w;
         }
     }
 }
 
-// the work list lives in the histogram array, which the next sampling call expects zeroed only up to its own fill:
-// nothing to restore (kgw_sample_batch clears t_cnt before every use)
-__global__ void k_t_end(SampArgs A, int l) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    A.B.meta->t_entries[l - 1] = A.B.meta->cur[4];
+// After the ranking the histogram array is free again (the next sampling call clears what it uses): it receives one flag
+// per group of 8 consecutive source rows of the layer input ("octet", row index / 8) for the backward's src-major pass
+// (kgw_gat_aggregate_bwd_src, KgwLayerArgs.oct_flags): 1 = eight real rows of ONE node type of KgwGraph.short_types, none
+// of them a destination row of the layer, each with at most 8 entries over all its relation slots.
+__global__ void __launch_bounds__(KGW_BLK) k_t_end(SampArgs A, int l) {
+    const KgwGraph& G = A.G;
+    KgwBatchMeta* M = A.B.meta;
+    if (blockIdx.x == 0 && threadIdx.x == 0) M->t_entries[l - 1] = M->cur[4];
+    const int NT = G.n_types;
+    const int n_oct = M->error ? 0 : (M->src_base[l - 1][NT] + 7) >> 3;
+    const int32_t* tp = A.B.t_ptr[l - 1];
+    int32_t* out = A.B.t_cnt[l - 1];
+    for (int o = blockIdx.x * KGW_BLK + threadIdx.x; o < n_oct; o += gridDim.x * KGW_BLK) {
+        const int u0 = 8 * o;
+        int ty = 0;
+        while (ty + 1 < NT && u0 >= M->src_base[l - 1][ty + 1]) ++ty;
+        const int j0 = u0 - M->src_base[l - 1][ty];
+        int ok = ((G.short_types >> ty) & 1u) && j0 + 8 <= M->n_src[l - 1][ty] &&
+                 !(G.R_dst[ty] > 0 && j0 < M->n_rows[l - 1][ty]);
+        if (ok) {
+            const int Rs = G.R_src[ty];
+            const int tb = M->t_base[l - 1][ty] + j0 * Rs;
+            int prev = tp[tb];
+            for (int q = 1; q <= 8; ++q) {
+                const int cur = tp[tb + q * Rs];
+                if (cur - prev > 8) ok = 0;
+                prev = cur;
+            }
+        }
+        out[o] = ok;
+    }
 }
 
 }  // namespace
@@ -631,7 +659,7 @@ extern "C" int kgw_sample_batch_parts(const KgwGraph* graph, const KgwBatchBuf* 
         k_t_pass<true><<<SG, KGW_BLK, 0, st>>>(A, l);
         k_t_rank<<<SG, KGW_BLK, 0, st>>>(A, l);
         k_t_rank_big<<<SG, KGW_BLK, 0, st>>>(A, l);
-        k_t_end<<<1, 64, 0, st>>>(A, l);
+        k_t_end<<<SG, KGW_BLK, 0, st>>>(A, l);
         KGW_LAUNCH_CHECK();
     }
     if (buf->meta_host) {

@@ -107,6 +107,9 @@ class KernelTimer:
 TIMER = KernelTimer()
 
 
+_SHORT_ROWS = os.environ.get('KGW_SHORT_ROWS', '1') != '0'     # 0: every source row on the general path (timing experiments)
+
+
 def _layer_args(batch, layer: int, neg_slope: float, inv_temp: float) -> KgwLayerArgs:
     dg, buf, m = batch.dg, batch.buf, batch.meta
     a = KgwLayerArgs()
@@ -125,6 +128,9 @@ def _layer_args(batch, layer: int, neg_slope: float, inv_temp: float) -> KgwLaye
     a.t_ptr = _p(buf.t_ptr[layer - 1])
     a.t_edge = _p(buf.t_edge[layer - 1])
     a.t_zrow = _p(buf.t_zrow[layer - 1])
+    if _SHORT_ROWS:
+        a.t_rel = _p(buf.t_rel[layer - 1])          # relation id per src-major entry: the 8-rows-per-wavefront backward path
+        a.oct_flags = _p(buf.t_cnt[layer - 1])      # (the histogram scratch holds the sampler's octet flags afterwards)
     perm = getattr(batch, 'chunk_perm', None)          # XCD-aware work order of the dst-major kernels (optional)
     if perm is not None and perm.get(layer) is not None:
         a.chunk_perm, a.chunk_perm_len = _p(perm[layer][0]), _p(perm[layer][1])

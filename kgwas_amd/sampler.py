@@ -59,6 +59,7 @@ class DeviceGraph:
         rowptrs, cols, rp_off, col_off = [], [], [], []
         seg_cap = edge_cap = chunk_cap = multi_cap = 0
         ro = co = 0
+        out_edges = [0] * sc.NT                        # edges leaving the nodes of each type (all relations)
         for r, et in enumerate(sc.edge_types):
             cached = data._extra.get('csr', {}).get(tuple(et)) if hasattr(data, '_extra') else None
             if cached is not None:                    # kgwas_amd/ingest.py: CSR straight from the on-disk cache
@@ -70,6 +71,7 @@ class DeviceGraph:
             deg = np.diff(rp)
             seg_cap += len(deg)
             edge_cap += int(rp[-1])
+            out_edges[sc.src_type[r]] += int(rp[-1])
             nch = (deg + KGW_CHUNK - 1) // KGW_CHUNK
             chunk_cap += int(nch.sum())
             multi_cap += int((nch > 1).sum())
@@ -77,6 +79,9 @@ class DeviceGraph:
             rp_off.append(ro); col_off.append(co)
             ro += len(rp); co += len(col)
         self.seg_cap, self.edge_cap = int(seg_cap), int(edge_cap)
+        # node types whose nodes average <= 4 out-edges: their source rows go to the backward's 8-rows-per-wavefront path
+        # (KgwGraph.short_types: a scheduling hint, rows that do not qualify fall back)
+        self.short_type_mask = sum(1 << t for t in range(sc.NT) if out_edges[t] <= 4 * max(self.n_nodes[t], 1))
         self.chunk_cap, self.multi_cap = int(chunk_cap) + 1, int(multi_cap) + 1
         self.trow_cap = int(sum(n * int(rs) for n, rs in zip(self.n_nodes, sc.R_src)))
         self.g_rowptr = torch.from_numpy(np.concatenate(rowptrs)).to(self.device)
@@ -92,6 +97,7 @@ class DeviceGraph:
 
         g = KgwGraph()
         g.n_types, g.n_rels, g.n_layers, g.n_hops = sc.NT, sc.NR, num_layers, self.n_hops
+        g.short_types = self.short_type_mask
         for t in range(sc.NT):
             g.n_nodes[t] = self.n_nodes[t]
             g.node_base[t] = self.node_base[t]
@@ -216,6 +222,7 @@ class BatchBuffers:
         self.t_ptr = [torch.empty(dg.trow_cap + 2, **i32) for _ in range(L)]
         self.t_edge = [torch.empty(dg.edge_cap + 1, **i32) for _ in range(L)]
         self.t_zrow = [torch.empty(dg.edge_cap + 1, **i32) for _ in range(L)]
+        self.t_rel = [torch.empty(dg.edge_cap + 1, dtype=torch.uint8, device=dev) for _ in range(L)]
         self.scan_cap = 2 * (max(dg.seg_cap, dg.node_slots, dg.trow_cap) // KGW_TILE + 4)
         self.scan_tmp = torch.empty(self.scan_cap, **i32)
         self.t_tmp = torch.empty(4 * (dg.edge_cap + 1), **i32)
@@ -230,6 +237,7 @@ class BatchBuffers:
         for l in range(L):
             b.t_cnt[l] = self.t_cnt[l].data_ptr(); b.t_ptr[l] = self.t_ptr[l].data_ptr()
             b.t_edge[l] = self.t_edge[l].data_ptr(); b.t_zrow[l] = self.t_zrow[l].data_ptr()
+            b.t_rel[l] = self.t_rel[l].data_ptr()
         b.scan_tmp, b.meta, b.meta_host = self.scan_tmp.data_ptr(), self.meta.data_ptr(), self.meta_host.data_ptr()
         b.t_tmp = self.t_tmp.data_ptr()
         b.seg_cap, b.edge_cap, b.chunk_cap = dg.seg_cap, dg.edge_cap, dg.chunk_cap
@@ -241,7 +249,7 @@ class BatchBuffers:
 
     def tensors(self):
         return [self.g2l, self.n_id, self.seg_deg, self.seg_nch, self.seg_ptr, self.seg_chptr, self.col_local,
-                self.chunks, self.multi, self.scan_tmp, self.t_tmp, self.meta] + self.t_cnt + self.t_ptr + self.t_edge + self.t_zrow
+                self.chunks, self.multi, self.scan_tmp, self.t_tmp, self.meta] + self.t_cnt + self.t_ptr + self.t_edge + self.t_zrow + self.t_rel
 
     def record_stream(self, stream):
         """The buffers were allocated on the consumer's stream but are written on the sampler's side stream:

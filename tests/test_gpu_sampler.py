@@ -102,6 +102,7 @@ def test_block_structures_are_consistent(small_kg, edge_case_graph, which):
         tptr = buf.t_ptr[l - 1][:t_rows + 1].cpu().numpy()
         tedge = buf.t_edge[l - 1][:n_live_edges].cpu().numpy()
         tz = buf.t_zrow[l - 1][:n_live_edges].cpu().numpy()
+        trel = buf.t_rel[l - 1][:n_live_edges].cpu().numpy()
         assert tptr[0] == 0 and tptr[-1] == n_live_edges and np.all(np.diff(tptr) >= 0)
         # permutation of the live edge ids
         expect = np.concatenate([np.arange(a, b) for a, b in chl[:, :2]]) if len(chl) else np.zeros(0, np.int64)
@@ -118,6 +119,23 @@ def test_block_structures_are_consistent(small_kg, edge_case_graph, which):
         pos = np.arange(n_live_edges)
         assert np.all(tptr[trow] <= pos) and np.all(pos < tptr[trow + 1])
         assert np.array_equal(tz, zb[dst_t] + row * sc.R_dst[dst_t] + sc.slot_dst[rel])
+        assert np.array_equal(buf.t_rel[l - 1][:n_live_edges].cpu().numpy(), rel)      # relation id per entry
+        # octet flags (the backward's 8-rows-per-wavefront path): set exactly for the groups of 8 real source rows of one
+        # short-row type that hold no destination row and no row above 8 entries
+        n_src_rows = int(m.src_base[l - 1][sc.NT])
+        flags = buf.t_cnt[l - 1][:(n_src_rows + 7) // 8].cpu().numpy()
+        sb = np.array([m.src_base[l - 1][t] for t in range(sc.NT + 1)])
+        for o in range(len(flags)):
+            u0 = 8 * o
+            ty = int(np.searchsorted(sb[1:], u0, side='right'))
+            j0 = u0 - sb[ty]
+            ok = bool((dg.short_type_mask >> ty) & 1) and j0 + 8 <= int(m.n_src[l - 1][ty]) and \
+                not (sc.R_dst[ty] > 0 and j0 < int(m.n_rows[l - 1][ty]))
+            if ok:
+                Rs = int(sc.R_src[ty])
+                t0 = tb[ty] + j0 * Rs
+                ok = all(tptr[t0 + (q + 1) * Rs] - tptr[t0 + q * Rs] <= 8 for q in range(8))
+            assert bool(flags[o]) == ok, (l, o)
         assert ne <= n_edges_all
         # deterministic order: inside every src-major row the entries ascend by edge id (the atomic cursor of the
         # fill only decides staging slots; k_t_rank fixes the final order)
