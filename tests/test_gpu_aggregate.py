@@ -120,3 +120,36 @@ def test_extreme_logits_do_not_overflow(edge_case_graph):
     assert torch.isfinite(Z).all()
     Zo = _oracle_layer(batch, 1, H.double(), V.double(), U.double())
     assert_close(Z, Zo, 2e-4, 1e-4, 'Z with spike')
+
+
+@pytest.mark.parametrize('relu_input', [False, True])
+def test_backward_short_row_path_equals_general_path(small_kg, monkeypatch, relu_input):
+    """The src-major backward's 8-rows-per-wavefront path (octets the sampler flags: short rows of a short-row type) and
+    the general path compute the same dH / dU / dV: same batch, once with the octet path switched off.  They differ in
+    summation order only (the a_src term is added per entry instead of per relation slot): rtol 1e-5."""
+    from kgwas_amd import ops
+    batch = _batch(small_kg.data, 2, n_seeds=64, seed=3)
+    dg, m = batch.dg, batch.meta
+    sc = dg.schema
+    layer = 1
+    n_src = int(m.src_base[layer - 1][sc.NT])
+    z_rows = int(m.z_base[layer - 1][sc.NT])
+    flags = batch.buf.t_cnt[layer - 1][:(n_src + 7) // 8].cpu().numpy()
+    assert dg.short_type_mask & 1 and flags.sum() > 10, 'the SNP rows of this graph should take the octet path'
+    g = torch.Generator().manual_seed(5)
+    H = torch.randn(n_src, 128, generator=g)
+    if relu_input:
+        H = torch.relu(H)
+    V = torch.randn(sc.NR, 128, generator=g) * 0.2
+    U = torch.randn(sc.NR, 128, generator=g) * 0.2
+    G = torch.randn(z_rows, 128, generator=g).cuda()
+    out = []
+    for short in (True, False):
+        monkeypatch.setattr(ops, '_SHORT_ROWS', short)
+        Hd, Vd, Ud = (t.cuda().requires_grad_(True) for t in (H, V, U))
+        Z, _, _ = ops.gat_aggregate(batch, layer, Hd, Ud, Vd, relu_input=relu_input)
+        (Z * G).sum().backward()
+        out.append((Hd.grad.clone(), Ud.grad.clone(), Vd.grad.clone()))
+    for a, b, name in zip(out[0], out[1], ('dH', 'dU', 'dV')):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-7, name
