@@ -417,6 +417,14 @@ int kgw_readout_wmse_bwd(const float* H, const float* w_lin, const float* pred, 
                          const double* grad_loss, float* dH, float* dw_lin, float* db_lin, float* scratch,
                          kgw_stream_t stream);
 
+/* The two calls above fused for a training step whose loss gradient is 1 (loss.backward() of kgwas/kgwas.py:147):
+ * prediction, loss, dH (zero beyond the seeds), d w_lin, d b_lin in two launches instead of four.  relu: bit 0 = ReLU
+ * read-out, bit 1 = H is the output of a ReLU whose backward is folded in (dH *= H > 0).  terms [n] doubles and
+ * scratch [((rows+3)/4) * 129] floats are workspaces.                                                             */
+int kgw_readout_wmse_train(const float* H, const float* w_lin, const float* b_lin, const int32_t* n_id, const float* y,
+                           const double* w, int32_t n, int64_t rows, int32_t relu, float* pred, double* loss, float* dH,
+                           float* dw_lin, float* db_lin, double* terms, float* scratch, kgw_stream_t stream);
+
 /* Self-test of the cross-lane reductions used by the aggregate kernels (one wavefront):
  * out_half[l] = sum over l's 32-lane half, out_wave[l] = sum over the wavefront,
  * out_steps[4][64] = the four intra-row DPP butterfly stages.                                  */

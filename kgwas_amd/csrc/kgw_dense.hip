@@ -1803,6 +1803,83 @@ __global__ void __launch_bounds__(1024) k_readout_fold(const float* __restrict__
     }
 }
 
+// Training step with a unit loss gradient (loss.backward()): forward and backward of the read-out in ONE launch per
+// stage -- the per-seed stage computes prediction, loss term, d prediction, the dH row and the block's weight-gradient
+// partial; the fold stage adds up the loss terms (float64, index order) and the partials.  Two launches instead of four.
+__global__ void __launch_bounds__(256) k_readout_wmse_train(const float* __restrict__ H, const float* __restrict__ wl,
+                                                            const float* __restrict__ bl, const int32_t* __restrict__ n_id,
+                                                            const float* __restrict__ y, const double* __restrict__ w, int n,
+                                                            int64_t rows, int relu, float* __restrict__ pred,
+                                                            double* __restrict__ terms, float* __restrict__ dH,
+                                                            float* __restrict__ part) {
+    __shared__ float sw[4][KGW_C + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    float2 dw = make_float2(0.f, 0.f);
+    float dp = 0.f;
+    if (i < n) {
+        const float2 w2 = ((const float2*)wl)[lane];
+        const float2 h2 = ((const float2*)(H + i * KGW_C))[lane];
+        float p = kgw_wave_allsum(fmaf(h2.x, w2.x, h2.y * w2.y)) + bl[0];
+        if (relu & 1) p = fmaxf(p, 0.f);
+        const int g = n_id[i];
+        const float d = p - y[g];
+        if (lane == 0) {
+            pred[i] = p;
+            terms[i] = w[g] * (double)(d * d);
+        }
+        dp = (float)(1.0 / (double)n * w[g]) * (2.0f * d);
+        if ((relu & 1) && !(p > 0.f)) dp = 0.f;
+        const bool mk = (relu & 2) != 0;
+        ((float2*)(dH + i * KGW_C))[lane] = make_float2((!mk || h2.x > 0.f) ? dp * w2.x : 0.f,
+                                                         (!mk || h2.y > 0.f) ? dp * w2.y : 0.f);
+        dw = make_float2(dp * h2.x, dp * h2.y);
+    } else if (i < rows) {
+        ((float2*)(dH + i * KGW_C))[lane] = make_float2(0.f, 0.f);
+    }
+    if ((int64_t)blockIdx.x * 4 >= n) return;            // blocks without seeds hold no partial
+    sw[wave][2 * lane] = dw.x; sw[wave][2 * lane + 1] = dw.y;
+    if (lane == 0) sw[wave][KGW_C] = dp;
+    __syncthreads();
+    if (threadIdx.x <= KGW_C) {
+        const int c = threadIdx.x;
+        part[(int64_t)blockIdx.x * (KGW_C + 1) + c] = (sw[0][c] + sw[1][c]) + (sw[2][c] + sw[3][c]);
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_readout_train_fold(const float* __restrict__ part, int nb, const double* __restrict__ terms,
+                                                             int n, float* __restrict__ dwl, float* __restrict__ dbl,
+                                                             double* __restrict__ loss) {
+    __shared__ float sm[7][KGW_C + 1];
+    __shared__ double sd[256];
+    const int c = threadIdx.x % (KGW_C + 1), g = threadIdx.x / (KGW_C + 1);
+    if (g < 7) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int q = g;
+        for (; q + 21 < nb; q += 28) {
+            a0 += part[(int64_t)q * (KGW_C + 1) + c];        a1 += part[(int64_t)(q + 7) * (KGW_C + 1) + c];
+            a2 += part[(int64_t)(q + 14) * (KGW_C + 1) + c]; a3 += part[(int64_t)(q + 21) * (KGW_C + 1) + c];
+        }
+        for (; q < nb; q += 7) a0 += part[(int64_t)q * (KGW_C + 1) + c];
+        sm[g][c] = (a0 + a1) + (a2 + a3);
+    }
+    if (threadIdx.x < 256) {                                  // the loss: same order as k_fold_f64
+        double acc = 0.0;
+        for (int q = threadIdx.x; q < n; q += 256) acc += terms[q];
+        sd[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sd[threadIdx.x] += sd[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = sd[0] / (double)n;
+    if (g == 0) {
+        const float t = ((sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c])) + ((sm[4][c] + sm[5][c]) + sm[6][c]);
+        if (c < KGW_C) dwl[c] = t; else dbl[0] = t;
+    }
+}
+
 }  // namespace
 
 extern "C" int kgw_readout_wmse_fwd(const float* H, const float* w_lin, const float* b_lin, const int32_t* n_id,
@@ -1830,6 +1907,22 @@ extern "C" int kgw_readout_wmse_bwd(const float* H, const float* w_lin, const fl
                                                                     scratch);
     KGW_LAUNCH_CHECK();
     k_readout_fold<<<1, 1024, 0, st>>>(scratch, (n + 3) / 4, dw_lin, db_lin);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+extern "C" int kgw_readout_wmse_train(const float* H, const float* w_lin, const float* b_lin, const int32_t* n_id,
+                                      const float* y, const double* w, int32_t n, int64_t rows, int32_t relu, float* pred,
+                                      double* loss, float* dH, float* dw_lin, float* db_lin, double* terms, float* scratch,
+                                      kgw_stream_t stream_) {
+    if (!H || !w_lin || !b_lin || !n_id || !y || !w || !pred || !loss || !dH || !dw_lin || !db_lin || !terms || !scratch)
+        return KGW_E_NULL;
+    if (n <= 0 || rows < n) return KGW_E_RANGE;
+    hipStream_t st = (hipStream_t)stream_;
+    k_readout_wmse_train<<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(H, w_lin, b_lin, n_id, y, w, n, rows, relu, pred, terms, dH,
+                                                                      scratch);
+    KGW_LAUNCH_CHECK();
+    k_readout_train_fold<<<1, 1024, 0, st>>>(scratch, (n + 3) / 4, terms, n, dw_lin, db_lin, loss);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }

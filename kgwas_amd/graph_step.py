@@ -110,7 +110,7 @@ class GraphTrainStep:
         if self.split_backward:
             mlp_out = []
             loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id(self.input_type),
-                                              self.dg.y[self.input_type], self.ld_w, mlp_out=mlp_out)
+                                              self.dg.y[self.input_type], self.ld_w, mlp_out=mlp_out, unit_grad=True)
             hs = [h for h in mlp_out if h.requires_grad]
             late = self._late_params()
             early = [p for p in self.model.parameters() if p.requires_grad and id(p) not in late]
@@ -126,7 +126,7 @@ class GraphTrainStep:
             self._cut[cur] = (hs, list(g[:len(hs)]))
         else:
             loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id(self.input_type),
-                                              self.dg.y[self.input_type], self.ld_w)          # kgwas.py:137-145
+                                              self.dg.y[self.input_type], self.ld_w, unit_grad=True)   # kgwas.py:137-145
             loss.backward(gradient=self._unit)                         # (a resident 1.0: no ones_like fill per step)
         if self.capture_optimizer:
             self.opt.step()

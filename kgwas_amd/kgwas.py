@@ -103,7 +103,8 @@ class KGWAS:
         optimizer.zero_grad(set_to_none=True)
         bs = batch['SNP'].batch_size
         # forward + mean(ld_weight * (pred - y)**2) in float64 (kgwas.py:137-145); labels / weights by the seeds' ids
-        loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id('SNP'), batch.dg.y['SNP'], ld_w)
+        loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id('SNP'), batch.dg.y['SNP'], ld_w,
+                                          unit_grad=True)
         loss.backward()
         if world > 1:
             kdist.allreduce_grads(self.model, world)

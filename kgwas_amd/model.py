@@ -521,12 +521,13 @@ class HeteroGNN(nn.Module):
         _, attn = self._fused_layers(batch, h, want_attention=True, hbuf=hbuf, folded=self.fold_fc)
         return attn
 
-    def forward_loss(self, x_dict, edge_index_dict, batch_size, n_id, y_all, w_all, mlp_out=None):
+    def forward_loss(self, x_dict, edge_index_dict, batch_size, n_id, y_all, w_all, mlp_out=None, unit_grad=False):
         """The training step's forward (kgwas/kgwas.py:137-145): HeteroGNN.forward followed by
         mean(w_all[n_id] * (pred - y_all[n_id])**2), with the read-out Linear + ReLU (model.py:86) and the loss fused
         into one node.  Returns (loss [float64 scalar], pred [batch_size]).  ``mlp_out`` (list): receives the feature MLPs'
         output tensors -- the cut between the two halves of a backward pass whose first half's gradients are all-reduced
-        while the second half runs (multi-GPU GraphTrainStep)."""
+        while the second half runs (multi-GPU GraphTrainStep).  ``unit_grad``: the caller will backpropagate exactly
+        ``loss.backward()`` (gradient 1): the read-out node then does its forward and backward in two launches."""
         batch: Optional[SampledBatch] = getattr(x_dict, 'kgw_batch', None) or getattr(edge_index_dict, 'kgw_batch', None)
         if batch is None:
             batch = self._block_from_coo(x_dict, edge_index_dict)
@@ -539,7 +540,7 @@ class HeteroGNN(nn.Module):
         gat = self.backbone == 'GAT' and self.aggr in ('sum', 'mean')
         h, _ = self._fused_layers(batch, h, hbuf=hbuf, last_premasked=gat, folded=self.fold_fc)
         return ops.readout_weighted_mse(h['SNP'], self.lin.weight, self.lin.bias, n_id, y_all, w_all, batch_size,
-                                        relu=not self.no_relu, h_is_relu=gat)
+                                        relu=not self.no_relu, h_is_relu=gat, unit_grad=unit_grad)
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()

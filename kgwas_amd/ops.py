@@ -1010,7 +1010,7 @@ class _ReadoutWeightedMSE(torch.autograd.Function):
     rows (kgwas/model.py:86) and the weighted MSE (kgwas/kgwas.py:139-145) as one node, two launches per step."""
 
     @staticmethod
-    def forward(ctx, H, w_lin, b_lin, n_id, y_all, w_all, n, relu, h_is_relu=False):
+    def forward(ctx, H, w_lin, b_lin, n_id, y_all, w_all, n, relu, h_is_relu=False, unit_grad=False):
         H = H.contiguous()
         assert H.dtype == torch.float32 and H.shape[1] == KGW_C and H.shape[0] >= n and w_lin.numel() == KGW_C
         assert n_id.dtype == torch.int32 and y_all.dtype == torch.float32 and w_all.dtype == torch.float64
@@ -1018,19 +1018,34 @@ class _ReadoutWeightedMSE(torch.autograd.Function):
         pred = torch.empty(n, device=dev)
         loss = torch.empty((), dtype=torch.float64, device=dev)
         terms = torch.empty(n, dtype=torch.float64, device=dev)
+        ctx.n, ctx.relu, ctx.h_is_relu = n, relu, h_is_relu
+        ctx.mark_non_differentiable(pred)
+        ctx.set_materialize_grads(False)
+        ctx.ready = None
+        if unit_grad and ctx.needs_input_grad[0]:
+            # the caller backpropagates a loss gradient of exactly 1: everything the backward returns is computed here
+            dH, dw, db = torch.empty_like(H), torch.empty_like(w_lin), torch.empty(1, device=dev)
+            part = torch.empty(((H.shape[0] + 3) // 4) * (KGW_C + 1), device=dev)
+            _lib.check(_lib.lib().kgw_readout_wmse_train(_p(H), _p(w_lin), _p(b_lin), _p(n_id), _p(y_all), _p(w_all), n, H.shape[0],
+                                                         (1 if relu else 0) | (2 if h_is_relu else 0), _p(pred), _p(loss), _p(dH),
+                                                         _p(dw), _p(db), _p(terms), _p(part), _lib.stream_ptr()),
+                       'kgw_readout_wmse_train')
+            ctx.ready = (dH, dw, db)
+            return loss, pred
         _lib.check(_lib.lib().kgw_readout_wmse_fwd(_p(H), _p(w_lin), _p(b_lin), _p(n_id), _p(y_all), _p(w_all), n,
                                                    1 if relu else 0, _p(pred), _p(loss), _p(terms), _lib.stream_ptr()),
                    'kgw_readout_wmse_fwd')
         ctx.save_for_backward(H, w_lin, pred, n_id, y_all, w_all)
-        ctx.n, ctx.relu, ctx.h_is_relu = n, relu, h_is_relu
-        ctx.mark_non_differentiable(pred)
-        ctx.set_materialize_grads(False)
         return loss, pred
 
     @staticmethod
     def backward(ctx, gloss, _gpred):
         if gloss is None:
-            return (None,) * 9
+            return (None,) * 10
+        if ctx.ready is not None:
+            dH, dw, db = ctx.ready
+            ctx.ready = None
+            return dH, dw, db, None, None, None, None, None, None, None
         H, w_lin, pred, n_id, y_all, w_all = ctx.saved_tensors
         gloss = gloss.contiguous().to(torch.float64)
         dH = torch.empty_like(H)
@@ -1041,10 +1056,12 @@ class _ReadoutWeightedMSE(torch.autograd.Function):
                                                    H.shape[0], (1 if ctx.relu else 0) | (2 if ctx.h_is_relu else 0), _p(gloss),
                                                    _p(dH), _p(dw), _p(db), _p(part), _lib.stream_ptr()),
                    'kgw_readout_wmse_bwd')
-        return dH, dw, db, None, None, None, None, None, None
+        return dH, dw, db, None, None, None, None, None, None, None
 
 
-def readout_weighted_mse(H, w_lin, b_lin, n_id, y_all, w_all, n: int, relu: bool = True, h_is_relu: bool = False):
+def readout_weighted_mse(H, w_lin, b_lin, n_id, y_all, w_all, n: int, relu: bool = True, h_is_relu: bool = False,
+                         unit_grad: bool = False):
     """Returns (loss float64 scalar, pred float32 [n]); ``w_lin`` [1,128] / ``b_lin`` [1] = HeteroGNN.lin.
-    ``h_is_relu``: see layer_transform's ``premasked``."""
-    return _ReadoutWeightedMSE.apply(H, w_lin, b_lin, n_id, y_all, w_all, int(n), bool(relu), bool(h_is_relu))
+    ``h_is_relu``: see layer_transform's ``premasked``.  ``unit_grad``: the caller promises to backpropagate a loss gradient of
+    exactly 1 (``loss.backward()``): forward and backward of this node then share two launches instead of four."""
+    return _ReadoutWeightedMSE.apply(H, w_lin, b_lin, n_id, y_all, w_all, int(n), bool(relu), bool(h_is_relu), bool(unit_grad))

@@ -370,6 +370,14 @@ def test_fused_readout_loss_equals_forward_plus_loss(small_kg, no_relu):
     assert set(g1) == set(g2)
     for n in g1:
         assert_close(g1[n], g2[n], 1e-4, 1e-7, 'grad ' + n, rel_to_max=1e-5)
+    # the training step's variant (loss gradient known to be 1: forward + backward of the node in two launches): bit-identical
+    model.zero_grad(set_to_none=True)
+    loss3, pred3 = model.forward_loss(batch.x_dict, batch.edge_index_dict, 96, batch.n_id('SNP'), y_all, w_all, unit_grad=True)
+    loss3.backward()
+    g3 = {n: t for n, t in grads_by_name(model).items() if t is not None}
+    assert torch.equal(loss3, loss) and torch.equal(pred3, pred) and set(g3) == set(g1)
+    for n in g1:
+        assert torch.equal(g3[n], g1[n]), n
 
 
 @pytest.mark.parametrize('which', ['small', 'edge'])
