@@ -369,6 +369,13 @@ int kgw_relvec_bwd(int32_t n_live, const int32_t* rel_ids, const int32_t* bip_po
                    const float* w_dst_t, const float* att_src, const float* att_dst, const float* dU_full,
                    const float* dV, float* dw_src_t, float* dw_dst_t, float* datt_src, float* datt_dst,
                    int32_t v_by_rel, kgw_stream_t stream);
+/* _bwd_acc: the same with (a) dw_src_acc (nullable): a gradient of w_src_t that reached the caller by another path -- the
+ * layer's transform GEMM (conv.py:138-144) or the FC_output fold use the same weights -- and is added into dw_src_t here
+ * instead of by a separate launch; (b) dU_full / dV nullable = zero.                                              */
+int kgw_relvec_bwd_acc(int32_t n_live, const int32_t* rel_ids, const int32_t* bip_pos, const float* w_src_t,
+                       const float* w_dst_t, const float* att_src, const float* att_dst, const float* dU_full,
+                       const float* dV, const float* dw_src_acc, float* dw_src_t, float* dw_dst_t, float* datt_src,
+                       float* datt_dst, int32_t v_by_rel, kgw_stream_t stream);
 
 /* FC_output of the feature MLPs folded into the layer-1 relation parameters (exact re-association; no counterpart call in
  * the reference, which runs SimpleMLP.FC_output, kgwas/model.py:15,21, on every sampled node).  H = h2 T + c with

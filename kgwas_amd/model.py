@@ -435,7 +435,8 @@ class HeteroGNN(nn.Module):
             # bias of every destination block: one launch
             # ... and the zero fill of the aggregate's workspace rides in the same launch
             zws = ops.aggregate_workspace(batch, l, self.lin.weight.device)
-            U, V, bsum = ops.rel_vectors(P, blocks, zero=zws)
+            # (the weights reach the transform / the fold THROUGH that node: their gradient is added inside its backward kernel)
+            U, V, bsum, Wv = ops.rel_vectors(P, blocks, zero=zws, pass_weights=True)
             # layer input, type-major (src_base): every type that sends or receives messages in this layer
             parts, spans = [], []
             for t, name in enumerate(sc.node_types):
@@ -462,7 +463,7 @@ class HeteroGNN(nn.Module):
                     used = k in self._fold_used
                     fc += [mm.FC_output.weight if used else mm.FC_output.weight.detach(),
                            mm.FC_output.bias if used else mm.FC_output.bias.detach()]
-                U, V, kap, Wp, gam = ops.fold_fc_output_hip(P, U, V, fc, self._fold_tab)
+                U, V, kap, Wp, gam = ops.fold_fc_output_hip(P, U, V, fc, self._fold_tab, weight=Wv)
             Z, stat, e_edge = ops.gat_aggregate(batch, l, H, U, V, self.negative_slope, self.temperature,
                                                 relu_input=((l > 1 or folded) and fused), zbuf=zws, logit_bias=kap)
             if want_attention:
@@ -475,7 +476,7 @@ class HeteroGNN(nn.Module):
                 for (lo, hi, z0, rows) in blocks:
                     R = hi - lo
                     zr = Z[z0:z0 + rows * R].view(rows, R, C).transpose(0, 1)
-                    o = torch.baddbmm(P.bias[lo:hi].unsqueeze(1), zr, P.w_src_t[lo:hi])
+                    o = torch.baddbmm(P.bias[lo:hi].unsqueeze(1), zr, Wv[lo:hi])
                     outs.append(torch.relu(self._combine_relations(o)))
                 h = {sc.node_types[t]: o for t, o in zip(tys, outs)}
                 continue
@@ -483,7 +484,7 @@ class HeteroGNN(nn.Module):
             hbuf, nxt = self._layer_input(batch, l + 1) if l < self.num_layers else (None, {})
             outs = ops.layer_transform(P, Z, blocks, [nxt.get(sc.node_types[t]) for t in tys],
                                        premasked=(l < self.num_layers) or last_premasked, bias_sum=bsum,
-                                       weight=Wp, gamma=gam, stat=stat if gam is not None else None)
+                                       weight=Wp if Wp is not None else Wv, gamma=gam, stat=stat if gam is not None else None)
             if self.aggr == 'mean':
                 # mean over the relations of a destination type = the sum scaled by 1/R; relu(s/R) = relu(s)/R, and the
                 # positive scale commutes with the folded ReLU masks

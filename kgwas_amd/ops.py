@@ -725,10 +725,13 @@ def linear_relu(x, W, b, fixed_shape=False):
 # per-layer parameter plumbing as two autograd nodes (instead of ~60 tiny framework ops per step)
 # ------------------------------------------------------------------------------------------------------
 class _RelVectors(torch.autograd.Function):
-    """(U [NR,C], V [NR,C]), rows by relation id, from the packed relation parameters of a layer -- kgw_relvec_fwd / _bwd."""
+    """(U [NR,C], V [NR,C]), rows by relation id, from the packed relation parameters of a layer -- kgw_relvec_fwd / _bwd.
+    ``pass_w``: also returns w_src_t itself (a view).  The layer's transform GEMM / the FC_output fold take THAT tensor
+    instead of the parameter, so the gradient they produce for the weights comes back to this node and is added inside
+    kgw_relvec_bwd_acc -- not by a framework add launch (the parameter would otherwise have two consumers)."""
 
     @staticmethod
-    def forward(ctx, w_src_t, w_dst_t, att_src, att_dst, pack, blk_of_live, n_blk, zero=None):
+    def forward(ctx, w_src_t, w_dst_t, att_src, att_dst, pack, blk_of_live, n_blk, zero=None, pass_w=False):
         n, C = att_src.shape
         if zero is not None:
             assert zero.dtype == torch.float32 and zero.is_contiguous() and zero.numel() % 4 == 0
@@ -743,45 +746,52 @@ class _RelVectors(torch.autograd.Function):
                                              _lib.stream_ptr()), 'kgw_relvec_fwd')
         ctx.save_for_backward(w_src_t, w_dst_t, att_src, att_dst)
         ctx.pack = pack
+        ctx.has_bsum = bsum is not None
         ctx.set_materialize_grads(False)
-        if bsum is None:
-            return U, V
-        ctx.mark_non_differentiable(bsum)
-        return U, V, bsum
+        outs = [U, V]
+        if bsum is not None:
+            ctx.mark_non_differentiable(bsum)
+            outs.append(bsum)
+        if pass_w:
+            outs.append(w_src_t.detach())          # (same storage; not a tracked view: no as_strided replay in the backward)
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, dU, dV, _dbsum=None):
+    def backward(ctx, dU, dV, *rest):
         w_src_t, w_dst_t, att_src, att_dst = ctx.saved_tensors
+        rest = list(rest)
+        if ctx.has_bsum and rest:
+            rest.pop(0)
+        dW_in = rest[0] if rest else None
         if dU is None and dV is None:
-            return (None,) * 8
-        if dU is None:
-            dU = torch.zeros(ctx.pack.n_rels_total, att_src.shape[1], device=att_src.device)
-        if dV is None:
-            dV = torch.zeros(ctx.pack.n_rels_total, att_src.shape[1], device=att_src.device)
+            return (dW_in,) + (None,) * 8
         pack = ctx.pack
         n = att_src.shape[0]
-        dU = dU.contiguous(); dV = dV.contiguous()
+        dU = dU.contiguous() if dU is not None else None
+        dV = dV.contiguous() if dV is not None else None
+        dW_in = dW_in.contiguous() if dW_in is not None else None
         dws = torch.empty_like(w_src_t)
         dwd = torch.empty_like(w_dst_t)
         das = torch.empty_like(att_src)
         dad = torch.empty_like(att_dst)
-        _lib.check(_lib.lib().kgw_relvec_bwd(n, _p(pack.rel_ids_i32), _p(pack.bip_pos_i32), _p(w_src_t),
-                                             _p(w_dst_t) if w_dst_t.numel() else 0, _p(att_src), _p(att_dst), _p(dU), _p(dV),
-                                             _p(dws), _p(dwd) if dwd.numel() else 0, _p(das), _p(dad), 1, _lib.stream_ptr()),
-                   'kgw_relvec_bwd')
-        return dws, dwd, das, dad, None, None, None, None
+        _lib.check(_lib.lib().kgw_relvec_bwd_acc(n, _p(pack.rel_ids_i32), _p(pack.bip_pos_i32), _p(w_src_t),
+                                                 _p(w_dst_t) if w_dst_t.numel() else 0, _p(att_src), _p(att_dst), _p(dU), _p(dV),
+                                                 _p(dW_in), _p(dws), _p(dwd) if dwd.numel() else 0, _p(das), _p(dad), 1,
+                                                 _lib.stream_ptr()), 'kgw_relvec_bwd_acc')
+        return dws, dwd, das, dad, None, None, None, None, None
 
 
 def _block_key(blocks):
     return tuple((lo, hi) for lo, hi, *_ in blocks)
 
 
-def rel_vectors(pack, blocks=None, zero=None):
+def rel_vectors(pack, blocks=None, zero=None, pass_weights=False):
     """(U, V) by relation id; with ``blocks`` (the layer_transform block list, [(lo, hi, ...)]) also the summed bias
     of every block, [n blocks, C] (no gradient flows through it: layer_transform produces d bias itself).
-    ``zero``: a float32 buffer to clear in the same launch (``aggregate_workspace``: the zero fill the aggregate needs)."""
+    ``zero``: a float32 buffer to clear in the same launch (``aggregate_workspace``: the zero fill the aggregate needs).
+    ``pass_weights``: one more output, pack.w_src_t as seen by autograd THROUGH this node (see _RelVectors)."""
     if blocks is None:
-        return _RelVectors.apply(pack.w_src_t, pack.w_dst_t, pack.att_src, pack.att_dst, pack, None, 0, zero)
+        return _RelVectors.apply(pack.w_src_t, pack.w_dst_t, pack.att_src, pack.att_dst, pack, None, 0, zero, pass_weights)
     key = ('blk',) + _block_key(blocks)
     tab = pack._sel_cache.get(key)
     if tab is None:
@@ -791,7 +801,7 @@ def rel_vectors(pack, blocks=None, zero=None):
                 blk[i] = b
         tab = torch.tensor(blk, dtype=torch.int32, device=pack.bias.device)
         pack._sel_cache[key] = tab
-    return _RelVectors.apply(pack.w_src_t, pack.w_dst_t, pack.att_src, pack.att_dst, pack, tab, len(blocks), zero)
+    return _RelVectors.apply(pack.w_src_t, pack.w_dst_t, pack.att_src, pack.att_dst, pack, tab, len(blocks), zero, pass_weights)
 
 
 class _LayerTransform(torch.autograd.Function):
@@ -940,10 +950,10 @@ class _FoldFC(torch.autograd.Function):
         return (dws, dU, dV, None, None) + tuple(dfc)
 
 
-def fold_fc_output_hip(pack, U, V, fc_params, tab):
+def fold_fc_output_hip(pack, U, V, fc_params, tab, weight=None):
     """fold_fc_output on the HIP kernels.  ``fc_params``: [weight_0, bias_0, weight_1, bias_1, ...] = FC_output of the MLPs
     (nn.Linear layout); ``tab`` = (rel ids, source MLP, destination MLP) of the packed relations as int32 numpy arrays."""
-    return _FoldFC.apply(pack.w_src_t, U, V, pack, tab, *fc_params)
+    return _FoldFC.apply(pack.w_src_t if weight is None else weight, U, V, pack, tab, *fc_params)
 
 
 def fold_fc_output(pack, U, V, T3, c3, src_m, dst_m):
