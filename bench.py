@@ -245,9 +245,10 @@ def main():
     local_rank %= torch.cuda.device_count()      # (single-GPU boxes: KGW_DIST_BACKEND=gloo lets 2 ranks share cuda:0 for a dry run)
     torch.cuda.set_device(local_rank)
     dev = f'cuda:{local_rank}'
-    if world > 1:
+    if world > 1 or os.environ.get('KGW_FORCE_MULTIRANK_PATH') == '1':       # (the latter: one rank through the RCCL path)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29555'); os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         backend = os.environ.get('KGW_DIST_BACKEND', 'nccl')          # "nccl" == RCCL over xGMI on ROCm
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device(dev))
@@ -530,6 +531,11 @@ def main():
         'roofline': roof, 'cpu_baseline': cpu, 'breakdown': breakdown,
     }
     sys.stdout.flush()
+    try:                                      # C stdio too: RCCL prints its version banner with printf, block-buffered on a pipe
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     os.dup2(_stdout_fd, 1)
     print(json.dumps(out), flush=True)
 

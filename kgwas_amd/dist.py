@@ -9,6 +9,8 @@ mean-over-ranks(mean-over-slice) == mean over the reference's 512-seed batch, so
 the reference's (up to summation order)."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -39,7 +41,7 @@ def _grads(model):
 
 def allreduce_flat(flat: torch.Tensor, world: int):
     """Average ``flat`` over the ranks in place: ONE collective (RCCL's AVG where the backend has it)."""
-    if world <= 1:
+    if world <= 1 and not (os.environ.get('KGW_FORCE_MULTIRANK_PATH') == '1' and dist.is_initialized()):
         return
     if dist.get_backend() == 'nccl':
         dist.all_reduce(flat, op=dist.ReduceOp.AVG)

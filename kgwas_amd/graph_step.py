@@ -58,14 +58,17 @@ class GraphTrainStep:
                 self.world = dist.get_world_size()
         except Exception:
             pass
-        if self.world > 1:
+        # (KGW_FORCE_MULTIRANK_PATH=1: a single rank takes the multi-rank path -- split backward, RCCL all-reduce of one rank on
+        # the side stream, eager Adam -- so that a 1-GPU box exercises exactly what an 8-GPU node runs)
+        self._multi = self.world > 1 or (os.environ.get('KGW_FORCE_MULTIRANK_PATH') == '1' and torch.distributed.is_initialized())
+        if self._multi:
             self.capture_optimizer = False       # gradients are all-reduced between backward and Adam
         # multi-rank: the backward pass is captured in TWO graphs, cut at the feature MLPs' outputs.  The gradients of the
         # first half (every relation pack, the read-out, the folded FC_output: ~3.9 MB) are all-reduced on a side stream
         # while the second half (the MLPs' backward: ~45 % of the backward's time, incl. the 5120-wide gene dW product)
         # runs; only the MLPs' own bucket (~2.7 MB) is reduced in the open.
-        self.split_backward = self.world > 1 and os.environ.get('KGW_SPLIT_BACKWARD', '1') == '1'
-        self._comm = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        self.split_backward = self._multi and os.environ.get('KGW_SPLIT_BACKWARD', '1') == '1'
+        self._comm = torch.cuda.Stream(device=dev) if self._multi else None
         self._ev_a, self._ev_ca = torch.cuda.Event(), torch.cuda.Event()
         self._flat_a = self._flat_b = None
         self._cut = [None, None]
@@ -132,7 +135,7 @@ class GraphTrainStep:
             self.opt.step()
         elif self.split_backward:
             pass                                                       # (second half: _step_body_b)
-        elif self.world > 1:
+        elif self._multi:
             # gradients of all live tensors into ONE persistent bucket (the all-reduce and Adam run on it after the replay)
             live = [p for p in self.model.parameters() if p.grad is not None]
             if self._flat is None:
@@ -268,7 +271,7 @@ class GraphTrainStep:
                 kdist.allreduce_flat(self._flat_b, self.world)        # second bucket: the MLPs' own gradients
                 main.wait_event(self._ev_ca)
                 self.opt.step(self._flat_grads)
-            elif self.world > 1:
+            elif self._multi:
                 from . import dist as kdist
                 kdist.allreduce_flat(self._flat, self.world)          # one RCCL collective over the bucket
                 self.opt.step(self._flat_grads)

@@ -94,3 +94,43 @@ def test_two_rank_graph_step_equals_hand_averaged_single_process(tmp_path):
         assert float(d) <= 2e-5 * float(scale) + 2e-6, (k, float(d))
         changed += 1
     assert changed > 20
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['KGW_FORCE_MULTIRANK_PATH'] = '1'
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda:0'))
+    try:
+        from kgwas_amd.graph_step import GraphTrainStep
+        data, run = _make_run()
+        ids = np.asarray(data.train_input_nodes[1])[:BS * (STEPS + 1)]
+        gs = GraphTrainStep(run, ('SNP', ids), BS, lr=1e-3, weight_decay=5e-4)
+        assert gs.split_backward and not gs.capture_optimizer and 'RCCL' in gs.describe()
+        for i in range(STEPS):
+            gs.step(i)
+        gs.check()
+        torch.save({k: v.detach().cpu() for k, v in run.model.named_reference_tensors().items()},
+                   os.path.join(out_dir, 'rccl.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_multirank_step_over_rccl_with_one_rank_equals_the_single_gpu_step(tmp_path):
+    """The multi-rank step exactly as an 8-GPU node runs it -- backend "nccl" (= RCCL), backward captured in two graphs,
+    the first gradient bucket all-reduced on a side stream under the second graph, eager Adam on the bucket views -- with
+    ONE rank (all a 1-GPU box can host: RCCL refuses two ranks on one device): averaging over one rank is the identity, so
+    the parameters after three steps equal the single-GPU captured step's bit for bit."""
+    mp.start_processes(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True, start_method='spawn')
+    got = torch.load(os.path.join(tmp_path, 'rccl.pt'), weights_only=False)
+    from kgwas_amd.graph_step import GraphTrainStep
+    data, run = _make_run()
+    ids = np.asarray(data.train_input_nodes[1])[:BS * (STEPS + 1)]
+    gs = GraphTrainStep(run, ('SNP', ids), BS, lr=1e-3, weight_decay=5e-4)
+    assert gs.capture_optimizer and not gs.split_backward
+    for i in range(STEPS):
+        gs.step(i)
+    gs.check()
+    for k, v in run.model.named_reference_tensors().items():
+        assert torch.equal(got[k], v.detach().cpu()), k
