@@ -32,6 +32,7 @@ this mode is for SNP sets whose features and edges do not (north_star: ~10 M SNP
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import numpy as np
@@ -87,6 +88,8 @@ class ShardExchange:
     def __init__(self, dg: DeviceGraph, sharded_type: str = 'SNP', group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # (KGW_FORCE_MULTIRANK_PATH=1: a single rank still issues every collective -- a 1-GPU box then exercises them over RCCL)
+        self.multi = self.world > 1 or (os.environ.get('KGW_FORCE_MULTIRANK_PATH') == '1' and dist.is_initialized())
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         sc = dg.schema
         self.sharded = sc.type_id[sharded_type]
@@ -121,7 +124,7 @@ class ShardExchange:
     # -- sampling ---------------------------------------------------------------------------------------------------
     def merge_frontier(self, buf: BatchBuffers):
         """Union of the ranks' PENDING flags on the replicated node types (KGW_PENDING = -2 < -1 = unsampled)."""
-        if self.world == 1:
+        if not self.multi:
             return
         for lo, hi in self.rep_runs:
             dist.all_reduce(buf.g2l[lo:hi], op=dist.ReduceOp.MIN, group=self.group)
@@ -156,7 +159,7 @@ class ShardExchange:
         L = _lib.lib()
         mine = torch.empty(n * PART_STRIDE, device=self.dev)
         _lib.check(L.kgw_softmax_pack(_ptr(Z), _ptr(stat), _ptr(seg), n, _ptr(mine), _lib.stream_ptr()), 'kgw_softmax_pack')
-        if self.world > 1:
+        if self.multi:
             allp = torch.empty(self.world * n * PART_STRIDE, device=self.dev)
             try:
                 dist.all_gather_into_tensor(allp, mine, group=self.group)
@@ -173,7 +176,7 @@ class ShardExchange:
         """dZ holds this rank's PARTIAL upstream gradient; the exchanged segments need the complete one: sum their rows
         over the ranks, in place."""
         seg = self.seg_rows(batch, layer)
-        if seg is None or self.world == 1:
+        if seg is None or not self.multi:
             return dZ
         n = int(seg.numel())
         L = _lib.lib()
@@ -271,7 +274,7 @@ class ShardedTrainer:
     def allreduce_grads(self):
         live = [p for p in self.model.parameters() if p.grad is not None]
         flat = torch.cat([p.grad.reshape(-1) for p in live])
-        if self.world > 1:
+        if self.xchg.multi:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.xchg.group)
             self.xchg.bytes_moved += flat.numel() * 4
         off = 0
@@ -340,7 +343,7 @@ class ShardedTrainer:
             p = self.model(batch.x_dict, batch.edge_index_dict, int(seeds.numel())).reshape(-1)
             if len(sel):
                 out[torch.from_numpy(a + sel).to(self.dev)] = p
-        if self.world > 1:
+        if self.xchg.multi:
             dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.xchg.group)
         if was_training:
             self.model.train()

@@ -61,14 +61,18 @@ def _ids(data):
     return np.asarray(data.train_input_nodes[1])[:BS * max(STEPS + 1, N_GRAD_BATCHES)]
 
 
-def _worker(rank, world, port, out_dir, which):
+def _worker(rank, world, port, out_dir, which, backend='gloo'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    if backend == 'nccl':                       # RCCL: one rank per device, so ONE rank that still issues every collective
+        os.environ['KGW_FORCE_MULTIRANK_PATH'] = '1'
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda:0'))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from kgwas_amd import dist as kdist
         from kgwas_amd.shard import ShardedTrainer
-        torch.cuda.set_device(0)
         data, run = _make_run(which)
         kdist.broadcast_params(run.model)
         run.model.train()
@@ -99,10 +103,12 @@ def _worker(rank, world, port, out_dir, which):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('which,world', [('small', 2), ('small', 4), ('edge', 2)])
-def test_sharded_mode_equals_single_process(tmp_path, which, world):
+@pytest.mark.parametrize('which,world,backend', [('small', 2, 'gloo'), ('small', 4, 'gloo'), ('edge', 2, 'gloo'), ('small', 1, 'nccl')])
+def test_sharded_mode_equals_single_process(tmp_path, which, world, backend):
+    """(the 'nccl' case: the exchange's collectives -- MIN all-reduce of the frontier flags, all-gather of the partial softmax
+    states, SUM all-reduce of dZ rows / gradients / predictions -- issued over RCCL by the one rank a 1-GPU box can host)"""
     port = _free_port()
-    mp.start_processes(_worker, args=(world, port, str(tmp_path), which), nprocs=world, join=True, start_method='spawn')
+    mp.start_processes(_worker, args=(world, port, str(tmp_path), which, backend), nprocs=world, join=True, start_method='spawn')
     recs = [torch.load(os.path.join(tmp_path, f'rank{r}.pt'), weights_only=False) for r in range(world)]
 
     from kgwas_amd.optim import FusedAdam
