@@ -14,7 +14,7 @@ tot = sum(float(r['TotalDurationNs']) for r in rows)
 ncalls = sum(int(r['Calls']) for r in rows)
 # forward/backward passes executed: timed + warm-up + capture warm-up steps AND the eager passes of the roofline leg
 # (those run no optimizer step, so k_adam shows fewer calls)
-nstep = max([int(r['Calls']) for r in rows if 'k_readout_wmse_bwd(' in r['Name']] + [0]) or 23   # (no eager leg: warm-ups + capture + timed)
+nstep = max([int(r['Calls']) for r in rows if 'k_readout_wmse_train(' in r['Name'] or 'k_readout_wmse_bwd(' in r['Name']] + [0]) or 23   # (no eager leg: warm-ups + capture + timed)
 print('kernel time total %.1f ms, %d launches; %d forward/backward passes executed (timed, warm-ups, roofline leg; the caps pre-pass adds sampler-only work)' % (tot / 1e6, ncalls, nstep))
 # kernels of the step itself: launched at least once per optimizer step (leaves out the one-off library tuning runs)
 step_rows = [r for r in rows if (int(r['Calls']) >= nstep or 'k_adam' in r['Name']) and 'flush_icache' not in r['Name']
