@@ -320,6 +320,15 @@ int kgw_linear(const float* X, int64_t ldx, const float* W, int64_t ldw, const f
                const float* mask, int64_t ldm, float* Y, int64_t ldy, int64_t rows, int32_t K, int32_t N,
                int32_t relu, int32_t w_is_kn, const int32_t* rows_dev, kgw_stream_t stream);
 
+/* SimpleMLP's two hidden layers (kgwas/model.py:17-20) for a NARROW input in one launch:
+ * H2 = relu(relu(X W1^T + b1) W2^T + b2), X [rows, K1] with K1 <= 20 and K1 % 4 == 0 (the 20-wide SNP features), W1 [128, K1],
+ * W2 [128, 128] (nn.Linear layout), hidden width 128.  The hidden state goes from the first product's accumulators straight
+ * into the second product's operand registers; it is ALSO written to H1 (nullable) for the backward, which reads it as the
+ * ReLU mask and in the weight gradient.  rows_dev: see kgw_linear.                                                  */
+int kgw_mlp2_fwd(const float* X, int64_t ldx, int32_t K1, const float* W1, int64_t ldw1, const float* b1, const float* W2,
+                 int64_t ldw2, const float* b2, float* H1, int64_t ldh1, float* H2, int64_t ldh2, int64_t rows,
+                 const int32_t* rows_dev, kgw_stream_t stream);
+
 /* The same product for FEW rows when one of K, N is 128 and the other a multiple of 128 -- the per-relation transform
  * of a layer after aggregate-then-transform, [N_dst, R*128] x [R*128, 128] with N_dst ~ 0.5-1.2 k destination rows of a
  * 512-seed batch (kgwas/conv.py:138-144 for all relations into one destination type + bias :190 + HeteroConv sum

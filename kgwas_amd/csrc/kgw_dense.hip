@@ -933,6 +933,162 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// kgw_mlp2_fwd: H2 = relu(relu(X W1^T + b1) W2^T + b2) for a NARROW first layer (K1 <= 20: the 20-wide SNP features,
+// kgwas/model.py:17-20 on ~120 k sampled rows) in ONE launch -- k_linear_wreg with its X tile COMPUTED instead of loaded:
+//   product 1 runs in the same orientation as product 2 (weights = MFMA A operand, the X' tile = B operand), so lane
+//   (row j, half h) ends up holding h1[j][32 t + 8 g + 4 h + c] -- exactly "one row, 64 of its 128 columns" as the second
+//   product's B operand wants it; only the K order differs from k_linear_wreg's, so W2 is loaded into its operand
+//   registers in THAT order.  The hidden state never goes through LDS or memory on its way to the second product.
+//   X' = [X | 1 | 0..] (24 wide), W1' = [W1 | b1 | 0..]: the bias of the first layer rides in the product.
+//   H1 is written too when the caller wants it (the backward's ReLU mask and weight gradient read it).
+// ------------------------------------------------------------------------------------------------------
+struct Mlp2Args {
+    const float* X; int64_t ldx;
+    const float* W1; int64_t ldw1; const float* b1;
+    const float* W2; int64_t ldw2; const float* b2;
+    float* H1; int64_t ldh1;          // nullable
+    float* H2; int64_t ldh2;
+    int64_t rows; int K1;
+    const int32_t* rows_dev;
+};
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) k_mlp2_fwd(Mlp2Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Wl = lds;                                         // [128 n][WST], k contiguous; bias b2 behind it
+    float* W1l = lds + 128 * WST + 128;                      // [128 n][24]: W1 | b1 | 0
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    int64_t rows = a.rows;
+    if (a.rows_dev) { const int64_t r = *a.rows_dev; rows = r < 0 ? 0 : (r < a.rows ? r : a.rows); }
+    {   // padding rows of a static layout: zeros
+        const int64_t npad = a.rows - rows;
+        for (int64_t q = (int64_t)blockIdx.x * 256 + tid; q < npad * 32; q += (int64_t)gridDim.x * 256) {
+            const int64_t r = rows + q / 32; const int c4 = (int)(q % 32) * 4;
+            *(float4*)(a.H2 + r * a.ldh2 + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.H1) *(float4*)(a.H1 + r * a.ldh1 + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if ((int64_t)blockIdx.x * 4 * 32 >= rows) return;    // (before any barrier: the whole block leaves)
+    }
+    const int ntiles = (int)((rows + 31) / 32);
+    const int nw = (int)gridDim.x * 4;
+    int tile = (int)blockIdx.x * 4 + wave;
+    const int K1 = a.K1;
+    // this lane's part of an X' row: k = 12 lk + 0..11 as three float4 (a chunk is data, the bias slot (1,0,0,0), or zero)
+    auto fetch_x = [&](int t, f32x4 (&x)[3]) {
+        int64_t r = (int64_t)(t < ntiles ? t : ntiles - 1) * 32 + li;
+        if (r >= rows) r = rows - 1;
+        const float* xp = a.X + r * a.ldx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int k4 = 12 * lk + 4 * c;
+            if (k4 + 4 <= K1) x[c] = *(const f32x4*)(xp + k4);
+            else x[c] = f32x4{k4 == K1 ? 1.f : 0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    f32x4 xn[3];
+    fetch_x(tile, xn);
+    {   // stage W2 (as k_linear_wreg) and W1' through LDS
+        f32x4 wv[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = tid + 256 * it;
+            wv[it] = *(const f32x4*)(a.W2 + (int64_t)(idx >> 5) * a.ldw2 + (idx & 31) * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = tid + 256 * it;
+            *(f32x4*)(Wl + (idx >> 5) * WST + (idx & 31) * 4) = wv[it];
+        }
+        for (int idx = tid; idx < 128 * 24; idx += 256) {
+            const int n = idx / 24, k = idx % 24;
+            W1l[idx] = k < K1 ? a.W1[(int64_t)n * a.ldw1 + k] : (k == K1 ? (a.b1 ? a.b1[n] : 0.f) : 0.f);
+        }
+    }
+    if (tid < 128) Wl[128 * WST + tid] = a.b2 ? a.b2[tid] : 0.f;
+    __syncthreads();
+    // operand registers.  Second product: MFMA step (q = 4 t + g, c) multiplies k = 32 t + 8 g + 4 lk + c -- the column the
+    // first product leaves in accumulator element 4 g + c of tile t of this lane.
+    f32x4 bw[3][16];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bw[t][q] = *(const f32x4*)(Wl + (t * 32 + li) * WST + 32 * (q >> 2) + 8 * (q & 3) + 4 * lk);
+    const float* w3 = Wl + (96 + li) * WST + 4 * lk;
+    f32x4 w1[4][3];                                          // W1'[32 t + li][12 lk + 0..11]
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) w1[t][c] = *(const f32x4*)(W1l + (t * 32 + li) * 24 + 12 * lk + 4 * c);
+    const float* bl = Wl + 128 * WST + 4 * lk;
+    for (; tile < ntiles; tile += nw) {
+        f32x4 x[3] = {xn[0], xn[1], xn[2]};
+        fetch_x(tile + nw, xn);                              // next tile's rows: in flight under this tile's MFMAs
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        // product 1: 12 steps x 4 column tiles
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#define KGW_MLP_STEP(C)                                                                                   \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                \
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[t][c].C, x[c].C, acc[t], 0, 0, 0);
+            KGW_MLP_STEP(x) KGW_MLP_STEP(y) KGW_MLP_STEP(z) KGW_MLP_STEP(w)
+#undef KGW_MLP_STEP
+        }
+        const int64_t row = (int64_t)tile * 32 + li;         // this lane's row
+        const bool live = row < rows;
+        f32x4 xa[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+                v.x = fmaxf(acc[t][4 * g + 0], 0.f); v.y = fmaxf(acc[t][4 * g + 1], 0.f);
+                v.z = fmaxf(acc[t][4 * g + 2], 0.f); v.w = fmaxf(acc[t][4 * g + 3], 0.f);
+                xa[4 * t + g] = v;
+            }
+        if (a.H1 && live) {
+            float* hp = a.H1 + row * a.ldh1 + 4 * lk;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) *(f32x4*)(hp + 32 * (q >> 2) + 8 * (q & 3)) = xa[q];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        // product 2: k_linear_wreg's MFMA stream
+        f32x4 b3n = *(const f32x4*)w3;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const f32x4 b3 = b3n;
+            if (q + 1 < 16) b3n = *(const f32x4*)(w3 + 32 * ((q + 1) >> 2) + 8 * ((q + 1) & 3));
+#define KGW_MLP_STEP(C)                                                                                   \
+            _Pragma("unroll") for (int t = 0; t < 3; ++t)                                                \
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[t][q].C, xa[q].C, acc[t], 0, 0, 0);      \
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(b3.C, xa[q].C, acc[3], 0, 0, 0);
+            KGW_MLP_STEP(x) KGW_MLP_STEP(y) KGW_MLP_STEP(z) KGW_MLP_STEP(w)
+#undef KGW_MLP_STEP
+        }
+        if (live) {
+            float* yp = a.H2 + row * a.ldh2 + 4 * lk;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b4 = *(const f32x4*)(bl + t * 32 + 8 * g);
+                    f32x4 v;
+                    v.x = fmaxf(acc[t][4 * g + 0] + b4.x, 0.f); v.y = fmaxf(acc[t][4 * g + 1] + b4.y, 0.f);
+                    v.z = fmaxf(acc[t][4 * g + 2] + b4.z, 0.f); v.w = fmaxf(acc[t][4 * g + 3] + b4.w, 0.f);
+                    *(f32x4*)(yp + t * 32 + 8 * g) = v;
+                }
+            }
+        }
+    }
+}
+
 // Same product for FEW row tiles (up to 512: the GO / gene matrices of a batch): with one 32-row tile per wavefront
 // only ntiles of the chip's 1024 SIMDs get work.  Here a wavefront takes one tile x ONE HALF of the output columns
 // (128 MFMAs, 128 registers of W), two wavefronts per SIMD, every task resident at once: no tile loop, no refill.
@@ -1113,6 +1269,28 @@ extern "C" int kgw_linear(const float* X, int64_t ldx, const float* W, int64_t l
     }
     dim3 grid((unsigned)((rows + LBM - 1) / LBM), (unsigned)((N + LBN - 1) / LBN));
     k_linear<<<grid, 256, 0, (hipStream_t)stream_>>>(a);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+extern "C" int kgw_mlp2_fwd(const float* X, int64_t ldx, int32_t K1, const float* W1, int64_t ldw1, const float* b1,
+                            const float* W2, int64_t ldw2, const float* b2, float* H1, int64_t ldh1, float* H2, int64_t ldh2,
+                            int64_t rows, const int32_t* rows_dev, kgw_stream_t stream_) {
+    if (rows == 0) return KGW_OK;
+    if (!X || !W1 || !W2 || !H2) return KGW_E_NULL;
+    if (rows < 0 || K1 <= 0) return KGW_E_RANGE;
+    if (K1 > 20 || (K1 & 3) || (ldx & 3) || (ldw2 & 3) || (ldh2 & 3) || (H1 && (ldh1 & 3)) || !aligned16(X) || !aligned16(W2) ||
+        !aligned16(H2) || (H1 && !aligned16(H1)))
+        return KGW_E_UNSUPPORTED;
+    Mlp2Args a{X, ldx, W1, ldw1, b1, W2, ldw2, b2, H1, ldh1, H2, ldh2, rows, K1, rows_dev};
+    const size_t lds = (size_t)(128 * WST + 128 + 128 * 24) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        KGW_HIP(hipFuncSetAttribute((const void*)k_mlp2_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int64_t nblk = ((rows + 31) / 32 + 3) / 4;
+    k_mlp2_fwd<<<(int)(nblk < 256 ? nblk : 256), 256, lds, (hipStream_t)stream_>>>(a);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }

@@ -107,6 +107,7 @@ class KernelTimer:
 TIMER = KernelTimer()
 
 
+_MLP2_FUSED = os.environ.get('KGW_MLP2_FUSED', '1') != '0'        # 0: the two hidden layers of a narrow MLP as two launches
 _SHORT_ROWS = os.environ.get('KGW_SHORT_ROWS', '1') != '0'     # 0: every source row on the general path (timing experiments)
 
 
@@ -566,8 +567,26 @@ class _MLP2(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2, out, rows_dev):
+        rows, K1 = x.shape
+        h2 = out.view() if out is not None else None
+        if (_MLP2_FUSED and rows >= 16384 and K1 <= 20 and K1 % 4 == 0 and W1.shape[0] == KGW_C and W2.shape == (KGW_C, KGW_C)
+                and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+                and W1.stride(1) == 1 and W2.stride(1) == 1 and W2.stride(0) % 4 == 0 and W2.data_ptr() % 16 == 0
+                and b1 is not None and b2 is not None
+                and (h2 is None or (h2.stride(1) == 1 and h2.stride(0) % 4 == 0 and h2.data_ptr() % 16 == 0))):
+            # narrow first layer on many rows (the 20-wide SNP features): both layers in one launch, the hidden state handed
+            # from the first product's accumulators to the second product's operand registers (kgw_mlp2_fwd)
+            if h2 is None:
+                h2 = torch.empty(rows, KGW_C, device=x.device)
+            h1 = torch.empty(rows, KGW_C, device=x.device)
+            _lib.check(_lib.lib().kgw_mlp2_fwd(_p(x), x.stride(0), K1, _p(W1), W1.stride(0), _p(b1), _p(W2), W2.stride(0), _p(b2),
+                                               _p(h1), h1.stride(0), _p(h2), h2.stride(0), rows, _p(rows_dev), _lib.stream_ptr()),
+                       'kgw_mlp2_fwd')
+            ctx.save_for_backward(x, h1, W2)
+            ctx.rows_dev = rows_dev
+            return h2
         h1 = linear(x, W1, b1, relu=True, rows_dev=rows_dev)
-        h2 = linear(h1, W2, b2, relu=True, out=out.view() if out is not None else None, rows_dev=rows_dev)
+        h2 = linear(h1, W2, b2, relu=True, out=h2, rows_dev=rows_dev)
         ctx.save_for_backward(x, h1, W2)
         ctx.rows_dev = rows_dev
         return h2

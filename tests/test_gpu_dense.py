@@ -82,6 +82,38 @@ def test_mlp_nodes_match_autograd():
         assert_close(a, b.grad, 1e-4, 1e-6, 'grad ' + n_)
 
 
+@pytest.mark.parametrize('rows,K1,real', [(120003, 20, None), (16384, 20, None), (50001, 8, None), (40000, 20, 33333), (20000, 12, 0)])
+def test_fused_two_layer_mlp_matches_fp64(rows, K1, real):
+    """kgw_mlp2_fwd (ops.mlp2 on a narrow input): relu(relu(x W1^T + b1) W2^T + b2) in one launch, the hidden state kept for
+    the backward; forward vs float64, gradients vs float64 autograd; whole / ragged last tiles; a static layout's padding
+    rows (``rows_dev``) come out as zeros.  Tolerance: fp32 MFMA accumulation over K <= 128, rtol 1e-5 of the largest value."""
+    from kgwas_amd import ops
+    g = torch.Generator().manual_seed(rows + K1)
+    x = torch.randn(rows, K1, generator=g).cuda()
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.2).cuda().requires_grad_(True)
+    W1, b1, W2, b2 = mk(128, K1), mk(128), mk(128, 128), mk(128)
+    G = torch.randn(rows, 128, generator=g).cuda()
+    rd = torch.tensor([real], dtype=torch.int32, device='cuda') if real is not None else None
+    n = rows if real is None else real
+    with torch.no_grad():
+        z1 = x.double() @ W1.double().t() + b1.double()
+        h1 = torch.relu(z1)
+        z2 = h1 @ W2.double().t() + b2.double()
+        G[(z1.abs() < 1e-5).any(1) | (z2.abs() < 1e-5).any(1)] = 0.0      # ill-defined ReLU masks: no upstream gradient
+        G[n:] = 0.0
+    h2 = ops.mlp2(x, W1, b1, W2, b2, rows_dev=rd)
+    assert_close(h2[:n], torch.relu(z2)[:n], 1e-5, 1e-6, 'h2', rel_to_max=2e-6)
+    assert float(h2.detach()[n:].abs().max() if n < rows else 0.0) == 0.0
+    # the consumer hands back a gradient already multiplied by (h2 > 0) (see _MLP2)
+    (h2 * G * (h2 > 0)).sum().backward()
+    ps = [t.detach().double().requires_grad_(True) for t in (W1, b1, W2, b2)]
+    ho = torch.relu(torch.relu(x.double()[:n] @ ps[0].t() + ps[1]) @ ps[2].t() + ps[3])
+    (ho * G.double()[:n]).sum().backward()
+    if n:
+        for a, b, nm in zip((W1, b1, W2, b2), ps, 'W1 b1 W2 b2'.split()):
+            assert_close(a.grad, b.grad, 1e-4, 1e-6, 'grad ' + nm, rel_to_max=1e-5)
+
+
 @pytest.mark.parametrize('rows,K,N,kn', [(120003, 128, 128, False), (50001, 20, 128, False), (1000, 2176, 128, True),
                                          (777, 128, 128, True), (130, 768, 128, True), (5, 16, 128, False),
                                          (4097, 128, 20, True), (3000, 128, 260, False),
