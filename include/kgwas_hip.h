@@ -324,10 +324,12 @@ int kgw_linear(const float* X, int64_t ldx, const float* W, int64_t ldw, const f
  * H2 = relu(relu(X W1^T + b1) W2^T + b2), X [rows, K1] with K1 <= 20 and K1 % 4 == 0 (the 20-wide SNP features), W1 [128, K1],
  * W2 [128, 128] (nn.Linear layout), hidden width 128.  The hidden state goes from the first product's accumulators straight
  * into the second product's operand registers; it is ALSO written to H1 (nullable) for the backward, which reads it as the
- * ReLU mask and in the weight gradient.  rows_dev: see kgw_linear.                                                  */
+ * ReLU mask and in the weight gradient.  rows_dev: see kgw_linear.  ids (nullable): input row r is X[ids[r]] -- the
+ * loader's x[n_id] slicing (kgwas/kgwas.py:135) folded in; Xg (nullable) then receives the gathered rows [rows, K1] for the
+ * backward's first-layer weight gradient.                                                                          */
 int kgw_mlp2_fwd(const float* X, int64_t ldx, int32_t K1, const float* W1, int64_t ldw1, const float* b1, const float* W2,
                  int64_t ldw2, const float* b2, float* H1, int64_t ldh1, float* H2, int64_t ldh2, int64_t rows,
-                 const int32_t* rows_dev, kgw_stream_t stream);
+                 const int32_t* rows_dev, const int32_t* ids, float* Xg, int64_t ldxg, kgw_stream_t stream);
 
 /* The same product for FEW rows when one of K, N is 128 and the other a multiple of 128 -- the per-relation transform
  * of a layer after aggregate-then-transform, [N_dst, R*128] x [R*128, 128] with N_dst ~ 0.5-1.2 k destination rows of a

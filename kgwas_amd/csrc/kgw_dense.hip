@@ -951,6 +951,8 @@ struct Mlp2Args {
     float* H2; int64_t ldh2;
     int64_t rows; int K1;
     const int32_t* rows_dev;
+    const int32_t* ids;               // nullable: row r of the input is X[ids[r]] (the loader's x[n_id] slicing folded in)
+    float* Xg; int64_t ldxg;          // nullable: the gathered rows, written for the backward's weight gradient
 };
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) k_mlp2_fwd(Mlp2Args a) {
@@ -978,7 +980,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     auto fetch_x = [&](int t, f32x4 (&x)[3]) {
         int64_t r = (int64_t)(t < ntiles ? t : ntiles - 1) * 32 + li;
         if (r >= rows) r = rows - 1;
-        const float* xp = a.X + r * a.ldx;
+        const float* xp = a.X + (a.ids ? (int64_t)a.ids[r] : r) * a.ldx;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int k4 = 12 * lk + 4 * c;
@@ -1040,6 +1042,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         }
         const int64_t row = (int64_t)tile * 32 + li;         // this lane's row
         const bool live = row < rows;
+        if (a.Xg && live) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (12 * lk + 4 * c + 4 <= K1) *(f32x4*)(a.Xg + row * a.ldxg + 12 * lk + 4 * c) = x[c];
+        }
         f32x4 xa[16];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -1275,14 +1282,16 @@ extern "C" int kgw_linear(const float* X, int64_t ldx, const float* W, int64_t l
 
 extern "C" int kgw_mlp2_fwd(const float* X, int64_t ldx, int32_t K1, const float* W1, int64_t ldw1, const float* b1,
                             const float* W2, int64_t ldw2, const float* b2, float* H1, int64_t ldh1, float* H2, int64_t ldh2,
-                            int64_t rows, const int32_t* rows_dev, kgw_stream_t stream_) {
+                            int64_t rows, const int32_t* rows_dev, const int32_t* ids, float* Xg, int64_t ldxg,
+                            kgw_stream_t stream_) {
     if (rows == 0) return KGW_OK;
     if (!X || !W1 || !W2 || !H2) return KGW_E_NULL;
+    if (Xg && ((ldxg & 3) || !aligned16(Xg))) return KGW_E_UNSUPPORTED;
     if (rows < 0 || K1 <= 0) return KGW_E_RANGE;
     if (K1 > 20 || (K1 & 3) || (ldx & 3) || (ldw2 & 3) || (ldh2 & 3) || (H1 && (ldh1 & 3)) || !aligned16(X) || !aligned16(W2) ||
         !aligned16(H2) || (H1 && !aligned16(H1)))
         return KGW_E_UNSUPPORTED;
-    Mlp2Args a{X, ldx, W1, ldw1, b1, W2, ldw2, b2, H1, ldh1, H2, ldh2, rows, K1, rows_dev};
+    Mlp2Args a{X, ldx, W1, ldw1, b1, W2, ldw2, b2, H1, ldh1, H2, ldh2, rows, K1, rows_dev, ids, Xg, ldxg};
     const size_t lds = (size_t)(128 * WST + 128 + 128 * 24) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

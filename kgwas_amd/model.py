@@ -77,11 +77,15 @@ class SimpleMLP(nn.Module):
         """relu(FC_hidden2(h1)): the MLP without FC_output (folded into layer 1, ops.fold_fc_output)."""
         return ops.mlp_tail2(h1, self.FC_hidden2.weight, self.FC_hidden2.bias, out)
 
-    def hidden(self, x, out=None, rows_dev=None):
-        """h2 = relu(FC_hidden2(relu(FC_hidden(x)))): the MLP without FC_output (folded into layer 1)."""
+    def hidden(self, x, out=None, rows_dev=None, ids=None):
+        """h2 = relu(FC_hidden2(relu(FC_hidden(x)))): the MLP without FC_output (folded into layer 1).  ``ids`` (int32): the
+        input rows are ``x[ids]`` of a resident feature matrix."""
         if x.requires_grad:
+            if ids is not None:
+                x = x[ids.long()]
             return self.tail2(self.first(x), out)
-        return ops.mlp2(x, self.FC_hidden.weight, self.FC_hidden.bias, self.FC_hidden2.weight, self.FC_hidden2.bias, out, rows_dev)
+        return ops.mlp2(x, self.FC_hidden.weight, self.FC_hidden.bias, self.FC_hidden2.weight, self.FC_hidden2.bias, out, rows_dev,
+                        ids)
 
     def forward(self, x, out=None, rows_dev=None):
         if x.requires_grad:
@@ -309,6 +313,9 @@ class HeteroGNN(nn.Module):
                 return mlp.tail2(h1, out) if fold else mlp.tail(h1, out)
         # static layout: the row block is padded to its capacity; the kernels skip the padding (count on the device)
         rd = batch.rows_dev(t) if n == batch.lay_src(1, dg.schema.type_id[t]) else None
+        if fold and lazy and dict.get(x_dict, t) is None and dg.x[t].shape[1] <= 20:
+            # narrow features (the 20-wide SNP rows): the x[n_id] slicing happens inside the fused two-layer kernel
+            return mlp.hidden(dg.x[t], out, rd, ids=batch.n_id(t))
         return mlp.hidden(x_dict[t], out, rd) if fold else mlp(x_dict[t], out, rd)
 
     def _layer_input(self, batch: SampledBatch, l: int):

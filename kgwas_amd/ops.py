@@ -566,25 +566,31 @@ class _MLP2(torch.autograd.Function):
     and the consumer of h2 (gat_aggregate(relu_input=True)) hands back a gradient ALREADY multiplied by (h2 > 0)."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, out, rows_dev):
-        rows, K1 = x.shape
+    def forward(ctx, x, W1, b1, W2, b2, out, rows_dev, ids=None):
+        # ``ids``: x is a RESIDENT feature matrix and the input rows are x[ids] (the loader's slicing, kgwas/kgwas.py:135)
+        rows, K1 = (x.shape if ids is None else (ids.numel(), x.shape[1]))
         h2 = out.view() if out is not None else None
         if (_MLP2_FUSED and rows >= 16384 and K1 <= 20 and K1 % 4 == 0 and W1.shape[0] == KGW_C and W2.shape == (KGW_C, KGW_C)
                 and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
                 and W1.stride(1) == 1 and W2.stride(1) == 1 and W2.stride(0) % 4 == 0 and W2.data_ptr() % 16 == 0
-                and b1 is not None and b2 is not None
+                and b1 is not None and b2 is not None and (ids is None or ids.dtype == torch.int32)
                 and (h2 is None or (h2.stride(1) == 1 and h2.stride(0) % 4 == 0 and h2.data_ptr() % 16 == 0))):
             # narrow first layer on many rows (the 20-wide SNP features): both layers in one launch, the hidden state handed
-            # from the first product's accumulators to the second product's operand registers (kgw_mlp2_fwd)
+            # from the first product's accumulators to the second product's operand registers (kgw_mlp2_fwd); the row gather
+            # rides along
             if h2 is None:
                 h2 = torch.empty(rows, KGW_C, device=x.device)
             h1 = torch.empty(rows, KGW_C, device=x.device)
+            xg = torch.empty(rows, K1, device=x.device) if ids is not None else None
             _lib.check(_lib.lib().kgw_mlp2_fwd(_p(x), x.stride(0), K1, _p(W1), W1.stride(0), _p(b1), _p(W2), W2.stride(0), _p(b2),
-                                               _p(h1), h1.stride(0), _p(h2), h2.stride(0), rows, _p(rows_dev), _lib.stream_ptr()),
-                       'kgw_mlp2_fwd')
-            ctx.save_for_backward(x, h1, W2)
+                                               _p(h1), h1.stride(0), _p(h2), h2.stride(0), rows, _p(rows_dev), _p(ids), _p(xg),
+                                               K1, _lib.stream_ptr()), 'kgw_mlp2_fwd')
+            ctx.save_for_backward(x if ids is None else xg, h1, W2)
             ctx.rows_dev = rows_dev
             return h2
+        if ids is not None:
+            from .sampler import gather_rows
+            x = gather_rows(x, ids)
         h1 = linear(x, W1, b1, relu=True, rows_dev=rows_dev)
         h2 = linear(h1, W2, b2, relu=True, out=h2, rows_dev=rows_dev)
         ctx.save_for_backward(x, h1, W2)
@@ -598,11 +604,12 @@ class _MLP2(torch.autograd.Function):
         dh2 = dh2.contiguous()
         dh1 = linear(dh2, W2, mask=h1, w_kn=True, rows_dev=rd)   # (dh2 @ W2) * (h1 > 0)
         (dW2, db2), (dW1, db1) = weight_grads([(dh2, h1), (dh1, x)], rows_dev=rd)
-        return None, dW1, db1, dW2, db2, None, None
+        return None, dW1, db1, dW2, db2, None, None, None
 
 
-def mlp2(x, W1, b1, W2, b2, out=None, rows_dev=None):
-    return _MLP2.apply(x, W1, b1, W2, b2, out, rows_dev)
+def mlp2(x, W1, b1, W2, b2, out=None, rows_dev=None, ids=None):
+    """``ids`` (int32): the input is ``x[ids]`` for a resident feature matrix ``x`` (gathered inside the fused kernel)."""
+    return _MLP2.apply(x, W1, b1, W2, b2, out, rows_dev, ids)
 
 
 class _MLPTail2(torch.autograd.Function):

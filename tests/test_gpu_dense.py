@@ -112,6 +112,22 @@ def test_fused_two_layer_mlp_matches_fp64(rows, K1, real):
     if n:
         for a, b, nm in zip((W1, b1, W2, b2), ps, 'W1 b1 W2 b2'.split()):
             assert_close(a.grad, b.grad, 1e-4, 1e-6, 'grad ' + nm, rel_to_max=1e-5)
+    # the same with the row gather folded in: x = X[ids] of a larger resident matrix -- bit-identical to the sliced input
+    Xres = torch.randn(rows + 1000, K1, generator=g).cuda()
+    ids = torch.randint(0, rows + 1000, (rows,), generator=g, dtype=torch.int32).cuda()
+    mine = [t.grad.clone() for t in (W1, b1, W2, b2)]
+    for t in (W1, b1, W2, b2):
+        t.grad = None
+    ha = ops.mlp2(Xres[ids.long()].contiguous(), W1, b1, W2, b2, rows_dev=rd)
+    (ha * G * (ha > 0)).sum().backward()
+    ga = [t.grad.clone() for t in (W1, b1, W2, b2)]
+    for t in (W1, b1, W2, b2):
+        t.grad = None
+    hb = ops.mlp2(Xres, W1, b1, W2, b2, rows_dev=rd, ids=ids)
+    (hb * G * (hb > 0)).sum().backward()
+    assert torch.equal(ha, hb)
+    for t, ref in zip((W1, b1, W2, b2), ga):
+        assert torch.equal(t.grad, ref)
 
 
 @pytest.mark.parametrize('rows,K,N,kn', [(120003, 128, 128, False), (50001, 20, 128, False), (1000, 2176, 128, True),
