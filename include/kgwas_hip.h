@@ -194,6 +194,9 @@ typedef struct KgwLayerArgs {
                                       KgwGraph.short_types, none of them a destination row of the layer, each with at most 8
                                       entries.  Such a group is processed by ONE wavefront, 8 lanes per row, without the per-row
                                       slot bookkeeping of the general path (the SNP rows: ~2 entries, two thirds of all rows)   */
+    float* rel_sums;               /* optional, kgw_gat_aggregate_bwd_src: [n_rels] <- per relation, the sum of d a_dst over its
+                                      destination rows = the gradient of logit_bias (what kgw_relation_sums computes), by
+                                      n_rels extra blocks of the same launch.  Needs V (in-kernel a_dst) so that da_dst is final */
 } KgwLayerArgs;
 
 /* ---- entry points ------------------------------------------------------------------------ */
@@ -254,6 +257,10 @@ int kgw_relation_sums(const KgwLayerArgs* args, const float* x, float* out, kgw_
  * stats[n_layers] += edges sampled, stats[n_layers+1] |= KgwBatchMeta.error.  stats: n_layers + 2 device int64.   */
 int kgw_accumulate_stats(const KgwBatchMeta* meta_dev, int32_t n_layers, int32_t n_hops, int64_t* stats,
                          kgw_stream_t stream);
+/* ... and, tick != NULL, advances that int32 by one in the same launch: the step counter of a kgw_adam_notick earlier in the
+ * captured step (one single-thread launch less per step).                                                           */
+int kgw_accumulate_stats_tick(const KgwBatchMeta* meta_dev, int32_t n_layers, int32_t n_hops, int64_t* stats, int32_t* tick,
+                              kgw_stream_t stream);
 
 /* Replaces: the index_select feature slicing of the loader (x[n_id], kgwas/kgwas.py:135).      */
 int kgw_gather_rows(const float* src, const int32_t* ids, int64_t n_rows, int32_t width,
@@ -360,6 +367,10 @@ int kgw_ind_colsum(const float* seg_stat, const float* dY, int64_t ldy, int64_t 
 int kgw_adam(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
              float* const* exp_avg_sq, const int64_t* numel, int32_t* step_dev, float lr, float beta1,
              float beta2, float eps, float weight_decay, kgw_stream_t stream);
+/* The same, leaving *step_dev alone: the caller advances it after this call (kgw_accumulate_stats_tick).            */
+int kgw_adam_notick(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq, const int64_t* numel, int32_t* step_dev, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, kgw_stream_t stream);
 
 /* Attention vectors of all relations of a layer (kgwas/conv.py:138-151 reduced to what the path consumes):
  * U_full[r] = W_src^T att_src for every relation id r the layer computes (live_of_rel[r] = its index i in the

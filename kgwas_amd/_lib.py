@@ -97,7 +97,7 @@ class KgwLayerArgs(C.Structure):
         ('t_ptr', C.c_void_p), ('t_edge', C.c_void_p), ('t_zrow', C.c_void_p),
         ('dH', C.c_void_p), ('ev_before', C.c_void_p), ('ev_after', C.c_void_p), ('da_src', C.c_void_p),
         ('logit_bias', C.c_void_p), ('chunk_perm', C.c_void_p), ('chunk_perm_len', C.c_void_p), ('partial_rels', C.c_uint64),
-        ('t_rel', C.c_void_p), ('oct_flags', C.c_void_p),
+        ('t_rel', C.c_void_p), ('oct_flags', C.c_void_p), ('rel_sums', C.c_void_p),
     ]
 
 
@@ -123,7 +123,7 @@ EXPORTS = ['kgw_version', 'kgw_status_string', 'kgw_struct_sizes', 'kgw_sample_b
            'kgw_softmax_pack', 'kgw_softmax_merge', 'kgw_scatter_rows', 'kgw_linear_splitk', 'kgw_linear_splitk_workspace_floats', 'kgw_linear_splitk_ind', 'kgw_ind_colsum', 'kgw_fold_fwd', 'kgw_fold_bwd', 'kgw_relation_sums',
            'kgw_gat_aggregate_fwd', 'kgw_gat_aggregate_bwd_dst', 'kgw_gat_aggregate_bwd_src',
            'kgw_gather_rows', 'kgw_gather_rows_multi', 'kgw_scatter_relu_rows', 'kgw_scatter_relu_rows_workspace_floats', 'kgw_edge_alpha', 'kgw_debug_reduce', 'kgw_debug_reduce8', 'kgw_tn_gemm', 'kgw_tn_gemm_ex', 'kgw_tn_gemm_multi', 'kgw_tn_gemm_workspace_floats',
-           'kgw_linear', 'kgw_mlp2_fwd', 'kgw_adam', 'kgw_relvec_fwd', 'kgw_relvec_bwd', 'kgw_relvec_bwd_acc', 'kgw_wmse_fwd', 'kgw_wmse_bwd', 'kgw_readout_wmse_fwd', 'kgw_readout_wmse_bwd', 'kgw_readout_wmse_train', 'kgw_accumulate_stats']
+           'kgw_linear', 'kgw_mlp2_fwd', 'kgw_adam', 'kgw_adam_notick', 'kgw_relvec_fwd', 'kgw_relvec_bwd', 'kgw_relvec_bwd_acc', 'kgw_wmse_fwd', 'kgw_wmse_bwd', 'kgw_readout_wmse_fwd', 'kgw_readout_wmse_bwd', 'kgw_readout_wmse_train', 'kgw_accumulate_stats', 'kgw_accumulate_stats_tick']
 
 _lib = None
 
@@ -191,6 +191,7 @@ def lib():
     L.kgw_fold_bwd.argtypes = [C.POINTER(KgwFoldArgs), C.c_void_p]
     L.kgw_adam.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    L.kgw_adam_notick.argtypes = L.kgw_adam.argtypes
     L.kgw_relvec_fwd.argtypes = [C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     L.kgw_relvec_bwd.argtypes = [C.c_int32] + [C.c_void_p] * 12 + [C.c_int32, C.c_void_p]
@@ -206,6 +207,7 @@ def lib():
     L.kgw_readout_wmse_bwd.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_int64, C.c_int32] + [C.c_void_p] * 6
     L.kgw_readout_wmse_train.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_int64, C.c_int32] + [C.c_void_p] * 8
     L.kgw_accumulate_stats.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.kgw_accumulate_stats_tick.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

@@ -898,10 +898,31 @@ __device__ __forceinline__ void bwd_src_octet(const LayerTab& T, const AggPtrs& 
     }
 }
 
-__global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, int n_src_rows) {
+__global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, int n_src_rows, int main_blocks,
+                                                         float* __restrict__ rel_sums) {
     __shared__ float s_dp[KGW_BLK];                           // 64 floats per wavefront (bwd_src_row_pair)
+    if ((int)blockIdx.x >= main_blocks) {
+        // riders of the launch (rel_sums != NULL): block main_blocks + r adds up d a_dst over the destination rows of
+        // relation r -- the gradient of a per-relation logit constant (KgwLayerArgs.rel_sums) -- in a fixed tree order
+        const int r = (int)blockIdx.x - main_blocks, t = threadIdx.x;
+        float sacc = 0.f;
+        if (T.live[r]) {
+            const int rows = P.meta->n_rows[P.layer - 1][T.rel_dst_type[r]];
+            const float* p = P.da_dst + T.z0[r];
+            const int st = T.zstride[r];
+            for (int i = t; i < rows; i += KGW_BLK) sacc += p[(int64_t)i * st];
+        }
+        s_dp[t] = sacc;
+        __syncthreads();
+        for (int o = KGW_BLK / 2; o > 0; o >>= 1) {
+            if (t < o) s_dp[t] += s_dp[t + o];
+            __syncthreads();
+        }
+        if (t == 0) rel_sums[r] = s_dp[0];
+        return;
+    }
     float* wdp = s_dp + (threadIdx.x & ~63);
-    const int nw = gridDim.x * 4;
+    const int nw = main_blocks * 4;
     // A wavefront takes source rows two at a time, LAST rows first: the layout is type-major with the SNPs (short rows,
     // most of the rows) in front and the genes / GO terms (longer rows) at the end -- the long rows must start at the
     // beginning of the kernel, not in its last round.  Pairs inside an octet that the sampler flagged for the short path
@@ -1082,7 +1103,8 @@ extern "C" int kgw_gat_aggregate_bwd_src(const KgwLayerArgs* a, kgw_stream_t str
     if (rc) return rc;
     AggPtrs P = build_ptrs(a);
     if (a->ev_before) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_before, (hipStream_t)stream_));
-    k_agg_bwd_src<<<grid_fine((a->n_src_rows + 1) / 2), KGW_BLK, 0, (hipStream_t)stream_>>>(T, P, a->n_src_rows);
+    const int gmain = grid_fine((a->n_src_rows + 1) / 2);
+    k_agg_bwd_src<<<gmain + (a->rel_sums ? T.n_rels : 0), KGW_BLK, 0, (hipStream_t)stream_>>>(T, P, a->n_src_rows, gmain, a->rel_sums);
     KGW_LAUNCH_CHECK();
     if (a->ev_after) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_after, (hipStream_t)stream_));
     return KGW_OK;

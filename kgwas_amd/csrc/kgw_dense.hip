@@ -1805,9 +1805,9 @@ __global__ void k_adam_tick(int32_t* step) { if (threadIdx.x == 0 && blockIdx.x 
 
 }  // namespace
 
-extern "C" int kgw_adam(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
-                        float* const* exp_avg_sq, const int64_t* numel, int32_t* step_dev, float lr, float beta1,
-                        float beta2, float eps, float weight_decay, kgw_stream_t stream_) {
+static int adam_launch(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const int64_t* numel, int32_t* step_dev, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, bool tick, kgw_stream_t stream_) {
     if (n_tensors == 0) return KGW_OK;
     if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !step_dev) return KGW_E_NULL;
     if (n_tensors < 0 || n_tensors > ADAM_MAX) return KGW_E_RANGE;
@@ -1828,9 +1828,26 @@ extern "C" int kgw_adam(int32_t n_tensors, float* const* params, const float* co
     if (g < 1) g = 1;
     k_adam<<<(int)g, 256, 0, st>>>(T, step_dev, lr, beta1, beta2, eps, weight_decay);
     KGW_LAUNCH_CHECK();
-    k_adam_tick<<<1, 64, 0, st>>>(step_dev);
-    KGW_LAUNCH_CHECK();
+    if (tick) {
+        k_adam_tick<<<1, 64, 0, st>>>(step_dev);
+        KGW_LAUNCH_CHECK();
+    }
     return KGW_OK;
+}
+
+extern "C" int kgw_adam(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                        float* const* exp_avg_sq, const int64_t* numel, int32_t* step_dev, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, kgw_stream_t stream_) {
+    return adam_launch(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, step_dev, lr, beta1, beta2, eps, weight_decay, true,
+                       stream_);
+}
+
+// the same without the launch that advances *step_dev: the caller does that later in the step (kgw_accumulate_stats_tick)
+extern "C" int kgw_adam_notick(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                               float* const* exp_avg_sq, const int64_t* numel, int32_t* step_dev, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, kgw_stream_t stream_) {
+    return adam_launch(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, step_dev, lr, beta1, beta2, eps, weight_decay, false,
+                       stream_);
 }
 
 // ======================================================================================================

@@ -679,21 +679,28 @@ extern "C" int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, c
 
 // ---- running totals of a captured training loop (one launch instead of index / cast / add / or framework ops) ----
 namespace {
-__global__ void k_accumulate_stats(const KgwBatchMeta* __restrict__ M, int n_layers, int n_hops, int64_t* __restrict__ stats) {
+__global__ void k_accumulate_stats(const KgwBatchMeta* __restrict__ M, int n_layers, int n_hops, int64_t* __restrict__ stats,
+                                   int32_t* __restrict__ tick) {
     const int t = threadIdx.x;
+    if (tick && t == 63) *tick += 1;                                   // (the optimiser's step counter: kgw_adam_notick)
     if (t < n_layers) stats[t] += M->n_edges[t];                       // edges aggregated by layer t+1
     else if (t == n_layers) stats[t] += M->edge_end[n_hops - 1];       // edges sampled
     else if (t == n_layers + 1) stats[t] |= M->error;                  // sticky capacity-overflow mask
 }
 }  // namespace
 
-extern "C" int kgw_accumulate_stats(const KgwBatchMeta* meta_dev, int32_t n_layers, int32_t n_hops, int64_t* stats,
-                                    kgw_stream_t stream_) {
+extern "C" int kgw_accumulate_stats_tick(const KgwBatchMeta* meta_dev, int32_t n_layers, int32_t n_hops, int64_t* stats,
+                                         int32_t* tick, kgw_stream_t stream_) {
     if (!meta_dev || !stats) return KGW_E_NULL;
     if (n_layers < 1 || n_layers > KGW_MAX_LAYERS || n_hops < 1 || n_hops > n_layers) return KGW_E_RANGE;
-    k_accumulate_stats<<<1, 64, 0, (hipStream_t)stream_>>>(meta_dev, n_layers, n_hops, stats);
+    k_accumulate_stats<<<1, 64, 0, (hipStream_t)stream_>>>(meta_dev, n_layers, n_hops, stats, tick);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
+}
+
+extern "C" int kgw_accumulate_stats(const KgwBatchMeta* meta_dev, int32_t n_layers, int32_t n_hops, int64_t* stats,
+                                    kgw_stream_t stream_) {
+    return kgw_accumulate_stats_tick(meta_dev, n_layers, n_hops, stats, nullptr, stream_);
 }
 
 // ---- x[n_id] feature slicing ---------------------------------------------------------------------

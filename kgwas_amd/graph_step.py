@@ -131,8 +131,10 @@ class GraphTrainStep:
             loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id(self.input_type),
                                               self.dg.y[self.input_type], self.ld_w, unit_grad=True)   # kgwas.py:137-145
             loss.backward(gradient=self._unit)                         # (a resident 1.0: no ones_like fill per step)
+        ticked = False
         if self.capture_optimizer:
-            self.opt.step()
+            self.opt.step(tick=False)                                  # (the counter advances in the statistics launch below)
+            ticked = True
         elif self.split_backward:
             pass                                                       # (second half: _step_body_b)
         elif self._multi:
@@ -145,8 +147,9 @@ class GraphTrainStep:
                     self._flat_grads[p] = self._flat[off:off + p.numel()].view_as(p)
                     off += p.numel()
             torch.cat([p.grad.reshape(-1) for p in live], out=self._flat)
-        _lib.check(_lib.lib().kgw_accumulate_stats(buf.meta.data_ptr(), self.run.gnn_num_layers, self.dg.n_hops,
-                                                   self.stats.data_ptr(), _lib.stream_ptr()), 'kgw_accumulate_stats')
+        _lib.check(_lib.lib().kgw_accumulate_stats_tick(buf.meta.data_ptr(), self.run.gnn_num_layers, self.dg.n_hops,
+                                                        self.stats.data_ptr(), self.opt.step_dev.data_ptr() if ticked else None,
+                                                        _lib.stream_ptr()), 'kgw_accumulate_stats_tick')
         if self.overlap:
             main.wait_stream(self._side)                               # join
         elif not self.twin:

@@ -228,6 +228,12 @@ class _GatAggregate(torch.autograd.Function):
         TIMER.attach(a, 'bwd_dst', layer, n_edges, z_rows, n_src)
         _lib.check(L.kgw_gat_aggregate_bwd_dst(C.byref(a), _lib.stream_ptr()), 'kgw_gat_aggregate_bwd_dst')
         TIMER.attach(a, 'bwd_src', layer, n_edges, z_rows, n_src)
+        dlb = None
+        if ctx.has_lbias:
+            # d(constant of relation r) = sum of d pre-activation over ALL its edges = the column sums of d a_dst: extra
+            # blocks of the src-major launch
+            dlb = torch.empty(sc.NR, device=dev)
+            a.rel_sums = _p(dlb)
         _lib.check(L.kgw_gat_aggregate_bwd_src(C.byref(a), _lib.stream_ptr()), 'kgw_gat_aggregate_bwd_src')
         # d u_r = sum_j d a_src[j, r] H[j], d v_r = sum_i d a_dst[i, r] H[i]: all relations, both sides, as ONE
         # tall-skinny product over H
@@ -236,10 +242,7 @@ class _GatAggregate(torch.autograd.Function):
             dU, dV = dUV[:sc.NR], dUV[ld_da:ld_da + sc.NR]
         else:
             dU, dV = torch.zeros_like(U), torch.zeros_like(V)
-        dlb = None
-        if ctx.has_lbias:
-            # d(constant of relation r) = sum of d pre-activation over ALL its edges = the column sums of d a_dst
-            dlb = torch.empty(sc.NR, device=dev)
+        if ctx.has_lbias and not n_src:                  # (no source rows: the launch above did not run)
             _lib.check(L.kgw_relation_sums(C.byref(a), _p(da_dst), _p(dlb), _lib.stream_ptr()), 'kgw_relation_sums')
         return dH[:n_src], dU, dV, None, None, None, None, None, None, None, dlb
 
@@ -873,11 +876,12 @@ class _LayerTransform(torch.autograd.Function):
     def backward(ctx, *dYs):
         w_src_t, Z, gamma, stat = ctx.saved_tensors[:4]
         ys = ctx.saved_tensors[4:]
-        dgamma = torch.zeros_like(gamma) if gamma is not None else None
         C = w_src_t.shape[-1]
         blocks = ctx.blocks
         covered = sum(hi - lo for lo, hi, _, _ in blocks)
         full = covered == w_src_t.shape[0] and all(d is not None for d in dYs)
+        # (every relation belongs to a block that has a gradient: kgw_ind_colsum writes all of d gamma, no zero fill)
+        dgamma = (torch.empty_like(gamma) if full else torch.zeros_like(gamma)) if gamma is not None else None
         dev = w_src_t.device
         dW = torch.empty_like(w_src_t) if full else torch.zeros_like(w_src_t)
         db = torch.empty(ctx.n_bias, C, device=dev) if full else torch.zeros(ctx.n_bias, C, device=dev)

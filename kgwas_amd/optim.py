@@ -39,9 +39,10 @@ class FusedAdam:
                 self._state(p)
 
     @torch.no_grad()
-    def step(self, grads=None):
+    def step(self, grads=None, tick=True):
         """``grads``: optional {parameter: gradient tensor} to use instead of ``p.grad`` (the all-reduced bucket's
-        views in the multi-GPU step); parameters missing from it are skipped."""
+        views in the multi-GPU step); parameters missing from it are skipped.  ``tick=False``: the caller advances
+        ``step_dev`` itself after this call (kgw_accumulate_stats_tick in the captured step: one launch less)."""
         if grads is not None:
             live = [p for p in self.params if p in grads]
         else:
@@ -60,8 +61,8 @@ class FusedAdam:
                 st = self._state(p)
                 P[k], G[k], M[k], V[k], N[k] = p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel()
             # chunks > 0 must not advance the step counter again: only the last call ticks it
-            rc = _lib.lib().kgw_adam(n, P, G, M, V, N, self.step_dev.data_ptr(), self.lr, self.betas[0], self.betas[1],
-                                     self.eps, self.weight_decay, _lib.stream_ptr())
+            last = i + 64 >= len(live)
+            fn = _lib.lib().kgw_adam if (tick and last) else _lib.lib().kgw_adam_notick      # only the last chunk ticks
+            rc = fn(n, P, G, M, V, N, self.step_dev.data_ptr(), self.lr, self.betas[0], self.betas[1],
+                    self.eps, self.weight_decay, _lib.stream_ptr())
             _lib.check(rc, 'kgw_adam')
-            if i + 64 < len(live):
-                self.step_dev.sub_(1)
