@@ -97,6 +97,9 @@ class GraphTrainStep:
         # (timing experiments only: train on stale batches to see what the concurrent sampler costs the step)
         self._skip_resample = os.environ.get('KGW_SKIP_RESAMPLE', '0') == '1'
         self._twin_pending = [False, False]        # the side stream holds an unfinished sample of this buffer
+        # (parameter-only kernels on a parallel branch of the captured step: measured 1.403 ms on one box and 1.85 ms on three
+        # others -- HIP-graph branch scheduling is bimodal here -- against 1.414 without: off)
+        self.param_branch = os.environ.get('KGW_PARAM_BRANCH', '0') == '1'
         self._capture()
 
     # train on the batch held by bufs[cur]; concurrently sample ``self.seeds`` into bufs[1 - cur]
@@ -113,7 +116,8 @@ class GraphTrainStep:
         if self.split_backward:
             mlp_out = []
             loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id(self.input_type),
-                                              self.dg.y[self.input_type], self.ld_w, mlp_out=mlp_out, unit_grad=True)
+                                              self.dg.y[self.input_type], self.ld_w, mlp_out=mlp_out, unit_grad=True,
+                                              param_branch=self.param_branch)
             hs = [h for h in mlp_out if h.requires_grad]
             late = self._late_params()
             early = [p for p in self.model.parameters() if p.requires_grad and id(p) not in late]
@@ -129,7 +133,8 @@ class GraphTrainStep:
             self._cut[cur] = (hs, list(g[:len(hs)]))
         else:
             loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id(self.input_type),
-                                              self.dg.y[self.input_type], self.ld_w, unit_grad=True)   # kgwas.py:137-145
+                                              self.dg.y[self.input_type], self.ld_w, unit_grad=True,
+                                              param_branch=self.param_branch)                # kgwas.py:137-145
             loss.backward(gradient=self._unit)                         # (a resident 1.0: no ones_like fill per step)
         ticked = False
         if self.capture_optimizer:

@@ -94,6 +94,9 @@ class SimpleMLP(nn.Module):
                         self.FC_output.weight, self.FC_output.bias, out, rows_dev)
 
 
+_PARAM_STREAMS = {}          # device -> side stream of forward_loss(param_branch=True)
+
+
 class RelationPack(nn.Module):
     """Parameters of a list of relations of one layer, packed (kgwas/conv.py:81-120 per relation):
     ``w_src_t[i]`` = lin_src.weight^T  ([in k, out c], glorot), ``w_dst_t[j]`` = lin_dst.weight^T of the
@@ -419,10 +422,41 @@ class HeteroGNN(nn.Module):
             h = h_next
         return h, []
 
+    def _layer_params(self, batch: SampledBatch, l: int, folded: bool):
+        """Everything layer l needs that depends on the PARAMETERS only (and on the batch's static row counts): the destination
+        blocks, the zeroed aggregate workspace, u_r / v_r / summed biases (ops.rel_vectors) and, for a folded layer 1, the
+        fold of FC_output into them.  No activation enters: the captured step runs this on a side branch beside the feature
+        MLPs (``forward_loss(param_branch=True)``)."""
+        sc, m = self.schema, batch.meta
+        P: RelationPack = self.live_packs[l - 1]
+        rng = self._dst_range[l - 1]
+        # destination blocks of the layer: one per node type that receives messages
+        tys = [t for t in range(sc.NT) if int(m.lay_rows[l - 1][t])]
+        blocks = [(rng[t][0], rng[t][1], int(m.z_base[l - 1][t]), int(m.lay_rows[l - 1][t])) for t in tys]
+        # u_r = W_src^T att_src ; v_r = W_dst^T att_dst (W_src^T att_dst for same-type relations) and the summed
+        # bias of every destination block: one launch
+        # ... and the zero fill of the aggregate's workspace rides in the same launch
+        zws = ops.aggregate_workspace(batch, l, self.lin.weight.device)
+        # (the weights reach the transform / the fold THROUGH that node: their gradient is added inside its backward kernel)
+        U, V, bsum, Wv = ops.rel_vectors(P, blocks, zero=zws, pass_weights=True)
+        Wp = gam = kap = None
+        if folded and l == 1:
+            # (an MLP no live layer-1 relation touches -- the GO one of a 1-layer model -- stays out of the graph: like
+            # in the reference its parameters get no gradient and Adam skips them)
+            mlps = (self.snp_feat_mlp, self.gene_feat_mlp, self.go_feat_mlp)
+            fc = []
+            for k, mm in enumerate(mlps):
+                used = k in self._fold_used
+                fc += [mm.FC_output.weight if used else mm.FC_output.weight.detach(),
+                       mm.FC_output.bias if used else mm.FC_output.bias.detach()]
+            U, V, kap, Wp, gam = ops.fold_fc_output_hip(P, U, V, fc, self._fold_tab, weight=Wv)
+        return tys, blocks, zws, U, V, bsum, Wv, kap, Wp, gam
+
     def _fused_layers(self, batch: SampledBatch, h: Dict[str, torch.Tensor], want_attention=False, hbuf=None,
-                      last_premasked=False, folded=False):
+                      last_premasked=False, folded=False, prep=None):
         """``folded``: h holds the feature MLPs' hidden state h2 (``_embed_all(fold=True)``), not their output: layer 1 runs
-        with FC_output folded into its relation parameters (ops.fold_fc_output)."""
+        with FC_output folded into its relation parameters (ops.fold_fc_output).  ``prep``: per layer, what
+        ``_layer_params`` returns, computed ahead by the caller."""
         if self.backbone == 'SAGE':
             if want_attention:
                 raise NotImplementedError('attention weights exist for the GAT backbone only (kgwas/model.py:65-72)')
@@ -434,16 +468,7 @@ class HeteroGNN(nn.Module):
         attn = []
         for l in range(1, self.num_layers + 1):
             P: RelationPack = self.live_packs[l - 1]
-            rng = self._dst_range[l - 1]
-            # destination blocks of the layer: one per node type that receives messages
-            tys = [t for t in range(sc.NT) if int(m.lay_rows[l - 1][t])]
-            blocks = [(rng[t][0], rng[t][1], int(m.z_base[l - 1][t]), int(m.lay_rows[l - 1][t])) for t in tys]
-            # u_r = W_src^T att_src ; v_r = W_dst^T att_dst (W_src^T att_dst for same-type relations) and the summed
-            # bias of every destination block: one launch
-            # ... and the zero fill of the aggregate's workspace rides in the same launch
-            zws = ops.aggregate_workspace(batch, l, self.lin.weight.device)
-            # (the weights reach the transform / the fold THROUGH that node: their gradient is added inside its backward kernel)
-            U, V, bsum, Wv = ops.rel_vectors(P, blocks, zero=zws, pass_weights=True)
+            tys, blocks, zws, U, V, bsum, Wv, kap, Wp, gam = prep[l - 1] if prep is not None else self._layer_params(batch, l, folded)
             # layer input, type-major (src_base): every type that sends or receives messages in this layer
             parts, spans = [], []
             for t, name in enumerate(sc.node_types):
@@ -460,17 +485,6 @@ class HeteroGNN(nn.Module):
             # (from layer 2 on, H is the previous layer's ReLU output: with the fused transform its backward is folded
             # into this node's)
             fused = self.aggr in ('sum', 'mean')
-            Wp = gam = kap = None
-            if folded and l == 1:
-                # (an MLP no live layer-1 relation touches -- the GO one of a 1-layer model -- stays out of the graph: like
-                # in the reference its parameters get no gradient and Adam skips them)
-                mlps = (self.snp_feat_mlp, self.gene_feat_mlp, self.go_feat_mlp)
-                fc = []
-                for k, mm in enumerate(mlps):
-                    used = k in self._fold_used
-                    fc += [mm.FC_output.weight if used else mm.FC_output.weight.detach(),
-                           mm.FC_output.bias if used else mm.FC_output.bias.detach()]
-                U, V, kap, Wp, gam = ops.fold_fc_output_hip(P, U, V, fc, self._fold_tab, weight=Wv)
             Z, stat, e_edge = ops.gat_aggregate(batch, l, H, U, V, self.negative_slope, self.temperature,
                                                 relu_input=((l > 1 or folded) and fused), zbuf=zws, logit_bias=kap)
             if want_attention:
@@ -529,24 +543,45 @@ class HeteroGNN(nn.Module):
         _, attn = self._fused_layers(batch, h, want_attention=True, hbuf=hbuf, folded=self.fold_fc)
         return attn
 
-    def forward_loss(self, x_dict, edge_index_dict, batch_size, n_id, y_all, w_all, mlp_out=None, unit_grad=False):
+    def forward_loss(self, x_dict, edge_index_dict, batch_size, n_id, y_all, w_all, mlp_out=None, unit_grad=False,
+                     param_branch=False):
         """The training step's forward (kgwas/kgwas.py:137-145): HeteroGNN.forward followed by
         mean(w_all[n_id] * (pred - y_all[n_id])**2), with the read-out Linear + ReLU (model.py:86) and the loss fused
         into one node.  Returns (loss [float64 scalar], pred [batch_size]).  ``mlp_out`` (list): receives the feature MLPs'
         output tensors -- the cut between the two halves of a backward pass whose first half's gradients are all-reduced
         while the second half runs (multi-GPU GraphTrainStep).  ``unit_grad``: the caller will backpropagate exactly
-        ``loss.backward()`` (gradient 1): the read-out node then does its forward and backward in two launches."""
+        ``loss.backward()`` (gradient 1): the read-out node then does its forward and backward in two launches.
+        ``param_branch``: the kernels that depend on the parameters only (attention vectors, FC_output fold, workspace
+        clears: tiny grids, ~30 us forward and ~45 us backward on the critical path) run on a side stream beside the feature
+        MLPs -- inside a captured step a parallel branch of the graph; autograd runs their backward on that stream too."""
         batch: Optional[SampledBatch] = getattr(x_dict, 'kgw_batch', None) or getattr(edge_index_dict, 'kgw_batch', None)
         if batch is None:
             batch = self._block_from_coo(x_dict, edge_index_dict)
         if self.lin.out_features != 1:
             raise NotImplementedError('the fused read-out + loss is for out_channels == 1 (kgwas/kgwas.py:52)')
         hbuf, blocks = self._layer_input(batch, 1)
+        prep = None
+        if param_branch and self.backbone == 'GAT':
+            main = torch.cuda.current_stream()
+            dev_key = str(self.lin.weight.device)                           # (not on the module: deepcopy(model) pickles it)
+            side = _PARAM_STREAMS.get(dev_key)
+            if side is None:
+                side = _PARAM_STREAMS[dev_key] = torch.cuda.Stream(device=self.lin.weight.device)
+            side.wait_stream(main)                                          # fork
+            with torch.cuda.stream(side):
+                prep = [self._layer_params(batch, l, self.fold_fc) for l in range(1, self.num_layers + 1)]
+                if not torch.cuda.is_current_stream_capturing():            # (a captured graph owns its memory pool)
+                    for pr in prep:
+                        for t in pr[2:]:
+                            if torch.is_tensor(t):
+                                t.record_stream(main)
         h = self._embed_all(batch, x_dict, blocks, fold=self.fold_fc)
         if mlp_out is not None:
             mlp_out.extend(h.values())
+        if prep is not None:
+            torch.cuda.current_stream().wait_stream(side)                   # join
         gat = self.backbone == 'GAT' and self.aggr in ('sum', 'mean')
-        h, _ = self._fused_layers(batch, h, hbuf=hbuf, last_premasked=gat, folded=self.fold_fc)
+        h, _ = self._fused_layers(batch, h, hbuf=hbuf, last_premasked=gat, folded=self.fold_fc, prep=prep)
         return ops.readout_weighted_mse(h['SNP'], self.lin.weight, self.lin.bias, n_id, y_all, w_all, batch_size,
                                         relu=not self.no_relu, h_is_relu=gat, unit_grad=unit_grad)
 
