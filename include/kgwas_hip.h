@@ -338,6 +338,13 @@ int kgw_mlp2_fwd(const float* X, int64_t ldx, int32_t K1, const float* W1, int64
                  int64_t ldw2, const float* b2, float* H1, int64_t ldh1, float* H2, int64_t ldh2, int64_t rows,
                  const int32_t* rows_dev, const int32_t* ids, float* Xg, int64_t ldxg, kgw_stream_t stream);
 
+/* The same two layers for a 128-WIDE input on few rows, the rows gathered from up to four resident feature matrices
+ * (src[j] [*, 128] with row stride ldx, ids[j] [n_rows[j]]: the three GO node types share go_feat_mlp, kgwas/model.py:58-60):
+ * rows of job 0, then job 1, ...  Outputs [sum n_rows, 128] with row stride ldo: Xg = the gathered input rows, H1, H2.    */
+int kgw_mlp2w_fwd(int32_t n_jobs, const float* const* src, const int32_t* const* ids, const int64_t* n_rows, int64_t ldx,
+                  const float* W1, int64_t ldw1, const float* b1, const float* W2, int64_t ldw2, const float* b2, float* Xg,
+                  float* H1, float* H2, int64_t ldo, kgw_stream_t stream);
+
 /* The same product for FEW rows when one of K, N is 128 and the other a multiple of 128 -- the per-relation transform
  * of a layer after aggregate-then-transform, [N_dst, R*128] x [R*128, 128] with N_dst ~ 0.5-1.2 k destination rows of a
  * 512-seed batch (kgwas/conv.py:138-144 for all relations into one destination type + bias :190 + HeteroConv sum

@@ -1096,6 +1096,154 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// kgw_mlp2w_fwd: the same two hidden layers for a 128-wide input on FEW rows (the three GO node types of a batch share
+// go_feat_mlp, kgwas/model.py:58-60: ~7 k rows), rows gathered from up to four resident feature matrices -- one launch
+// instead of gather + Linear + Linear.  A wavefront takes (32-row tile, half of the OUTPUT columns): it computes all of
+// h1 for its rows (256 MFMAs, first-layer operands from LDS) and its half of h2 (128 MFMAs) -- the duplicated first
+// product buys twice the wavefronts for a launch that has ~220 tiles for 1024 SIMDs.  Hidden state handed over in
+// registers as in k_mlp2_fwd; the column-half-0 wavefront also writes the gathered rows and h1 for the backward.
+// ------------------------------------------------------------------------------------------------------
+struct Mlp2wArgs {
+    const float* src[4]; const int32_t* ids[4]; int64_t row0[5];     // job j covers rows [row0[j], row0[j+1])
+    int n_jobs; int64_t ldx;
+    const float* W1; int64_t ldw1; const float* b1;
+    const float* W2; int64_t ldw2; const float* b2;
+    float* Xg; float* H1; float* H2; int64_t ldo;                    // [rows, 128] each (row stride ldo)
+    int64_t rows;
+};
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) k_mlp2w_fwd(Mlp2wArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* W1l = lds;                                        // [128 n][WST]
+    float* W2l = lds + 128 * WST;                            // [128 n][WST]
+    float* bl = lds + 2 * 128 * WST;                         // b1 | b2
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * 2 + (wave >> 1);
+    const int half = wave & 1, t0 = half * 2;
+    const int64_t row = tile * 32 + li;
+    const bool live = row < a.rows;
+    const int64_t rc = live ? row : a.rows - 1;
+    f32x4 xa[16];
+    {
+        int j = 0;
+        while (j + 1 < a.n_jobs && rc >= a.row0[j + 1]) ++j;
+        const float* xp = a.src[j] + (int64_t)a.ids[j][rc - a.row0[j]] * a.ldx + lk * 64;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xa[q] = *(const f32x4*)(xp + 4 * q);
+    }
+    {   // stage both weight matrices: 32 float4 per thread in flight before the LDS writes
+        f32x4 wv[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = tid + 256 * it;
+            wv[it] = *(const f32x4*)(a.W1 + (int64_t)(idx >> 5) * a.ldw1 + (idx & 31) * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = tid + 256 * it;
+            *(f32x4*)(W1l + (idx >> 5) * WST + (idx & 31) * 4) = wv[it];
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = tid + 256 * it;
+            wv[it] = *(const f32x4*)(a.W2 + (int64_t)(idx >> 5) * a.ldw2 + (idx & 31) * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = tid + 256 * it;
+            *(f32x4*)(W2l + (idx >> 5) * WST + (idx & 31) * 4) = wv[it];
+        }
+    }
+    if (tid < 128) bl[tid] = a.b1 ? a.b1[tid] : 0.f; else bl[tid] = a.b2 ? a.b2[tid - 128] : 0.f;
+    __syncthreads();
+    if (half == 0 && live) {                                 // the gathered rows, for the first layer's weight gradient
+        float* gp = a.Xg + row * a.ldo + lk * 64;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) *(f32x4*)(gp + 4 * q) = xa[q];
+    }
+    // product 1: every column tile; operands W1[32 t + li][64 lk + 4 q + c] from LDS, a step ahead
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    const float* w1p = W1l + li * WST + lk * 64;
+    f32x4 wn[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wn[t] = *(const f32x4*)(w1p + t * 32 * WST);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        f32x4 w[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w[t] = wn[t];
+        if (q + 1 < 16) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wn[t] = *(const f32x4*)(w1p + t * 32 * WST + 4 * (q + 1));
+        }
+#define KGW_MLPW_STEP(C)                                                                                  \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                    \
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].C, xa[q].C, acc[t], 0, 0, 0);
+        KGW_MLPW_STEP(x) KGW_MLPW_STEP(y) KGW_MLPW_STEP(z) KGW_MLPW_STEP(w)
+#undef KGW_MLPW_STEP
+    }
+    // h1 = relu(. + b1): accumulator element 4 g + c of tile t = column 32 t + 8 g + 4 lk + c of this lane's row
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = *(const f32x4*)(bl + t * 32 + 8 * g + 4 * lk);
+            f32x4 v;
+            v.x = fmaxf(acc[t][4 * g + 0] + b4.x, 0.f); v.y = fmaxf(acc[t][4 * g + 1] + b4.y, 0.f);
+            v.z = fmaxf(acc[t][4 * g + 2] + b4.z, 0.f); v.w = fmaxf(acc[t][4 * g + 3] + b4.w, 0.f);
+            xa[4 * t + g] = v;
+        }
+    if (half == 0 && live) {
+        float* hp = a.H1 + row * a.ldo + 4 * lk;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) *(f32x4*)(hp + 32 * (q >> 2) + 8 * (q & 3)) = xa[q];
+    }
+    // product 2: this wavefront's two column tiles; MFMA step (q, c) multiplies k = 32 (q >> 2) + 8 (q & 3) + 4 lk + c
+    f32x16 ac2[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ac2[t][e] = 0.f;
+    const float* w2p = W2l + (t0 * 32 + li) * WST + 4 * lk;
+    f32x4 vn[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) vn[t] = *(const f32x4*)(w2p + t * 32 * WST);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        f32x4 w[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) w[t] = vn[t];
+        if (q + 1 < 16) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) vn[t] = *(const f32x4*)(w2p + t * 32 * WST + 32 * ((q + 1) >> 2) + 8 * ((q + 1) & 3));
+        }
+#define KGW_MLPW_STEP(C)                                                                                  \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                    \
+            ac2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].C, xa[q].C, ac2[t], 0, 0, 0);
+        KGW_MLPW_STEP(x) KGW_MLPW_STEP(y) KGW_MLPW_STEP(z) KGW_MLPW_STEP(w)
+#undef KGW_MLPW_STEP
+    }
+    if (live) {
+        float* yp = a.H2 + row * a.ldo + 4 * lk;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *(const f32x4*)(bl + 128 + (t0 + t) * 32 + 8 * g + 4 * lk);
+                f32x4 v;
+                v.x = fmaxf(ac2[t][4 * g + 0] + b4.x, 0.f); v.y = fmaxf(ac2[t][4 * g + 1] + b4.y, 0.f);
+                v.z = fmaxf(ac2[t][4 * g + 2] + b4.z, 0.f); v.w = fmaxf(ac2[t][4 * g + 3] + b4.w, 0.f);
+                *(f32x4*)(yp + (t0 + t) * 32 + 8 * g) = v;
+            }
+    }
+}
+
 // Same product for FEW row tiles (up to 512: the GO / gene matrices of a batch): with one 32-row tile per wavefront
 // only ntiles of the chip's 1024 SIMDs get work.  Here a wavefront takes one tile x ONE HALF of the output columns
 // (128 MFMAs, 128 registers of W), two wavefronts per SIMD, every task resident at once: no tile loop, no refill.
@@ -1300,6 +1448,39 @@ extern "C" int kgw_mlp2_fwd(const float* X, int64_t ldx, int32_t K1, const float
     }
     const int64_t nblk = ((rows + 31) / 32 + 3) / 4;
     k_mlp2_fwd<<<(int)(nblk < 256 ? nblk : 256), 256, lds, (hipStream_t)stream_>>>(a);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+extern "C" int kgw_mlp2w_fwd(int32_t n_jobs, const float* const* src, const int32_t* const* ids, const int64_t* n_rows,
+                             int64_t ldx, const float* W1, int64_t ldw1, const float* b1, const float* W2, int64_t ldw2,
+                             const float* b2, float* Xg, float* H1, float* H2, int64_t ldo, kgw_stream_t stream_) {
+    if (n_jobs <= 0) return KGW_OK;
+    if (n_jobs > 4) return KGW_E_RANGE;
+    if (!src || !ids || !n_rows || !W1 || !W2 || !Xg || !H1 || !H2) return KGW_E_NULL;
+    if ((ldx & 3) || (ldw1 & 3) || (ldw2 & 3) || (ldo & 3) || !aligned16(W1) || !aligned16(W2) || !aligned16(Xg) || !aligned16(H1) ||
+        !aligned16(H2))
+        return KGW_E_UNSUPPORTED;
+    Mlp2wArgs a{};
+    a.n_jobs = n_jobs; a.ldx = ldx;
+    a.row0[0] = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        if (!src[j] || !ids[j] || n_rows[j] < 0) return KGW_E_NULL;
+        if (!aligned16(src[j])) return KGW_E_UNSUPPORTED;
+        a.src[j] = src[j]; a.ids[j] = ids[j]; a.row0[j + 1] = a.row0[j] + n_rows[j];
+    }
+    a.rows = a.row0[n_jobs];
+    if (a.rows == 0) return KGW_OK;
+    a.W1 = W1; a.ldw1 = ldw1; a.b1 = b1; a.W2 = W2; a.ldw2 = ldw2; a.b2 = b2;
+    a.Xg = Xg; a.H1 = H1; a.H2 = H2; a.ldo = ldo;
+    const size_t lds = (size_t)(2 * 128 * WST + 256) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        KGW_HIP(hipFuncSetAttribute((const void*)k_mlp2w_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int64_t ntiles = (a.rows + 31) / 32;
+    k_mlp2w_fwd<<<(unsigned)((ntiles + 1) / 2), 256, lds, (hipStream_t)stream_>>>(a);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }

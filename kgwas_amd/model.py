@@ -341,7 +341,16 @@ class HeteroGNN(nn.Module):
         if len(go) > 1:
             lazy = getattr(x_dict, 'kgw_batch', None) is batch and all(t in batch.dg.x for t in go) and \
                 len({batch.dg.x[t].shape[1] for t in go}) == 1
-            if lazy:            # gather the three types' rows straight into one matrix (no concatenation copy)
+            fused_jobs = None
+            if lazy and fold:
+                mlp = self.go_feat_mlp
+                fj = [(batch.dg.x[t], batch.n_id(t)) for t in go]
+                if ops.mlp2_gathered_ok(fj, mlp.FC_hidden.weight, mlp.FC_hidden2.weight):
+                    fused_jobs = fj         # gather + both hidden layers in one launch (kgw_mlp2w_fwd)
+            if fused_jobs is not None:
+                ns = [batch.n_nodes[t] for t in go]
+                xg = xs = None
+            elif lazy:            # gather the three types' rows straight into one matrix (no concatenation copy)
                 ns = [batch.n_nodes[t] for t in go]
                 xg = torch.empty(sum(ns), batch.dg.x[go[0]].shape[1], device=self.lin.weight.device)
                 off, jobs = 0, []
@@ -359,7 +368,12 @@ class HeteroGNN(nn.Module):
             if all(b is not None and b.n == n for b, n in zip(bl, ns)) and \
                     all(bl[k + 1].lo == bl[k].lo + bl[k].n for k in range(len(bl) - 1)):
                 out = ops.RowBlock(bl[0].buf, bl[0].lo, sum(ns))          # the GO blocks are adjacent: one output
-            y = self.go_feat_mlp.hidden(xg, out) if fold else self.go_feat_mlp(xg, out)
+            if fused_jobs is not None:
+                mlp = self.go_feat_mlp
+                y = ops.mlp2_gathered(fused_jobs, mlp.FC_hidden.weight, mlp.FC_hidden.bias, mlp.FC_hidden2.weight,
+                                      mlp.FC_hidden2.bias, out)
+            else:
+                y = self.go_feat_mlp.hidden(xg, out) if fold else self.go_feat_mlp(xg, out)
             for t, piece in zip(go, ops.split_rows(y, ns)):
                 h[t] = piece
         for t in self.node_types:

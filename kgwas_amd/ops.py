@@ -615,6 +615,59 @@ def mlp2(x, W1, b1, W2, b2, out=None, rows_dev=None, ids=None):
     return _MLP2.apply(x, W1, b1, W2, b2, out, rows_dev, ids)
 
 
+class _MLP2Gathered(torch.autograd.Function):
+    """_MLP2 for a 128-wide input whose rows are gathered from several resident feature matrices (the three GO node types
+    share go_feat_mlp, kgwas/model.py:58-60): gather + FC_hidden + FC_hidden2 in ONE launch (kgw_mlp2w_fwd); backward as
+    _MLP2's (the kernel leaves the gathered rows and h1 for it)."""
+
+    @staticmethod
+    def forward(ctx, W1, b1, W2, b2, out, *jobs):
+        srcs, idss = jobs[0::2], jobs[1::2]
+        n = len(srcs)
+        rows = sum(int(i.numel()) for i in idss)
+        dev = W1.device
+        h2 = out.view() if out is not None else torch.empty(rows, KGW_C, device=dev)
+        xg = torch.empty(rows, KGW_C, device=dev)
+        h1 = torch.empty(rows, KGW_C, device=dev)
+        S = (C.c_void_p * n)(*[_p(x) for x in srcs])
+        I = (C.c_void_p * n)(*[_p(i) for i in idss])
+        N = (C.c_int64 * n)(*[int(i.numel()) for i in idss])
+        assert h2.stride(0) == KGW_C or rows == 0 or h2.stride(0) % 4 == 0
+        if h2.stride(0) != KGW_C:                       # (outputs share one row stride in the kernel)
+            h2c = torch.empty(rows, KGW_C, device=dev)
+        else:
+            h2c = h2
+        _lib.check(_lib.lib().kgw_mlp2w_fwd(n, S, I, N, srcs[0].stride(0), _p(W1), W1.stride(0), _p(b1), _p(W2), W2.stride(0), _p(b2),
+                                            _p(xg), _p(h1), _p(h2c), KGW_C, _lib.stream_ptr()), 'kgw_mlp2w_fwd')
+        if h2c is not h2:
+            h2.copy_(h2c)
+        ctx.save_for_backward(xg, h1, W2)
+        return h2
+
+    @staticmethod
+    def backward(ctx, dh2):
+        x, h1, W2 = ctx.saved_tensors
+        dh2 = dh2.contiguous()
+        dh1 = linear(dh2, W2, mask=h1, w_kn=True)       # (dh2 @ W2) * (h1 > 0)
+        (dW2, db2), (dW1, db1) = weight_grads([(dh2, h1), (dh1, x)])
+        return (dW1, db1, dW2, db2, None) + (None,) * (len(ctx.needs_input_grad) - 5)
+
+
+def mlp2_gathered(jobs, W1, b1, W2, b2, out=None):
+    """``jobs``: [(resident feature matrix [N_t, 128], int32 ids)]: h2 = relu(FC_hidden2(relu(FC_hidden(cat_t X_t[ids_t]))))."""
+    flat = []
+    for x, i in jobs:
+        flat += [x, i]
+    return _MLP2Gathered.apply(W1, b1, W2, b2, out, *flat)
+
+
+def mlp2_gathered_ok(jobs, W1, W2) -> bool:
+    return (_MLP2_FUSED and 1 <= len(jobs) <= 4 and W1.shape == (KGW_C, KGW_C) and W2.shape == (KGW_C, KGW_C)
+            and all(x.dtype == torch.float32 and x.shape[1] == KGW_C and x.stride(1) == 1 and x.stride(0) % 4 == 0 and
+                    x.data_ptr() % 16 == 0 and i.dtype == torch.int32 and x.stride(0) == jobs[0][0].stride(0) for x, i in jobs)
+            and 0 < sum(int(i.numel()) for _, i in jobs) <= 16384)
+
+
 class _MLPTail2(torch.autograd.Function):
     """h2 = relu(FC_hidden2(h1)) (the folded counterpart of _MLPTail); incoming gradient premasked like _MLP2's."""
 

@@ -374,3 +374,31 @@ def test_splitk_transform_kernel_matches_fp64(rows, K, N, kn, real):
     L = _lib.lib()
     assert L.kgw_linear_splitk(X.cuda().data_ptr(), K, W.cuda().data_ptr(), N if kn else K, None, Y2.data_ptr(), N, rows, K + 4, N,
                                0, 1 if kn else 0, None, 0, None, None) == -3
+
+
+def test_fused_wide_gathered_mlp_matches_unfused():
+    """kgw_mlp2w_fwd (ops.mlp2_gathered: three resident 128-wide matrices, rows by id, both hidden layers in one launch) vs
+    gather + ops.mlp2 on the concatenated rows: forward within fp32 summation order (rtol 1e-5), gradients likewise; ragged
+    job sizes, a last partial tile."""
+    from kgwas_amd import ops
+    g = torch.Generator().manual_seed(9)
+    Xs = [torch.randn(n, 128, generator=g).cuda() for n in (1192, 17248, 4512)]
+    ids = [torch.randint(0, x.shape[0], (m,), generator=g, dtype=torch.int32).cuda() for x, m in zip(Xs, (377, 5003, 1201))]
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.1).cuda().requires_grad_(True)
+    W1, b1, W2, b2 = mk(128, 128), mk(128), mk(128, 128), mk(128)
+    jobs = list(zip(Xs, ids))
+    assert ops.mlp2_gathered_ok(jobs, W1, W2)
+    rows = sum(int(i.numel()) for i in ids)
+    G = torch.randn(rows, 128, generator=g).cuda()
+    ya = ops.mlp2_gathered(jobs, W1, b1, W2, b2)
+    (ya * G * (ya > 0)).sum().backward()
+    ga = [t.grad.clone() for t in (W1, b1, W2, b2)]
+    for t in (W1, b1, W2, b2):
+        t.grad = None
+    x = torch.cat([X[i.long()] for X, i in jobs], 0)
+    yo = torch.relu(torch.relu(x.double() @ W1.double().t() + b1.double()) @ W2.double().t() + b2.double())
+    assert_close(ya, yo, 1e-5, 1e-6, 'h2', rel_to_max=2e-6)
+    yb = ops.mlp2(x, W1, b1, W2, b2)
+    (yb * G * (yb > 0)).sum().backward()
+    for a, t, nm in zip(ga, (W1, b1, W2, b2), 'W1 b1 W2 b2'.split()):
+        assert_close(a, t.grad, 1e-4, 1e-6, 'grad ' + nm, rel_to_max=1e-5)
