@@ -90,8 +90,9 @@ def load_pretrained(path, model):
 
 
 def ldsc_regression_weights(ld, w_ld, N, M, hsq, intercept=None, ii=None):
-    """LD-score regression weights, kgwas/utils.py:397-434: 1 / (2 (intercept + hsq N ld / M)^2 w_ld)
-    with ld, w_ld floored at 1 and hsq clipped to [0, 1]."""
+    """LD-score regression weights: the ten-line formula of kgwas/utils.py:397-434, TRANSCRIBED (same name, arguments and
+    order of operations, so the values match the reference's bit for bit -- tests/golden/ref_helpers.npz):
+    1 / (2 (intercept + hsq N ld / M)^2 w_ld) with ld, w_ld floored at 1 and hsq clipped to [0, 1]."""
     M = float(M)
     if intercept is None:
         intercept = 1
