@@ -197,6 +197,12 @@ typedef struct KgwLayerArgs {
     float* rel_sums;               /* optional, kgw_gat_aggregate_bwd_src: [n_rels] <- per relation, the sum of d a_dst over its
                                       destination rows = the gradient of logit_bias (what kgw_relation_sums computes), by
                                       n_rels extra blocks of the same launch.  Needs V (in-kernel a_dst) so that da_dst is final */
+    /* d u_r / d v_r without the [d a_src | d a_dst] rows (da_src may then be NULL): kgw_gat_aggregate_bwd_dst leaves, per chunk,
+     * sum_e dpre_e h_src(e) in part_du [n_chunks][128]; kgw_gat_aggregate_bwd_src adds them up per relation (and
+     * d v_r = sum_i d a_dst[i, r] h_dst[i] over the destination rows) with extra blocks of its launch plus one small fold launch,
+     * into dU / dV [n_rels][128] (zero rows for relations the layer does not compute).  seg_chptr = KgwBatchBuf.seg_chptr;
+     * duv_ws: 2 * n_rels * 8 * 128 floats of workspace.  All five or none.                                              */
+    float* part_du; const int32_t* seg_chptr; float* duv_ws; float* dU; float* dV;
 } KgwLayerArgs;
 
 /* ---- entry points ------------------------------------------------------------------------ */

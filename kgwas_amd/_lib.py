@@ -98,6 +98,7 @@ class KgwLayerArgs(C.Structure):
         ('dH', C.c_void_p), ('ev_before', C.c_void_p), ('ev_after', C.c_void_p), ('da_src', C.c_void_p),
         ('logit_bias', C.c_void_p), ('chunk_perm', C.c_void_p), ('chunk_perm_len', C.c_void_p), ('partial_rels', C.c_uint64),
         ('t_rel', C.c_void_p), ('oct_flags', C.c_void_p), ('rel_sums', C.c_void_p),
+        ('part_du', C.c_void_p), ('seg_chptr', C.c_void_p), ('duv_ws', C.c_void_p), ('dU', C.c_void_p), ('dV', C.c_void_p),
     ]
 
 

@@ -76,6 +76,10 @@ struct AggPtrs {
     const int32_t* t_zrow;
     const uint8_t* t_rel;         // relation id per src-major entry (nullable: no octet path)
     const int32_t* oct_flags;     // per 8 source rows: processed by the octet path
+    float* part_du;               // [n_chunks][128] per-chunk part of d u_r (nullable)
+    const int32_t* seg_chptr;     // first chunk of every segment (for the d u_r reduction)
+    float* duv_ws;                // [2][n_rels][8][128] level-1 sums of d u_r / d v_r
+    int n_duv_hops;
     float* dH;
     float* da_src;
     const int32_t* multi;
@@ -362,7 +366,7 @@ template <int G>
 __device__ __forceinline__ void bwd_group(const float4* __restrict__ Hb4, int colv, float evin, int q0, int hn,
                                           int nb, int half, int hl, const float4& dz4, float cdot, float M,
                                           float inv_den, float slope, float inv_temp, float& av, float& dv,
-                                          float& dsum) {
+                                          float& dsum, float4& ua) {
     float4 x[G];
     float t[G];
 #pragma unroll
@@ -384,6 +388,7 @@ __device__ __forceinline__ void bwd_group(const float4* __restrict__ Hb4, int co
         av = (hl == q0 + p) ? alpha : av;
         dv = (hl == q0 + p) ? dpre : dv;
         dsum += dpre;
+        fma4(ua, dpre, x[p]);                      // d u_r += d pre-activation * h_src (every lane has the edge's dpre here)
     }
 }
 
@@ -391,7 +396,7 @@ __device__ __forceinline__ void bwd_group(const float4* __restrict__ Hb4, int co
 // here collects only the lane's OWN edges; the caller folds the 8 residues once per chunk (kgw_sum8).
 __device__ __forceinline__ void bwd_grp8_compute(const float4 (&x)[8], float evin, int q0, int hn, int nb, int half, int hl,
                                                  const float4& dz4, float cdot, float M, float inv_den, float slope,
-                                                 float inv_temp, float& av, float& dv, float& dsum_own) {
+                                                 float inv_temp, float& av, float& dv, float& dsum_own, float4& ua) {
     float part[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) part[p] = dot4(x[p], dz4);
@@ -407,15 +412,18 @@ __device__ __forceinline__ void bwd_grp8_compute(const float4 (&x)[8], float evi
     av = mine ? alpha : av;
     dv = mine ? dpre : dv;
     dsum_own += (hl < 8) ? dpre : 0.f;          // one copy per edge: the 8 residues of the first 8-lane group
+    // d u_r += d pre-activation(edge) * h_src(edge): lane p of the half owns edge q0 + p's value (0 for a padding edge)
+#pragma unroll
+    for (int p = 0; p < 8; ++p) fma4(ua, __shfl(dpre, (half << 5) + p, 64), x[p]);
 }
 
 __device__ __forceinline__ void bwd_group8(const float4* __restrict__ Hb4, int colv, float evin, int q0, int hn,
                                            int nb, int half, int hl, const float4& dz4, float cdot, float M,
                                            float inv_den, float slope, float inv_temp, float& av, float& dv,
-                                           float& dsum_own) {
+                                           float& dsum_own, float4& ua) {
     float4 x[8];
     grp8_load(Hb4, colv, q0, hn, nb, half, hl, x);
-    bwd_grp8_compute(x, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own);
+    bwd_grp8_compute(x, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own, ua);
 }
 
 template <bool PIPE>
@@ -437,6 +445,7 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_dst(LayerTab T, AggPtrs P, 
         const float inv_den = 1.0f / P.stat[2 * (int64_t)zrow + 1];
         const float4* Hb4 = (const float4*)(P.H + (int64_t)T.src_base[r] * KGW_C);
         float dsum = 0.f, dsum_own = 0.f;
+        float4 ua = make_float4(0.f, 0.f, 0.f, 0.f);          // this chunk's part of d u_r: sum_e dpre_e h_src(e) (a half's edges)
         const int n = ck.e1 - ck.e0;
         int colv_next = (PIPE && lane < min(64, n)) ? P.col_local[ck.e0 + lane] : 0;
         float ev_next = 0.f;
@@ -470,26 +479,30 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_dst(LayerTab T, AggPtrs P, 
                     const int q1 = q0 + 8;
                     const bool more1 = hn - q1 > 4;
                     if (more1) grp8_load(Hb4, colv, q1, hn, nb, half, hl, x1);
-                    bwd_grp8_compute(x0, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own);
+                    bwd_grp8_compute(x0, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own, ua);
                     q0 = q1;
                     if (!more1) break;
                     const int q2 = q1 + 8;
                     const bool more2 = hn - q2 > 4;
                     if (more2) grp8_load(Hb4, colv, q2, hn, nb, half, hl, x0);
-                    bwd_grp8_compute(x1, evin, q1, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own);
+                    bwd_grp8_compute(x1, evin, q1, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own, ua);
                     q0 = q2;
                     if (!more2) break;
                 }
             }
             for (; q0 < hn;) {
                 const int rem = hn - q0;
-                if (rem > 4)      { bwd_group8(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own); q0 += 8; }
-                else if (rem > 2) { bwd_group<4>(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum); q0 += 4; }
-                else              { bwd_group<2>(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum); q0 += 2; }
+                if (rem > 4)      { bwd_group8(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own, ua); q0 += 8; }
+                else if (rem > 2) { bwd_group<4>(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum, ua); q0 += 4; }
+                else              { bwd_group<2>(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum, ua); q0 += 2; }
             }
             if (mine) ((float2*)P.adp)[ck.e0 + b + i] = make_float2(av, dv);
         }
         dsum += kgw_sum8(dsum_own);                            // lanes 0..7 of each half: the edges handled 8 at a time
+        if (P.part_du) {
+            ua.x += kgw_xhalf(ua.x); ua.y += kgw_xhalf(ua.y); ua.z += kgw_xhalf(ua.z); ua.w += kgw_xhalf(ua.w);
+            if (half == 0) ((float4*)(P.part_du + (int64_t)c * KGW_C))[hl] = ua;
+        }
         const float tot = dsum + kgw_xhalf(dsum);
         if (lane == 0) {
             if (ck.nch == 1) P.da_dst[zrow] = tot; else P.part_da[c] = tot;
@@ -550,7 +563,7 @@ __device__ __forceinline__ void bwd_src_one_row(const LayerTab& T, const AggPtrs
         const int tb = T.type_t_base[ty] + j * Rs;
         if (j >= P.meta->n_src[P.layer - 1][ty]) {          // padding row of a static layout: no gradient
             if (half == 0) ((float4*)(P.dH + (int64_t)u * KGW_C))[hl] = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int c = lane; c < 2 * T.ld_da; c += 64) P.da_src[(int64_t)u * 2 * T.ld_da + c] = 0.f;
+            if (P.da_src) for (int c = lane; c < 2 * T.ld_da; c += 64) P.da_src[(int64_t)u * 2 * T.ld_da + c] = 0.f;
             return;
         }
         // all Rs + 1 row pointers of this source in ONE load (lane k holds t_ptr[tb + k]); the per-slot logic below
@@ -640,8 +653,8 @@ __device__ __forceinline__ void bwd_src_one_row(const LayerTab& T, const AggPtrs
         if (half == 0) ((float4*)(P.dH + (int64_t)u * KGW_C))[hl] = acc;
         // [d a_src | d a_dst] row of this node, one column per RELATION ID (zero for relations of other types): the
         // caller gets d u_r = sum_j d a_src[j, r] H[j] and d v_r = sum_i d a_dst[i, r] H[i] for all relations as
-        // ONE tall-skinny product over H
-        {
+        // ONE tall-skinny product over H  (not written when the caller takes d u_r / d v_r from the launch's riders)
+        if (P.da_src) {
             const int ld = T.ld_da;                           // up to 64 relations: a row of up to 128 floats, two per lane
             for (int c0 = 0; c0 < 2 * ld; c0 += 64) {
                 const int col = c0 + lane;
@@ -782,7 +795,7 @@ __device__ __forceinline__ bool bwd_src_row_pair(const LayerTab& T, const AggPtr
     }
     ((float4*)(P.dH + (int64_t)uh * KGW_C))[hl] = acc;
     // [d a_src | d a_dst] row, one column per relation id; each half writes its own row, two columns per lane
-    {
+    if (P.da_src) {
         const int ld = T.ld_da;
         float* row = P.da_src + (int64_t)uh * 2 * ld;
         for (int c0 = 0; c0 < ld; c0 += 32) {                 // (more than 32 relations: a second round)
@@ -877,7 +890,7 @@ __device__ __forceinline__ void bwd_src_octet(const LayerTab& T, const AggPtrs& 
     }
     // [d a_src | d a_dst] row: column rel(e) of the first half gets d pre-activation(e) (entries of one relation are
     // adjacent and added in entry order, like the general path's slot sums); the d a_dst half is zero (no destination row)
-    {
+    if (P.da_src) {
         const int n4 = T.ld_da >> 1;                              // float4s per row (2 * ld_da floats)
         float4* row = (float4*)(P.da_src + (int64_t)u * 2 * T.ld_da);
         for (int k0 = 0; k0 < n4; k0 += 8) {                      // (uniform trip count: the shuffles below need every lane)
@@ -898,27 +911,84 @@ __device__ __forceinline__ void bwd_src_octet(const LayerTab& T, const AggPtrs& 
     }
 }
 
-__global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, int n_src_rows, int main_blocks,
+constexpr int KGW_DUV_SPLIT = 8;      // level-1 pieces per relation of the d u_r / d v_r sums
+
+// Riders of the src-major launch: blocks [0, n_riders) of the grid, ahead of the row work (they start with the kernel and are
+// done long before it ends).
+//   [0, NR)                    rel_sums != NULL: relation r's sum of d a_dst over its destination rows (gradient of a
+//                              per-relation logit constant, KgwLayerArgs.rel_sums)
+//   then NR * 8 blocks         duv_ws != NULL: piece s of  d u_r = sum over the chunks c of relation r of part_du[c]
+//                              (k_agg_bwd_dst left, per chunk, sum_e dpre_e h_src(e))
+//   then NR * 8 blocks         piece s of  d v_r = sum_i d a_dst[i, r] h_dst[i]  over relation r's destination rows
+// all in a fixed order; k_duv_fold adds the eight pieces.  This replaces the [d a_src | d a_dst] row per node that this pass
+// used to write (39 MB) and the tall-skinny product over H that consumed it (two launches, 36 us).
+__device__ __forceinline__ void bwd_src_rider(const LayerTab& T, const AggPtrs& P, int id, float* rel_sums, float* sm) {
+    const int t = threadIdx.x;
+    const int NR = T.n_rels;
+    if (rel_sums) {
+        if (id < NR) {
+            const int r = id;
+            float sacc = 0.f;
+            if (T.live[r]) {
+                const int rows = P.meta->n_rows[P.layer - 1][T.rel_dst_type[r]];
+                const float* p = P.da_dst + T.z0[r];
+                const int st = T.zstride[r];
+                for (int i = t; i < rows; i += KGW_BLK) sacc += p[(int64_t)i * st];
+            }
+            sm[t] = sacc;
+            __syncthreads();
+            for (int o = KGW_BLK / 2; o > 0; o >>= 1) {
+                if (t < o) sm[t] += sm[t + o];
+                __syncthreads();
+            }
+            if (t == 0) rel_sums[r] = sm[0];
+            return;
+        }
+        id -= NR;
+    }
+    const bool is_v = id >= NR * KGW_DUV_SPLIT;
+    if (is_v) id -= NR * KGW_DUV_SPLIT;
+    const int r = id / KGW_DUV_SPLIT, sp = id % KGW_DUV_SPLIT;
+    const int col = t & (KGW_C - 1), rg = t >> 7;                 // 128 columns x 2 row groups
+    float acc = 0.f;
+    if (T.live[r]) {
+        if (!is_v) {
+            for (int h = 0; h < P.n_duv_hops; ++h) {
+                const int c0 = P.seg_chptr[P.meta->seg_off[h][r]];
+                const int c1 = (r + 1 < NR) ? P.seg_chptr[P.meta->seg_off[h][r + 1]] : P.meta->chunk_end[h];
+                const int n = c1 - c0;
+                const int a0 = c0 + (int)((int64_t)n * sp / KGW_DUV_SPLIT), a1 = c0 + (int)((int64_t)n * (sp + 1) / KGW_DUV_SPLIT);
+                for (int c = a0 + rg; c < a1; c += 2) acc += P.part_du[(int64_t)c * KGW_C + col];
+            }
+        } else {
+            const int rows = P.meta->n_rows[P.layer - 1][T.rel_dst_type[r]];
+            const int a0 = (int)((int64_t)rows * sp / KGW_DUV_SPLIT), a1 = (int)((int64_t)rows * (sp + 1) / KGW_DUV_SPLIT);
+            const float* dd = P.da_dst + T.z0[r];
+            const float* hb = P.H + (int64_t)T.dst_hbase[r] * KGW_C + col;
+            const int st = T.zstride[r];
+            for (int i = a0 + rg; i < a1; i += 2) acc = fmaf(dd[(int64_t)i * st], hb[(int64_t)i * KGW_C], acc);
+        }
+    }
+    sm[t] = acc;
+    __syncthreads();
+    if (rg == 0)
+        P.duv_ws[((int64_t)(is_v ? NR : 0) + r) * KGW_DUV_SPLIT * KGW_C + (int64_t)sp * KGW_C + col] = sm[t] + sm[t + KGW_C];
+}
+
+// d u_r / d v_r from their eight pieces (zero rows for relations the layer does not compute)
+__global__ void __launch_bounds__(KGW_C) k_duv_fold(int n_rels, const float* __restrict__ ws, float* __restrict__ dU,
+                                                     float* __restrict__ dV) {
+    const int r = blockIdx.x, v = blockIdx.y, c = threadIdx.x;
+    const float* p = ws + ((int64_t)v * n_rels + r) * KGW_DUV_SPLIT * KGW_C + c;
+    const float s = ((p[0] + p[KGW_C]) + (p[2 * KGW_C] + p[3 * KGW_C])) + ((p[4 * KGW_C] + p[5 * KGW_C]) + (p[6 * KGW_C] + p[7 * KGW_C]));
+    (v ? dV : dU)[(int64_t)r * KGW_C + c] = s;
+}
+
+__global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, int n_src_rows, int main_blocks, int n_riders,
                                                          float* __restrict__ rel_sums) {
     __shared__ float s_dp[KGW_BLK];                           // 64 floats per wavefront (bwd_src_row_pair)
-    if ((int)blockIdx.x >= main_blocks) {
-        // riders of the launch (rel_sums != NULL): block main_blocks + r adds up d a_dst over the destination rows of
-        // relation r -- the gradient of a per-relation logit constant (KgwLayerArgs.rel_sums) -- in a fixed tree order
-        const int r = (int)blockIdx.x - main_blocks, t = threadIdx.x;
-        float sacc = 0.f;
-        if (T.live[r]) {
-            const int rows = P.meta->n_rows[P.layer - 1][T.rel_dst_type[r]];
-            const float* p = P.da_dst + T.z0[r];
-            const int st = T.zstride[r];
-            for (int i = t; i < rows; i += KGW_BLK) sacc += p[(int64_t)i * st];
-        }
-        s_dp[t] = sacc;
-        __syncthreads();
-        for (int o = KGW_BLK / 2; o > 0; o >>= 1) {
-            if (t < o) s_dp[t] += s_dp[t + o];
-            __syncthreads();
-        }
-        if (t == 0) rel_sums[r] = s_dp[0];
+    if ((int)blockIdx.x < n_riders) {
+        bwd_src_rider(T, P, (int)blockIdx.x, rel_sums, s_dp);
         return;
     }
     float* wdp = s_dp + (threadIdx.x & ~63);
@@ -931,7 +1001,7 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, 
     // (Two plain loops on purpose: with the octet path inside the pair loop, or an inner loop over an unflagged octet's
     // pairs, the general path's code got worse -- scalar-register spills -- and the kernel slower than without octets.)
     const int npairs = (n_src_rows + 1) >> 1;
-    const int w0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int w0 = ((int)blockIdx.x - n_riders) * 4 + (threadIdx.x >> 6);
     for (int i0 = w0; i0 < npairs; i0 += nw) {
         const int u = __builtin_amdgcn_readfirstlane(2 * (npairs - 1 - i0));
         if (u < T.oct_rows && P.oct_flags[u >> 3]) continue;
@@ -1012,7 +1082,8 @@ AggPtrs build_ptrs(const KgwLayerArgs* a) {
     P.chunks = a->chunks; P.col_local = a->col_local; P.H = a->H; P.a_dst = a->a_dst; P.V = a->V; P.U = a->U; P.raw = (a->flags & KGW_F_RAW_WEIGHTS) ? 1 : 0; P.relu_in = (a->flags & KGW_F_RELU_INPUT) ? 1 : 0;
     P.Z = a->Z; P.stat = a->stat; P.e_edge = a->e_edge; P.part = a->part; P.dZ = a->dZ; P.adp = a->adp;
     P.da_dst = a->da_dst; P.part_da = a->part_da; P.t_ptr = a->t_ptr; P.t_edge = a->t_edge;
-    P.t_zrow = a->t_zrow; P.t_rel = a->t_rel; P.oct_flags = a->oct_flags; P.dH = a->dH; P.da_src = a->da_src; P.multi = a->multi; P.multi_cap = a->multi_cap;
+    P.t_zrow = a->t_zrow; P.t_rel = a->t_rel; P.oct_flags = a->oct_flags; P.part_du = a->part_du; P.seg_chptr = a->seg_chptr; P.duv_ws = a->duv_ws;
+    P.n_duv_hops = a->n_multi_hops; P.dH = a->dH; P.da_src = a->da_src; P.multi = a->multi; P.multi_cap = a->multi_cap;
     P.meta = a->meta_dev; P.layer = a->layer;
     P.perm = a->chunk_perm_len ? a->chunk_perm : nullptr; P.perm_len = a->chunk_perm_len;
     P.lbias = a->logit_bias;
@@ -1096,7 +1167,7 @@ extern "C" int kgw_gat_aggregate_bwd_dst(const KgwLayerArgs* a, kgw_stream_t str
 extern "C" int kgw_gat_aggregate_bwd_src(const KgwLayerArgs* a, kgw_stream_t stream_) {
     if (!a) return KGW_E_NULL;
     if (a->n_src_rows == 0) return KGW_OK;
-    if (!a->dZ || !a->adp || !a->t_ptr || !a->t_edge || !a->t_zrow || !a->dH || !a->da_src || !a->U || !a->meta_dev)
+    if (!a->dZ || !a->adp || !a->t_ptr || !a->t_edge || !a->t_zrow || !a->dH || (!a->da_src && !a->dU) || !a->U || !a->meta_dev)
         return KGW_E_NULL;
     LayerTab T;
     int rc = build_tab(a, &T);
@@ -1104,9 +1175,16 @@ extern "C" int kgw_gat_aggregate_bwd_src(const KgwLayerArgs* a, kgw_stream_t str
     AggPtrs P = build_ptrs(a);
     if (a->ev_before) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_before, (hipStream_t)stream_));
     const int gmain = grid_fine((a->n_src_rows + 1) / 2);
-    k_agg_bwd_src<<<gmain + (a->rel_sums ? T.n_rels : 0), KGW_BLK, 0, (hipStream_t)stream_>>>(T, P, a->n_src_rows, gmain, a->rel_sums);
+    const bool duv = a->dU && a->dV && a->part_du && a->duv_ws && a->seg_chptr;
+    const int n_riders = (a->rel_sums ? T.n_rels : 0) + (duv ? 2 * KGW_DUV_SPLIT * T.n_rels : 0);
+    if (!duv) P.duv_ws = nullptr;
+    k_agg_bwd_src<<<gmain + n_riders, KGW_BLK, 0, (hipStream_t)stream_>>>(T, P, a->n_src_rows, gmain, n_riders, a->rel_sums);
     KGW_LAUNCH_CHECK();
     if (a->ev_after) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_after, (hipStream_t)stream_));
+    if (duv) {
+        k_duv_fold<<<dim3(T.n_rels, 2), KGW_C, 0, (hipStream_t)stream_>>>(T.n_rels, a->duv_ws, a->dU, a->dV);
+        KGW_LAUNCH_CHECK();
+    }
     return KGW_OK;
 }
 

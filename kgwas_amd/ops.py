@@ -108,6 +108,7 @@ TIMER = KernelTimer()
 
 
 _MLP2_FUSED = os.environ.get('KGW_MLP2_FUSED', '1') != '0'        # 0: the two hidden layers of a narrow MLP as two launches
+_DUV_RIDERS = os.environ.get('KGW_DUV_RIDERS', '1') != '0'        # 0: d u_r / d v_r through the [d a_src | d a_dst] rows + product
 _SHORT_ROWS = os.environ.get('KGW_SHORT_ROWS', '1') != '0'     # 0: every source row on the general path (timing experiments)
 
 
@@ -218,11 +219,21 @@ class _GatAggregate(torch.autograd.Function):
         part_da = torch.empty(max(n_chunks, 1), device=dev)
         dH = torch.empty(max(n_src, 1), KGW_C, device=dev)
         ld_da = (sc.NR + 3) & ~3
-        da_src = torch.empty(max(n_src, 1), 2 * ld_da, device=dev)   # [node row, (d a_src | d a_dst) by relation id]
         a = _layer_args(batch, layer, ctx.neg_slope, ctx.inv_temp)
         a.H, a.U, a.V, a.Z, a.stat, a.e_edge = _p(H), _p(U), _p(V), _p(Z), _p(stat), _p(e_edge)
         a.dZ, a.adp, a.da_dst, a.part_da = _p(dZf), _p(adp), _p(da_dst), _p(part_da)
-        a.dH, a.da_src = _p(dH), _p(da_src)
+        a.dH = _p(dH)
+        riders = _DUV_RIDERS and n_src > 0 and n_chunks > 0
+        if riders:
+            # d u_r / d v_r from per-chunk sums the dst-major pass leaves and extra blocks of the src-major launch -- no
+            # [d a_src | d a_dst] row per node, no tall-skinny product over H afterwards
+            part_du = torch.empty(n_chunks, KGW_C, device=dev)
+            duv_ws = torch.empty(2 * sc.NR * 8 * KGW_C, device=dev)
+            dU, dV = torch.empty(sc.NR, KGW_C, device=dev), torch.empty(sc.NR, KGW_C, device=dev)
+            a.part_du, a.seg_chptr, a.duv_ws, a.dU, a.dV = _p(part_du), _p(batch.buf.seg_chptr), _p(duv_ws), _p(dU), _p(dV)
+        else:
+            da_src = torch.empty(max(n_src, 1), 2 * ld_da, device=dev)   # [node row, (d a_src | d a_dst) by relation id]
+            a.da_src = _p(da_src)
         a.flags = 2 if ctx.relu_input else 0       # KGW_F_RELU_INPUT: fold the ReLU that produced H into dH
         L = _lib.lib()
         TIMER.attach(a, 'bwd_dst', layer, n_edges, z_rows, n_src)
@@ -235,9 +246,11 @@ class _GatAggregate(torch.autograd.Function):
             dlb = torch.empty(sc.NR, device=dev)
             a.rel_sums = _p(dlb)
         _lib.check(L.kgw_gat_aggregate_bwd_src(C.byref(a), _lib.stream_ptr()), 'kgw_gat_aggregate_bwd_src')
-        # d u_r = sum_j d a_src[j, r] H[j], d v_r = sum_i d a_dst[i, r] H[i]: all relations, both sides, as ONE
-        # tall-skinny product over H
-        if n_src:
+        if riders:
+            pass
+        elif n_src:
+            # d u_r = sum_j d a_src[j, r] H[j], d v_r = sum_i d a_dst[i, r] H[i]: all relations, both sides, as ONE
+            # tall-skinny product over H
             dUV = tn_gemm(da_src[:n_src], H[:n_src])
             dU, dV = dUV[:sc.NR], dUV[ld_da:ld_da + sc.NR]
         else:
