@@ -413,8 +413,14 @@ __device__ __forceinline__ void bwd_grp8_compute(const float4 (&x)[8], float evi
     dv = mine ? dpre : dv;
     dsum_own += (hl < 8) ? dpre : 0.f;          // one copy per edge: the 8 residues of the first 8-lane group
     // d u_r += d pre-activation(edge) * h_src(edge): lane p of the half owns edge q0 + p's value (0 for a padding edge)
+    // (two scalar lane reads + a select per edge instead of a cross-lane permute through the LDS crossbar)
+    const int dbits = __builtin_bit_cast(int, dpre);
 #pragma unroll
-    for (int p = 0; p < 8; ++p) fma4(ua, __shfl(dpre, (half << 5) + p, 64), x[p]);
+    for (int p = 0; p < 8; ++p) {
+        const float d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(dbits, p));
+        const float d1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(dbits, 32 + p));
+        fma4(ua, half ? d1 : d0, x[p]);
+    }
 }
 
 __device__ __forceinline__ void bwd_group8(const float4* __restrict__ Hb4, int colv, float evin, int q0, int hn,
