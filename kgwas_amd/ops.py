@@ -108,6 +108,7 @@ TIMER = KernelTimer()
 
 
 _MLP2_FUSED = os.environ.get('KGW_MLP2_FUSED', '1') != '0'        # 0: the two hidden layers of a narrow MLP as two launches
+_TN_GROUP = os.environ.get('KGW_TN_GROUP', '1') != '0'             # 0: one launch pair per destination type in the transform's backward
 _DUV_RIDERS = os.environ.get('KGW_DUV_RIDERS', '1') != '0'        # 0: d u_r / d v_r through the [d a_src | d a_dst] rows + product
 _SHORT_ROWS = os.environ.get('KGW_SHORT_ROWS', '1') != '0'     # 0: every source row on the general path (timing experiments)
 
@@ -343,6 +344,35 @@ def tn_gemm(A: torch.Tensor, B: torch.Tensor, colsum: bool = False, out: torch.T
                                 1 if transpose_out else 0, _p(cs), rep, cs_ld, _p(ws), nws, _p(rows_dev), _lib.stream_ptr()),
                'kgw_tn_gemm_ex')
     return (out, cs) if (colsum or colsum_out is not None) else out
+
+
+def _tn_gemm_group(jobs) -> bool:
+    """Several C^T = (A^T B)^T products with column sums of A (``jobs``: [(A [rows, M], B [rows, N], out [N, M] row-major view,
+    colsum_out [q, M])]) in one kgw_tn_gemm_multi launch pair.  False: not taken (one job, shapes outside the grouped tiling)."""
+    if not (_TN_GROUP and 2 <= len(jobs) <= 4):
+        return False
+    for A, B, out, cs in jobs:
+        if not (A.dtype == torch.float32 and B.dtype == torch.float32 and A.stride(1) == 1 and B.stride(1) == 1 and out.stride(1) == 1 and
+                cs.stride(1) == 1 and A.shape[0] == B.shape[0] and A.shape[0] > 0 and A.shape[1] % 2 == 0 and B.shape[1] % 2 == 0 and
+                A.shape[1] >= 64 and B.shape[1] >= 64 and A.stride(0) % 2 == 0 and B.stride(0) % 2 == 0 and A.data_ptr() % 8 == 0 and
+                B.data_ptr() % 8 == 0 and out.shape == (B.shape[1], A.shape[1]) and cs.shape[1] == A.shape[1]):
+            return False
+    L = _lib.lib()
+    arr = (_lib.KgwTnJob * len(jobs))()
+    keep = []
+    for q, (A, B, out, cs) in enumerate(jobs):
+        rows, M = A.shape
+        N = B.shape[1]
+        nws = int(L.kgw_tn_gemm_workspace_floats(rows, M, N))
+        ws = torch.empty(nws, device=A.device)
+        keep.append(ws)
+        j = arr[q]
+        j.A, j.lda, j.B, j.ldb, j.rows = _p(A), A.stride(0), _p(B), B.stride(0), rows
+        j.C, j.ldc, j.colsum_a, j.colsum_ld = _p(out), out.stride(0), _p(cs), cs.stride(0)
+        j.workspace, j.workspace_floats, j.rows_dev = _p(ws), nws, None
+        j.M, j.N, j.c_transposed, j.colsum_repeat = M, N, 1, cs.shape[0]
+    _lib.check(L.kgw_tn_gemm_multi(len(jobs), arr, _lib.stream_ptr()), 'kgw_tn_gemm_multi')
+    return True
 
 
 def weight_grads(pairs, rows_dev: torch.Tensor = None):
@@ -957,6 +987,7 @@ class _LayerTransform(torch.autograd.Function):
         dZ = None
         if need_dz:
             dZ = torch.empty_like(Z) if (z_cov == z_rows and all(d is not None for d in dYs)) else torch.zeros_like(Z)
+        live_blocks = []
         for k, ((lo, hi, z0, rows), dy) in enumerate(zip(blocks, dYs)):
             if dy is None or rows == 0:
                 continue
@@ -964,8 +995,13 @@ class _LayerTransform(torch.autograd.Function):
             x = Z[z0:z0 + rows * R].view(rows, R * C)
             # (premasked: the consumer of y already multiplied its gradient by (y > 0))
             dz = dy.contiguous() if ctx.premasked else torch.ops.aten.threshold_backward(dy.contiguous(), ys[k], 0.0)
-            # dWt = x^T dz lands transposed in place (the pack keeps [in, out]); db = colsum(dz) for each relation
-            tn_gemm(dz, x, out=dW[lo:hi].view(R * C, C), transpose_out=True, colsum_out=db[lo:hi])
+            live_blocks.append((lo, hi, z0, rows, R, x, dz))
+        # dWt = x^T dz lands transposed in place (the pack keeps [in, out]); db = colsum(dz) for each relation: the
+        # destination types' products in ONE launch pair when the grouped kernel takes them
+        if not _tn_gemm_group([(dz, x, dW[lo:hi].view(R * C, C), db[lo:hi]) for lo, hi, z0, rows, R, x, dz in live_blocks]):
+            for lo, hi, z0, rows, R, x, dz in live_blocks:
+                tn_gemm(dz, x, out=dW[lo:hi].view(R * C, C), transpose_out=True, colsum_out=db[lo:hi])
+        for lo, hi, z0, rows, R, x, dz in live_blocks:
             if need_dz:
                 linear(dz, w_src_t[lo:hi].view(R * C, C), out=dZ[z0:z0 + rows * R].view(rows, R * C))
             if gamma is not None:
