@@ -351,6 +351,15 @@ int kgw_mlp2w_fwd(int32_t n_jobs, const float* const* src, const int32_t* const*
                   const float* W1, int64_t ldw1, const float* b1, const float* W2, int64_t ldw2, const float* b2, float* Xg,
                   float* H1, float* H2, int64_t ldo, kgw_stream_t stream);
 
+/* Backward of the NARROW first layer behind kgw_mlp2_fwd (no input gradient wanted): d W1 [128, K1] (row stride ldw1) and
+ * d b1 [128] of  h1 = relu(x W1^T + b1)  given the upstream dH2 [rows, 128] of h2 = relu(h1 W2^T + b2) (already multiplied
+ * by h2 > 0), W2, h1 and x [rows, K1 <= 31]: dh1 = (dH2 W2) * (h1 > 0) is formed tile by tile and consumed in place by the
+ * d W1 product -- never written.  workspace: kgw_mlp2_bwd_first_workspace_floats(rows) floats.                      */
+int64_t kgw_mlp2_bwd_first_workspace_floats(int64_t rows);
+int kgw_mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2, int64_t ldw2, const float* H1, int64_t ldh1,
+                       const float* X, int64_t ldx, int32_t K1, int64_t rows, const int32_t* rows_dev, float* dW1,
+                       int64_t ldw1, float* db1, float* workspace, int64_t workspace_floats, kgw_stream_t stream);
+
 /* The same product for FEW rows when one of K, N is 128 and the other a multiple of 128 -- the per-relation transform
  * of a layer after aggregate-then-transform, [N_dst, R*128] x [R*128, 128] with N_dst ~ 0.5-1.2 k destination rows of a
  * 512-seed batch (kgwas/conv.py:138-144 for all relations into one destination type + bias :190 + HeteroConv sum

@@ -1244,6 +1244,207 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// kgw_mlp2_bwd_first: the backward of a NARROW first layer behind kgw_mlp2_fwd (the 20-wide SNP features need no input
+// gradient): d W1 = dh1^T x, d b1 = colsum(dh1) with dh1 = (dh2 W2) * (h1 > 0) -- WITHOUT materialising dh1.  It is
+// k_linear_wreg<w_kn, mask> (dh2 tiles streamed into the MFMA B operand, W2 stationary) whose epilogue, instead of
+// storing the 32 x 128 tile of dh1, hands it through wavefront-private LDS to a second product: the tile, read back
+// "column per lane", is the B operand of  C[k][col] += x'[row][k] dh1[row][col]  (x' = [x | 1]: row K1 of C is d b1), 64
+// more MFMAs per tile into four persistent accumulators.  The blocks' partial C's are added by k_mlp2_bwd_fold.
+// Replaces a 61 MB store, its re-read and the [rows, 128]^T [rows, 20] product (k_tn_gemm<2,1> + reduce: 35 us).
+// ------------------------------------------------------------------------------------------------------
+struct Mlp2BwdArgs {
+    const float* dH2; int64_t ldd;      // [rows, 128] upstream gradient (already multiplied by h2 > 0)
+    const float* W2; int64_t ldw;       // [128 out, 128 in] (nn.Linear layout): dh1 = dh2 @ W2
+    const float* H1; int64_t ldm;       // [rows, 128] ReLU mask
+    const float* X; int64_t ldx;        // [rows, K1] the first layer's input rows
+    float* part;                        // [gridDim.x][4096] block partials, fragment order
+    int64_t rows; int K1;
+    const int32_t* rows_dev;
+};
+
+constexpr int TST = 132;                // LDS row stride of the transposing tile
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) k_mlp2_bwd_first(Mlp2BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Wl = lds;                                         // [128 k][WST]: W2^T as the MFMA A operand wants it
+    float* Tl = lds + 128 * WST;                             // [4 wavefronts][32 rows][TST]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    int64_t rows = a.rows;
+    if (a.rows_dev) { const int64_t r = *a.rows_dev; rows = r < 0 ? 0 : (r < a.rows ? r : a.rows); }
+    const int ntiles = (int)((rows + 31) / 32);
+    const int nw = (int)gridDim.x * 4;
+    float* Tw = Tl + wave * 32 * TST;
+    {   // stage W2 transposed (dX form, w_kn): Wl[k][n] = W2[n][k]; lanes along n: conflict-free transposing writes
+        f32x4 wv[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = tid + 256 * it;
+            wv[it] = *(const f32x4*)(a.W2 + (int64_t)(idx & 127) * a.ldw + (idx >> 7) * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = tid + 256 * it;
+            const int k = idx & 127, n4 = (idx >> 7) * 4;
+            Wl[(n4 + 0) * WST + k] = wv[it].x; Wl[(n4 + 1) * WST + k] = wv[it].y;
+            Wl[(n4 + 2) * WST + k] = wv[it].z; Wl[(n4 + 3) * WST + k] = wv[it].w;
+        }
+    }
+    __syncthreads();
+    // output columns (= input features of W2) 0-63 of the operand in registers, 64-127 from LDS a step ahead
+    f32x4 bw[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bw[t][q] = *(const f32x4*)(Wl + (t * 32 + li) * WST + lk * 64 + 4 * q);
+    const float* w2 = Wl + (64 + li) * WST + lk * 64;
+    const float* w3 = Wl + (96 + li) * WST + lk * 64;
+    f32x16 accw[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accw[t][e] = 0.f;
+    const int K1 = a.K1;
+    int tile = (int)blockIdx.x * 4 + wave;
+    f32x4 xa[16];
+    {
+        int64_t r = (int64_t)(tile < ntiles ? tile : ntiles - 1) * 32 + li;
+        if (r >= rows) r = rows - 1;
+        const float* xp = a.dH2 + r * a.ldd + lk * 64;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xa[q] = *(const f32x4*)(xp + 4 * q);
+    }
+    for (; tile < ntiles; tile += nw) {
+        const int64_t r0 = (int64_t)tile * 32;
+        const int64_t row = r0 + li;
+        const bool live = row < rows;
+        const int64_t rc = live ? row : rows - 1;
+        const float* xn;                                      // this lane's half row of the wavefront's NEXT tile
+        {
+            int nt = tile + nw;
+            if (nt >= ntiles) nt = ntiles - 1;               // last round: a harmless re-read
+            int64_t r = (int64_t)nt * 32 + li;
+            if (r >= rows) r = rows - 1;
+            xn = a.dH2 + r * a.ldd + lk * 64;
+        }
+        // x' in "k per lane" form for the second product: lane (k = li, row parity lk), step s = row pair (needed after
+        // the first product: the loads ride under its MFMAs)
+        float xs[16];
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const int64_t rr = r0 + 2 * s2 + lk;
+            float v = 0.f;
+            if (rr < rows) v = li < K1 ? a.X[rr * a.ldx + li] : (li == K1 ? 1.f : 0.f);
+            xs[s2] = v;
+        }
+        // ReLU mask of this lane's row (columns 32 t + 8 g + 4 lk + c), fetched under the MFMAs, kept as bits
+        const float* mp = a.H1 + rc * a.ldm + 4 * lk;
+        unsigned mb[2] = {0u, 0u};
+        f32x4 mv[4];
+#define KGW_MLPB_MFETCH(T)                                                                                \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) mv[g] = *(const f32x4*)(mp + (T) * 32 + 8 * g);
+#define KGW_MLPB_MBITS(T)                                                                                 \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                  \
+            const int b0 = ((T) & 1) * 16 + 4 * g;                                                        \
+            mb[(T) >> 1] |= (mv[g].x > 0.f ? 1u : 0u) << (b0 + 0);                                        \
+            mb[(T) >> 1] |= (mv[g].y > 0.f ? 1u : 0u) << (b0 + 1);                                        \
+            mb[(T) >> 1] |= (mv[g].z > 0.f ? 1u : 0u) << (b0 + 2);                                        \
+            mb[(T) >> 1] |= (mv[g].w > 0.f ? 1u : 0u) << (b0 + 3);                                        \
+        }
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        f32x4 b2n = *(const f32x4*)w2, b3n = *(const f32x4*)w3;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (q == 0) { KGW_MLPB_MFETCH(0) }
+            if (q == 3) { KGW_MLPB_MBITS(0) KGW_MLPB_MFETCH(1) }
+            if (q == 6) { KGW_MLPB_MBITS(1) KGW_MLPB_MFETCH(2) }
+            if (q == 10) { KGW_MLPB_MBITS(2) KGW_MLPB_MFETCH(3) }
+            if (q == 14) { KGW_MLPB_MBITS(3) }
+            const f32x4 b2 = b2n, b3 = b3n;
+            if (q + 1 < 16) { b2n = *(const f32x4*)(w2 + 4 * (q + 1)); b3n = *(const f32x4*)(w3 + 4 * (q + 1)); }
+#define KGW_MLPB_STEP(C)                                                                                  \
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[0][q].C, xa[q].C, acc[0], 0, 0, 0);          \
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[1][q].C, xa[q].C, acc[1], 0, 0, 0);          \
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2.C, xa[q].C, acc[2], 0, 0, 0);                \
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(b3.C, xa[q].C, acc[3], 0, 0, 0);
+            KGW_MLPB_STEP(x) KGW_MLPB_STEP(y) KGW_MLPB_STEP(z) KGW_MLPB_STEP(w)
+#undef KGW_MLPB_STEP
+            if (q == 7) {                                      // first half row of the next tile, in place
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int qq = 0; qq < 8; ++qq) xa[qq] = *(const f32x4*)(xn + 4 * qq);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef KGW_MLPB_MFETCH
+#undef KGW_MLPB_MBITS
+        if (!live) { mb[0] = 0u; mb[1] = 0u; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qq = 8; qq < 16; ++qq) xa[qq] = *(const f32x4*)(xn + 4 * qq);     // second half: under the second product
+        __builtin_amdgcn_sched_barrier(0);
+        // masked dh1 tile -> the wavefront's LDS tile, row per lane (nobody else reads it: no barrier)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned m4 = mb[t >> 1] >> (((t & 1) << 4) + 4 * g);
+                f32x4 v;
+                v.x = (m4 & 1u) ? acc[t][4 * g + 0] : 0.f; v.y = (m4 & 2u) ? acc[t][4 * g + 1] : 0.f;
+                v.z = (m4 & 4u) ? acc[t][4 * g + 2] : 0.f; v.w = (m4 & 8u) ? acc[t][4 * g + 3] : 0.f;
+                *(f32x4*)(Tw + li * TST + t * 32 + 8 * g + 4 * lk) = v;
+            }
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // second product: C[k][col] += x'[row][k] dh1[row][col], two rows per MFMA step
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const float* tp = Tw + (2 * s2 + lk) * TST + li;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[s2], tp[t * 32], accw[t], 0, 0, 0);
+        }
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the tile is rewritten by the next iteration)
+    }
+    // the block's four partial C's through LDS (fragment order), added in wavefront order
+    __syncthreads();
+    float* R = Tl;                                            // 4 x 4096 floats
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) R[wave * 4096 + (t * 16 + e) * 64 + lane] = accw[t][e];
+    __syncthreads();
+    for (int f = tid; f < 4096; f += 256)
+        a.part[(int64_t)blockIdx.x * 4096 + f] = (R[f] + R[4096 + f]) + (R[2 * 4096 + f] + R[3 * 4096 + f]);
+}
+
+// d W1 [128, K1] and d b1 [128] from the block partials: fragment f = (t * 16 + e) * 64 + lane holds
+// C[k = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)][col = 32 t + (lane & 31)]; fixed summation order
+__global__ void __launch_bounds__(1024) k_mlp2_bwd_fold(const float* __restrict__ part, int nblk, int K1, float* __restrict__ dW1,
+                                                        int64_t ldw, float* __restrict__ db1) {
+    __shared__ float sm[1024];
+    const int fl = threadIdx.x & 63, g = threadIdx.x >> 6;        // 64 fragment elements x 16 groups of blocks
+    const int f = blockIdx.x * 64 + fl;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    int q = 0;
+    for (int b = g; b < nblk; b += 16, ++q) s4[q & 3] += part[(int64_t)b * 4096 + f];
+    sm[threadIdx.x] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    __syncthreads();
+    if (g == 0) {
+        float sv = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) sv += (sm[k * 64 + fl] + sm[(k + 1) * 64 + fl]) + (sm[(k + 2) * 64 + fl] + sm[(k + 3) * 64 + fl]);
+        const int lane = f & 63, e = (f >> 6) & 15, t = f >> 10;
+        const int k = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), col = 32 * t + (lane & 31);
+        if (k < K1) dW1[(int64_t)col * ldw + k] = sv;
+        else if (k == K1) db1[col] = sv;
+    }
+}
+
 // Same product for FEW row tiles (up to 512: the GO / gene matrices of a batch): with one 32-row tile per wavefront
 // only ntiles of the chip's 1024 SIMDs get work.  Here a wavefront takes one tile x ONE HALF of the output columns
 // (128 MFMAs, 128 registers of W), two wavefronts per SIMD, every task resident at once: no tile loop, no refill.
@@ -1481,6 +1682,37 @@ extern "C" int kgw_mlp2w_fwd(int32_t n_jobs, const float* const* src, const int3
     }
     const int64_t ntiles = (a.rows + 31) / 32;
     k_mlp2w_fwd<<<(unsigned)((ntiles + 1) / 2), 256, lds, (hipStream_t)stream_>>>(a);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+extern "C" int64_t kgw_mlp2_bwd_first_workspace_floats(int64_t rows) {
+    int64_t nblk = ((rows + 31) / 32 + 3) / 4;
+    if (nblk > 256) nblk = 256;
+    if (nblk < 1) nblk = 1;
+    return nblk * 4096;
+}
+
+extern "C" int kgw_mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2, int64_t ldw2, const float* H1, int64_t ldh1,
+                                  const float* X, int64_t ldx, int32_t K1, int64_t rows, const int32_t* rows_dev, float* dW1,
+                                  int64_t ldw1, float* db1, float* workspace, int64_t workspace_floats, kgw_stream_t stream_) {
+    if (!dH2 || !W2 || !H1 || !X || !dW1 || !db1 || !workspace) return KGW_E_NULL;
+    if (rows <= 0 || K1 <= 0) return KGW_E_RANGE;
+    if (K1 > 31 || (ldd & 3) || (ldw2 & 3) || (ldh1 & 3) || !aligned16(dH2) || !aligned16(W2) || !aligned16(H1)) return KGW_E_UNSUPPORTED;
+    int64_t nblk = ((rows + 31) / 32 + 3) / 4;
+    if (nblk > 256) nblk = 256;
+    if (workspace_floats < nblk * 4096) return KGW_E_RANGE;
+    Mlp2BwdArgs a{dH2, ldd, W2, ldw2, H1, ldh1, X, ldx, workspace, rows, K1, rows_dev};
+    const size_t lds = (size_t)(128 * WST + 4 * 32 * TST) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        KGW_HIP(hipFuncSetAttribute((const void*)k_mlp2_bwd_first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipStream_t st = (hipStream_t)stream_;
+    k_mlp2_bwd_first<<<(int)nblk, 256, lds, st>>>(a);
+    KGW_LAUNCH_CHECK();
+    k_mlp2_bwd_fold<<<4096 / 64, 1024, 0, st>>>(workspace, (int)nblk, K1, dW1, ldw1, db1);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }

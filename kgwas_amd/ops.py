@@ -648,6 +648,21 @@ class _MLP2(torch.autograd.Function):
         x, h1, W2 = ctx.saved_tensors
         rd = ctx.rows_dev
         dh2 = dh2.contiguous()
+        rows, K1 = x.shape
+        if (_MLP2_FUSED and rows >= 16384 and K1 <= 31 and h1.shape[1] == KGW_C and W2.shape == (KGW_C, KGW_C) and x.stride(1) == 1
+                and h1.stride(1) == 1 and dh2.stride(0) % 4 == 0 and h1.stride(0) % 4 == 0 and W2.stride(0) % 4 == 0
+                and dh2.data_ptr() % 16 == 0 and h1.data_ptr() % 16 == 0 and W2.data_ptr() % 16 == 0):
+            # narrow first layer, no input gradient: dh1 = (dh2 @ W2) * (h1 > 0) is consumed tile by tile by the d W1 / d b1
+            # product inside ONE kernel (kgw_mlp2_bwd_first) -- neither written nor re-read
+            L = _lib.lib()
+            dW1 = torch.empty(KGW_C, K1, device=x.device)
+            db1 = torch.empty(KGW_C, device=x.device)
+            nws = int(L.kgw_mlp2_bwd_first_workspace_floats(rows))
+            ws = torch.empty(nws, device=x.device)
+            _lib.check(L.kgw_mlp2_bwd_first(_p(dh2), dh2.stride(0), _p(W2), W2.stride(0), _p(h1), h1.stride(0), _p(x), x.stride(0), K1,
+                                            rows, _p(rd), _p(dW1), K1, _p(db1), _p(ws), nws, _lib.stream_ptr()), 'kgw_mlp2_bwd_first')
+            dW2, db2 = linear_weight_grad(dh2, h1, rows_dev=rd)
+            return None, dW1, db1, dW2, db2, None, None, None
         dh1 = linear(dh2, W2, mask=h1, w_kn=True, rows_dev=rd)   # (dh2 @ W2) * (h1 > 0)
         (dW2, db2), (dW1, db1) = weight_grads([(dh2, h1), (dh1, x)], rows_dev=rd)
         return None, dW1, db1, dW2, db2, None, None, None
