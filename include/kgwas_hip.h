@@ -354,11 +354,15 @@ int kgw_mlp2w_fwd(int32_t n_jobs, const float* const* src, const int32_t* const*
 /* Backward of the NARROW first layer behind kgw_mlp2_fwd (no input gradient wanted): d W1 [128, K1] (row stride ldw1) and
  * d b1 [128] of  h1 = relu(x W1^T + b1)  given the upstream dH2 [rows, 128] of h2 = relu(h1 W2^T + b2) (already multiplied
  * by h2 > 0), W2, h1 and x [rows, K1 <= 31]: dh1 = (dH2 W2) * (h1 > 0) is formed tile by tile and consumed in place by the
- * d W1 product -- never written.  workspace: kgw_mlp2_bwd_first_workspace_floats(rows) floats.                      */
+ * d W1 product -- never written.  workspace: kgw_mlp2_bwd_first_workspace_floats(rows) floats.
+ * Variant for a WIDE first layer computed on a resident feature matrix (the gene layer): in_ids [rows] (row r of the product
+ * reads dH2[in_ids[r]], < 0: the node is not in the batch, its dh1 row is zero), dZ [rows, 128] receives the masked dh1 rows
+ * (the layer's own weight gradient is a library product over them) and K1 = 0 leaves only d b1 (X, dW1 unused).        */
 int64_t kgw_mlp2_bwd_first_workspace_floats(int64_t rows);
 int kgw_mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2, int64_t ldw2, const float* H1, int64_t ldh1,
                        const float* X, int64_t ldx, int32_t K1, int64_t rows, const int32_t* rows_dev, float* dW1,
-                       int64_t ldw1, float* db1, float* workspace, int64_t workspace_floats, kgw_stream_t stream);
+                       int64_t ldw1, float* db1, float* workspace, int64_t workspace_floats, const int32_t* in_ids, float* dZ,
+                       int64_t ldz, kgw_stream_t stream);
 
 /* The same product for FEW rows when one of K, N is 128 and the other a multiple of 128 -- the per-relation transform
  * of a layer after aggregate-then-transform, [N_dst, R*128] x [R*128, 128] with N_dst ~ 0.5-1.2 k destination rows of a

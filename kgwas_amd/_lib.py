@@ -185,7 +185,8 @@ def lib():
     L.kgw_mlp2_bwd_first_workspace_floats.restype = C.c_int64
     L.kgw_mlp2_bwd_first_workspace_floats.argtypes = [C.c_int64]
     L.kgw_mlp2_bwd_first.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32,
-                                     C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+                                     C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                     C.c_int64, C.c_void_p]
     L.kgw_linear_splitk_workspace_floats.restype = C.c_int64
     L.kgw_linear_splitk_workspace_floats.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     L.kgw_linear_splitk.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,

@@ -1261,6 +1261,9 @@ struct Mlp2BwdArgs {
     float* part;                        // [gridDim.x][4096] block partials, fragment order
     int64_t rows; int K1;
     const int32_t* rows_dev;
+    const int32_t* in_ids;              // nullable: row r of the product reads dH2[in_ids[r]]; in_ids[r] < 0 => dh1 row r is zero
+    float* dZ; int64_t ldz;             // nullable: the masked dh1 rows are ALSO written here (a wide first layer's own
+                                        // weight gradient is a library product over them); K1 = 0 then leaves just d b1
 };
 
 constexpr int TST = 132;                // LDS row stride of the transposing tile
@@ -1308,25 +1311,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int K1 = a.K1;
     int tile = (int)blockIdx.x * 4 + wave;
     f32x4 xa[16];
+    int src_cur;                                              // input row of this lane's row (-1: none -> zero row)
     {
         int64_t r = (int64_t)(tile < ntiles ? tile : ntiles - 1) * 32 + li;
         if (r >= rows) r = rows - 1;
-        const float* xp = a.dH2 + r * a.ldd + lk * 64;
+        src_cur = a.in_ids ? a.in_ids[r] : 0;
+        const float* xp = a.dH2 + (a.in_ids ? (int64_t)(src_cur < 0 ? 0 : src_cur) : r) * a.ldd + lk * 64;
 #pragma unroll
         for (int q = 0; q < 16; ++q) xa[q] = *(const f32x4*)(xp + 4 * q);
     }
     for (; tile < ntiles; tile += nw) {
         const int64_t r0 = (int64_t)tile * 32;
         const int64_t row = r0 + li;
-        const bool live = row < rows;
-        const int64_t rc = live ? row : rows - 1;
+        const bool live = row < rows && src_cur >= 0;
+        const int64_t rc = row < rows ? row : rows - 1;
         const float* xn;                                      // this lane's half row of the wavefront's NEXT tile
         {
             int nt = tile + nw;
             if (nt >= ntiles) nt = ntiles - 1;               // last round: a harmless re-read
             int64_t r = (int64_t)nt * 32 + li;
             if (r >= rows) r = rows - 1;
-            xn = a.dH2 + r * a.ldd + lk * 64;
+            src_cur = a.in_ids ? a.in_ids[r] : 0;            // (of the NEXT tile from here on: `live` above is this tile's)
+            xn = a.dH2 + (a.in_ids ? (int64_t)(src_cur < 0 ? 0 : src_cur) : r) * a.ldd + lk * 64;
         }
         // x' in "k per lane" form for the second product: lane (k = li, row parity lk), step s = row pair (needed after
         // the first product: the loads ride under its MFMAs)
@@ -1398,6 +1404,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 v.x = (m4 & 1u) ? acc[t][4 * g + 0] : 0.f; v.y = (m4 & 2u) ? acc[t][4 * g + 1] : 0.f;
                 v.z = (m4 & 4u) ? acc[t][4 * g + 2] : 0.f; v.w = (m4 & 8u) ? acc[t][4 * g + 3] : 0.f;
                 *(f32x4*)(Tw + li * TST + t * 32 + 8 * g + 4 * lk) = v;
+                if (a.dZ && row < rows) *(f32x4*)(a.dZ + row * a.ldz + t * 32 + 8 * g + 4 * lk) = v;
             }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // second product: C[k][col] += x'[row][k] dh1[row][col], two rows per MFMA step
@@ -1695,14 +1702,17 @@ extern "C" int64_t kgw_mlp2_bwd_first_workspace_floats(int64_t rows) {
 
 extern "C" int kgw_mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2, int64_t ldw2, const float* H1, int64_t ldh1,
                                   const float* X, int64_t ldx, int32_t K1, int64_t rows, const int32_t* rows_dev, float* dW1,
-                                  int64_t ldw1, float* db1, float* workspace, int64_t workspace_floats, kgw_stream_t stream_) {
-    if (!dH2 || !W2 || !H1 || !X || !dW1 || !db1 || !workspace) return KGW_E_NULL;
-    if (rows <= 0 || K1 <= 0) return KGW_E_RANGE;
+                                  int64_t ldw1, float* db1, float* workspace, int64_t workspace_floats, const int32_t* in_ids,
+                                  float* dZ, int64_t ldz, kgw_stream_t stream_) {
+    if (!dH2 || !W2 || !H1 || !db1 || !workspace) return KGW_E_NULL;
+    if (rows <= 0 || K1 < 0) return KGW_E_RANGE;
+    if (K1 > 0 && (!X || !dW1)) return KGW_E_NULL;
+    if (dZ && ((ldz & 3) || !aligned16(dZ))) return KGW_E_UNSUPPORTED;
     if (K1 > 31 || (ldd & 3) || (ldw2 & 3) || (ldh1 & 3) || !aligned16(dH2) || !aligned16(W2) || !aligned16(H1)) return KGW_E_UNSUPPORTED;
     int64_t nblk = ((rows + 31) / 32 + 3) / 4;
     if (nblk > 256) nblk = 256;
     if (workspace_floats < nblk * 4096) return KGW_E_RANGE;
-    Mlp2BwdArgs a{dH2, ldd, W2, ldw2, H1, ldh1, X, ldx, workspace, rows, K1, rows_dev};
+    Mlp2BwdArgs a{dH2, ldd, W2, ldw2, H1, ldh1, X, ldx, workspace, rows, K1, rows_dev, in_ids, dZ, ldz};
     const size_t lds = (size_t)(128 * WST + 4 * 32 * TST) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

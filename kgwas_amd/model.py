@@ -312,6 +312,9 @@ class HeteroGNN(nn.Module):
             if X.shape[1] >= 512 and 2 * n > X.shape[0]:
                 i = dg.schema.type_id[t]
                 g2l = batch.buf.g2l[dg.node_base[i]:dg.node_base[i] + X.shape[0]]
+                if fold and ops.resident_mlp2_ok(X, mlp.FC_hidden.weight, mlp.FC_hidden2.weight, n):
+                    return ops.resident_mlp2(X, mlp.FC_hidden.weight, mlp.FC_hidden.bias, mlp.FC_hidden2.weight,
+                                             mlp.FC_hidden2.bias, batch.n_id(t), g2l, out)
                 h1 = ops.resident_linear_relu_rows(X, mlp.FC_hidden.weight, mlp.FC_hidden.bias, batch.n_id(t), g2l)
                 return mlp.tail2(h1, out) if fold else mlp.tail(h1, out)
         # static layout: the row block is padded to its capacity; the kernels skip the padding (count on the device)

@@ -660,7 +660,7 @@ class _MLP2(torch.autograd.Function):
             nws = int(L.kgw_mlp2_bwd_first_workspace_floats(rows))
             ws = torch.empty(nws, device=x.device)
             _lib.check(L.kgw_mlp2_bwd_first(_p(dh2), dh2.stride(0), _p(W2), W2.stride(0), _p(h1), h1.stride(0), _p(x), x.stride(0), K1,
-                                            rows, _p(rd), _p(dW1), K1, _p(db1), _p(ws), nws, _lib.stream_ptr()), 'kgw_mlp2_bwd_first')
+                                            rows, _p(rd), _p(dW1), K1, _p(db1), _p(ws), nws, None, None, 0, _lib.stream_ptr()), 'kgw_mlp2_bwd_first')
             dW2, db2 = linear_weight_grad(dh2, h1, rows_dev=rd)
             return None, dW1, db1, dW2, db2, None, None, None
         dh1 = linear(dh2, W2, mask=h1, w_kn=True, rows_dev=rd)   # (dh2 @ W2) * (h1 > 0)
@@ -802,6 +802,50 @@ class _ResidentLinearReLURows(torch.autograd.Function):
         with _TUNED:
             dW = dz.t().mm(X)
         return None, dW, db, None, None
+
+
+class _ResidentMLP2(torch.autograd.Function):
+    """h2 = relu(FC_hidden2(relu(FC_hidden(X))[ids])) for a RESIDENT wide feature matrix X (the gene features): the two nodes
+    _ResidentLinearReLURows + _MLPTail2 as one, so that the backward forms  dz = ((dh2[g2l] @ W2) * (h > 0))  -- dense over
+    the resident rows, zero where a node is not in the batch -- and d b1 in ONE kernel (kgw_mlp2_bwd_first with row
+    indirection) instead of dX product + scatter/mask pass + column-sum fold; d W1 stays the library product dz^T X."""
+
+    @staticmethod
+    def forward(ctx, X, W1, b1, W2, b2, ids, g2l, out):
+        h = linear(X, W1, b1, relu=True, fixed_shape=True)
+        n = int(ids.numel())
+        h1g = torch.empty(n, h.shape[1], device=h.device)
+        if n:
+            _lib.check(_lib.lib().kgw_gather_rows(_p(h), _p(ids), n, h.shape[1], _p(h1g), _lib.stream_ptr()), 'kgw_gather_rows')
+        h2 = linear(h1g, W2, b2, relu=True, out=out.view() if out is not None else None)
+        ctx.save_for_backward(X, h, h1g, W2, g2l)
+        return h2
+
+    @staticmethod
+    def backward(ctx, dh2):
+        X, h, h1g, W2, g2l = ctx.saved_tensors
+        dh2 = dh2.contiguous()
+        N = h.shape[0]
+        L = _lib.lib()
+        dz = torch.empty_like(h)
+        db1 = torch.empty(KGW_C, device=h.device)
+        nws = int(L.kgw_mlp2_bwd_first_workspace_floats(N))
+        ws = torch.empty(nws, device=h.device)
+        _lib.check(L.kgw_mlp2_bwd_first(_p(dh2), dh2.stride(0), _p(W2), W2.stride(0), _p(h), h.stride(0), None, 0, 0, N, None, None, 0,
+                                        _p(db1), _p(ws), nws, _p(g2l), _p(dz), dz.stride(0), _lib.stream_ptr()), 'kgw_mlp2_bwd_first')
+        with _TUNED:
+            dW1 = dz.t().mm(X)
+        dW2, db2 = linear_weight_grad(dh2, h1g)
+        return None, dW1, db1, dW2, db2, None, None, None
+
+
+def resident_mlp2(X, W1, b1, W2, b2, ids, g2l, out=None):
+    return _ResidentMLP2.apply(X, W1, b1, W2, b2, ids, g2l, out)
+
+
+def resident_mlp2_ok(X, W1, W2, n_local: int) -> bool:
+    return (_MLP2_FUSED and W1.shape[0] == KGW_C and W2.shape == (KGW_C, KGW_C) and n_local > 0 and X.shape[0] >= 4096
+            and W2.stride(1) == 1 and W2.stride(0) % 4 == 0 and W2.data_ptr() % 16 == 0)
 
 
 def resident_linear_relu_rows(X, W, b, ids, g2l):
