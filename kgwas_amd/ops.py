@@ -125,8 +125,13 @@ def _layer_args(batch, layer: int, neg_slope: float, inv_temp: float) -> KgwLaye
     a.meta_host = C.addressof(m)
     a.meta_dev = _p(buf.meta)
     a.chunks = _p(buf.chunks)
-    a.multi = _p(buf.multi)
-    a.multi_cap = dg.multi_cap
+    # hub rows (segments of more than one chunk) need the combine launches -- unless no destination row this layer can have is
+    # one: the top layer of a minibatch only aggregates into the seeds' type (a static property of the graph)
+    seeds_only = (not dg.full_graph) and a.n_multi_hops == 1 and batch.input_type is not None and \
+        dg.schema.type_id[batch.input_type] not in dg.multi_dst_types
+    if not seeds_only:
+        a.multi = _p(buf.multi)
+        a.multi_cap = dg.multi_cap
     a.col_local = _p(buf.col_local)
     a.t_ptr = _p(buf.t_ptr[layer - 1])
     a.t_edge = _p(buf.t_edge[layer - 1])

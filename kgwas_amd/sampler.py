@@ -60,6 +60,7 @@ class DeviceGraph:
         seg_cap = edge_cap = chunk_cap = multi_cap = 0
         ro = co = 0
         out_edges = [0] * sc.NT                        # edges leaving the nodes of each type (all relations)
+        self.multi_dst_types = set()                    # destination types that have a row of more than KGW_CHUNK in-edges
         for r, et in enumerate(sc.edge_types):
             cached = data._extra.get('csr', {}).get(tuple(et)) if hasattr(data, '_extra') else None
             if cached is not None:                    # kgwas_amd/ingest.py: CSR straight from the on-disk cache
@@ -75,6 +76,8 @@ class DeviceGraph:
             nch = (deg + KGW_CHUNK - 1) // KGW_CHUNK
             chunk_cap += int(nch.sum())
             multi_cap += int((nch > 1).sum())
+            if len(nch) and int(nch.max()) > 1:
+                self.multi_dst_types.add(sc.dst_type[r])
             rowptrs.append(rp.astype(np.int32)); cols.append(col)
             rp_off.append(ro); col_off.append(co)
             ro += len(rp); co += len(col)
