@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define KGW_VERSION      111          /* 0.1.1 */
+#define KGW_VERSION      112          /* 0.1.2 */
 #define KGW_MAX_TYPES    8
 #define KGW_MAX_RELS     64
 #define KGW_MAX_LAYERS   4
@@ -363,6 +363,21 @@ int kgw_mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2, int64_t l
                        const float* X, int64_t ldx, int32_t K1, int64_t rows, const int32_t* rows_dev, float* dW1,
                        int64_t ldw1, float* db1, float* workspace, int64_t workspace_floats, const int32_t* in_ids, float* dZ,
                        int64_t ldz, kgw_stream_t stream);
+
+/* C[M, 128] = A[M, K] B[K, 128] for a tall RESIDENT fp32 matrix A -- the first gene Linear, kgwas/model.py:13,19 over the
+ * 5 120-wide gene features (kgwas_data.py:236,244): forward with A = X [genes, K], B = W1^T (out = relu(C + bias)), and its
+ * weight gradient with A = X^T [K, genes], B = dz (transpose_out: out[n, m] = C[m, n], i.e. dW1 [128, K]).  Runs on the bf16
+ * matrix pipe with fp32 error: every fp32 operand is split exactly into three bf16 pieces and the six piece products of
+ * weight >= 2^-16 are accumulated in fp32; the dropped products are below the rounding of one fp32 multiply-add (see
+ * kgwas_amd/csrc/kgw_gemm3.hip).  kgw_gemm3_pack splits B once per call into the kernel's operand image (packed:
+ * kgw_gemm3_packed_bytes(K) bytes; s_is_kn: B[k, n] = S[k * lds + n], else B[k, n] = S[n * lds + k], n < 128).  A is split in
+ * the kernel.  K % 32 == 0, lda % 4 == 0, 16-byte aligned pointers, else KGW_E_UNSUPPORTED.  workspace:
+ * kgw_gemm3_workspace_floats(M, K) floats (partial products of the K ranges, added in index order: deterministic).      */
+int64_t kgw_gemm3_packed_bytes(int64_t K);
+int64_t kgw_gemm3_workspace_floats(int64_t M, int64_t K);
+int kgw_gemm3_pack(const float* S, int64_t lds, int64_t K, int32_t s_is_kn, void* packed, kgw_stream_t stream);
+int kgw_gemm3(const float* A, int64_t lda, int64_t M, int64_t K, const void* packed, float* workspace, int64_t workspace_floats,
+              const float* bias, int32_t relu, float* out, int64_t ldo, int32_t transpose_out, kgw_stream_t stream);
 
 /* The same product for FEW rows when one of K, N is 128 and the other a multiple of 128 -- the per-relation transform
  * of a layer after aggregate-then-transform, [N_dst, R*128] x [R*128, 128] with N_dst ~ 0.5-1.2 k destination rows of a

@@ -1,0 +1,340 @@
+// kgw_gemm3.hip -- C[M, 128] = A[M, K] * B[K, 128] for a tall RESIDENT fp32 matrix A: the first gene Linear
+// (kgwas/model.py:13,19 -- FC_hidden over the 5 120-wide gene features, kgwas_data.py:236,244) forward, A = X, B = W1^T, and
+// its weight gradient, A = X^T (a second resident copy), B = dz.  2 x 26 GFLOP per step: on the fp32 matrix pipe (157 TF)
+// that is 0.17 ms each at 100 %.
+//
+// Here the product runs on the bf16 matrix pipe WITHOUT narrowing the arithmetic.  Every fp32 operand is split EXACTLY into
+// three bf16 pieces, a = a1 + a2 + a3 (a1 = bf16(a), a2 = bf16(a - a1), a3 = a - a1 - a2: 3 x 8 significand bits = the 24 of
+// fp32, the residuals are exact in fp32), and of the nine piece products the six of weight >= 2^-16,
+//      a1 b1 + (a1 b2 + a2 b1) + (a2 b2 + a1 b3 + a3 b1),
+// are accumulated in fp32 (each bf16 x bf16 product is exact in fp32).  The three dropped ones are bounded by
+// 3 * 2^-25 |a||b| per term of the dot product -- below the rounding of ONE fp32 multiply-add (2^-24 |a||b|), i.e. the
+// result differs from an fp32 chain by less than the fp32 chain's own error bound (tests/test_gpu_gemm3.py measures both
+// against float64).  6 x 26 GFLOP on a 2.5 PF pipe = 63 us; reading A once (410 MB) = ~75 us: the kernel is HBM bound where
+// the fp32 product is MFMA bound.
+//
+// Shape of the kernel.  Work item = (128-row tile of A, K range); 4 wavefronts, each owns 32 rows x 128 columns (four
+// 32x32x16 accumulators), two blocks per CU.  K advances in chunks of 32:
+//   A: a wavefront loads its 32 x 32 fp32 block coalesced (8 rows x 128 B per instruction, non-temporal), two chunks ahead,
+//      writes it to a wavefront-PRIVATE 4 KB LDS tile (XOR-swizzled 16-byte slots: ds_write_b128 and ds_read_b128 conflict
+//      free) and reads it back in MFMA operand layout (lane = row, 8 consecutive k) -- no block barrier on this path; the
+//      three-way split is 44 VALU instructions per 24 MFMAs, done on the operand registers;
+//   B: split once per call by kgw_gemm3_pack_* into the LDS image itself ([chunk][k16 step][piece][column tile][lane] x 16 B,
+//      lane-linear: a straight copy, conflict-free ds_read_b128), double buffered, one barrier per chunk.
+// Partial products go to a workspace [split][M][128]; kgw_gemm3 ends with a fixed-order reduction (+ bias, ReLU, or a
+// transposed store for the weight gradient).  Deterministic: no atomics, fixed K ranges.
+#include "kgw_common.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 g3_bf8;
+typedef __attribute__((ext_vector_type(16))) float g3_f16;
+typedef __attribute__((ext_vector_type(4))) float g3_f4;
+typedef __attribute__((ext_vector_type(4))) unsigned g3_u4;
+
+static constexpr int G3_CH_U4 = 1536;          // uint4 per packed chunk of 32 k: 2 steps x 3 pieces x 4 column tiles x 64 lanes
+static constexpr int G3_MAX_ITEMS = 512;       // 128-row blocks resident at once: two per CU on 256 CUs (256-row blocks: one)
+
+__device__ __forceinline__ uint32_t g3_cvt_pk(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float g3_lo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float g3_hi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// eight fp32 -> three pieces of eight bf16 (element i in bits 16 (i & 1) of word i / 2)
+__device__ __forceinline__ void g3_split8(const float (&x)[8], uint4& p1, uint4& p2, uint4& p3) {
+    uint32_t a[4], b[4], c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = x[2 * i], x1 = x[2 * i + 1];
+        a[i] = g3_cvt_pk(x0, x1);
+        const float r0 = x0 - g3_lo(a[i]), r1 = x1 - g3_hi(a[i]);
+        b[i] = g3_cvt_pk(r0, r1);
+        const float s0 = r0 - g3_lo(b[i]), s1 = r1 - g3_hi(b[i]);
+        c[i] = g3_cvt_pk(s0, s1);
+    }
+    p1 = make_uint4(a[0], a[1], a[2], a[3]);
+    p2 = make_uint4(b[0], b[1], b[2], b[3]);
+    p3 = make_uint4(c[0], c[1], c[2], c[3]);
+}
+
+// ---- B operand packing ------------------------------------------------------------------------------------------------------
+// image index (((c * 2 + j) * 3 + p) * 4 + nt) * 64 + lane: the eight bf16 of piece p for k = 32 c + 16 j + 8 (lane >> 5) + i,
+// column 32 nt + (lane & 31).  One thread per (c, j, nt, lane).
+template <bool KN>
+__global__ void __launch_bounds__(256) k_g3_pack(const float* __restrict__ S, long lds_, int K, uint4* __restrict__ out) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)K * 16) return;
+    const int lane = (int)(t & 63), nt = (int)((t >> 6) & 3), j = (int)((t >> 8) & 1);
+    const long c = t >> 9;
+    const int n = 32 * nt + (lane & 31);
+    const long k0 = 32 * c + 16 * j + 8 * (lane >> 5);
+    float x[8];
+    if (KN) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = S[(k0 + i) * lds_ + n];
+    } else {
+        const float4 u = *(const float4*)(S + n * lds_ + k0), v = *(const float4*)(S + n * lds_ + k0 + 4);
+        x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
+    }
+    uint4 p1, p2, p3;
+    g3_split8(x, p1, p2, p3);
+    uint4* o = out + ((c * 2 + j) * 3 * 4 + nt) * 64 + lane;
+    o[0] = p1; o[4 * 64] = p2; o[8 * 64] = p3;
+}
+
+// ---- the product ---------------------------------------------------------------------------------------------------------------
+struct G3Args {
+    const float* A; long lda; int M, K;
+    const uint4* Bp;
+    float* ws;
+    int nsplit;
+    int dbg;          // timing experiments: 1 = A always chunk 0 (compute only), 2 = no MFMA work (memory only)
+};
+
+// MT = 32-row tiles per wavefront: 1 -> 128-row blocks, two per CU (two wavefronts per SIMD); 2 -> 256-row blocks, one per
+// CU, every B operand read from LDS feeds two MFMAs and a barrier comes every 96 MFMAs instead of 48.
+// Both LDS tiles are double buffered in SEPARATE arrays (the compiler then knows that the stores of chunk c + 1 do not alias
+// the operand reads of chunk c and spreads them over the MFMA stream instead of queueing them in front of a barrier).
+template <int MT, int DBG = 0>
+__global__ void __launch_bounds__(256, 2 / MT) k_g3_gemm(G3Args a) {
+    constexpr int NQ = 4 * MT;                 // A load instructions per chunk (8 rows x 128 B each)
+    constexpr int AT = 256 * MT;               // 16-byte slots per wavefront-private A tile
+    __shared__ g3_u4 smB0[G3_CH_U4], smB1[G3_CH_U4];
+    __shared__ g3_f4 smA0[4 * AT], smA1[4 * AT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x / a.nsplit, split = blockIdx.x - tile * a.nsplit;
+    const int nch = a.K >> 5;
+    const int c0 = (int)((long)nch * split / a.nsplit), c1 = (int)((long)nch * (split + 1) / a.nsplit);
+    const int nc = c1 - c0;
+    const int row0 = tile * (128 * MT) + wave * (32 * MT);
+
+    // A addressing: instruction q covers rows 8 q .. 8 q + 7 of the wavefront's rows, 128 contiguous bytes each; 16-byte
+    // slot s of row r lives at slot s ^ ((r >> 1) & 7) of its 128-byte LDS row
+    const float* ap[NQ];
+    int aw[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int r = 8 * q + (lane >> 3);
+        int row = row0 + r;
+        row = row < a.M ? row : a.M - 1;
+        ap[q] = a.A + (long)row * a.lda + (long)c0 * 32 + (lane & 7) * 4;
+        aw[q] = wave * AT + r * 8 + ((lane & 7) ^ ((r >> 1) & 7));
+    }
+    const int m = lane & 31, g = lane >> 5, sw = (m >> 1) & 7;
+    const g3_u4* bp = (const g3_u4*)a.Bp + (long)c0 * G3_CH_U4 + tid;
+
+    g3_f4 ra[NQ], rb[NQ];
+    g3_u4 bs[6];
+    g3_f16 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+    auto load_a = [&](g3_f4 (&r)[NQ], int c) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) r[q] = __builtin_nontemporal_load((const g3_f4*)(ap[q] + (long)c * 32));
+    };
+    auto store_a = [&](const g3_f4 (&r)[NQ], g3_f4* A) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) A[aw[q]] = r[q];
+    };
+    auto load_b = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) bs[i] = bp[(long)c * G3_CH_U4 + i * 256];
+    };
+    auto store_b = [&](g3_u4* B) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) B[tid + i * 256] = bs[i];
+    };
+    auto compute = [&](const g3_f4* A_, const g3_u4* B_) {
+        const g3_u4* B = B_ + lane;
+        const g3_f4* A = A_ + wave * AT + m * 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int seg = 2 * (2 * j + g);
+            g3_bf8 ap_[MT][3];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const g3_f4 u = A[mt * 256 + (seg ^ sw)], v = A[mt * 256 + ((seg + 1) ^ sw)];
+                const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+                uint4 p1, p2, p3;
+                if (DBG == 3) { p1 = __builtin_bit_cast(uint4, u); p2 = __builtin_bit_cast(uint4, v); p3 = p1; } else g3_split8(x, p1, p2, p3);
+                ap_[mt][0] = __builtin_bit_cast(g3_bf8, p1);
+                ap_[mt][1] = __builtin_bit_cast(g3_bf8, p2);
+                ap_[mt][2] = __builtin_bit_cast(g3_bf8, p3);
+            }
+            g3_bf8 b[3][4];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) b[p][nt] = __builtin_bit_cast(g3_bf8, DBG == 4 ? bs[(p + nt) % 6] : B[((j * 3 + p) * 4 + nt) * 64]);
+            // (piece of A, piece of B), smallest products first; 4 MT independent accumulators between two uses of one
+            constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap_[mt][TA[t]], b[TB[t]][nt], acc[mt][nt], 0, 0, 0);
+        }
+    };
+
+    // steady state without branches: chunk indices past the end are clamped (a redundant load of the last chunk into a
+    // buffer nobody reads), so the load counters stay exact.  Iteration c: A of chunk c + 2 leaves for registers, chunk
+    // c + 1 (registers since iteration c - 1) goes to the other LDS buffers, chunk c is multiplied.
+    const int last = a.dbg == 1 ? 0 : nc - 1;
+    load_a(ra, 0);
+    load_b(0);
+    store_a(ra, smA0);
+    store_b(smB0);
+    load_a(ra, min(1, last));
+    load_b(min(1, last));
+    __syncthreads();
+    for (int c = 0; c < nc; c += 2) {
+        load_a(rb, min(c + 2, last));
+        if (DBG != 6) { store_a(ra, smA1); store_b(smB1); }
+        load_b(min(c + 2, last));
+        if (a.dbg != 2) compute(smA0, smB0);
+        if (DBG != 5) __syncthreads();
+        if (c + 1 >= nc) break;
+        load_a(ra, min(c + 3, last));
+        if (DBG != 6) { store_a(rb, smA0); store_b(smB0); }
+        load_b(min(c + 3, last));
+        if (a.dbg != 2) compute(smA1, smB1);
+        if (DBG != 5) __syncthreads();
+    }
+
+    // accumulator register r of a 32x32 tile: row 8 (r / 4) + 4 g + r % 4, column lane & 31
+    float* wp = a.ws + ((long)split * a.M) * 128 + m;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + 32 * mt + 8 * (r >> 2) + 4 * g + (r & 3);
+            if (row < a.M) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) wp[(long)row * 128 + 32 * nt] = acc[mt][nt][r];
+            }
+        }
+}
+
+// out[row, :] = act(sum_s ws[s, row, :] + bias), splits added in index order
+__global__ void __launch_bounds__(256) k_g3_reduce(const float* __restrict__ ws, int nsplit, long M, const float* __restrict__ bias,
+                                                   int relu, float* __restrict__ out, long ldo) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= M * 32) return;
+    const long row = t >> 5;
+    const int c4 = (int)(t & 31);
+    const float4* w = (const float4*)ws + t;
+    float4 s = w[0];
+    for (int k = 1; k < nsplit; ++k) {
+        const float4 v = w[(long)k * M * 32];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (bias) {
+        const float4 b = ((const float4*)bias)[c4];
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+    *(float4*)(out + row * ldo + 4 * c4) = s;
+}
+
+// out[col, row] = sum_s ws[s, row, col]: 32-row x 128-column tiles through LDS
+__global__ void __launch_bounds__(256) k_g3_reduce_t(const float* __restrict__ ws, int nsplit, long M, float* __restrict__ out, long ldo) {
+    __shared__ float tl[32][129];
+    const int tid = threadIdx.x;
+    const long r0 = (long)blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i;               // float4 index in the tile: row e / 32, column group e % 32
+        const int r = e >> 5, c4 = e & 31;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + r < M) {
+            const float4* w = (const float4*)ws + (r0 + r) * 32 + c4;
+            s = w[0];
+            for (int k = 1; k < nsplit; ++k) {
+                const float4 v = w[(long)k * M * 32];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        }
+        tl[r][4 * c4] = s.x; tl[r][4 * c4 + 1] = s.y; tl[r][4 * c4 + 2] = s.z; tl[r][4 * c4 + 3] = s.w;
+    }
+    __syncthreads();
+    const int r = tid & 31;
+    if (r0 + r < M) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int col = (tid >> 5) + 8 * i;
+            out[(long)col * ldo + r0 + r] = tl[r][col];
+        }
+    }
+}
+
+// ---- C ABI ---------------------------------------------------------------------------------------------------------------------
+static int g3_mt() {
+    static const int mt = getenv("KGW_G3_MT") ? atoi(getenv("KGW_G3_MT")) : 1;
+    return mt == 1 ? 1 : 2;
+}
+
+static int g3_splits(int64_t M, int64_t K) {
+    const int mt = g3_mt();
+    const int64_t tiles = (M + 128 * mt - 1) / (128 * mt), nch = K / 32;
+    int64_t s = (G3_MAX_ITEMS / mt) / tiles;
+    if (s > nch / 8) s = nch / 8;
+    if (s > 16) s = 16;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+extern "C" int64_t kgw_gemm3_packed_bytes(int64_t K) { return K > 0 && K % 32 == 0 ? (K / 32) * G3_CH_U4 * 16 : 0; }
+
+extern "C" int64_t kgw_gemm3_workspace_floats(int64_t M, int64_t K) {
+    return M > 0 && K > 0 ? (int64_t)g3_splits(M, K) * M * 128 : 0;
+}
+
+extern "C" int kgw_gemm3_pack(const float* S, int64_t lds_, int64_t K, int32_t s_is_kn, void* packed, kgw_stream_t stream_) {
+    if (!S || !packed) return KGW_E_NULL;
+    if (K <= 0) return KGW_E_RANGE;
+    if (K % 32 || ((uintptr_t)packed & 15)) return KGW_E_UNSUPPORTED;
+    if (!s_is_kn && ((lds_ & 3) || ((uintptr_t)S & 15))) return KGW_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream_;
+    const int64_t nthr = K * 16;
+    if (s_is_kn) k_g3_pack<true><<<(int)((nthr + 255) / 256), 256, 0, st>>>(S, lds_, (int)K, (uint4*)packed);
+    else k_g3_pack<false><<<(int)((nthr + 255) / 256), 256, 0, st>>>(S, lds_, (int)K, (uint4*)packed);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+extern "C" int kgw_gemm3(const float* A, int64_t lda, int64_t M, int64_t K, const void* packed, float* workspace,
+                         int64_t workspace_floats, const float* bias, int32_t relu, float* out, int64_t ldo, int32_t transpose_out,
+                         kgw_stream_t stream_) {
+    if (!A || !packed || !workspace || !out) return KGW_E_NULL;
+    if (M <= 0 || K <= 0 || M > (1 << 30) || K > (1 << 30)) return KGW_E_RANGE;
+    if (K % 32 || (lda & 3) || ((uintptr_t)A & 15) || ((uintptr_t)packed & 15) || ((uintptr_t)workspace & 15)) return KGW_E_UNSUPPORTED;
+    if (!transpose_out && ((ldo & 3) || ((uintptr_t)out & 15) || (bias && ((uintptr_t)bias & 15)))) return KGW_E_UNSUPPORTED;
+    if (transpose_out && (bias || relu)) return KGW_E_UNSUPPORTED;
+    const int ns = g3_splits(M, K);
+    if (workspace_floats < (int64_t)ns * M * 128) return KGW_E_RANGE;
+    const int mt = g3_mt();
+    const int tiles = (int)((M + 128 * mt - 1) / (128 * mt));
+    hipStream_t st = (hipStream_t)stream_;
+    static const int dbg = getenv("KGW_G3_DBG") ? atoi(getenv("KGW_G3_DBG")) : 0;
+    G3Args a{A, (long)lda, (int)M, (int)K, (const uint4*)packed, workspace, ns, dbg};
+    if (mt == 1 && dbg == 3) k_g3_gemm<1, 3><<<tiles * ns, 256, 0, st>>>(a);
+    else if (mt == 1 && dbg == 4) k_g3_gemm<1, 4><<<tiles * ns, 256, 0, st>>>(a);
+    else if (mt == 1 && dbg == 5) k_g3_gemm<1, 5><<<tiles * ns, 256, 0, st>>>(a);
+    else if (mt == 1 && dbg == 6) k_g3_gemm<1, 6><<<tiles * ns, 256, 0, st>>>(a);
+    else if (mt == 1) k_g3_gemm<1><<<tiles * ns, 256, 0, st>>>(a);
+    else k_g3_gemm<2><<<tiles * ns, 256, 0, st>>>(a);
+    KGW_LAUNCH_CHECK();
+    if (transpose_out) k_g3_reduce_t<<<(int)((M + 31) / 32), 256, 0, st>>>(workspace, ns, (long)M, out, (long)ldo);
+    else k_g3_reduce<<<(int)((M * 32 + 255) / 256), 256, 0, st>>>(workspace, ns, (long)M, bias, relu, out, (long)ldo);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}

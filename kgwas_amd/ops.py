@@ -110,6 +110,7 @@ TIMER = KernelTimer()
 _MLP2_FUSED = os.environ.get('KGW_MLP2_FUSED', '1') != '0'        # 0: the two hidden layers of a narrow MLP as two launches
 _TN_GROUP = os.environ.get('KGW_TN_GROUP', '1') != '0'             # 0: one launch pair per destination type in the transform's backward
 _DUV_RIDERS = os.environ.get('KGW_DUV_RIDERS', '1') != '0'        # 0: d u_r / d v_r through the [d a_src | d a_dst] rows + product
+_GEMM3 = os.environ.get('KGW_GEMM3', '1') != '0'                   # 0: the first gene Linear and its weight gradient on the library's fp32 product
 _SHORT_ROWS = os.environ.get('KGW_SHORT_ROWS', '1') != '0'     # 0: every source row on the general path (timing experiments)
 
 
@@ -490,6 +491,74 @@ def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask
     return Y
 
 
+def gemm3_ok(M: int, K: int) -> bool:
+    return _GEMM3 and K % 32 == 0 and M >= 2048 and K >= 1024
+
+
+def gemm3_pack(S: torch.Tensor, K: int, s_is_kn: bool) -> torch.Tensor:
+    """B [K, 128] of a kgw_gemm3 product, split into its three bf16 pieces in the kernel's operand image.  ``s_is_kn``: S is
+    B itself ([K, 128]); else S = B^T ([128, K], an nn.Linear weight)."""
+    assert S.dtype == torch.float32 and S.stride(1) == 1 and (S.shape == (K, KGW_C) if s_is_kn else S.shape == (KGW_C, K))
+    L = _lib.lib()
+    packed = torch.empty(int(L.kgw_gemm3_packed_bytes(K)), dtype=torch.uint8, device=S.device)
+    _lib.check(L.kgw_gemm3_pack(_p(S), S.stride(0), K, 1 if s_is_kn else 0, _p(packed), _lib.stream_ptr()), 'kgw_gemm3_pack')
+    return packed
+
+
+def gemm3(A: torch.Tensor, packed: torch.Tensor, bias=None, relu: bool = False, transpose_out: bool = False, out=None):
+    """act(A [M, K] @ B [K, 128] + bias) -> [M, 128], or its transpose [128, M] (``transpose_out``): the tall resident product
+    of the first gene Linear on the bf16 matrix pipe with fp32 error (three exact bf16 pieces per operand, kgw_gemm3)."""
+    M, K = A.shape
+    assert A.dtype == torch.float32 and A.stride(1) == 1
+    L = _lib.lib()
+    if out is None:
+        out = torch.empty((KGW_C, M) if transpose_out else (M, KGW_C), device=A.device)
+    nws = int(L.kgw_gemm3_workspace_floats(M, K))
+    ws = torch.empty(nws, device=A.device)
+    _lib.check(L.kgw_gemm3(_p(A), A.stride(0), M, K, _p(packed), _p(ws), nws, _p(bias), 1 if relu else 0, _p(out), out.stride(0),
+                           1 if transpose_out else 0, _lib.stream_ptr()), 'kgw_gemm3')
+    return out
+
+
+_RESIDENT_T = {}
+
+
+def _resident_transpose(X: torch.Tensor) -> torch.Tensor:
+    """X^T of a resident feature matrix, built once per matrix (a second resident copy: 0.4 GB for the 5 120-wide gene
+    features) -- the A operand of the weight-gradient product on kgw_gemm3."""
+    key = (X.data_ptr(), tuple(X.shape), X.device)
+    Xt = _RESIDENT_T.get(key)
+    if Xt is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('resident transpose requested inside a graph capture: run one eager step first')
+        Xt = X.t().contiguous()
+        _RESIDENT_T[key] = Xt
+    return Xt
+
+
+def _resident_ok(X: torch.Tensor, W: torch.Tensor) -> bool:
+    M, K = X.shape
+    return (gemm3_ok(M, K) and M % 32 == 0 and W.shape[0] == KGW_C and X.dtype == torch.float32 and X.stride(1) == 1
+            and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0 and W.stride(1) == 1 and W.stride(0) % 4 == 0
+            and W.data_ptr() % 16 == 0)
+
+
+def resident_first_linear(X, W, b):
+    """relu(X W^T + b) over ALL rows of a resident wide feature matrix (kgwas/model.py:19 on the gene features)."""
+    if _resident_ok(X, W):
+        _resident_transpose(X)
+        return gemm3(X, gemm3_pack(W, X.shape[1], False), bias=b, relu=True)
+    return linear(X, W, b, relu=True, fixed_shape=True)
+
+
+def resident_first_weight_grad(dz, X, W):
+    """dW [128, K] = dz^T X for the same layer."""
+    if _resident_ok(X, W) and dz.is_contiguous():
+        return gemm3(_resident_transpose(X), gemm3_pack(dz, X.shape[0], True), transpose_out=True)
+    with _TUNED:
+        return dz.t().mm(X)
+
+
 class _MLPTail(torch.autograd.Function):
     """y = FC_output(relu(FC_hidden2(h1)))  (kgwas/model.py:19-21) as ONE autograd node: MFMA Linear kernels
     forward and for dX (ReLU mask fused in the epilogue), split-K MFMA kernel for the weight / bias gradients."""
@@ -785,17 +854,17 @@ class _ResidentLinearReLURows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, W, b, ids, g2l):
-        h = linear(X, W, b, relu=True, fixed_shape=True)
+        h = resident_first_linear(X, W, b)
         n = int(ids.numel())
         out = torch.empty(n, h.shape[1], device=h.device)
         if n:
             _lib.check(_lib.lib().kgw_gather_rows(_p(h), _p(ids), n, h.shape[1], _p(out), _lib.stream_ptr()), 'kgw_gather_rows')
-        ctx.save_for_backward(X, h, g2l)
+        ctx.save_for_backward(X, h, g2l, W)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        X, h, g2l = ctx.saved_tensors
+        X, h, g2l, W = ctx.saved_tensors
         g = g.contiguous()
         N = h.shape[0]
         assert h.shape[1] == KGW_C and g2l.numel() == N and g2l.dtype == torch.int32
@@ -804,8 +873,7 @@ class _ResidentLinearReLURows(torch.autograd.Function):
         ws = torch.empty(int(_lib.lib().kgw_scatter_relu_rows_workspace_floats(N)), device=h.device)
         _lib.check(_lib.lib().kgw_scatter_relu_rows(_p(g), _p(g2l), _p(h), N, _p(dz), _p(db), _p(ws), _lib.stream_ptr()),
                    'kgw_scatter_relu_rows')
-        with _TUNED:
-            dW = dz.t().mm(X)
+        dW = resident_first_weight_grad(dz, X, W)
         return None, dW, db, None, None
 
 
@@ -817,18 +885,18 @@ class _ResidentMLP2(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, W1, b1, W2, b2, ids, g2l, out):
-        h = linear(X, W1, b1, relu=True, fixed_shape=True)
+        h = resident_first_linear(X, W1, b1)
         n = int(ids.numel())
         h1g = torch.empty(n, h.shape[1], device=h.device)
         if n:
             _lib.check(_lib.lib().kgw_gather_rows(_p(h), _p(ids), n, h.shape[1], _p(h1g), _lib.stream_ptr()), 'kgw_gather_rows')
         h2 = linear(h1g, W2, b2, relu=True, out=out.view() if out is not None else None)
-        ctx.save_for_backward(X, h, h1g, W2, g2l)
+        ctx.save_for_backward(X, h, h1g, W2, g2l, W1)
         return h2
 
     @staticmethod
     def backward(ctx, dh2):
-        X, h, h1g, W2, g2l = ctx.saved_tensors
+        X, h, h1g, W2, g2l, W1 = ctx.saved_tensors
         dh2 = dh2.contiguous()
         N = h.shape[0]
         L = _lib.lib()
@@ -838,8 +906,7 @@ class _ResidentMLP2(torch.autograd.Function):
         ws = torch.empty(nws, device=h.device)
         _lib.check(L.kgw_mlp2_bwd_first(_p(dh2), dh2.stride(0), _p(W2), W2.stride(0), _p(h), h.stride(0), None, 0, 0, N, None, None, 0,
                                         _p(db1), _p(ws), nws, _p(g2l), _p(dz), dz.stride(0), _lib.stream_ptr()), 'kgw_mlp2_bwd_first')
-        with _TUNED:
-            dW1 = dz.t().mm(X)
+        dW1 = resident_first_weight_grad(dz, X, W1)
         dW2, db2 = linear_weight_grad(dh2, h1g)
         return None, dW1, db1, dW2, db2, None, None, None
 

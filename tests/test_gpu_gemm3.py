@@ -1,0 +1,79 @@
+"""kgw_gemm3: the first gene Linear (kgwas/model.py:13,19 on the 5 120-wide gene features) and its weight gradient on the
+bf16 matrix pipe, three exact bf16 pieces per fp32 operand.  The bar is the fp32 product's own error: the kernel's distance
+from float64 must not exceed what a plain fp32 GEMM of the same operands is away from float64."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref64(A, B):
+    return A.double() @ B.double()
+
+
+def _scale(A, B):
+    """sum_k |a||b| per output element: what every rounding-error bound of a dot product is relative to."""
+    return A.double().abs() @ B.double().abs()
+
+
+@pytest.mark.parametrize('M,K', [(128, 32), (1000, 512), (333, 1024), (4100, 2048)])
+@pytest.mark.parametrize('kn', [False, True])
+def test_gemm3_matches_float64_as_well_as_fp32(M, K, kn):
+    from kgwas_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(M + K)
+    # wide dynamic range: magnitudes over 2^-20 .. 2^20 so that every piece of the split carries signal
+    A = torch.randn(M, K, device='cuda', generator=g) * torch.exp2(torch.randint(-20, 21, (M, K), device='cuda', generator=g).float())
+    B = torch.randn(K, 128, device='cuda', generator=g) * torch.exp2(torch.randint(-8, 9, (K, 128), device='cuda', generator=g).float())
+    S = B if kn else B.t().contiguous()
+    packed = ops.gemm3_pack(S, K, kn)
+    C = ops.gemm3(A, packed)
+    ref = _ref64(A, B)
+    sc = _scale(A, B)
+    err = ((C.double() - ref).abs() / sc).max().item()
+    err32 = (((A @ B).double() - ref).abs() / sc).max().item()
+    # u = 2^-24.  A K-term fp32 chain is bounded by K u; both products sit far below that (pairwise / blocked sums)
+    assert err <= max(2.0 * err32, 4 * 2.0 ** -24), (err, err32)
+    assert err <= 16 * 2.0 ** -24, err
+    Ct = ops.gemm3(A, packed, transpose_out=True)
+    assert torch.equal(Ct, C.t())
+    C2 = ops.gemm3(A, packed)
+    assert torch.equal(C, C2)                       # deterministic
+
+
+def test_gemm3_bias_relu_epilogue_and_strides():
+    from kgwas_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(5)
+    M, K = 2100, 640
+    Abig = torch.randn(M, K + 64, device='cuda', generator=g)
+    A = Abig[:, :K]                                  # row stride K + 64
+    W = torch.randn(128, K, device='cuda', generator=g) / K ** 0.5
+    b = torch.randn(128, device='cuda', generator=g)
+    y = ops.gemm3(A, ops.gemm3_pack(W, K, False), bias=b, relu=True)
+    ref = torch.relu(A.double() @ W.double().t() + b.double())
+    assert (y.double() - ref).abs().max().item() < 1e-5
+    assert (y >= 0).all()
+
+
+def test_gemm3_split_is_exact():
+    """a1 + a2 + a3 == a bit for bit: the product of a matrix with the identity block returns the matrix."""
+    from kgwas_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(9)
+    M, K = 512, 128
+    A = torch.randn(M, K, device='cuda', generator=g) * torch.exp2(torch.randint(-30, 31, (M, K), device='cuda', generator=g).float())
+    eye = torch.eye(K, 128, device='cuda')
+    C = ops.gemm3(A, ops.gemm3_pack(eye, K, True))
+    assert torch.equal(C, A)
+    # and the packed side: identity times a full-precision matrix
+    Bm = torch.randn(K, 128, device='cuda', generator=g) * torch.exp2(torch.randint(-30, 31, (K, 128), device='cuda', generator=g).float())
+    I = torch.eye(M, K, device='cuda')
+    C = ops.gemm3(I, ops.gemm3_pack(Bm, K, True))
+    assert torch.equal(C[:K], Bm)
+
+
+def test_gemm3_rejects_unsupported_shapes():
+    from kgwas_amd import _lib, ops
+    A = torch.zeros(64, 40, device='cuda')
+    L = _lib.lib()
+    assert L.kgw_gemm3_packed_bytes(40) == 0
+    with pytest.raises(RuntimeError):
+        ops.gemm3_pack(torch.zeros(40, 128, device='cuda'), 40, True)
