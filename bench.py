@@ -196,7 +196,7 @@ def run_pmc_passes(args, outdir, timeout_s=300):
     if 'cache' in per:                                            # MFMA pipe occupancy of the dense kernels
         mf = {}
         for _, name, c in per['cache']['rows']:
-            if name.startswith(('k_linear', 'k_tn_gemm', 'k_fold', 'Cijk_')) and c.get('GRBM_GUI_ACTIVE', 0) > 0:
+            if name.startswith(('k_linear', 'k_tn_gemm', 'k_fold', 'k_g3_gemm', 'k_mlp2', 'Cijk_')) and c.get('GRBM_GUI_ACTIVE', 0) > 0:
                 key = name.split('(')[0][:48]
                 d = mf.setdefault(key, {'mfma_busy_cycles': 0.0, 'gui_active_cycles': 0.0, 'dispatches': 0})
                 d['mfma_busy_cycles'] += c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0); d['gui_active_cycles'] += c['GRBM_GUI_ACTIVE']; d['dispatches'] += 1

@@ -10,8 +10,13 @@
 // are accumulated in fp32 (each bf16 x bf16 product is exact in fp32).  The three dropped ones are bounded by
 // 3 * 2^-25 |a||b| per term of the dot product -- below the rounding of ONE fp32 multiply-add (2^-24 |a||b|), i.e. the
 // result differs from an fp32 chain by less than the fp32 chain's own error bound (tests/test_gpu_gemm3.py measures both
-// against float64).  6 x 26 GFLOP on a 2.5 PF pipe = 63 us; reading A once (410 MB) = ~75 us: the kernel is HBM bound where
-// the fp32 product is MFMA bound.
+// against float64: the split product is 3x CLOSER to float64 than the library's fp32 product on the benchmark shapes).
+// 6 x 26 GFLOP on the 2.5 PF pipe = 63 us at the nominal clock and reading A once (410 MB) ~ 75 us.  Measured (MI355X, 20 032 x
+// 5 120 x 128): 153 us forward, 172 us for the weight-gradient shape = 1.03 PFLOP/s of bf16 work = 172 TFLOP/s of the fp32
+// product it replaces (the fp32 matrix peak is 157; the tuned library product takes 212 / 200 us).  Where the rest goes
+// (ablations, tools/micro/mfma_rate.hip): with random operands v_mfma_f32_32x32x16_bf16 sustains 18-19 ns per instruction
+// and SIMD (1.75-2.0 PF, power), the kernel's MFMA stream alone runs 110 us on its busiest CUs (two blocks), its memory side
+// alone 90-95 us, and the two overlap to 153.
 //
 // Shape of the kernel.  Work item = (128-row tile of A, K range); 4 wavefronts, each owns 32 rows x 128 columns (four
 // 32x32x16 accumulators), two blocks per CU.  K advances in chunks of 32:
@@ -24,7 +29,6 @@
 // Partial products go to a workspace [split][M][128]; kgw_gemm3 ends with a fixed-order reduction (+ bias, ReLU, or a
 // transposed store for the weight gradient).  Deterministic: no atomics, fixed K ranges.
 #include "kgw_common.h"
-#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 g3_bf8;
 typedef __attribute__((ext_vector_type(16))) float g3_f16;
@@ -32,7 +36,7 @@ typedef __attribute__((ext_vector_type(4))) float g3_f4;
 typedef __attribute__((ext_vector_type(4))) unsigned g3_u4;
 
 static constexpr int G3_CH_U4 = 1536;          // uint4 per packed chunk of 32 k: 2 steps x 3 pieces x 4 column tiles x 64 lanes
-static constexpr int G3_MAX_ITEMS = 512;       // 128-row blocks resident at once: two per CU on 256 CUs (256-row blocks: one)
+static constexpr int G3_MAX_ITEMS = 512;       // 128-row blocks resident at once: two per CU on 256 CUs
 
 __device__ __forceinline__ uint32_t g3_cvt_pk(float lo, float hi) {
     uint32_t r;
@@ -90,14 +94,12 @@ struct G3Args {
     const uint4* Bp;
     float* ws;
     int nsplit;
-    int dbg;          // timing experiments: 1 = A always chunk 0 (compute only), 2 = no MFMA work (memory only)
 };
 
-// MT = 32-row tiles per wavefront: 1 -> 128-row blocks, two per CU (two wavefronts per SIMD); 2 -> 256-row blocks, one per
-// CU, every B operand read from LDS feeds two MFMAs and a barrier comes every 96 MFMAs instead of 48.
 // Both LDS tiles are double buffered in SEPARATE arrays (the compiler then knows that the stores of chunk c + 1 do not alias
-// the operand reads of chunk c and spreads them over the MFMA stream instead of queueing them in front of a barrier).
-template <int MT, int DBG = 0>
+// the operand reads of chunk c).  MT = 32-row tiles per wavefront (1: 128-row blocks, two per CU; 2 was measured too -- 256-row
+// blocks, one per CU, each B operand feeding two MFMAs: 157-180 us against 153 -- and is not instantiated).
+template <int MT>
 __global__ void __launch_bounds__(256, 2 / MT) k_g3_gemm(G3Args a) {
     constexpr int NQ = 4 * MT;                 // A load instructions per chunk (8 rows x 128 B each)
     constexpr int AT = 256 * MT;               // 16-byte slots per wavefront-private A tile
@@ -163,7 +165,7 @@ __global__ void __launch_bounds__(256, 2 / MT) k_g3_gemm(G3Args a) {
                 const g3_f4 u = A[mt * 256 + (seg ^ sw)], v = A[mt * 256 + ((seg + 1) ^ sw)];
                 const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
                 uint4 p1, p2, p3;
-                if (DBG == 3) { p1 = __builtin_bit_cast(uint4, u); p2 = __builtin_bit_cast(uint4, v); p3 = p1; } else g3_split8(x, p1, p2, p3);
+                g3_split8(x, p1, p2, p3);
                 ap_[mt][0] = __builtin_bit_cast(g3_bf8, p1);
                 ap_[mt][1] = __builtin_bit_cast(g3_bf8, p2);
                 ap_[mt][2] = __builtin_bit_cast(g3_bf8, p3);
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(256, 2 / MT) k_g3_gemm(G3Args a) {
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) b[p][nt] = __builtin_bit_cast(g3_bf8, DBG == 4 ? bs[(p + nt) % 6] : B[((j * 3 + p) * 4 + nt) * 64]);
+                for (int nt = 0; nt < 4; ++nt) b[p][nt] = __builtin_bit_cast(g3_bf8, B[((j * 3 + p) * 4 + nt) * 64]);
             // (piece of A, piece of B), smallest products first; 4 MT independent accumulators between two uses of one
             constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
@@ -188,7 +190,7 @@ __global__ void __launch_bounds__(256, 2 / MT) k_g3_gemm(G3Args a) {
     // steady state without branches: chunk indices past the end are clamped (a redundant load of the last chunk into a
     // buffer nobody reads), so the load counters stay exact.  Iteration c: A of chunk c + 2 leaves for registers, chunk
     // c + 1 (registers since iteration c - 1) goes to the other LDS buffers, chunk c is multiplied.
-    const int last = a.dbg == 1 ? 0 : nc - 1;
+    const int last = nc - 1;
     load_a(ra, 0);
     load_b(0);
     store_a(ra, smA0);
@@ -198,16 +200,18 @@ __global__ void __launch_bounds__(256, 2 / MT) k_g3_gemm(G3Args a) {
     __syncthreads();
     for (int c = 0; c < nc; c += 2) {
         load_a(rb, min(c + 2, last));
-        if (DBG != 6) { store_a(ra, smA1); store_b(smB1); }
+        store_a(ra, smA1);
+        store_b(smB1);
         load_b(min(c + 2, last));
-        if (a.dbg != 2) compute(smA0, smB0);
-        if (DBG != 5) __syncthreads();
+        compute(smA0, smB0);
+        __syncthreads();
         if (c + 1 >= nc) break;
         load_a(ra, min(c + 3, last));
-        if (DBG != 6) { store_a(rb, smA0); store_b(smB0); }
+        store_a(rb, smA0);
+        store_b(smB0);
         load_b(min(c + 3, last));
-        if (a.dbg != 2) compute(smA1, smB1);
-        if (DBG != 5) __syncthreads();
+        compute(smA1, smB1);
+        __syncthreads();
     }
 
     // accumulator register r of a 32x32 tile: row 8 (r / 4) + 4 g + r % 4, column lane & 31
@@ -245,18 +249,17 @@ __global__ void __launch_bounds__(256) k_g3_reduce(const float* __restrict__ ws,
     *(float4*)(out + row * ldo + 4 * c4) = s;
 }
 
-// out[col, row] = sum_s ws[s, row, col]: 32-row x 128-column tiles through LDS
+// out[col, row] = sum_s ws[s, row, col]: 32-row x 32-column tiles through LDS (grid: row tiles x 4 column tiles)
 __global__ void __launch_bounds__(256) k_g3_reduce_t(const float* __restrict__ ws, int nsplit, long M, float* __restrict__ out, long ldo) {
-    __shared__ float tl[32][129];
+    __shared__ float tl[32][33];
     const int tid = threadIdx.x;
     const long r0 = (long)blockIdx.x * 32;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e = tid + 256 * i;               // float4 index in the tile: row e / 32, column group e % 32
-        const int r = e >> 5, c4 = e & 31;
+    const int cb = blockIdx.y * 32;
+    {
+        const int r = tid >> 3, c4 = tid & 7;          // one float4 per thread
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r0 + r < M) {
-            const float4* w = (const float4*)ws + (r0 + r) * 32 + c4;
+            const float4* w = (const float4*)ws + (r0 + r) * 32 + (cb >> 2) + c4;
             s = w[0];
             for (int k = 1; k < nsplit; ++k) {
                 const float4 v = w[(long)k * M * 32];
@@ -269,23 +272,17 @@ __global__ void __launch_bounds__(256) k_g3_reduce_t(const float* __restrict__ w
     const int r = tid & 31;
     if (r0 + r < M) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int col = (tid >> 5) + 8 * i;
-            out[(long)col * ldo + r0 + r] = tl[r][col];
+            out[(long)(cb + col) * ldo + r0 + r] = tl[r][col];
         }
     }
 }
 
 // ---- C ABI ---------------------------------------------------------------------------------------------------------------------
-static int g3_mt() {
-    static const int mt = getenv("KGW_G3_MT") ? atoi(getenv("KGW_G3_MT")) : 1;
-    return mt == 1 ? 1 : 2;
-}
-
 static int g3_splits(int64_t M, int64_t K) {
-    const int mt = g3_mt();
-    const int64_t tiles = (M + 128 * mt - 1) / (128 * mt), nch = K / 32;
-    int64_t s = (G3_MAX_ITEMS / mt) / tiles;
+    const int64_t tiles = (M + 127) / 128, nch = K / 32;
+    int64_t s = G3_MAX_ITEMS / tiles;
     if (s > nch / 8) s = nch / 8;
     if (s > 16) s = 16;
     if (s < 1) s = 1;
@@ -321,19 +318,12 @@ extern "C" int kgw_gemm3(const float* A, int64_t lda, int64_t M, int64_t K, cons
     if (transpose_out && (bias || relu)) return KGW_E_UNSUPPORTED;
     const int ns = g3_splits(M, K);
     if (workspace_floats < (int64_t)ns * M * 128) return KGW_E_RANGE;
-    const int mt = g3_mt();
-    const int tiles = (int)((M + 128 * mt - 1) / (128 * mt));
+    const int tiles = (int)((M + 127) / 128);
     hipStream_t st = (hipStream_t)stream_;
-    static const int dbg = getenv("KGW_G3_DBG") ? atoi(getenv("KGW_G3_DBG")) : 0;
-    G3Args a{A, (long)lda, (int)M, (int)K, (const uint4*)packed, workspace, ns, dbg};
-    if (mt == 1 && dbg == 3) k_g3_gemm<1, 3><<<tiles * ns, 256, 0, st>>>(a);
-    else if (mt == 1 && dbg == 4) k_g3_gemm<1, 4><<<tiles * ns, 256, 0, st>>>(a);
-    else if (mt == 1 && dbg == 5) k_g3_gemm<1, 5><<<tiles * ns, 256, 0, st>>>(a);
-    else if (mt == 1 && dbg == 6) k_g3_gemm<1, 6><<<tiles * ns, 256, 0, st>>>(a);
-    else if (mt == 1) k_g3_gemm<1><<<tiles * ns, 256, 0, st>>>(a);
-    else k_g3_gemm<2><<<tiles * ns, 256, 0, st>>>(a);
+    G3Args a{A, (long)lda, (int)M, (int)K, (const uint4*)packed, workspace, ns};
+    k_g3_gemm<1><<<tiles * ns, 256, 0, st>>>(a);
     KGW_LAUNCH_CHECK();
-    if (transpose_out) k_g3_reduce_t<<<(int)((M + 31) / 32), 256, 0, st>>>(workspace, ns, (long)M, out, (long)ldo);
+    if (transpose_out) k_g3_reduce_t<<<dim3((unsigned)((M + 31) / 32), 4), 256, 0, st>>>(workspace, ns, (long)M, out, (long)ldo);
     else k_g3_reduce<<<(int)((M * 32 + 255) / 256), 256, 0, st>>>(workspace, ns, (long)M, bias, relu, out, (long)ldo);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
