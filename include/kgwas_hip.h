@@ -371,7 +371,9 @@ int kgw_mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2, int64_t l
  * weight >= 2^-16 are accumulated in fp32; the dropped products are below the rounding of one fp32 multiply-add (see
  * kgwas_amd/csrc/kgw_gemm3.hip).  kgw_gemm3_pack splits B once per call into the kernel's operand image (packed:
  * kgw_gemm3_packed_bytes(K) bytes; s_is_kn: B[k, n] = S[k * lds + n], else B[k, n] = S[n * lds + k], n < 128).  A is split in
- * the kernel.  K % 32 == 0, lda % 4 == 0, 16-byte aligned pointers, else KGW_E_UNSUPPORTED.  workspace:
+ * the kernel.  lda == 0: A is stored in 32 x 32 tiles, [ceil(M / 32)][K / 32][32][32] floats (rows past M present, any value) --
+ * the layout for a resident copy, every 4 KB a wavefront reads per step is contiguous.  K % 32 == 0, lda % 4 == 0, 16-byte
+ * aligned pointers, else KGW_E_UNSUPPORTED.  workspace:
  * kgw_gemm3_workspace_floats(M, K) floats (partial products of the K ranges, added in index order: deterministic).      */
 int64_t kgw_gemm3_packed_bytes(int64_t K);
 int64_t kgw_gemm3_workspace_floats(int64_t M, int64_t K);

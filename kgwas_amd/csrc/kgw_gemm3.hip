@@ -90,10 +90,10 @@ __global__ void __launch_bounds__(256) k_g3_pack(const float* __restrict__ S, lo
 
 // ---- the product ---------------------------------------------------------------------------------------------------------------
 struct G3Args {
-    const float* A; long lda; int M, K;
+    const float* A; long lda; int M, K;          // lda == 0: A in 32 x 32 tiles, [ceil(M / 32)][K / 32][32][32]
     const uint4* Bp;
     float* ws;
-    int nsplit;
+    int nsplit, n_tiles, per_xcd;
 };
 
 // Both LDS tiles are double buffered in SEPARATE arrays (the compiler then knows that the stores of chunk c + 1 do not alias
@@ -106,7 +106,12 @@ __global__ void __launch_bounds__(256, 2 / MT) k_g3_gemm(G3Args a) {
     __shared__ g3_u4 smB0[G3_CH_U4], smB1[G3_CH_U4];
     __shared__ g3_f4 smA0[4 * AT], smA1[4 * AT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x / a.nsplit, split = blockIdx.x - tile * a.nsplit;
+    // block -> work item: workgroups go round-robin to the 8 XCDs (blockIdx % 8), and XCD x takes the contiguous range
+    // [x per_xcd, (x + 1) per_xcd) of the items in (K range, row tile) order -- one or two K ranges per XCD, so the packed B
+    // of a range (1.3 MB of the 15 MB in the weight-gradient product) is fetched into that XCD's L2 once and hit by the rest
+    const int item = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= a.per_xcd || item >= a.n_tiles * a.nsplit) return;
+    const int split = item / a.n_tiles, tile = item - split * a.n_tiles;
     const int nch = a.K >> 5;
     const int c0 = (int)((long)nch * split / a.nsplit), c1 = (int)((long)nch * (split + 1) / a.nsplit);
     const int nc = c1 - c0;
@@ -114,6 +119,7 @@ __global__ void __launch_bounds__(256, 2 / MT) k_g3_gemm(G3Args a) {
 
     // A addressing: instruction q covers rows 8 q .. 8 q + 7 of the wavefront's rows, 128 contiguous bytes each; 16-byte
     // slot s of row r lives at slot s ^ ((r >> 1) & 7) of its 128-byte LDS row
+    const long cstep = a.lda ? 32 : 1024;      // floats between consecutive chunks of a row
     const float* ap[NQ];
     int aw[NQ];
 #pragma unroll
@@ -121,7 +127,10 @@ __global__ void __launch_bounds__(256, 2 / MT) k_g3_gemm(G3Args a) {
         const int r = 8 * q + (lane >> 3);
         int row = row0 + r;
         row = row < a.M ? row : a.M - 1;
-        ap[q] = a.A + (long)row * a.lda + (long)c0 * 32 + (lane & 7) * 4;
+        // row-major: 128 contiguous bytes of each of 8 rows per instruction; tiled: the wavefront's 32 x 32 block of a chunk
+        // is 4 KB contiguous (1 KB per instruction), the next chunk follows it
+        ap[q] = a.lda ? a.A + (long)row * a.lda + (long)c0 * 32 + (lane & 7) * 4
+                      : a.A + ((long)(row >> 5) * nch + c0) * 1024 + (row & 31) * 32 + (lane & 7) * 4;
         aw[q] = wave * AT + r * 8 + ((lane & 7) ^ ((r >> 1) & 7));
     }
     const int m = lane & 31, g = lane >> 5, sw = (m >> 1) & 7;
@@ -139,7 +148,7 @@ __global__ void __launch_bounds__(256, 2 / MT) k_g3_gemm(G3Args a) {
 
     auto load_a = [&](g3_f4 (&r)[NQ], int c) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) r[q] = __builtin_nontemporal_load((const g3_f4*)(ap[q] + (long)c * 32));
+        for (int q = 0; q < NQ; ++q) r[q] = __builtin_nontemporal_load((const g3_f4*)(ap[q] + (long)c * cstep));
     };
     auto store_a = [&](const g3_f4 (&r)[NQ], g3_f4* A) {
 #pragma unroll
@@ -313,15 +322,16 @@ extern "C" int kgw_gemm3(const float* A, int64_t lda, int64_t M, int64_t K, cons
                          kgw_stream_t stream_) {
     if (!A || !packed || !workspace || !out) return KGW_E_NULL;
     if (M <= 0 || K <= 0 || M > (1 << 30) || K > (1 << 30)) return KGW_E_RANGE;
-    if (K % 32 || (lda & 3) || ((uintptr_t)A & 15) || ((uintptr_t)packed & 15) || ((uintptr_t)workspace & 15)) return KGW_E_UNSUPPORTED;
+    if (K % 32 || lda < 0 || (lda & 3) || ((uintptr_t)A & 15) || ((uintptr_t)packed & 15) || ((uintptr_t)workspace & 15)) return KGW_E_UNSUPPORTED;
     if (!transpose_out && ((ldo & 3) || ((uintptr_t)out & 15) || (bias && ((uintptr_t)bias & 15)))) return KGW_E_UNSUPPORTED;
     if (transpose_out && (bias || relu)) return KGW_E_UNSUPPORTED;
     const int ns = g3_splits(M, K);
     if (workspace_floats < (int64_t)ns * M * 128) return KGW_E_RANGE;
     const int tiles = (int)((M + 127) / 128);
     hipStream_t st = (hipStream_t)stream_;
-    G3Args a{A, (long)lda, (int)M, (int)K, (const uint4*)packed, workspace, ns};
-    k_g3_gemm<1><<<tiles * ns, 256, 0, st>>>(a);
+    const int per_xcd = (tiles * ns + 7) / 8;
+    G3Args a{A, (long)lda, (int)M, (int)K, (const uint4*)packed, workspace, ns, tiles, per_xcd};
+    k_g3_gemm<1><<<per_xcd * 8, 256, 0, st>>>(a);
     KGW_LAUNCH_CHECK();
     if (transpose_out) k_g3_reduce_t<<<dim3((unsigned)((M + 31) / 32), 4), 256, 0, st>>>(workspace, ns, (long)M, out, (long)ldo);
     else k_g3_reduce<<<(int)((M * 32 + 255) / 256), 256, 0, st>>>(workspace, ns, (long)M, bias, relu, out, (long)ldo);

@@ -505,35 +505,53 @@ def gemm3_pack(S: torch.Tensor, K: int, s_is_kn: bool) -> torch.Tensor:
     return packed
 
 
-def gemm3(A: torch.Tensor, packed: torch.Tensor, bias=None, relu: bool = False, transpose_out: bool = False, out=None):
-    """act(A [M, K] @ B [K, 128] + bias) -> [M, 128], or its transpose [128, M] (``transpose_out``): the tall resident product
-    of the first gene Linear on the bf16 matrix pipe with fp32 error (three exact bf16 pieces per operand, kgw_gemm3)."""
+def gemm3_tile(A: torch.Tensor) -> torch.Tensor:
+    """A [M, K] -> its 32 x 32-tiled copy [ceil(M / 32), K / 32, 32, 32] (rows past M zero): the layout kgw_gemm3 reads fastest."""
     M, K = A.shape
-    assert A.dtype == torch.float32 and A.stride(1) == 1
+    assert K % 32 == 0
+    Mp = (M + 31) // 32 * 32
+    if Mp != M:
+        A = torch.cat([A, A.new_zeros(Mp - M, K)])
+    return A.view(Mp // 32, 32, K // 32, 32).permute(0, 2, 1, 3).contiguous()
+
+
+def gemm3(A: torch.Tensor, packed: torch.Tensor, bias=None, relu: bool = False, transpose_out: bool = False, out=None, tiled_rows: int = 0):
+    """act(A [M, K] @ B [K, 128] + bias) -> [M, 128], or its transpose [128, M] (``transpose_out``): the tall resident product
+    of the first gene Linear on the bf16 matrix pipe with fp32 error (three exact bf16 pieces per operand, kgw_gemm3).
+    ``tiled_rows`` = M when A is a gemm3_tile() copy."""
+    if tiled_rows:
+        M, K, lda = tiled_rows, A.shape[1] * 32, 0
+        assert A.dim() == 4 and A.shape[2:] == (32, 32) and A.is_contiguous() and A.shape[0] * 32 >= M
+    else:
+        M, K = A.shape
+        lda = A.stride(0)
+        assert A.stride(1) == 1
+    assert A.dtype == torch.float32
     L = _lib.lib()
     if out is None:
         out = torch.empty((KGW_C, M) if transpose_out else (M, KGW_C), device=A.device)
     nws = int(L.kgw_gemm3_workspace_floats(M, K))
     ws = torch.empty(nws, device=A.device)
-    _lib.check(L.kgw_gemm3(_p(A), A.stride(0), M, K, _p(packed), _p(ws), nws, _p(bias), 1 if relu else 0, _p(out), out.stride(0),
+    _lib.check(L.kgw_gemm3(_p(A), lda, M, K, _p(packed), _p(ws), nws, _p(bias), 1 if relu else 0, _p(out), out.stride(0),
                            1 if transpose_out else 0, _lib.stream_ptr()), 'kgw_gemm3')
     return out
 
 
-_RESIDENT_T = {}
+_RESIDENT_TILES = {}
 
 
-def _resident_transpose(X: torch.Tensor) -> torch.Tensor:
-    """X^T of a resident feature matrix, built once per matrix (a second resident copy: 0.4 GB for the 5 120-wide gene
-    features) -- the A operand of the weight-gradient product on kgw_gemm3."""
+def _resident_transpose_tiles(X: torch.Tensor) -> torch.Tensor:
+    """32 x 32-tiled copy of X^T for a resident feature matrix, built once per matrix: the A operand of the weight-gradient
+    product on kgw_gemm3 (a second resident copy: 0.4 GB for the 5 120-wide gene features; the forward reads X itself --
+    measured, the tiled and the row-major layout run the same 150 us)."""
     key = (X.data_ptr(), tuple(X.shape), X.device)
-    Xt = _RESIDENT_T.get(key)
-    if Xt is None:
+    t = _RESIDENT_TILES.get(key)
+    if t is None:
         if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError('resident transpose requested inside a graph capture: run one eager step first')
-        Xt = X.t().contiguous()
-        _RESIDENT_T[key] = Xt
-    return Xt
+            raise RuntimeError('resident tiles requested inside a graph capture: run one eager step first')
+        t = gemm3_tile(X.t())
+        _RESIDENT_TILES[key] = t
+    return t
 
 
 def _resident_ok(X: torch.Tensor, W: torch.Tensor) -> bool:
@@ -546,7 +564,7 @@ def _resident_ok(X: torch.Tensor, W: torch.Tensor) -> bool:
 def resident_first_linear(X, W, b):
     """relu(X W^T + b) over ALL rows of a resident wide feature matrix (kgwas/model.py:19 on the gene features)."""
     if _resident_ok(X, W):
-        _resident_transpose(X)
+        _resident_transpose_tiles(X)                     # built outside any graph capture, on the first eager step
         return gemm3(X, gemm3_pack(W, X.shape[1], False), bias=b, relu=True)
     return linear(X, W, b, relu=True, fixed_shape=True)
 
@@ -554,7 +572,7 @@ def resident_first_linear(X, W, b):
 def resident_first_weight_grad(dz, X, W):
     """dW [128, K] = dz^T X for the same layer."""
     if _resident_ok(X, W) and dz.is_contiguous():
-        return gemm3(_resident_transpose(X), gemm3_pack(dz, X.shape[0], True), transpose_out=True)
+        return gemm3(_resident_transpose_tiles(X), gemm3_pack(dz, X.shape[0], True), transpose_out=True, tiled_rows=X.shape[1])
     with _TUNED:
         return dz.t().mm(X)
 

@@ -38,6 +38,8 @@ def test_gemm3_matches_float64_as_well_as_fp32(M, K, kn):
     assert torch.equal(Ct, C.t())
     C2 = ops.gemm3(A, packed)
     assert torch.equal(C, C2)                       # deterministic
+    C3 = ops.gemm3(ops.gemm3_tile(A), packed, tiled_rows=M)
+    assert torch.equal(C, C3)                       # the tiled resident layout: same products in the same order
 
 
 def test_gemm3_bias_relu_epilogue_and_strides():
