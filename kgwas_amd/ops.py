@@ -537,20 +537,20 @@ def gemm3(A: torch.Tensor, packed: torch.Tensor, bias=None, relu: bool = False, 
     return out
 
 
-_RESIDENT_TILES = {}
+_RESIDENT_T = {}
 
 
-def _resident_transpose_tiles(X: torch.Tensor) -> torch.Tensor:
-    """32 x 32-tiled copy of X^T for a resident feature matrix, built once per matrix: the A operand of the weight-gradient
-    product on kgw_gemm3 (a second resident copy: 0.4 GB for the 5 120-wide gene features; the forward reads X itself --
-    measured, the tiled and the row-major layout run the same 150 us)."""
+def _resident_transpose(X: torch.Tensor) -> torch.Tensor:
+    """X^T of a resident feature matrix, built once per matrix: the A operand of the weight-gradient product on kgw_gemm3 (a
+    second resident copy, 0.4 GB for the 5 120-wide gene features).  Row-major like X: the 32 x 32-tiled layout the kernel
+    also takes (gemm3_tile) measured the same in isolation and in the step."""
     key = (X.data_ptr(), tuple(X.shape), X.device)
-    t = _RESIDENT_TILES.get(key)
+    t = _RESIDENT_T.get(key)
     if t is None:
         if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError('resident tiles requested inside a graph capture: run one eager step first')
-        t = gemm3_tile(X.t())
-        _RESIDENT_TILES[key] = t
+            raise RuntimeError('resident transpose requested inside a graph capture: run one eager step first')
+        t = X.t().contiguous()
+        _RESIDENT_T[key] = t
     return t
 
 
@@ -564,7 +564,7 @@ def _resident_ok(X: torch.Tensor, W: torch.Tensor) -> bool:
 def resident_first_linear(X, W, b):
     """relu(X W^T + b) over ALL rows of a resident wide feature matrix (kgwas/model.py:19 on the gene features)."""
     if _resident_ok(X, W):
-        _resident_transpose_tiles(X)                     # built outside any graph capture, on the first eager step
+        _resident_transpose(X)                           # built outside any graph capture, on the first eager step
         return gemm3(X, gemm3_pack(W, X.shape[1], False), bias=b, relu=True)
     return linear(X, W, b, relu=True, fixed_shape=True)
 
@@ -572,7 +572,7 @@ def resident_first_linear(X, W, b):
 def resident_first_weight_grad(dz, X, W):
     """dW [128, K] = dz^T X for the same layer."""
     if _resident_ok(X, W) and dz.is_contiguous():
-        return gemm3(_resident_transpose_tiles(X), gemm3_pack(dz, X.shape[0], True), transpose_out=True, tiled_rows=X.shape[1])
+        return gemm3(_resident_transpose(X), gemm3_pack(dz, X.shape[0], True), transpose_out=True)
     with _TUNED:
         return dz.t().mm(X)
 
