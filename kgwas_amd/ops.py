@@ -899,7 +899,9 @@ class _ResidentMLP2(torch.autograd.Function):
     """h2 = relu(FC_hidden2(relu(FC_hidden(X))[ids])) for a RESIDENT wide feature matrix X (the gene features): the two nodes
     _ResidentLinearReLURows + _MLPTail2 as one, so that the backward forms  dz = ((dh2[g2l] @ W2) * (h > 0))  -- dense over
     the resident rows, zero where a node is not in the batch -- and d b1 in ONE kernel (kgw_mlp2_bwd_first with row
-    indirection) instead of dX product + scatter/mask pass + column-sum fold; d W1 stays the library product dz^T X."""
+    indirection) instead of dX product + scatter/mask pass + column-sum fold; d W1 = dz^T X on kgw_gemm3 (or the library).
+    Contract (like _MLP2): the incoming gradient is ALREADY multiplied by (h2 > 0) -- the node sits below the layer-1 aggregate,
+    whose backward applies the ReLU mask of its input (KGW_F_RELU_INPUT); tests/test_gpu_gemm3.py checks it against float64."""
 
     @staticmethod
     def forward(ctx, X, W1, b1, W2, b2, ids, g2l, out):

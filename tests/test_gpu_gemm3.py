@@ -79,3 +79,41 @@ def test_gemm3_rejects_unsupported_shapes():
     assert L.kgw_gemm3_packed_bytes(40) == 0
     with pytest.raises(RuntimeError):
         ops.gemm3_pack(torch.zeros(40, 128, device='cuda'), 40, True)
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_resident_gene_layer_on_gemm3_matches_float64_autograd(fused):
+    """The two autograd nodes that carry the wide resident first layer (kgwas/model.py:13,19-20 on the gene features), at a
+    shape that takes the kgw_gemm3 route: forward rows, d W1 (orientation [128, K]), d b1, d W2, d b2 against float64 autograd."""
+    from kgwas_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(21)
+    N, K, n = 4128, 1056, 1500                       # resident rows (a multiple of 32), feature width, rows in the batch
+    assert ops.gemm3_ok(N, K) or not ops._GEMM3
+    X = torch.randn(N, K, device='cuda', generator=g)
+    W1 = (torch.randn(128, K, device='cuda', generator=g) / K ** 0.5).requires_grad_()
+    b1 = torch.randn(128, device='cuda', generator=g).mul_(0.1).requires_grad_()
+    W2 = (torch.randn(128, 128, device='cuda', generator=g) / 128 ** 0.5).requires_grad_()
+    b2 = torch.randn(128, device='cuda', generator=g).mul_(0.1).requires_grad_()
+    ids = torch.randperm(N, device='cuda', generator=g)[:n].to(torch.int32)
+    g2l = torch.full((N,), -1, dtype=torch.int32, device='cuda')
+    g2l[ids.long()] = torch.arange(n, dtype=torch.int32, device='cuda')
+    up = torch.randn(n, 128, device='cuda', generator=g)
+    if fused:
+        y = ops.resident_mlp2(X, W1, b1, W2, b2, ids, g2l)
+    else:
+        h1 = ops.resident_linear_relu_rows(X, W1, b1, ids, g2l)
+        y = torch.relu(torch.nn.functional.linear(h1, W2, b2))
+    # the fused node's contract (it runs below the layer-1 aggregate, whose backward applies the ReLU mask of its input,
+    # KGW_F_RELU_INPUT): the incoming gradient is already multiplied by (h2 > 0)
+    y.backward(up * (y > 0))
+    got = [y.detach()] + [p.grad for p in (W1, b1, W2, b2)]
+    Xd = X.double()
+    P = [p.detach().double().requires_grad_() for p in (W1, b1, W2, b2)]
+    h = torch.relu(Xd @ P[0].t() + P[1])[ids.long()]
+    yr = torch.relu(h @ P[2].t() + P[3])
+    (yr * up.double()).sum().backward()
+    ref = [yr.detach()] + [p.grad for p in P]
+    for name, a, r in zip(('h2', 'dW1', 'db1', 'dW2', 'db2'), got, ref):
+        assert a.shape == r.shape, name
+        tol = 2e-5 * max(1.0, float(r.abs().max()))
+        assert float((a.double() - r).abs().max()) <= tol, (name, float((a.double() - r).abs().max()), tol)
