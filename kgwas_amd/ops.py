@@ -540,39 +540,46 @@ def gemm3(A: torch.Tensor, packed: torch.Tensor, bias=None, relu: bool = False, 
 _RESIDENT_T = {}
 
 
-def _resident_transpose(X: torch.Tensor) -> torch.Tensor:
-    """X^T of a resident feature matrix, built once per matrix: the A operand of the weight-gradient product on kgw_gemm3 (a
-    second resident copy, 0.4 GB for the 5 120-wide gene features).  Row-major like X: the 32 x 32-tiled layout the kernel
-    also takes (gemm3_tile) measured the same in isolation and in the step."""
+def _resident_copies(X: torch.Tensor):
+    """(A operand of the forward, X^T) for a resident feature matrix, built once per matrix.  X^T [K, N] is the A operand of the
+    weight-gradient product on kgw_gemm3 (a second resident copy, 0.4 GB for the 5 120-wide gene features; row-major like X --
+    the 32 x 32-tiled layout the kernel also takes, gemm3_tile, measured the same in isolation and in the step).  The forward
+    reads X itself when its width is a multiple of 32 (5 120), else a copy padded with zero columns (57 742 -> 57 760,
+    mode='full')."""
     key = (X.data_ptr(), tuple(X.shape), X.device)
     t = _RESIDENT_T.get(key)
     if t is None:
         if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError('resident transpose requested inside a graph capture: run one eager step first')
-        t = X.t().contiguous()
+            raise RuntimeError('resident copies requested inside a graph capture: run one eager step first')
+        K = X.shape[1]
+        Kp = (K + 31) // 32 * 32
+        direct = Kp == K and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0
+        Xf = X if direct else torch.nn.functional.pad(X, (0, Kp - K))
+        t = (Xf, X.t().contiguous())
         _RESIDENT_T[key] = t
     return t
 
 
 def _resident_ok(X: torch.Tensor, W: torch.Tensor) -> bool:
     M, K = X.shape
-    return (gemm3_ok(M, K) and M % 32 == 0 and W.shape[0] == KGW_C and X.dtype == torch.float32 and X.stride(1) == 1
-            and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0 and W.stride(1) == 1 and W.stride(0) % 4 == 0
-            and W.data_ptr() % 16 == 0)
+    return (gemm3_ok(M, (K + 31) // 32 * 32) and M % 32 == 0 and W.shape[0] == KGW_C and X.dtype == torch.float32
+            and X.stride(1) == 1 and W.stride(1) == 1)
 
 
 def resident_first_linear(X, W, b):
     """relu(X W^T + b) over ALL rows of a resident wide feature matrix (kgwas/model.py:19 on the gene features)."""
     if _resident_ok(X, W):
-        _resident_transpose(X)                           # built outside any graph capture, on the first eager step
-        return gemm3(X, gemm3_pack(W, X.shape[1], False), bias=b, relu=True)
+        Xf = _resident_copies(X)[0]                      # built outside any graph capture, on the first eager step
+        Kp = Xf.shape[1]
+        Wp = W if Kp == W.shape[1] and W.stride(0) % 4 == 0 and W.data_ptr() % 16 == 0 else torch.nn.functional.pad(W, (0, Kp - W.shape[1]))
+        return gemm3(Xf, gemm3_pack(Wp, Kp, False), bias=b, relu=True)
     return linear(X, W, b, relu=True, fixed_shape=True)
 
 
 def resident_first_weight_grad(dz, X, W):
     """dW [128, K] = dz^T X for the same layer."""
     if _resident_ok(X, W) and dz.is_contiguous():
-        return gemm3(_resident_transpose(X), gemm3_pack(dz, X.shape[0], True), transpose_out=True)
+        return gemm3(_resident_copies(X)[1], gemm3_pack(dz, X.shape[0], True), transpose_out=True)
     with _TUNED:
         return dz.t().mm(X)
 

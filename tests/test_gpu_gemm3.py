@@ -81,14 +81,15 @@ def test_gemm3_rejects_unsupported_shapes():
         ops.gemm3_pack(torch.zeros(40, 128, device='cuda'), 40, True)
 
 
+@pytest.mark.parametrize('K', [1056, 1050])           # 1050: not a multiple of 32 -- the padded resident copy (mode='full' widths)
 @pytest.mark.parametrize('fused', [True, False])
-def test_resident_gene_layer_on_gemm3_matches_float64_autograd(fused):
+def test_resident_gene_layer_on_gemm3_matches_float64_autograd(fused, K):
     """The two autograd nodes that carry the wide resident first layer (kgwas/model.py:13,19-20 on the gene features), at a
     shape that takes the kgw_gemm3 route: forward rows, d W1 (orientation [128, K]), d b1, d W2, d b2 against float64 autograd."""
     from kgwas_amd import ops
     g = torch.Generator(device='cuda').manual_seed(21)
-    N, K, n = 4128, 1056, 1500                       # resident rows (a multiple of 32), feature width, rows in the batch
-    assert ops.gemm3_ok(N, K) or not ops._GEMM3
+    N, n = 4128, 1500                                # resident rows (a multiple of 32), rows in the batch
+    assert ops._resident_ok(torch.empty(N, K, device='cuda'), torch.empty(128, K, device='cuda')) or not ops._GEMM3
     X = torch.randn(N, K, device='cuda', generator=g)
     W1 = (torch.randn(128, K, device='cuda', generator=g) / K ** 0.5).requires_grad_()
     b1 = torch.randn(128, device='cuda', generator=g).mul_(0.1).requires_grad_()
