@@ -112,6 +112,31 @@ __device__ __forceinline__ float kgw_xhalf(float v) {   // value held by the sam
     return __shfl_xor(v, 32, 64);
 }
 
+// ---- exact three-way bf16 split of fp32 values (kgw_gemm3.hip, k_mlp2_fwd3) -----------------------------------------
+// x = p1 + p2 + p3 with p1 = bf16(x), p2 = bf16(x - p1), p3 = x - p1 - p2: three 8-bit significands = the 24 bits of fp32, both
+// residuals exact in fp32.  Eight values -> three registers-of-eight (element i in bits 16 (i & 1) of word i / 2), 44 VALU ops.
+typedef __attribute__((ext_vector_type(8))) __bf16 kgw_bf8;
+__device__ __forceinline__ uint32_t kgw_cvt_pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ void kgw_split3x8(const float (&x)[8], uint4& p1, uint4& p2, uint4& p3) {
+    uint32_t a[4], b[4], c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = x[2 * i], x1 = x[2 * i + 1];
+        a[i] = kgw_cvt_pk_bf16(x0, x1);
+        const float r0 = x0 - __builtin_bit_cast(float, a[i] << 16), r1 = x1 - __builtin_bit_cast(float, a[i] & 0xffff0000u);
+        b[i] = kgw_cvt_pk_bf16(r0, r1);
+        const float s0 = r0 - __builtin_bit_cast(float, b[i] << 16), s1 = r1 - __builtin_bit_cast(float, b[i] & 0xffff0000u);
+        c[i] = kgw_cvt_pk_bf16(s0, s1);
+    }
+    p1 = make_uint4(a[0], a[1], a[2], a[3]);
+    p2 = make_uint4(b[0], b[1], b[2], b[3]);
+    p3 = make_uint4(c[0], c[1], c[2], c[3]);
+}
+
 // block-wide exclusive scan of one int per thread (256 threads); returns exclusive prefix,
 // *total receives the block sum.  sm must hold 256 ints.
 __device__ __forceinline__ int kgw_block_exscan(int v, int* sm, int* total) {

@@ -15,6 +15,7 @@
 // are balanced at ~5 TB/s.  Waves of a block are summed through LDS, blocks through a partial buffer and a
 // second kernel in a fixed order: no atomics, deterministic.
 #include "kgw_common.h"
+#include <stdlib.h>
 #include <cstdlib>
 
 namespace {
@@ -1097,6 +1098,156 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 }
 
 // ------------------------------------------------------------------------------------------------------
+// k_mlp2_fwd3: the same launch with the SECOND product (128 x 128, 84 % of the multiply-adds) on the bf16 matrix pipe at fp32
+// error -- the exact three-way bf16 split of kgw_gemm3.hip: six v_mfma_f32_32x32x16_bf16 per 16 k instead of eight
+// v_mfma_f32_32x32x2_f32 of twice the issue time, 6 144 instead of 16 384 MFMA cycles per 32-row tile.  W2 is split once per
+// block into an LDS image of MFMA operands (96 KB: [8 steps][3 pieces][4 output tiles][64 lanes] x 16 B, conflict-free
+// ds_read_b128); the hidden state stays in the registers the first product leaves it in (lane = row, 64 columns) and is split
+// there, 8 values per step -- MFMA step s multiplies, in lane group lk, k = 32 (s >> 1) + 16 (s & 1) + 8 e + 4 lk + c (i = 4 e + c),
+// and the W2 image is packed with the same map.  Weights no longer sit in registers (W1' comes from LDS too), so a block is
+// 8 wavefronts = two per SIMD instead of one.
+// ------------------------------------------------------------------------------------------------------
+static constexpr int M3_W2_U4 = 8 * 3 * 4 * 64;              // uint4 in the W2 operand image
+
+__global__ void __launch_bounds__(512, 1) k_mlp2_fwd3(Mlp2Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    uint4* W2p = (uint4*)lds;
+    float* W1l = lds + M3_W2_U4 * 4;                         // [128 n][24]: W1 | b1 | 0
+    float* bl = W1l + 128 * 24;                              // b2
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    int64_t rows = a.rows;
+    if (a.rows_dev) { const int64_t r = *a.rows_dev; rows = r < 0 ? 0 : (r < a.rows ? r : a.rows); }
+    {   // padding rows of a static layout: zeros
+        const int64_t npad = a.rows - rows;
+        for (int64_t q = (int64_t)blockIdx.x * 512 + tid; q < npad * 32; q += (int64_t)gridDim.x * 512) {
+            const int64_t r = rows + q / 32; const int c4 = (int)(q % 32) * 4;
+            *(float4*)(a.H2 + r * a.ldh2 + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.H1) *(float4*)(a.H1 + r * a.ldh1 + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if ((int64_t)blockIdx.x * 8 * 32 >= rows) return;    // (before any barrier: the whole block leaves)
+    }
+    const int ntiles = (int)((rows + 31) / 32);
+    const int nw = (int)gridDim.x * 8;
+    int tile = (int)blockIdx.x * 8 + wave;
+    const int K1 = a.K1;
+    auto fetch_x = [&](int t, f32x4 (&x)[3]) {
+        int64_t r = (int64_t)(t < ntiles ? t : ntiles - 1) * 32 + li;
+        if (r >= rows) r = rows - 1;
+        const float* xp = a.X + (a.ids ? (int64_t)a.ids[r] : r) * a.ldx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int k4 = 12 * lk + 4 * c;
+            if (k4 + 4 <= K1) x[c] = *(const f32x4*)(xp + k4);
+            else x[c] = f32x4{k4 == K1 ? 1.f : 0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    f32x4 xn[3];
+    fetch_x(tile, xn);
+    // the W2 operand image: entry (s, p, ot, lane) = piece p of W2[32 ot + li][k(s, lk, i)], i = 0..7
+    for (int idx = tid; idx < 8 * 4 * 64; idx += 512) {
+        const int ln = idx & 63, ot = (idx >> 6) & 3, s_ = idx >> 8;
+        const float* wp = a.W2 + (int64_t)(32 * ot + (ln & 31)) * a.ldw2 + 32 * (s_ >> 1) + 16 * (s_ & 1) + 4 * (ln >> 5);
+        const f32x4 u = *(const f32x4*)wp, v = *(const f32x4*)(wp + 8);
+        const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+        uint4 p1, p2, p3;
+        kgw_split3x8(x, p1, p2, p3);
+        uint4* o = W2p + ((s_ * 3) * 4 + ot) * 64 + ln;
+        o[0] = p1; o[4 * 64] = p2; o[8 * 64] = p3;
+    }
+    for (int idx = tid; idx < 128 * 24; idx += 512) {
+        const int n = idx / 24, k = idx % 24;
+        W1l[idx] = k < K1 ? a.W1[(int64_t)n * a.ldw1 + k] : (k == K1 ? (a.b1 ? a.b1[n] : 0.f) : 0.f);
+    }
+    if (tid < 128) bl[tid] = a.b2 ? a.b2[tid] : 0.f;
+    __syncthreads();
+    const float* w1p = W1l + li * 24 + 12 * lk;              // W1'[32 t + li][12 lk + 0..11] at + t * 32 * 24
+    const uint4* w2p = W2p + lane;
+    const float* blp = bl + 4 * lk;
+    for (; tile < ntiles; tile += nw) {
+        f32x4 x[3] = {xn[0], xn[1], xn[2]};
+        fetch_x(tile + nw, xn);                              // next tile's rows: in flight under this tile's MFMAs
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        // product 1 (fp32 pipe, K = 21 -> 24): 12 steps x 4 column tiles, operands from LDS
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            f32x4 w[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w[t] = *(const f32x4*)(w1p + t * 32 * 24 + 4 * c);
+#define KGW_MLP_STEP(C)                                                                                   \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                \
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].C, x[c].C, acc[t], 0, 0, 0);
+            KGW_MLP_STEP(x) KGW_MLP_STEP(y) KGW_MLP_STEP(z) KGW_MLP_STEP(w)
+#undef KGW_MLP_STEP
+        }
+        const int64_t row = (int64_t)tile * 32 + li;         // this lane's row
+        const bool live = row < rows;
+        if (a.Xg && live) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (12 * lk + 4 * c + 4 <= K1) *(f32x4*)(a.Xg + row * a.ldxg + 12 * lk + 4 * c) = x[c];
+        }
+        f32x4 xa[16];                                        // h1: element c of xa[4 t + g] = column 32 t + 8 g + 4 lk + c
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+                v.x = fmaxf(acc[t][4 * g + 0], 0.f); v.y = fmaxf(acc[t][4 * g + 1], 0.f);
+                v.z = fmaxf(acc[t][4 * g + 2], 0.f); v.w = fmaxf(acc[t][4 * g + 3], 0.f);
+                xa[4 * t + g] = v;
+            }
+        if (a.H1 && live) {
+            float* hp = a.H1 + row * a.ldh1 + 4 * lk;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) *(f32x4*)(hp + 32 * (q >> 2) + 8 * (q & 3)) = xa[q];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        // product 2 (bf16 pipe, three exact pieces per operand): 8 steps x 6 piece products x 4 output tiles
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            const f32x4 u = xa[2 * s_], v = xa[2 * s_ + 1];
+            const float h[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+            uint4 p1, p2, p3;
+            kgw_split3x8(h, p1, p2, p3);
+            const kgw_bf8 hb[3] = {__builtin_bit_cast(kgw_bf8, p1), __builtin_bit_cast(kgw_bf8, p2), __builtin_bit_cast(kgw_bf8, p3)};
+            kgw_bf8 wa[3][4];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot) wa[p][ot] = __builtin_bit_cast(kgw_bf8, w2p[((s_ * 3 + p) * 4 + ot) * 64]);
+            constexpr int TW[6] = {0, 2, 1, 0, 1, 0}, TH[6] = {2, 0, 1, 1, 0, 0};       // (piece of W2, piece of h1), smallest first
+#pragma unroll
+            for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot)
+                    acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[TW[t6]][ot], hb[TH[t6]], acc[ot], 0, 0, 0);
+        }
+        if (live) {
+            float* yp = a.H2 + row * a.ldh2 + 4 * lk;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b4 = *(const f32x4*)(blp + t * 32 + 8 * g);
+                    f32x4 v;
+                    v.x = fmaxf(acc[t][4 * g + 0] + b4.x, 0.f); v.y = fmaxf(acc[t][4 * g + 1] + b4.y, 0.f);
+                    v.z = fmaxf(acc[t][4 * g + 2] + b4.z, 0.f); v.w = fmaxf(acc[t][4 * g + 3] + b4.w, 0.f);
+                    *(f32x4*)(yp + t * 32 + 8 * g) = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // kgw_mlp2w_fwd: the same two hidden layers for a 128-wide input on FEW rows (the three GO node types of a batch share
 // go_feat_mlp, kgwas/model.py:58-60: ~7 k rows), rows gathered from up to four resident feature matrices -- one launch
 // instead of gather + Linear + Linear.  A wavefront takes (32-row tile, half of the OUTPUT columns): it computes all of
@@ -1653,6 +1804,19 @@ extern "C" int kgw_mlp2_fwd(const float* X, int64_t ldx, int32_t K1, const float
     if (!attr_set) {
         KGW_HIP(hipFuncSetAttribute((const void*)k_mlp2_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
+    }
+    static const bool split3 = !(getenv("KGW_MLP2_SPLIT") && getenv("KGW_MLP2_SPLIT")[0] == '0');
+    if (split3) {           // second product on the bf16 pipe (three exact pieces per operand)
+        const size_t lds3 = (size_t)M3_W2_U4 * 16 + (size_t)(128 * 24 + 128) * sizeof(float);
+        static bool attr3_set = false;
+        if (!attr3_set) {
+            KGW_HIP(hipFuncSetAttribute((const void*)k_mlp2_fwd3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+            attr3_set = true;
+        }
+        const int64_t nblk3 = ((rows + 31) / 32 + 7) / 8;
+        k_mlp2_fwd3<<<(int)(nblk3 < 256 ? nblk3 : 256), 512, lds3, (hipStream_t)stream_>>>(a);
+        KGW_LAUNCH_CHECK();
+        return KGW_OK;
     }
     const int64_t nblk = ((rows + 31) / 32 + 3) / 4;
     k_mlp2_fwd<<<(int)(nblk < 256 ? nblk : 256), 256, lds, (hipStream_t)stream_>>>(a);

@@ -30,38 +30,13 @@
 // transposed store for the weight gradient).  Deterministic: no atomics, fixed K ranges.
 #include "kgw_common.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 g3_bf8;
+typedef kgw_bf8 g3_bf8;
 typedef __attribute__((ext_vector_type(16))) float g3_f16;
 typedef __attribute__((ext_vector_type(4))) float g3_f4;
 typedef __attribute__((ext_vector_type(4))) unsigned g3_u4;
 
 static constexpr int G3_CH_U4 = 1536;          // uint4 per packed chunk of 32 k: 2 steps x 3 pieces x 4 column tiles x 64 lanes
 static constexpr int G3_MAX_ITEMS = 512;       // 128-row blocks resident at once: two per CU on 256 CUs
-
-__device__ __forceinline__ uint32_t g3_cvt_pk(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-__device__ __forceinline__ float g3_lo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float g3_hi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
-
-// eight fp32 -> three pieces of eight bf16 (element i in bits 16 (i & 1) of word i / 2)
-__device__ __forceinline__ void g3_split8(const float (&x)[8], uint4& p1, uint4& p2, uint4& p3) {
-    uint32_t a[4], b[4], c[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float x0 = x[2 * i], x1 = x[2 * i + 1];
-        a[i] = g3_cvt_pk(x0, x1);
-        const float r0 = x0 - g3_lo(a[i]), r1 = x1 - g3_hi(a[i]);
-        b[i] = g3_cvt_pk(r0, r1);
-        const float s0 = r0 - g3_lo(b[i]), s1 = r1 - g3_hi(b[i]);
-        c[i] = g3_cvt_pk(s0, s1);
-    }
-    p1 = make_uint4(a[0], a[1], a[2], a[3]);
-    p2 = make_uint4(b[0], b[1], b[2], b[3]);
-    p3 = make_uint4(c[0], c[1], c[2], c[3]);
-}
 
 // ---- B operand packing ------------------------------------------------------------------------------------------------------
 // image index (((c * 2 + j) * 3 + p) * 4 + nt) * 64 + lane: the eight bf16 of piece p for k = 32 c + 16 j + 8 (lane >> 5) + i,
@@ -83,7 +58,7 @@ __global__ void __launch_bounds__(256) k_g3_pack(const float* __restrict__ S, lo
         x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
     }
     uint4 p1, p2, p3;
-    g3_split8(x, p1, p2, p3);
+    kgw_split3x8(x, p1, p2, p3);
     uint4* o = out + ((c * 2 + j) * 3 * 4 + nt) * 64 + lane;
     o[0] = p1; o[4 * 64] = p2; o[8 * 64] = p3;
 }
@@ -174,7 +149,7 @@ __global__ void __launch_bounds__(256, 2 / MT) k_g3_gemm(G3Args a) {
                 const g3_f4 u = A[mt * 256 + (seg ^ sw)], v = A[mt * 256 + ((seg + 1) ^ sw)];
                 const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
                 uint4 p1, p2, p3;
-                g3_split8(x, p1, p2, p3);
+                kgw_split3x8(x, p1, p2, p3);
                 ap_[mt][0] = __builtin_bit_cast(g3_bf8, p1);
                 ap_[mt][1] = __builtin_bit_cast(g3_bf8, p2);
                 ap_[mt][2] = __builtin_bit_cast(g3_bf8, p3);
