@@ -13,13 +13,14 @@
 // against float64: the split product is 3x CLOSER to float64 than the library's fp32 product on the benchmark shapes).
 // 6 x 26 GFLOP on the 2.5 PF pipe = 63 us at the nominal clock and reading A once (410 MB) ~ 75 us.  Measured (MI355X, 20 032 x
 // 5 120 x 128): 153 us forward, 172 us for the weight-gradient shape = 1.03 PFLOP/s of bf16 work = 172 TFLOP/s of the fp32
-// product it replaces (the fp32 matrix peak is 157; the tuned library product takes 212 / 200 us).  Where the rest goes
+// product it replaces (the fp32 matrix peak is 157; the tuned library product takes 212 / 200 us); 143 us with 256-row blocks.  Where the rest goes
 // (ablations, tools/micro/mfma_rate.hip): with random operands v_mfma_f32_32x32x16_bf16 sustains 18-19 ns per instruction
 // and SIMD (1.75-2.0 PF, power), the kernel's MFMA stream alone runs 110 us on its busiest CUs (two blocks), its memory side
 // alone 90-95 us, and the two overlap to 153.
 //
-// Shape of the kernel.  Work item = (128-row tile of A, K range); 4 wavefronts, each owns 32 rows x 128 columns (four
-// 32x32x16 accumulators), two blocks per CU.  K advances in chunks of 32:
+// Shape of the kernel.  Work item = (256-row tile of A, K range); 8 wavefronts (two per SIMD, one block per CU), each owns
+// 32 rows x 128 columns (four 32x32x16 accumulators) and all share the B tile (128-row blocks, two per CU, read B from L2
+// twice as often: 153 vs 143 us).  K advances in chunks of 32:
 //   A: a wavefront loads its 32 x 32 fp32 block coalesced (8 rows x 128 B per instruction, non-temporal), two chunks ahead,
 //      writes it to a wavefront-PRIVATE 4 KB LDS tile (XOR-swizzled 16-byte slots: ds_write_b128 and ds_read_b128 conflict
 //      free) and reads it back in MFMA operand layout (lane = row, 8 consecutive k) -- no block barrier on this path; the
@@ -29,6 +30,7 @@
 // Partial products go to a workspace [split][M][128]; kgw_gemm3 ends with a fixed-order reduction (+ bias, ReLU, or a
 // transposed store for the weight gradient).  Deterministic: no atomics, fixed K ranges.
 #include "kgw_common.h"
+#include <stdlib.h>
 
 typedef kgw_bf8 g3_bf8;
 typedef __attribute__((ext_vector_type(16))) float g3_f16;
@@ -36,7 +38,7 @@ typedef __attribute__((ext_vector_type(4))) float g3_f4;
 typedef __attribute__((ext_vector_type(4))) unsigned g3_u4;
 
 static constexpr int G3_CH_U4 = 1536;          // uint4 per packed chunk of 32 k: 2 steps x 3 pieces x 4 column tiles x 64 lanes
-static constexpr int G3_MAX_ITEMS = 512;       // 128-row blocks resident at once: two per CU on 256 CUs
+static constexpr int G3_MAX_ITEMS = 512;       // 128-row blocks resident at once (two per CU on 256 CUs; 256-row blocks: half)
 
 // ---- B operand packing ------------------------------------------------------------------------------------------------------
 // image index (((c * 2 + j) * 3 + p) * 4 + nt) * 64 + lane: the eight bf16 of piece p for k = 32 c + 16 j + 8 (lane >> 5) + i,
@@ -74,12 +76,13 @@ struct G3Args {
 // Both LDS tiles are double buffered in SEPARATE arrays (the compiler then knows that the stores of chunk c + 1 do not alias
 // the operand reads of chunk c).  MT = 32-row tiles per wavefront (1: 128-row blocks, two per CU; 2 was measured too -- 256-row
 // blocks, one per CU, each B operand feeding two MFMAs: 157-180 us against 153 -- and is not instantiated).
-template <int MT>
-__global__ void __launch_bounds__(256, 2 / MT) k_g3_gemm(G3Args a) {
+template <int MT, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, (8 / NW) / MT) k_g3_gemm(G3Args a) {
+    constexpr int NT = 64 * NW, NB = G3_CH_U4 / NT;   // threads, B staging registers (uint4) per thread
     constexpr int NQ = 4 * MT;                 // A load instructions per chunk (8 rows x 128 B each)
     constexpr int AT = 256 * MT;               // 16-byte slots per wavefront-private A tile
     __shared__ g3_u4 smB0[G3_CH_U4], smB1[G3_CH_U4];
-    __shared__ g3_f4 smA0[4 * AT], smA1[4 * AT];
+    __shared__ g3_f4 smA0[NW * AT], smA1[NW * AT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // block -> work item: workgroups go round-robin to the 8 XCDs (blockIdx % 8), and XCD x takes the contiguous range
     // [x per_xcd, (x + 1) per_xcd) of the items in (K range, row tile) order -- one or two K ranges per XCD, so the packed B
@@ -90,7 +93,7 @@ __global__ void __launch_bounds__(256, 2 / MT) k_g3_gemm(G3Args a) {
     const int nch = a.K >> 5;
     const int c0 = (int)((long)nch * split / a.nsplit), c1 = (int)((long)nch * (split + 1) / a.nsplit);
     const int nc = c1 - c0;
-    const int row0 = tile * (128 * MT) + wave * (32 * MT);
+    const int row0 = tile * (32 * NW * MT) + wave * (32 * MT);
 
     // A addressing: instruction q covers rows 8 q .. 8 q + 7 of the wavefront's rows, 128 contiguous bytes each; 16-byte
     // slot s of row r lives at slot s ^ ((r >> 1) & 7) of its 128-byte LDS row
@@ -112,7 +115,7 @@ __global__ void __launch_bounds__(256, 2 / MT) k_g3_gemm(G3Args a) {
     const g3_u4* bp = (const g3_u4*)a.Bp + (long)c0 * G3_CH_U4 + tid;
 
     g3_f4 ra[NQ], rb[NQ];
-    g3_u4 bs[6];
+    g3_u4 bs[NB];
     g3_f16 acc[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -131,11 +134,11 @@ __global__ void __launch_bounds__(256, 2 / MT) k_g3_gemm(G3Args a) {
     };
     auto load_b = [&](int c) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) bs[i] = bp[(long)c * G3_CH_U4 + i * 256];
+        for (int i = 0; i < NB; ++i) bs[i] = bp[(long)c * G3_CH_U4 + i * NT];
     };
     auto store_b = [&](g3_u4* B) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) B[tid + i * 256] = bs[i];
+        for (int i = 0; i < NB; ++i) B[tid + i * NT] = bs[i];
     };
     auto compute = [&](const g3_f4* A_, const g3_u4* B_) {
         const g3_u4* B = B_ + lane;
@@ -264,9 +267,15 @@ __global__ void __launch_bounds__(256) k_g3_reduce_t(const float* __restrict__ w
 }
 
 // ---- C ABI ---------------------------------------------------------------------------------------------------------------------
+static int g3_nw() {
+    static const int nw = getenv("KGW_G3_NW") ? atoi(getenv("KGW_G3_NW")) : 8;    // wavefronts per block (experiments: 4)
+    return nw == 4 ? 4 : 8;
+}
+
 static int g3_splits(int64_t M, int64_t K) {
-    const int64_t tiles = (M + 127) / 128, nch = K / 32;
-    int64_t s = G3_MAX_ITEMS / tiles;
+    const int rt = 32 * g3_nw();
+    const int64_t tiles = (M + rt - 1) / rt, nch = K / 32;
+    int64_t s = (G3_MAX_ITEMS * 4 / g3_nw()) / tiles;
     if (s > nch / 8) s = nch / 8;
     if (s > 16) s = 16;
     if (s < 1) s = 1;
@@ -302,11 +311,13 @@ extern "C" int kgw_gemm3(const float* A, int64_t lda, int64_t M, int64_t K, cons
     if (transpose_out && (bias || relu)) return KGW_E_UNSUPPORTED;
     const int ns = g3_splits(M, K);
     if (workspace_floats < (int64_t)ns * M * 128) return KGW_E_RANGE;
-    const int tiles = (int)((M + 127) / 128);
+    const int rt = 32 * g3_nw();
+    const int tiles = (int)((M + rt - 1) / rt);
     hipStream_t st = (hipStream_t)stream_;
     const int per_xcd = (tiles * ns + 7) / 8;
     G3Args a{A, (long)lda, (int)M, (int)K, (const uint4*)packed, workspace, ns, tiles, per_xcd};
-    k_g3_gemm<1><<<per_xcd * 8, 256, 0, st>>>(a);
+    if (g3_nw() == 8) k_g3_gemm<1, 8><<<per_xcd * 8, 512, 0, st>>>(a);
+    else k_g3_gemm<1, 4><<<per_xcd * 8, 256, 0, st>>>(a);
     KGW_LAUNCH_CHECK();
     if (transpose_out) k_g3_reduce_t<<<dim3((unsigned)((M + 31) / 32), 4), 256, 0, st>>>(workspace, ns, (long)M, out, (long)ldo);
     else k_g3_reduce<<<(int)((M * 32 + 255) / 256), 256, 0, st>>>(workspace, ns, (long)M, bias, relu, out, (long)ldo);
