@@ -1580,6 +1580,174 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         a.part[(int64_t)blockIdx.x * 4096 + f] = (R[f] + R[4096 + f]) + (R[2 * 4096 + f] + R[3 * 4096 + f]);
 }
 
+// k_mlp2_bwd_first3: the same kernel with its FIRST product (dh1 = dH2 W2, 128 x 128, 80 % of the MFMA cycles) on the bf16
+// matrix pipe, three exact bf16 pieces per operand as in kgw_gemm3.hip / k_mlp2_fwd3: W2^T is split once per block into an LDS
+// image of MFMA operands (96 KB), the dH2 half row a lane holds is split in its registers, eight values per step; 6 144 instead
+// of 16 384 MFMA cycles per 32-row tile.  The masked tile goes through LDS 64 columns at a time (35 KB for the four wavefronts).
+constexpr int TS2 = 68;                 // LDS row stride of the half-width transposing tile
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) k_mlp2_bwd_first3(Mlp2BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    uint4* W2p = (uint4*)lds;                                // W2^T operand image: [8 steps][3 pieces][4 column tiles][64 lanes]
+    float* Tl = lds + M3_W2_U4 * 4;                          // [4 wavefronts][32 rows][TS2]: half of the columns at a time
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    int64_t rows = a.rows;
+    if (a.rows_dev) { const int64_t r = *a.rows_dev; rows = r < 0 ? 0 : (r < a.rows ? r : a.rows); }
+    const int ntiles = (int)((rows + 31) / 32);
+    const int nw = (int)gridDim.x * 4;
+    float* Tw = Tl + wave * 32 * TS2;
+    // the operand image: entry (s, p, jt, lane) = piece p of W2[o = 64 lk + 8 s + i][32 jt + li], i = 0..7 -- the eight values of
+    // dH2 lane group lk multiplies in step s (its half row, in order)
+    for (int idx = tid; idx < 8 * 4 * 64; idx += 256) {
+        const int ln = idx & 63, jt = (idx >> 6) & 3, s_ = idx >> 8;
+        const float* wp = a.W2 + (int64_t)(64 * (ln >> 5) + 8 * s_) * a.ldw + 32 * jt + (ln & 31);
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = wp[(int64_t)i * a.ldw];
+        uint4 p1, p2, p3;
+        kgw_split3x8(x, p1, p2, p3);
+        uint4* o = W2p + ((s_ * 3) * 4 + jt) * 64 + ln;
+        o[0] = p1; o[4 * 64] = p2; o[8 * 64] = p3;
+    }
+    __syncthreads();
+    const uint4* w2p = W2p + lane;
+    f32x16 accw[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accw[t][e] = 0.f;
+    const int K1 = a.K1;
+    int tile = (int)blockIdx.x * 4 + wave;
+    f32x4 xa[16];
+    int src_cur;                                              // input row of this lane's row (-1: none -> zero row)
+    {
+        int64_t r = (int64_t)(tile < ntiles ? tile : ntiles - 1) * 32 + li;
+        if (r >= rows) r = rows - 1;
+        src_cur = a.in_ids ? a.in_ids[r] : 0;
+        const float* xp = a.dH2 + (a.in_ids ? (int64_t)(src_cur < 0 ? 0 : src_cur) : r) * a.ldd + lk * 64;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xa[q] = *(const f32x4*)(xp + 4 * q);
+    }
+    for (; tile < ntiles; tile += nw) {
+        const int64_t r0 = (int64_t)tile * 32;
+        const int64_t row = r0 + li;
+        const bool live = row < rows && src_cur >= 0;
+        const int64_t rc = row < rows ? row : rows - 1;
+        const float* xn;                                      // this lane's half row of the wavefront's NEXT tile
+        {
+            int nt = tile + nw;
+            if (nt >= ntiles) nt = ntiles - 1;               // last round: a harmless re-read
+            int64_t r = (int64_t)nt * 32 + li;
+            if (r >= rows) r = rows - 1;
+            src_cur = a.in_ids ? a.in_ids[r] : 0;            // (of the NEXT tile from here on: `live` above is this tile's)
+            xn = a.dH2 + (a.in_ids ? (int64_t)(src_cur < 0 ? 0 : src_cur) : r) * a.ldd + lk * 64;
+        }
+        // x' in "k per lane" form for the second product: lane (k = li, row parity lk), step s = row pair (needed after
+        // the first product: the loads ride under its MFMAs)
+        float xs[16];
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const int64_t rr = r0 + 2 * s2 + lk;
+            float v = 0.f;
+            if (rr < rows) v = li < K1 ? a.X[rr * a.ldx + li] : (li == K1 ? 1.f : 0.f);
+            xs[s2] = v;
+        }
+        // ReLU mask of this lane's row (columns 32 t + 8 g + 4 lk + c), fetched under the MFMAs, kept as bits
+        const float* mp = a.H1 + rc * a.ldm + 4 * lk;
+        unsigned mb[2] = {0u, 0u};
+        f32x4 mv[4];
+#define KGW_MLPB_MFETCH(T)                                                                                \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) mv[g] = *(const f32x4*)(mp + (T) * 32 + 8 * g);
+#define KGW_MLPB_MBITS(T)                                                                                 \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                  \
+            const int b0 = ((T) & 1) * 16 + 4 * g;                                                        \
+            mb[(T) >> 1] |= (mv[g].x > 0.f ? 1u : 0u) << (b0 + 0);                                        \
+            mb[(T) >> 1] |= (mv[g].y > 0.f ? 1u : 0u) << (b0 + 1);                                        \
+            mb[(T) >> 1] |= (mv[g].z > 0.f ? 1u : 0u) << (b0 + 2);                                        \
+            mb[(T) >> 1] |= (mv[g].w > 0.f ? 1u : 0u) << (b0 + 3);                                        \
+        }
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        // first product on the bf16 pipe (three exact pieces per operand): 8 steps x 6 piece products x 4 column tiles
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            if (s_ == 0) { KGW_MLPB_MFETCH(0) }
+            if (s_ == 1) { KGW_MLPB_MBITS(0) KGW_MLPB_MFETCH(1) }
+            if (s_ == 3) { KGW_MLPB_MBITS(1) KGW_MLPB_MFETCH(2) }
+            if (s_ == 5) { KGW_MLPB_MBITS(2) KGW_MLPB_MFETCH(3) }
+            if (s_ == 7) { KGW_MLPB_MBITS(3) }
+            const f32x4 u = xa[2 * s_], v = xa[2 * s_ + 1];
+            const float h[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+            uint4 p1, p2, p3;
+            kgw_split3x8(h, p1, p2, p3);
+            const kgw_bf8 hb[3] = {__builtin_bit_cast(kgw_bf8, p1), __builtin_bit_cast(kgw_bf8, p2), __builtin_bit_cast(kgw_bf8, p3)};
+            kgw_bf8 wa[3][4];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) wa[p][jt] = __builtin_bit_cast(kgw_bf8, w2p[((s_ * 3 + p) * 4 + jt) * 64]);
+            constexpr int TW[6] = {0, 2, 1, 0, 1, 0}, TH[6] = {2, 0, 1, 1, 0, 0};       // (piece of W2, piece of dH2), smallest first
+#pragma unroll
+            for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+                    acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[TW[t6]][jt], hb[TH[t6]], acc[jt], 0, 0, 0);
+            if (s_ == 3) {                                     // first half row of the next tile, in place
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int qq = 0; qq < 8; ++qq) xa[qq] = *(const f32x4*)(xn + 4 * qq);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef KGW_MLPB_MFETCH
+#undef KGW_MLPB_MBITS
+        if (!live) { mb[0] = 0u; mb[1] = 0u; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qq = 8; qq < 16; ++qq) xa[qq] = *(const f32x4*)(xn + 4 * qq);     // second half: under the second product
+        __builtin_amdgcn_sched_barrier(0);
+        // masked dh1 tile -> the wavefront's LDS tile, row per lane (nobody else reads it: no barrier), 64 columns at a time;
+        // second product: C[k][col] += x'[row][k] dh1[row][col], two rows per MFMA step
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int t = 2 * hh; t < 2 * hh + 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned m4 = mb[t >> 1] >> (((t & 1) << 4) + 4 * g);
+                    f32x4 v;
+                    v.x = (m4 & 1u) ? acc[t][4 * g + 0] : 0.f; v.y = (m4 & 2u) ? acc[t][4 * g + 1] : 0.f;
+                    v.z = (m4 & 4u) ? acc[t][4 * g + 2] : 0.f; v.w = (m4 & 8u) ? acc[t][4 * g + 3] : 0.f;
+                    *(f32x4*)(Tw + li * TS2 + (t - 2 * hh) * 32 + 8 * g + 4 * lk) = v;
+                    if (a.dZ && row < rows) *(f32x4*)(a.dZ + row * a.ldz + t * 32 + 8 * g + 4 * lk) = v;
+                }
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const float* tp = Tw + (2 * s2 + lk) * TS2 + li;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    accw[2 * hh + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[s2], tp[t * 32], accw[2 * hh + t], 0, 0, 0);
+            }
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the tile is rewritten next)
+        }
+    }
+    // the block's four partial C's through LDS (fragment order), added in wavefront order
+    __syncthreads();
+    float* R = lds;                                           // 4 x 4096 floats over the operand image (done with)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) R[wave * 4096 + (t * 16 + e) * 64 + lane] = accw[t][e];
+    __syncthreads();
+    for (int f = tid; f < 4096; f += 256)
+        a.part[(int64_t)blockIdx.x * 4096 + f] = (R[f] + R[4096 + f]) + (R[2 * 4096 + f] + R[3 * 4096 + f]);
+}
+
 // d W1 [128, K1] and d b1 [128] from the block partials: fragment f = (t * 16 + e) * 64 + lane holds
 // C[k = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)][col = 32 t + (lane & 31)]; fixed summation order
 __global__ void __launch_bounds__(1024) k_mlp2_bwd_fold(const float* __restrict__ part, int nblk, int K1, float* __restrict__ dW1,
@@ -1884,7 +2052,18 @@ extern "C" int kgw_mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream_;
-    k_mlp2_bwd_first<<<(int)nblk, 256, lds, st>>>(a);
+    static const bool split3 = !(getenv("KGW_MLP2_SPLIT") && getenv("KGW_MLP2_SPLIT")[0] == '0');
+    if (split3) {
+        const size_t lds3 = (size_t)M3_W2_U4 * 16 + (size_t)(4 * 32 * TS2) * sizeof(float);
+        static bool attr3_set = false;
+        if (!attr3_set) {
+            KGW_HIP(hipFuncSetAttribute((const void*)k_mlp2_bwd_first3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+            attr3_set = true;
+        }
+        k_mlp2_bwd_first3<<<(int)nblk, 256, lds3, st>>>(a);
+    } else {
+        k_mlp2_bwd_first<<<(int)nblk, 256, lds, st>>>(a);
+    }
     KGW_LAUNCH_CHECK();
     k_mlp2_bwd_fold<<<4096 / 64, 1024, 0, st>>>(workspace, (int)nblk, K1, dW1, ldw1, db1);
     KGW_LAUNCH_CHECK();
