@@ -217,7 +217,8 @@ __global__ void __launch_bounds__(64 * NW, (8 / NW) / MT) k_g3_gemm(G3Args a) {
 
 // out[row, :] = act(sum_s ws[s, row, :] + bias), splits added in index order
 __global__ void __launch_bounds__(256) k_g3_reduce(const float* __restrict__ ws, int nsplit, long M, const float* __restrict__ bias,
-                                                   int relu, float* __restrict__ out, long ldo) {
+                                                   int relu, float* __restrict__ out, long ldo, const int32_t* __restrict__ row_map,
+                                                   float* __restrict__ out_rows, long ld_rows) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= M * 32) return;
     const long row = t >> 5;
@@ -234,6 +235,10 @@ __global__ void __launch_bounds__(256) k_g3_reduce(const float* __restrict__ ws,
     }
     if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
     *(float4*)(out + row * ldo + 4 * c4) = s;
+    if (row_map) {                       // the batch's copy of the row (the loader's x[n_id] slicing of the layer's output)
+        const int l = row_map[row];
+        if (l >= 0) *(float4*)(out_rows + (long)l * ld_rows + 4 * c4) = s;
+    }
 }
 
 // out[col, row] = sum_s ws[s, row, col]: 32-row x 32-column tiles through LDS (grid: row tiles x 4 column tiles)
@@ -303,12 +308,13 @@ extern "C" int kgw_gemm3_pack(const float* S, int64_t lds_, int64_t K, int32_t s
 
 extern "C" int kgw_gemm3(const float* A, int64_t lda, int64_t M, int64_t K, const void* packed, float* workspace,
                          int64_t workspace_floats, const float* bias, int32_t relu, float* out, int64_t ldo, int32_t transpose_out,
-                         kgw_stream_t stream_) {
+                         const int32_t* row_map, float* out_rows, int64_t ld_rows, kgw_stream_t stream_) {
     if (!A || !packed || !workspace || !out) return KGW_E_NULL;
     if (M <= 0 || K <= 0 || M > (1 << 30) || K > (1 << 30)) return KGW_E_RANGE;
     if (K % 32 || lda < 0 || (lda & 3) || ((uintptr_t)A & 15) || ((uintptr_t)packed & 15) || ((uintptr_t)workspace & 15)) return KGW_E_UNSUPPORTED;
     if (!transpose_out && ((ldo & 3) || ((uintptr_t)out & 15) || (bias && ((uintptr_t)bias & 15)))) return KGW_E_UNSUPPORTED;
-    if (transpose_out && (bias || relu)) return KGW_E_UNSUPPORTED;
+    if (transpose_out && (bias || relu || row_map)) return KGW_E_UNSUPPORTED;
+    if (row_map && (!out_rows || (ld_rows & 3) || ((uintptr_t)out_rows & 15))) return KGW_E_UNSUPPORTED;
     const int ns = g3_splits(M, K);
     if (workspace_floats < (int64_t)ns * M * 128) return KGW_E_RANGE;
     const int rt = 32 * g3_nw();
@@ -320,7 +326,7 @@ extern "C" int kgw_gemm3(const float* A, int64_t lda, int64_t M, int64_t K, cons
     else k_g3_gemm<1, 4><<<per_xcd * 8, 256, 0, st>>>(a);
     KGW_LAUNCH_CHECK();
     if (transpose_out) k_g3_reduce_t<<<dim3((unsigned)((M + 31) / 32), 4), 256, 0, st>>>(workspace, ns, (long)M, out, (long)ldo);
-    else k_g3_reduce<<<(int)((M * 32 + 255) / 256), 256, 0, st>>>(workspace, ns, (long)M, bias, relu, out, (long)ldo);
+    else k_g3_reduce<<<(int)((M * 32 + 255) / 256), 256, 0, st>>>(workspace, ns, (long)M, bias, relu, out, (long)ldo, row_map, out_rows, (long)ld_rows);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }

@@ -515,10 +515,12 @@ def gemm3_tile(A: torch.Tensor) -> torch.Tensor:
     return A.view(Mp // 32, 32, K // 32, 32).permute(0, 2, 1, 3).contiguous()
 
 
-def gemm3(A: torch.Tensor, packed: torch.Tensor, bias=None, relu: bool = False, transpose_out: bool = False, out=None, tiled_rows: int = 0):
+def gemm3(A: torch.Tensor, packed: torch.Tensor, bias=None, relu: bool = False, transpose_out: bool = False, out=None, tiled_rows: int = 0,
+          row_map=None, out_rows=None):
     """act(A [M, K] @ B [K, 128] + bias) -> [M, 128], or its transpose [128, M] (``transpose_out``): the tall resident product
     of the first gene Linear on the bf16 matrix pipe with fp32 error (three exact bf16 pieces per operand, kgw_gemm3).
-    ``tiled_rows`` = M when A is a gemm3_tile() copy."""
+    ``tiled_rows`` = M when A is a gemm3_tile() copy.  ``row_map`` [M] int32 + ``out_rows``: row m also goes to
+    out_rows[row_map[m]] where row_map[m] >= 0 (the batch's rows of a resident layer output, no gather launch)."""
     if tiled_rows:
         M, K, lda = tiled_rows, A.shape[1] * 32, 0
         assert A.dim() == 4 and A.shape[2:] == (32, 32) and A.is_contiguous() and A.shape[0] * 32 >= M
@@ -533,7 +535,8 @@ def gemm3(A: torch.Tensor, packed: torch.Tensor, bias=None, relu: bool = False, 
     nws = int(L.kgw_gemm3_workspace_floats(M, K))
     ws = torch.empty(nws, device=A.device)
     _lib.check(L.kgw_gemm3(_p(A), lda, M, K, _p(packed), _p(ws), nws, _p(bias), 1 if relu else 0, _p(out), out.stride(0),
-                           1 if transpose_out else 0, _lib.stream_ptr()), 'kgw_gemm3')
+                           1 if transpose_out else 0, _p(row_map), _p(out_rows), out_rows.stride(0) if out_rows is not None else 0,
+                           _lib.stream_ptr()), 'kgw_gemm3')
     return out
 
 
@@ -566,14 +569,18 @@ def _resident_ok(X: torch.Tensor, W: torch.Tensor) -> bool:
             and X.stride(1) == 1 and W.stride(1) == 1)
 
 
-def resident_first_linear(X, W, b):
-    """relu(X W^T + b) over ALL rows of a resident wide feature matrix (kgwas/model.py:19 on the gene features)."""
+def resident_first_linear(X, W, b, g2l=None, rows_out=None):
+    """relu(X W^T + b) over ALL rows of a resident wide feature matrix (kgwas/model.py:19 on the gene features).  ``g2l`` +
+    ``rows_out``: the batch's rows (rows_out[g2l[r]] = row r where g2l[r] >= 0) are written by the same launch; returns
+    (h, True) then, (h, False) when the caller still has to gather them."""
     if _resident_ok(X, W):
         Xf = _resident_copies(X)[0]                      # built outside any graph capture, on the first eager step
         Kp = Xf.shape[1]
         Wp = W if Kp == W.shape[1] and W.stride(0) % 4 == 0 and W.data_ptr() % 16 == 0 else torch.nn.functional.pad(W, (0, Kp - W.shape[1]))
-        return gemm3(Xf, gemm3_pack(Wp, Kp, False), bias=b, relu=True)
-    return linear(X, W, b, relu=True, fixed_shape=True)
+        fused = g2l is not None and rows_out is not None and rows_out.numel() > 0
+        h = gemm3(Xf, gemm3_pack(Wp, Kp, False), bias=b, relu=True, row_map=g2l if fused else None, out_rows=rows_out if fused else None)
+        return h, fused
+    return linear(X, W, b, relu=True, fixed_shape=True), False
 
 
 def resident_first_weight_grad(dz, X, W):
@@ -879,10 +886,12 @@ class _ResidentLinearReLURows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, W, b, ids, g2l):
-        h = resident_first_linear(X, W, b)
         n = int(ids.numel())
-        out = torch.empty(n, h.shape[1], device=h.device)
-        if n:
+        # zeros: the rows past the batch's real node count (static capacity of a captured step) are written by nobody on the
+        # fused route, and 0 x garbage must stay 0 in the weight gradients downstream
+        out = torch.zeros(n, KGW_C, device=X.device) if _resident_ok(X, W) else torch.empty(n, KGW_C, device=X.device)
+        h, done = resident_first_linear(X, W, b, g2l, out)
+        if n and not done:
             _lib.check(_lib.lib().kgw_gather_rows(_p(h), _p(ids), n, h.shape[1], _p(out), _lib.stream_ptr()), 'kgw_gather_rows')
         ctx.save_for_backward(X, h, g2l, W)
         return out
@@ -912,10 +921,10 @@ class _ResidentMLP2(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, W1, b1, W2, b2, ids, g2l, out):
-        h = resident_first_linear(X, W1, b1)
         n = int(ids.numel())
-        h1g = torch.empty(n, h.shape[1], device=h.device)
-        if n:
+        h1g = torch.zeros(n, KGW_C, device=X.device) if _resident_ok(X, W1) else torch.empty(n, KGW_C, device=X.device)   # (see _ResidentLinearReLURows)
+        h, done = resident_first_linear(X, W1, b1, g2l, h1g)
+        if n and not done:
             _lib.check(_lib.lib().kgw_gather_rows(_p(h), _p(ids), n, h.shape[1], _p(h1g), _lib.stream_ptr()), 'kgw_gather_rows')
         h2 = linear(h1g, W2, b2, relu=True, out=out.view() if out is not None else None)
         ctx.save_for_backward(X, h, h1g, W2, g2l, W1)
