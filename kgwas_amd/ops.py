@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 import sys
 
 import torch
@@ -550,17 +551,19 @@ def _resident_copies(X: torch.Tensor):
     reads X itself when its width is a multiple of 32 (5 120), else a copy padded with zero columns (57 742 -> 57 760,
     mode='full')."""
     key = (X.data_ptr(), tuple(X.shape), X.device)
-    t = _RESIDENT_T.get(key)
-    if t is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError('resident copies requested inside a graph capture: run one eager step first')
-        K = X.shape[1]
-        Kp = (K + 31) // 32 * 32
-        direct = Kp == K and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0
-        Xf = X if direct else torch.nn.functional.pad(X, (0, Kp - K))
-        t = (Xf, X.t().contiguous())
-        _RESIDENT_T[key] = t
-    return t
+    ent = _RESIDENT_T.get(key)
+    if ent is not None and ent[0]() is not None:         # the tensor the copies were made from is alive: same memory, same features
+        return (X if ent[1][0] is None else ent[1][0]), ent[1][1]
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError('resident copies requested inside a graph capture: run one eager step first')
+    for k in [k for k, e in _RESIDENT_T.items() if e[0]() is None]:
+        del _RESIDENT_T[k]                               # copies of matrices that are gone (their address may be reused)
+    K = X.shape[1]
+    Kp = (K + 31) // 32 * 32
+    direct = Kp == K and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0
+    t = (None if direct else torch.nn.functional.pad(X, (0, Kp - K)), X.t().contiguous())      # (no strong reference to X itself)
+    _RESIDENT_T[key] = (weakref.ref(X), t)
+    return (X if t[0] is None else t[0]), t[1]
 
 
 def _resident_ok(X: torch.Tensor, W: torch.Tensor) -> bool:

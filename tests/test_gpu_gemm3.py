@@ -118,3 +118,20 @@ def test_resident_gene_layer_on_gemm3_matches_float64_autograd(fused, K):
         assert a.shape == r.shape, name
         tol = 2e-5 * max(1.0, float(r.abs().max()))
         assert float((a.double() - r).abs().max()) <= tol, (name, float((a.double() - r).abs().max()), tol)
+
+
+def test_resident_copies_follow_the_matrix_not_its_address():
+    """The cached X^T belongs to one feature matrix: a new matrix of the same shape at the same address gets its own."""
+    from kgwas_amd import ops
+    N, K = 4128, 1056
+    W = torch.zeros(128, K, device='cuda')
+    dz = torch.randn(N, 128, device='cuda')
+    ptrs = []
+    for seed in (1, 2):
+        X = torch.randn(N, K, device='cuda', generator=torch.Generator(device='cuda').manual_seed(seed))
+        ptrs.append(X.data_ptr())
+        got = ops.resident_first_weight_grad(dz, X, W)
+        ref = dz.double().t() @ X.double()
+        assert float((got.double() - ref).abs().max()) < 1e-3 * float(ref.abs().max())
+        del X, got, ref
+    # (the allocator normally hands the second matrix the first one's block; the check above holds either way)
