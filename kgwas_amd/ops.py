@@ -882,10 +882,10 @@ class _LinearReLU(torch.autograd.Function):
 
 class _ResidentLinearReLURows(torch.autograd.Function):
     """rows ``ids`` of relu(X W^T + b) where X is a RESIDENT feature matrix (the 5120 / 57742-wide gene features): the
-    product runs on all of X (same shape every step -> tuned library GEMM) and the batch takes its rows -- no x[n_id]
+    product runs on all of X (kgw_gemm3; small or unaligned shapes: the tuned library GEMM) and the batch takes its rows -- no x[n_id]
     copy of 20 KB rows (kgwas/kgwas.py:135).  ``g2l`` [N] int32: local index of each row of X in the batch, -1 = not
     sampled (the inverse of ``ids``, kept by the sampler).  Backward: kgw_scatter_relu_rows builds the dense dz (zero
-    rows for unsampled nodes, ReLU mask applied) and the bias gradient in two launches; dW is one library GEMM."""
+    rows for unsampled nodes, ReLU mask applied) and the bias gradient in two launches; dW = dz^T X on kgw_gemm3 (or the library)."""
 
     @staticmethod
     def forward(ctx, X, W, b, ids, g2l):
