@@ -527,6 +527,14 @@ def main():
                    'seeds_per_s': seeds / elapsed,
                    'epoch_time_s_956_steps': 956 * ms / 1e3 / (1 if strong else world),
                    'epoch_measured': epoch,
+                   'arithmetic': ('fp32 operands, fp32 accumulation, fp32 results.  The two 5120-wide gene products and the 128 x 128 products '
+                                  'of the SNP feature MLP (forward, first-layer backward) run on the bf16 matrix pipe from three EXACT bf16 '
+                                  'pieces per fp32 operand (a = a1 + a2 + a3, six piece products kept, the dropped ones <= 3*2^-25|ab| per term: '
+                                  'below one fp32 multiply-add rounding); measured against float64 at or below the fp32 product\'s own error '
+                                  '(tests/test_gpu_gemm3.py, tests/test_split3_bound.py, DESIGN.md section 1); '
+                                  'KGW_GEMM3=0 KGW_MLP2_SPLIT=0 run them on the fp32 pipe instead')
+                                 if (os.environ.get('KGW_GEMM3', '1') != '0' or os.environ.get('KGW_MLP2_SPLIT', '1') != '0') else
+                                 'fp32 operands, fp32 accumulation, fp32 matrix pipe throughout (KGW_GEMM3=0 KGW_MLP2_SPLIT=0)',
                    'setup_s': setup_s},
         'roofline': roof, 'cpu_baseline': cpu, 'breakdown': breakdown,
     }
