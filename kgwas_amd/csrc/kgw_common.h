@@ -116,6 +116,7 @@ __device__ __forceinline__ float kgw_xhalf(float v) {   // value held by the sam
 // x = p1 + p2 + p3 with p1 = bf16(x), p2 = bf16(x - p1), p3 = x - p1 - p2: three 8-bit significands = the 24 bits of fp32, both
 // residuals exact in fp32.  Eight values -> three registers-of-eight (element i in bits 16 (i & 1) of word i / 2), 44 VALU ops.
 typedef __attribute__((ext_vector_type(8))) __bf16 kgw_bf8;
+__device__ __forceinline__ float kgw_fxor(float x, unsigned m) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) ^ m); }
 __device__ __forceinline__ uint32_t kgw_cvt_pk_bf16(float lo, float hi) {
     uint32_t r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));

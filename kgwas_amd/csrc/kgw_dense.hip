@@ -1592,6 +1592,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     float* Tl = lds + M3_W2_U4 * 4;                          // [4 wavefronts][32 rows][TS2]: half of the columns at a time
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lk = lane >> 5;
+    const unsigned sgn = (li & 1) ? 0x80000000u : 0u;
     int64_t rows = a.rows;
     if (a.rows_dev) { const int64_t r = *a.rows_dev; rows = r < 0 ? 0 : (r < a.rows ? r : a.rows); }
     const int ntiles = (int)((rows + 31) / 32);
@@ -1681,7 +1682,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             if (s_ == 5) { KGW_MLPB_MBITS(2) KGW_MLPB_MFETCH(3) }
             if (s_ == 7) { KGW_MLPB_MBITS(3) }
             const f32x4 u = xa[2 * s_], v = xa[2 * s_ + 1];
-            const float h[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+            // odd rows are multiplied NEGATED (exact) and their result negated back: the bf16 MFMA's internal addition truncates
+            // (a small negative mean error), and dW1 / db1 sum dh1 over the rows -- with alternating signs the means cancel
+            const float h[8] = {kgw_fxor(u.x, sgn), kgw_fxor(u.y, sgn), kgw_fxor(u.z, sgn), kgw_fxor(u.w, sgn),
+                                kgw_fxor(v.x, sgn), kgw_fxor(v.y, sgn), kgw_fxor(v.z, sgn), kgw_fxor(v.w, sgn)};
             uint4 p1, p2, p3;
             kgw_split3x8(h, p1, p2, p3);
             const kgw_bf8 hb[3] = {__builtin_bit_cast(kgw_bf8, p1), __builtin_bit_cast(kgw_bf8, p2), __builtin_bit_cast(kgw_bf8, p3)};
@@ -1720,8 +1724,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 for (int g = 0; g < 4; ++g) {
                     const unsigned m4 = mb[t >> 1] >> (((t & 1) << 4) + 4 * g);
                     f32x4 v;
-                    v.x = (m4 & 1u) ? acc[t][4 * g + 0] : 0.f; v.y = (m4 & 2u) ? acc[t][4 * g + 1] : 0.f;
-                    v.z = (m4 & 4u) ? acc[t][4 * g + 2] : 0.f; v.w = (m4 & 8u) ? acc[t][4 * g + 3] : 0.f;
+                    v.x = (m4 & 1u) ? kgw_fxor(acc[t][4 * g + 0], sgn) : 0.f; v.y = (m4 & 2u) ? kgw_fxor(acc[t][4 * g + 1], sgn) : 0.f;
+                    v.z = (m4 & 4u) ? kgw_fxor(acc[t][4 * g + 2], sgn) : 0.f; v.w = (m4 & 8u) ? kgw_fxor(acc[t][4 * g + 3], sgn) : 0.f;
                     *(f32x4*)(Tw + li * TS2 + (t - 2 * hh) * 32 + 8 * g + 4 * lk) = v;
                     if (a.dZ && row < rows) *(f32x4*)(a.dZ + row * a.ldz + t * 32 + 8 * g + 4 * lk) = v;
                 }
