@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define KGW_VERSION      113          /* 0.1.3 */
+#define KGW_VERSION      114          /* 0.1.4 */
 #define KGW_MAX_TYPES    8
 #define KGW_MAX_RELS     64
 #define KGW_MAX_LAYERS   4
@@ -370,14 +370,16 @@ int kgw_mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2, int64_t l
  * matrix pipe with fp32 error: every fp32 operand is split exactly into three bf16 pieces and the six piece products of
  * weight >= 2^-16 are accumulated in fp32; the dropped products are below the rounding of one fp32 multiply-add (see
  * kgwas_amd/csrc/kgw_gemm3.hip).  kgw_gemm3_pack splits B once per call into the kernel's operand image (packed:
- * kgw_gemm3_packed_bytes(K) bytes; s_is_kn: B[k, n] = S[k * lds + n], else B[k, n] = S[n * lds + k], n < 128).  A is split in
+ * kgw_gemm3_packed_bytes(K) bytes; s_is_kn: B[k, n] = S[k * lds + n], else B[k, n] = S[n * lds + k], n < 128; S holds
+ * k < k_valid only, B[k >= k_valid] = 0: a gene count / feature width that is not a multiple of 32 is padded HERE and in a
+ * zero-padded resident A, never by falling back to a library product).  A is split in
  * the kernel.  lda == 0: A is stored in 32 x 32 tiles, [ceil(M / 32)][K / 32][32][32] floats (rows past M present, any value) --
  * the layout for a resident copy, every 4 KB a wavefront reads per step is contiguous.  K % 32 == 0, lda % 4 == 0, 16-byte
  * aligned pointers, else KGW_E_UNSUPPORTED.  workspace:
  * kgw_gemm3_workspace_floats(M, K) floats (partial products of the K ranges, added in index order: deterministic).      */
 int64_t kgw_gemm3_packed_bytes(int64_t K);
 int64_t kgw_gemm3_workspace_floats(int64_t M, int64_t K);
-int kgw_gemm3_pack(const float* S, int64_t lds, int64_t K, int32_t s_is_kn, void* packed, kgw_stream_t stream);
+int kgw_gemm3_pack(const float* S, int64_t lds, int64_t K, int64_t k_valid, int32_t s_is_kn, void* packed, kgw_stream_t stream);
 int kgw_gemm3(const float* A, int64_t lda, int64_t M, int64_t K, const void* packed, float* workspace, int64_t workspace_floats,
               const float* bias, int32_t relu, float* out, int64_t ldo, int32_t transpose_out, const int32_t* row_map,
               float* out_rows, int64_t ld_rows, kgw_stream_t stream);

@@ -42,9 +42,10 @@ static constexpr int G3_MAX_ITEMS = 512;       // 128-row blocks resident at onc
 
 // ---- B operand packing ------------------------------------------------------------------------------------------------------
 // image index (((c * 2 + j) * 3 + p) * 4 + nt) * 64 + lane: the eight bf16 of piece p for k = 32 c + 16 j + 8 (lane >> 5) + i,
-// column 32 nt + (lane & 31).  One thread per (c, j, nt, lane).
+// column 32 nt + (lane & 31).  One thread per (c, j, nt, lane).  k >= kv reads as zero (S holds kv rows / columns only: a gene
+// count or a feature width that is not a multiple of 32 -- the A operand then carries zero padding there as well).
 template <bool KN>
-__global__ void __launch_bounds__(256) k_g3_pack(const float* __restrict__ S, long lds_, int K, uint4* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_g3_pack(const float* __restrict__ S, long lds_, int K, long kv, int vec, uint4* __restrict__ out) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long)K * 16) return;
     const int lane = (int)(t & 63), nt = (int)((t >> 6) & 3), j = (int)((t >> 8) & 1);
@@ -54,10 +55,13 @@ __global__ void __launch_bounds__(256) k_g3_pack(const float* __restrict__ S, lo
     float x[8];
     if (KN) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = S[(k0 + i) * lds_ + n];
-    } else {
+        for (int i = 0; i < 8; ++i) x[i] = k0 + i < kv ? S[(k0 + i) * lds_ + n] : 0.f;
+    } else if (vec && k0 + 8 <= kv) {
         const float4 u = *(const float4*)(S + n * lds_ + k0), v = *(const float4*)(S + n * lds_ + k0 + 4);
         x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = k0 + i < kv ? S[n * lds_ + k0 + i] : 0.f;
     }
     uint4 p1, p2, p3;
     kgw_split3x8(x, p1, p2, p3);
@@ -293,15 +297,16 @@ extern "C" int64_t kgw_gemm3_workspace_floats(int64_t M, int64_t K) {
     return M > 0 && K > 0 ? (int64_t)g3_splits(M, K) * M * 128 : 0;
 }
 
-extern "C" int kgw_gemm3_pack(const float* S, int64_t lds_, int64_t K, int32_t s_is_kn, void* packed, kgw_stream_t stream_) {
+extern "C" int kgw_gemm3_pack(const float* S, int64_t lds_, int64_t K, int64_t k_valid, int32_t s_is_kn, void* packed,
+                              kgw_stream_t stream_) {
     if (!S || !packed) return KGW_E_NULL;
-    if (K <= 0) return KGW_E_RANGE;
+    if (K <= 0 || k_valid < 0 || k_valid > K) return KGW_E_RANGE;
     if (K % 32 || ((uintptr_t)packed & 15)) return KGW_E_UNSUPPORTED;
-    if (!s_is_kn && ((lds_ & 3) || ((uintptr_t)S & 15))) return KGW_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream_;
     const int64_t nthr = K * 16;
-    if (s_is_kn) k_g3_pack<true><<<(int)((nthr + 255) / 256), 256, 0, st>>>(S, lds_, (int)K, (uint4*)packed);
-    else k_g3_pack<false><<<(int)((nthr + 255) / 256), 256, 0, st>>>(S, lds_, (int)K, (uint4*)packed);
+    const int vec = !(lds_ & 3) && !((uintptr_t)S & 15);       // 16-byte loads along k (S = B^T); else element loads
+    if (s_is_kn) k_g3_pack<true><<<(int)((nthr + 255) / 256), 256, 0, st>>>(S, lds_, (int)K, (long)k_valid, 0, (uint4*)packed);
+    else k_g3_pack<false><<<(int)((nthr + 255) / 256), 256, 0, st>>>(S, lds_, (int)K, (long)k_valid, vec, (uint4*)packed);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }

@@ -50,6 +50,18 @@ def _feature_matrix(node_map, feat, dim, gen):
     return x
 
 
+def _weighted_line_fit(x, y, w):
+    """(intercept, slope) minimising sum_i w_i (y_i - a - b x_i)^2 -- what sm.WLS(y, add_constant(x), weights=w).fit().params
+    returns (kgwas/kgwas_data.py:456-460); w = 1: sm.OLS.  Solved on centred data (the normal equations of the raw columns are
+    badly conditioned when x ~ 1..200 over 5e5 rows)."""
+    x, y, w = (np.asarray(v, dtype=np.float64) for v in (x, y, w))
+    sw = w.sum()
+    mx, my = (w * x).sum() / sw, (w * y).sum() / sw
+    dx = x - mx
+    b = (w * dx * (y - my)).sum() / (w * dx * dx).sum()
+    return my - b * mx, b
+
+
 class KGWAS_Data:
     def __init__(self, data_path='./data/'):
         self.data_path = data_path
@@ -130,7 +142,7 @@ class KGWAS_Data:
     @classmethod
     def from_synthetic(cls, scale=1.0, seed=1, mode='fast', data_path='/tmp/kgwas_synth', n_labelled=None,
                        gwas_kind='causal', sample_size=None, feat_dims=None, split=True, snp_scale=1.0,
-                       sample_edges=False, sample_ratio=1.0):
+                       sample_edges=False, sample_ratio=1.0, node_counts=None):
         """SynthKG + synthetic summary statistics through the same pipeline as the real files.
         ``gwas_kind`` mirrors the reference's four label sources (BASELINE.json configs): 'causal' / 'null' = the
         simulations of load_simulation_gwas (N = 5000, kgwas_data.py:275-294), 'subsample' = load_gwas_subsample
@@ -142,7 +154,7 @@ class KGWAS_Data:
         self = cls(data_path)
         if sample_size is None:
             sample_size = {'subsample': 10000, 'full_cohort': 387113}.get(gwas_kind, 5000)
-        edges, nc = make_synth_edges(scale, seed, snp_scale=snp_scale)
+        edges, nc = make_synth_edges(scale, seed, node_counts=node_counts, snp_scale=snp_scale)
         if sample_edges:
             gen_e = torch.Generator().manual_seed(seed)
             for et in list(edges.keys()):
@@ -242,7 +254,7 @@ class KGWAS_Data:
         self.lr_uni = lr_uni
         self.seed = seed
 
-    # --- labels + LD weights (kgwas_data.py:391-447) ----------------------------------------------
+    # --- labels + LD weights (kgwas_data.py:391-500) ----------------------------------------------
     def process_gwas_file(self, label='chi'):
         import pandas as pd
         lr_uni = self.lr_uni
@@ -282,8 +294,25 @@ class KGWAS_Data:
                 from scipy.stats import chi2
                 lr_uni['y'] = chi2.ppf(1 - lr_uni['P'].values, 1)
                 lr_uni['y'] = lr_uni.y.fillna(0)
-        elif label == 'residual-w-ld':                                # kgwas_data.py:449-450
+        elif label in ('residual-w-ld', 'residual-ld', 'residual-ld-ols', 'residual-ld-ols-abs'):
+            # kgwas_data.py:448-500: chi-square from BETA / SE, NaN -> 0, then the residual of a straight-line fit on an LD
+            # score -- weighted by the LDSC weights (sm.WLS) for the first two, unweighted (sm.OLS) for the '-ols' ones.
+            # As in the reference: 'residual-w-ld' fits on w_ld_score; the three 'residual-ld*' labels FIT on ld_score but
+            # PREDICT with w_ld_score (:475,487,499) -- kept, a label is only comparable to the reference's if it is the same
+            # number.  statsmodels is not needed for a two-parameter least-squares fit.
             lr_uni['y'] = (lr_uni['BETA'] / lr_uni['SE']).values ** 2
+            lr_uni['y'] = lr_uni.y.fillna(0)
+            y = lr_uni.y.values.astype(np.float64)
+            fit_x = (lr_uni.w_ld_score if label == 'residual-w-ld' else lr_uni.ld_score).values.astype(np.float64)
+            wt = np.asarray(w, dtype=np.float64) if label in ('residual-w-ld', 'residual-ld') else np.ones_like(y)
+            if label in ('residual-w-ld', 'residual-ld'):
+                lr_uni['ld_weight'] = wt
+            a, b = _weighted_line_fit(fit_x, y, wt)
+            y_pred = a + b * lr_uni.w_ld_score.values
+            lr_uni['y'] = np.abs(y - y_pred) if label == 'residual-ld-ols-abs' else y - y_pred
+        else:
+            raise NotImplementedError(f"label {label!r}: the reference defines 'chi', 'residual-w-ld', 'residual-ld', "
+                                      "'residual-ld-ols', 'residual-ld-ols-abs' (kgwas/kgwas_data.py:429-500)")
         id2idx = self.id2idx['SNP']
         self.all_ids = np.array([id2idx[i] for i in lr_uni.ID.values], dtype=np.int64)
         self.y = lr_uni.y.values

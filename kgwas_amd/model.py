@@ -426,12 +426,14 @@ class HeteroGNN(nn.Module):
                 z0 = int(m.z_base[l - 1][t])
                 if self.aggr in ('min', 'max'):
                     zr = Z[z0:z0 + rows * R].view(rows, R, C).transpose(0, 1)                    # [R, rows, C]
+                    ops.LIBRARY_GEMM.note('sage min/max per-relation outputs', R, rows, C)
                     o = torch.baddbmm(P.bias[lo:hi].unsqueeze(1), zr, P.w_l_t[lo:hi]) + \
                         torch.matmul(h[name][:rows].unsqueeze(0), P.w_r_t[lo:hi])
                     h_next[name] = torch.relu(self._combine_relations(o))
                     continue
                 x = Z[z0:z0 + rows * R].view(rows, R * C)
                 y = ops.linear_act(x, P.w_l_t[lo:hi].reshape(R * C, C), P.bias[lo:hi].sum(0), relu=False)
+                ops.LIBRARY_GEMM.note('sage root term', rows, C, C)
                 y = y + h[name][:rows] @ P.w_r_t[lo:hi].sum(0)            # root term: sum_r lin_r^r(h_d[i])
                 if self.aggr == 'mean':
                     y = y * (1.0 / R)
@@ -514,6 +516,7 @@ class HeteroGNN(nn.Module):
                 for (lo, hi, z0, rows) in blocks:
                     R = hi - lo
                     zr = Z[z0:z0 + rows * R].view(rows, R, C).transpose(0, 1)
+                    ops.LIBRARY_GEMM.note('gat min/max per-relation outputs', R, rows, C)
                     o = torch.baddbmm(P.bias[lo:hi].unsqueeze(1), zr, Wv[lo:hi])
                     outs.append(torch.relu(self._combine_relations(o)))
                 h = {sc.node_types[t]: o for t, o in zip(tys, outs)}
@@ -543,12 +546,20 @@ class HeteroGNN(nn.Module):
         h = self._embed_all(batch, x_dict, blocks, fold=self.fold_fc)
         h, attn = self._fused_layers(batch, h, hbuf=hbuf, folded=self.fold_fc)
         snp = h['SNP']
-        out = self.lin(snp)[:batch_size]
+        out = self._readout(snp[:batch_size])
         if return_h:                                            # model.py:78-79
             return self.ReLU(out), snp[:batch_size]
         if self.no_relu:                                        # model.py:83-84
             return out
         return self.ReLU(out)                                   # model.py:86
+
+    def _readout(self, h):
+        """self.lin(h) (kgwas/model.py:50,83-86).  For the reference's out_channels == 1 (kgwas.py:52) the Linear(128 -> 1) is a
+        row-wise dot product: elementwise multiply + row sum, not a library GEMV."""
+        if self.lin.out_features == 1:
+            return (h * self.lin.weight.view(1, -1)).sum(1, keepdim=True) + self.lin.bias
+        ops.LIBRARY_GEMM.note('read-out', h.shape[0], h.shape[1], self.lin.out_features)
+        return self.lin(h)
 
     @torch.no_grad()
     def hot_path_attention(self, batch: SampledBatch):
@@ -643,7 +654,7 @@ class HeteroGNN(nn.Module):
                     pack = self.live_packs[l - 1] if which == 'live' else self.dead_packs[l - 1]
                     ws.append(pack.w_src_t[i])
                     bs = bs + pack.bias[i]
-                y = torch.addmm(bs, x, torch.cat(ws, 0))
+                y = ops.linear(x, torch.cat(ws, 0), bs, w_kn=True)
                 h_next[name] = y if raw else torch.relu(y)                   # model.py:75 / no ReLU at utils.py:460
             h = h_next
         return h, per_layer
@@ -708,7 +719,7 @@ class HeteroGNN(nn.Module):
         batch = finish_sample(dg, buf, sc.node_types[0], dg.n_nodes[0])
         h, per_layer = self._forward_all_relations(batch, raw=False)
         self.last_attention = per_layer
-        out = self.ReLU(self.lin(h['SNP']))[:batch_size]
+        out = self.ReLU(self._readout(h['SNP'][:batch_size]))
         return out, [a.mean() if a.numel() else a.sum() for a in per_layer]
 
     # ------------------------------------------------------------------------------------------

@@ -63,6 +63,39 @@ class _TunedLibraryGemm:
 _TUNED = _TunedLibraryGemm()
 
 
+class LibraryGemmLog:
+    """Every product this package hands to the framework's GEMM library (hipBLASLt / rocBLAS) instead of its own HIP kernels is
+    recorded here -- ``calls`` (total) and ``by_site`` ({(site, shape): n}).  The default GAT / relation-sum training step of a
+    KG-sized graph must not have any (bench.py reports ``config.library_gemm_calls``; the full-size tests assert 0);
+    ``KGW_STRICT=1`` (or ``strict = True``) turns a library route into an error instead of a silent fallback.  Calls made while a
+    HIP graph is being captured count once (the capture), like every other launch of a captured step."""
+
+    def __init__(self):
+        self.strict = os.environ.get('KGW_STRICT', '0') == '1'
+        self.calls = 0
+        self.by_site = {}
+
+    def note(self, site: str, *shape):
+        key = (site, tuple(int(v) for v in shape))
+        if self.strict:
+            raise RuntimeError(f'KGW_STRICT: {site} {key[1]} would run on the library GEMM (no HIP kernel of this package takes '
+                               f'that shape); unset KGW_STRICT to allow the fallback')
+        self.calls += 1
+        self.by_site[key] = self.by_site.get(key, 0) + 1
+
+    def reset(self):
+        self.calls = 0
+        self.by_site = {}
+
+
+LIBRARY_GEMM = LibraryGemmLog()
+ROUTES = {}          # launches of selected own kernels by C-ABI name (tests assert that a product really took the route they check)
+
+
+def _route(name: str):
+    ROUTES[name] = ROUTES.get(name, 0) + 1
+
+
 class KernelTimer:
     """Optional HIP-event timing of the main aggregate kernels (bench.py's live roofline measurement): raw
     hipEvent_t pairs handed to the C ABI (KgwLayerArgs.ev_before / ev_after), which records them on the launch
@@ -415,6 +448,7 @@ def weight_grads(pairs, rows_dev: torch.Tensor = None):
 
 
 def _library_linear(X, W, bias, relu, mask, w_kn, out, fixed_shape):
+    LIBRARY_GEMM.note('linear', X.shape[0], X.shape[1], W.shape[1] if w_kn else W.shape[0])
     Wop = W if w_kn else W.t()
     if fixed_shape and mask is None and out is None:          # same shape every step: tuned library solution
         with _TUNED:
@@ -496,13 +530,15 @@ def gemm3_ok(M: int, K: int) -> bool:
     return _GEMM3 and K % 32 == 0 and M >= 2048 and K >= 1024
 
 
-def gemm3_pack(S: torch.Tensor, K: int, s_is_kn: bool) -> torch.Tensor:
+def gemm3_pack(S: torch.Tensor, K: int, s_is_kn: bool, k_valid: int = None) -> torch.Tensor:
     """B [K, 128] of a kgw_gemm3 product, split into its three bf16 pieces in the kernel's operand image.  ``s_is_kn``: S is
-    B itself ([K, 128]); else S = B^T ([128, K], an nn.Linear weight)."""
-    assert S.dtype == torch.float32 and S.stride(1) == 1 and (S.shape == (K, KGW_C) if s_is_kn else S.shape == (KGW_C, K))
+    B itself ([k_valid, 128]); else S = B^T ([128, k_valid], an nn.Linear weight).  ``k_valid`` < K (default K): S stops there,
+    the rows of B up to K -- a multiple of 32 -- are zero."""
+    kv = K if k_valid is None else int(k_valid)
+    assert S.dtype == torch.float32 and S.stride(1) == 1 and (S.shape == (kv, KGW_C) if s_is_kn else S.shape == (KGW_C, kv))
     L = _lib.lib()
     packed = torch.empty(int(L.kgw_gemm3_packed_bytes(K)), dtype=torch.uint8, device=S.device)
-    _lib.check(L.kgw_gemm3_pack(_p(S), S.stride(0), K, 1 if s_is_kn else 0, _p(packed), _lib.stream_ptr()), 'kgw_gemm3_pack')
+    _lib.check(L.kgw_gemm3_pack(_p(S), S.stride(0), K, kv, 1 if s_is_kn else 0, _p(packed), _lib.stream_ptr()), 'kgw_gemm3_pack')
     return packed
 
 
@@ -535,6 +571,7 @@ def gemm3(A: torch.Tensor, packed: torch.Tensor, bias=None, relu: bool = False, 
         out = torch.empty((KGW_C, M) if transpose_out else (M, KGW_C), device=A.device)
     nws = int(L.kgw_gemm3_workspace_floats(M, K))
     ws = torch.empty(nws, device=A.device)
+    _route('kgw_gemm3')
     _lib.check(L.kgw_gemm3(_p(A), lda, M, K, _p(packed), _p(ws), nws, _p(bias), 1 if relu else 0, _p(out), out.stride(0),
                            1 if transpose_out else 0, _p(row_map), _p(out_rows), out_rows.stride(0) if out_rows is not None else 0,
                            _lib.stream_ptr()), 'kgw_gemm3')
@@ -545,30 +582,33 @@ _RESIDENT_T = {}
 
 
 def _resident_copies(X: torch.Tensor):
-    """(A operand of the forward, X^T) for a resident feature matrix, built once per matrix.  X^T [K, N] is the A operand of the
-    weight-gradient product on kgw_gemm3 (a second resident copy, 0.4 GB for the 5 120-wide gene features; row-major like X --
-    the 32 x 32-tiled layout the kernel also takes, gemm3_tile, measured the same in isolation and in the step).  The forward
-    reads X itself when its width is a multiple of 32 (5 120), else a copy padded with zero columns (57 742 -> 57 760,
-    mode='full')."""
-    key = (X.data_ptr(), tuple(X.shape), X.device)
+    """(A operand of the forward, X^T) for a resident feature matrix, built once per matrix (and again if it is modified in
+    place: the tensor's version counter is part of the key).  X^T [K, Np] is the A operand of the weight-gradient product on
+    kgw_gemm3 (a second resident copy, 0.4 GB for the 5 120-wide gene features; row-major like X -- the 32 x 32-tiled layout the
+    kernel also takes, gemm3_tile, measured the same in isolation and in the step), its N node columns padded with zeros to a
+    multiple of 32 (the product's reduction runs over the nodes; the real KG's gene count need not be one -- SURVEY 8d gives
+    20 032 only as a lower bound -- and zero columns against zero rows of the packed dz leave dW exact).  The forward reads X
+    itself when its width is a multiple of 32 (5 120), else a copy padded with zero columns (57 742 -> 57 760, mode='full')."""
+    key = (X.data_ptr(), tuple(X.shape), X.device, X._version)
     ent = _RESIDENT_T.get(key)
     if ent is not None and ent[0]() is not None:         # the tensor the copies were made from is alive: same memory, same features
         return (X if ent[1][0] is None else ent[1][0]), ent[1][1]
     if torch.cuda.is_current_stream_capturing():
         raise RuntimeError('resident copies requested inside a graph capture: run one eager step first')
-    for k in [k for k, e in _RESIDENT_T.items() if e[0]() is None]:
-        del _RESIDENT_T[k]                               # copies of matrices that are gone (their address may be reused)
-    K = X.shape[1]
-    Kp = (K + 31) // 32 * 32
+    for k in [k for k, e in _RESIDENT_T.items() if e[0]() is None or (k[0] == key[0] and k[3] != key[3])]:
+        del _RESIDENT_T[k]                               # copies of matrices that are gone (their address may be reused) or changed
+    N, K = X.shape
+    Kp, Np = (K + 31) // 32 * 32, (N + 31) // 32 * 32
     direct = Kp == K and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0
-    t = (None if direct else torch.nn.functional.pad(X, (0, Kp - K)), X.t().contiguous())      # (no strong reference to X itself)
+    xt = X.t().contiguous() if Np == N else torch.nn.functional.pad(X.t(), (0, Np - N))
+    t = (None if direct else torch.nn.functional.pad(X, (0, Kp - K)), xt)      # (no strong reference to X itself)
     _RESIDENT_T[key] = (weakref.ref(X), t)
     return (X if t[0] is None else t[0]), t[1]
 
 
 def _resident_ok(X: torch.Tensor, W: torch.Tensor) -> bool:
     M, K = X.shape
-    return (gemm3_ok(M, (K + 31) // 32 * 32) and M % 32 == 0 and W.shape[0] == KGW_C and X.dtype == torch.float32
+    return (gemm3_ok(M, (K + 31) // 32 * 32) and W.shape[0] == KGW_C and X.dtype == torch.float32
             and X.stride(1) == 1 and W.stride(1) == 1)
 
 
@@ -579,9 +619,10 @@ def resident_first_linear(X, W, b, g2l=None, rows_out=None):
     if _resident_ok(X, W):
         Xf = _resident_copies(X)[0]                      # built outside any graph capture, on the first eager step
         Kp = Xf.shape[1]
-        Wp = W if Kp == W.shape[1] and W.stride(0) % 4 == 0 and W.data_ptr() % 16 == 0 else torch.nn.functional.pad(W, (0, Kp - W.shape[1]))
         fused = g2l is not None and rows_out is not None and rows_out.numel() > 0
-        h = gemm3(Xf, gemm3_pack(Wp, Kp, False), bias=b, relu=True, row_map=g2l if fused else None, out_rows=rows_out if fused else None)
+        # (a width that is not a multiple of 32: the packing kernel reads the weight's real columns and pads with zeros)
+        h = gemm3(Xf, gemm3_pack(W, Kp, False, k_valid=W.shape[1]), bias=b, relu=True, row_map=g2l if fused else None,
+                  out_rows=rows_out if fused else None)
         return h, fused
     return linear(X, W, b, relu=True, fixed_shape=True), False
 
@@ -589,7 +630,9 @@ def resident_first_linear(X, W, b, g2l=None, rows_out=None):
 def resident_first_weight_grad(dz, X, W):
     """dW [128, K] = dz^T X for the same layer."""
     if _resident_ok(X, W) and dz.is_contiguous():
-        return gemm3(_resident_copies(X)[1], gemm3_pack(dz, X.shape[0], True), transpose_out=True)
+        Xt = _resident_copies(X)[1]                      # [K, Np], Np = the node count rounded up to 32, zero columns past it
+        return gemm3(Xt, gemm3_pack(dz, Xt.shape[1], True, k_valid=X.shape[0]), transpose_out=True)
+    LIBRARY_GEMM.note('resident_first_weight_grad', dz.shape[0], dz.shape[1], X.shape[1])
     with _TUNED:
         return dz.t().mm(X)
 
@@ -978,7 +1021,11 @@ class _LinearAct(torch.autograd.Function):
     def backward(ctx, dy):
         x, y, Wt = ctx.saved_tensors
         dz = torch.ops.aten.threshold_backward(dy.contiguous(), y, 0.0) if ctx.relu else dy.contiguous()
-        dWt = tn_gemm(x, dz) if x.shape[0] >= _TN_MIN_ROWS else x.t().mm(dz)          # [K,N]
+        if x.shape[0] >= _TN_MIN_ROWS:
+            dWt = tn_gemm(x, dz)                                                       # [K,N]
+        else:
+            LIBRARY_GEMM.note('linear_act.backward', x.shape[0], x.shape[1], dz.shape[1])
+            dWt = x.t().mm(dz)
         db = dz.sum(0)
         dx = linear(dz, Wt) if ctx.needs_input_grad[0] else None                       # dz @ Wt^T: Wt is [K,N] = "[N',K']" form
         return dx, dWt, db, None
@@ -993,6 +1040,7 @@ def linear_weight_grad(dY: torch.Tensor, X: torch.Tensor, fixed_shape: bool = Fa
     rows, K = X.shape
     if rows >= _TN_MIN_ROWS and K <= 1024:
         return tn_gemm(dY, X, colsum=True, rows_dev=rows_dev)
+    LIBRARY_GEMM.note('linear_weight_grad', rows, dY.shape[1], K)
     if fixed_shape:
         with _TUNED:
             return dY.t().mm(X), colsum(dY)
@@ -1129,7 +1177,7 @@ class _LayerTransform(torch.autograd.Function):
                 y = linear(x, w_src_t[lo:hi].view(R * C, C), bsum[k], relu=False if gamma is not None else True, w_kn=True, out=out)
                 if gamma is not None and rows:      # (single relation into the type: no K split; rare, framework ops)
                     ind = (stat[z0:z0 + rows * R, 1] > 0).to(y.dtype).view(rows, R)
-                    y = torch.relu_(y.add_(ind @ gamma[lo:hi]))
+                    y = torch.relu_(y.add_((ind.unsqueeze(2) * gamma[lo:hi].unsqueeze(0)).sum(1)))
             outs.append(y)
             ys.append(y)
         ctx.save_for_backward(w_src_t, Z, gamma, stat, *ys)
@@ -1193,7 +1241,7 @@ def layer_transform(pack, Z, blocks, out_blocks=None, premasked=False, bias_sum=
             for k, (lo, hi) in enumerate(key):
                 sel[k, lo:hi] = 1.0
             pack._sel_cache[key] = sel
-        bias_sum = torch.mm(sel, pack.bias.detach())
+        bias_sum = (sel.unsqueeze(2) * pack.bias.detach().unsqueeze(0)).sum(1)        # [blocks, n, 1] * [1, n, C]: no GEMM for a sum
     return _LayerTransform.apply(pack.w_src_t if weight is None else weight, pack.bias, Z, blocks, bias_sum, out_blocks, premasked,
                                  gamma, stat)
 
@@ -1269,6 +1317,7 @@ def fold_fc_output(pack, U, V, T3, c3, src_m, dst_m):
     ``U``, ``V`` [n_rels, C] by relation id (rel_vectors); ``T3`` [n_mlp, C, C] = FC_output.weight^T, ``c3`` [n_mlp, C];
     ``src_m`` / ``dst_m`` [n] long: MLP index of the source / destination type of every packed relation.
     Returns (U' [n_rels,C], V' [n_rels,C], kappa [n_rels] by relation id; W' [n,C,C], gamma [n,C] by packed slot)."""
+    LIBRARY_GEMM.note('fold_fc_output (framework-op reference of kgw_fold_fwd)', pack.w_src_t.shape[0], KGW_C, KGW_C)
     ids = pack.rel_ids_t
     Ui, Vi = U[ids], V[ids]
     Ts, Td = T3[src_m], T3[dst_m]

@@ -77,3 +77,35 @@ def test_cohort_size_reaches_the_ld_weights(kind, n):
     w = ldsc_regression_weights(ld, wld, float(n), 15000000, 0.5)
     assert np.allclose(d.ldsc_weight, w / w.mean(), rtol=1e-12)
     assert np.isfinite(d.y).all() and float(np.mean(d.y)) > 1.0           # causal architecture: inflated chi-square
+
+
+def test_residual_labels_follow_the_reference_definition():
+    """kgwas/kgwas_data.py:448-500: chi-square of BETA / SE (NaN -> 0) minus a straight-line fit on an LD score -- weighted by the
+    LDSC weights for 'residual-w-ld' / 'residual-ld', plain least squares for the '-ols' labels; the 'residual-ld*' labels fit on
+    ld_score and predict with w_ld_score, as the reference does.  Checked against an independent weighted least-squares solve."""
+    import pandas as pd
+    from kgwas_amd.kgwas_data import KGWAS_Data
+    kg = KGWAS_Data.from_synthetic(scale=0.002, seed=2, data_path='/tmp/kgwas_synth_resid', split=False)
+    rng = np.random.default_rng(0)
+    n = len(kg.lr_uni)
+    base = kg.lr_uni.drop(columns=['chi'])
+    base['BETA'] = rng.standard_normal(n)
+    base['SE'] = rng.uniform(0.5, 2.0, n)
+    base.loc[base.index[:3], 'SE'] = np.nan                      # NaN labels become 0 before the fit (kgwas_data.py:450)
+    for label in ('residual-w-ld', 'residual-ld', 'residual-ld-ols', 'residual-ld-ols-abs'):
+        kg.lr_uni = base.copy()
+        kg.process_gwas_file(label=label)
+        lr = kg.lr_uni
+        y0 = np.nan_to_num((base['BETA'] / base['SE']).values ** 2, nan=0.0)
+        fit_x = (lr.w_ld_score if label == 'residual-w-ld' else lr.ld_score).values
+        w = np.asarray(kg.ldsc_weight) if label in ('residual-w-ld', 'residual-ld') else np.ones(n)
+        X = np.stack([np.ones(n), fit_x], 1) * np.sqrt(w)[:, None]
+        a, b = np.linalg.lstsq(X, y0 * np.sqrt(w), rcond=None)[0]
+        want = y0 - (a + b * lr.w_ld_score.values)
+        if label.endswith('abs'):
+            want = np.abs(want)
+        assert np.allclose(kg.y, want, rtol=1e-9, atol=1e-9), label
+        assert np.isfinite(kg.y).all()
+    with pytest.raises(NotImplementedError):
+        kg.lr_uni = base.copy()
+        kg.process_gwas_file(label='no-such-label')

@@ -157,6 +157,90 @@ def test_backward_is_linear_and_bitwise_reproducible(full_run):
     assert any(float(g.abs().max()) > 0 for g in g1.values())
 
 
+def test_no_library_gemm_in_the_training_step_at_full_size(full_run):
+    """Every product of an eager step and of the captured step runs on this package's own kernels on every BASELINE configuration
+    (ops.LIBRARY_GEMM.strict turns a library route into an error); the thinned graph (c0) has node types too small for the
+    MFMA kernels' row thresholds and is exempt."""
+    from kgwas_amd import ops
+    from kgwas_amd.graph_step import GraphTrainStep
+    from kgwas_amd.kgwas import KGWAS
+    run = full_run
+    if run.cfg_name == 'c0_thinned_null':
+        pytest.skip('thinned graph: a few hundred rows per type, below the own kernels\' row thresholds by design')
+    run_s = KGWAS(run.data, device='cuda:0', seed=4)
+    run_s.initialize_model()
+    ids = np.asarray(run.data.train_input_nodes[1][:3 * BS])
+    was = ops.LIBRARY_GEMM.strict
+    ops.LIBRARY_GEMM.reset()
+    g3 = ops.ROUTES.get('kgw_gemm3', 0)
+    try:
+        ops.LIBRARY_GEMM.strict = True
+        opt = torch.optim.Adam(run_s.model.parameters(), lr=1e-4, weight_decay=5e-4)
+        run_s.model.train()
+        loss = float(run_s.train_step(next(iter(_loader(run_s, ids))), opt, run_s._ld_weight_vector()))
+        gs = GraphTrainStep(run_s, ('SNP', ids), BS, lr=1e-4, weight_decay=5e-4)
+        losses = [float(gs.step(i)) for i in range(3)]
+        gs.check()
+    finally:
+        ops.LIBRARY_GEMM.strict = was
+    assert np.isfinite(loss) and np.isfinite(losses).all()
+    assert ops.LIBRARY_GEMM.calls == 0 and ops.ROUTES.get('kgw_gemm3', 0) - g3 >= 4
+
+
+def test_gene_count_not_a_multiple_of_32_stays_on_gemm3():
+    """SURVEY 8d gives 20 032 genes only as a lower bound (max index 20 031 in the notebooks); the real node_idx2id.pkl decides
+    (kgwas/kgwas_data.py:123-127).  With 20 031 genes the first gene Linear and its weight gradient still run on kgw_gemm3
+    (zero-padded resident X^T against zero rows of the packed dz), no library GEMM anywhere in the step, and the step agrees
+    with the same step computed with the library product (KGW_GEMM3 off) to fp32 accuracy."""
+    from kgwas_amd import ops
+    from kgwas_amd.kgwas import KGWAS
+    from kgwas_amd.kgwas_data import KGWAS_Data
+    from kgwas_amd.synth import NODE_COUNTS
+    nc = dict(NODE_COUNTS); nc['Gene'] = 20031
+    data = KGWAS_Data.from_synthetic(scale=1.0, seed=1, data_path='/tmp/kgwas_synth_full_test_g20031', node_counts=nc)
+    assert int(data.data['Gene'].x.shape[0]) == 20031
+    run = KGWAS(data, device='cuda:0', seed=1)
+    run.initialize_model()
+    ids = np.asarray(data.train_input_nodes[1][:BS])
+    ld_w = run._ld_weight_vector()
+    run.model.train()
+
+    def grads(strict):
+        batch = next(iter(NeighborLoader_(run, ids)))
+        for p in run.model.parameters():
+            p.grad = None
+        was = ops.LIBRARY_GEMM.strict
+        try:
+            ops.LIBRARY_GEMM.strict = strict
+            loss, _ = run.model.forward_loss(batch.x_dict, batch.edge_index_dict, BS, batch.n_id('SNP'), batch.dg.y['SNP'], ld_w)
+            loss.backward()
+        finally:
+            ops.LIBRARY_GEMM.strict = was
+        return float(loss), {n: p.grad.clone() for n, p in run.model.named_parameters() if p.grad is not None}
+
+    ops.LIBRARY_GEMM.reset()
+    g3 = ops.ROUTES.get('kgw_gemm3', 0)
+    l_own, g_own = grads(True)
+    assert ops.ROUTES.get('kgw_gemm3', 0) - g3 == 2 and ops.LIBRARY_GEMM.calls == 0
+    was = ops._GEMM3
+    try:
+        ops._GEMM3 = False                          # the library's fp32 product for the same two GEMMs
+        l_lib, g_lib = grads(False)
+    finally:
+        ops._GEMM3 = was
+    assert ops.LIBRARY_GEMM.calls >= 2
+    assert abs(l_own - l_lib) <= 1e-5 * abs(l_lib)
+    for n in g_lib:
+        assert_close(g_own[n], g_lib[n], 1e-4, 1e-4 * float(g_lib[n].abs().max()) + 1e-7, f'grad {n}')
+    data.data._extra.pop('_device_graphs', None)
+    del run, data
+    torch.cuda.empty_cache()
+
+
+def NeighborLoader_(run, ids):
+    return _loader(run, ids)
+
+
 def test_graph_step_reproduces_eager_losses_at_full_size(full_run):
     from kgwas_amd.graph_step import GraphTrainStep
     from kgwas_amd.kgwas import KGWAS

@@ -81,15 +81,19 @@ def test_gemm3_rejects_unsupported_shapes():
         ops.gemm3_pack(torch.zeros(40, 128, device='cuda'), 40, True)
 
 
-@pytest.mark.parametrize('K', [1056, 1050])           # 1050: not a multiple of 32 -- the padded resident copy (mode='full' widths)
+@pytest.mark.parametrize('N,K', [(4128, 1056), (4128, 1050), (4131, 1056), (4131, 1050)])
+# 1050: a width that is not a multiple of 32 (mode='full': 57 742) -- zero COLUMNS in the resident copy / the packed weight;
+# 4131: a gene count that is not one (the real KG's need not be) -- zero columns in the resident X^T against zero rows of the packed dz
 @pytest.mark.parametrize('fused', [True, False])
-def test_resident_gene_layer_on_gemm3_matches_float64_autograd(fused, K):
+def test_resident_gene_layer_on_gemm3_matches_float64_autograd(fused, N, K):
     """The two autograd nodes that carry the wide resident first layer (kgwas/model.py:13,19-20 on the gene features), at a
     shape that takes the kgw_gemm3 route: forward rows, d W1 (orientation [128, K]), d b1, d W2, d b2 against float64 autograd."""
     from kgwas_amd import ops
     g = torch.Generator(device='cuda').manual_seed(21)
-    N, n = 4128, 1500                                # resident rows (a multiple of 32), rows in the batch
+    n = 1500                                         # rows in the batch
     assert ops._resident_ok(torch.empty(N, K, device='cuda'), torch.empty(128, K, device='cuda')) or not ops._GEMM3
+    ops.LIBRARY_GEMM.reset()
+    g3 = ops.ROUTES.get('kgw_gemm3', 0)
     X = torch.randn(N, K, device='cuda', generator=g)
     W1 = (torch.randn(128, K, device='cuda', generator=g) / K ** 0.5).requires_grad_()
     b1 = torch.randn(128, device='cuda', generator=g).mul_(0.1).requires_grad_()
@@ -107,6 +111,9 @@ def test_resident_gene_layer_on_gemm3_matches_float64_autograd(fused, K):
     # the fused node's contract (it runs below the layer-1 aggregate, whose backward applies the ReLU mask of its input,
     # KGW_F_RELU_INPUT): the incoming gradient is already multiplied by (h2 > 0)
     y.backward(up * (y > 0))
+    if ops._GEMM3:
+        assert ops.ROUTES.get('kgw_gemm3', 0) - g3 == 2          # forward and d W1 both on kgw_gemm3, whatever N % 32 and K % 32 are
+        assert not any(site[0].startswith('resident') or site[1][1:] == (K, 128) for site in ops.LIBRARY_GEMM.by_site)
     got = [y.detach()] + [p.grad for p in (W1, b1, W2, b2)]
     Xd = X.double()
     P = [p.detach().double().requires_grad_() for p in (W1, b1, W2, b2)]
@@ -135,3 +142,30 @@ def test_resident_copies_follow_the_matrix_not_its_address():
         assert float((got.double() - ref).abs().max()) < 1e-3 * float(ref.abs().max())
         del X, got, ref
     # (the allocator normally hands the second matrix the first one's block; the check above holds either way)
+
+
+def test_resident_copies_are_rebuilt_when_the_matrix_changes_in_place():
+    """The cache key carries the tensor's version counter: an in-place update of the feature matrix is seen by the next d W."""
+    from kgwas_amd import ops
+    N, K = 4100, 1056
+    W = torch.zeros(128, K, device='cuda')
+    dz = torch.randn(N, 128, device='cuda')
+    X = torch.randn(N, K, device='cuda')
+    a = ops.resident_first_weight_grad(dz, X, W)
+    X.mul_(2.0)
+    b = ops.resident_first_weight_grad(dz, X, W)
+    assert torch.equal(b, 2.0 * a)                  # (a power-of-two scale: exact)
+
+
+def test_gemm3_pack_pads_with_zero_rows():
+    """k_valid < K: the packed operand's rows past k_valid are zero whatever lies behind S."""
+    from kgwas_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(3)
+    M, K, kv = 300, 96, 70
+    A = torch.randn(M, K, device='cuda', generator=g)
+    big = torch.randn(K, 128, device='cuda', generator=g)            # rows >= kv hold garbage the kernel must not read as B
+    for kn in (True, False):
+        S = big[:kv] if kn else big.t().contiguous()[:, :kv]
+        C = ops.gemm3(A, ops.gemm3_pack(S, K, kn, k_valid=kv))
+        ref = A[:, :kv].double() @ big[:kv].double()
+        assert float((C.double() - ref).abs().max()) < 1e-4
