@@ -343,6 +343,8 @@ def main():
         do_step(args.warmup + i)
     sync()
     elapsed = time.perf_counter() - t_start
+    # products handed to the framework's GEMM library so far (set-up, warm-up, capture, timed steps): must be 0 on the headline
+    lib_calls, lib_sites = ops.LIBRARY_GEMM.calls, {f'{k[0]} {k[1]}': v for k, v in ops.LIBRARY_GEMM.by_site.items()}
     seeds = args.steps * (bs if shard else bs_rank)
     if gs is not None:
         st = gs.check()                       # raises if a batch overflowed the static layout
@@ -527,6 +529,10 @@ def main():
                    'seeds_per_s': seeds / elapsed,
                    'epoch_time_s_956_steps': 956 * ms / 1e3 / (1 if strong else world),
                    'epoch_measured': epoch,
+                   'library_gemm_calls': lib_calls,
+                   'library_gemm_note': ('products of set-up + warm-up + capture + the timed steps that went to hipBLASLt / rocBLAS instead of this '
+                                         'package\'s HIP kernels (kgwas_amd.ops.LIBRARY_GEMM; KGW_STRICT=1 makes any such route an error)' +
+                                         (': ' + json.dumps(lib_sites) if lib_sites else '')),
                    'arithmetic': ('fp32 operands, fp32 accumulation, fp32 results.  The two 5120-wide gene products and the 128 x 128 products '
                                   'of the SNP feature MLP (forward, first-layer backward) run on the bf16 matrix pipe from three EXACT bf16 '
                                   'pieces per fp32 operand (a = a1 + a2 + a3, six piece products kept, the dropped ones <= 3*2^-25|ab| per term: '

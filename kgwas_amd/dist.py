@@ -50,19 +50,50 @@ def allreduce_flat(flat: torch.Tensor, world: int):
         flat.div_(world)
 
 
+_LIVE = {}          # id(model) -> liveness of its requires_grad parameters, agreed over the ranks at the first reduction
+
+
 def allreduce_grads(model, world: int):
     """Average the parameter gradients over ranks: one flat bucket, one all-reduce.  The averaged gradients are
-    handed back as VIEWS of the bucket (``p.grad`` re-pointed: no copy-back launch per parameter)."""
-    params = [p for p in model.parameters() if p.grad is not None]
+    handed back as VIEWS of the bucket (``p.grad`` re-pointed: no copy-back launch per parameter).
+    The bucket covers a FIXED list -- every parameter with requires_grad, zero where this rank's backward produced no gradient (a
+    node type absent from its slice of the batch) -- so the collective has the same size on every rank; a parameter is live (keeps
+    a gradient, is stepped by Adam) if it was on ANY rank at the first reduction, else its gradient stays None as in the
+    reference (kgwas/kgwas.py:150-151 skips parameters without a gradient)."""
+    params = [p for p in model.parameters() if p.requires_grad]
     if not params:
         return
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    multi = world > 1 or (os.environ.get('KGW_FORCE_MULTIRANK_PATH') == '1' and dist.is_initialized())
+    if not multi:
+        return
+    had = [p.grad is not None for p in params]
+    live = _LIVE.get(id(model))
+    if live is None or len(live) != len(params):
+        t = torch.tensor(had, dtype=torch.int32, device=params[0].device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        live = _LIVE[id(model)] = [bool(v) for v in t.cpu().tolist()]
+    sel = [p for p, l in zip(params, live) if l]
+    if not sel:
+        return
+    flat = torch.cat([p.grad.reshape(-1) if p.grad is not None else p.new_zeros(p.numel()) for p in sel])
     allreduce_flat(flat, world)
     off = 0
-    for p in params:
+    for p in sel:
         n = p.numel()
         p.grad = flat[off:off + n].view_as(p)
         off += n
+
+
+def check_same_on_all_ranks(value: int, what: str):
+    """Raise on EVERY rank if ``value`` differs between ranks (a mismatch in a later collective's size would hang instead)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.tensor([value, -value], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if int(t[0]) != -int(t[1]):
+        raise RuntimeError(f'{what} differs between ranks (max {int(t[0])}, min {-int(t[1])}): the ranks would issue collectives of '
+                           'different sizes')
 
 
 def broadcast_params(model, src: int = 0):

@@ -78,7 +78,7 @@ class GraphTrainStep:
         # device-side statistics accumulated inside the graph: [edges layer 1..L, sampled edges, error mask]
         self.stats = torch.zeros(L + 2, dtype=torch.int64, device=dev)
         self.loss = [None, None]
-        self._unit = torch.ones((), dtype=torch.float64, device=dev)
+        self._unit = ops.unit_gradient(dev)
         self._flat = None                         # multi-rank: gradient bucket + {param: view}
         self._flat_grads = None
         self.graphs = [None, None]
@@ -213,6 +213,12 @@ class GraphTrainStep:
             err = int(b.read_meta().error)
             if err:
                 raise _lib.KgwasHipError(f'static layout does not fit the sampler buffers (error mask {err})')
+        if self.world > 1:
+            # the gradient buckets hold the parameters that received a gradient in the warm-up steps: the same set on every rank
+            # unless a node type is missing from one rank's batches -- agree before the first collective is sized by it
+            from . import dist as kdist
+            for name, b in (('first', self._flat_a), ('second', self._flat_b), ('whole', self._flat)):
+                kdist.check_same_on_all_ranks(0 if b is None else b.numel(), f'size of the {name} gradient bucket')
         with torch.no_grad():
             for p, q in zip(params, snap):
                 p.copy_(q)

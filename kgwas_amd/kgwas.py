@@ -105,7 +105,7 @@ class KGWAS:
         # forward + mean(ld_weight * (pred - y)**2) in float64 (kgwas.py:137-145); labels / weights by the seeds' ids
         loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id('SNP'), batch.dg.y['SNP'], ld_w,
                                           unit_grad=True)
-        loss.backward()
+        loss.backward(gradient=ops.unit_gradient(loss.device))      # (the resident 1.0: no ones_like fill, see readout_weighted_mse)
         if world > 1:
             kdist.allreduce_grads(self.model, world)
         optimizer.step()

@@ -1366,6 +1366,19 @@ def weighted_mse(pred, n_id, y_all, w_all):
     return _WeightedMSE.apply(pred, n_id, y_all, w_all)
 
 
+_UNIT_GRADS = {}          # device -> resident float64 1.0 (the loss gradient of a plain ``loss.backward()``)
+
+
+def unit_gradient(device) -> torch.Tensor:
+    """A resident float64 1.0 on ``device``: ``loss.backward(gradient=unit_gradient(dev))`` is ``loss.backward()`` without the
+    ones_like fill, and lets the fused read-out node recognise the gradient it precomputed for (``unit_grad=True``)."""
+    dev = torch.device(device)
+    t = _UNIT_GRADS.get(dev)
+    if t is None:
+        t = _UNIT_GRADS[dev] = torch.ones((), dtype=torch.float64, device=dev)
+    return t
+
+
 class _ReadoutWeightedMSE(torch.autograd.Function):
     """loss = mean(w[n_id] * ([relu](H[:n] @ w_lin^T + b_lin) - y[n_id])**2): the read-out Linear(128 -> 1) of the seed
     rows (kgwas/model.py:86) and the weighted MSE (kgwas/kgwas.py:139-145) as one node, two launches per step."""
@@ -1406,6 +1419,12 @@ class _ReadoutWeightedMSE(torch.autograd.Function):
         if ctx.ready is not None:
             dH, dw, db = ctx.ready
             ctx.ready = None
+            unit = _UNIT_GRADS.get(gloss.device)
+            if unit is None or gloss.data_ptr() != unit.data_ptr():
+                # the caller did NOT backpropagate the resident 1.0 (a scaled loss, gradient accumulation, plain loss.backward()
+                # with its ones_like): the precomputed gradients are for a loss gradient of 1 -- scale them
+                k = gloss.to(torch.float32)
+                dH, dw, db = dH * k, dw * k, db * k
             return dH, dw, db, None, None, None, None, None, None, None
         H, w_lin, pred, n_id, y_all, w_all = ctx.saved_tensors
         gloss = gloss.contiguous().to(torch.float64)
@@ -1423,6 +1442,8 @@ class _ReadoutWeightedMSE(torch.autograd.Function):
 def readout_weighted_mse(H, w_lin, b_lin, n_id, y_all, w_all, n: int, relu: bool = True, h_is_relu: bool = False,
                          unit_grad: bool = False):
     """Returns (loss float64 scalar, pred float32 [n]); ``w_lin`` [1,128] / ``b_lin`` [1] = HeteroGNN.lin.
-    ``h_is_relu``: see layer_transform's ``premasked``.  ``unit_grad``: the caller promises to backpropagate a loss gradient of
-    exactly 1 (``loss.backward()``): forward and backward of this node then share two launches instead of four."""
+    ``h_is_relu``: see layer_transform's ``premasked``.  ``unit_grad``: the caller expects to backpropagate a loss gradient of
+    exactly 1: forward and backward of this node then share two launches instead of four.  Passing the resident
+    ``unit_gradient(device)`` to ``backward(gradient=...)`` takes the precomputed gradients as they are; any other loss gradient
+    (``(k * loss).backward()``) multiplies them -- correct either way."""
     return _ReadoutWeightedMSE.apply(H, w_lin, b_lin, n_id, y_all, w_all, int(n), bool(relu), bool(h_is_relu), bool(unit_grad))

@@ -91,6 +91,11 @@ class ShardExchange:
         # (KGW_FORCE_MULTIRANK_PATH=1: a single rank still issues every collective -- a 1-GPU box then exercises them over RCCL)
         self.multi = self.world > 1 or (os.environ.get('KGW_FORCE_MULTIRANK_PATH') == '1' and dist.is_initialized())
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # the flat all-gather exists on RCCL ("nccl"); gloo (the CPU / one-GPU tests) takes the list form.  Decided ONCE, from
+        # the backend: a collective that fails at run time must surface as an error on every rank, not send one rank down a
+        # different collective sequence from its peers.
+        self.flat_gather = self.multi and dist.get_backend(group) == 'nccl'
+        self.collectives = {}                     # name -> [calls, bytes this rank handed to the collective]
         sc = dg.schema
         self.sharded = sc.type_id[sharded_type]
         self.dev = dg.device
@@ -121,6 +126,12 @@ class ShardExchange:
             self.slots[l] = {d: torch.tensor(sorted(v), dtype=torch.int32, device=self.dev) for d, v in by_type.items()}
         self.bytes_moved = 0
 
+    def _count(self, name: str, nbytes: int):
+        c = self.collectives.setdefault(name, [0, 0])
+        c[0] += 1
+        c[1] += int(nbytes)
+        self.bytes_moved += int(nbytes)
+
     # -- sampling ---------------------------------------------------------------------------------------------------
     def merge_frontier(self, buf: BatchBuffers):
         """Union of the ranks' PENDING flags on the replicated node types (KGW_PENDING = -2 < -1 = unsampled)."""
@@ -128,7 +139,7 @@ class ShardExchange:
             return
         for lo, hi in self.rep_runs:
             dist.all_reduce(buf.g2l[lo:hi], op=dist.ReduceOp.MIN, group=self.group)
-            self.bytes_moved += (hi - lo) * 4
+            self._count('all_reduce_min(frontier flags)', (hi - lo) * 4)
 
     # -- layer exchange ---------------------------------------------------------------------------------------------
     def seg_rows(self, batch: SampledBatch, layer: int) -> Optional[torch.Tensor]:
@@ -161,12 +172,11 @@ class ShardExchange:
         _lib.check(L.kgw_softmax_pack(_ptr(Z), _ptr(stat), _ptr(seg), n, _ptr(mine), _lib.stream_ptr()), 'kgw_softmax_pack')
         if self.multi:
             allp = torch.empty(self.world * n * PART_STRIDE, device=self.dev)
-            try:
+            if self.flat_gather:
                 dist.all_gather_into_tensor(allp, mine, group=self.group)
-            except (RuntimeError, NotImplementedError):                       # backends without the flat variant
-                chunks = list(allp.view(self.world, -1).unbind(0))
-                dist.all_gather(chunks, mine, group=self.group)
-            self.bytes_moved += allp.numel() * 4
+            else:
+                dist.all_gather(list(allp.view(self.world, -1).unbind(0)), mine, group=self.group)
+            self._count('all_gather(partial softmax states)', allp.numel() * 4)
         else:
             allp = mine
         _lib.check(L.kgw_softmax_merge(_ptr(allp), self.world, _ptr(seg), n, _ptr(Z), _ptr(stat), _lib.stream_ptr()),
@@ -183,7 +193,7 @@ class ShardExchange:
         rows = torch.empty(n, KGW_C, device=self.dev)
         _lib.check(L.kgw_gather_rows(_ptr(dZ), _ptr(seg), n, KGW_C, _ptr(rows), _lib.stream_ptr()), 'kgw_gather_rows')
         dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group)
-        self.bytes_moved += rows.numel() * 4
+        self._count('all_reduce_sum(dZ of exchanged segments)', rows.numel() * 4)
         _lib.check(L.kgw_scatter_rows(_ptr(rows), _ptr(seg), n, KGW_C, _ptr(dZ), _lib.stream_ptr()), 'kgw_scatter_rows')
         return dZ
 
@@ -229,12 +239,18 @@ class ShardedTrainer:
         self.buf = BatchBuffers(self.dg)
         ids = np.asarray(ids.cpu() if torch.is_tensor(ids) else ids, dtype=np.int64).reshape(-1)
         self.n_batches = len(ids) // self.batch_size
-        self.local_seeds = []
+        if self.hi <= self.lo:
+            raise ValueError(f'rank {self.rank} of {self.world} owns no {sharded_type} node ({int(full[sharded_type].num_nodes)} nodes)')
+        # a rank that owns no seed of a batch still takes part in every collective of the step: it expands one node it owns
+        # and its loss share is multiplied by zero (the extra hop-1 genes this adds to the merged frontier change no real
+        # seed's prediction: a seed's output depends on ITS neighbourhood only)
+        self.local_seeds, self.loss_scale = [], []
         for i in range(self.n_batches):
             b = ids[i * self.batch_size:(i + 1) * self.batch_size]
             mine = b[(b >= self.lo) & (b < self.hi)] - self.lo
+            self.loss_scale.append(len(mine) / self.batch_size)
             if len(mine) == 0:
-                raise NotImplementedError(f'batch {i}: rank {self.rank} owns none of its seeds (use larger batches or fewer ranks)')
+                mine = np.zeros(1, dtype=np.int64)
             self.local_seeds.append(torch.from_numpy(mine).to(dev))
         self.ld_w = run._ld_weight_vector()[self.lo:self.hi].contiguous()
         self.y = self.dg.y[self.input_type]
@@ -242,6 +258,7 @@ class ShardedTrainer:
         self.opt = FusedAdam(self.model.parameters(), lr=lr, weight_decay=weight_decay)
         self.use_graph = False               # (the collectives sit between kernels of a step: issued eagerly)
         self._flat = None
+        self._live = None
         self.last_loss = None
 
     def describe(self) -> str:
@@ -267,20 +284,44 @@ class ShardedTrainer:
         for p in self.model.parameters():
             p.grad = None
         loss, pred = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, n, batch.n_id(self.input_type), self.y, self.ld_w)
-        part = loss * (n / self.batch_size)                       # mean over the rank's seeds -> its share of the batch mean
+        # mean over the rank's seeds -> its share of the batch mean (0 for a rank that owns none of the batch's seeds)
+        part = loss * self.loss_scale[i % self.n_batches]
         part.backward()
         return batch, part.detach(), pred
 
     def allreduce_grads(self):
-        live = [p for p in self.model.parameters() if p.grad is not None]
-        flat = torch.cat([p.grad.reshape(-1) for p in live])
-        if self.xchg.multi:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.xchg.group)
-            self.xchg.bytes_moved += flat.numel() * 4
+        """One flat SUM all-reduce over a FIXED parameter list -- every parameter that can receive a gradient (requires_grad:
+        the structurally dead relation packs do not), zero-filled where this rank's backward produced none (a relation or
+        node type that is empty on this shard), so the collective has the same size on every rank whatever its batch held.
+        Parameters whose gradient is None on EVERY rank of every step (an MLP no live relation touches) cost a few zeros."""
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        if self._flat is None:
+            self._flat = torch.empty(sum(p.numel() for p in params), device=self.dev)
+        flat = self._flat
         off = 0
-        for p in live:
+        had = []
+        for p in params:
             n = p.numel()
-            p.grad = flat[off:off + n].view_as(p)
+            had.append(p.grad is not None)
+            if p.grad is None:
+                flat[off:off + n].zero_()
+            else:
+                flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        if self.xchg.multi:
+            # which parameters are live is structural (the same relations / MLPs reach the read-out on every rank) except for
+            # a node type or relation that happens to be empty on one shard: live = live on ANY rank, agreed once (first step)
+            if self._live is None:
+                live = torch.tensor(had, dtype=torch.int32, device=self.dev)
+                dist.all_reduce(live, op=dist.ReduceOp.MAX, group=self.xchg.group)
+                self._live = [bool(v) for v in live.cpu().tolist()]
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.xchg.group)
+            self.xchg._count('all_reduce_sum(parameter gradients)', flat.numel() * 4)
+            had = self._live
+        off = 0
+        for p, h in zip(params, had):
+            n = p.numel()
+            p.grad = flat[off:off + n].view_as(p) if h else None      # (None: Adam skips it, like the reference's unused parameters)
             off += n
 
     def _count_edges(self, batch: SampledBatch):
@@ -338,7 +379,10 @@ class ShardedTrainer:
             sample_sharded(self.dg, self.buf, seeds, self.seed_type, self.xchg)
             torch.cuda.current_stream().wait_event(self.buf.ready)
             self.buf.ready.synchronize()
-            batch = SampledBatch(self.dg, self.buf, self.buf.read_meta(), self.input_type, int(seeds.numel()))
+            meta = self.buf.read_meta()
+            if meta.error:
+                raise _lib.KgwasHipError(f'sampler capacity exceeded (error mask {meta.error})')
+            batch = SampledBatch(self.dg, self.buf, meta, self.input_type, int(seeds.numel()))
             batch.exchange = self.xchg
             p = self.model(batch.x_dict, batch.edge_index_dict, int(seeds.numel())).reshape(-1)
             if len(sel):

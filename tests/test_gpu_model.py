@@ -378,6 +378,18 @@ def test_fused_readout_loss_equals_forward_plus_loss(small_kg, no_relu):
     assert torch.equal(loss3, loss) and torch.equal(pred3, pred) and set(g3) == set(g1)
     for n in g1:
         assert torch.equal(g3[n], g1[n]), n
+    # ... and a caller that scales the loss anyway (gradient accumulation, loss * k) gets the scaled gradients, not those of k = 1
+    from kgwas_amd import ops
+    for scale, how in ((4.0, 'scaled'), (1.0, 'resident unit')):
+        model.zero_grad(set_to_none=True)
+        loss4, _ = model.forward_loss(batch.x_dict, batch.edge_index_dict, 96, batch.n_id('SNP'), y_all, w_all, unit_grad=True)
+        if how == 'scaled':
+            (loss4 * scale).backward()
+        else:
+            loss4.backward(gradient=ops.unit_gradient(loss4.device))
+        g4 = {n: t for n, t in grads_by_name(model).items() if t is not None}
+        for n in g1:
+            assert torch.equal(g4[n], scale * g1[n]), (how, n)
 
 
 @pytest.mark.parametrize('which', ['small', 'edge'])

@@ -242,3 +242,144 @@ def test_kgwas_train_in_sharded_mode_matches_single_process_training(tmp_path, m
     assert abs(float(r0['val']['mse']) - float(run.val_metrics['mse'])) < 1e-3 * float(run.val_metrics['mse'])
     assert abs(float(r0['test']['mse']) - float(run.test_metrics['mse'])) < 1e-3 * float(run.test_metrics['mse'])
     assert np.allclose(r0['pred'], ref, rtol=2e-3, atol=2e-4)
+
+
+def _golden_run():
+    """The committed tiny case (tests/golden/gat_case.py) as a KGWAS run: its graph, its fixed parameters, its LD weights."""
+    from collections import OrderedDict
+    from kgwas_amd.kgwas import KGWAS
+    from kgwas_amd.kgwas_data import KGWAS_Data
+    from tests.golden import gat_case as gc
+    from tests.golden_io import case_graph
+    g, w_all = case_graph()
+    data = KGWAS_Data(f'/tmp/kgwas_gpushard_golden_{os.getpid()}')
+    data.data = g
+    data.snp_init_dim_size, data.gene_init_dim_size, data.go_init_dim_size = gc.DIMS['SNP'], gc.DIMS['Gene'], gc.DIMS['GO']
+    data.all_ids = np.arange(gc.NODES['SNP'])
+    data.ldsc_weight = w_all.numpy()
+    data.train_input_nodes = ('SNP', gc.SEEDS.copy())
+    run = KGWAS(data, device='cuda:0', seed=1)
+    run.initialize_model()
+    sd = OrderedDict((k, torch.from_numpy(v)) for k, v in gc.parameters(list(g.edge_types)).items())
+    run.model.load_state_dict(sd, strict=True)
+    return data, run
+
+
+def _golden_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from kgwas_amd.shard import ShardedTrainer
+        from tests.golden import gat_case as gc
+        data, run = _golden_run()
+        run.model.train()
+        st = ShardedTrainer(run, ('SNP', gc.SEEDS.copy()), gc.BATCH, lr=1e-3, weight_decay=5e-4)
+        batch, part, pred = st.forward_backward(0)
+        own = (batch.n_id('SNP')[:batch.batch_size].long() + st.lo).cpu()
+        real = st.loss_scale[0] > 0
+        st.allreduce_grads()
+        grads = {k: (None if v is None else v.detach().cpu().clone()) for k, v in run.model.named_reference_tensors(grad=True).items()}
+        torch.save({'own': own if real else own[:0], 'pred': pred.detach().cpu() if real else pred.detach().cpu()[:0], 'part': part.cpu(),
+                    'grads': grads, 'collectives': dict(st.xchg.collectives)}, os.path.join(out_dir, f'gold{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_sharded_mode_reproduces_the_committed_golden_vectors(tmp_path, world):
+    """The SNP-sharded HIP path held to tests/golden/gat_small.npz directly (not to another mode of the same build): every rank's
+    predictions of the seeds it owns, the sum of the loss shares, and the all-reduced gradient of every parameter.  With 4 ranks
+    over 400 SNPs one rank owns seeds on one side of the hub gene only and the partial softmax states of three relations
+    (hub row of 300 in-edges split over the ranks, an empty relation, duplicate edges) are merged."""
+    from tests.golden import gat_case as gc
+    from tests.golden_io import golden
+    port = _free_port()
+    mp.start_processes(_golden_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method='spawn')
+    recs = [torch.load(os.path.join(tmp_path, f'gold{r}.pt'), weights_only=False) for r in range(world)]
+    G = golden()
+    pos = {int(s): k for k, s in enumerate(gc.SEEDS)}
+    seen = []
+    for r in recs:
+        idx = [pos[int(s)] for s in r['own']]
+        seen += idx
+        want = torch.from_numpy(G['pred'])[idx]
+        assert torch.allclose(r['pred'].double(), want, rtol=1e-4, atol=1e-5), (r['pred'], want)
+    assert sorted(seen) == list(range(gc.BATCH))
+    total = sum(float(r['part']) for r in recs)
+    assert abs(total - float(G['loss'])) <= 1e-5 * abs(float(G['loss'])) + 1e-7
+    none = set(G['grad_none'].tolist())
+    stride = int(G['grad_stride'])
+    n = 0
+    for r in recs:                                   # after the all-reduce every rank holds the full-batch gradient
+        for name, g in r['grads'].items():
+            if name in none or g is None:
+                assert g is None or float(g.abs().max()) == 0.0 or name not in none, name
+                continue
+            g = g.double().numpy()
+            if f'g_{name}' in G.files:
+                ref = G[f'g_{name}']
+                assert np.allclose(g.reshape(ref.shape), ref, rtol=1e-4, atol=2e-4 * max(np.abs(ref).max(), 1e-6) + 1e-7), name
+            elif f'gs_{name}' in G.files:
+                ref = G[f'gs_{name}']
+                assert np.allclose(g.reshape(-1)[::stride], ref, rtol=1e-4, atol=2e-4 * max(np.abs(ref).max(), 1e-6) + 1e-7), name
+            else:
+                continue
+            n += 1
+    assert n > 60 * world
+    assert any('all_gather' in k for k in recs[0]['collectives']) and any('gradients' in k for k in recs[0]['collectives'])
+
+
+def _noseed_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from kgwas_amd.shard import ShardedTrainer
+        from tests.golden import gat_case as gc
+        data, run = _golden_run()
+        run.model.train()
+        seeds = gc.SEEDS[gc.SEEDS < 200].copy()                 # every seed belongs to rank 0 of 2
+        st = ShardedTrainer(run, ('SNP', seeds), len(seeds), lr=1e-3, weight_decay=5e-4)
+        assert st.loss_scale[0] == (1.0 if rank == 0 else 0.0)
+        batch, part, pred = st.forward_backward(0)
+        st.allreduce_grads()
+        grads = {k: (None if v is None else v.detach().cpu().clone()) for k, v in run.model.named_reference_tensors(grad=True).items()}
+        st.opt.step()
+        torch.save({'part': part.cpu(), 'pred': pred.detach().cpu(), 'grads': grads,
+                    'params': {k: v.detach().cpu() for k, v in run.model.named_reference_tensors().items()},
+                    'pred_all': st.predict(seeds).cpu()}, os.path.join(out_dir, f'ns{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_that_owns_no_seed_of_a_batch_still_takes_part(tmp_path):
+    """A batch whose seeds all lie in rank 0's id range: rank 1 expands a node of its own with loss weight 0, joins every
+    collective, contributes its SNP-side partial softmax states -- and the step equals the single-process step."""
+    from kgwas_amd.sampler import NeighborLoader
+    from tests.golden import gat_case as gc
+    port = _free_port()
+    mp.start_processes(_noseed_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method='spawn')
+    r0, r1 = (torch.load(os.path.join(tmp_path, f'ns{r}.pt'), weights_only=False) for r in range(2))
+    data, run = _golden_run()
+    run.model.train()
+    seeds = gc.SEEDS[gc.SEEDS < 200].copy()
+    n = len(seeds)
+    batch = next(iter(NeighborLoader(data.data, [-1, -1], ('SNP', seeds), batch_size=n, device='cuda:0')))
+    loss, pred = run.model.forward_loss(batch.x_dict, batch.edge_index_dict, n, batch.n_id('SNP'), batch.dg.y['SNP'], run._ld_weight_vector())
+    loss.backward()
+    assert float(r1['part']) == 0.0 and abs(float(r0['part']) - float(loss)) <= 1e-5 * abs(float(loss))
+    assert torch.allclose(r0['pred'].double(), pred.detach().cpu().double(), rtol=1e-4, atol=1e-5)
+    ref = run.model.named_reference_tensors(grad=True)
+    for k, g in ref.items():
+        if g is None:
+            continue
+        g = g.detach().cpu().double()
+        for r in (r0, r1):
+            assert r['grads'][k] is not None, k
+            assert float((r['grads'][k].double() - g).abs().max()) <= 2e-4 * float(g.abs().max()) + 1e-6, k
+    for k in r0['params']:
+        assert torch.equal(r0['params'][k], r1['params'][k]), k
+    assert torch.equal(r0['pred_all'], r1['pred_all']) and r0['pred_all'].shape == (n,)
