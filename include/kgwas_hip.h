@@ -124,8 +124,8 @@ typedef struct KgwBatchBuf {
     int32_t* t_zrow[KGW_MAX_LAYERS];  /* [edge_cap] Z row (dst row * R_dst + slot) of the entry */
     uint8_t* t_rel[KGW_MAX_LAYERS];   /* [edge_cap] relation id of the entry (optional: NULL = not written)  */
     int32_t* scan_tmp;     /* [2 * (max(seg_cap, node_cap, trow_cap) / KGW_TILE + 2)]          */
-    int32_t* t_tmp;        /* [4 * edge_cap], 16-B aligned: unsorted (edge, Z row, src-major row, relation) entries: the atomic cursor
-                              fill lands here, a rank pass writes them in ascending edge order         */
+    int32_t* t_tmp;        /* [8 * edge_cap], 16-B aligned: unsorted (edge, Z row, src-major row, relation) entries of up to TWO layers (the
+                              second behind the first): the atomic cursor fill lands here, a rank pass writes them in ascending edge order */
     KgwBatchMeta* meta;    /* device                                                           */
     KgwBatchMeta* meta_host; /* pinned host mirror (async D2H at the end of sampling)          */
     int64_t seg_cap, edge_cap, chunk_cap, multi_cap, trow_cap, scan_cap;

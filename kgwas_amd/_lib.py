@@ -14,7 +14,7 @@ KGW_C = 128
 PART_STRIDE = 132
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libkgwas_hip.so')
+LIB_PATH = os.environ.get('KGW_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libkgwas_hip.so')     # (override: A/B runs of two builds)
 
 
 class KgwGraph(C.Structure):

@@ -106,39 +106,101 @@ __global__ void __launch_bounds__(KGW_BLK) k_init(SampArgs A, const int64_t* see
 }
 
 // ---- per hop: segment bookkeeping --------------------------------------------------------------
-__global__ void k_hop_begin(SampArgs A, int h) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// Segment offsets of hop h (a prefix over <= 64 relations) are recomputed by EVERY block into LDS -- scalar work of a
+// microsecond -- instead of by a one-thread launch of their own; block 0 also publishes them (KgwBatchMeta.seg_off / seg_end /
+// cur) for the kernels that follow.
+__device__ __forceinline__ void hop_offsets(const SampArgs& A, int h, int* s_off, int* s_cur, bool publish) {
     const KgwGraph& G = A.G;
     KgwBatchMeta* M = A.B.meta;
     int s = (h == 0) ? 0 : M->seg_end[h - 1];
     const int begin = s;
     for (int r = 0; r < G.n_rels; ++r) {
-        M->seg_off[h][r] = s;
+        s_off[r] = s;
         s += M->hop_cnt[G.rel_dst[r]][h];
     }
-    M->seg_off[h][G.n_rels] = s;
-    M->seg_end[h] = s;
-    if ((int64_t)s > A.B.seg_cap) { M->error |= 1; s = begin; }   // empty range: nothing runs past capacity
-    M->cur[0] = begin;   // scan range [cur0, cur1)
-    M->cur[1] = s;
-    M->cur[2] = (h == 0) ? 0 : M->edge_end[h - 1];    // carry-in for seg_ptr
-    M->cur[3] = (h == 0) ? 0 : M->chunk_end[h - 1];   // carry-in for seg_chptr
+    s_off[G.n_rels] = s;
+    const bool over = (int64_t)s > A.B.seg_cap;
+    if (publish) {
+        for (int r = 0; r <= G.n_rels; ++r) M->seg_off[h][r] = s_off[r];
+        M->seg_end[h] = s;
+        if (over) M->error |= 1;
+    }
+    if (over) s = begin;                              // empty range: nothing runs past capacity
+    s_cur[0] = begin; s_cur[1] = s;
+    if (publish) {
+        M->cur[0] = begin;   // scan range [cur0, cur1)
+        M->cur[1] = s;
+        M->cur[2] = (h == 0) ? 0 : M->edge_end[h - 1];    // carry-in for seg_ptr
+        M->cur[3] = (h == 0) ? 0 : M->chunk_end[h - 1];   // carry-in for seg_chptr
+    }
 }
 
 __global__ void __launch_bounds__(KGW_BLK) k_seg_deg(SampArgs A, int h) {
+    __shared__ int s_off[KGW_MAX_RELS + 1], s_cur[2];
     const KgwGraph& G = A.G;
     const KgwBatchMeta* M = A.B.meta;
-    const int begin = M->cur[0], end = M->cur[1];
-    if ((int64_t)end > A.B.seg_cap) return;
+    if (threadIdx.x == 0) hop_offsets(A, h, s_off, s_cur, blockIdx.x == 0);
+    __syncthreads();
+    const int begin = s_cur[0], end = s_cur[1];
     for (int sg = begin + blockIdx.x * KGW_BLK + threadIdx.x; sg < end; sg += gridDim.x * KGW_BLK) {
-        int r = find_rel(M->seg_off[h], G.n_rels, sg);
+        int r = find_rel(s_off, G.n_rels, sg);
         int d = G.rel_dst[r];
-        int li = M->node_off[d][h] + (sg - M->seg_off[h][r]);
+        int li = M->node_off[d][h] + (sg - s_off[r]);
         int g = A.B.n_id[G.node_base[d] + li];
         const int32_t* rp = G.g_rowptr + G.rowptr_off[r];
         int deg = rp[g + 1] - rp[g];
         A.B.seg_deg[sg] = deg;
         A.B.seg_nch[sg] = (deg + KGW_CHUNK - 1) / KGW_CHUNK;
+    }
+}
+
+// ---- ONE-block exclusive scan of a device-side range (the segments of a minibatch hop: a few 10 k entries) ------------
+// Replaces the three launches of the tiled scan below where the range is small: 1024 threads walk the range in tiles of 4096,
+// one int4 per thread (coalesced), scan inside the thread, the wavefront (shuffles) and across the 16 wavefronts (LDS), carry
+// from tile to tile.  K arrays together; carries in cur[2 + k], totals out to cur[4 + k] and the end sentinels.
+template <int K>
+__global__ void __launch_bounds__(1024) k_scan_block(const int32_t* in0, const int32_t* in1, int32_t* out0, int32_t* out1,
+                                                     KgwBatchMeta* M, int use_carry) {
+    __shared__ int s_w[16], s_tot;
+    const int begin = M->cur[0], end = M->cur[1];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int k = 0; k < K; ++k) {
+        const int32_t* in = k ? in1 : in0;
+        int32_t* out = k ? out1 : out0;
+        int carry = use_carry ? M->cur[2 + k] : 0;
+        for (int base = begin; base < end; base += 4096) {
+            const int i = base + 4 * tid;
+            int v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (i + j < end) ? in[i + j] : 0;
+            const int mine = v[0] + v[1] + v[2] + v[3];
+            int incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d, 64);
+                incl += lane >= d ? o : 0;
+            }
+            __syncthreads();                       // (s_w / s_tot of the previous tile are read)
+            if (lane == 63) s_w[wv] = incl;
+            __syncthreads();
+            if (tid < 64) {
+                const int w = tid < 16 ? s_w[tid] : 0;
+                int wi = w;
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) {
+                    const int o = __shfl_up(wi, d, 64);
+                    wi += tid >= d ? o : 0;
+                }
+                if (tid < 16) s_w[tid] = wi - w;   // exclusive prefix of the wavefront sums
+                if (tid == 15) s_tot = wi;
+            }
+            __syncthreads();
+            int ex = carry + s_w[wv] + incl - mine;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { if (i + j < end) out[i + j] = ex; ex += v[j]; }
+            carry += s_tot;
+        }
+        if (tid == 0) { M->cur[4 + k] = carry; out[end] = carry; }
     }
 }
 
@@ -212,26 +274,34 @@ __global__ void __launch_bounds__(KGW_BLK) k_scan_apply(const int32_t* in0, cons
     }
 }
 
-__global__ void k_hop_mid(SampArgs A, int h) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    KgwBatchMeta* M = A.B.meta;
-    M->edge_end[h] = M->cur[4];
-    M->chunk_end[h] = M->cur[5];
-    if ((int64_t)M->cur[4] > A.B.edge_cap) M->error |= 2;
-    if ((int64_t)M->cur[5] > A.B.chunk_cap) M->error |= 4;
-}
-
+// (the bookkeeping of the finished scans -- edge_end / chunk_end of the hop, capacity checks -- rides in this launch: every
+//  block evaluates the checks for itself, block 0 publishes)
 __global__ void __launch_bounds__(KGW_BLK) k_fill_chunks(SampArgs A, int h) {
+    __shared__ int s_off[KGW_MAX_RELS + 1], s_err;
     const KgwGraph& G = A.G;
     KgwBatchMeta* M = A.B.meta;
-    if (M->error) return;
+    if (threadIdx.x == 0) {
+        const int e4 = M->cur[4], e5 = M->cur[5];
+        int err = M->error;
+        if ((int64_t)e4 > A.B.edge_cap) err |= 2;
+        if ((int64_t)e5 > A.B.chunk_cap) err |= 4;
+        s_err = err;
+        if (blockIdx.x == 0) {
+            M->edge_end[h] = e4;
+            M->chunk_end[h] = e5;
+            if (err != M->error) atomicOr(&M->error, err);
+        }
+        for (int r = 0; r <= G.n_rels; ++r) s_off[r] = M->seg_off[h][r];
+    }
+    __syncthreads();
+    if (s_err) return;
     const int begin = M->cur[0], end = M->cur[1];
     for (int sg = begin + blockIdx.x * KGW_BLK + threadIdx.x; sg < end; sg += gridDim.x * KGW_BLK) {
         const int nch = A.B.seg_nch[sg];
         if (nch == 0) continue;
-        const int r = find_rel(M->seg_off[h], G.n_rels, sg);
+        const int r = find_rel(s_off, G.n_rels, sg);
         const int d = G.rel_dst[r];
-        const int li = M->node_off[d][h] + (sg - M->seg_off[h][r]);
+        const int li = M->node_off[d][h] + (sg - s_off[r]);
         const int g = A.B.n_id[G.node_base[d] + li];
         const int32_t* rp = G.g_rowptr + G.rowptr_off[r];
         int64_t gpos = G.col_off[r] + rp[g];
@@ -254,7 +324,7 @@ __global__ void __launch_bounds__(KGW_BLK) k_fill_chunks(SampArgs A, int h) {
                 int32_t* mm = A.B.multi + ((int64_t)h * A.B.multi_cap + idx) * 4;
                 mm[0] = c0; mm[1] = nch; mm[2] = li; mm[3] = r;
             } else {
-                M->error |= 8;
+                atomicOr(&M->error, 8);
             }
         }
     }
@@ -330,20 +400,17 @@ __global__ void __launch_bounds__(KGW_BLK) k_assign(SampArgs A, const int32_t* t
     }
 }
 
-__global__ void k_hop_end(SampArgs A, const int32_t* tile_pref, int h) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// (block 0 also closes the hop: node counts of hop h + 1 from the compaction's tile prefix -- k_hop_end's one-thread launch)
+__global__ void __launch_bounds__(KGW_BLK) k_relabel(SampArgs A, const int32_t* tile_pref, int h) {
     const KgwGraph& G = A.G;
     KgwBatchMeta* M = A.B.meta;
-    for (int t = 0; t < G.n_types; ++t) {
-        int c = tile_pref[G.node_base[t + 1] / KGW_TILE] - tile_pref[G.node_base[t] / KGW_TILE];
-        M->hop_cnt[t][h + 1] = c;
-        M->node_off[t][h + 2] = M->node_off[t][h + 1] + c;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int t = 0; t < G.n_types; ++t) {
+            int c = tile_pref[G.node_base[t + 1] / KGW_TILE] - tile_pref[G.node_base[t] / KGW_TILE];
+            M->hop_cnt[t][h + 1] = c;
+            M->node_off[t][h + 2] = M->node_off[t][h + 1] + c;
+        }
     }
-}
-
-__global__ void __launch_bounds__(KGW_BLK) k_relabel(SampArgs A, int h) {
-    const KgwGraph& G = A.G;
-    const KgwBatchMeta* M = A.B.meta;
     if (M->error) return;
     const int cb = (h == 0) ? 0 : M->chunk_end[h - 1], ce = M->chunk_end[h];
     const int lane = kgw_lane();
@@ -417,44 +484,52 @@ __global__ void __launch_bounds__(64) k_layer_tables(SampArgs A) {
     }
 }
 
-// ---- src-major (transposed) structure of one layer ------------------------------------------------
-__global__ void k_t_begin(SampArgs A, int l) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    KgwBatchMeta* M = A.B.meta;
-    M->cur[0] = 0;
-    M->cur[1] = M->error ? 0 : M->t_base[l - 1][A.G.n_types];
-    M->cur[5] = 0;                                   // length of k_t_rank's work list of long rows
-}
+// ---- src-major (transposed) structures: up to TWO layers per launch ------------------------------------------------------
+// (layers l0 and l0 + 1: every kernel below loops over the pair, so the default 2-layer model builds both structures with
+//  one set of launches; KgwBatchMeta.cur: [0, 1] = scan range, [4 + k] = entries of layer l0 + k after the scan,
+//  [6 + k] = length of that layer's work list of long rows; layer l0 + 1 stages behind layer l0 in t_tmp)
 
 // One wavefront per chunk (chunks of the benchmark graph average ~100 edges: the lanes are busy; a
 // lane-per-chunk variant measured 2-4x slower because only n_chunks/64 wavefronts had work).
 template <bool FILL>
-__global__ void __launch_bounds__(KGW_BLK) k_t_pass(SampArgs A, int l) {
+__global__ void __launch_bounds__(KGW_BLK) k_t_pass(SampArgs A, int l0, int nl) {
     const KgwGraph& G = A.G;
-    const KgwBatchMeta* M = A.B.meta;
+    KgwBatchMeta* M = A.B.meta;
+    if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) {
+        // (k_t_begin's one-thread launch: the range of the histogram scan that follows, empty work lists)
+        int range = 0;
+        for (int k = 0; k < nl; ++k) range = max(range, M->t_base[l0 + k - 1][G.n_types]);
+        M->cur[0] = 0;
+        M->cur[1] = M->error ? 0 : range;
+        M->cur[6] = 0; M->cur[7] = 0;
+    }
     if (M->error) return;
-    const int nc = M->n_chunks[l - 1];
     const int lane = kgw_lane();
-    int32_t* cnt = A.B.t_cnt[l - 1];
-    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < nc; c += gridDim.x * 4) {
-        const KgwChunk ck = A.B.chunks[c];
-        const int r = ck.rel;
-        if (!G.rel_live[l - 1][r]) continue;
-        const int s = G.rel_src[r], d = G.rel_dst[r];
-        const int tb = M->t_base[l - 1][s] + G.rel_slot_src[r];
-        const int Rs = G.R_src[s];
-        const int zrow = M->z_base[l - 1][d] + ck.row * G.R_dst[d] + G.rel_slot_dst[r];
-        const int n = ck.e1 - ck.e0;
-        for (int t = lane; t < n; t += 64) {
-            const int e = ck.e0 + t;
-            const int trow = tb + A.B.col_local[e] * Rs;
-            if (!FILL) {
-                atomicAdd(&cnt[trow], 1);
-            } else {
-                // position inside the row in ARRIVAL order (atomic cursor): staged, then k_t_rank puts the row in
-                // ascending edge order so that the backward's summation order is the same run to run
-                const int pos = A.B.t_ptr[l - 1][trow] + atomicSub(&cnt[trow], 1) - 1;
-                ((int4*)A.B.t_tmp)[pos] = make_int4(e, zrow, trow, r);
+    for (int k = 0; k < nl; ++k) {
+        const int l = l0 + k;
+        const int nc = M->n_chunks[l - 1];
+        int32_t* cnt = A.B.t_cnt[l - 1];
+        const int stage0 = (FILL && k) ? M->cur[4] : 0;          // layer l0 + 1 stages behind layer l0's entries
+        for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < nc; c += gridDim.x * 4) {
+            const KgwChunk ck = A.B.chunks[c];
+            const int r = ck.rel;
+            if (!G.rel_live[l - 1][r]) continue;
+            const int s = G.rel_src[r], d = G.rel_dst[r];
+            const int tb = M->t_base[l - 1][s] + G.rel_slot_src[r];
+            const int Rs = G.R_src[s];
+            const int zrow = M->z_base[l - 1][d] + ck.row * G.R_dst[d] + G.rel_slot_dst[r];
+            const int n = ck.e1 - ck.e0;
+            for (int t = lane; t < n; t += 64) {
+                const int e = ck.e0 + t;
+                const int trow = tb + A.B.col_local[e] * Rs;
+                if (!FILL) {
+                    atomicAdd(&cnt[trow], 1);
+                } else {
+                    // position inside the row in ARRIVAL order (atomic cursor): staged, then k_t_rank puts the row in
+                    // ascending edge order so that the backward's summation order is the same run to run
+                    const int pos = stage0 + A.B.t_ptr[l - 1][trow] + atomicSub(&cnt[trow], 1) - 1;
+                    ((int4*)A.B.t_tmp)[pos] = make_int4(e, zrow, trow, r);
+                }
             }
         }
     }
@@ -470,62 +545,68 @@ __global__ void __launch_bounds__(KGW_BLK) k_t_pass(SampArgs A, int l) {
 // On the benchmark graph 99 % of the rows have <= 40 entries but the 0.1 % above 64 hold most of sum(n^2).
 constexpr int T_BIG = 64, T_LDS = 4096;
 
-__global__ void __launch_bounds__(KGW_BLK) k_t_rank(SampArgs A, int l) {
+__global__ void __launch_bounds__(KGW_BLK) k_t_rank(SampArgs A, int l0, int nl) {
     KgwBatchMeta* M = A.B.meta;
     if (M->error) return;
-    const int n = M->cur[4];                       // entries of this layer (total of the histogram scan)
-    const int4* tmp = (const int4*)A.B.t_tmp;
-    const int32_t* tp = A.B.t_ptr[l - 1];
-    int32_t* big = A.B.t_cnt[l - 1];               // histogram scratch is free again: work list of long rows
-    for (int p = blockIdx.x * KGW_BLK + threadIdx.x; p < n; p += gridDim.x * KGW_BLK) {
-        const int4 me = tmp[p];
-        const int e = me.x, trow = me.z;
-        const int s0 = tp[trow], s1 = tp[trow + 1];
-        if (s1 - s0 > T_BIG) {
-            if (p == s0) big[atomicAdd(&M->cur[5], 1)] = trow;
-            continue;
+    for (int k = 0; k < nl; ++k) {
+        const int l = l0 + k;
+        const int n = M->cur[4 + k];                   // entries of this layer (total of the histogram scan)
+        const int4* tmp = (const int4*)A.B.t_tmp + (k ? M->cur[4] : 0);
+        const int32_t* tp = A.B.t_ptr[l - 1];
+        int32_t* big = A.B.t_cnt[l - 1];               // histogram scratch is free again: work list of long rows
+        for (int p = blockIdx.x * KGW_BLK + threadIdx.x; p < n; p += gridDim.x * KGW_BLK) {
+            const int4 me = tmp[p];
+            const int e = me.x, trow = me.z;
+            const int s0 = tp[trow], s1 = tp[trow + 1];
+            if (s1 - s0 > T_BIG) {
+                if (p == s0) big[atomicAdd(&M->cur[6 + k], 1)] = trow;
+                continue;
+            }
+            int rank = 0;
+            if (s1 - s0 > 1)
+                for (int q = s0; q < s1; ++q) rank += (tmp[q].x < e) ? 1 : 0;
+            A.B.t_edge[l - 1][s0 + rank] = e;
+            A.B.t_zrow[l - 1][s0 + rank] = me.y;
+            if (A.B.t_rel[l - 1]) A.B.t_rel[l - 1][s0 + rank] = (uint8_t)me.w;
         }
-        int rank = 0;
-        if (s1 - s0 > 1)
-            for (int q = s0; q < s1; ++q) rank += (tmp[q].x < e) ? 1 : 0;
-        A.B.t_edge[l - 1][s0 + rank] = e;
-        A.B.t_zrow[l - 1][s0 + rank] = me.y;
-        if (A.B.t_rel[l - 1]) A.B.t_rel[l - 1][s0 + rank] = (uint8_t)me.w;
     }
 }
 
-__global__ void __launch_bounds__(KGW_BLK) k_t_rank_big(SampArgs A, int l) {
+__global__ void __launch_bounds__(KGW_BLK) k_t_rank_big(SampArgs A, int l0, int nl) {
     __shared__ __attribute__((aligned(16))) int keys[T_LDS];
     const KgwBatchMeta* M = A.B.meta;
     if (M->error) return;
-    const int nbig = M->cur[5];
-    const int4* tmp = (const int4*)A.B.t_tmp;
-    const int32_t* tp = A.B.t_ptr[l - 1];
-    const int32_t* big = A.B.t_cnt[l - 1];
-    for (int b = blockIdx.x; b < nbig; b += gridDim.x) {
-        const int trow = big[b];
-        const int s0 = tp[trow], len = tp[trow + 1] - s0;
-        const bool in_lds = len <= T_LDS;
-        const int len4 = (len + 3) & ~3;
-        __syncthreads();
-        if (in_lds)
-            for (int i = threadIdx.x; i < len4; i += KGW_BLK) keys[i] = (i < len) ? tmp[s0 + i].x : 0x7fffffff;
-        __syncthreads();
-        for (int i = threadIdx.x; i < len; i += KGW_BLK) {
-            const int4 me = tmp[s0 + i];
-            int rank = 0;
-            if (in_lds) {
+    for (int k = 0; k < nl; ++k) {
+        const int l = l0 + k;
+        const int nbig = M->cur[6 + k];
+        const int4* tmp = (const int4*)A.B.t_tmp + (k ? M->cur[4] : 0);
+        const int32_t* tp = A.B.t_ptr[l - 1];
+        const int32_t* big = A.B.t_cnt[l - 1];
+        for (int b = blockIdx.x; b < nbig; b += gridDim.x) {
+            const int trow = big[b];
+            const int s0 = tp[trow], len = tp[trow + 1] - s0;
+            const bool in_lds = len <= T_LDS;
+            const int len4 = (len + 3) & ~3;
+            __syncthreads();
+            if (in_lds)
+                for (int i = threadIdx.x; i < len4; i += KGW_BLK) keys[i] = (i < len) ? tmp[s0 + i].x : 0x7fffffff;
+            __syncthreads();
+            for (int i = threadIdx.x; i < len; i += KGW_BLK) {
+                const int4 me = tmp[s0 + i];
+                int rank = 0;
+                if (in_lds) {
 #pragma unroll 4
-                for (int q = 0; q < len4; q += 4) {
-                    const int4 k4 = *(const int4*)(keys + q);
-                    rank += (k4.x < me.x) + (k4.y < me.x) + (k4.z < me.x) + (k4.w < me.x);
+                    for (int q = 0; q < len4; q += 4) {
+                        const int4 k4 = *(const int4*)(keys + q);
+                        rank += (k4.x < me.x) + (k4.y < me.x) + (k4.z < me.x) + (k4.w < me.x);
+                    }
+                } else {
+                    for (int q = 0; q < len; ++q) rank += (tmp[s0 + q].x < me.x) ? 1 : 0;
                 }
-            } else {
-                for (int q = 0; q < len; ++q) rank += (tmp[s0 + q].x < me.x) ? 1 : 0;
+                A.B.t_edge[l - 1][s0 + rank] = me.x;
+                A.B.t_zrow[l - 1][s0 + rank] = me.y;
+                if (A.B.t_rel[l - 1]) A.B.t_rel[l - 1][s0 + rank] = (uint8_t)me.w;
             }
-            A.B.t_edge[l - 1][s0 + rank] = me.x;
-            A.B.t_zrow[l - 1][s0 + rank] = me.y;
-            if (A.B.t_rel[l - 1]) A.B.t_rel[l - 1][s0 + rank] = (uint8_t)me.w;
         }
     }
 }
@@ -534,32 +615,47 @@ __global__ void __launch_bounds__(KGW_BLK) k_t_rank_big(SampArgs A, int l) {
 // per group of 8 consecutive source rows of the layer input ("octet", row index / 8) for the backward's src-major pass
 // (kgw_gat_aggregate_bwd_src, KgwLayerArgs.oct_flags): 1 = eight real rows of ONE node type of KgwGraph.short_types, none
 // of them a destination row of the layer, each with at most 8 entries over all its relation slots.
-__global__ void __launch_bounds__(KGW_BLK) k_t_end(SampArgs A, int l) {
+__global__ void __launch_bounds__(KGW_BLK) k_t_end(SampArgs A, int l0, int nl) {
     const KgwGraph& G = A.G;
     KgwBatchMeta* M = A.B.meta;
-    if (blockIdx.x == 0 && threadIdx.x == 0) M->t_entries[l - 1] = M->cur[4];
     const int NT = G.n_types;
-    const int n_oct = M->error ? 0 : (M->src_base[l - 1][NT] + 7) >> 3;
-    const int32_t* tp = A.B.t_ptr[l - 1];
-    int32_t* out = A.B.t_cnt[l - 1];
-    for (int o = blockIdx.x * KGW_BLK + threadIdx.x; o < n_oct; o += gridDim.x * KGW_BLK) {
-        const int u0 = 8 * o;
-        int ty = 0;
-        while (ty + 1 < NT && u0 >= M->src_base[l - 1][ty + 1]) ++ty;
-        const int j0 = u0 - M->src_base[l - 1][ty];
-        int ok = ((G.short_types >> ty) & 1u) && j0 + 8 <= M->n_src[l - 1][ty] &&
-                 !(G.R_dst[ty] > 0 && j0 < M->n_rows[l - 1][ty]);
-        if (ok) {
-            const int Rs = G.R_src[ty];
-            const int tb = M->t_base[l - 1][ty] + j0 * Rs;
-            int prev = tp[tb];
-            for (int q = 1; q <= 8; ++q) {
-                const int cur = tp[tb + q * Rs];
-                if (cur - prev > 8) ok = 0;
-                prev = cur;
+    for (int k = 0; k < nl; ++k) {
+        const int l = l0 + k;
+        if (blockIdx.x == 0 && threadIdx.x == 0) M->t_entries[l - 1] = M->cur[4 + k];
+        const int n_oct = M->error ? 0 : (M->src_base[l - 1][NT] + 7) >> 3;
+        const int32_t* tp = A.B.t_ptr[l - 1];
+        int32_t* out = A.B.t_cnt[l - 1];
+        for (int o = blockIdx.x * KGW_BLK + threadIdx.x; o < n_oct; o += gridDim.x * KGW_BLK) {
+            const int u0 = 8 * o;
+            int ty = 0;
+            while (ty + 1 < NT && u0 >= M->src_base[l - 1][ty + 1]) ++ty;
+            const int j0 = u0 - M->src_base[l - 1][ty];
+            int ok = ((G.short_types >> ty) & 1u) && j0 + 8 <= M->n_src[l - 1][ty] &&
+                     !(G.R_dst[ty] > 0 && j0 < M->n_rows[l - 1][ty]);
+            if (ok) {
+                const int Rs = G.R_src[ty];
+                const int tb = M->t_base[l - 1][ty] + j0 * Rs;
+                int prev = tp[tb];
+                for (int q = 1; q <= 8; ++q) {
+                    const int cur = tp[tb + q * Rs];
+                    if (cur - prev > 8) ok = 0;
+                    prev = cur;
+                }
             }
+            out[o] = ok;
         }
-        out[o] = ok;
+    }
+}
+
+// zero fill of up to two int32 arrays in one launch
+__global__ void __launch_bounds__(KGW_BLK) k_fill2_i32(int32_t* __restrict__ p0, int64_t n0, int32_t* __restrict__ p1, int64_t n1) {
+    const int64_t tid = (int64_t)blockIdx.x * KGW_BLK + threadIdx.x, nthr = (int64_t)gridDim.x * KGW_BLK;
+    const int4 z = make_int4(0, 0, 0, 0);
+    for (int64_t i = tid; i < (n0 >> 2); i += nthr) ((int4*)p0)[i] = z;
+    for (int64_t i = (n0 & ~3ll) + tid; i < n0; i += nthr) p0[i] = 0;
+    if (p1) {
+        for (int64_t i = tid; i < (n1 >> 2); i += nthr) ((int4*)p1)[i] = z;
+        for (int64_t i = (n1 & ~3ll) + tid; i < n1; i += nthr) p1[i] = 0;
     }
 }
 
@@ -605,14 +701,17 @@ extern "C" int kgw_sample_batch_parts(const KgwGraph* graph, const KgwBatchBuf* 
 
     for (int h = 0; h < graph->n_hops; ++h) {
         if (2 * h >= part_begin && 2 * h <= part_end) {
-            k_hop_begin<<<1, 64, 0, st>>>(A, h);
-            k_seg_deg<<<SG, KGW_BLK, 0, st>>>(A, h);
-            k_scan_tiles<2><<<SG, KGW_BLK, 0, st>>>(buf->seg_deg, buf->seg_nch, buf->meta, buf->scan_tmp);
-            k_scan_top<2><<<1, KGW_BLK, 0, st>>>(buf->scan_tmp, buf->meta, 1);
-            k_scan_apply<2><<<SG, KGW_BLK, 0, st>>>(buf->seg_deg, buf->seg_nch, buf->seg_ptr,
-                                                          buf->seg_chptr, buf->meta, buf->scan_tmp);
-            k_hop_mid<<<1, 64, 0, st>>>(A, h);
-            k_fill_chunks<<<SG, KGW_BLK, 0, st>>>(A, h);
+            k_seg_deg<<<SG, KGW_BLK, 0, st>>>(A, h);                       // (+ the hop's segment offsets)
+            if (!full_graph) {
+                // a minibatch hop has a few 10 k segments: one block scans them (one launch instead of three)
+                k_scan_block<2><<<1, 1024, 0, st>>>(buf->seg_deg, buf->seg_nch, buf->seg_ptr, buf->seg_chptr, buf->meta, 1);
+            } else {
+                k_scan_tiles<2><<<SG, KGW_BLK, 0, st>>>(buf->seg_deg, buf->seg_nch, buf->meta, buf->scan_tmp);
+                k_scan_top<2><<<1, KGW_BLK, 0, st>>>(buf->scan_tmp, buf->meta, 1);
+                k_scan_apply<2><<<SG, KGW_BLK, 0, st>>>(buf->seg_deg, buf->seg_nch, buf->seg_ptr,
+                                                              buf->seg_chptr, buf->meta, buf->scan_tmp);
+            }
+            k_fill_chunks<<<SG, KGW_BLK, 0, st>>>(A, h);                   // (+ edge / chunk totals of the hop, capacity checks)
             KGW_LAUNCH_CHECK();
             if (!full_graph) {
                 k_mark<<<SG, KGW_BLK, 0, st>>>(A, h);
@@ -624,13 +723,11 @@ extern "C" int kgw_sample_batch_parts(const KgwGraph* graph, const KgwBatchBuf* 
                 k_count_pending<<<SG, KGW_BLK, 0, st>>>(A, buf->scan_tmp, ntiles_nodes);
                 k_scan_top_fixed<<<1, KGW_BLK, 0, st>>>(buf->scan_tmp, ntiles_nodes);
                 k_assign<<<SG, KGW_BLK, 0, st>>>(A, buf->scan_tmp, ntiles_nodes, h);
-                k_hop_end<<<1, 64, 0, st>>>(A, buf->scan_tmp, h);
             } else {
                 // every node is already a seed: hop h+1 adds nothing
                 { int rc = fill_i32(buf->scan_tmp, 0, ntiles_nodes + 2, st, SG); if (rc) return rc; }
-                k_hop_end<<<1, 64, 0, st>>>(A, buf->scan_tmp, h);
             }
-            k_relabel<<<SG, KGW_BLK, 0, st>>>(A, h);
+            k_relabel<<<SG, KGW_BLK, 0, st>>>(A, buf->scan_tmp, h);        // (+ node counts of hop h + 1)
             KGW_LAUNCH_CHECK();
         }
     }
@@ -638,28 +735,45 @@ extern "C" int kgw_sample_batch_parts(const KgwGraph* graph, const KgwBatchBuf* 
     k_layer_tables<<<1, 64, 0, st>>>(A);
     KGW_LAUNCH_CHECK();
 
-    for (int l = 1; l <= graph->n_layers; ++l) {
-        if (!buf->t_cnt[l - 1] || !buf->t_ptr[l - 1] || !buf->t_edge[l - 1] || !buf->t_zrow[l - 1] || !buf->t_tmp)
-            return KGW_E_NULL;
-        // histogram of the src-major rows: only the rows the layer can have need clearing -- with a static layout that is the
-        // capacity of its source blocks (~1.1 M of the 5 M rows the whole graph would need: 16 MB less to write per layer)
-        int64_t trows = buf->trow_cap;
-        if (graph->static_layout) {
-            int64_t tb = 0;
-            for (int t = 0; t < graph->n_types; ++t) tb += (int64_t)graph->cap_src[l - 1][t] * graph->R_src[t];
-            if (tb < trows) trows = tb;
+    // src-major structures, two layers per set of launches (the default model has two)
+    for (int l0 = 1; l0 <= graph->n_layers; l0 += 2) {
+        const int nl = l0 + 1 <= graph->n_layers ? 2 : 1;
+        int64_t trows = 0;
+        for (int k = 0; k < nl; ++k) {
+            const int l = l0 + k;
+            if (!buf->t_cnt[l - 1] || !buf->t_ptr[l - 1] || !buf->t_edge[l - 1] || !buf->t_zrow[l - 1] || !buf->t_tmp)
+                return KGW_E_NULL;
+            // histogram of the src-major rows: only the rows the layers can have need clearing -- with a static layout that is
+            // the capacity of their source blocks (~1.1 M of the 5 M rows the whole graph would need: 16 MB less to write per layer)
+            int64_t tr = buf->trow_cap;
+            if (graph->static_layout) {
+                int64_t tb = 0;
+                for (int t = 0; t < graph->n_types; ++t) tb += (int64_t)graph->cap_src[l - 1][t] * graph->R_src[t];
+                if (tb < tr) tr = tb;
+            }
+            if (tr > trows) trows = tr;
         }
-        { int rc = fill_i32(buf->t_cnt[l - 1], 0, trows + 1, st, SG); if (rc) return rc; }
-        k_t_begin<<<1, 64, 0, st>>>(A, l);
-        k_t_pass<false><<<SG, KGW_BLK, 0, st>>>(A, l);
-        k_scan_tiles<1><<<SG, KGW_BLK, 0, st>>>(buf->t_cnt[l - 1], nullptr, buf->meta, buf->scan_tmp);
-        k_scan_top<1><<<1, KGW_BLK, 0, st>>>(buf->scan_tmp, buf->meta, 0);
-        k_scan_apply<1><<<SG, KGW_BLK, 0, st>>>(buf->t_cnt[l - 1], nullptr, buf->t_ptr[l - 1],
-                                                      nullptr, buf->meta, buf->scan_tmp);
-        k_t_pass<true><<<SG, KGW_BLK, 0, st>>>(A, l);
-        k_t_rank<<<SG, KGW_BLK, 0, st>>>(A, l);
-        k_t_rank_big<<<SG, KGW_BLK, 0, st>>>(A, l);
-        k_t_end<<<SG, KGW_BLK, 0, st>>>(A, l);
+        {
+            int64_t g = ((trows + 1) / 4 + KGW_BLK - 1) / KGW_BLK;
+            if (g > SG) g = SG;
+            if (g < 1) g = 1;
+            k_fill2_i32<<<(int)g, KGW_BLK, 0, st>>>(buf->t_cnt[l0 - 1], trows + 1, nl == 2 ? buf->t_cnt[l0] : nullptr, trows + 1);
+        }
+        k_t_pass<false><<<SG, KGW_BLK, 0, st>>>(A, l0, nl);               // (+ the scan range)
+        if (nl == 2) {
+            k_scan_tiles<2><<<SG, KGW_BLK, 0, st>>>(buf->t_cnt[l0 - 1], buf->t_cnt[l0], buf->meta, buf->scan_tmp);
+            k_scan_top<2><<<1, KGW_BLK, 0, st>>>(buf->scan_tmp, buf->meta, 0);
+            k_scan_apply<2><<<SG, KGW_BLK, 0, st>>>(buf->t_cnt[l0 - 1], buf->t_cnt[l0], buf->t_ptr[l0 - 1], buf->t_ptr[l0],
+                                                          buf->meta, buf->scan_tmp);
+        } else {
+            k_scan_tiles<1><<<SG, KGW_BLK, 0, st>>>(buf->t_cnt[l0 - 1], nullptr, buf->meta, buf->scan_tmp);
+            k_scan_top<1><<<1, KGW_BLK, 0, st>>>(buf->scan_tmp, buf->meta, 0);
+            k_scan_apply<1><<<SG, KGW_BLK, 0, st>>>(buf->t_cnt[l0 - 1], nullptr, buf->t_ptr[l0 - 1], nullptr, buf->meta, buf->scan_tmp);
+        }
+        k_t_pass<true><<<SG, KGW_BLK, 0, st>>>(A, l0, nl);
+        k_t_rank<<<SG, KGW_BLK, 0, st>>>(A, l0, nl);
+        k_t_rank_big<<<SG, KGW_BLK, 0, st>>>(A, l0, nl);
+        k_t_end<<<SG, KGW_BLK, 0, st>>>(A, l0, nl);
         KGW_LAUNCH_CHECK();
     }
     if (buf->meta_host) {

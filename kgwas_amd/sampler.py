@@ -228,7 +228,7 @@ class BatchBuffers:
         self.t_rel = [torch.empty(dg.edge_cap + 1, dtype=torch.uint8, device=dev) for _ in range(L)]
         self.scan_cap = 2 * (max(dg.seg_cap, dg.node_slots, dg.trow_cap) // KGW_TILE + 4)
         self.scan_tmp = torch.empty(self.scan_cap, **i32)
-        self.t_tmp = torch.empty(4 * (dg.edge_cap + 1), **i32)
+        self.t_tmp = torch.empty(8 * (dg.edge_cap + 1), **i32)       # (two layers stage their entries one behind the other)
         nbytes = C.sizeof(KgwBatchMeta)
         self.meta = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         self.meta_host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
