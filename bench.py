@@ -323,7 +323,8 @@ def main():
         mode = 'eager launches'
     else:
         from kgwas_amd.graph_step import GraphTrainStep
-        gs = GraphTrainStep(run, ('SNP', mine), bs_rank, lr=1e-4, weight_decay=5e-4)
+        # (strong scaling: every rank would repeat the batch-independent first gene Linear -- split it by gene rows instead)
+        gs = GraphTrainStep(run, ('SNP', mine), bs_rank, lr=1e-4, weight_decay=5e-4, shard_gene_layer=strong and world >= 4)
 
         def do_step(i):
             gs.step(i)
@@ -413,6 +414,19 @@ def main():
                  'the validation pass of kgwas.py:157 (first use: includes capturing its forward graph)'}
         del ge
 
+    # what moved between the ranks: every collective of the timed region, by name, per step and rank (world 1: empty)
+    coll = {}
+    if world > 1 or os.environ.get('KGW_FORCE_MULTIRANK_PATH') == '1':
+        src = dict(kdist.COLLECTIVES)
+        if shard:
+            src.update(st_.collectives())
+        elif gs is not None and gs.gene_shard is not None:
+            src.update({k: v for k, v in gs.gene_shard.bytes.items() if v[0]})
+        n_all = args.steps + args.warmup
+        coll = {k: {'calls_per_step': v[0] / n_all, 'bytes_per_step': v[1] / n_all} for k, v in src.items()}
+    comm = {'world_size': world, 'backend': (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
+            'rccl': bool(torch.distributed.is_initialized() and torch.distributed.get_backend() == 'nccl'),
+            'collectives_per_step_and_rank': coll}
     stats = torch.tensor([elapsed, float(edges_kernel), float(edges_ref), float(seeds)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = stats[:1].clone()
@@ -529,6 +543,8 @@ def main():
                    'seeds_per_s': seeds / elapsed,
                    'epoch_time_s_956_steps': 956 * ms / 1e3 / (1 if strong else world),
                    'epoch_measured': epoch,
+                   'rccl_world_size': world if comm['rccl'] else 0,
+                   'communication': comm,
                    'library_gemm_calls': lib_calls,
                    'library_gemm_note': ('products of set-up + warm-up + capture + the timed steps that went to hipBLASLt / rocBLAS instead of this '
                                          'package\'s HIP kernels (kgwas_amd.ops.LIBRARY_GEMM; KGW_STRICT=1 makes any such route an error)' +

@@ -39,10 +39,20 @@ def _grads(model):
     return [p.grad for p in model.parameters() if p.grad is not None]
 
 
-def allreduce_flat(flat: torch.Tensor, world: int):
+COLLECTIVES = {}          # name -> [calls, bytes this rank handed to the collective] (bench.py reports them per step)
+
+
+def count_collective(name: str, nbytes: int):
+    c = COLLECTIVES.setdefault(name, [0, 0])
+    c[0] += 1
+    c[1] += int(nbytes)
+
+
+def allreduce_flat(flat: torch.Tensor, world: int, what: str = 'parameter gradients'):
     """Average ``flat`` over the ranks in place: ONE collective (RCCL's AVG where the backend has it)."""
     if world <= 1 and not (os.environ.get('KGW_FORCE_MULTIRANK_PATH') == '1' and dist.is_initialized()):
         return
+    count_collective(f'all_reduce_avg({what})', flat.numel() * flat.element_size())
     if dist.get_backend() == 'nccl':
         dist.all_reduce(flat, op=dist.ReduceOp.AVG)
     else:                                            # gloo (CPU tests) has no AVG

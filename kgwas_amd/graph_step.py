@@ -28,7 +28,8 @@ SIDE_SAMPLER_GRID = 256
 
 class GraphTrainStep:
     def __init__(self, run, input_nodes, batch_size: int, lr: float = 1e-4, weight_decay: float = 5e-4,
-                 margin: float = 1.03, capture_optimizer: bool = True, overlap_sampling: bool = None):
+                 margin: float = 1.03, capture_optimizer: bool = True, overlap_sampling: bool = None,
+                 shard_gene_layer: bool = None):
         self.run = run
         self.model = run.model
         self.batch_size = int(batch_size)
@@ -68,6 +69,19 @@ class GraphTrainStep:
         # while the second half (the MLPs' backward: ~45 % of the backward's time, incl. the 5120-wide gene dW product)
         # runs; only the MLPs' own bucket (~2.7 MB) is reduced in the open.
         self.split_backward = self._multi and os.environ.get('KGW_SPLIT_BACKWARD', '1') == '1'
+        # multi-rank, optional: the first gene Linear over the resident feature matrix (forward + weight gradient: 0.27 of the
+        # step's 1.2 ms, identical work on every rank) split by gene rows over the ranks -- ops.GeneLayerShard in its STAGED form:
+        # partial product (captured) | all-gather | the step's graphs | reduce-scatter of dz | partial weight gradient (captured).
+        # Pays when (world - 1) / world of 0.27 ms exceeds two 10 MB collectives + three extra graph boundaries: strong scaling /
+        # many ranks.  KGW_SHARD_GENE_LAYER=1/0 overrides the caller's choice.
+        env = os.environ.get('KGW_SHARD_GENE_LAYER')
+        want = (shard_gene_layer if env is None else env == '1') and self.split_backward
+        self.gene_shard = None
+        if want:
+            import torch.distributed as dist
+            self.gene_shard = ops.GeneLayerShard(dist.get_rank(), dist.get_world_size(), None, inline=True)
+        ops.GENE_SHARD = self.gene_shard
+        self._g_partial = self._g_dw = None
         self._comm = torch.cuda.Stream(device=dev) if self._multi else None
         self._ev_a, self._ev_ca = torch.cuda.Event(), torch.cuda.Event()
         self._flat_a = self._flat_b = None
@@ -179,13 +193,19 @@ class GraphTrainStep:
         torch.autograd.backward([h for h, _ in keep], grad_tensors=[d for _, d in keep])
         late = self._late_params()
         live = [p for p in self.model.parameters() if id(p) in late and p.grad is not None]
+        gs = self.gene_shard
+        staged = gs is not None and not gs.inline and gs.last is not None
+        w1 = gs.last[1] if staged else None            # (its gradient is NOT produced by the backward: the partial product after the
+        n_live = sum(p.numel() for p in live)          #  reduce-scatter writes it straight into the bucket, _stage_dw)
         if self._flat_b is None:
-            self._flat_b = torch.empty(sum(p.numel() for p in live), device=self.seeds.device)
+            self._flat_b = torch.empty(n_live + (w1.numel() if staged else 0), device=self.seeds.device)
             off = 0
             for p in live:
                 self._flat_grads[p] = self._flat_b[off:off + p.numel()].view_as(p)
                 off += p.numel()
-        torch.cat([p.grad.reshape(-1) for p in live], out=self._flat_b)
+            if staged:
+                self._flat_grads[w1] = self._flat_b[off:off + w1.numel()].view_as(w1)
+        torch.cat([p.grad.reshape(-1) for p in live], out=self._flat_b[:n_live])
 
     def _sample_now(self, which: int, i: int):
         b = self.batch_size
@@ -201,10 +221,26 @@ class GraphTrainStep:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             self._sample_now(0, 0)
+            gs = self.gene_shard
             for k in range(4):
+                if gs is not None and not gs.inline:                   # staged form from the second warm-up step on
+                    gs.forward_partial(*gs.last)
+                    gs.gather()
                 self._step_body(k % 2)
                 if self.split_backward:
                     self._step_body_b(k % 2)
+                if gs is not None:
+                    if k == 0:
+                        # the first warm-up step ran the shard INLINE (collectives inside the autograd node: fine outside a
+                        # capture) -- which also tells whether the model takes the resident route for the gene features at all
+                        if gs.last is None:
+                            self.gene_shard = gs = ops.GENE_SHARD = None
+                        else:
+                            gs.inline = False
+                            self._flat_b = None                        # (rebuilt with a slot for the first layer's weight)
+                    else:
+                        gs.scatter()
+                        gs.weight_grad_partial(gs.last[0], out=self._flat_grads[gs.last[1]])
                 if self.twin:
                     self._sample_now(1 - k % 2, 0)
         torch.cuda.current_stream().wait_stream(s)
@@ -239,6 +275,14 @@ class GraphTrainStep:
                 with torch.cuda.graph(gb, pool=g.pool()):
                     self._step_body_b(cur)
                 self.graphs_b[cur] = gb
+                gs = self.gene_shard
+                if gs is not None and self._g_partial is None:
+                    # the two products of the sharded first gene layer: batch independent, captured once
+                    self._g_partial, self._g_dw = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._g_partial, pool=g.pool()):
+                        gs.forward_partial(*gs.last)
+                    with torch.cuda.graph(self._g_dw, pool=g.pool()):
+                        gs.weight_grad_partial(gs.last[0], out=self._flat_grads[gs.last[1]])
             if self.twin:
                 gs = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gs, stream=self._side):
@@ -254,6 +298,9 @@ class GraphTrainStep:
             self._sample_now(cur, i)
         nxt = (i + 1) % self.n_batches
         b = self.batch_size
+        if self.gene_shard is not None:
+            self._g_partial.replay()               # this rank's rows of the first gene layer, then everybody's
+            self.gene_shard.gather()
         if self.twin:
             main = torch.cuda.current_stream()
             self._side.wait_stream(main)          # the previous step (reader of bufs[1 - cur], writer of nothing here) is done
@@ -279,10 +326,13 @@ class GraphTrainStep:
                 self._ev_a.record(main)
                 with torch.cuda.stream(self._comm):                   # first bucket: reduced while the MLPs' backward runs
                     self._comm.wait_event(self._ev_a)
-                    kdist.allreduce_flat(self._flat_a, self.world)
+                    kdist.allreduce_flat(self._flat_a, self.world, 'gradients of the relation packs + read-out, under the MLPs\' backward')
                     self._ev_ca.record(self._comm)
                 self.graphs_b[cur].replay()
-                kdist.allreduce_flat(self._flat_b, self.world)        # second bucket: the MLPs' own gradients
+                if self.gene_shard is not None:
+                    self.gene_shard.scatter()      # dz summed over the ranks' batches, each rank its own gene rows
+                    self._g_dw.replay()            # partial weight gradient of the first gene layer -> its slot of the bucket
+                kdist.allreduce_flat(self._flat_b, self.world, 'gradients of the feature MLPs')        # second bucket: the MLPs' own gradients
                 main.wait_event(self._ev_ca)
                 self.opt.step(self._flat_grads)
             elif self._multi:

@@ -176,8 +176,11 @@ class KGWAS:
         graph_step = None
         if use_graph and len(self.train_loader) > 0:
             from .graph_step import GraphTrainStep
+            # (multi-GPU: a 512-seed batch split over the ranks = strong scaling; from 4 ranks on the batch-independent first gene
+            #  Linear is split by gene rows instead of repeated on every rank -- ops.GeneLayerShard)
             graph_step = GraphTrainStep(self, (self.train_loader.input_type, self.train_loader.ids.cpu().numpy()),
-                                        self.train_loader.batch_size, lr=lr, weight_decay=weight_decay)
+                                        self.train_loader.batch_size, lr=lr, weight_decay=weight_decay,
+                                        shard_gene_layer=world >= 4)
             optimizer = graph_step.opt
         else:
             optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay)   # kgwas.py:116

@@ -619,11 +619,102 @@ def _resident_ok(X: torch.Tensor, W: torch.Tensor) -> bool:
             and X.stride(1) == 1 and W.stride(1) == 1)
 
 
-def resident_first_linear(X, W, b, g2l=None, rows_out=None):
+class GeneLayerShard:
+    """The first Linear over a RESIDENT wide feature matrix (the gene features: [20 032, 5 120] x [5 120, 128], forward and
+    weight gradient -- the two largest products of a step, kgwas/model.py:13,19) split by node rows over the ranks of a
+    multi-GPU job.  Its output does not depend on the batch and the weights are replicated, so every rank would compute the
+    SAME 2 x 26 GFLOP; instead rank p computes rows [p chunk, (p + 1) chunk):
+        forward    h[rows_p] = relu(X[rows_p] W^T + b)              then ALL-GATHER of h (10 MB in total)
+        backward   dz summed over the ranks' batches by REDUCE-SCATTER (rank p receives the sum of rows_p), then
+                   dW_p = dz_sum[rows_p]^T X[rows_p]  -- a PARTIAL of the weight gradient: the sum over ranks of dW_p is the sum
+                   over ranks of the full gradients, which is what the parameter-gradient all-reduce that follows computes
+                   anyway (SUM in the SNP-sharded mode, AVG = SUM / world in the seed-parallel mode: both linear).
+    ``inline``: the collectives are issued inside the autograd node (eager steps: kgwas_amd/shard.py, KGWAS.train_step);
+    otherwise the caller runs the stages itself around captured graphs (kgwas_amd/graph_step.py): ``forward_partial`` ->
+    ``gather`` -> (the node reads ``h_all``, leaves ``dz``) -> ``scatter`` -> ``weight_grad_partial``."""
+
+    def __init__(self, rank: int, world: int, group=None, inline: bool = True):
+        import torch.distributed as dist
+        self.rank, self.world, self.group, self.inline = int(rank), int(world), group, inline
+        self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        self.h_all = self.dz = self.dz_mine = None
+        self.n = self.chunk = 0
+        self.last = None                                       # (X, W, b) of the layer this shard was last applied to
+        self.bytes = {'all_gather(first gene layer output)': [0, 0], 'reduce_scatter(first gene layer dz)': [0, 0]}
+
+    def _setup(self, X):
+        N = X.shape[0]
+        if self.h_all is not None and self.n == N:
+            return
+        self.n = N
+        self.chunk = -(-N // (self.world * 32)) * 32                   # rows per rank, a multiple of 32
+        dev = X.device
+        self.h_all = torch.zeros(self.world * self.chunk, KGW_C, device=dev)
+        self.dz = torch.zeros(self.world * self.chunk, KGW_C, device=dev)     # rows >= N stay zero
+        self.dz_mine = torch.empty(self.chunk, KGW_C, device=dev)
+
+    def rows(self):
+        lo = self.rank * self.chunk
+        return lo, max(min(self.n, lo + self.chunk), lo)
+
+    def forward_partial(self, X, W, b):
+        self._setup(X)
+        self.last = (X, W, b)
+        lo, hi = self.rows()
+        if hi > lo:
+            Xf = _resident_copies(X)[0]
+            Kp = Xf.shape[1]
+            gemm3(Xf[lo:hi], gemm3_pack(W, Kp, False, k_valid=W.shape[1]), bias=b, relu=True, out=self.h_all[lo:hi])
+
+    def gather(self):
+        import torch.distributed as dist
+        lo = self.rank * self.chunk
+        mine = self.h_all[lo:lo + self.chunk]
+        if self.backend == 'nccl':
+            dist.all_gather_into_tensor(self.h_all, mine, group=self.group)      # in place: the rank's rows already lie in their slot
+        else:
+            dist.all_gather(list(self.h_all.view(self.world, self.chunk, KGW_C).unbind(0)), mine.clone(), group=self.group)
+        c = self.bytes['all_gather(first gene layer output)']
+        c[0] += 1; c[1] += self.h_all.numel() * 4
+
+    def scatter(self):
+        """dz (this rank's, dense over the resident rows) -> dz_mine = sum over ranks of the rows this rank owns."""
+        import torch.distributed as dist
+        lo = self.rank * self.chunk
+        if self.backend == 'nccl':
+            dist.reduce_scatter_tensor(self.dz_mine, self.dz, op=dist.ReduceOp.SUM, group=self.group)
+        else:                                                     # gloo (tests): no reduce-scatter on device tensors
+            t = self.dz.clone()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self.dz_mine.copy_(t[lo:lo + self.chunk])
+        c = self.bytes['reduce_scatter(first gene layer dz)']
+        c[0] += 1; c[1] += self.dz.numel() * 4
+
+    def weight_grad_partial(self, X, out=None):
+        """[128, K] partial of the weight gradient from the rows this rank owns (zeros if it owns none)."""
+        lo, hi = self.rows()
+        Xt = _resident_copies(X)[1]                                # [K, Np]
+        kin = min(self.chunk, Xt.shape[1] - lo)
+        if out is None:
+            out = torch.empty(KGW_C, X.shape[1], device=X.device)
+        if hi <= lo or kin <= 0:
+            return out.zero_()
+        return gemm3(Xt[:, lo:lo + kin], gemm3_pack(self.dz_mine[:hi - lo], kin, True, k_valid=hi - lo), transpose_out=True, out=out)
+
+
+GENE_SHARD = None          # the active GeneLayerShard of this process (set by the multi-GPU trainers), or None
+
+
+def resident_first_linear(X, W, b, g2l=None, rows_out=None, gs=None):
     """relu(X W^T + b) over ALL rows of a resident wide feature matrix (kgwas/model.py:19 on the gene features).  ``g2l`` +
     ``rows_out``: the batch's rows (rows_out[g2l[r]] = row r where g2l[r] >= 0) are written by the same launch; returns
     (h, True) then, (h, False) when the caller still has to gather them."""
     if _resident_ok(X, W):
+        if gs is not None:
+            if gs.inline:
+                gs.forward_partial(X, W, b)
+                gs.gather()
+            return gs.h_all[:X.shape[0]], False            # (staged: the trainer ran forward_partial + gather for this step)
         Xf = _resident_copies(X)[0]                      # built outside any graph capture, on the first eager step
         Kp = Xf.shape[1]
         fused = g2l is not None and rows_out is not None and rows_out.numel() > 0
@@ -634,14 +725,36 @@ def resident_first_linear(X, W, b, g2l=None, rows_out=None):
     return linear(X, W, b, relu=True, fixed_shape=True), False
 
 
-def resident_first_weight_grad(dz, X, W):
-    """dW [128, K] = dz^T X for the same layer."""
+def active_gene_shard(ctx, w_index: int):
+    """The process's GeneLayerShard while a TRAINING forward runs (the autograd node is asked for the layer's weight gradient);
+    inference passes -- captured forward graphs, loaders of different lengths per rank -- always compute the whole layer locally."""
+    return GENE_SHARD if (GENE_SHARD is not None and ctx.needs_input_grad[w_index]) else None
+
+
+def resident_first_weight_grad(dz, X, W, gs=None):
+    """dW [128, K] = dz^T X for the same layer (``gs``, the GeneLayerShard the forward used: this rank's PARTIAL of it, or None
+    when the trainer computes the partial itself after its reduce-scatter stage)."""
     if _resident_ok(X, W) and dz.is_contiguous():
+        if gs is not None:
+            assert dz.data_ptr() == gs.dz.data_ptr(), 'the sharded first layer differentiates into GeneLayerShard.dz'
+            if not gs.inline:
+                return None
+            gs.scatter()
+            return gs.weight_grad_partial(X)
         Xt = _resident_copies(X)[1]                      # [K, Np], Np = the node count rounded up to 32, zero columns past it
         return gemm3(Xt, gemm3_pack(dz, Xt.shape[1], True, k_valid=X.shape[0]), transpose_out=True)
     LIBRARY_GEMM.note('resident_first_weight_grad', dz.shape[0], dz.shape[1], X.shape[1])
     with _TUNED:
         return dz.t().mm(X)
+
+
+def _dz_buffer(h, gs):
+    """Where the dense d(pre-activation) of the resident first layer is written: GeneLayerShard.dz (its first N rows) when the
+    layer is sharded over ranks, else a fresh [N, 128]."""
+    if gs is not None:
+        assert gs.dz is not None and gs.n == h.shape[0]
+        return gs.dz[:h.shape[0]]
+    return torch.empty_like(h)
 
 
 class _MLPTail(torch.autograd.Function):
@@ -943,7 +1056,8 @@ class _ResidentLinearReLURows(torch.autograd.Function):
         # zeros: the rows past the batch's real node count (static capacity of a captured step) are written by nobody on the
         # fused route, and 0 x garbage must stay 0 in the weight gradients downstream
         out = torch.zeros(n, KGW_C, device=X.device) if _resident_ok(X, W) else torch.empty(n, KGW_C, device=X.device)
-        h, done = resident_first_linear(X, W, b, g2l, out)
+        ctx.shard = active_gene_shard(ctx, 1) if _resident_ok(X, W) else None
+        h, done = resident_first_linear(X, W, b, g2l, out, ctx.shard)
         if n and not done:
             _lib.check(_lib.lib().kgw_gather_rows(_p(h), _p(ids), n, h.shape[1], _p(out), _lib.stream_ptr()), 'kgw_gather_rows')
         ctx.save_for_backward(X, h, g2l, W)
@@ -955,12 +1069,12 @@ class _ResidentLinearReLURows(torch.autograd.Function):
         g = g.contiguous()
         N = h.shape[0]
         assert h.shape[1] == KGW_C and g2l.numel() == N and g2l.dtype == torch.int32
-        dz = torch.empty_like(h)
+        dz = _dz_buffer(h, ctx.shard)
         db = torch.empty(KGW_C, device=h.device)
         ws = torch.empty(int(_lib.lib().kgw_scatter_relu_rows_workspace_floats(N)), device=h.device)
         _lib.check(_lib.lib().kgw_scatter_relu_rows(_p(g), _p(g2l), _p(h), N, _p(dz), _p(db), _p(ws), _lib.stream_ptr()),
                    'kgw_scatter_relu_rows')
-        dW = resident_first_weight_grad(dz, X, W)
+        dW = resident_first_weight_grad(dz, X, W, ctx.shard)
         return None, dW, db, None, None
 
 
@@ -976,7 +1090,8 @@ class _ResidentMLP2(torch.autograd.Function):
     def forward(ctx, X, W1, b1, W2, b2, ids, g2l, out):
         n = int(ids.numel())
         h1g = torch.zeros(n, KGW_C, device=X.device) if _resident_ok(X, W1) else torch.empty(n, KGW_C, device=X.device)   # (see _ResidentLinearReLURows)
-        h, done = resident_first_linear(X, W1, b1, g2l, h1g)
+        ctx.shard = active_gene_shard(ctx, 1) if _resident_ok(X, W1) else None
+        h, done = resident_first_linear(X, W1, b1, g2l, h1g, ctx.shard)
         if n and not done:
             _lib.check(_lib.lib().kgw_gather_rows(_p(h), _p(ids), n, h.shape[1], _p(h1g), _lib.stream_ptr()), 'kgw_gather_rows')
         h2 = linear(h1g, W2, b2, relu=True, out=out.view() if out is not None else None)
@@ -989,13 +1104,13 @@ class _ResidentMLP2(torch.autograd.Function):
         dh2 = dh2.contiguous()
         N = h.shape[0]
         L = _lib.lib()
-        dz = torch.empty_like(h)
+        dz = _dz_buffer(h, ctx.shard)
         db1 = torch.empty(KGW_C, device=h.device)
         nws = int(L.kgw_mlp2_bwd_first_workspace_floats(N))
         ws = torch.empty(nws, device=h.device)
         _lib.check(L.kgw_mlp2_bwd_first(_p(dh2), dh2.stride(0), _p(W2), W2.stride(0), _p(h), h.stride(0), None, 0, 0, N, None, None, 0,
                                         _p(db1), _p(ws), nws, _p(g2l), _p(dz), dz.stride(0), _lib.stream_ptr()), 'kgw_mlp2_bwd_first')
-        dW1 = resident_first_weight_grad(dz, X, W1)
+        dW1 = resident_first_weight_grad(dz, X, W1, ctx.shard)
         dW2, db2 = linear_weight_grad(dh2, h1g)
         return None, dW1, db1, dW2, db2, None, None, None
 

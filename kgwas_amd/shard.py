@@ -235,6 +235,14 @@ class ShardedTrainer:
         L = run.gnn_num_layers
         self.dg = DeviceGraph(self.local, L, dev)
         self.xchg = ShardExchange(self.dg, sharded_type, group)
+        # the first gene Linear over the resident (replicated) gene features is the same 2 x 26 GFLOP on every rank: split by gene
+        # rows over the ranks, inline collectives inside the autograd node (ops.GeneLayerShard).  Default from 4 ranks on (two 10 MB
+        # collectives against (world - 1) / world of 0.27 ms); KGW_SHARD_GENE_LAYER=1/0 overrides.
+        from . import ops
+        env = os.environ.get('KGW_SHARD_GENE_LAYER')
+        on = self.xchg.multi and (self.world >= 4 if env is None else env == '1')
+        self.gene_shard = ops.GeneLayerShard(self.rank, self.world, group, inline=True) if on else None
+        ops.GENE_SHARD = self.gene_shard
         self.seed_type = self.dg.schema.type_id[self.input_type]
         self.buf = BatchBuffers(self.dg)
         ids = np.asarray(ids.cpu() if torch.is_tensor(ids) else ids, dtype=np.int64).reshape(-1)
@@ -263,7 +271,16 @@ class ShardedTrainer:
 
     def describe(self) -> str:
         return ('eager launches; per step: 1 frontier all-reduce(MIN), 1 all-gather of partial softmax states + 1 all-reduce of '
-                'their dZ per exchanged layer, 1 flat gradient all-reduce (SUM)')
+                'their dZ per exchanged layer, 1 flat gradient all-reduce (SUM)' +
+                ('; first gene Linear split by gene rows over the ranks (all-gather of its output, reduce-scatter of its dz)'
+                 if self.gene_shard is not None else ''))
+
+    def collectives(self) -> dict:
+        """{name: [calls, bytes handed to the collective by this rank]} of everything this trainer moved so far."""
+        out = dict(self.xchg.collectives)
+        if self.gene_shard is not None:
+            out.update({k: v for k, v in self.gene_shard.bytes.items() if v[0]})
+        return out
 
     def sample(self, i: int) -> SampledBatch:
         seeds = self.local_seeds[i % self.n_batches]

@@ -134,3 +134,101 @@ def test_multirank_step_over_rccl_with_one_rank_equals_the_single_gpu_step(tmp_p
     gs.check()
     for k, v in run.model.named_reference_tensors().items():
         assert torch.equal(got[k], v.detach().cpu()), k
+
+
+# ---- the first gene Linear split by gene rows over the ranks (ops.GeneLayerShard, staged around the captured graphs) ----------
+WBS, WSTEPS = 256, 2
+
+
+def _wide_run():
+    """The benchmark-shaped case of tests/golden/gat_wide_case.py (4 613 genes x 1 050 features: the resident first gene layer
+    on kgw_gemm3) as a KGWAS run with its fixed parameters."""
+    from collections import OrderedDict
+    from kgwas_amd.graph import HeteroGraph
+    from kgwas_amd.kgwas import KGWAS
+    from kgwas_amd.kgwas_data import KGWAS_Data
+    from tests.golden import gat_wide_case as wc
+    from tests.golden.make_gat_wide_golden import transformed_edges
+    g = HeteroGraph()
+    for t, x in wc.features().items():
+        g[t].x = torch.from_numpy(x)
+    und = transformed_edges()
+    for et, ei in und.items():
+        g[et].edge_index = ei
+    y_all, w_all = wc.labels_and_weights()
+    g['SNP'].y = torch.from_numpy(y_all)
+    data = KGWAS_Data(f'/tmp/kgwas_gpudist_wide_{os.getpid()}')
+    data.data = g
+    data.snp_init_dim_size, data.gene_init_dim_size, data.go_init_dim_size = wc.DIMS['SNP'], wc.DIMS['Gene'], wc.DIMS['GO']
+    data.all_ids = np.arange(wc.NODES['SNP'])
+    data.ldsc_weight = w_all
+    run = KGWAS(data, device='cuda:0', seed=1)
+    run.initialize_model()
+    run.model.load_state_dict(OrderedDict((k, torch.from_numpy(v)) for k, v in wc.parameters(list(und)).items()), strict=True)
+    return data, run, wc.seeds()[:WBS * 2 * (WSTEPS + 1)]
+
+
+def _wide_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from kgwas_amd import ops
+        from kgwas_amd.graph_step import GraphTrainStep
+        torch.cuda.set_device(0)
+        data, run, ids = _wide_run()
+        mine = ids.reshape(-1, world, WBS)[:, rank].reshape(-1)
+        gs = GraphTrainStep(run, ('SNP', mine), WBS, lr=1e-3, weight_decay=5e-4, shard_gene_layer=True)
+        assert gs.split_backward and gs.gene_shard is not None and not gs.gene_shard.inline, 'the staged gene-layer shard must be active'
+        g3 = ops.ROUTES.get('kgw_gemm3', 0)
+        for i in range(WSTEPS):
+            gs.step(i)
+        gs.check()
+        lo, hi = gs.gene_shard.rows()
+        torch.save({'params': {k: v.detach().cpu() for k, v in run.model.named_reference_tensors().items()},
+                    'rows': (lo, hi), 'bytes': {k: list(v) for k, v in gs.gene_shard.bytes.items()}},
+                   os.path.join(out_dir, f'wide{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gene_layer_split_over_two_ranks_equals_hand_averaged_single_process(tmp_path):
+    """Seed-parallel captured step with the first gene Linear split by gene rows (rank p: its rows of the forward product, the
+    all-gather, the reduce-scatter of dz, its partial of the weight gradient) vs one process that runs both ranks' batches and
+    averages the gradients by hand: same parameters after two Adam steps, on every rank."""
+    world = 2
+    mp.start_processes(_wide_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method='spawn')
+    r0 = torch.load(os.path.join(tmp_path, 'wide0.pt'), weights_only=False)
+    r1 = torch.load(os.path.join(tmp_path, 'wide1.pt'), weights_only=False)
+    assert r0['rows'][0] == 0 and r0['rows'][1] == r1['rows'][0] and r1['rows'][1] == 4613     # 2 336 rows (a multiple of 32) + the rest
+    assert all(v[0] > 0 for v in r0['bytes'].values())
+    for k in r0['params']:
+        assert torch.equal(r0['params'][k], r1['params'][k]), f'{k}: ranks diverged'
+    from kgwas_amd.optim import FusedAdam
+    from kgwas_amd.sampler import NeighborLoader
+    data, run, ids = _wide_run()
+    ld_w = run._ld_weight_vector()
+    ids = ids.reshape(-1, world, WBS)
+    opt = FusedAdam(run.model.parameters(), lr=1e-3, weight_decay=5e-4)
+    params = [p for p in run.model.parameters()]
+    run.model.train()
+    for i in range(WSTEPS):
+        acc = None
+        for r in range(world):
+            batch = next(iter(NeighborLoader(data.data, [-1, -1], ('SNP', ids[i, r]), batch_size=WBS, device='cuda:0')))
+            run.model.zero_grad(set_to_none=True)
+            loss, _ = run.model.forward_loss(batch.x_dict, batch.edge_index_dict, WBS, batch.n_id('SNP'), batch.dg.y['SNP'], ld_w)
+            loss.backward()
+            g = [None if p.grad is None else p.grad.clone() for p in params]
+            acc = g if acc is None else [a if b is None else (b if a is None else a + b) for a, b in zip(acc, g)]
+        for p, a in zip(params, acc):
+            p.grad = None if a is None else a / world
+        opt.step()
+    ref = {k: v.detach().cpu() for k, v in run.model.named_reference_tensors().items()}
+    for k in ref:
+        d = (r0['params'][k].double() - ref[k].double()).abs().max()
+        scale = ref[k].double().abs().max().clamp(min=1e-6)
+        assert float(d) <= 5e-5 * float(scale) + 4e-6, (k, float(d), float(scale))
+    k = 'gene_feat_mlp.FC_hidden.weight'
+    assert float((r0['params'][k] - torch.from_numpy(__import__('tests.golden.gat_wide_case', fromlist=['x']).parameters(
+        [tuple(e) for e in data.data.edge_types])[k])).abs().max()) > 0          # the sharded layer's weight did move

@@ -383,3 +383,53 @@ def test_rank_that_owns_no_seed_of_a_batch_still_takes_part(tmp_path):
     for k in r0['params']:
         assert torch.equal(r0['params'][k], r1['params'][k]), k
     assert torch.equal(r0['pred_all'], r1['pred_all']) and r0['pred_all'].shape == (n,)
+
+
+def _wide_shard_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['KGW_SHARD_GENE_LAYER'] = '1'
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from kgwas_amd.shard import ShardedTrainer
+        from tests.test_gpu_dist import _wide_run
+        data, run, ids = _wide_run()
+        data.train_input_nodes = ('SNP', ids)
+        run.model.train()
+        st = ShardedTrainer(run, ('SNP', ids[:512 * 2]), 512, lr=1e-3, weight_decay=5e-4)
+        assert st.gene_shard is not None and st.gene_shard.inline
+        st.forward_backward(0)
+        st.allreduce_grads()
+        grads = {k: (None if v is None else v.detach().cpu().clone()) for k, v in run.model.named_reference_tensors(grad=True).items()}
+        st.opt.step()
+        st.step(1)
+        torch.save({'grads': grads, 'params': {k: v.detach().cpu() for k, v in run.model.named_reference_tensors().items()},
+                    'collectives': st.collectives()}, os.path.join(out_dir, f'ws{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_mode_with_the_gene_layer_split_by_rows_equals_single_process(tmp_path):
+    """SNP-sharded mode on the benchmark-shaped case (resident first gene layer on kgw_gemm3) with that layer ALSO split by gene
+    rows over the ranks (inline all-gather / reduce-scatter inside the autograd node): all-reduced gradients of batch 0 equal the
+    single-process gradients, the ranks stay bit-identical through two steps."""
+    from tests.test_gpu_dist import _wide_run
+    world = 2
+    mp.start_processes(_wide_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method='spawn')
+    r0, r1 = (torch.load(os.path.join(tmp_path, f'ws{r}.pt'), weights_only=False) for r in range(world))
+    for k in r0['params']:
+        assert torch.equal(r0['params'][k], r1['params'][k]), k
+    assert any('gene layer' in k for k in r0['collectives'])
+    from kgwas_amd.sampler import NeighborLoader
+    data, run, ids = _wide_run()
+    run.model.train()
+    batch = next(iter(NeighborLoader(data.data, [-1, -1], ('SNP', ids[:512]), batch_size=512, device='cuda:0')))
+    loss, _ = run.model.forward_loss(batch.x_dict, batch.edge_index_dict, 512, batch.n_id('SNP'), batch.dg.y['SNP'], run._ld_weight_vector())
+    loss.backward()
+    for k, g in run.model.named_reference_tensors(grad=True).items():
+        if g is None:
+            continue
+        g = g.detach().cpu().double()
+        err = float((r0['grads'][k].double() - g).abs().max())
+        assert err <= 2e-4 * float(g.abs().max()) + 1e-6, (k, err)
