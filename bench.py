@@ -307,8 +307,9 @@ def main():
         stats_e = [0, 0]
 
         def do_step(i):
-            e1, e2 = st_.step(i)
-            stats_e[0] += e1; stats_e[1] += e2
+            e = st_.step(i)
+            if e is not None:                 # (uncaptured form counts as it goes; the captured one after the timed region)
+                stats_e[0] += e[0]; stats_e[1] += e[1]
         mode = st_.describe()
     elif args.eager:
         opt = torch.optim.Adam(run.model.parameters(), lr=1e-4, weight_decay=5e-4)
@@ -344,6 +345,8 @@ def main():
         do_step(args.warmup + i)
     sync()
     elapsed = time.perf_counter() - t_start
+    shard_coll = st_.collectives() if shard else None     # (before the untimed edge-counting pass below adds its own)
+    shard_coll = {k: list(v) for k, v in shard_coll.items()} if shard_coll is not None else None
     # products handed to the framework's GEMM library so far (set-up, warm-up, capture, timed steps): must be 0 on the headline
     lib_calls, lib_sites = ops.LIBRARY_GEMM.calls, {f'{k[0]} {k[1]}': v for k, v in ops.LIBRARY_GEMM.by_site.items()}
     seeds = args.steps * (bs if shard else bs_rank)
@@ -351,6 +354,11 @@ def main():
         st = gs.check()                       # raises if a batch overflowed the static layout
         edges_kernel, edges_ref = sum(st[:2]), 2 * st[2]
     else:
+        if shard and st_.use_graph:
+            st_.check()                       # raises if a batch overflowed the static layout
+            for i in range(args.steps):       # edges of the timed batches, each counted once across the ranks (untimed pass)
+                e1, e2 = st_.count_edges(args.warmup + i)
+                stats_e[0] += e1; stats_e[1] += e2
         edges_kernel, edges_ref = stats_e
     if shard and rank != 0:
         seeds = 0                             # (every rank works on the same batches: count the seeds once)
@@ -419,7 +427,7 @@ def main():
     if world > 1 or os.environ.get('KGW_FORCE_MULTIRANK_PATH') == '1':
         src = dict(kdist.COLLECTIVES)
         if shard:
-            src.update(st_.collectives())
+            src.update(shard_coll)
         elif gs is not None and gs.gene_shard is not None:
             src.update({k: v for k, v in gs.gene_shard.bytes.items() if v[0]})
         n_all = args.steps + args.warmup

@@ -111,7 +111,7 @@ class KGWAS:
         optimizer.step()
         return loss
 
-    def _train_sharded(self, batch_size, lr, weight_decay, total_epoch, save_best_model, save_name):
+    def _train_sharded(self, batch_size, lr, weight_decay, total_epoch, save_best_model, save_name, use_graph=True):
         """kgwas/kgwas.py:85-212 in the SNP-sharded multi-GPU mode (kgwas_amd/shard.py): every rank works on the SAME
         batches of the reference's order and owns the SNPs of one id range; validation / test / inference predictions are
         computed shard-wise and summed, so every rank sees the same metrics and keeps the same best model."""
@@ -119,7 +119,7 @@ class KGWAS:
         rank, world = kdist.rank_world()
         if world > 1:
             kdist.broadcast_params(self.model)
-        st = ShardedTrainer(self, self.data.train_input_nodes, batch_size, lr=lr, weight_decay=weight_decay)
+        st = ShardedTrainer(self, self.data.train_input_nodes, batch_size, lr=lr, weight_decay=weight_decay, use_graph=use_graph)
         y_all = self.data.data['SNP'].y
 
         def evaluate(ids, model, drop_last=False):
@@ -138,6 +138,7 @@ class KGWAS:
                 st.step(step)
                 if (step % 500 == 0) and (step >= 500):
                     print_sys('Epoch {} Step {} Train Loss (this rank\'s share): {:.4f}'.format(ep + 1, step + 1, float(st.last_loss)))
+            st.check()                                      # (captured form: no batch overflowed the static layout)
             val_metrics = compute_metrics(evaluate(self.data.val_input_nodes[1], self.model, True), False, -1, -1, F.mse_loss)
             print_sys('Epoch {}: Validation MSE: {:.4f} Validation Pearson: {:.4f}. '.format(
                 ep + 1, val_metrics['mse'], val_metrics['pearsonr']))
@@ -165,7 +166,7 @@ class KGWAS:
             save_name = self.exp_name
         self.save_name = save_name
         if parallelism == 'shard':
-            return self._train_sharded(batch_size, lr, weight_decay, total_epoch, save_best_model, save_name)
+            return self._train_sharded(batch_size, lr, weight_decay, total_epoch, save_best_model, save_name, use_graph)
         if parallelism != 'seed':
             raise ValueError(f"parallelism {parallelism!r}: 'seed' or 'shard'")
         print_sys('Creating data loader...')

@@ -250,8 +250,9 @@ class _GatAggregate(torch.autograd.Function):
         dev = H.device
         dZf = dZ.contiguous() if z_rows else torch.zeros(1, KGW_C, device=dev)
         xchg = getattr(batch, 'exchange', None)
-        if xchg is not None and z_rows and xchg.mask[layer]:
+        if xchg is not None and z_rows and xchg.mask[layer] and not xchg.staged:
             # sharded mode: this rank's upstream gradient is partial; its own edges of the exchanged segments need the sum
+            # (staged form: the trainer summed it before it got here, see gat_aggregate)
             dZf = xchg.backward(batch, layer, dZf)
         adp = torch.empty(max(n_edges, 1), 2, device=dev)
         da_dst, ctx.da_dst = ctx.da_dst, None            # zeroed with Z in forward; consumed once
@@ -325,6 +326,13 @@ def gat_aggregate(batch, layer: int, H: torch.Tensor, U: torch.Tensor, V: torch.
     into layer 1, see fold_fc_output); differentiable."""
     stat, e_edge, Z = _GatAggregate.apply(H, U, V, batch, layer, float(neg_slope), 1.0 / float(temperature), raw_weights,
                                           relu_input, zbuf, logit_bias)
+    xchg = getattr(batch, 'exchange', None)
+    if xchg is not None and xchg.staged and xchg.mask[layer] and Z.requires_grad:
+        # SNP-sharded mode, step captured in segments: cut the autograd graph at the merged Z -- the trainer sums the gradient
+        # of this leaf over the ranks (a collective BETWEEN two graph segments) and continues the backward from Z
+        Zx = Z.detach().requires_grad_()
+        xchg.cuts.append((layer, Z, Zx))
+        Z = Zx
     return Z, stat, e_edge
 
 

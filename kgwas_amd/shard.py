@@ -49,10 +49,11 @@ def shard_range(n: int, rank: int, world: int):
     return n * rank // world, n * (rank + 1) // world
 
 
-def shard_graph(data: HeteroGraph, rank: int, world: int, sharded_type: str = 'SNP'):
+def shard_graph(data: HeteroGraph, rank: int, world: int, sharded_type: str = 'SNP', n_pad: int = 0):
     """Rank-local graph: nodes of ``sharded_type`` restricted to this rank's id range [lo, hi) and renumbered from 0,
-    every other type whole; a relation keeps the edges whose ``sharded_type`` endpoint the rank owns.  Returns
-    (local HeteroGraph, lo, hi)."""
+    every other type whole; a relation keeps the edges whose ``sharded_type`` endpoint the rank owns.  ``n_pad`` extra nodes of
+    the sharded type follow the owned ones (local ids hi - lo ...): zero features, no edges -- seeds of zero loss weight that pad
+    a rank's share of a batch to a fixed count (the static layout of a captured step).  Returns (local HeteroGraph, lo, hi)."""
     n = int(data[sharded_type].num_nodes)
     lo, hi = shard_range(n, rank, world)
     g = HeteroGraph()
@@ -60,9 +61,13 @@ def shard_graph(data: HeteroGraph, rank: int, world: int, sharded_type: str = 'S
         st = data[t]
         for k, v in st.items():
             if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == st.num_nodes:
-                g[t][k] = v[lo:hi] if t == sharded_type else v
+                if t == sharded_type:
+                    v = v[lo:hi]
+                    if n_pad:
+                        v = torch.cat([v, v.new_zeros((n_pad,) + tuple(v.shape[1:]))])
+                g[t][k] = v
             elif k == 'num_nodes_':
-                g[t][k] = (hi - lo) if t == sharded_type else v
+                g[t][k] = (hi - lo + n_pad) if t == sharded_type else v
     for et in data.edge_types:
         s, _, d = et
         ei = data[et].edge_index
@@ -82,6 +87,42 @@ def shard_graph(data: HeteroGraph, rank: int, world: int, sharded_type: str = 'S
     return g, lo, hi
 
 
+class SegmentedCapture:
+    """A step whose kernels are captured as HIP graphs with EAGER pieces (collectives) in between: ``cut(fn)`` ends the graph
+    being captured, registers ``fn`` to run between the graphs at replay, and starts the next graph (one shared memory pool, so
+    tensors allocated in one segment are the operands of the next and of the collectives).  While capturing, ``fn`` is NOT run
+    -- every rank skips it alike."""
+
+    def __init__(self, device):
+        self.items, self.pool, self.g = [], None, None
+        self.stream = torch.cuda.Stream(device=device)
+        self.capturing = False
+
+    def begin(self):
+        self.g = torch.cuda.CUDAGraph()
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        self.g.capture_begin(pool=self.pool)
+        self.capturing = True
+
+    def cut(self, fn):
+        self.g.capture_end()
+        self.items += [self.g, fn]
+        self.begin()
+
+    def end(self):
+        self.g.capture_end()
+        self.items.append(self.g)
+        self.g, self.capturing = None, False
+
+    def replay(self):
+        for it in self.items:
+            if isinstance(it, torch.cuda.CUDAGraph):
+                it.replay()
+            else:
+                it()
+
+
 class ShardExchange:
     """The collectives of the sharded mode for one rank-local DeviceGraph (see the module docstring)."""
 
@@ -96,6 +137,13 @@ class ShardExchange:
         # different collective sequence from its peers.
         self.flat_gather = self.multi and dist.get_backend(group) == 'nccl'
         self.collectives = {}                     # name -> [calls, bytes this rank handed to the collective]
+        # STAGED form (a step captured in segments, ShardedTrainer(use_graph=True)): the backward's exchange is not issued from
+        # inside the autograd node (the engine runs it on another thread: no place to end a capture) -- ops.gat_aggregate hands the
+        # downstream graph a detached leaf of the merged Z and lists (layer, Z, leaf) in ``cuts``; the trainer differentiates down
+        # to the leaves, exchanges their gradients itself (``backward``) and continues from Z.
+        self.staged = False
+        self.seg = None                           # SegmentedCapture while a step is being captured
+        self.cuts = []
         sc = dg.schema
         self.sharded = sc.type_id[sharded_type]
         self.dev = dg.device
@@ -126,6 +174,14 @@ class ShardExchange:
             self.slots[l] = {d: torch.tensor(sorted(v), dtype=torch.int32, device=self.dev) for d, v in by_type.items()}
         self.bytes_moved = 0
 
+    def _collective(self, fn):
+        """Run ``fn`` (a closure issuing collectives on persistent tensors) now -- or, while a step is being captured, end the
+        current graph segment, register ``fn`` to run between the segments at replay, and open the next one."""
+        if self.seg is not None and self.seg.capturing:
+            self.seg.cut(fn)
+        else:
+            fn()
+
     def _count(self, name: str, nbytes: int):
         c = self.collectives.setdefault(name, [0, 0])
         c[0] += 1
@@ -137,9 +193,12 @@ class ShardExchange:
         """Union of the ranks' PENDING flags on the replicated node types (KGW_PENDING = -2 < -1 = unsampled)."""
         if not self.multi:
             return
-        for lo, hi in self.rep_runs:
-            dist.all_reduce(buf.g2l[lo:hi], op=dist.ReduceOp.MIN, group=self.group)
-            self._count('all_reduce_min(frontier flags)', (hi - lo) * 4)
+
+        def fn():
+            for lo, hi in self.rep_runs:
+                dist.all_reduce(buf.g2l[lo:hi], op=dist.ReduceOp.MIN, group=self.group)
+                self._count('all_reduce_min(frontier flags)', (hi - lo) * 4)
+        self._collective(fn)
 
     # -- layer exchange ---------------------------------------------------------------------------------------------
     def seg_rows(self, batch: SampledBatch, layer: int) -> Optional[torch.Tensor]:
@@ -172,11 +231,14 @@ class ShardExchange:
         _lib.check(L.kgw_softmax_pack(_ptr(Z), _ptr(stat), _ptr(seg), n, _ptr(mine), _lib.stream_ptr()), 'kgw_softmax_pack')
         if self.multi:
             allp = torch.empty(self.world * n * PART_STRIDE, device=self.dev)
-            if self.flat_gather:
-                dist.all_gather_into_tensor(allp, mine, group=self.group)
-            else:
-                dist.all_gather(list(allp.view(self.world, -1).unbind(0)), mine, group=self.group)
-            self._count('all_gather(partial softmax states)', allp.numel() * 4)
+
+            def fn():
+                if self.flat_gather:
+                    dist.all_gather_into_tensor(allp, mine, group=self.group)
+                else:
+                    dist.all_gather(list(allp.view(self.world, -1).unbind(0)), mine, group=self.group)
+                self._count('all_gather(partial softmax states)', allp.numel() * 4)
+            self._collective(fn)
         else:
             allp = mine
         _lib.check(L.kgw_softmax_merge(_ptr(allp), self.world, _ptr(seg), n, _ptr(Z), _ptr(stat), _lib.stream_ptr()),
@@ -192,13 +254,16 @@ class ShardExchange:
         L = _lib.lib()
         rows = torch.empty(n, KGW_C, device=self.dev)
         _lib.check(L.kgw_gather_rows(_ptr(dZ), _ptr(seg), n, KGW_C, _ptr(rows), _lib.stream_ptr()), 'kgw_gather_rows')
-        dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group)
-        self._count('all_reduce_sum(dZ of exchanged segments)', rows.numel() * 4)
+
+        def fn():
+            dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group)
+            self._count('all_reduce_sum(dZ of exchanged segments)', rows.numel() * 4)
+        self._collective(fn)
         _lib.check(L.kgw_scatter_rows(_ptr(rows), _ptr(seg), n, KGW_C, _ptr(dZ), _lib.stream_ptr()), 'kgw_scatter_rows')
         return dZ
 
 
-def sample_sharded(dg: DeviceGraph, buf: BatchBuffers, seeds: torch.Tensor, seed_type: int, xchg: ShardExchange):
+def sample_sharded(dg: DeviceGraph, buf: BatchBuffers, seeds: torch.Tensor, seed_type: int, xchg: ShardExchange, record: bool = True):
     """kgw_sample_batch with the frontier merge between the two halves of every hop but the last."""
     st = torch.cuda.current_stream()
     L = _lib.lib()
@@ -212,7 +277,8 @@ def sample_sharded(dg: DeviceGraph, buf: BatchBuffers, seeds: torch.Tensor, seed
         begin = 2 * h + 1
     _lib.check(L.kgw_sample_batch_parts(C.byref(dg.kg), C.byref(buf.c), _ptr(seeds), n, seed_type, 0, begin, last,
                                         C.c_void_p(st.cuda_stream)), 'kgw_sample_batch_parts')
-    buf.ready.record(st)
+    if record:
+        buf.ready.record(st)
 
 
 class ShardedTrainer:
@@ -231,7 +297,12 @@ class ShardedTrainer:
         dev = torch.device(run.device)
         self.dev = dev
         full = run.data.data
-        self.local, self.lo, self.hi = shard_graph(full, self.rank, self.world, sharded_type)
+        # ``use_graph``: the step runs from captured HIP graphs, its collectives between them (SegmentedCapture).  That needs a
+        # STATIC layout: a rank's share of a batch is padded to a fixed seed count with zero-weight, edge-less pad nodes appended
+        # to its SNP range (they contribute nothing to loss, gradients or the exchange)
+        self.use_graph = bool(use_graph) and os.environ.get('KGW_SHARD_GRAPH', '1') == '1'
+        self.n_pad = self.batch_size if self.use_graph else 0
+        self.local, self.lo, self.hi = shard_graph(full, self.rank, self.world, sharded_type, n_pad=self.n_pad)
         L = run.gnn_num_layers
         self.dg = DeviceGraph(self.local, L, dev)
         self.xchg = ShardExchange(self.dg, sharded_type, group)
@@ -240,7 +311,9 @@ class ShardedTrainer:
         # collectives against (world - 1) / world of 0.27 ms); KGW_SHARD_GENE_LAYER=1/0 overrides.
         from . import ops
         env = os.environ.get('KGW_SHARD_GENE_LAYER')
-        on = self.xchg.multi and (self.world >= 4 if env is None else env == '1')
+        on = self.xchg.multi and (self.world >= 4 if env is None else env == '1') and not self.use_graph
+        # (captured form: the layer stays replicated for now -- its reduce-scatter would sit inside the autograd engine's thread,
+        #  where a capture cannot be cut; capturing the step is worth far more than the 0.2 ms the split saves)
         self.gene_shard = ops.GeneLayerShard(self.rank, self.world, group, inline=True) if on else None
         ops.GENE_SHARD = self.gene_shard
         self.seed_type = self.dg.schema.type_id[self.input_type]
@@ -261,16 +334,145 @@ class ShardedTrainer:
                 mine = np.zeros(1, dtype=np.int64)
             self.local_seeds.append(torch.from_numpy(mine).to(dev))
         self.ld_w = run._ld_weight_vector()[self.lo:self.hi].contiguous()
+        if self.n_pad:
+            self.ld_w = torch.cat([self.ld_w, self.ld_w.new_zeros(self.n_pad)])       # pad seeds: loss weight 0
         self.y = self.dg.y[self.input_type]
         from .optim import FusedAdam
         self.opt = FusedAdam(self.model.parameters(), lr=lr, weight_decay=weight_decay)
-        self.use_graph = False               # (the collectives sit between kernels of a step: issued eagerly)
         self._flat = None
         self._live = None
         self.last_loss = None
+        self.seg = None
+        if self.use_graph:
+            self._setup_static()
+
+    # ---- captured form ------------------------------------------------------------------------------------------------------
+    def _setup_static(self):
+        """Static layout + capture: (1) every batch's seed list padded to this rank's largest share; (2) a dry pass over all
+        batches (with the frontier merges: every rank takes part) measures the capacities; (3) warm-up steps in the staged eager
+        form (real collectives: allocator, Adam state, parameter liveness agreed), parameters restored; (4) ONE step captured
+        as graph segments with the collectives between them."""
+        from . import dist as kdist
+        dev, sc, L = self.dev, self.dg.schema, self.dg.num_layers
+        n_own = self.hi - self.lo
+        self.s_cap = max(1, max(int(t.numel()) if sc_ > 0 else 0 for t, sc_ in zip(self.local_seeds, self.loss_scale)))
+        seeds = []
+        for t, sc_ in zip(self.local_seeds, self.loss_scale):
+            real = t if sc_ > 0 else t[:0]
+            pad = torch.arange(n_own, n_own + self.s_cap - int(real.numel()), dtype=torch.int64, device=dev)
+            seeds.append(torch.cat([real, pad]))
+        self.seed_table = torch.stack(seeds)                       # [n_batches, s_cap] local ids, real seeds first
+        self.seeds_dev = torch.zeros(self.s_cap, dtype=torch.int64, device=dev)
+        # (2) capacities
+        node_off = np.zeros((sc.NT, L + 2), dtype=np.int64)
+        edges, chunks = np.zeros(L, dtype=np.int64), np.zeros(L, dtype=np.int64)
+        for i in range(self.n_batches):
+            sample_sharded(self.dg, self.buf, self.seed_table[i], self.seed_type, self.xchg)
+            self.buf.ready.synchronize()
+            m = self.buf.read_meta()
+            if m.error:
+                raise _lib.KgwasHipError(f'sampler capacity exceeded (error mask {m.error})')
+            for t in range(sc.NT):
+                for k in range(L + 2):
+                    node_off[t, k] = max(node_off[t, k], int(m.node_off[t][min(k, self.dg.n_hops + 1)]))
+            for l in range(L):
+                edges[l] = max(edges[l], int(m.n_edges[l])); chunks[l] = max(chunks[l], int(m.n_chunks[l]))
+
+        def up(v, hi=None):
+            w = int(-(-int(v * 1.03 + 1) // 64) * 64)
+            return min(w, hi) if hi is not None else w
+        for t in range(sc.NT):
+            for k in range(L + 2):
+                if k == 0:
+                    node_off[t, k] = 0
+                elif t == self.seed_type and k == 1:
+                    node_off[t, k] = self.s_cap
+                else:
+                    node_off[t, k] = up(node_off[t, k], hi=self.dg.n_nodes[t])
+            node_off[t] = np.maximum.accumulate(node_off[t])
+        from .sampler import BatchCaps
+        caps = BatchCaps(node_off.tolist(), [up(e) for e in edges], [up(c) for c in chunks])
+        # replicated types expand the same merged frontier on every rank: their capacities -- hence the exchanged row counts --
+        # must agree (checked, not assumed: a mismatch would size the all-gather differently per rank)
+        for t in range(sc.NT):
+            if t != self.xchg.sharded:
+                for k in range(L + 2):
+                    kdist.check_same_on_all_ranks(int(node_off[t, k]), f'capacity of replicated node type {sc.node_types[t]}, hop {k}')
+        self.dg_eager, self.buf_eager = self.dg, self.buf
+        self.dg = self.dg_eager.with_static_caps(caps)
+        self.buf = BatchBuffers(self.dg)
+        self.meta = self.dg.static_meta()
+        self.xchg.staged = True
+        self.loss_const = self.s_cap / self.batch_size              # mean over s_cap seeds (pads weigh 0) -> share of the batch mean
+        self.loss_dev = None
+        self.stats = torch.zeros(L + 2, dtype=torch.int64, device=dev)
+        # (3) warm-up, eager + staged
+        params = [p for p in self.model.parameters()]
+        snap = [p.detach().clone() for p in params]
+        for k in range(3):
+            self.seeds_dev.copy_(self.seed_table[0])
+            self._static_body()
+        torch.cuda.synchronize()
+        if int(self.buf.read_meta().error):
+            raise _lib.KgwasHipError('static layout of the sharded step does not fit its buffers')
+        with torch.no_grad():
+            for p, q in zip(params, snap):
+                p.copy_(q)
+            for st in self.opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+            self.opt.step_dev.zero_()
+        self.stats.zero_()
+        # (4) capture
+        self.seg = SegmentedCapture(dev)
+        self.xchg.seg = self.seg
+        torch.cuda.synchronize()
+        with torch.cuda.stream(self.seg.stream):
+            self.seg.begin()
+            self._static_body()
+            self.seg.end()
+        torch.cuda.current_stream().wait_stream(self.seg.stream)
+        self.xchg.seg = None
+        self.xchg.collectives, self.xchg.bytes_moved = {}, 0       # (count what the training steps move, not the set-up passes)
+
+    def _static_body(self):
+        """One training step on the seeds in ``seeds_dev`` with a static layout and the staged exchange; every collective goes
+        through ShardExchange._collective (run now, or turned into a cut between two graph segments while capturing)."""
+        xchg = self.xchg
+        sample_sharded(self.dg, self.buf, self.seeds_dev, self.seed_type, xchg, record=False)
+        batch = SampledBatch(self.dg, self.buf, self.meta, self.input_type, self.s_cap, static=True)
+        batch.exchange = xchg
+        xchg.cuts = []
+        for p in self.model.parameters():
+            p.grad = None
+        loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, self.s_cap, batch.n_id(self.input_type), self.y, self.ld_w)
+        part = loss * self.loss_const
+        # down to the leaves ops.gat_aggregate cut at the exchanged Z.  (retain_graph: parameter-side nodes -- the attention
+        # vectors, the FC_output fold -- feed both sides of a cut and are differentiated once per side, each time with the part
+        # of their output gradient that side produces: the parameter gradients accumulate to the same sums.)
+        cuts = [c for c in reversed(xchg.cuts)]
+        part.backward(retain_graph=bool(cuts))
+        for k, (layer, Z, Zx) in enumerate(cuts):
+            if Zx.grad is None:
+                continue
+            dZ = xchg.backward(batch, layer, Zx.grad)              # partial upstream gradient -> summed over the ranks
+            Z.backward(dZ, retain_graph=k + 1 < len(cuts))         # ... and on through this rank's own edges
+        xchg.cuts = []
+        self.allreduce_grads()
+        self.opt.step()
+        _lib.check(_lib.lib().kgw_accumulate_stats(self.buf.meta.data_ptr(), self.dg.num_layers, self.dg.n_hops,
+                                                   self.stats.data_ptr(), _lib.stream_ptr()), 'kgw_accumulate_stats')
+        self.loss_dev = part.detach()
+
+    def check(self):
+        """Synchronise; raise if a batch overflowed the static capacities (captured form)."""
+        torch.cuda.synchronize()
+        if self.use_graph and int(self.stats[-1]):
+            raise _lib.KgwasHipError(f'a batch exceeded the static capacities of the sharded step (error mask {int(self.stats[-1])})')
 
     def describe(self) -> str:
-        return ('eager launches; per step: 1 frontier all-reduce(MIN), 1 all-gather of partial softmax states + 1 all-reduce of '
+        return (('HIP-graph segments with the collectives between them' if self.use_graph else 'eager launches') + '; per step: 1 frontier all-reduce(MIN), 1 all-gather of partial softmax states + 1 all-reduce of '
                 'their dZ per exchanged layer, 1 flat gradient all-reduce (SUM)' +
                 ('; first gene Linear split by gene rows over the ranks (all-gather of its output, reduce-scatter of its dz)'
                  if self.gene_shard is not None else ''))
@@ -282,20 +484,32 @@ class ShardedTrainer:
             out.update({k: v for k, v in self.gene_shard.bytes.items() if v[0]})
         return out
 
+    def _eager(self):
+        """(graph, buffers) of the exact-size eager passes: inference, edge counting, the uncaptured training step."""
+        return (self.dg_eager, self.buf_eager) if self.use_graph else (self.dg, self.buf)
+
     def sample(self, i: int) -> SampledBatch:
         seeds = self.local_seeds[i % self.n_batches]
-        sample_sharded(self.dg, self.buf, seeds, self.seed_type, self.xchg)
-        torch.cuda.current_stream().wait_event(self.buf.ready)
-        self.buf.ready.synchronize()
-        meta = self.buf.read_meta()
+        dg, buf = self._eager()
+        sample_sharded(dg, buf, seeds, self.seed_type, self.xchg)
+        torch.cuda.current_stream().wait_event(buf.ready)
+        buf.ready.synchronize()
+        meta = buf.read_meta()
         if meta.error:
             raise _lib.KgwasHipError(f'sampler capacity exceeded (error mask {meta.error})')
-        batch = SampledBatch(self.dg, self.buf, meta, self.input_type, int(seeds.numel()))
+        batch = SampledBatch(dg, buf, meta, self.input_type, int(seeds.numel()))
         batch.exchange = self.xchg
         return batch
 
+    def count_edges(self, i: int):
+        """(edges the step's kernels aggregate, edges the reference would touch) for batch i, every edge of the GLOBAL batch
+        counted once across the ranks -- an exact-size sampling pass outside any timing (collective: every rank calls it)."""
+        return self._count_edges(self.sample(i))
+
     def forward_backward(self, i: int):
         """Loss contribution of this rank's seeds (their weighted squared errors / batch_size) and its backward."""
+        if self.use_graph:
+            raise NotImplementedError('forward_backward is the uncaptured form: ShardedTrainer(use_graph=False)')
         batch = self.sample(i)
         n = batch.batch_size
         for p in self.model.parameters():
@@ -315,16 +529,9 @@ class ShardedTrainer:
         if self._flat is None:
             self._flat = torch.empty(sum(p.numel() for p in params), device=self.dev)
         flat = self._flat
-        off = 0
-        had = []
-        for p in params:
-            n = p.numel()
-            had.append(p.grad is not None)
-            if p.grad is None:
-                flat[off:off + n].zero_()
-            else:
-                flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
+        had = [p.grad is not None for p in params]
+        # one launch for the whole bucket (zeros for the parameters without a gradient on this rank)
+        torch.cat([p.grad.reshape(-1) if p.grad is not None else p.new_zeros(p.numel()) for p in params], out=flat)
         if self.xchg.multi:
             # which parameters are live is structural (the same relations / MLPs reach the read-out on every rank) except for
             # a node type or relation that happens to be empty on one shard: live = live on ANY rank, agreed once (first step)
@@ -332,8 +539,10 @@ class ShardedTrainer:
                 live = torch.tensor(had, dtype=torch.int32, device=self.dev)
                 dist.all_reduce(live, op=dist.ReduceOp.MAX, group=self.xchg.group)
                 self._live = [bool(v) for v in live.cpu().tolist()]
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.xchg.group)
-            self.xchg._count('all_reduce_sum(parameter gradients)', flat.numel() * 4)
+            def fn():
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.xchg.group)
+                self.xchg._count('all_reduce_sum(parameter gradients)', flat.numel() * 4)
+            self.xchg._collective(fn)
             had = self._live
         off = 0
         for p, h in zip(params, had):
@@ -345,9 +554,9 @@ class ShardedTrainer:
         """(edges this step's kernels aggregated, edges the reference would touch) counting every edge of the GLOBAL batch
         once across the ranks: an edge with a sharded endpoint exists on exactly one rank, an edge between replicated
         types on all of them (counted by rank 0 only)."""
-        m, dg = batch.meta, self.dg
+        m, dg = batch.meta, batch.dg
         sc, L = dg.schema, dg.num_layers
-        sp = self.buf.seg_ptr
+        sp = batch.buf.seg_ptr
         idx, wk, wr = [], [], []
         for h in range(dg.n_hops):
             for r in range(sc.NR):
@@ -364,6 +573,11 @@ class ShardedTrainer:
         return int((cnt * np.asarray(wk)).sum()), int((cnt * np.asarray(wr)).sum())
 
     def step(self, i: int):
+        if self.use_graph:
+            self.seeds_dev.copy_(self.seed_table[i % self.n_batches])
+            self.seg.replay()
+            self.last_loss = self.loss_dev
+            return None
         batch, part, _ = self.forward_backward(i)
         self.allreduce_grads()
         self.opt.step()
@@ -393,13 +607,14 @@ class ShardedTrainer:
             # (a rank without a seed in the batch still takes part in the exchange: it samples an arbitrary owned node)
             mine = b[sel] - self.lo if len(sel) else np.zeros(1, dtype=np.int64)
             seeds = torch.from_numpy(np.ascontiguousarray(mine)).to(self.dev)
-            sample_sharded(self.dg, self.buf, seeds, self.seed_type, self.xchg)
-            torch.cuda.current_stream().wait_event(self.buf.ready)
-            self.buf.ready.synchronize()
-            meta = self.buf.read_meta()
+            dg, buf = self._eager()
+            sample_sharded(dg, buf, seeds, self.seed_type, self.xchg)
+            torch.cuda.current_stream().wait_event(buf.ready)
+            buf.ready.synchronize()
+            meta = buf.read_meta()
             if meta.error:
                 raise _lib.KgwasHipError(f'sampler capacity exceeded (error mask {meta.error})')
-            batch = SampledBatch(self.dg, self.buf, meta, self.input_type, int(seeds.numel()))
+            batch = SampledBatch(dg, buf, meta, self.input_type, int(seeds.numel()))
             batch.exchange = self.xchg
             p = self.model(batch.x_dict, batch.edge_index_dict, int(seeds.numel())).reshape(-1)
             if len(sel):

@@ -433,3 +433,58 @@ def test_sharded_mode_with_the_gene_layer_split_by_rows_equals_single_process(tm
         g = g.detach().cpu().double()
         err = float((r0['grads'][k].double() - g).abs().max())
         assert err <= 2e-4 * float(g.abs().max()) + 1e-6, (k, err)
+
+
+def _graph_worker(rank, world, port, out_dir, which):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from kgwas_amd import dist as kdist
+        from kgwas_amd.shard import ShardedTrainer
+        out = {}
+        for use_graph in (False, True):
+            data, run = _make_run(which)
+            kdist.broadcast_params(run.model)
+            run.model.train()
+            ids = _ids(data)[:BS * 4]
+            if which == 'edge':                                   # a batch whose seeds all lie in rank 0's range
+                ids = np.concatenate([ids[:BS], np.sort(ids)[:BS], ids[BS:2 * BS]])
+            st = ShardedTrainer(run, ('SNP', ids), BS, lr=1e-3, weight_decay=5e-4, use_graph=use_graph)
+            assert st.use_graph == use_graph
+            losses = []
+            for i in range(st.n_batches):
+                st.step(i)
+                losses.append(float(st.last_loss))
+            st.check() if use_graph else None
+            out[use_graph] = {'params': {k: v.detach().cpu() for k, v in run.model.named_reference_tensors().items()},
+                              'losses': losses, 'pred': st.predict(ids[:BS + 7]).cpu(),
+                              'segments': len(st.seg.items) if use_graph else 0, 'collectives': st.collectives()}
+        torch.save(out, os.path.join(out_dir, f'g{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('which', ['small', 'edge'])
+def test_captured_sharded_step_equals_the_uncaptured_one(tmp_path, which):
+    """ShardedTrainer(use_graph=True): static layout (a rank's share of a batch padded with zero-weight pad nodes), the staged
+    exchange, the step replayed from graph segments with the collectives between them -- against the uncaptured step on the
+    same batches: per-rank loss shares, parameters after every batch's Adam step, sharded inference.  'edge': one batch has no
+    seed in rank 1's range (all of its seeds are pads there)."""
+    world = 2
+    mp.start_processes(_graph_worker, args=(world, _free_port(), str(tmp_path), which), nprocs=world, join=True, start_method='spawn')
+    recs = [torch.load(os.path.join(tmp_path, f'g{r}.pt'), weights_only=False) for r in range(world)]
+    for r in recs:
+        e, g = r[False], r[True]
+        assert g['segments'] >= 7                                  # graphs and collectives alternate
+        for a, b in zip(e['losses'], g['losses']):
+            assert abs(a - b) <= 1e-5 * abs(a) + 1e-7, (e['losses'], g['losses'])
+        for k in e['params']:
+            d = float((e['params'][k].double() - g['params'][k].double()).abs().max())
+            scale = float(e['params'][k].double().abs().max())
+            assert d <= 5e-5 * max(scale, 1e-6) + 3e-6, (k, d, scale)
+        assert torch.allclose(e['pred'], g['pred'], rtol=1e-4, atol=1e-5)
+        assert set(e['collectives']) == set(g['collectives'])
+    for k in recs[0][True]['params']:
+        assert torch.equal(recs[0][True]['params'][k], recs[1][True]['params'][k]), k
