@@ -54,14 +54,29 @@ def _uniform_(t: torch.Tensor, a: float):
     return t
 
 
-class SimpleMLP(nn.Module):
-    """kgwas/model.py:10-22."""
+def _padded_linear(in_l: int, out_l: int, in_p: int, out_p: int) -> nn.Linear:
+    """nn.Linear(in_l, out_l) with its default initialisation, stored zero-padded as [out_p, in_p] (see HeteroGNN: a hidden width
+    below 128 runs on the 128-wide kernels; the padding stays exactly zero through training)."""
+    if (in_l, out_l) == (in_p, out_p):
+        return nn.Linear(in_p, out_p)
+    src = nn.Linear(in_l, out_l)
+    lin = nn.Linear(in_p, out_p)
+    with torch.no_grad():
+        lin.weight.zero_(); lin.bias.zero_()
+        lin.weight[:out_l, :in_l].copy_(src.weight)
+        lin.bias[:out_l].copy_(src.bias)
+    return lin
 
-    def __init__(self, input_dim, hidden_dim, output_dim):
+
+class SimpleMLP(nn.Module):
+    """kgwas/model.py:10-22.  ``c_logical``: the model's hidden width when it is below the kernels' 128 (zero-padded storage)."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, c_logical=None):
         super().__init__()
-        self.FC_hidden = nn.Linear(input_dim, hidden_dim)
-        self.FC_hidden2 = nn.Linear(hidden_dim, hidden_dim)
-        self.FC_output = nn.Linear(hidden_dim, output_dim)
+        cl = hidden_dim if c_logical is None else c_logical
+        self.FC_hidden = _padded_linear(input_dim, cl, input_dim, hidden_dim)
+        self.FC_hidden2 = _padded_linear(cl, cl, hidden_dim, hidden_dim)
+        self.FC_output = _padded_linear(cl, cl, hidden_dim, output_dim)
         self.ReLU = nn.ReLU()
 
     def first(self, x, fixed_shape=False):
@@ -103,7 +118,7 @@ class RelationPack(nn.Module):
     j-th bipartite relation (same-type relations never materialise lin_dst in the reference),
     ``att_src`` / ``att_dst`` (glorot on [1,1,C]), ``bias`` (zeros)."""
 
-    def __init__(self, edge_types: List[EdgeType], rel_ids: List[int], C: int):
+    def __init__(self, edge_types: List[EdgeType], rel_ids: List[int], C: int, c_logical: int = None):
         super().__init__()
         self.n_rels_total = len(edge_types)
         self.rel_ids = list(rel_ids)
@@ -112,12 +127,24 @@ class RelationPack(nn.Module):
         bip = [i for i, et in enumerate(self.rel_types) if et[0] != et[2]]
         self.bip = bip
         self.bip_pos = {i: j for j, i in enumerate(bip)}
-        a_w = math.sqrt(6.0 / (C + C))          # glorot on [C_out, C_in]
-        a_a = math.sqrt(6.0 / (1 + C))          # glorot on [1, heads=1, C]
-        self.w_src_t = nn.Parameter(_uniform_(torch.empty(n, C, C), a_w))
-        self.w_dst_t = nn.Parameter(_uniform_(torch.empty(len(bip), C, C), a_w))
-        self.att_src = nn.Parameter(_uniform_(torch.empty(n, C), a_a))
-        self.att_dst = nn.Parameter(_uniform_(torch.empty(n, C), a_a))
+        cl = self.cl = C if c_logical is None else c_logical      # the model's width; storage is C (= 128) wide, zero beyond cl
+        a_w = math.sqrt(6.0 / (cl + cl))        # glorot on [C_out, C_in]
+        a_a = math.sqrt(6.0 / (1 + cl))         # glorot on [1, heads=1, C]
+
+        def block(shape, a):
+            if cl == C:
+                return _uniform_(torch.empty(*shape), a)
+            t = torch.zeros(*shape)
+            with torch.no_grad():
+                if len(shape) == 3:
+                    t[:, :cl, :cl].uniform_(-a, a)
+                else:
+                    t[:, :cl].uniform_(-a, a)
+            return t
+        self.w_src_t = nn.Parameter(block((n, C, C), a_w))
+        self.w_dst_t = nn.Parameter(block((len(bip), C, C), a_w))
+        self.att_src = nn.Parameter(block((n, C), a_a))
+        self.att_dst = nn.Parameter(block((n, C), a_a))
         self.bias = nn.Parameter(torch.zeros(n, C))
         self.register_buffer('rel_ids_t', torch.tensor(rel_ids, dtype=torch.long), persistent=False)
         self.register_buffer('bip_t', torch.tensor(bip, dtype=torch.long), persistent=False)
@@ -138,30 +165,32 @@ class RelationPack(nn.Module):
             if grad:
                 return None if p.grad is None else p.grad
             return p.detach()
+        cl = self.cl
         if field == 'lin_src.weight':
             t = pick(self.w_src_t)
-            return None if t is None else t[i].t()
+            return None if t is None else t[i, :cl, :cl].t()
         if field == 'lin_dst.weight':
             if i not in self.bip_pos:
                 return 'lazy'
             t = pick(self.w_dst_t)
-            return None if t is None else t[self.bip_pos[i]].t()
+            return None if t is None else t[self.bip_pos[i], :cl, :cl].t()
         t = pick(getattr(self, field))
         if t is None:
             return None
-        return t[i].view(1, 1, -1) if field.startswith('att') else t[i]
+        return t[i, :cl].reshape(1, 1, -1) if field.startswith('att') else t[i, :cl]
 
     def set(self, i: int, field: str, value: torch.Tensor):
+        cl = self.cl
         with torch.no_grad():
             if field == 'lin_src.weight':
-                self.w_src_t[i].copy_(value.t())
+                self.w_src_t[i, :cl, :cl].copy_(value.t())
             elif field == 'lin_dst.weight':
                 if i in self.bip_pos:
-                    self.w_dst_t[self.bip_pos[i]].copy_(value.t())
+                    self.w_dst_t[self.bip_pos[i], :cl, :cl].copy_(value.t())
             elif field.startswith('att'):
-                getattr(self, field)[i].copy_(value.reshape(-1))
+                getattr(self, field)[i, :cl].copy_(value.reshape(-1))
             else:
-                getattr(self, field)[i].copy_(value)
+                getattr(self, field)[i, :cl].copy_(value)
 
 
 class SagePack(nn.Module):
@@ -172,15 +201,24 @@ class SagePack(nn.Module):
 
     FIELDS = ('lin_l.weight', 'lin_l.bias', 'lin_r.weight')
 
-    def __init__(self, edge_types: List[EdgeType], rel_ids: List[int], C: int):
+    def __init__(self, edge_types: List[EdgeType], rel_ids: List[int], C: int, c_logical: int = None):
         super().__init__()
         self.n_rels_total = len(edge_types)
         self.rel_ids = list(rel_ids)
         n = len(rel_ids)
-        a = 1.0 / math.sqrt(C)                     # nn.Linear's default (kaiming_uniform a=sqrt(5)) bound for fan_in = C
-        self.w_l_t = nn.Parameter(_uniform_(torch.empty(n, C, C), a))
-        self.bias = nn.Parameter(_uniform_(torch.empty(n, C), a))
-        self.w_r_t = nn.Parameter(_uniform_(torch.empty(n, C, C), a))
+        cl = self.cl = C if c_logical is None else c_logical
+        a = 1.0 / math.sqrt(cl)                    # nn.Linear's default (kaiming_uniform a=sqrt(5)) bound for fan_in = cl
+
+        def block(shape):
+            if cl == C:
+                return _uniform_(torch.empty(*shape), a)
+            t = torch.zeros(*shape)
+            with torch.no_grad():
+                (t[:, :cl, :cl] if len(shape) == 3 else t[:, :cl]).uniform_(-a, a)
+            return t
+        self.w_l_t = nn.Parameter(block((n, C, C)))
+        self.bias = nn.Parameter(block((n, C)))
+        self.w_r_t = nn.Parameter(block((n, C, C)))
         self._sel_cache = {}
 
     def get(self, i: int, field: str, grad: bool = False):
@@ -188,14 +226,16 @@ class SagePack(nn.Module):
         t = p.grad if grad else p.detach()
         if t is None:
             return None
-        return t[i] if field == 'lin_l.bias' else t[i].t()
+        cl = self.cl
+        return t[i, :cl] if field == 'lin_l.bias' else t[i, :cl, :cl].t()
 
     def set(self, i: int, field: str, value: torch.Tensor):
+        cl = self.cl
         with torch.no_grad():
             if field == 'lin_l.bias':
-                self.bias[i].copy_(value)
+                self.bias[i, :cl].copy_(value)
             else:
-                (self.w_l_t if field == 'lin_l.weight' else self.w_r_t)[i].copy_(value.t())
+                (self.w_l_t if field == 'lin_l.weight' else self.w_r_t)[i, :cl, :cl].copy_(value.t())
 
 
 class HeteroGNN(nn.Module):
@@ -215,8 +255,9 @@ class HeteroGNN(nn.Module):
                                       "built; 'cat' widens the hidden state to R*128 and breaks the reference's own "
                                       "read-out (kgwas/model.py:50), like gat_num_head > 1")
         self.aggr = gnn_aggr
-        if hidden_channels != 128:
-            raise NotImplementedError('the fused kernels are specialised for gnn_hidden_dim=128')
+        if not 1 <= hidden_channels <= 128:
+            raise NotImplementedError('gnn_hidden_dim > 128: the fused kernels are 128 wide (narrower models run on them '
+                                      'zero-padded; wider ones would need a second instantiation of every kernel -- DESIGN.md section 8)')
         if gat_num_head != 1:
             raise NotImplementedError('gat_num_head > 1 breaks the reference read-out (model.py:50 expects '
                                       'hidden_channels inputs); only heads=1 is supported')
@@ -225,6 +266,12 @@ class HeteroGNN(nn.Module):
         self.schema = GraphSchema(self.node_types, self.edge_types)
         sc = self.schema
         self.num_layers = num_layers
+        # gnn_hidden_dim < 128 (kgwas/kgwas.py:52): the model is embedded in the 128-wide kernels -- every hidden tensor and
+        # parameter zero-padded to 128.  Exact: padded channels are 0 after every Linear / ReLU, padded parameters receive a
+        # gradient of exactly 0 (their inputs or their output gradients are 0) and Adam with L2 leaves 0 at 0; checkpoints,
+        # state_dict and gradients are exposed at the model's own width.  Costs what 128 costs.
+        self.hidden_logical = cl = int(hidden_channels)
+        hidden_channels = 128
         self.hidden = hidden_channels
         self.negative_slope, self.temperature = 0.2, 1.0          # conv.py:43,50 defaults (model.py:40-42)
         self.rel_fields = REL_FIELDS if gnn_backbone == 'GAT' else SagePack.FIELDS
@@ -238,8 +285,8 @@ class HeteroGNN(nn.Module):
             order = [r for t in range(sc.NT) for r in sc.rels_by_dst[t] if r in live]   # grouped by dst type
             dead = [r for r in range(sc.NR) if r not in live]
             Pack = RelationPack if gnn_backbone == 'GAT' else SagePack
-            self.live_packs.append(Pack(self.edge_types, order, hidden_channels))
-            self.dead_packs.append(Pack(self.edge_types, dead, hidden_channels))
+            self.live_packs.append(Pack(self.edge_types, order, hidden_channels, cl))
+            self.dead_packs.append(Pack(self.edge_types, dead, hidden_channels, cl))
             slot = {r: ('live', i) for i, r in enumerate(order)}
             slot.update({r: ('dead', i) for i, r in enumerate(dead)})
             self._slot.append(slot)
@@ -251,11 +298,11 @@ class HeteroGNN(nn.Module):
                     rng[t] = (lo, lo + k)
                     lo += k
             self._dst_range.append(rng)
-        self.snp_feat_mlp = SimpleMLP(snp_init_dim_size, hidden_channels, hidden_channels)
-        self.go_feat_mlp = SimpleMLP(go_init_dim_size, hidden_channels, hidden_channels)
-        self.gene_feat_mlp = SimpleMLP(gene_init_dim_size, hidden_channels, hidden_channels)
+        self.snp_feat_mlp = SimpleMLP(snp_init_dim_size, hidden_channels, hidden_channels, cl)
+        self.go_feat_mlp = SimpleMLP(go_init_dim_size, hidden_channels, hidden_channels, cl)
+        self.gene_feat_mlp = SimpleMLP(gene_init_dim_size, hidden_channels, hidden_channels, cl)
         self.ReLU = nn.ReLU()
-        self.lin = nn.Linear(hidden_channels, out_channels)
+        self.lin = _padded_linear(cl, out_channels, hidden_channels, out_channels)
         self.no_relu = no_relu
         self.last_attention = None
         # FC_output of the feature MLPs folded into the layer-1 relation parameters (ops.fold_fc_output): exact, removes a
@@ -548,7 +595,7 @@ class HeteroGNN(nn.Module):
         snp = h['SNP']
         out = self._readout(snp[:batch_size])
         if return_h:                                            # model.py:78-79
-            return self.ReLU(out), snp[:batch_size]
+            return self.ReLU(out), snp[:batch_size, :self.hidden_logical]
         if self.no_relu:                                        # model.py:83-84
             return out
         return self.ReLU(out)                                   # model.py:86
@@ -745,6 +792,24 @@ class HeteroGNN(nn.Module):
                 for f in self.rel_fields:
                     yield f'convs.{l}.convs.{edge_key(et)}.{f}', pack.get(i, f, grad)
 
+    def _dense_items(self, grad: bool = False, keep_vars: bool = False):
+        """(reference key, tensor at the model's own width) of the feature MLPs and the read-out."""
+        cl = self.hidden_logical
+        for prefix, mod in (('snp_feat_mlp', self.snp_feat_mlp), ('go_feat_mlp', self.go_feat_mlp),
+                            ('gene_feat_mlp', self.gene_feat_mlp), ('lin', self.lin)):
+            for n, p in mod.named_parameters():
+                t = p.grad if grad else (p if keep_vars else p.detach())
+                if t is not None and cl != self.hidden:
+                    if prefix == 'lin':
+                        t = t[:, :cl] if n == 'weight' else t
+                    elif n == 'FC_hidden.weight':
+                        t = t[:cl]
+                    elif n.endswith('weight'):
+                        t = t[:cl, :cl]
+                    else:
+                        t = t[:cl]
+                yield f'{prefix}.{n}', t
+
     def named_reference_tensors(self, grad: bool = False) -> "OrderedDict[str, Optional[torch.Tensor]]":
         """Parameters (or their gradients) under the reference's names.  Lazy lin_dst of same-type relations
         is omitted; structurally dead relations have gradient None."""
@@ -753,20 +818,16 @@ class HeteroGNN(nn.Module):
             if isinstance(v, str):
                 continue
             out[k] = v
-        for prefix, mod in (('snp_feat_mlp', self.snp_feat_mlp), ('go_feat_mlp', self.go_feat_mlp),
-                            ('gene_feat_mlp', self.gene_feat_mlp), ('lin', self.lin)):
-            for n, p in mod.named_parameters():
-                out[f'{prefix}.{n}'] = (p.grad if grad else p.detach())
+        for k, t in self._dense_items(grad):
+            out[k] = t
         return out
 
     def state_dict(self, *args, destination=None, prefix='', keep_vars=False):
         out = OrderedDict() if destination is None else destination
         for k, v in self._rel_items():
             out[prefix + k] = torch.nn.parameter.UninitializedParameter() if isinstance(v, str) else v.clone()
-        for name, mod in (('snp_feat_mlp', self.snp_feat_mlp), ('go_feat_mlp', self.go_feat_mlp),
-                          ('gene_feat_mlp', self.gene_feat_mlp), ('lin', self.lin)):
-            for n, p in mod.state_dict(keep_vars=keep_vars).items():
-                out[f'{prefix}{name}.{n}'] = p
+        for k, t in self._dense_items(keep_vars=keep_vars):
+            out[prefix + k] = t
         return out
 
     def load_state_dict(self, state_dict, strict=True, **kw):
@@ -791,13 +852,17 @@ class HeteroGNN(nn.Module):
         missing = [k for k, (l, r, f) in want.items() if k not in seen and
                    not (f == 'lin_dst.weight' and self.edge_types[r][0] == self.edge_types[r][2])]
         unexpected = []
-        for name, mod in (('snp_feat_mlp', self.snp_feat_mlp), ('go_feat_mlp', self.go_feat_mlp),
-                          ('gene_feat_mlp', self.gene_feat_mlp), ('lin', self.lin)):
-            sub = OrderedDict((k[len(name) + 1:], v) for k, v in rest.items() if k.startswith(name + '.'))
-            res = mod.load_state_dict(sub, strict=False)
-            missing += [f'{name}.{k}' for k in res.missing_keys]
-            unexpected += [f'{name}.{k}' for k in res.unexpected_keys]
         known = ('snp_feat_mlp.', 'go_feat_mlp.', 'gene_feat_mlp.', 'lin.')
+        with torch.no_grad():
+            for k, dst in self._dense_items():              # (views of the padded storage at the model's own width)
+                if k in rest:
+                    if tuple(rest[k].shape) != tuple(dst.shape):
+                        raise RuntimeError(f'load_state_dict: {k} has shape {tuple(rest[k].shape)}, the model expects {tuple(dst.shape)}')
+                    dst.copy_(rest[k])
+                else:
+                    missing.append(k)
+        have = {k for k, _ in self._dense_items()}
+        unexpected += [k for k in rest if k.startswith(known) and k not in have]
         unexpected += [k for k in rest if not k.startswith(known)]
         if strict and (missing or unexpected):
             raise RuntimeError(f'load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}')

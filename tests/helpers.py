@@ -14,7 +14,7 @@ def product_dims(model):
 
 def oracle_from_product(model, dtype=torch.float64):
     snp, gene, go = product_dims(model)
-    o = HeteroGNNOracle(model.edge_types, model.hidden, model.lin.out_features, model.num_layers,
+    o = HeteroGNNOracle(model.edge_types, getattr(model, 'hidden_logical', model.hidden), model.lin.out_features, model.num_layers,
                         getattr(model, 'backbone', 'GAT'), getattr(model, 'aggr', 'sum'),
                         snp, gene, go, 1, no_relu=model.no_relu, dtype=dtype)
     sd = OrderedDict()

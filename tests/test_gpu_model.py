@@ -81,6 +81,60 @@ def test_forward_backward_matches_reference_restatement(small_kg, edge_case_grap
         or float((out.flatten().cpu().double() - out_o.flatten()).abs().max()) < 1e-6
 
 
+@pytest.mark.parametrize('hc', [64, 20])
+def test_hidden_width_below_128_matches_the_restatement_at_that_width(small_kg, hc):
+    """gnn_hidden_dim (kgwas/kgwas.py:52) below the kernels' 128: the model runs zero-padded on the 128-wide kernels and must
+    equal the reference restatement BUILT AT THAT WIDTH -- prediction, loss, every gradient (exposed at the model's own width) --
+    and stay inside its block through Adam steps with weight decay (the padding receives exactly zero gradient)."""
+    from kgwas_amd.kgwas import KGWAS
+    run = KGWAS(small_kg, device='cuda:0', seed=13)
+    run.initialize_model(gnn_hidden_dim=hc)
+    model = run.model
+    assert model.hidden_logical == hc and run.config['gnn_hidden_dim'] == hc
+    with torch.no_grad():
+        for pack in list(model.live_packs) + list(model.dead_packs):
+            pack.bias[:, :hc].normal_(0, 0.1)
+    oracle = oracle_from_product(model)
+    assert oracle.lin.in_features == hc
+    ids = np.asarray(small_kg.train_input_nodes[1][:3 * 64])
+    ld_w = run._ld_weight_vector()
+    y_all = small_kg.data['SNP'].y.double()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
+    model.train()
+    for k, batch in enumerate(_loader(small_kg.data, ids, 64)):
+        if k == 0:
+            out = model(batch.x_dict, batch.edge_index_dict, 64)
+            n_id = batch.n_id('SNP')[:64].long()
+            loss = weighted_mse(out, y_all[n_id.cpu()].cuda(), ld_w[n_id])
+            loss.backward()
+            x, ei = batch_cpu(batch)
+            out_o = oracle(x, ei, 64)
+            loss_o = weighted_mse(out_o, y_all[n_id.cpu()], ld_w[n_id].cpu())
+            loss_o.backward()
+            assert_close(out, out_o.detach(), RTOL, ATOL, 'pred')
+            go = grads_by_name(oracle)
+            n_live = 0
+            for name, g in grads_by_name(model).items():
+                if g is None:
+                    continue
+                assert g.shape == go[name].shape, name
+                assert_close(g, go[name], RTOL, max(ATOL, 1e-4 * float(go[name].abs().max())), f'grad {name}')
+                n_live += 1
+            assert n_live > 10
+            model.zero_grad(set_to_none=True)
+        run.train_step(batch, opt, ld_w)
+    for p in model.parameters():                      # three Adam steps later the padding is still exactly zero
+        if p.dim() == 3 and p.shape[-1] == 128:
+            assert float(p[:, hc:, :].abs().sum()) == 0.0 and float(p[:, :, hc:].abs().sum()) == 0.0
+        elif p.dim() == 2 and p.shape[-1] == 128 and p.shape[0] != 128:
+            assert float(p[:, hc:].abs().sum()) == 0.0
+    for mlp in (model.snp_feat_mlp, model.gene_feat_mlp, model.go_feat_mlp):
+        assert float(mlp.FC_hidden.weight[hc:].abs().sum()) == 0.0 and float(mlp.FC_hidden2.weight[hc:].abs().sum()) == 0.0
+        assert float(mlp.FC_hidden2.weight[:, hc:].abs().sum()) == 0.0 and float(mlp.FC_output.bias[hc:].abs().sum()) == 0.0
+    p, h = model(batch.x_dict, batch.edge_index_dict, 64, return_h=True)
+    assert h.shape == (64, hc)
+
+
 def test_minibatch_equals_full_graph(edge_case_graph):
     """the seeds' minibatch output equals the full-graph 2-layer output (generic
     (x_dict, edge_index_dict) entry of HeteroGNN.forward = every row, every layer)."""
