@@ -311,9 +311,9 @@ class ShardedTrainer:
         # collectives against (world - 1) / world of 0.27 ms); KGW_SHARD_GENE_LAYER=1/0 overrides.
         from . import ops
         env = os.environ.get('KGW_SHARD_GENE_LAYER')
-        on = self.xchg.multi and (self.world >= 4 if env is None else env == '1') and not self.use_graph
-        # (captured form: the layer stays replicated for now -- its reduce-scatter would sit inside the autograd engine's thread,
-        #  where a capture cannot be cut; capturing the step is worth far more than the 0.2 ms the split saves)
+        on = self.xchg.multi and (self.world >= 4 if env is None else env == '1')
+        # (captured form: the STAGED variant -- partial product and all-gather ahead of the forward, reduce-scatter and the partial
+        #  weight gradient after the backward, all at the trainer's level where a capture can be cut: _static_body)
         self.gene_shard = ops.GeneLayerShard(self.rank, self.world, group, inline=True) if on else None
         ops.GENE_SHARD = self.gene_shard
         self.seed_type = self.dg.schema.type_id[self.input_type]
@@ -412,6 +412,15 @@ class ShardedTrainer:
         for k in range(3):
             self.seeds_dev.copy_(self.seed_table[0])
             self._static_body()
+            gs = self.gene_shard
+            if k == 0 and gs is not None:
+                # the first warm-up step ran the gene-layer shard INLINE (fine outside a capture) -- which also tells whether the
+                # model takes the resident route for the gene features at all; from here on the stages run at this level
+                if gs.last is None:
+                    from . import ops
+                    self.gene_shard = ops.GENE_SHARD = None
+                else:
+                    gs.inline = False
         torch.cuda.synchronize()
         if int(self.buf.read_meta().error):
             raise _lib.KgwasHipError('static layout of the sharded step does not fit its buffers')
@@ -440,6 +449,11 @@ class ShardedTrainer:
         """One training step on the seeds in ``seeds_dev`` with a static layout and the staged exchange; every collective goes
         through ShardExchange._collective (run now, or turned into a cut between two graph segments while capturing)."""
         xchg = self.xchg
+        gs = self.gene_shard
+        staged = gs is not None and not gs.inline
+        if staged:                       # this rank's rows of the first gene Linear, then everybody's (batch independent)
+            gs.forward_partial(*gs.last)
+            xchg._collective(gs.gather)
         sample_sharded(self.dg, self.buf, self.seeds_dev, self.seed_type, xchg, record=False)
         batch = SampledBatch(self.dg, self.buf, self.meta, self.input_type, self.s_cap, static=True)
         batch.exchange = xchg
@@ -459,6 +473,9 @@ class ShardedTrainer:
             dZ = xchg.backward(batch, layer, Zx.grad)              # partial upstream gradient -> summed over the ranks
             Z.backward(dZ, retain_graph=k + 1 < len(cuts))         # ... and on through this rank's own edges
         xchg.cuts = []
+        if staged:                       # dz summed over the ranks for the rows this rank owns -> its partial of the weight gradient
+            xchg._collective(gs.scatter)
+            gs.last[1].grad = gs.weight_grad_partial(gs.last[0])
         self.allreduce_grads()
         self.opt.step()
         _lib.check(_lib.lib().kgw_accumulate_stats(self.buf.meta.data_ptr(), self.dg.num_layers, self.dg.n_hops,

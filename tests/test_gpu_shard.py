@@ -404,8 +404,17 @@ def _wide_shard_worker(rank, world, port, out_dir):
         grads = {k: (None if v is None else v.detach().cpu().clone()) for k, v in run.model.named_reference_tensors(grad=True).items()}
         st.opt.step()
         st.step(1)
-        torch.save({'grads': grads, 'params': {k: v.detach().cpu() for k, v in run.model.named_reference_tensors().items()},
-                    'collectives': st.collectives()}, os.path.join(out_dir, f'ws{rank}.pt'))
+        params = {k: v.detach().cpu() for k, v in run.model.named_reference_tensors().items()}
+        coll = st.collectives()
+        # the same two steps in the CAPTURED form (staged gene-layer shard: stages at the trainer's level, between graph segments)
+        data2, run2, _ = _wide_run()
+        run2.model.train()
+        st2 = ShardedTrainer(run2, ('SNP', ids[:512 * 2]), 512, lr=1e-3, weight_decay=5e-4, use_graph=True)
+        assert st2.use_graph and st2.gene_shard is not None and not st2.gene_shard.inline
+        st2.step(0); st2.step(1); st2.check()
+        params_g = {k: v.detach().cpu() for k, v in run2.model.named_reference_tensors().items()}
+        torch.save({'grads': grads, 'params': params, 'params_graph': params_g, 'collectives': coll,
+                    'collectives_graph': st2.collectives()}, os.path.join(out_dir, f'ws{rank}.pt'))
     finally:
         dist.destroy_process_group()
 
@@ -420,7 +429,10 @@ def test_sharded_mode_with_the_gene_layer_split_by_rows_equals_single_process(tm
     r0, r1 = (torch.load(os.path.join(tmp_path, f'ws{r}.pt'), weights_only=False) for r in range(world))
     for k in r0['params']:
         assert torch.equal(r0['params'][k], r1['params'][k]), k
-    assert any('gene layer' in k for k in r0['collectives'])
+        assert torch.equal(r0['params_graph'][k], r1['params_graph'][k]), k
+        d = float((r0['params_graph'][k].double() - r0['params'][k].double()).abs().max())
+        assert d <= 5e-5 * max(float(r0['params'][k].double().abs().max()), 1e-6) + 3e-6, (k, d)      # captured == uncaptured
+    assert any('gene layer' in k for k in r0['collectives']) and any('gene layer' in k for k in r0['collectives_graph'])
     from kgwas_amd.sampler import NeighborLoader
     data, run, ids = _wide_run()
     run.model.train()
