@@ -87,15 +87,64 @@ def shard_graph(data: HeteroGraph, rank: int, world: int, sharded_type: str = 'S
     return g, lo, hi
 
 
+def _streams_on_own_queues(device, group, multi: bool, n: int = 2, tries: int = 16):
+    """``n`` streams that really run BESIDE each other AND beside the collective backend's stream.  HIP maps streams onto a few
+    hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in creation order; two streams on one queue execute one after the other
+    whatever the program says, and a REPLAYED GRAPH RUNS ON THE QUEUE OF THE STREAM IT WAS CAPTURED ON, not of the stream it is
+    launched into.  Measured on the captured sharded step (one RCCL rank): 1.72 ms with the sampler's graphs on the step's queue,
+    1.37 ms beside it; raising the queue count globally is no cure (16 queues: the seed-parallel step 1.25 -> 2.5 ms).  Which pool
+    stream lands where depends on how many streams the process made before, so the choice is MEASURED: a busy stretch -- a spin
+    kernel on an already chosen stream, a 64 MB all-reduce on the backend's stream -- and a tiny kernel on the candidate that
+    must finish long before it.  Every rank runs the same sequence of collectives."""
+    dev = torch.device(device)
+    main = torch.cuda.current_stream(dev)
+    x = torch.zeros(64, device=dev)
+    big = torch.zeros(16 << 20, device=dev) if multi else None
+
+    def beside(busy, cand):
+        torch.cuda.synchronize(dev)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        if busy is None:                                   # the collective backend's stream
+            e0.record(main)
+            dist.all_reduce(big, group=group)              # (the main stream waits for it)
+            e1.record(main)
+        else:
+            with torch.cuda.stream(busy):
+                e0.record(busy)
+                torch.cuda._sleep(200_000)
+                e1.record(busy)
+        with torch.cuda.stream(cand):
+            cand.wait_event(e0)
+            x.add_(1.0)
+            e2.record(cand)
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e2) < 0.5 * e0.elapsed_time(e1)
+
+    chosen, spare = [], []
+    for _ in range(tries):
+        if len(chosen) == n:
+            break
+        cand = torch.cuda.Stream(device=dev)
+        spare.append(cand)
+        ok = beside(None, cand) if multi else True         # (every test on every candidate: the ranks stay in step)
+        for c in chosen:
+            ok = beside(c, cand) and ok
+        if ok:
+            chosen.append(cand)
+    while len(chosen) < n:                                 # (no free queue found: correctness does not depend on it)
+        chosen.append(spare[len(chosen) % len(spare)])
+    return chosen
+
+
 class SegmentedCapture:
     """A step whose kernels are captured as HIP graphs with EAGER pieces (collectives) in between: ``cut(fn)`` ends the graph
     being captured, registers ``fn`` to run between the graphs at replay, and starts the next graph (one shared memory pool, so
     tensors allocated in one segment are the operands of the next and of the collectives).  While capturing, ``fn`` is NOT run
     -- every rank skips it alike."""
 
-    def __init__(self, device):
+    def __init__(self, device, stream=None):
         self.items, self.pool, self.g = [], None, None
-        self.stream = torch.cuda.Stream(device=device)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=device)
         self.capturing = False
 
     def begin(self):
@@ -400,18 +449,31 @@ class ShardedTrainer:
                     kdist.check_same_on_all_ranks(int(node_off[t, k]), f'capacity of replicated node type {sc.node_types[t]}, hop {k}')
         self.dg_eager, self.buf_eager = self.dg, self.buf
         self.dg = self.dg_eager.with_static_caps(caps)
-        self.buf = BatchBuffers(self.dg)
+        # two batch buffers: while the step computes on one, the NEXT batch is sampled into the other on a side stream (its
+        # frontier merge is a collective of that stream's segment list)
+        self.overlap = os.environ.get('KGW_SHARD_OVERLAP_SAMPLING', '1') == '1'
+        from .graph_step import SIDE_SAMPLER_GRID               # (a sampler beside a step keeps its launches small)
+        grid = int(os.environ.get('KGW_SHARD_SAMPLER_GRID', SIDE_SAMPLER_GRID if self.overlap else 0))
+        self.bufs = [BatchBuffers(self.dg, grid), BatchBuffers(self.dg, grid)]
+        self.buf = self.bufs[0]
+        self.seeds2 = [self.seeds_dev, torch.zeros_like(self.seeds_dev)]
         self.meta = self.dg.static_meta()
         self.xchg.staged = True
         self.loss_const = self.s_cap / self.batch_size              # mean over s_cap seeds (pads weigh 0) -> share of the batch mean
-        self.loss_dev = None
+        self.loss_dev = [None, None]
+        # (the stream the step's graphs are captured on, and the one the sampler's are captured on AND replayed on)
+        self._cap_stream, self._side = _streams_on_own_queues(dev, self.xchg.group, self.xchg.multi)
+        self._sampled = [torch.cuda.Event(), torch.cuda.Event()]
+        self._pending = [False, False]
+        self._have = [-1, -1]
         self.stats = torch.zeros(L + 2, dtype=torch.int64, device=dev)
         # (3) warm-up, eager + staged
         params = [p for p in self.model.parameters()]
         snap = [p.detach().clone() for p in params]
         for k in range(3):
-            self.seeds_dev.copy_(self.seed_table[0])
-            self._static_body()
+            self.seeds2[k % 2].copy_(self.seed_table[0])
+            self._sample_body(k % 2)
+            self._compute_body(k % 2)
             gs = self.gene_shard
             if k == 0 and gs is not None:
                 # the first warm-up step ran the gene-layer shard INLINE (fine outside a capture) -- which also tells whether the
@@ -422,8 +484,9 @@ class ShardedTrainer:
                 else:
                     gs.inline = False
         torch.cuda.synchronize()
-        if int(self.buf.read_meta().error):
-            raise _lib.KgwasHipError('static layout of the sharded step does not fit its buffers')
+        for b in self.bufs:
+            if int(b.read_meta().error):
+                raise _lib.KgwasHipError('static layout of the sharded step does not fit its buffers')
         with torch.no_grad():
             for p, q in zip(params, snap):
                 p.copy_(q)
@@ -434,28 +497,38 @@ class ShardedTrainer:
             self.opt.step_dev.zero_()
         self.stats.zero_()
         # (4) capture
-        self.seg = SegmentedCapture(dev)
-        self.xchg.seg = self.seg
+        self.samp_seg, self.comp_seg = [], []
         torch.cuda.synchronize()
-        with torch.cuda.stream(self.seg.stream):
-            self.seg.begin()
-            self._static_body()
-            self.seg.end()
-        torch.cuda.current_stream().wait_stream(self.seg.stream)
+        for b in (0, 1):
+            for body, lst in ((self._sample_body, self.samp_seg), (self._compute_body, self.comp_seg)):
+                # (a replayed graph runs on the hardware queue of the stream it was CAPTURED on: the sampler's segments are
+                #  captured on the side stream they are replayed on, the step's on one stream of their own)
+                seg = SegmentedCapture(dev, self._side if body == self._sample_body else self._cap_stream)
+                self.xchg.seg = seg
+                with torch.cuda.stream(seg.stream):
+                    seg.begin()
+                    body(b)
+                    seg.end()
+                torch.cuda.current_stream().wait_stream(seg.stream)
+                lst.append(seg)
+        self.seg = self.comp_seg[0]
         self.xchg.seg = None
         self.xchg.collectives, self.xchg.bytes_moved = {}, 0       # (count what the training steps move, not the set-up passes)
 
-    def _static_body(self):
-        """One training step on the seeds in ``seeds_dev`` with a static layout and the staged exchange; every collective goes
-        through ShardExchange._collective (run now, or turned into a cut between two graph segments while capturing)."""
+    def _sample_body(self, b: int):
+        """Sampling of the seeds in ``seeds2[b]`` into ``bufs[b]`` (static layout; the frontier merge goes through
+        ShardExchange._collective like every collective: run now, or a cut between two graph segments while capturing)."""
+        sample_sharded(self.dg, self.bufs[b], self.seeds2[b], self.seed_type, self.xchg, record=False)
+
+    def _compute_body(self, b: int):
+        """One training step on the batch held by ``bufs[b]``: static layout, staged exchange."""
         xchg = self.xchg
         gs = self.gene_shard
         staged = gs is not None and not gs.inline
         if staged:                       # this rank's rows of the first gene Linear, then everybody's (batch independent)
             gs.forward_partial(*gs.last)
             xchg._collective(gs.gather)
-        sample_sharded(self.dg, self.buf, self.seeds_dev, self.seed_type, xchg, record=False)
-        batch = SampledBatch(self.dg, self.buf, self.meta, self.input_type, self.s_cap, static=True)
+        batch = SampledBatch(self.dg, self.bufs[b], self.meta, self.input_type, self.s_cap, static=True)
         batch.exchange = xchg
         xchg.cuts = []
         for p in self.model.parameters():
@@ -478,9 +551,9 @@ class ShardedTrainer:
             gs.last[1].grad = gs.weight_grad_partial(gs.last[0])
         self.allreduce_grads()
         self.opt.step()
-        _lib.check(_lib.lib().kgw_accumulate_stats(self.buf.meta.data_ptr(), self.dg.num_layers, self.dg.n_hops,
+        _lib.check(_lib.lib().kgw_accumulate_stats(self.bufs[b].meta.data_ptr(), self.dg.num_layers, self.dg.n_hops,
                                                    self.stats.data_ptr(), _lib.stream_ptr()), 'kgw_accumulate_stats')
-        self.loss_dev = part.detach()
+        self.loss_dev[b] = part.detach()
 
     def check(self):
         """Synchronise; raise if a batch overflowed the static capacities (captured form)."""
@@ -591,9 +664,28 @@ class ShardedTrainer:
 
     def step(self, i: int):
         if self.use_graph:
-            self.seeds_dev.copy_(self.seed_table[i % self.n_batches])
-            self.seg.replay()
-            self.last_loss = self.loss_dev
+            cur, nb = i % 2, self.n_batches
+            main = torch.cuda.current_stream()
+            if self._have[cur] != i % nb:                          # first call / non-sequential access: sample it now
+                self.seeds2[cur].copy_(self.seed_table[i % nb])
+                self.samp_seg[cur].replay()
+                self._have[cur], self._pending[cur] = i % nb, False
+            if self.overlap:
+                # the NEXT batch, on the side stream beside this step (the previous step, reader of that buffer, is enqueued
+                # on the main stream already).  Its frontier all-reduce is issued before this step's collectives on every rank.
+                nxt = (i + 1) % nb
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    self.seeds2[1 - cur].copy_(self.seed_table[nxt])
+                    self.samp_seg[1 - cur].replay()
+                    self._sampled[1 - cur].record(self._side)
+                self._have[1 - cur], self._pending[1 - cur] = nxt, True
+            if self._pending[cur]:
+                main.wait_event(self._sampled[cur])
+                self._pending[cur] = False
+            self.comp_seg[cur].replay()
+            self._have[cur] = -1
+            self.last_loss = self.loss_dev[cur]
             return None
         batch, part, _ = self.forward_backward(i)
         self.allreduce_grads()

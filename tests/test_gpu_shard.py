@@ -472,7 +472,7 @@ def _graph_worker(rank, world, port, out_dir, which):
             st.check() if use_graph else None
             out[use_graph] = {'params': {k: v.detach().cpu() for k, v in run.model.named_reference_tensors().items()},
                               'losses': losses, 'pred': st.predict(ids[:BS + 7]).cpu(),
-                              'segments': len(st.seg.items) if use_graph else 0, 'collectives': st.collectives()}
+                              'segments': (len(st.comp_seg[0].items) + len(st.samp_seg[0].items)) if use_graph else 0, 'collectives': st.collectives()}
         torch.save(out, os.path.join(out_dir, f'g{rank}.pt'))
     finally:
         dist.destroy_process_group()
