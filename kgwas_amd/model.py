@@ -89,7 +89,7 @@ class SimpleMLP(nn.Module):
                             out)
 
     def tail2(self, h1, out=None):
-        """relu(FC_hidden2(h1)): the MLP without FC_output (folded into layer 1, ops.fold_fc_output)."""
+        """relu(FC_hidden2(h1)): the MLP without FC_output (folded into layer 1, ops.fold_fc_output_hip)."""
         return ops.mlp_tail2(h1, self.FC_hidden2.weight, self.FC_hidden2.bias, out)
 
     def hidden(self, x, out=None, rows_dev=None, ids=None):
@@ -305,7 +305,7 @@ class HeteroGNN(nn.Module):
         self.lin = _padded_linear(cl, out_channels, hidden_channels, out_channels)
         self.no_relu = no_relu
         self.last_attention = None
-        # FC_output of the feature MLPs folded into the layer-1 relation parameters (ops.fold_fc_output): exact, removes a
+        # FC_output of the feature MLPs folded into the layer-1 relation parameters (ops.fold_fc_output_hip): exact, removes a
         # 128 x 128 Linear (forward, dX, dW) over every sampled node.  GAT with a relation SUM only: SAGE has a root term and
         # min / max are not linear in the messages.
         import os
@@ -473,15 +473,24 @@ class HeteroGNN(nn.Module):
                 z0 = int(m.z_base[l - 1][t])
                 if self.aggr in ('min', 'max'):
                     zr = Z[z0:z0 + rows * R].view(rows, R, C).transpose(0, 1)                    # [R, rows, C]
-                    ops.LIBRARY_GEMM.note('sage min/max per-relation outputs', R, rows, C)
-                    o = torch.baddbmm(P.bias[lo:hi].unsqueeze(1), zr, P.w_l_t[lo:hi]) + \
-                        torch.matmul(h[name][:rows].unsqueeze(0), P.w_r_t[lo:hi])
+                    if ops.LIBRARY_GEMM.strict:          # (library-free form: one own-kernel product per relation and term)
+                        hr = h[name][:rows].contiguous()
+                        zero = torch.zeros(C, device=dev)
+                        o = torch.stack([ops.linear_act(zr[r].contiguous(), P.w_l_t[lo + r], P.bias[lo + r], relu=False) +
+                                         ops.linear_act(hr, P.w_r_t[lo + r], zero, relu=False) for r in range(R)])
+                    else:
+                        ops.LIBRARY_GEMM.note('sage min/max per-relation outputs', R, rows, C)
+                        o = torch.baddbmm(P.bias[lo:hi].unsqueeze(1), zr, P.w_l_t[lo:hi]) + \
+                            torch.matmul(h[name][:rows].unsqueeze(0), P.w_r_t[lo:hi])
                     h_next[name] = torch.relu(self._combine_relations(o))
                     continue
                 x = Z[z0:z0 + rows * R].view(rows, R * C)
                 y = ops.linear_act(x, P.w_l_t[lo:hi].reshape(R * C, C), P.bias[lo:hi].sum(0), relu=False)
-                ops.LIBRARY_GEMM.note('sage root term', rows, C, C)
-                y = y + h[name][:rows] @ P.w_r_t[lo:hi].sum(0)            # root term: sum_r lin_r^r(h_d[i])
+                if ops.LIBRARY_GEMM.strict:
+                    y = y + ops.linear_act(h[name][:rows].contiguous(), P.w_r_t[lo:hi].sum(0), torch.zeros(C, device=dev), relu=False)
+                else:
+                    ops.LIBRARY_GEMM.note('sage root term', rows, C, C)
+                    y = y + h[name][:rows] @ P.w_r_t[lo:hi].sum(0)        # root term: sum_r lin_r^r(h_d[i])
                 if self.aggr == 'mean':
                     y = y * (1.0 / R)
                 h_next[name] = torch.relu(y)
@@ -521,7 +530,7 @@ class HeteroGNN(nn.Module):
     def _fused_layers(self, batch: SampledBatch, h: Dict[str, torch.Tensor], want_attention=False, hbuf=None,
                       last_premasked=False, folded=False, prep=None):
         """``folded``: h holds the feature MLPs' hidden state h2 (``_embed_all(fold=True)``), not their output: layer 1 runs
-        with FC_output folded into its relation parameters (ops.fold_fc_output).  ``prep``: per layer, what
+        with FC_output folded into its relation parameters (ops.fold_fc_output_hip).  ``prep``: per layer, what
         ``_layer_params`` returns, computed ahead by the caller."""
         if self.backbone == 'SAGE':
             if want_attention:
@@ -563,8 +572,11 @@ class HeteroGNN(nn.Module):
                 for (lo, hi, z0, rows) in blocks:
                     R = hi - lo
                     zr = Z[z0:z0 + rows * R].view(rows, R, C).transpose(0, 1)
-                    ops.LIBRARY_GEMM.note('gat min/max per-relation outputs', R, rows, C)
-                    o = torch.baddbmm(P.bias[lo:hi].unsqueeze(1), zr, Wv[lo:hi])
+                    if ops.LIBRARY_GEMM.strict:
+                        o = torch.stack([ops.linear_act(zr[r].contiguous(), Wv[lo + r], P.bias[lo + r], relu=False) for r in range(R)])
+                    else:
+                        ops.LIBRARY_GEMM.note('gat min/max per-relation outputs', R, rows, C)
+                        o = torch.baddbmm(P.bias[lo:hi].unsqueeze(1), zr, Wv[lo:hi])
                     outs.append(torch.relu(self._combine_relations(o)))
                 h = {sc.node_types[t]: o for t, o in zip(tys, outs)}
                 continue

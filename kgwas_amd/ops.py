@@ -323,7 +323,7 @@ def gat_aggregate(batch, layer: int, H: torch.Tensor, U: torch.Tensor, V: torch.
     produced it expects its incoming gradient ALREADY multiplied by (H > 0): the source-side backward does it while
     writing dH (see layer_transform's ``premasked``).  ``zbuf``: an ``aggregate_workspace`` that is ALREADY zero.
     ``logit_bias`` [n_rels]: constant added to the pre-activation logit of every edge of a relation (FC_output folded
-    into layer 1, see fold_fc_output); differentiable."""
+    into layer 1, see fold_fc_output_hip); differentiable."""
     stat, e_edge, Z = _GatAggregate.apply(H, U, V, batch, layer, float(neg_slope), 1.0 / float(temperature), raw_weights,
                                           relu_input, zbuf, logit_bias)
     xchg = getattr(batch, 'exchange', None)
@@ -514,7 +514,9 @@ def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask
                                        1 if relu else 0, 1 if w_kn else 0, _p(ws), nws, _p(rows_dev), _lib.stream_ptr()),
                    'kgw_linear_splitk')
         return Y
-    if K % 4 and K <= _LIN_MAX_K and X.dtype == torch.float32 and (rows >= 8192 or (rows >= 4096 and K <= 128 and N <= 128)):
+    # (strict mode: the package's own kernel whenever it CAN run -- the row thresholds below are performance choices)
+    big = LIBRARY_GEMM.strict or rows >= 8192 or (rows >= 4096 and K <= 128 and N <= 128)
+    if K % 4 and K <= _LIN_MAX_K and X.dtype == torch.float32 and big and rows > 0:
         # a reduction length that is not a multiple of 4 (the 70-wide mode='full' SNP features, kgwas_data.py:167): zero-pad it --
         # an elementwise copy of X and of the (small) weight, then this package's kernel; never the library for this
         Kp = (K + 3) & ~3
@@ -526,7 +528,7 @@ def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask
           and (not w_kn or N % 4 == 0) and (mask is None or mask.stride(1) == 1)
           # 128-row tiles, no split over K: problems with few row tiles stay on the library (measured at 1171 rows,
           # K = 128, N = 1536 / 2176 -- the dZ product of a layer transform: 9 / 18.5 us there vs 23 / 24 us here)
-          and (rows >= 8192 or (rows >= 4096 and K <= 128 and N <= 128)))
+          and big)
     if not ok:
         Y = _library_linear(X, W, bias, relu, mask, w_kn, out, fixed_shape)
         if rows_dev is not None:          # padding rows of a static layout: zeros, whatever the inputs held there
@@ -751,6 +753,8 @@ def resident_first_weight_grad(dz, X, W, gs=None):
             return gs.weight_grad_partial(X)
         Xt = _resident_copies(X)[1]                      # [K, Np], Np = the node count rounded up to 32, zero columns past it
         return gemm3(Xt, gemm3_pack(dz, Xt.shape[1], True, k_valid=X.shape[0]), transpose_out=True)
+    if LIBRARY_GEMM.strict and 0 < dz.shape[0] and X.dtype == torch.float32:
+        return tn_gemm(dz, X)
     LIBRARY_GEMM.note('resident_first_weight_grad', dz.shape[0], dz.shape[1], X.shape[1])
     with _TUNED:
         return dz.t().mm(X)
@@ -888,7 +892,7 @@ class _MLP3(torch.autograd.Function):
 
 class _MLP2(torch.autograd.Function):
     """h2 = relu(FC_hidden2(relu(FC_hidden(x)))) -- SimpleMLP without its last Linear (kgwas/model.py:18-20), for a
-    feature matrix that needs no gradient.  FC_output is folded into the layer-1 relation parameters (fold_fc_output),
+    feature matrix that needs no gradient.  FC_output is folded into the layer-1 relation parameters (fold_fc_output_hip),
     and the consumer of h2 (gat_aggregate(relu_input=True)) hands back a gradient ALREADY multiplied by (h2 > 0)."""
 
     @staticmethod
@@ -1151,7 +1155,7 @@ class _LinearAct(torch.autograd.Function):
     def backward(ctx, dy):
         x, y, Wt = ctx.saved_tensors
         dz = torch.ops.aten.threshold_backward(dy.contiguous(), y, 0.0) if ctx.relu else dy.contiguous()
-        if x.shape[0] >= _TN_MIN_ROWS:
+        if x.shape[0] >= _TN_MIN_ROWS or (LIBRARY_GEMM.strict and x.shape[0] > 0):
             dWt = tn_gemm(x, dz)                                                       # [K,N]
         else:
             LIBRARY_GEMM.note('linear_act.backward', x.shape[0], x.shape[1], dz.shape[1])
@@ -1168,7 +1172,7 @@ def linear_act(x, Wt, b, relu=True):
 def linear_weight_grad(dY: torch.Tensor, X: torch.Tensor, fixed_shape: bool = False, rows_dev: torch.Tensor = None):
     """(dW [out,in], db [out]) of Y = X W^T + b given dY [rows,out], X [rows,in]."""
     rows, K = X.shape
-    if rows >= _TN_MIN_ROWS and K <= 1024:
+    if (rows >= _TN_MIN_ROWS and K <= 1024) or (LIBRARY_GEMM.strict and rows > 0 and X.dtype == torch.float32):
         return tn_gemm(dY, X, colsum=True, rows_dev=rows_dev)
     LIBRARY_GEMM.note('linear_weight_grad', rows, dY.shape[1], K)
     if fixed_shape:
@@ -1377,7 +1381,7 @@ def layer_transform(pack, Z, blocks, out_blocks=None, premasked=False, bias_sum=
 
 
 class _FoldFC(torch.autograd.Function):
-    """fold_fc_output on the HIP kernels (kgw_fold_fwd / kgw_fold_bwd): two launches instead of ~40 framework ops."""
+    """fold_fc_output_hip's autograd node (kgw_fold_fwd / kgw_fold_bwd): two launches instead of ~40 framework ops."""
 
     @staticmethod
     def forward(ctx, w_src_t, U, V, pack, tab, *fc):
@@ -1431,12 +1435,6 @@ class _FoldFC(torch.autograd.Function):
 
 
 def fold_fc_output_hip(pack, U, V, fc_params, tab, weight=None):
-    """fold_fc_output on the HIP kernels.  ``fc_params``: [weight_0, bias_0, weight_1, bias_1, ...] = FC_output of the MLPs
-    (nn.Linear layout); ``tab`` = (rel ids, source MLP, destination MLP) of the packed relations as int32 numpy arrays."""
-    return _FoldFC.apply(pack.w_src_t if weight is None else weight, U, V, pack, tab, *fc_params)
-
-
-def fold_fc_output(pack, U, V, T3, c3, src_m, dst_m):
     """Fold the last Linear of the feature MLPs, H = h2 T_m + c_m (FC_output, kgwas/model.py:15,21; m = the MLP of the node's
     type), into the layer-1 relation parameters -- exact, like aggregate-then-transform: H enters GATConv (which has no
     root term) only linearly, as the message sum_j alpha_ij H_j and through the logit projections <H_j, u_r>, <H_i, v_r>
@@ -1444,24 +1442,11 @@ def fold_fc_output(pack, U, V, T3, c3, src_m, dst_m):
         U'_r = T_src U_r,  V'_r = T_dst V_r,  kappa_r = <c_src, U_r> + <c_dst, V_r>         (logits)
         W'_r = T_src W_r^T (the packed [in, out] form),  gamma_r = c_src W_r^T                (transform; gamma is added
         wherever the segment is not empty: sum_j alpha_ij = 1)
-    ``U``, ``V`` [n_rels, C] by relation id (rel_vectors); ``T3`` [n_mlp, C, C] = FC_output.weight^T, ``c3`` [n_mlp, C];
-    ``src_m`` / ``dst_m`` [n] long: MLP index of the source / destination type of every packed relation.
+    on the HIP kernels kgw_fold_fwd / kgw_fold_bwd (tests/helpers.py:fold_fc_output_reference is the same in framework ops,
+    float64).  ``fc_params``: [weight_0, bias_0, weight_1, bias_1, ...] = FC_output of the MLPs (nn.Linear layout); ``tab`` =
+    (rel ids, source MLP, destination MLP) of the packed relations as int32 numpy arrays.
     Returns (U' [n_rels,C], V' [n_rels,C], kappa [n_rels] by relation id; W' [n,C,C], gamma [n,C] by packed slot)."""
-    LIBRARY_GEMM.note('fold_fc_output (framework-op reference of kgw_fold_fwd)', pack.w_src_t.shape[0], KGW_C, KGW_C)
-    ids = pack.rel_ids_t
-    Ui, Vi = U[ids], V[ids]
-    Ts, Td = T3[src_m], T3[dst_m]
-    cs, cd = c3[src_m], c3[dst_m]
-    Wp = torch.bmm(Ts, pack.w_src_t)
-    Up = torch.bmm(Ts, Ui.unsqueeze(-1)).squeeze(-1)
-    Vp = torch.bmm(Td, Vi.unsqueeze(-1)).squeeze(-1)
-    kap = (cs * Ui).sum(-1) + (cd * Vi).sum(-1)
-    gam = torch.bmm(cs.unsqueeze(1), pack.w_src_t).squeeze(1)
-    NR = U.shape[0]
-    Uf = torch.zeros_like(U).index_copy(0, ids, Up)
-    Vf = torch.zeros_like(V).index_copy(0, ids, Vp)
-    kf = torch.zeros(NR, device=U.device, dtype=U.dtype).index_copy(0, ids, kap)
-    return Uf, Vf, kf, Wp, gam
+    return _FoldFC.apply(pack.w_src_t if weight is None else weight, U, V, pack, tab, *fc_params)
 
 
 # ------------------------------------------------------------------------------------------------------

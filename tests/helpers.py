@@ -71,3 +71,31 @@ def global_edge_set(batch, et):
     pairs = np.stack([ns[ei[0]], nd[ei[1]]], axis=1) if ei.shape[1] else np.zeros((0, 2), np.int64)
     order = np.lexsort((pairs[:, 0], pairs[:, 1]))
     return pairs[order]
+
+
+def fold_fc_output_reference(pack, U, V, T3, c3, src_m, dst_m):
+    """Test reference of kgwas_amd.ops.fold_fc_output_hip (kgw_fold_fwd / kgw_fold_bwd) in framework ops + autograd.
+    Fold the last Linear of the feature MLPs, H = h2 T_m + c_m (FC_output, kgwas/model.py:15,21; m = the MLP of the node's
+    type), into the layer-1 relation parameters -- exact, like aggregate-then-transform: H enters GATConv (which has no
+    root term) only linearly, as the message sum_j alpha_ij H_j and through the logit projections <H_j, u_r>, <H_i, v_r>
+    (kgwas/conv.py:150-152,227-228).  With layer 1 running on h2:
+        U'_r = T_src U_r,  V'_r = T_dst V_r,  kappa_r = <c_src, U_r> + <c_dst, V_r>         (logits)
+        W'_r = T_src W_r^T (the packed [in, out] form),  gamma_r = c_src W_r^T                (transform; gamma is added
+        wherever the segment is not empty: sum_j alpha_ij = 1)
+    ``U``, ``V`` [n_rels, C] by relation id (rel_vectors); ``T3`` [n_mlp, C, C] = FC_output.weight^T, ``c3`` [n_mlp, C];
+    ``src_m`` / ``dst_m`` [n] long: MLP index of the source / destination type of every packed relation.
+    Returns (U' [n_rels,C], V' [n_rels,C], kappa [n_rels] by relation id; W' [n,C,C], gamma [n,C] by packed slot)."""
+    ids = pack.rel_ids_t
+    Ui, Vi = U[ids], V[ids]
+    Ts, Td = T3[src_m], T3[dst_m]
+    cs, cd = c3[src_m], c3[dst_m]
+    Wp = torch.bmm(Ts, pack.w_src_t)
+    Up = torch.bmm(Ts, Ui.unsqueeze(-1)).squeeze(-1)
+    Vp = torch.bmm(Td, Vi.unsqueeze(-1)).squeeze(-1)
+    kap = (cs * Ui).sum(-1) + (cd * Vi).sum(-1)
+    gam = torch.bmm(cs.unsqueeze(1), pack.w_src_t).squeeze(1)
+    NR = U.shape[0]
+    Uf = torch.zeros_like(U).index_copy(0, ids, Up)
+    Vf = torch.zeros_like(V).index_copy(0, ids, Vp)
+    kf = torch.zeros(NR, device=U.device, dtype=U.dtype).index_copy(0, ids, kap)
+    return Uf, Vf, kf, Wp, gam

@@ -1,6 +1,6 @@
 """-m gpu: FC_output folded into the layer-1 relation parameters (kgw_fold_fwd / kgw_fold_bwd, kgw_linear_splitk_ind,
 kgw_ind_colsum, the logit constant of kgw_gat_aggregate_fwd) -- the HIP kernels against the same algebra written with
-framework ops in float64 (ops.fold_fc_output + autograd), and the folded model against the unfolded one.  The folded
+framework ops in float64 (tests.helpers.fold_fc_output_reference + autograd), and the folded model against the unfolded one.  The folded
 model is what every other parity test (oracle, committed vectors) runs."""
 import os
 
@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import assert_close
+from tests.helpers import assert_close, fold_fc_output_reference
 
 pytestmark = pytest.mark.gpu
 
@@ -38,7 +38,7 @@ def test_fold_kernels_match_the_framework_formulation():
     fc64 = [t.detach().double().requires_grad_(True) for t in fc]
     T3 = torch.stack([fc64[2 * m].t() for m in range(3)])
     c3 = torch.stack([fc64[2 * m + 1] for m in range(3)])
-    ref = ops.fold_fc_output(p64, U64, V64, T3, c3, torch.from_numpy(sm).long().cuda(), torch.from_numpy(dm).long().cuda())
+    ref = fold_fc_output_reference(p64, U64, V64, T3, c3, torch.from_numpy(sm).long().cuda(), torch.from_numpy(dm).long().cuda())
     names = ('U', 'V', 'kappa', 'W', 'gamma')
     for nm, a, b in zip(names, outs, ref):
         assert_close(a, b, 1e-5, 1e-6, f'fold fwd {nm}', rel_to_max=2e-6)

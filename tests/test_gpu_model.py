@@ -30,6 +30,21 @@ def _model(data, dims, seed=0, L=2, backbone='GAT', aggr='sum', **kw):
     return m
 
 
+@pytest.fixture(params=['default-routes', 'own-kernels-only'])
+def gemm_routing(request):
+    """'own-kernels-only': ops.LIBRARY_GEMM.strict -- every product of the step on this package's kernels whatever its
+    shape (the row thresholds that send small problems to hipBLASLt are performance choices), a library GEMM is an error.
+    'default-routes': what a user gets.  Both must match the restatement."""
+    from kgwas_amd import ops
+    was = ops.LIBRARY_GEMM.strict
+    ops.LIBRARY_GEMM.strict = request.param == 'own-kernels-only'
+    ops.LIBRARY_GEMM.reset()
+    yield request.param
+    own, calls = ops.LIBRARY_GEMM.strict, ops.LIBRARY_GEMM.calls
+    ops.LIBRARY_GEMM.strict = was
+    assert not own or calls == 0
+
+
 def _loader(data, ids, bs, L=2):
     from kgwas_amd.sampler import NeighborLoader
     return NeighborLoader(data, [-1] * L, ('SNP', ids), batch_size=bs, device='cuda:0')
@@ -37,7 +52,7 @@ def _loader(data, ids, bs, L=2):
 
 @pytest.mark.parametrize('which', ['small', 'edge'])
 @pytest.mark.parametrize('L', [1, 2, 3])
-def test_forward_backward_matches_reference_restatement(small_kg, edge_case_graph, which, L):
+def test_forward_backward_matches_reference_restatement(small_kg, edge_case_graph, which, L, gemm_routing):
     if which == 'small':
         data, dims = small_kg.data, (small_kg.snp_init_dim_size, small_kg.gene_init_dim_size, small_kg.go_init_dim_size)
     else:
@@ -448,7 +463,7 @@ def test_fused_readout_loss_equals_forward_plus_loss(small_kg, no_relu):
 
 @pytest.mark.parametrize('which', ['small', 'edge'])
 @pytest.mark.parametrize('L', [1, 2])
-def test_sage_backbone_matches_reference_restatement(small_kg, edge_case_graph, which, L):
+def test_sage_backbone_matches_reference_restatement(small_kg, edge_case_graph, which, L, gemm_routing):
     """Row f-4: gnn_backbone='SAGE' (kgwas/model.py:38: SAGEConv((-1,-1), 128) per relation, HeteroConv sum, ReLU) on
     the same kernels -- the neighbour mean is the attention aggregate with zero attention vectors -- against the
     op-for-op oracle (oracle.gat_oracle.SAGEConvOracle): prediction, loss, every parameter gradient, checkpoint keys."""
@@ -493,7 +508,7 @@ def test_sage_backbone_matches_reference_restatement(small_kg, edge_case_graph, 
 
 
 @pytest.mark.parametrize('backbone,aggr', [('GAT', 'mean'), ('GAT', 'max'), ('GAT', 'min'), ('SAGE', 'mean'), ('SAGE', 'max')])
-def test_relation_aggregation_modes_match_reference_restatement(edge_case_graph, backbone, aggr):
+def test_relation_aggregation_modes_match_reference_restatement(edge_case_graph, backbone, aggr, gemm_routing):
     """gnn_aggr in {mean, min, max} (HeteroConv(aggr), kgwas/model.py:47; README options): 'mean' rides the fused sum
     path (scaled by 1/R), 'min' / 'max' reduce per-relation outputs; prediction, loss and every gradient vs the oracle,
     through forward() and through the fused training forward."""
