@@ -234,11 +234,17 @@ class KGWAS:
         """The graph-side half of kgwas/kgwas.py:268-273: per-edge raw attention weights of the best model."""
         return get_network_weight(self, self.data)
 
-    def get_disease_critical_network(self, *args, **kwargs):
-        """kgwas/kgwas.py:268-273 goes on to `generate_viz` (MAGMA binary, plots): outside this build's scope
-        (SURVEY.md 8); the network weights it starts from are `get_network_weight()`."""
-        raise NotImplementedError('only the attention export is built: use KGWAS.get_network_weight(); generate_viz '
-                                  '(external MAGMA binary + plotting, kgwas/utils.py:496-) is out of scope')
+    def get_disease_critical_network(self, variant_threshold=5e-8, magma_path=None, magma_threshold=0.05,
+                                     program_threshold=0.05, K_neighbors=3, num_cpus=1):
+        """kgwas/kgwas.py:268-273: (attention table, variant interpretation, disease-critical network).  The attention pass
+        runs on the fused kernels (get_network_weight), the tables are host work (utils.generate_viz); the MAGMA / GSEA filter
+        (``magma_path``) is not built."""
+        from .utils import generate_viz
+        df_network_weight = get_network_weight(self, self.data)
+        df_variant_interpretation, disease_critical_network = generate_viz(
+            self, df_network_weight, self.data_path, variant_threshold, magma_path, magma_threshold, program_threshold,
+            K_neighbors, num_cpus)
+        return df_network_weight, df_variant_interpretation, disease_critical_network
 
     def _postprocess(self, save_name, save_best_model):
         """kgwas.py:192-212: prediction-weighted p-values (Storey-Tibshirani pi0 per prediction-quantile bin,

@@ -133,3 +133,149 @@ def get_network_weight(run, data):
     cols = ['h_idx', 't_idx', 'weight', 'h_type', 'rel_type', 't_type', 'layer']
     df_all = pd.concat(frames)[cols] if frames else pd.DataFrame(columns=cols)
     return df_all.drop_duplicates(['h_idx', 't_idx', 'rel_type', 'layer'])
+
+
+# ------------------------------------------------------------------------------------------------------
+# Disease-critical network + variant interpretation (kgwas/utils.py:496-724; SURVEY.md 8 row f-2, second half)
+# ------------------------------------------------------------------------------------------------------
+_NET_COLS = ['h_idx', 't_idx', 'importance', 'h_type', 't_type', 'rel_type']
+
+
+def _importance_by_relation(edges, reference_edges):
+    """z-score of every edge weight inside its relation, with the relation's mean and (n - 1) standard deviation taken over
+    ``reference_edges`` (the reference's rel2mean / rel2std tables, kgwas/utils.py:584-589: pandas' groupby std).  Relations
+    without a row in ``reference_edges`` drop out, as the reference's inner merges make them."""
+    stats = reference_edges.groupby('rel_type').weight.agg(['mean', 'std'])
+    kept = edges[edges.rel_type.isin(stats.index)]
+    z = (kept.weight.to_numpy() - kept.rel_type.map(stats['mean']).to_numpy()) / kept.rel_type.map(stats['std']).to_numpy()
+    return kept.assign(importance=z)
+
+
+def _strongest_relation_per_pair(scored):
+    """One row per (h_idx, t_idx): the relation / layer whose importance is the pair's maximum (every row equal to the
+    maximum is kept, like the reference's merge back on the value, kgwas/utils.py:591-593), pairs in ascending order."""
+    if not len(scored):
+        return scored[_NET_COLS]
+    top = scored.groupby(['h_idx', 't_idx']).importance.transform('max')
+    imp = scored.importance
+    keep = (imp == top) | (imp.isna() & top.isna())
+    out = scored[keep.to_numpy()].sort_values(['h_idx', 't_idx'], kind='stable')
+    return out[_NET_COLS].reset_index(drop=True)
+
+
+def _names(idx, table):
+    return [table[i] for i in idx.to_numpy()]
+
+
+def _top_k_by_tail(frame, k):
+    """{t_id: row positions of its k most important rows, most important first}; NaN importances rank first, which is
+    where the reference's ascending sort read backwards puts them (kgwas/utils.py:499,505)."""
+    order = frame.sort_values('importance', ascending=False, na_position='first', kind='stable')
+    order = order.groupby('t_id', sort=False).head(k)
+    pos = {}
+    for p, t in zip(order['_pos'].to_numpy(), order['t_id'].to_numpy()):
+        pos.setdefault(t, []).append(p)
+    return pos
+
+
+def generate_viz(run, df_network, data_path, variant_threshold=5e-8, magma_path=None, magma_threshold=0.05,
+                 program_threshold=0.05, K_neighbors=3, num_cpus=1):
+    """kgwas/utils.py:523-724 without the MAGMA / GSEA filter: from the attention table of ``get_network_weight`` build
+      * the disease-critical network: Gene->SNP edges at the GWAS hits (V2G), Gene->Gene (G2G) and BiologicalProcess->Gene (G2P)
+        edges, TSS relations left out, every weight z-scored inside its relation over the selected edges, one row per node pair
+        (its strongest relation), with readable ids;
+      * the variant interpretation: for every hit SNP that has a gene edge, its ``K_neighbors`` strongest genes and, around each of
+        them, the strongest gene, gene-program and SNP neighbours (importance = z-score with the statistics of the selected edges).
+    Returns (df_variant_interpretation, disease_critical_network) with the reference's columns.
+    Checked against the frames the reference's own function returns (tests/golden/viz_network.npz).
+
+    Differences by design: hits are ``P < variant_threshold`` (the reference hard-codes 5e-8, the default, and ignores the
+    argument, utils.py:547); the per-SNP loop is table look-ups instead of a multiprocessing pool (``num_cpus`` is accepted and
+    unused); misc_data/go2name.pkl is optional (terms keep their ids without it); a hit SNP without any gene edge is left out
+    of the interpretation, which is what the reference's bare ``except`` amounts to (utils.py:521).
+    ``magma_path`` (gene-level MAGMA output filtered by Bonferroni + GSEA prerank, utils.py:553-579) needs an external binary's
+    output, statsmodels and gseapy: not built."""
+    import pandas as pd
+    if magma_path is not None:
+        raise NotImplementedError('the MAGMA / GSEA filter (kgwas/utils.py:553-579: external MAGMA output, statsmodels, gseapy) is '
+                                  'not built; pass magma_path=None for the unfiltered network')
+    gwas = run.kgwas_res
+    idx2id, id2idx = run.data.idx2id, run.data.id2idx
+    print('Start generating disease critical network...')
+    go2name = {}
+    p = os.path.join(data_path, 'misc_data', 'go2name.pkl')
+    if os.path.exists(p):
+        go2name = load_dict(p)
+
+    def program_name(i):
+        g = idx2id['BiologicalProcess'][i]
+        return go2name[g].capitalize() if g in go2name else g
+
+    net = df_network[~df_network.rel_type.isin(['TSS', 'rev_TSS'])]
+    gene_to_snp = net[(net.t_type == 'SNP') & (net.h_type == 'Gene')]
+    gene_to_gene = net[(net.t_type == 'Gene') & (net.h_type == 'Gene')]
+    program_to_gene = net[(net.t_type == 'Gene') & (net.h_type == 'BiologicalProcess')]
+    snp_to_gene = net[(net.h_type == 'SNP') & (net.t_type == 'Gene')]
+    if 'SNP' not in gwas.columns.values:
+        gwas.loc[:, 'SNP'] = gwas['ID']
+    hit_snps = gwas[gwas.P < variant_threshold].SNP.values
+    hit_idx = np.array([id2idx['SNP'][s] for s in hit_snps], dtype=np.float64)
+    print('No filters... Using all genes and gene programs...')
+
+    # --- the network over the hits ------------------------------------------------------------------------------------
+    at_hits = gene_to_snp[gene_to_snp.t_idx.isin(hit_idx)]
+    v2g_hit = _strongest_relation_per_pair(_importance_by_relation(at_hits, at_hits))
+    v2g_hit['rel_type'] = [r[4:] for r in v2g_hit.rel_type]                          # 'rev_ABC' -> 'ABC'
+    v2g_hit['Category'] = 'V2G'
+    v2g_hit['h_id'], v2g_hit['t_id'] = _names(v2g_hit.h_idx, idx2id['Gene']), _names(v2g_hit.t_idx, idx2id['SNP'])
+    g2g_hit = _strongest_relation_per_pair(_importance_by_relation(gene_to_gene, gene_to_gene))
+    g2g_hit['rel_type'] = [r.split('-')[1] for r in g2g_hit.rel_type]                 # 'Gene-Literature-Gene' -> 'Literature'
+    g2g_hit['Category'] = 'G2G'
+    g2g_hit['h_id'], g2g_hit['t_id'] = _names(g2g_hit.h_idx, idx2id['Gene']), _names(g2g_hit.t_idx, idx2id['Gene'])
+    g2p_hit = _strongest_relation_per_pair(_importance_by_relation(program_to_gene, program_to_gene))
+    g2p_hit['rel_type'] = [r.split('-')[1] for r in g2p_hit.rel_type]
+    g2p_hit['Category'] = 'G2P'
+    g2p_hit['h_id'] = [program_name(i) for i in g2p_hit.h_idx.to_numpy()]
+    g2p_hit['t_id'] = _names(g2p_hit.t_idx, idx2id['Gene'])
+    disease_critical_network = pd.concat((v2g_hit, g2g_hit, g2p_hit)).reset_index(drop=True)
+    print('Disease critical network finished generating...')
+    print('Generating variant interpretation networks...')
+
+    # --- neighbourhoods of the hits: every edge scored, statistics still those of the selected edges ------------------------
+    v2g = _strongest_relation_per_pair(_importance_by_relation(gene_to_snp, at_hits))
+    v2g['h_id'], v2g['t_id'] = _names(v2g.h_idx, idx2id['Gene']), _names(v2g.t_idx, idx2id['SNP'])
+    g2g = _strongest_relation_per_pair(_importance_by_relation(gene_to_gene, gene_to_gene))
+    g2g['h_id'], g2g['t_id'] = _names(g2g.h_idx, idx2id['Gene']), _names(g2g.t_idx, idx2id['Gene'])
+    g2g = g2g[g2g.h_idx != g2g.t_idx].reset_index(drop=True)                          # self loops say nothing
+    g2p = _strongest_relation_per_pair(_importance_by_relation(program_to_gene, program_to_gene))
+    g2p['h_id'] = [program_name(i) for i in g2p.h_idx.to_numpy()]
+    g2p['t_id'] = _names(g2p.t_idx, idx2id['Gene'])
+    g2v = _strongest_relation_per_pair(_importance_by_relation(snp_to_gene, snp_to_gene[snp_to_gene.h_idx.isin(hit_idx)]))
+    g2v['h_id'], g2v['t_id'] = _names(g2v.h_idx, idx2id['SNP']), _names(g2v.t_idx, idx2id['Gene'])
+    print('Number of hit snps: ', len(hit_snps))
+    tables = []
+    for t in (v2g, g2g, g2p, g2v):
+        t = t.copy()
+        t['_pos'] = np.arange(len(t))
+        tables.append(t)
+    v2g, g2g, g2p, g2v = tables
+    v2g['rel_type_short'] = [r[4:] for r in v2g.rel_type]
+    for t in (g2g, g2p):
+        t['rel_type_short'] = [r.split('-')[1] for r in t.rel_type]
+    g2v['rel_type_short'] = g2v.rel_type
+    best = [_top_k_by_tail(t, K_neighbors) for t in (v2g, g2g, g2p, g2v)]
+    parts = []
+    for snp in hit_snps:
+        genes_at = best[0].get(snp)
+        if not genes_at:
+            continue
+        genes = v2g['h_id'].to_numpy()[genes_at]
+        rows = [v2g.iloc[genes_at]]
+        for tab, pos in ((g2g, best[1]), (g2p, best[2]), (g2v, best[3])):
+            take = [q for g in genes for q in pos.get(g, ())]
+            rows.append(tab.iloc[take])
+        local = pd.concat(rows)
+        local = local.assign(rel_type=local['rel_type_short'], QUERY_SNP=snp).drop(columns=['_pos', 'rel_type_short'])
+        parts.append(local)
+    df_variant_interpretation = pd.concat(parts) if parts else pd.DataFrame()
+    return df_variant_interpretation, disease_critical_network

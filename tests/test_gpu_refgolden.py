@@ -53,3 +53,41 @@ def test_p_value_postprocessing_of_hip_predictions_follows_the_reference_pinned_
     assert np.array_equal(np.asarray(pw, dtype=np.float64), res['P_weighted'].values.astype(np.float64))
     scale = find_closest_x(pd.DataFrame({'P': res['P'].values, 'P_weighted': pw}))
     assert np.array_equal(np.clip(scale * np.asarray(pw, dtype=np.float64), 0, 1), res['KGWAS_P'].values)
+
+
+# ---- the disease-critical network (row f-2, second half): the reference's own generate_viz output (viz_network.npz) ------
+from tests import test_viz_golden as _vg          # noqa: E402
+
+test_disease_critical_network_matches_the_reference_output = _vg.test_disease_critical_network_matches_the_reference_output
+test_variant_interpretation_matches_the_reference_output = _vg.test_variant_interpretation_matches_the_reference_output
+
+
+def test_disease_critical_network_end_to_end_on_the_device(tiny_kg):
+    """kgwas/kgwas.py:268-273 on the HIP path: train, whole-graph raw attention on the fused kernels, then the tables (whose
+    arithmetic the two golden tests above hold to the reference's output).  V2G importances are recomputed here from the returned
+    attention table with plain numpy."""
+    from kgwas_amd.kgwas import KGWAS
+    run = KGWAS(tiny_kg, device='cuda:0', seed=5)
+    run.initialize_model()
+    run.train(batch_size=32, epoch=1, save_best_model=False, save_name='viz')
+    thr = float(np.quantile(run.kgwas_res['P'].values, 0.15))                     # a threshold the synthetic GWAS has hits under
+    df_w, df_var, df_net = run.get_disease_critical_network(variant_threshold=thr, K_neighbors=2)
+    assert {'h_idx', 't_idx', 'weight', 'h_type', 'rel_type', 't_type', 'layer'} <= set(df_w.columns) and len(df_w) > 0
+    assert set(df_net.Category) <= {'V2G', 'G2G', 'G2P'} and (df_net.Category == 'G2G').any()
+    assert np.isfinite(df_net.importance.to_numpy(np.float64)[~np.isnan(df_net.importance.to_numpy(np.float64))]).all()
+    v2g = df_net[df_net.Category == 'V2G']
+    assert len(v2g) > 0 and len(df_var) > 0 and df_var.QUERY_SNP.nunique() > 0
+    hit_idx = {run.data.id2idx['SNP'][s] for s in run.kgwas_res[run.kgwas_res.P < thr].ID.values}
+    sel = df_w[(df_w.h_type == 'Gene') & (df_w.t_type == 'SNP') & ~df_w.rel_type.isin(['rev_TSS']) & df_w.t_idx.isin(hit_idx)]
+    assert len(sel) > 0
+    for rel, grp in sel.groupby('rel_type'):
+        w = grp.weight.to_numpy(np.float64)
+        if len(w) < 2 or w.std(ddof=1) == 0:
+            continue
+        z = (w - w.mean()) / w.std(ddof=1)
+        best = {}
+        for h, t, zz in zip(grp.h_idx, grp.t_idx, z):
+            best[(h, t)] = max(best.get((h, t), -np.inf), zz)
+        rows = v2g[v2g.rel_type == rel[4:]]
+        for h, t, imp in zip(rows.h_idx, rows.t_idx, rows.importance):
+            assert abs(best[(h, t)] - imp) <= 1e-9 * max(1.0, abs(imp))

@@ -1,0 +1,29 @@
+"""One steady-state training step from a rocprofv3 kernel trace: the launches between two consecutive k_adam kernels, in start
+order, per hardware queue, with the idle gap before each.  usage: python tools/step_timeline.py <dir with r_kernel_trace.csv> [k]
+(k: which step from the end, default 2)."""
+import csv, sys, glob, collections
+d = sys.argv[1]
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+f = (glob.glob(d + '/**/*kernel_trace.csv', recursive=True) + glob.glob(d + '/*kernel_trace.csv'))[0]
+rows = list(csv.DictReader(open(f)))
+for r in rows:
+    r['s'], r['e'] = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    r['n'] = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')
+    r['n'] = r['n'].split('(')[0]
+rows.sort(key=lambda r: r['s'])
+adam = [r for r in rows if r['n'].startswith('k_adam')]
+a0, a1 = adam[-back - 1], adam[-back]
+win = [r for r in rows if r['s'] > a0['e'] and r['e'] <= a1['e']]
+print('step window %.1f us, %d launches (all queues)' % ((a1['e'] - a0['e']) / 1e3, len(win)))
+byq = collections.defaultdict(list)
+for r in win:
+    byq[r.get('Queue_Id', '?')].append(r)
+for q, rs in sorted(byq.items(), key=lambda kv: -len(kv[1])):
+    busy = sum(r['e'] - r['s'] for r in rs)
+    print('--- queue %s: %d launches, busy %.1f us' % (q, len(rs), busy / 1e3))
+    prev = None
+    for r in rs:
+        gap = (r['s'] - prev) / 1e3 if prev else 0.0
+        print('  +%8.1f  gap %6.1f  dur %7.1f  grid %-9s wg %-5s %s' % ((r['s'] - a0['e']) / 1e3, gap, (r['e'] - r['s']) / 1e3,
+              r.get('Grid_Size_X', r.get('Grid_Size', '?')), r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?')), r['n'][:70]))
+        prev = r['e']
