@@ -11,7 +11,7 @@ for r in rows:
     r['n'] = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')
     r['n'] = r['n'].split('(')[0]
 rows.sort(key=lambda r: r['s'])
-adam = [r for r in rows if r['n'].startswith('k_adam')]
+adam = [r for r in rows if r['n'].startswith('k_accumulate_stats')] or [r for r in rows if r['n'].startswith('k_adam')]   # one per step
 a0, a1 = adam[-back - 1], adam[-back]
 win = [r for r in rows if r['s'] > a0['e'] and r['e'] <= a1['e']]
 print('step window %.1f us, %d launches (all queues)' % ((a1['e'] - a0['e']) / 1e3, len(win)))
