@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define KGW_VERSION      114          /* 0.1.4 */
+#define KGW_VERSION      115          /* 0.1.5 */
 #define KGW_MAX_TYPES    8
 #define KGW_MAX_RELS     64
 #define KGW_MAX_LAYERS   4
@@ -123,9 +123,10 @@ typedef struct KgwBatchBuf {
     int32_t* t_edge[KGW_MAX_LAYERS];  /* [edge_cap] local edge id of each entry                */
     int32_t* t_zrow[KGW_MAX_LAYERS];  /* [edge_cap] Z row (dst row * R_dst + slot) of the entry */
     uint8_t* t_rel[KGW_MAX_LAYERS];   /* [edge_cap] relation id of the entry (optional: NULL = not written)  */
-    int32_t* scan_tmp;     /* [2 * (max(seg_cap, node_cap, trow_cap) / KGW_TILE + 2)]          */
-    int32_t* t_tmp;        /* [8 * edge_cap], 16-B aligned: unsorted (edge, Z row, src-major row, relation) entries of up to TWO layers (the
-                              second behind the first): the atomic cursor fill lands here, a rank pass writes them in ascending edge order */
+    int32_t* scan_tmp;     /* [scan_cap] >= kgw_sampler_scan_ints(seg_cap, node slots, trow_cap): scan scratch of the hops, then
+                              the [layer][bucket][block] counts of the src-major sort                                             */
+    int32_t* t_tmp;        /* [8 * (edge_cap + 1)], 16-B aligned: per layer of a pair (the second behind the first) row key and chunk
+                              of every edge, then the keys and edge ids stably sorted by bucket (the src-major radix sort)          */
     KgwBatchMeta* meta;    /* device                                                           */
     KgwBatchMeta* meta_host; /* pinned host mirror (async D2H at the end of sampling)          */
     int64_t seg_cap, edge_cap, chunk_cap, multi_cap, trow_cap, scan_cap;
@@ -221,6 +222,8 @@ int kgw_struct_sizes(int64_t* out, int n);
  * kgwas/utils.py:446-461).                                                                    */
 int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, const int64_t* seeds,
                      int32_t n_seeds, int32_t seed_type, int32_t full_graph, kgw_stream_t stream);
+/* ints KgwBatchBuf.scan_tmp must hold (KgwBatchBuf.scan_cap) for buffers of these capacities.                              */
+int64_t kgw_sampler_scan_ints(int64_t seg_cap, int64_t node_slots, int64_t trow_cap);
 /* The same call in parts [part_begin, part_end] (kgw_sample_batch = parts 0 .. 2*n_hops): hop h is part 2h (its segments
  * and chunks, and the flag KGW_PENDING = -2 in g2l on every not-yet-sampled source node) and part 2h+1 (flags -> local
  * ids, relabelled edges); part 2*n_hops = layer tables, src-major structures, meta export.  SNP-sharded multi-GPU mode

@@ -120,7 +120,7 @@ class KgwFoldArgs(C.Structure):
                 ('d_fc_weight', C.c_void_p * 4), ('d_fc_bias', C.c_void_p * 4)]
 
 
-EXPORTS = ['kgw_version', 'kgw_status_string', 'kgw_struct_sizes', 'kgw_sample_batch', 'kgw_sample_batch_parts',
+EXPORTS = ['kgw_version', 'kgw_status_string', 'kgw_struct_sizes', 'kgw_sample_batch', 'kgw_sample_batch_parts', 'kgw_sampler_scan_ints',
            'kgw_softmax_pack', 'kgw_softmax_merge', 'kgw_scatter_rows', 'kgw_linear_splitk', 'kgw_linear_splitk_workspace_floats', 'kgw_linear_splitk_ind', 'kgw_ind_colsum', 'kgw_fold_fwd', 'kgw_fold_bwd', 'kgw_relation_sums',
            'kgw_gat_aggregate_fwd', 'kgw_gat_aggregate_bwd_dst', 'kgw_gat_aggregate_bwd_src',
            'kgw_gather_rows', 'kgw_gather_rows_multi', 'kgw_scatter_relu_rows', 'kgw_scatter_relu_rows_workspace_floats', 'kgw_edge_alpha', 'kgw_debug_reduce', 'kgw_debug_reduce8', 'kgw_tn_gemm', 'kgw_tn_gemm_ex', 'kgw_tn_gemm_multi', 'kgw_tn_gemm_workspace_floats',
@@ -157,6 +157,8 @@ def lib():
                                    C.c_int32, C.c_int32, C.c_void_p]
     L.kgw_sample_batch_parts.argtypes = [C.POINTER(KgwGraph), C.POINTER(KgwBatchBuf), C.c_void_p, C.c_int32,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    L.kgw_sampler_scan_ints.argtypes = [C.c_int64, C.c_int64, C.c_int64]
+    L.kgw_sampler_scan_ints.restype = C.c_int64
     L.kgw_softmax_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.kgw_softmax_merge.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.kgw_scatter_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]

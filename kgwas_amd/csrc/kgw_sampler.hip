@@ -486,132 +486,278 @@ __global__ void __launch_bounds__(64) k_layer_tables(SampArgs A) {
 
 // ---- src-major (transposed) structures: up to TWO layers per launch ------------------------------------------------------
 // (layers l0 and l0 + 1: every kernel below loops over the pair, so the default 2-layer model builds both structures with
-//  one set of launches; KgwBatchMeta.cur: [0, 1] = scan range, [4 + k] = entries of layer l0 + k after the scan,
-//  [6 + k] = length of that layer's work list of long rows; layer l0 + 1 stages behind layer l0 in t_tmp)
+//  one set of launches.)
+//
+// The structure is the layer's edge list STABLY SORTED by src-major row (row = (source node, relation slot), t_base + col * R_src
+// + slot): inside a row the entries then stand in ascending edge order, the summation order of the backward pass, the same run
+// to run.  Round 3: a two-digit radix sort without global atomics instead of atomic histogram + atomic cursor fill + in-row rank
+// (those were 0.25 of the sampler's 0.43 ms):
+//   k_ts_keys     lane per edge: chunk of the edge (binary search), row key (INVALID for relations the layer does not compute),
+//                 the HIGH digit (key >> sh; one bucket = 2^sh consecutive rows) counted per block in LDS.  Blocks own
+//                 CONTIGUOUS edge ranges;
+//   k_ts_scan     exclusive scan of the [digit][block] counts (one block per layer);
+//   k_ts_scatter  stable scatter by high digit: a block's four wavefronts own contiguous quarters of its range, count them,
+//                 start behind each other, and walk their quarter in order 64 edges at a time -- the rank of an edge among the
+//                 lanes with the same digit comes from ballots (no atomics, no dependence on arrival order);
+//   k_ts_rows     one wavefront per bucket: counts of the bucket's rows in LDS, exclusive scan = the row pointers (written for
+//                 every row, empty ones included), then the bucket's entries placed in order the same way, with the Z row and
+//                 relation of each looked up from its chunk.
+// KgwBatchBuf.t_tmp per layer: key[edge], chunk[edge], sorted key, sorted edge -- 4 x (edge_cap + 1) ints; the counts live in
+// KgwBatchBuf.scan_tmp ([layer][digit][block]); KgwBatchMeta.cur[4 + k] = entries of layer l0 + k.
+// (blocks of k_ts_keys / k_ts_scatter = contiguous edge ranges: 128 beside a training step, 512 when the call has the GPU)
+constexpr int TS_INVALID = 0x7fffffff;
+constexpr int TS_MAX_NB = 4000;                // buckets: 4 x (nb + 1) counters must fit 64 KB of LDS in k_ts_scatter
 
-// One wavefront per chunk (chunks of the benchmark graph average ~100 edges: the lanes are busy; a
-// lane-per-chunk variant measured 2-4x slower because only n_chunks/64 wavefronts had work).
-template <bool FILL>
-__global__ void __launch_bounds__(KGW_BLK) k_t_pass(SampArgs A, int l0, int nl) {
+__device__ __forceinline__ void ts_block_range(int n, int b, int nblk, int& beg, int& end) {
+    int per = (n + nblk - 1) / nblk;
+    per = (per + 255) & ~255;                  // whole groups of 64 for each of the four wavefronts
+    beg = min(n, b * per);
+    end = min(n, beg + per);
+}
+
+// rank of this lane among the (valid) lanes whose ``d`` equals its own, and their number: ``nbits`` ballots
+__device__ __forceinline__ void ts_match(int d, bool valid, int nbits, int lane, int& rank, int& cnt) {
+    unsigned long long m = __ballot(valid);
+    for (int b = 0; b < nbits; ++b) {
+        const bool bit = (d >> b) & 1;
+        const unsigned long long bal = __ballot(valid && bit);
+        m &= bit ? bal : ~bal;
+    }
+    rank = __popcll(m & ((1ull << lane) - 1ull));
+    cnt = __popcll(m);
+}
+
+__global__ void __launch_bounds__(KGW_BLK) k_ts_keys(SampArgs A, int l0, int nl, int sh, int nb) {
+    extern __shared__ int ts_lds[];            // [nb + 1] digit counts of this block
     const KgwGraph& G = A.G;
     KgwBatchMeta* M = A.B.meta;
-    if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) {
-        // (k_t_begin's one-thread launch: the range of the histogram scan that follows, empty work lists)
-        int range = 0;
-        for (int k = 0; k < nl; ++k) range = max(range, M->t_base[l0 + k - 1][G.n_types]);
-        M->cur[0] = 0;
-        M->cur[1] = M->error ? 0 : range;
-        M->cur[6] = 0; M->cur[7] = 0;
+    if (M->error) return;
+    const int64_t E1 = A.B.edge_cap + 1;
+    const int lane = kgw_lane(), wv = threadIdx.x >> 6;
+    for (int k = 0; k < nl; ++k) {
+        const int l = l0 + k;
+        const int n = M->n_edges[l - 1], nc = M->n_chunks[l - 1];
+        int32_t* keyE = A.B.t_tmp + (int64_t)k * 4 * E1;
+        int32_t* cE = keyE + E1;
+        int32_t* H = A.B.scan_tmp + (int64_t)k * (nb + 1) * gridDim.x;
+        for (int d = threadIdx.x; d <= nb; d += KGW_BLK) ts_lds[d] = 0;
+        __syncthreads();
+        int beg, end;
+        ts_block_range(n, blockIdx.x, gridDim.x, beg, end);
+        const int q = (((end - beg) + 3) / 4 + 63) & ~63;          // a wavefront's quarter: whole groups of 64
+        const int wb = min(end, beg + wv * q), we = min(end, wb + q);
+        // chunk of the quarter's first edge: one binary search; after that the chunk list is walked (64 consecutive edges span
+        // at most 64 chunks: their end offsets are one coalesced load, the lane's chunk a 6-step search through shuffles)
+        int c0 = 0;
+        if (wb < we) {
+            int lo = 0, hi = nc;               // chunks[lo].e0 <= wb < chunks[hi].e0
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (A.B.chunks[mid].e0 <= wb) lo = mid; else hi = mid;
+            }
+            c0 = lo;
+        }
+        for (int g = wb; g < we; g += 64) {
+            const int e = g + lane;
+            const bool valid = e < we;
+            const int ce = (c0 + lane < nc) ? A.B.chunks[c0 + lane].e1 : 0x7fffffff;
+            int lo = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const int v = __shfl(ce, lo + step - 1, 64);
+                lo += (v <= e) ? step : 0;
+            }
+            const int c = min(c0 + lo, nc - 1);
+            if (valid) {
+                const int r = A.B.chunks[c].rel;
+                int key = TS_INVALID;
+                if (G.rel_live[l - 1][r]) {
+                    const int sT = G.rel_src[r];
+                    key = M->t_base[l - 1][sT] + A.B.col_local[e] * G.R_src[sT] + G.rel_slot_src[r];
+                }
+                keyE[e] = key;
+                cE[e] = c;
+                atomicAdd(&ts_lds[key == TS_INVALID ? nb : (key >> sh)], 1);
+            }
+            c0 = __shfl(c, 63, 64);            // (lane 63's edge is the group's last: the next group starts in its chunk or later)
+        }
+        __syncthreads();
+        for (int d = threadIdx.x; d <= nb; d += KGW_BLK) H[(int64_t)d * gridDim.x + blockIdx.x] = ts_lds[d];
+        __syncthreads();
     }
+}
+
+// Offsets of the (digit, block) cells: inside a digit the exclusive prefix over its blocks (one wavefront per digit row, in
+// place) and the digit's total; then the exclusive scan of the totals (one block per layer).  Start of cell (d, b) =
+// dbase[d] + H[d][b]; dbase[nb] = entries of the layer (digit nb collects the edges of relations the layer does not compute).
+__global__ void __launch_bounds__(KGW_BLK) k_ts_scan_rows(int32_t* scan_tmp, int nl, int nb, int nblk, const KgwBatchMeta* __restrict__ M) {
     if (M->error) return;
     const int lane = kgw_lane();
-    for (int k = 0; k < nl; ++k) {
-        const int l = l0 + k;
-        const int nc = M->n_chunks[l - 1];
-        int32_t* cnt = A.B.t_cnt[l - 1];
-        const int stage0 = (FILL && k) ? M->cur[4] : 0;          // layer l0 + 1 stages behind layer l0's entries
-        for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < nc; c += gridDim.x * 4) {
-            const KgwChunk ck = A.B.chunks[c];
-            const int r = ck.rel;
-            if (!G.rel_live[l - 1][r]) continue;
-            const int s = G.rel_src[r], d = G.rel_dst[r];
-            const int tb = M->t_base[l - 1][s] + G.rel_slot_src[r];
-            const int Rs = G.R_src[s];
-            const int zrow = M->z_base[l - 1][d] + ck.row * G.R_dst[d] + G.rel_slot_dst[r];
-            const int n = ck.e1 - ck.e0;
-            for (int t = lane; t < n; t += 64) {
-                const int e = ck.e0 + t;
-                const int trow = tb + A.B.col_local[e] * Rs;
-                if (!FILL) {
-                    atomicAdd(&cnt[trow], 1);
-                } else {
-                    // position inside the row in ARRIVAL order (atomic cursor): staged, then k_t_rank puts the row in
-                    // ascending edge order so that the backward's summation order is the same run to run
-                    const int pos = stage0 + A.B.t_ptr[l - 1][trow] + atomicSub(&cnt[trow], 1) - 1;
-                    ((int4*)A.B.t_tmp)[pos] = make_int4(e, zrow, trow, r);
-                }
+    int32_t* tot0 = scan_tmp + (int64_t)nl * (nb + 1) * nblk;
+    const int nrow = nl * (nb + 1);
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < nrow; row += gridDim.x * 4) {
+        int32_t* H = scan_tmp + (int64_t)row * nblk;
+        int carry = 0;
+        for (int i0 = 0; i0 < nblk; i0 += 64) {
+            const int v = (i0 + lane < nblk) ? H[i0 + lane] : 0;
+            int incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d, 64);
+                incl += lane >= d ? o : 0;
             }
+            if (i0 + lane < nblk) H[i0 + lane] = carry + incl - v;
+            carry += __shfl(incl, 63, 64);
         }
+        if (lane == 0) tot0[(row / (nb + 1)) * (nb + 2) + row % (nb + 1)] = carry;
     }
 }
 
-// Final (deterministic) order of the src-major rows: ascending edge id inside every row.  The rank of a staged
-// entry = #entries of its row with a smaller edge id (edge ids are unique).
-//   k_t_rank      one lane per staged entry; rows of <= T_BIG entries are ranked by a short loop over the row's
-//                 staged keys (L1-resident: neighbouring lanes read the same keys); longer rows are put on a work
-//                 list by the lane that owns their first entry;
-//   k_t_rank_big  one block per listed row, keys staged in LDS and compared four per ds_read_b128 (rows above
-//                 T_LDS entries, which only whole-graph blocks have: plain memory loop).
-// On the benchmark graph 99 % of the rows have <= 40 entries but the 0.1 % above 64 hold most of sum(n^2).
-constexpr int T_BIG = 64, T_LDS = 4096;
-
-__global__ void __launch_bounds__(KGW_BLK) k_t_rank(SampArgs A, int l0, int nl) {
-    KgwBatchMeta* M = A.B.meta;
+__global__ void __launch_bounds__(1024) k_ts_scan_tot(int32_t* scan_tmp, int nl, int nb, int nblk, const KgwBatchMeta* __restrict__ M) {
+    __shared__ int s_w[16];
     if (M->error) return;
-    for (int k = 0; k < nl; ++k) {
-        const int l = l0 + k;
-        const int n = M->cur[4 + k];                   // entries of this layer (total of the histogram scan)
-        const int4* tmp = (const int4*)A.B.t_tmp + (k ? M->cur[4] : 0);
-        const int32_t* tp = A.B.t_ptr[l - 1];
-        int32_t* big = A.B.t_cnt[l - 1];               // histogram scratch is free again: work list of long rows
-        for (int p = blockIdx.x * KGW_BLK + threadIdx.x; p < n; p += gridDim.x * KGW_BLK) {
-            const int4 me = tmp[p];
-            const int e = me.x, trow = me.z;
-            const int s0 = tp[trow], s1 = tp[trow + 1];
-            if (s1 - s0 > T_BIG) {
-                if (p == s0) big[atomicAdd(&M->cur[6 + k], 1)] = trow;
-                continue;
-            }
-            int rank = 0;
-            if (s1 - s0 > 1)
-                for (int q = s0; q < s1; ++q) rank += (tmp[q].x < e) ? 1 : 0;
-            A.B.t_edge[l - 1][s0 + rank] = e;
-            A.B.t_zrow[l - 1][s0 + rank] = me.y;
-            if (A.B.t_rel[l - 1]) A.B.t_rel[l - 1][s0 + rank] = (uint8_t)me.w;
+    int32_t* T = scan_tmp + (int64_t)nl * (nb + 1) * nblk + (int64_t)blockIdx.x * (nb + 2);      // [nb + 1] totals -> [nb + 2] starts
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = nb + 1;
+    int carry = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int v = i < n ? T[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            incl += lane >= d ? o : 0;
         }
+        __syncthreads();
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        int wbase = 0, total = 0;
+        for (int w = 0; w < 16; ++w) { wbase += w < wv ? s_w[w] : 0; total += s_w[w]; }
+        if (i < n) T[i] = carry + wbase + incl - v;
+        carry += total;
     }
+    if (tid == 0) T[n] = carry;
 }
 
-__global__ void __launch_bounds__(KGW_BLK) k_t_rank_big(SampArgs A, int l0, int nl) {
-    __shared__ __attribute__((aligned(16))) int keys[T_LDS];
+__global__ void __launch_bounds__(KGW_BLK) k_ts_scatter(SampArgs A, int l0, int nl, int sh, int nb, int nbits) {
+    extern __shared__ int ts_lds[];            // [4][nb + 1]: per wavefront, first its counts, then its running write positions
     const KgwBatchMeta* M = A.B.meta;
     if (M->error) return;
+    const int64_t E1 = A.B.edge_cap + 1;
+    const int lane = kgw_lane(), wv = threadIdx.x >> 6;
+    int* mine = ts_lds + wv * (nb + 1);
     for (int k = 0; k < nl; ++k) {
         const int l = l0 + k;
-        const int nbig = M->cur[6 + k];
-        const int4* tmp = (const int4*)A.B.t_tmp + (k ? M->cur[4] : 0);
-        const int32_t* tp = A.B.t_ptr[l - 1];
-        const int32_t* big = A.B.t_cnt[l - 1];
-        for (int b = blockIdx.x; b < nbig; b += gridDim.x) {
-            const int trow = big[b];
-            const int s0 = tp[trow], len = tp[trow + 1] - s0;
-            const bool in_lds = len <= T_LDS;
-            const int len4 = (len + 3) & ~3;
-            __syncthreads();
-            if (in_lds)
-                for (int i = threadIdx.x; i < len4; i += KGW_BLK) keys[i] = (i < len) ? tmp[s0 + i].x : 0x7fffffff;
-            __syncthreads();
-            for (int i = threadIdx.x; i < len; i += KGW_BLK) {
-                const int4 me = tmp[s0 + i];
-                int rank = 0;
-                if (in_lds) {
-#pragma unroll 4
-                    for (int q = 0; q < len4; q += 4) {
-                        const int4 k4 = *(const int4*)(keys + q);
-                        rank += (k4.x < me.x) + (k4.y < me.x) + (k4.z < me.x) + (k4.w < me.x);
-                    }
-                } else {
-                    for (int q = 0; q < len; ++q) rank += (tmp[s0 + q].x < me.x) ? 1 : 0;
-                }
-                A.B.t_edge[l - 1][s0 + rank] = me.x;
-                A.B.t_zrow[l - 1][s0 + rank] = me.y;
-                if (A.B.t_rel[l - 1]) A.B.t_rel[l - 1][s0 + rank] = (uint8_t)me.w;
+        const int n = M->n_edges[l - 1];
+        const int32_t* keyE = A.B.t_tmp + (int64_t)k * 4 * E1;
+        int32_t* keyS = A.B.t_tmp + (int64_t)k * 4 * E1 + 2 * E1;
+        int32_t* eS = keyS + E1;
+        const int32_t* H = A.B.scan_tmp + (int64_t)k * (nb + 1) * gridDim.x;
+        const int32_t* dbase = A.B.scan_tmp + (int64_t)nl * (nb + 1) * gridDim.x + (int64_t)k * (nb + 2);
+        for (int d = threadIdx.x; d < 4 * (nb + 1); d += KGW_BLK) ts_lds[d] = 0;
+        __syncthreads();
+        int beg, end;
+        ts_block_range(n, blockIdx.x, gridDim.x, beg, end);
+        const int q = (((end - beg) + 3) / 4 + 63) & ~63;          // a wavefront's quarter: whole groups of 64
+        const int wb = min(end, beg + wv * q), we = min(end, wb + q);
+        for (int e = wb + lane; e < we; e += 64) {
+            const int key = keyE[e];
+            atomicAdd(&mine[key == TS_INVALID ? nb : (key >> sh)], 1);
+        }
+        __syncthreads();
+        for (int d = threadIdx.x; d <= nb; d += KGW_BLK) {
+            int run = dbase[d] + H[(int64_t)d * gridDim.x + blockIdx.x];
+            for (int w = 0; w < 4; ++w) { const int t = ts_lds[w * (nb + 1) + d]; ts_lds[w * (nb + 1) + d] = run; run += t; }
+        }
+        __syncthreads();
+        for (int g = wb; g < we; g += 64) {
+            const int e = g + lane;
+            const bool valid = e < we;
+            const int key = valid ? keyE[e] : TS_INVALID;
+            const int d = key == TS_INVALID ? nb : (key >> sh);
+            int rank, cnt;
+            ts_match(d, valid, nbits, lane, rank, cnt);
+            int pos = 0;
+            if (valid) pos = mine[d] + rank;
+            __builtin_amdgcn_wave_barrier();                          // (every lane has read its digit's position)
+            if (valid && rank == cnt - 1) mine[d] += cnt;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && d < nb) { keyS[pos] = key; eS[pos] = e; }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(64) k_ts_rows(SampArgs A, int l0, int nl, int sh, int nb, int nblk) {
+    extern __shared__ int ts_lds[];            // [2^sh]: counts of the bucket's rows, then their running write positions
+    const KgwGraph& G = A.G;
+    KgwBatchMeta* M = A.B.meta;
+    if (M->error) return;
+    const int64_t E1 = A.B.edge_cap + 1;
+    const int lane = kgw_lane();
+    const int nrow = 1 << sh;
+    for (int k = 0; k < nl; ++k) {
+        const int l = l0 + k;
+        const int TR = M->t_base[l - 1][G.n_types];
+        const int32_t* keyS = A.B.t_tmp + (int64_t)k * 4 * E1 + 2 * E1;
+        const int32_t* eS = keyS + E1;
+        const int32_t* dbase = A.B.scan_tmp + (int64_t)nl * (nb + 1) * nblk + (int64_t)k * (nb + 2);
+        int32_t* tp = A.B.t_ptr[l - 1];
+        int32_t* te = A.B.t_edge[l - 1];
+        if (blockIdx.x == 0 && lane == 0) M->cur[4 + k] = dbase[nb];                            // entries of the layer
+        for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+            const int row0 = b << sh;
+            if (row0 > TR) break;
+            const int s0 = dbase[b], s1 = dbase[b + 1];
+            for (int i = lane; i < nrow; i += 64) ts_lds[i] = 0;
+            __builtin_amdgcn_wave_barrier();
+            for (int p = s0 + lane; p < s1; p += 256) {                   // (four independent loads in flight)
+                int kk[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) kk[u] = (p + 64 * u < s1) ? keyS[p + 64 * u] : -1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (kk[u] >= 0) atomicAdd(&ts_lds[kk[u] - row0], 1);
             }
+            __builtin_amdgcn_wave_barrier();
+            int carry = s0;
+            for (int i0 = 0; i0 < nrow && row0 + i0 <= TR; i0 += 64) {
+                const int v = ts_lds[i0 + lane];
+                int incl = v;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(incl, d, 64);
+                    incl += lane >= d ? o : 0;
+                }
+                const int ex = carry + incl - v;
+                ts_lds[i0 + lane] = ex;
+                if (row0 + i0 + lane <= TR) tp[row0 + i0 + lane] = ex;
+                carry += __shfl(incl, 63, 64);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // the bucket's entries in order, 64 at a time (the next group's key / edge loads are issued before this group is placed)
+            int kn = (s0 + lane < s1) ? keyS[s0 + lane] : 0, en = (s0 + lane < s1) ? eS[s0 + lane] : 0;
+            for (int g = s0; g < s1; g += 64) {
+                const int p = g + lane;
+                const bool valid = p < s1;
+                const int key = kn, e = en;
+                if (p + 64 < s1) { kn = keyS[p + 64]; en = eS[p + 64]; }
+                const int low = valid ? key - row0 : 0;
+                int rank, cnt;
+                ts_match(low, valid, sh, lane, rank, cnt);
+                int pos = 0;
+                if (valid) pos = ts_lds[low] + rank;
+                __builtin_amdgcn_wave_barrier();
+                if (valid && rank == cnt - 1) ts_lds[low] += cnt;
+                __builtin_amdgcn_wave_barrier();
+                if (valid) te[pos] = e;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
 
-// After the ranking the histogram array is free again (the next sampling call clears what it uses): it receives one flag
+// KgwBatchBuf.t_cnt (the histogram of the round-2 build; nothing else uses it now) receives one flag
 // per group of 8 consecutive source rows of the layer input ("octet", row index / 8) for the backward's src-major pass
 // (kgw_gat_aggregate_bwd_src, KgwLayerArgs.oct_flags): 1 = eight real rows of ONE node type of KgwGraph.short_types, none
 // of them a destination row of the layer, each with at most 8 entries over all its relation slots.
@@ -619,9 +765,23 @@ __global__ void __launch_bounds__(KGW_BLK) k_t_end(SampArgs A, int l0, int nl) {
     const KgwGraph& G = A.G;
     KgwBatchMeta* M = A.B.meta;
     const int NT = G.n_types;
+    const int64_t E1 = A.B.edge_cap + 1;
     for (int k = 0; k < nl; ++k) {
         const int l = l0 + k;
         if (blockIdx.x == 0 && threadIdx.x == 0) M->t_entries[l - 1] = M->cur[4 + k];
+        if (!M->error) {
+            // Z row and relation of every entry, from the chunk of its edge (independent gathers: this is the parallel half of
+            // the placement, k_ts_rows does the ordered half)
+            const int32_t* cE = A.B.t_tmp + (int64_t)k * 4 * E1 + E1;
+            const int n_ent = M->cur[4 + k];
+            for (int j = blockIdx.x * KGW_BLK + threadIdx.x; j < n_ent; j += gridDim.x * KGW_BLK) {
+                const int e = A.B.t_edge[l - 1][j];
+                const KgwChunk ck = A.B.chunks[cE[e]];
+                const int r = ck.rel, dT = G.rel_dst[r];
+                A.B.t_zrow[l - 1][j] = M->z_base[l - 1][dT] + ck.row * G.R_dst[dT] + G.rel_slot_dst[r];
+                if (A.B.t_rel[l - 1]) A.B.t_rel[l - 1][j] = (uint8_t)r;
+            }
+        }
         const int n_oct = M->error ? 0 : (M->src_base[l - 1][NT] + 7) >> 3;
         const int32_t* tp = A.B.t_ptr[l - 1];
         int32_t* out = A.B.t_cnt[l - 1];
@@ -647,18 +807,6 @@ __global__ void __launch_bounds__(KGW_BLK) k_t_end(SampArgs A, int l0, int nl) {
     }
 }
 
-// zero fill of up to two int32 arrays in one launch
-__global__ void __launch_bounds__(KGW_BLK) k_fill2_i32(int32_t* __restrict__ p0, int64_t n0, int32_t* __restrict__ p1, int64_t n1) {
-    const int64_t tid = (int64_t)blockIdx.x * KGW_BLK + threadIdx.x, nthr = (int64_t)gridDim.x * KGW_BLK;
-    const int4 z = make_int4(0, 0, 0, 0);
-    for (int64_t i = tid; i < (n0 >> 2); i += nthr) ((int4*)p0)[i] = z;
-    for (int64_t i = (n0 & ~3ll) + tid; i < n0; i += nthr) p0[i] = 0;
-    if (p1) {
-        for (int64_t i = tid; i < (n1 >> 2); i += nthr) ((int4*)p1)[i] = z;
-        for (int64_t i = (n1 & ~3ll) + tid; i < n1; i += nthr) p1[i] = 0;
-    }
-}
-
 }  // namespace
 
 // Parts of one sampling call (kgw_sample_batch_parts): hop h contributes part 2h (segments, chunks, and the flags on every
@@ -667,6 +815,31 @@ __global__ void __launch_bounds__(KGW_BLK) k_fill2_i32(int32_t* __restrict__ p0,
 // the meta block.  Between part 2h and 2h + 1 the caller may merge the flags of node types that are REPLICATED across
 // ranks (SNP-sharded multi-GPU mode: element-wise MIN over the ranks' g2l regions -- KGW_PENDING = -2 < -1 = unsampled,
 // local ids >= 0 are equal on every rank), so that every rank expands the same replicated frontier at the next hop.
+// buckets of 2^sh rows: as many as k_ts_scatter's LDS counters allow (small buckets = many wavefronts in k_ts_rows, short
+// ordered walks), at most 2^14 rows each (one wavefront keeps a bucket's row counters in LDS); digits 0 .. nb (nb = "relation
+// not computed by the layer")
+static int ts_plan(int64_t trows, int* sh_, int* nb_, int* nbits_) {
+    int sh = 8;
+    while (sh < 14 && (trows >> sh) + 1 > TS_MAX_NB) ++sh;
+    const int64_t nb = (trows >> sh) + 1;
+    if (nb > TS_MAX_NB) return 1;
+    int nbits = 1;
+    while ((1 << nbits) <= nb) ++nbits;
+    *sh_ = sh; *nb_ = (int)nb; *nbits_ = nbits;
+    return 0;
+}
+
+extern "C" int64_t kgw_sampler_scan_ints(int64_t seg_cap, int64_t node_slots, int64_t trow_cap) {
+    int64_t m = seg_cap > node_slots ? seg_cap : node_slots;
+    int64_t need = 2 * (m / KGW_TILE + 4);
+    int sh, nb, nbits;
+    if (!ts_plan(trow_cap, &sh, &nb, &nbits)) {
+        const int64_t t = (int64_t)2 * (nb + 1) * 512 + 2 * (nb + 2);
+        if (t > need) need = t;
+    }
+    return need;
+}
+
 extern "C" int kgw_sample_batch_parts(const KgwGraph* graph, const KgwBatchBuf* buf, const int64_t* seeds,
                                       int32_t n_seeds, int32_t seed_type, int32_t full_graph, int32_t part_begin,
                                       int32_t part_end, kgw_stream_t stream_) {
@@ -753,26 +926,15 @@ extern "C" int kgw_sample_batch_parts(const KgwGraph* graph, const KgwBatchBuf* 
             }
             if (tr > trows) trows = tr;
         }
-        {
-            int64_t g = ((trows + 1) / 4 + KGW_BLK - 1) / KGW_BLK;
-            if (g > SG) g = SG;
-            if (g < 1) g = 1;
-            k_fill2_i32<<<(int)g, KGW_BLK, 0, st>>>(buf->t_cnt[l0 - 1], trows + 1, nl == 2 ? buf->t_cnt[l0] : nullptr, trows + 1);
-        }
-        k_t_pass<false><<<SG, KGW_BLK, 0, st>>>(A, l0, nl);               // (+ the scan range)
-        if (nl == 2) {
-            k_scan_tiles<2><<<SG, KGW_BLK, 0, st>>>(buf->t_cnt[l0 - 1], buf->t_cnt[l0], buf->meta, buf->scan_tmp);
-            k_scan_top<2><<<1, KGW_BLK, 0, st>>>(buf->scan_tmp, buf->meta, 0);
-            k_scan_apply<2><<<SG, KGW_BLK, 0, st>>>(buf->t_cnt[l0 - 1], buf->t_cnt[l0], buf->t_ptr[l0 - 1], buf->t_ptr[l0],
-                                                          buf->meta, buf->scan_tmp);
-        } else {
-            k_scan_tiles<1><<<SG, KGW_BLK, 0, st>>>(buf->t_cnt[l0 - 1], nullptr, buf->meta, buf->scan_tmp);
-            k_scan_top<1><<<1, KGW_BLK, 0, st>>>(buf->scan_tmp, buf->meta, 0);
-            k_scan_apply<1><<<SG, KGW_BLK, 0, st>>>(buf->t_cnt[l0 - 1], nullptr, buf->t_ptr[l0 - 1], nullptr, buf->meta, buf->scan_tmp);
-        }
-        k_t_pass<true><<<SG, KGW_BLK, 0, st>>>(A, l0, nl);
-        k_t_rank<<<SG, KGW_BLK, 0, st>>>(A, l0, nl);
-        k_t_rank_big<<<SG, KGW_BLK, 0, st>>>(A, l0, nl);
+        int sh, nb, nbits;
+        if (ts_plan(trows, &sh, &nb, &nbits)) return KGW_E_UNSUPPORTED;  // (> 65 M src-major rows in one block)
+        const int nblk = SG >= 2048 ? 512 : 128;
+        if ((int64_t)nl * (nb + 1) * nblk + (int64_t)nl * (nb + 2) > buf->scan_cap) return KGW_E_RANGE;
+        k_ts_keys<<<nblk, KGW_BLK, (size_t)(nb + 1) * sizeof(int), st>>>(A, l0, nl, sh, nb);
+        k_ts_scan_rows<<<SG < 256 ? SG : 256, KGW_BLK, 0, st>>>(buf->scan_tmp, nl, nb, nblk, buf->meta);
+        k_ts_scan_tot<<<nl, 1024, 0, st>>>(buf->scan_tmp, nl, nb, nblk, buf->meta);
+        k_ts_scatter<<<nblk, KGW_BLK, (size_t)4 * (nb + 1) * sizeof(int), st>>>(A, l0, nl, sh, nb, nbits);
+        k_ts_rows<<<nb < 4 * SG ? nb : 4 * SG, 64, (size_t)sizeof(int) << sh, st>>>(A, l0, nl, sh, nb, nblk);
         k_t_end<<<SG, KGW_BLK, 0, st>>>(A, l0, nl);
         KGW_LAUNCH_CHECK();
     }

@@ -226,9 +226,10 @@ class BatchBuffers:
         self.t_edge = [torch.empty(dg.edge_cap + 1, **i32) for _ in range(L)]
         self.t_zrow = [torch.empty(dg.edge_cap + 1, **i32) for _ in range(L)]
         self.t_rel = [torch.empty(dg.edge_cap + 1, dtype=torch.uint8, device=dev) for _ in range(L)]
-        self.scan_cap = 2 * (max(dg.seg_cap, dg.node_slots, dg.trow_cap) // KGW_TILE + 4)
+        self.scan_cap = max(2 * (max(dg.seg_cap, dg.node_slots, dg.trow_cap) // KGW_TILE + 4),
+                            int(_lib.lib().kgw_sampler_scan_ints(dg.seg_cap, dg.node_slots, dg.trow_cap)))
         self.scan_tmp = torch.empty(self.scan_cap, **i32)
-        self.t_tmp = torch.empty(8 * (dg.edge_cap + 1), **i32)       # (two layers stage their entries one behind the other)
+        self.t_tmp = torch.empty(8 * (dg.edge_cap + 1), **i32)       # (the src-major sort's keys / chunk ids / sorted pairs of two layers)
         nbytes = C.sizeof(KgwBatchMeta)
         self.meta = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         self.meta_host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
