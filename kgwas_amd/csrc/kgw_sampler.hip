@@ -492,19 +492,23 @@ __global__ void __launch_bounds__(64) k_layer_tables(SampArgs A) {
 // + slot): inside a row the entries then stand in ascending edge order, the summation order of the backward pass, the same run
 // to run.  Round 3: a two-digit radix sort without global atomics instead of atomic histogram + atomic cursor fill + in-row rank
 // (those were 0.25 of the sampler's 0.43 ms):
-//   k_ts_keys     lane per edge: chunk of the edge (binary search), row key (INVALID for relations the layer does not compute),
-//                 the HIGH digit (key >> sh; one bucket = 2^sh consecutive rows) counted per block in LDS.  Blocks own
-//                 CONTIGUOUS edge ranges;
-//   k_ts_scan     exclusive scan of the [digit][block] counts (one block per layer);
-//   k_ts_scatter  stable scatter by high digit: a block's four wavefronts own contiguous quarters of its range, count them,
-//                 start behind each other, and walk their quarter in order 64 edges at a time -- the rank of an edge among the
-//                 lanes with the same digit comes from ballots (no atomics, no dependence on arrival order);
-//   k_ts_rows     one wavefront per bucket: counts of the bucket's rows in LDS, exclusive scan = the row pointers (written for
-//                 every row, empty ones included), then the bucket's entries placed in order the same way, with the Z row and
-//                 relation of each looked up from its chunk.
+//   k_ts_keys      lane per edge: chunk of the edge (the chunk list is walked: one binary search per wavefront, then the end
+//                  offsets of 64 chunks in registers and a 6-step search through shuffles), row key (INVALID for relations the
+//                  layer does not compute), the HIGH digit (key >> sh; one bucket = 2^sh consecutive rows) counted per block in
+//                  LDS.  Blocks own CONTIGUOUS edge ranges;
+//   k_ts_scan_rows / k_ts_scan_tot   starts of the (digit, block) cells: prefix over the blocks inside a digit, then over the
+//                  digits' totals;
+//   k_ts_scatter   stable scatter by high digit: a block's four wavefronts own contiguous quarters of its range, count them,
+//                  start behind each other, and walk their quarter in order 64 edges at a time -- the rank of an edge among the
+//                  lanes with the same digit comes from ballots (no atomics, no dependence on arrival order);
+//   k_ts_rows      one block per bucket, done the same way on the low digit: counts of the bucket's rows in LDS, exclusive scan
+//                  = the row pointers (written for every row, empty ones included), then the entries' edge ids placed in order;
+//   k_t_end        Z row and relation of every entry looked up from its chunk (independent gathers), octet flags.
+// Measured (512-seed batch of the benchmark graph, sampler alone, 256-block launches): 433 -> 355 us per batch; beside the
+// training step it now costs the step 40 - 50 us instead of 70 - 80 (no global atomics: 1.18 -> 1.155 ms per step).
 // KgwBatchBuf.t_tmp per layer: key[edge], chunk[edge], sorted key, sorted edge -- 4 x (edge_cap + 1) ints; the counts live in
 // KgwBatchBuf.scan_tmp ([layer][digit][block]); KgwBatchMeta.cur[4 + k] = entries of layer l0 + k.
-// (blocks of k_ts_keys / k_ts_scatter = contiguous edge ranges: 128 beside a training step, 512 when the call has the GPU)
+// (blocks of k_ts_keys / k_ts_scatter = contiguous edge ranges: 256 beside a training step, 512 when the call has the GPU)
 constexpr int TS_INVALID = 0x7fffffff;
 constexpr int TS_MAX_NB = 4000;                // buckets: 4 x (nb + 1) counters must fit 64 KB of LDS in k_ts_scatter
 
@@ -590,26 +594,35 @@ __global__ void __launch_bounds__(KGW_BLK) k_ts_keys(SampArgs A, int l0, int nl,
 // Offsets of the (digit, block) cells: inside a digit the exclusive prefix over its blocks (one wavefront per digit row, in
 // place) and the digit's total; then the exclusive scan of the totals (one block per layer).  Start of cell (d, b) =
 // dbase[d] + H[d][b]; dbase[nb] = entries of the layer (digit nb collects the edges of relations the layer does not compute).
-__global__ void __launch_bounds__(KGW_BLK) k_ts_scan_rows(int32_t* scan_tmp, int nl, int nb, int nblk, const KgwBatchMeta* __restrict__ M) {
+template <int V>      // V = nblk / 64 consecutive cells per lane
+__global__ void __launch_bounds__(KGW_BLK) k_ts_scan_rows(int32_t* scan_tmp, int nl, int nb, const KgwBatchMeta* __restrict__ M) {
     if (M->error) return;
+    constexpr int nblk = 64 * V;
     const int lane = kgw_lane();
     int32_t* tot0 = scan_tmp + (int64_t)nl * (nb + 1) * nblk;
     const int nrow = nl * (nb + 1);
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < nrow; row += gridDim.x * 4) {
-        int32_t* H = scan_tmp + (int64_t)row * nblk;
-        int carry = 0;
-        for (int i0 = 0; i0 < nblk; i0 += 64) {
-            const int v = (i0 + lane < nblk) ? H[i0 + lane] : 0;
-            int incl = v;
+        int32_t* H = scan_tmp + (int64_t)row * nblk + V * lane;
+        int v[V];
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int o = __shfl_up(incl, d, 64);
-                incl += lane >= d ? o : 0;
-            }
-            if (i0 + lane < nblk) H[i0 + lane] = carry + incl - v;
-            carry += __shfl(incl, 63, 64);
+        for (int j = 0; j < V; j += 2) { const int2 t = *(const int2*)(H + j); v[j] = t.x; v[j + 1] = t.y; }
+        int mine = 0;
+#pragma unroll
+        for (int j = 0; j < V; ++j) mine += v[j];
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            incl += lane >= d ? o : 0;
         }
-        if (lane == 0) tot0[(row / (nb + 1)) * (nb + 2) + row % (nb + 1)] = carry;
+        int ex = incl - mine;
+#pragma unroll
+        for (int j = 0; j < V; j += 2) {
+            const int a = ex, b = ex + v[j];
+            *(int2*)(H + j) = make_int2(a, b);
+            ex = b + v[j + 1];
+        }
+        if (lane == 63) tot0[(row / (nb + 1)) * (nb + 2) + row % (nb + 1)] = incl;
     }
 }
 
@@ -640,6 +653,11 @@ __global__ void __launch_bounds__(1024) k_ts_scan_tot(int32_t* scan_tmp, int nl,
     if (tid == 0) T[n] = carry;
 }
 
+// (ordered walks below: a global store inside the loop would put its acknowledgement on the critical path of the next
+//  group's loads -- vector memory operations return in issue order -- so a tile's keys are loaded up front, its positions kept
+//  in registers, and the stores of the whole tile issued together)
+constexpr int TS_TILE = 512;                   // entries of an ordered tile (8 groups of 64)
+
 __global__ void __launch_bounds__(KGW_BLK) k_ts_scatter(SampArgs A, int l0, int nl, int sh, int nb, int nbits) {
     extern __shared__ int ts_lds[];            // [4][nb + 1]: per wavefront, first its counts, then its running write positions
     const KgwBatchMeta* M = A.B.meta;
@@ -661,9 +679,13 @@ __global__ void __launch_bounds__(KGW_BLK) k_ts_scatter(SampArgs A, int l0, int 
         ts_block_range(n, blockIdx.x, gridDim.x, beg, end);
         const int q = (((end - beg) + 3) / 4 + 63) & ~63;          // a wavefront's quarter: whole groups of 64
         const int wb = min(end, beg + wv * q), we = min(end, wb + q);
-        for (int e = wb + lane; e < we; e += 64) {
-            const int key = keyE[e];
-            atomicAdd(&mine[key == TS_INVALID ? nb : (key >> sh)], 1);
+        for (int g = wb; g < we; g += TS_TILE) {
+            int kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kk[u] = (g + 64 * u + lane < we) ? keyE[g + 64 * u + lane] : -1;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (kk[u] >= 0) atomicAdd(&mine[kk[u] == TS_INVALID ? nb : (kk[u] >> sh)], 1);
         }
         __syncthreads();
         for (int d = threadIdx.x; d <= nb; d += KGW_BLK) {
@@ -671,32 +693,45 @@ __global__ void __launch_bounds__(KGW_BLK) k_ts_scatter(SampArgs A, int l0, int 
             for (int w = 0; w < 4; ++w) { const int t = ts_lds[w * (nb + 1) + d]; ts_lds[w * (nb + 1) + d] = run; run += t; }
         }
         __syncthreads();
-        for (int g = wb; g < we; g += 64) {
-            const int e = g + lane;
-            const bool valid = e < we;
-            const int key = valid ? keyE[e] : TS_INVALID;
-            const int d = key == TS_INVALID ? nb : (key >> sh);
-            int rank, cnt;
-            ts_match(d, valid, nbits, lane, rank, cnt);
-            int pos = 0;
-            if (valid) pos = mine[d] + rank;
-            __builtin_amdgcn_wave_barrier();                          // (every lane has read its digit's position)
-            if (valid && rank == cnt - 1) mine[d] += cnt;
-            __builtin_amdgcn_wave_barrier();
-            if (valid && d < nb) { keyS[pos] = key; eS[pos] = e; }
+        for (int g = wb; g < we; g += TS_TILE) {
+            int kk[8], pp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kk[u] = (g + 64 * u + lane < we) ? keyE[g + 64 * u + lane] : -1;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool valid = kk[u] >= 0;
+                const int d = (!valid || kk[u] == TS_INVALID) ? nb : (kk[u] >> sh);
+                int rank, cnt;
+                ts_match(d, valid, nbits, lane, rank, cnt);
+                int pos = -1;
+                if (valid) pos = mine[d] + rank;
+                __builtin_amdgcn_wave_barrier();                      // (every lane has read its digit's position)
+                if (valid && rank == cnt - 1) mine[d] += cnt;
+                __builtin_amdgcn_wave_barrier();
+                pp[u] = (valid && d < nb) ? pos : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (pp[u] >= 0) { keyS[pp[u]] = kk[u]; eS[pp[u]] = g + 64 * u + lane; }
         }
         __syncthreads();
     }
 }
 
-__global__ void __launch_bounds__(64) k_ts_rows(SampArgs A, int l0, int nl, int sh, int nb, int nblk) {
-    extern __shared__ int ts_lds[];            // [2^sh]: counts of the bucket's rows, then their running write positions
+// W wavefronts per bucket: each owns a contiguous W-th of the bucket's (already edge-ordered) entries, counts its rows, starts
+// behind the wavefronts before it, and places its entries in order -- the longest bucket (a few thousand entries around the most
+// connected genes) sets the kernel's time, W = 4 divides it.
+template <int W>
+__global__ void __launch_bounds__(64 * W) k_ts_rows(SampArgs A, int l0, int nl, int sh, int nb, int nblk) {
+    extern __shared__ int ts_lds[];            // [W][2^sh]: per wavefront the counts of the bucket's rows, then its running positions
+    __shared__ int s_w[W];
     const KgwGraph& G = A.G;
     KgwBatchMeta* M = A.B.meta;
     if (M->error) return;
     const int64_t E1 = A.B.edge_cap + 1;
-    const int lane = kgw_lane();
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nrow = 1 << sh;
+    int* mine = ts_lds + wv * nrow;
     for (int k = 0; k < nl; ++k) {
         const int l = l0 + k;
         const int TR = M->t_base[l - 1][G.n_types];
@@ -705,54 +740,75 @@ __global__ void __launch_bounds__(64) k_ts_rows(SampArgs A, int l0, int nl, int 
         const int32_t* dbase = A.B.scan_tmp + (int64_t)nl * (nb + 1) * nblk + (int64_t)k * (nb + 2);
         int32_t* tp = A.B.t_ptr[l - 1];
         int32_t* te = A.B.t_edge[l - 1];
-        if (blockIdx.x == 0 && lane == 0) M->cur[4 + k] = dbase[nb];                            // entries of the layer
+        if (blockIdx.x == 0 && tid == 0) M->cur[4 + k] = dbase[nb];                             // entries of the layer
         for (int b = blockIdx.x; b < nb; b += gridDim.x) {
             const int row0 = b << sh;
             if (row0 > TR) break;
             const int s0 = dbase[b], s1 = dbase[b + 1];
-            for (int i = lane; i < nrow; i += 64) ts_lds[i] = 0;
-            __builtin_amdgcn_wave_barrier();
-            for (int p = s0 + lane; p < s1; p += 256) {                   // (four independent loads in flight)
-                int kk[4];
+            for (int i = tid; i < W * nrow; i += 64 * W) ts_lds[i] = 0;
+            __syncthreads();
+            const int q = (((s1 - s0) + W - 1) / W + 63) & ~63;      // a wavefront's share: whole groups of 64
+            const int wb = min(s1, s0 + wv * q), we = min(s1, wb + q);
+            for (int p = wb; p < we; p += TS_TILE) {
+                int kk[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) kk[u] = (p + 64 * u < s1) ? keyS[p + 64 * u] : -1;
+                for (int u = 0; u < 8; ++u) kk[u] = (p + 64 * u + lane < we) ? keyS[p + 64 * u + lane] : -1;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) if (kk[u] >= 0) atomicAdd(&ts_lds[kk[u] - row0], 1);
+                for (int u = 0; u < 8; ++u) if (kk[u] >= 0) atomicAdd(&mine[kk[u] - row0], 1);
             }
-            __builtin_amdgcn_wave_barrier();
+            __syncthreads();
+            // row pointers = exclusive scan of the rows' totals (every row of the bucket, empty ones included); each wavefront's
+            // counter becomes its first write position in the row
             int carry = s0;
-            for (int i0 = 0; i0 < nrow && row0 + i0 <= TR; i0 += 64) {
-                const int v = ts_lds[i0 + lane];
-                int incl = v;
+            for (int i0 = 0; i0 < nrow && row0 + i0 <= TR; i0 += 64 * W) {
+                const int i = i0 + tid;
+                int c[W], tot = 0;
+#pragma unroll
+                for (int w = 0; w < W; ++w) { c[w] = ts_lds[w * nrow + i]; tot += c[w]; }
+                int incl = tot;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) {
                     const int o = __shfl_up(incl, d, 64);
                     incl += lane >= d ? o : 0;
                 }
-                const int ex = carry + incl - v;
-                ts_lds[i0 + lane] = ex;
-                if (row0 + i0 + lane <= TR) tp[row0 + i0 + lane] = ex;
-                carry += __shfl(incl, 63, 64);
+                if (lane == 63) s_w[wv] = incl;
+                __syncthreads();
+                int wbase = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < W; ++w) { wbase += w < wv ? s_w[w] : 0; total += s_w[w]; }
+                int run = carry + wbase + incl - tot;
+                if (row0 + i <= TR) tp[row0 + i] = run;
+#pragma unroll
+                for (int w = 0; w < W; ++w) { ts_lds[w * nrow + i] = run; run += c[w]; }
+                carry += total;
+                __syncthreads();
             }
-            __builtin_amdgcn_wave_barrier();
-            // the bucket's entries in order, 64 at a time (the next group's key / edge loads are issued before this group is placed)
-            int kn = (s0 + lane < s1) ? keyS[s0 + lane] : 0, en = (s0 + lane < s1) ? eS[s0 + lane] : 0;
-            for (int g = s0; g < s1; g += 64) {
-                const int p = g + lane;
-                const bool valid = p < s1;
-                const int key = kn, e = en;
-                if (p + 64 < s1) { kn = keyS[p + 64]; en = eS[p + 64]; }
-                const int low = valid ? key - row0 : 0;
-                int rank, cnt;
-                ts_match(low, valid, sh, lane, rank, cnt);
-                int pos = 0;
-                if (valid) pos = ts_lds[low] + rank;
-                __builtin_amdgcn_wave_barrier();
-                if (valid && rank == cnt - 1) ts_lds[low] += cnt;
-                __builtin_amdgcn_wave_barrier();
-                if (valid) te[pos] = e;
+            // the wavefront's entries in order, a tile of 8 groups at a time: keys and edge ids loaded up front, positions kept in
+            // registers, the tile's stores issued together
+            for (int g = wb; g < we; g += TS_TILE) {
+                int kk[8], ee[8], pp[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool in = g + 64 * u + lane < we;
+                    kk[u] = in ? keyS[g + 64 * u + lane] : -1;
+                    ee[u] = in ? eS[g + 64 * u + lane] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool valid = kk[u] >= 0;
+                    const int low = valid ? kk[u] - row0 : 0;
+                    int rank, cnt;
+                    ts_match(low, valid, sh, lane, rank, cnt);
+                    pp[u] = -1;
+                    if (valid) pp[u] = mine[low] + rank;
+                    __builtin_amdgcn_wave_barrier();
+                    if (valid && rank == cnt - 1) mine[low] += cnt;
+                    __builtin_amdgcn_wave_barrier();
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (pp[u] >= 0) te[pp[u]] = ee[u];
             }
-            __builtin_amdgcn_wave_barrier();
+            __syncthreads();
         }
     }
 }
@@ -774,12 +830,21 @@ __global__ void __launch_bounds__(KGW_BLK) k_t_end(SampArgs A, int l0, int nl) {
             // the placement, k_ts_rows does the ordered half)
             const int32_t* cE = A.B.t_tmp + (int64_t)k * 4 * E1 + E1;
             const int n_ent = M->cur[4 + k];
-            for (int j = blockIdx.x * KGW_BLK + threadIdx.x; j < n_ent; j += gridDim.x * KGW_BLK) {
-                const int e = A.B.t_edge[l - 1][j];
-                const KgwChunk ck = A.B.chunks[cE[e]];
-                const int r = ck.rel, dT = G.rel_dst[r];
-                A.B.t_zrow[l - 1][j] = M->z_base[l - 1][dT] + ck.row * G.R_dst[dT] + G.rel_slot_dst[r];
-                if (A.B.t_rel[l - 1]) A.B.t_rel[l - 1][j] = (uint8_t)r;
+            const int nthr = gridDim.x * KGW_BLK;
+            for (int j0 = blockIdx.x * KGW_BLK + threadIdx.x; j0 < n_ent; j0 += 4 * nthr) {       // (four independent chains in flight)
+                int e[4], c[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) e[u] = (j0 + u * nthr < n_ent) ? A.B.t_edge[l - 1][j0 + u * nthr] : -1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) c[u] = e[u] >= 0 ? cE[e[u]] : 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (e[u] < 0) continue;
+                    const KgwChunk ck = A.B.chunks[c[u]];
+                    const int r = ck.rel, dT = G.rel_dst[r];
+                    A.B.t_zrow[l - 1][j0 + u * nthr] = M->z_base[l - 1][dT] + ck.row * G.R_dst[dT] + G.rel_slot_dst[r];
+                    if (A.B.t_rel[l - 1]) A.B.t_rel[l - 1][j0 + u * nthr] = (uint8_t)r;
+                }
             }
         }
         const int n_oct = M->error ? 0 : (M->src_base[l - 1][NT] + 7) >> 3;
@@ -832,12 +897,12 @@ static int ts_plan(int64_t trows, int* sh_, int* nb_, int* nbits_) {
 extern "C" int64_t kgw_sampler_scan_ints(int64_t seg_cap, int64_t node_slots, int64_t trow_cap) {
     int64_t m = seg_cap > node_slots ? seg_cap : node_slots;
     int64_t need = 2 * (m / KGW_TILE + 4);
-    int sh, nb, nbits;
-    if (!ts_plan(trow_cap, &sh, &nb, &nbits)) {
-        const int64_t t = (int64_t)2 * (nb + 1) * 512 + 2 * (nb + 2);
-        if (t > need) need = t;
-    }
-    return need;
+    // the sort's [layer][bucket][block] counts + bucket starts: the bucket count depends on the rows a CALL can have (static
+    // capacities may be far below trow_cap and then use finer buckets), so the bound is the largest plan there is
+    int64_t nbmax = trow_cap / 256 + 2;                                  // (sh >= 8)
+    if (nbmax > TS_MAX_NB) nbmax = TS_MAX_NB;
+    const int64_t t = 2 * (nbmax + 1) * 512 + 2 * (nbmax + 2);
+    return t > need ? t : need;
 }
 
 extern "C" int kgw_sample_batch_parts(const KgwGraph* graph, const KgwBatchBuf* buf, const int64_t* seeds,
@@ -928,13 +993,27 @@ extern "C" int kgw_sample_batch_parts(const KgwGraph* graph, const KgwBatchBuf* 
         }
         int sh, nb, nbits;
         if (ts_plan(trows, &sh, &nb, &nbits)) return KGW_E_UNSUPPORTED;  // (> 65 M src-major rows in one block)
-        const int nblk = SG >= 2048 ? 512 : 128;
+        const int nblk = SG >= 2048 ? 512 : (SG >= 256 ? 256 : 128);
         if ((int64_t)nl * (nb + 1) * nblk + (int64_t)nl * (nb + 2) > buf->scan_cap) return KGW_E_RANGE;
         k_ts_keys<<<nblk, KGW_BLK, (size_t)(nb + 1) * sizeof(int), st>>>(A, l0, nl, sh, nb);
-        k_ts_scan_rows<<<SG < 256 ? SG : 256, KGW_BLK, 0, st>>>(buf->scan_tmp, nl, nb, nblk, buf->meta);
+        static bool attr_set = false;     // idempotent; a benign race at worst repeats the call
+        if (!attr_set) {
+            KGW_HIP(hipFuncSetAttribute((const void*)k_ts_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        if (nblk == 128) k_ts_scan_rows<2><<<SG < 1024 ? SG : 1024, KGW_BLK, 0, st>>>(buf->scan_tmp, nl, nb, buf->meta);
+        else if (nblk == 256) k_ts_scan_rows<4><<<SG < 1024 ? SG : 1024, KGW_BLK, 0, st>>>(buf->scan_tmp, nl, nb, buf->meta);
+        else if (nblk == 512) k_ts_scan_rows<8><<<SG < 1024 ? SG : 1024, KGW_BLK, 0, st>>>(buf->scan_tmp, nl, nb, buf->meta);
+        else return KGW_E_RANGE;
         k_ts_scan_tot<<<nl, 1024, 0, st>>>(buf->scan_tmp, nl, nb, nblk, buf->meta);
         k_ts_scatter<<<nblk, KGW_BLK, (size_t)4 * (nb + 1) * sizeof(int), st>>>(A, l0, nl, sh, nb, nbits);
-        k_ts_rows<<<nb < 4 * SG ? nb : 4 * SG, 64, (size_t)sizeof(int) << sh, st>>>(A, l0, nl, sh, nb, nblk);
+        if (sh <= 12) {                   // four wavefronts per bucket while their counters fit 64 KB of LDS
+            // (beside a training step, sampler grid 256: 1 024 blocks here 1.154 - 1.165 ms per step, 512: 1.175, 256: 1.195 --
+            // the short launch disturbs the step less than the narrow one)
+            k_ts_rows<4><<<nb < 4 * SG ? nb : 4 * SG, 256, (size_t)4 * sizeof(int) << sh, st>>>(A, l0, nl, sh, nb, nblk);
+        } else {
+            k_ts_rows<1><<<nb < 4 * SG ? nb : 4 * SG, 64, (size_t)sizeof(int) << sh, st>>>(A, l0, nl, sh, nb, nblk);
+        }
         k_t_end<<<SG, KGW_BLK, 0, st>>>(A, l0, nl);
         KGW_LAUNCH_CHECK();
     }
