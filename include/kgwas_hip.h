@@ -9,7 +9,10 @@
  * caller (torch-allocated); no function allocates, frees or synchronises; every function only
  * enqueues work on `stream` (a hipStream_t) and returns a status:
  *      0 = ok, <0 = argument error (KGW_E_*), >0 = hipError_t from a launch.
- * No C++ exceptions cross this boundary.  Functions are re-entrant (no global mutable state).
+ * No C++ exceptions cross this boundary.  Functions are re-entrant (no global mutable state).  What the library keeps per
+ * process is immutable after first use: a handful of launch-shape constants read ONCE from KGW_* environment variables (timing
+ * experiments: KGW_AGG_GRID_CAP, KGW_G3_NW, KGW_SPLITK_BLOCKS, ... -- unset in normal use) and the one-time
+ * hipFuncSetAttribute calls of the kernels that take more than 64 KB of LDS.
  *
  * Vocabulary (the reference's domain): node types, relations (= edge types), seeds, hops,
  * segments (= one destination row of one relation), chunks (<= KGW_CHUNK edges of one segment).
