@@ -23,6 +23,25 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.kgw_status_string(-1) == b'null pointer argument'
 
 
+def test_sampler_scratch_size_covers_every_sort_plan():
+    """kgw_sampler_scan_ints (the size KgwBatchBuf.scan_tmp must have): at least the hops' scan scratch, and at least the
+    [2 layers][buckets + 1][512 blocks] counts + bucket starts of the src-major radix sort for ANY row count up to trow_cap
+    (static capacities below trow_cap use finer buckets: up to 4 000 of them, never fewer than 256 rows each)."""
+    from kgwas_amd import _lib
+    lib = _lib.lib()
+    for trow_cap in (0, 100, 5_000, 1_087_035, 5_000_000, 60_000_000):
+        n = int(lib.kgw_sampler_scan_ints(10_000, 900_000, trow_cap))
+        assert n >= 2 * (900_000 // _lib.KGW_TILE + 4)
+        for rows in {trow_cap, trow_cap // 2, trow_cap // 5, min(trow_cap, 1_100_000)}:
+            sh = 8
+            while sh < 14 and (rows >> sh) + 1 > 4000:
+                sh += 1
+            nb = (rows >> sh) + 1
+            if nb <= 4000:
+                assert n >= 2 * (nb + 1) * 512 + 2 * (nb + 2), (trow_cap, rows, nb)
+    assert int(lib.kgw_sampler_scan_ints(50_000_000, 10, 10)) >= 2 * (50_000_000 // _lib.KGW_TILE + 4)
+
+
 def test_abi_struct_sizes_and_argument_checks():
     from kgwas_amd import _lib
     lib = _lib.lib()
