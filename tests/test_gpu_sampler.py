@@ -137,8 +137,8 @@ def test_block_structures_are_consistent(small_kg, edge_case_graph, which):
                 ok = all(tptr[t0 + (q + 1) * Rs] - tptr[t0 + q * Rs] <= 8 for q in range(8))
             assert bool(flags[o]) == ok, (l, o)
         assert ne <= n_edges_all
-        # deterministic order: inside every src-major row the entries ascend by edge id (the atomic cursor of the
-        # fill only decides staging slots; k_t_rank fixes the final order)
+        # deterministic order: inside every src-major row the entries ascend by edge id (the structure is the edge list
+        # STABLY sorted by row: k_ts_scatter / k_ts_rows rank equal keys by lane order, nothing depends on arrival order)
         row_of = np.repeat(np.arange(t_rows), np.diff(tptr))
         same = row_of[1:] == row_of[:-1]
         assert np.all(tedge[1:][same] > tedge[:-1][same])
