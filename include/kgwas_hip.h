@@ -225,7 +225,9 @@ int kgw_struct_sizes(int64_t* out, int n);
  * kgwas/utils.py:446-461).                                                                    */
 int kgw_sample_batch(const KgwGraph* graph, const KgwBatchBuf* buf, const int64_t* seeds,
                      int32_t n_seeds, int32_t seed_type, int32_t full_graph, kgw_stream_t stream);
-/* ints KgwBatchBuf.scan_tmp must hold (KgwBatchBuf.scan_cap) for buffers of these capacities.                              */
+/* ints KgwBatchBuf.scan_tmp must hold (KgwBatchBuf.scan_cap) for buffers of these capacities.  (The src-major sort of
+ * kgw_sample_batch takes blocks of up to 147 M src-major rows = sum over node types of rows x relations leaving the type;
+ * beyond that the call returns KGW_E_UNSUPPORTED.)                                                                          */
 int64_t kgw_sampler_scan_ints(int64_t seg_cap, int64_t node_slots, int64_t trow_cap);
 /* The same call in parts [part_begin, part_end] (kgw_sample_batch = parts 0 .. 2*n_hops): hop h is part 2h (its segments
  * and chunks, and the flag KGW_PENDING = -2 in g2l on every not-yet-sampled source node) and part 2h+1 (flags -> local

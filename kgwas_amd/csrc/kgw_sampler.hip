@@ -510,7 +510,8 @@ __global__ void __launch_bounds__(64) k_layer_tables(SampArgs A) {
 // KgwBatchBuf.scan_tmp ([layer][digit][block]); KgwBatchMeta.cur[4 + k] = entries of layer l0 + k.
 // (blocks of k_ts_keys / k_ts_scatter = contiguous edge ranges: 256 beside a training step, 512 when the call has the GPU)
 constexpr int TS_INVALID = 0x7fffffff;
-constexpr int TS_MAX_NB = 4000;                // buckets: 4 x (nb + 1) counters must fit 64 KB of LDS in k_ts_scatter
+constexpr int TS_MAX_NB = 4000;                // buckets aimed at: 4 x (nb + 1) counters fit 64 KB of LDS in k_ts_scatter
+constexpr int TS_HARD_MAX_NB = 9000;           // buckets at most (graphs above 65 M src-major rows: 2^14-row buckets, 144 KB of LDS)
 
 __device__ __forceinline__ void ts_block_range(int n, int b, int nblk, int& beg, int& end) {
     int per = (n + nblk - 1) / nblk;
@@ -887,7 +888,7 @@ static int ts_plan(int64_t trows, int* sh_, int* nb_, int* nbits_) {
     int sh = 8;
     while (sh < 14 && (trows >> sh) + 1 > TS_MAX_NB) ++sh;
     const int64_t nb = (trows >> sh) + 1;
-    if (nb > TS_MAX_NB) return 1;
+    if (nb > TS_HARD_MAX_NB) return 1;
     int nbits = 1;
     while ((1 << nbits) <= nb) ++nbits;
     *sh_ = sh; *nb_ = (int)nb; *nbits_ = nbits;
@@ -901,6 +902,7 @@ extern "C" int64_t kgw_sampler_scan_ints(int64_t seg_cap, int64_t node_slots, in
     // capacities may be far below trow_cap and then use finer buckets), so the bound is the largest plan there is
     int64_t nbmax = trow_cap / 256 + 2;                                  // (sh >= 8)
     if (nbmax > TS_MAX_NB) nbmax = TS_MAX_NB;
+    if ((trow_cap >> 14) + 2 > nbmax) nbmax = (trow_cap >> 14) + 2;      // (beyond 65 M rows the 2^14-row buckets outnumber that)
     const int64_t t = 2 * (nbmax + 1) * 512 + 2 * (nbmax + 2);
     return t > need ? t : need;
 }
@@ -992,7 +994,7 @@ extern "C" int kgw_sample_batch_parts(const KgwGraph* graph, const KgwBatchBuf* 
             if (tr > trows) trows = tr;
         }
         int sh, nb, nbits;
-        if (ts_plan(trows, &sh, &nb, &nbits)) return KGW_E_UNSUPPORTED;  // (> 65 M src-major rows in one block)
+        if (ts_plan(trows, &sh, &nb, &nbits)) return KGW_E_UNSUPPORTED;  // (> 147 M src-major rows in one block)
         const int nblk = SG >= 2048 ? 512 : (SG >= 256 ? 256 : 128);
         if ((int64_t)nl * (nb + 1) * nblk + (int64_t)nl * (nb + 2) > buf->scan_cap) return KGW_E_RANGE;
         k_ts_keys<<<nblk, KGW_BLK, (size_t)(nb + 1) * sizeof(int), st>>>(A, l0, nl, sh, nb);
