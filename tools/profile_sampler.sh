@@ -1,3 +1,6 @@
+#!/bin/bash
+# The sampler's structural tests, its stand-alone timing (tools/sampler_bench.py) and a rocprofv3 kernel trace of it with the
+# median duration of every kernel per grid size.  usage (via gpurun, from the repo root): bash tools/profile_sampler.sh
 timeout 600 python -m pytest tests/test_gpu_sampler.py tests/test_gpu_graph.py tests/test_gpu_golden.py -q -m gpu -x 2>&1 | tail -2
 timeout 300 python tools/sampler_bench.py 2>/dev/null | tail -4
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
