@@ -2,7 +2,12 @@
 """bench.py -- KGWAS hot path on MI355X: full fast-mode KG minibatch training.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under a launcher -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ... --
+     or plainly: without WORLD_SIZE in the environment bench.py starts its N ranks itself, one per GPU over RCCL; on a box with
+     fewer than N GPUs the ranks share devices over gloo -- a dry run of the code path, flagged in the line, not a measurement)
+    python bench.py --as-rank R/P [--scaling ... --parallelism ...]
+     ONE GPU doing the work of rank R of a P-GPU job with every collective stubbed (torch.distributed's "fake" backend): the
+     per-rank compute time a P-GPU run would have, to which tools/scale_model.py adds the xGMI cost of the collectives the line lists
 
 One "step" = one training step of kgwas/kgwas.py:129-151 on one 512-seed batch per GPU: device-side
 2-hop full-neighbourhood sampling, feature slicing, 3 feature MLPs, 2 fused attention-aggregate
@@ -205,6 +210,24 @@ def run_pmc_passes(args, outdir, timeout_s=300):
     return summ, None
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, exactly as the documented
+    command does (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    <same arguments>).  The children inherit stdout: rank 0's JSON line is the only thing written to it."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    print('bench.py: starting %d ranks: %s' % (args.gpus, ' '.join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -228,7 +251,12 @@ def main():
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 counter passes (roofline.traffic = null)')
     ap.add_argument('--no-epoch', action='store_true', help='skip the measured epoch (956 training steps + validation pass)')
     ap.add_argument('--eager', action='store_true', help='issue every launch from the host instead of replaying one HIP graph per step')
+    ap.add_argument('--as-rank', default=None, metavar='R/P',
+                    help='emulate rank R of a P-GPU job on ONE GPU: its share of the seeds / of the SNP range, every collective a '
+                         'no-op of the right size ("fake" process group); prints that rank\'s compute time per step')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and args.as_rank is None:
+        raise SystemExit(self_launch(args))
 
     # stdout carries EXACTLY one JSON line: everything else that writes to file descriptor 1 (native libraries included --
     # a collective backend announcing its peers, a BLAS tuner) goes to stderr until the line is printed
@@ -239,17 +267,28 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}')
+    if args.gpus > 1 and world != args.gpus and args.as_rank is None:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks (or unset WORLD_SIZE: bench.py starts them itself)')
     assert torch.cuda.is_available(), 'bench.py needs a ROCm GPU'
-    local_rank %= torch.cuda.device_count()      # (single-GPU boxes: KGW_DIST_BACKEND=gloo lets 2 ranks share cuda:0 for a dry run)
+    n_dev = torch.cuda.device_count()
+    shared_devices = world > n_dev               # fewer GPUs than ranks: the ranks share devices (RCCL refuses that: gloo)
+    local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     dev = f'cuda:{local_rank}'
-    if world > 1 or os.environ.get('KGW_FORCE_MULTIRANK_PATH') == '1':       # (the latter: one rank through the RCCL path)
+    emulated = None
+    if args.as_rank is not None:
+        # rank R of P on one GPU: partitioning, buffers and launches of that rank, collectives that move nothing
+        import torch.distributed as dist
+        from torch.testing._internal.distributed.fake_pg import FakeStore
+        r_, p_ = (int(v) for v in args.as_rank.split('/'))
+        assert 0 <= r_ < p_ and world == 1, '--as-rank R/P runs in ONE process'
+        dist.init_process_group(backend='fake', rank=r_, world_size=p_, store=FakeStore())
+        rank, world, emulated = r_, p_, {'rank': r_, 'world': p_}
+    elif world > 1 or os.environ.get('KGW_FORCE_MULTIRANK_PATH') == '1':       # (the latter: one rank through the RCCL path)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29555'); os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
-        backend = os.environ.get('KGW_DIST_BACKEND', 'nccl')          # "nccl" == RCCL over xGMI on ROCm
+        backend = os.environ.get('KGW_DIST_BACKEND', 'gloo' if shared_devices else 'nccl')   # "nccl" == RCCL over xGMI on ROCm
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device(dev))
         else:
@@ -362,6 +401,14 @@ def main():
         edges_kernel, edges_ref = stats_e
     if shard and rank != 0:
         seeds = 0                             # (every rank works on the same batches: count the seeds once)
+    # did the next batch's sampler really run beside the step (two streams on one hardware queue would serialise silently)?
+    # measured, after the timed region: n steps with it, n without, n sampler replays alone (every rank takes part)
+    overlap = None
+    if os.environ.get('KGW_BENCH_OVERLAP_CHECK', '1') == '1':
+        if gs is not None:
+            overlap = gs.measure_overlap(min(args.steps, 20))
+        elif shard and st_.use_graph:
+            overlap = st_.measure_overlap(min(args.steps, 20))
 
     single = world == 1 and not shard
     # kernel-level timing for the roofline: HIP events around the aggregate launches on their stream, in an
@@ -435,18 +482,26 @@ def main():
     comm = {'world_size': world, 'backend': (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
             'rccl': bool(torch.distributed.is_initialized() and torch.distributed.get_backend() == 'nccl'),
             'collectives_per_step_and_rank': coll}
+    if shared_devices:
+        comm['note'] = ('%d ranks on %d GPU(s): the ranks SHARE devices and talk over %s -- a dry run of the multi-rank code path, '
+                        'not a scaling measurement' % (world, n_dev, comm['backend']))
+    if emulated is not None:
+        comm['note'] = ('--as-rank %d/%d: ONE GPU doing the work of that rank, every collective a no-op of the listed size ("fake" '
+                        'process group); ms_per_step is the rank\'s compute time, value the rank\'s own throughput; '
+                        'tools/scale_model.py adds the xGMI time of the collectives' % (rank, world))
     stats = torch.tensor([elapsed, float(edges_kernel), float(edges_ref), float(seeds)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if world > 1 and emulated is None:
         tmax = stats[:1].clone()
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         tot = stats[1:].clone()
         torch.distributed.all_reduce(tot, op=torch.distributed.ReduceOp.SUM)
         elapsed = float(tmax[0]); edges_kernel, edges_ref, seeds = (float(x) for x in tot)
 
-    if world > 1:
-        torch.distributed.barrier()
+    if torch.distributed.is_initialized():
+        if emulated is None:
+            torch.distributed.barrier()
         torch.distributed.destroy_process_group()
-    if rank != 0:
+    if rank != 0 and emulated is None:
         return
 
     pmc, pmc_err = (None, 'skipped')
@@ -531,7 +586,7 @@ def main():
     par = (f'snp-shard{world} (SNP rows by id range, Gene/GO replicated, partial-softmax exchange)' if shard else f'seed-dp{world}')
     out = {
         'metric': 'edges aggregated/sec (full fast-mode KG minibatch training; epoch time in config)',
-        'value': edges_kernel / elapsed, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps,
+        'value': edges_kernel / elapsed, 'unit': 'edges/s', 'n_gpus': 1 if emulated is not None else world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': ('SynthKG-fast full KG (784256 SNP / 20032 Gene / ~20.6M directed edges; features '
@@ -552,6 +607,8 @@ def main():
                    'epoch_time_s_956_steps': 956 * ms / 1e3 / (1 if strong else world),
                    'epoch_measured': epoch,
                    'rccl_world_size': world if comm['rccl'] else 0,
+                   'emulated_rank': emulated,
+                   'sampler_overlap': overlap,
                    'communication': comm,
                    'library_gemm_calls': lib_calls,
                    'library_gemm_note': ('products of set-up + warm-up + capture + the timed steps that went to hipBLASLt / rocBLAS instead of this '

@@ -1,38 +1,88 @@
-"""Build libkgwas_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libkgwas_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+One object per ``.hip`` source, compiled in parallel, then one link.  What decides whether an object (and the library) is
+current is a CONTENT hash of the source, of every header it can include and of the compile command -- not file times: a fresh
+checkout, a copy to another box or a touched file neither trigger nor hide a rebuild.  ``build(force=True)`` (what
+``__graft_entry__.build()`` calls: the driver's "does it build" check really compiles) ignores the hashes."""
 from __future__ import annotations
 
+import hashlib
+import json
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(CSRC, 'libkgwas_hip.so')
+OBJ = os.path.join(CSRC, 'build')
+STAMP = os.path.join(OBJ, 'stamp.json')
+FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC']
 
 
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
 
 
+def _headers():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join(ROOT, 'include', 'kgwas_hip.h')]
+
+
+def _digest(paths, extra=''):
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _hashes():
+    """{source name: hash of (flags, headers, source)} -- every source may include every header of csrc/ and the public one."""
+    hd = _digest(_headers(), ' '.join(FLAGS))
+    return {os.path.basename(s): _digest([s], hd) for s in sources()}
+
+
+def _stamp():
+    try:
+        with open(STAMP) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
 def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
-    t = os.path.getmtime(OUT)
-    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + \
-        [os.path.join(ROOT, 'include', 'kgwas_hip.h')]
-    return any(os.path.getmtime(d) > t for d in deps)
+    st = _stamp()
+    return st.get('objects') != _hashes() or st.get('lib_size') != os.path.getsize(OUT)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-shared', '-fPIC',
-           '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC] + sources() + ['-o', OUT]
-    if verbose:
-        print(' '.join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ, exist_ok=True)
+    want, have = _hashes(), ({} if force else _stamp().get('objects', {}))
+    inc = ['-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
+    jobs = []
+    for s in sources():
+        name = os.path.basename(s)
+        o = os.path.join(OBJ, name[:-4] + '.o')
+        if force or have.get(name) != want[name] or not os.path.exists(o):
+            jobs.append([hipcc, *FLAGS, *inc, '-c', s, '-o', o])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + '.o') for s in sources()]
+    run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', OUT])
+    with open(STAMP, 'w') as f:
+        json.dump({'objects': want, 'lib_size': os.path.getsize(OUT)}, f)
     return OUT
 
 

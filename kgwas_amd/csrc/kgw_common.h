@@ -21,6 +21,20 @@ static constexpr int KGW_GRID = 2048;   // grid-stride launches: 8 blocks per CU
         if (e__ != hipSuccess) return (int)e__;              \
     } while (0)
 
+// one-time set-up PER DEVICE (hipFuncSetAttribute is per device, and a process may drive more than one GPU): need() is true
+// the first time it is called with a given device current.  A benign race at worst repeats the idempotent set-up.
+struct KgwPerDevice {
+    uint64_t done = 0;
+    bool need() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess) return true;
+        const uint64_t b = 1ull << (d & 63);
+        if (done & b) return false;
+        done |= b;
+        return true;
+    }
+};
+
 // ---- wave-level helpers (wavefront = 64 lanes) -------------------------------------------------
 __device__ __forceinline__ int kgw_lane() { return threadIdx.x & 63; }
 

@@ -335,10 +335,9 @@ int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st) {
     }
     const size_t lds_bytes = (size_t)(2 * FRAG + 4 * 32 * MT) * sizeof(float);
     auto kern = k_tn_gemm<MT, NT>;
-    static bool attr_set = false;     // idempotent; a benign race at worst repeats the call
-    if (lds_bytes > 64 * 1024 && !attr_set) {
+    static KgwPerDevice attr_once;
+    if (lds_bytes > 64 * 1024 && attr_once.need()) {
         KGW_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_set = true;
     }
     kern<<<dim3((unsigned)blk, gy_max, gz_max), 256, lds_bytes, st>>>(J);
     KGW_LAUNCH_CHECK();
@@ -1878,11 +1877,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 template <bool WKN>
 int launch_wreg(const LinArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(128 * WST + 128) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static KgwPerDevice attr_once;
+    if (attr_once.need()) {
         KGW_HIP(hipFuncSetAttribute((const void*)k_linear_wreg<WKN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         KGW_HIP(hipFuncSetAttribute((const void*)k_linear_wreg<WKN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     const int64_t ntiles = (a.rows + 31) / 32;
     static const int64_t half_max = getenv("KGW_WREG_HALF_MAX_TILES") ? atoll(getenv("KGW_WREG_HALF_MAX_TILES")) : 512;
@@ -1912,10 +1910,9 @@ template <int KC, bool WKN, int RT>
 int launch_wres(const LinArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(128 * WST + RT * (KC + 4)) * sizeof(float);
     auto kern = k_linear_wres<KC, WKN, RT>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static KgwPerDevice attr_once;
+    if (attr_once.need()) {
         KGW_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     int64_t ntiles = (a.rows + RT - 1) / RT;
     int grid = (int)(ntiles < 256 ? ntiles : 256);
@@ -1972,10 +1969,9 @@ extern "C" int kgw_mlp2_fwd(const float* X, int64_t ldx, int32_t K1, const float
         return KGW_E_UNSUPPORTED;
     Mlp2Args a{X, ldx, W1, ldw1, b1, W2, ldw2, b2, H1, ldh1, H2, ldh2, rows, K1, rows_dev, ids, Xg, ldxg};
     const size_t lds = (size_t)(128 * WST + 128 + 128 * 24) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static KgwPerDevice attr_once;
+    if (attr_once.need()) {
         KGW_HIP(hipFuncSetAttribute((const void*)k_mlp2_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     static const bool split3 = !(getenv("KGW_MLP2_SPLIT") && getenv("KGW_MLP2_SPLIT")[0] == '0');
     if (split3) {           // second product on the bf16 pipe (three exact pieces per operand)
@@ -2018,10 +2014,9 @@ extern "C" int kgw_mlp2w_fwd(int32_t n_jobs, const float* const* src, const int3
     a.W1 = W1; a.ldw1 = ldw1; a.b1 = b1; a.W2 = W2; a.ldw2 = ldw2; a.b2 = b2;
     a.Xg = Xg; a.H1 = H1; a.H2 = H2; a.ldo = ldo;
     const size_t lds = (size_t)(2 * 128 * WST + 256) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static KgwPerDevice attr_once;
+    if (attr_once.need()) {
         KGW_HIP(hipFuncSetAttribute((const void*)k_mlp2w_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     const int64_t ntiles = (a.rows + 31) / 32;
     k_mlp2w_fwd<<<(unsigned)((ntiles + 1) / 2), 256, lds, (hipStream_t)stream_>>>(a);
@@ -2050,10 +2045,9 @@ extern "C" int kgw_mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2
     if (workspace_floats < nblk * 4096) return KGW_E_RANGE;
     Mlp2BwdArgs a{dH2, ldd, W2, ldw2, H1, ldh1, X, ldx, workspace, rows, K1, rows_dev, in_ids, dZ, ldz};
     const size_t lds = (size_t)(128 * WST + 4 * 32 * TST) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static KgwPerDevice attr_once;
+    if (attr_once.need()) {
         KGW_HIP(hipFuncSetAttribute((const void*)k_mlp2_bwd_first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream_;
     static const bool split3 = !(getenv("KGW_MLP2_SPLIT") && getenv("KGW_MLP2_SPLIT")[0] == '0');
@@ -2399,10 +2393,9 @@ int splitk_launch(const float* X, int64_t ldx, const float* W, int64_t ldw, cons
     static const int fused = getenv("KGW_SPLITK_FUSED") ? atoi(getenv("KGW_SPLITK_FUSED")) : 1;
     if (fused && a.KS > 1 && w_is_kn && N == 128) {        // forward transform: one launch
         const size_t lds_bytes = (size_t)8 * 32 * SK_LD * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static KgwPerDevice attr_once;
+        if (attr_once.need()) {
             KGW_HIP(hipFuncSetAttribute((const void*)k_linear_splitk_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            attr_set = true;
         }
         k_linear_splitk_fused<<<a.RT * 4, 512, lds_bytes, (hipStream_t)stream_>>>(a);
         KGW_LAUNCH_CHECK();

@@ -885,7 +885,10 @@ __global__ void __launch_bounds__(KGW_BLK) k_t_end(SampArgs A, int l0, int nl) {
 // ordered walks), at most 2^14 rows each (one wavefront keeps a bucket's row counters in LDS); digits 0 .. nb (nb = "relation
 // not computed by the layer")
 static int ts_plan(int64_t trows, int* sh_, int* nb_, int* nbits_) {
-    int sh = 8;
+    // (KGW_TS_MIN_SHIFT, tests only: force the coarse-bucket plans -- 2^12 / 2^14 rows per bucket, the 64 KB-of-LDS launches --
+    //  that otherwise need 8 M / 65 M src-major rows)
+    static const int sh_env = getenv("KGW_TS_MIN_SHIFT") ? atoi(getenv("KGW_TS_MIN_SHIFT")) : 8;
+    int sh = sh_env < 8 ? 8 : (sh_env > 14 ? 14 : sh_env);
     while (sh < 14 && (trows >> sh) + 1 > TS_MAX_NB) ++sh;
     const int64_t nb = (trows >> sh) + 1;
     if (nb > TS_HARD_MAX_NB) return 1;
@@ -998,10 +1001,12 @@ extern "C" int kgw_sample_batch_parts(const KgwGraph* graph, const KgwBatchBuf* 
         const int nblk = SG >= 2048 ? 512 : (SG >= 256 ? 256 : 128);
         if ((int64_t)nl * (nb + 1) * nblk + (int64_t)nl * (nb + 2) > buf->scan_cap) return KGW_E_RANGE;
         k_ts_keys<<<nblk, KGW_BLK, (size_t)(nb + 1) * sizeof(int), st>>>(A, l0, nl, sh, nb);
-        static bool attr_set = false;     // idempotent; a benign race at worst repeats the call
-        if (!attr_set) {
+        static KgwPerDevice attr_once;
+        if (attr_once.need()) {
             KGW_HIP(hipFuncSetAttribute((const void*)k_ts_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
+            // (k_ts_rows: 4 << 12 / 1 << 14 counters = 64 KB of dynamic LDS on top of the kernel's static words)
+            KGW_HIP(hipFuncSetAttribute((const void*)k_ts_rows<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            KGW_HIP(hipFuncSetAttribute((const void*)k_ts_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
         if (nblk == 128) k_ts_scan_rows<2><<<SG < 1024 ? SG : 1024, KGW_BLK, 0, st>>>(buf->scan_tmp, nl, nb, buf->meta);
         else if (nblk == 256) k_ts_scan_rows<4><<<SG < 1024 ? SG : 1024, KGW_BLK, 0, st>>>(buf->scan_tmp, nl, nb, buf->meta);

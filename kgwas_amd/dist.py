@@ -10,6 +10,7 @@ the reference's (up to summation order)."""
 from __future__ import annotations
 
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -53,14 +54,14 @@ def allreduce_flat(flat: torch.Tensor, world: int, what: str = 'parameter gradie
     if world <= 1 and not (os.environ.get('KGW_FORCE_MULTIRANK_PATH') == '1' and dist.is_initialized()):
         return
     count_collective(f'all_reduce_avg({what})', flat.numel() * flat.element_size())
-    if dist.get_backend() == 'nccl':
+    if dist.get_backend() in ('nccl', 'fake'):       # ("fake": bench.py --as-rank, collectives that move nothing)
         dist.all_reduce(flat, op=dist.ReduceOp.AVG)
     else:                                            # gloo (CPU tests) has no AVG
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(world)
 
 
-_LIVE = {}          # id(model) -> liveness of its requires_grad parameters, agreed over the ranks at the first reduction
+_LIVE = weakref.WeakKeyDictionary()   # model -> liveness of its requires_grad parameters, as agreed over the ranks
 
 
 def allreduce_grads(model, world: int):
@@ -77,12 +78,24 @@ def allreduce_grads(model, world: int):
     if not multi:
         return
     had = [p.grad is not None for p in params]
-    live = _LIVE.get(id(model))
-    if live is None or len(live) != len(params):
-        t = torch.tensor(had, dtype=torch.int32, device=params[0].device)
+    live = _LIVE.get(model)
+    # liveness is agreed at the first reduction and RE-agreed whenever a rank sees a gradient on a parameter the agreement left
+    # out (a node type or relation absent from every rank's first batch that a later batch reaches): one 1-element MAX
+    # all-reduce per step keeps the decision to re-agree itself collective -- every rank runs the same sequence
+    fresh = live is None or len(live) != len(params)
+    if not fresh:
+        t1 = torch.tensor([1 if any(h and not l for h, l in zip(had, live)) else 0], dtype=torch.int32, device=params[0].device)
+        dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+        fresh = bool(int(t1[0]))
+    if fresh:
+        t = torch.tensor([h or (live is not None and len(live) == len(params) and live[i]) for i, h in enumerate(had)],
+                         dtype=torch.int32, device=params[0].device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        live = _LIVE[id(model)] = [bool(v) for v in t.cpu().tolist()]
+        live = _LIVE[model] = [bool(v) for v in t.cpu().tolist()]
     sel = [p for p, l in zip(params, live) if l]
+    for p, l in zip(params, live):
+        if not l:
+            p.grad = None            # (never stepped on a local, unreduced gradient)
     if not sel:
         return
     flat = torch.cat([p.grad.reshape(-1) if p.grad is not None else p.new_zeros(p.numel()) for p in sel])

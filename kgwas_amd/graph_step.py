@@ -76,11 +76,11 @@ class GraphTrainStep:
         # many ranks.  KGW_SHARD_GENE_LAYER=1/0 overrides the caller's choice.
         env = os.environ.get('KGW_SHARD_GENE_LAYER')
         want = (shard_gene_layer if env is None else env == '1') and self.split_backward
+        # (whether the model takes the resident route for the gene features depends on the rank's own batches: probed by a
+        #  warm-up step WITHOUT the shard and agreed over the ranks before any collective depends on it -- _capture)
         self.gene_shard = None
-        if want:
-            import torch.distributed as dist
-            self.gene_shard = ops.GeneLayerShard(dist.get_rank(), dist.get_world_size(), None, inline=True)
-        ops.GENE_SHARD = self.gene_shard
+        self._want_gene_shard = bool(want)
+        self._probe = None
         self._g_partial = self._g_dw = None
         self._comm = torch.cuda.Stream(device=dev) if self._multi else None
         self._ev_a, self._ev_ca = torch.cuda.Event(), torch.cuda.Event()
@@ -118,6 +118,11 @@ class GraphTrainStep:
 
     # train on the batch held by bufs[cur]; concurrently sample ``self.seeds`` into bufs[1 - cur]
     def _step_body(self, cur: int):
+        # (the shard is active for the forward passes THIS trainer issues and for nothing else in the process)
+        with ops.gene_shard_scope(self.gene_shard, self._probe):
+            return self._step_body_inner(cur)
+
+    def _step_body_inner(self, cur: int):
         bs = self.batch_size
         main = torch.cuda.current_stream()
         if self.overlap:
@@ -221,26 +226,35 @@ class GraphTrainStep:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             self._sample_now(0, 0)
+            if self._want_gene_shard:
+                # probe: one step with the layer computed locally (no collective) tells whether -- and on which (X, W, b) -- this
+                # rank's model takes the resident route; the shard is switched on only if EVERY rank does (MIN over the ranks),
+                # and then directly in its staged form: no collective is ever issued from inside an autograd node here
+                import torch.distributed as dist
+                self._probe = []
+                self._step_body(0)
+                if self.split_backward:
+                    self._step_body_b(0)
+                seen, self._probe = self._probe, None
+                ok = torch.tensor([1 if len(seen) == 1 else 0], dtype=torch.int32, device=self.seeds.device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok[0]):
+                    gs0 = ops.GeneLayerShard(dist.get_rank(), dist.get_world_size(), None, inline=False)
+                    gs0._setup(seen[0][0])
+                    gs0.last = seen[0]
+                    self.gene_shard = gs0
+                    self._flat_b = None                        # (rebuilt with a slot for the first layer's weight)
             gs = self.gene_shard
             for k in range(4):
-                if gs is not None and not gs.inline:                   # staged form from the second warm-up step on
+                if gs is not None:
                     gs.forward_partial(*gs.last)
                     gs.gather()
                 self._step_body(k % 2)
                 if self.split_backward:
                     self._step_body_b(k % 2)
                 if gs is not None:
-                    if k == 0:
-                        # the first warm-up step ran the shard INLINE (collectives inside the autograd node: fine outside a
-                        # capture) -- which also tells whether the model takes the resident route for the gene features at all
-                        if gs.last is None:
-                            self.gene_shard = gs = ops.GENE_SHARD = None
-                        else:
-                            gs.inline = False
-                            self._flat_b = None                        # (rebuilt with a slot for the first layer's weight)
-                    else:
-                        gs.scatter()
-                        gs.weight_grad_partial(gs.last[0], out=self._flat_grads[gs.last[1]])
+                    gs.scatter()
+                    gs.weight_grad_partial(gs.last[0], out=self._flat_grads[gs.last[1]])
                 if self.twin:
                     self._sample_now(1 - k % 2, 0)
         torch.cuda.current_stream().wait_stream(s)
@@ -342,6 +356,47 @@ class GraphTrainStep:
             else:
                 self.opt.step()
         return self.loss[cur]
+
+    def measure_overlap(self, n: int = 20) -> dict:
+        """Did the next batch's sampler really run BESIDE the step?  HIP maps streams onto a few hardware queues and a replayed
+        graph runs on the queue of the stream it was captured on: two streams that share a queue serialise whatever the program
+        says.  Times ``n`` steps with the side sampler, ``n`` without it (stale batches) and ``n`` sampler replays alone; overlap =
+        the share of the sampler's own time that did NOT show up in the step.  Every rank calls it (multi-rank steps contain
+        collectives).  Leaves the buffers unsampled (the next step() samples its batch itself)."""
+        import time
+        if not self.twin:
+            return {'overlapped': False, 'note': 'the sampler is not run beside the step in this configuration'}
+
+        def timed(fn):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for i in range(n):
+                fn(i)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n * 1e3
+
+        def samp(i):
+            with torch.cuda.stream(self._side):
+                self.sample_graphs[i % 2].replay()
+        k = [0]
+
+        def step(_):
+            self.step(k[0] % self.n_batches)                  # (consecutive batch indices: no step samples in the open)
+            k[0] += 1
+        keep = self._skip_resample
+        for i in range(2):
+            step(i)
+        both = timed(step)
+        self._skip_resample = True
+        step(0)
+        alone = timed(step)
+        self._skip_resample = keep
+        sampler = timed(samp)
+        torch.cuda.current_stream().wait_stream(self._side)
+        self._have, self._twin_pending = [-1, -1], [False, False]
+        ratio = (alone + sampler - both) / max(sampler, 1e-9)
+        return {'step_with_side_sampler_ms': both, 'step_alone_ms': alone, 'sampler_alone_ms': sampler, 'overlap_ratio': ratio,
+                'overlapped': bool(ratio > 0.5), 'steps': n}
 
     def describe(self) -> str:
         if self.split_backward:

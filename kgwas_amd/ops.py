@@ -647,6 +647,8 @@ class GeneLayerShard:
         import torch.distributed as dist
         self.rank, self.world, self.group, self.inline = int(rank), int(world), group, inline
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        if self.backend == 'fake':                              # (bench.py --as-rank: collectives that move nothing)
+            self.backend = 'nccl'
         self.h_all = self.dz = self.dz_mine = None
         self.n = self.chunk = 0
         self.last = None                                       # (X, W, b) of the layer this shard was last applied to
@@ -712,7 +714,30 @@ class GeneLayerShard:
         return gemm3(Xt[:, lo:lo + kin], gemm3_pack(self.dz_mine[:hi - lo], kin, True, k_valid=hi - lo), transpose_out=True, out=out)
 
 
-GENE_SHARD = None          # the active GeneLayerShard of this process (set by the multi-GPU trainers), or None
+GENE_SHARD = None          # the GeneLayerShard of the training step being issued (gene_shard_scope), or None
+RESIDENT_SEEN = None       # a list while a trainer probes which layer takes the resident route (gene_shard_scope(None, probe))
+
+
+class gene_shard_scope:
+    """``with gene_shard_scope(gs):`` -- the forward passes issued inside take ``gs`` for the resident first gene Linear; outside
+    (another model, an evaluation pass, KGWAS.train_step after a trainer has finished) no shard is active: the layer is computed
+    locally and nothing stale is read.  ``probe``: a list that receives (X, W, b) of every training forward that takes the
+    resident route -- how a trainer learns, WITHOUT issuing a collective, whether (and on which layer) the route is taken, so that
+    the ranks can agree on it before the first collective depends on it."""
+
+    def __init__(self, gs, probe=None):
+        self.gs, self.probe = gs, probe
+
+    def __enter__(self):
+        global GENE_SHARD, RESIDENT_SEEN
+        self.prev = (GENE_SHARD, RESIDENT_SEEN)
+        GENE_SHARD, RESIDENT_SEEN = self.gs, self.probe
+        return self.gs
+
+    def __exit__(self, *exc):
+        global GENE_SHARD, RESIDENT_SEEN
+        GENE_SHARD, RESIDENT_SEEN = self.prev
+        return False
 
 
 def resident_first_linear(X, W, b, g2l=None, rows_out=None, gs=None):
@@ -735,10 +760,21 @@ def resident_first_linear(X, W, b, g2l=None, rows_out=None, gs=None):
     return linear(X, W, b, relu=True, fixed_shape=True), False
 
 
-def active_gene_shard(ctx, w_index: int):
-    """The process's GeneLayerShard while a TRAINING forward runs (the autograd node is asked for the layer's weight gradient);
-    inference passes -- captured forward graphs, loaders of different lengths per rank -- always compute the whole layer locally."""
-    return GENE_SHARD if (GENE_SHARD is not None and ctx.needs_input_grad[w_index]) else None
+def active_gene_shard(ctx, w_index: int, X=None, W=None, b=None):
+    """The GeneLayerShard of the step being issued while a TRAINING forward runs (the autograd node is asked for the layer's weight
+    gradient); inference passes -- captured forward graphs, loaders of different lengths per rank -- always compute the whole layer
+    locally.  A shard serves ONE layer: it is bound to the (X, W) it is first applied to, and a second resident layer of the same
+    model (wide GO features) computes locally instead of clobbering its buffers."""
+    if not ctx.needs_input_grad[w_index]:
+        return None
+    if RESIDENT_SEEN is not None and X is not None:
+        RESIDENT_SEEN.append((X, W, b))
+    gs = GENE_SHARD
+    if gs is None:
+        return None
+    if gs.last is not None and X is not None and not (gs.last[0] is X and gs.last[1] is W):
+        return None
+    return gs
 
 
 def resident_first_weight_grad(dz, X, W, gs=None):
@@ -1068,7 +1104,7 @@ class _ResidentLinearReLURows(torch.autograd.Function):
         # zeros: the rows past the batch's real node count (static capacity of a captured step) are written by nobody on the
         # fused route, and 0 x garbage must stay 0 in the weight gradients downstream
         out = torch.zeros(n, KGW_C, device=X.device) if _resident_ok(X, W) else torch.empty(n, KGW_C, device=X.device)
-        ctx.shard = active_gene_shard(ctx, 1) if _resident_ok(X, W) else None
+        ctx.shard = active_gene_shard(ctx, 1, X, W, b) if _resident_ok(X, W) else None
         h, done = resident_first_linear(X, W, b, g2l, out, ctx.shard)
         if n and not done:
             _lib.check(_lib.lib().kgw_gather_rows(_p(h), _p(ids), n, h.shape[1], _p(out), _lib.stream_ptr()), 'kgw_gather_rows')
@@ -1102,7 +1138,7 @@ class _ResidentMLP2(torch.autograd.Function):
     def forward(ctx, X, W1, b1, W2, b2, ids, g2l, out):
         n = int(ids.numel())
         h1g = torch.zeros(n, KGW_C, device=X.device) if _resident_ok(X, W1) else torch.empty(n, KGW_C, device=X.device)   # (see _ResidentLinearReLURows)
-        ctx.shard = active_gene_shard(ctx, 1) if _resident_ok(X, W1) else None
+        ctx.shard = active_gene_shard(ctx, 1, X, W1, b1) if _resident_ok(X, W1) else None
         h, done = resident_first_linear(X, W1, b1, g2l, h1g, ctx.shard)
         if n and not done:
             _lib.check(_lib.lib().kgw_gather_rows(_p(h), _p(ids), n, h.shape[1], _p(h1g), _lib.stream_ptr()), 'kgw_gather_rows')

@@ -41,6 +41,8 @@ import torch.distributed as dist
 
 from . import _lib
 from ._lib import KGW_C, PART_STRIDE
+
+KGW_PENDING = -2            # include/kgwas_hip.h: a node flagged for expansion in the global->local table (unsampled = -1)
 from .graph import HeteroGraph
 from .sampler import BatchBuffers, DeviceGraph, SampledBatch, _ptr
 
@@ -129,6 +131,13 @@ def _streams_on_own_queues(device, group, multi: bool, n: int = 2, tries: int = 
         ok = beside(None, cand) if multi else True         # (every test on every candidate: the ranks stay in step)
         for c in chosen:
             ok = beside(c, cand) and ok
+        if multi:
+            # the verdict is a TIMING measurement, it can differ between ranks: a candidate is accepted only if every rank accepts
+            # it (MIN), so that all ranks leave the loop after the same number of all-reduces -- a rank that went on probing alone
+            # would pair its next probe with its peers' next real collective
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            ok = bool(int(t[0]))
         if ok:
             chosen.append(cand)
     while len(chosen) < n:                                 # (no free queue found: correctness does not depend on it)
@@ -184,7 +193,12 @@ class ShardExchange:
         # the flat all-gather exists on RCCL ("nccl"); gloo (the CPU / one-GPU tests) takes the list form.  Decided ONCE, from
         # the backend: a collective that fails at run time must surface as an error on every rank, not send one rank down a
         # different collective sequence from its peers.
-        self.flat_gather = self.multi and dist.get_backend(group) == 'nccl'
+        backend = dist.get_backend(group) if self.multi else None
+        # ("fake": bench.py --as-rank R/P -- one GPU doing rank R's work, collectives that move nothing.  The stand-ins below keep
+        #  the data finite and the merged frontier the size it has in the real job: see emulate_peers)
+        self.fake = backend == 'fake'
+        self.flat_gather = self.multi and backend in ('nccl', 'fake')
+        self.peer_frontier, self.emu_batch = None, 0
         self.collectives = {}                     # name -> [calls, bytes this rank handed to the collective]
         # STAGED form (a step captured in segments, ShardedTrainer(use_graph=True)): the backward's exchange is not issued from
         # inside the autograd node (the engine runs it on another thread: no place to end a capture) -- ops.gat_aggregate hands the
@@ -247,7 +261,44 @@ class ShardExchange:
             for lo, hi in self.rep_runs:
                 dist.all_reduce(buf.g2l[lo:hi], op=dist.ReduceOp.MIN, group=self.group)
                 self._count('all_reduce_min(frontier flags)', (hi - lo) * 4)
+            if self.peer_frontier is not None:             # emulation: what the peers' flags would have added
+                idx = self.peer_frontier[self.emu_batch % len(self.peer_frontier)]
+                if idx.numel():
+                    buf.g2l.index_fill_(0, idx, KGW_PENDING)
         self._collective(fn)
+
+    def emulate_peers(self, dg: DeviceGraph, full: HeteroGraph, batches, lo: int, hi: int, sharded_type: str = 'SNP'):
+        """bench.py --as-rank only (the "fake" backend): the frontier merge is a no-op there, so this rank would expand only the
+        hop-1 neighbours of ITS seeds and the replicated work (70 % of a batch's edges) would come out too small.  Precompute, from
+        the full host graph, the replicated nodes the OTHER ranks' seeds of every batch reach in one hop -- exactly the flags their
+        all-reduce would deliver -- and set them in place of the collective.  ``batches``: global seed ids per batch."""
+        assert self.fake, 'peer emulation is for the fake backend only'
+        assert dg.n_hops == 2, 'one frontier merge (2 hops): later merges would meet nodes that already have local ids'
+        dg_base = {name: int(dg.node_base[dg.schema.type_id[name]]) for name in full.node_types}
+        adj = []
+        n_sh = int(full[sharded_type].num_nodes)
+        for et in full.edge_types:
+            s_, _, d_ = et
+            if d_ != sharded_type or s_ == sharded_type:
+                continue
+            ei = full[et].edge_index
+            ei = (ei if torch.is_tensor(ei) else torch.as_tensor(ei)).cpu().numpy()
+            order = np.argsort(ei[1], kind='stable')
+            ptr = np.zeros(n_sh + 1, dtype=np.int64)
+            np.add.at(ptr, ei[1] + 1, 1)
+            adj.append((np.cumsum(ptr), ei[0][order], dg_base[s_]))
+        out = []
+        for b in batches:
+            b = np.asarray(b, dtype=np.int64)
+            other = b[(b < lo) | (b >= hi)]
+            found = []
+            for ptr, src, base in adj:
+                a, e = ptr[other], ptr[other + 1]
+                if len(other) and int((e - a).sum()):
+                    found.append(np.concatenate([src[x:y] for x, y in zip(a, e)]) + base)
+            idx = np.unique(np.concatenate(found)) if found else np.zeros(0, dtype=np.int64)
+            out.append(torch.from_numpy(idx.astype(np.int64)).to(self.dev))
+        self.peer_frontier = out
 
     # -- layer exchange ---------------------------------------------------------------------------------------------
     def seg_rows(self, batch: SampledBatch, layer: int) -> Optional[torch.Tensor]:
@@ -282,7 +333,9 @@ class ShardExchange:
             allp = torch.empty(self.world * n * PART_STRIDE, device=self.dev)
 
             def fn():
-                if self.flat_gather:
+                if self.fake:                                # (stand-in: every peer's partial state = this rank's; finite)
+                    allp.view(self.world, -1).copy_(mine.view(1, -1).expand(self.world, -1))
+                elif self.flat_gather:
                     dist.all_gather_into_tensor(allp, mine, group=self.group)
                 else:
                     dist.all_gather(list(allp.view(self.world, -1).unbind(0)), mine, group=self.group)
@@ -363,8 +416,9 @@ class ShardedTrainer:
         on = self.xchg.multi and (self.world >= 4 if env is None else env == '1')
         # (captured form: the STAGED variant -- partial product and all-gather ahead of the forward, reduce-scatter and the partial
         #  weight gradient after the backward, all at the trainer's level where a capture can be cut: _static_body)
+        # (the replicated gene type expands the MERGED frontier: its row count -- hence the resident-route decision -- is the same
+        #  on every rank by construction; the shard is active only inside this trainer's own forward passes, ops.gene_shard_scope)
         self.gene_shard = ops.GeneLayerShard(self.rank, self.world, group, inline=True) if on else None
-        ops.GENE_SHARD = self.gene_shard
         self.seed_type = self.dg.schema.type_id[self.input_type]
         self.buf = BatchBuffers(self.dg)
         ids = np.asarray(ids.cpu() if torch.is_tensor(ids) else ids, dtype=np.int64).reshape(-1)
@@ -382,6 +436,9 @@ class ShardedTrainer:
             if len(mine) == 0:
                 mine = np.zeros(1, dtype=np.int64)
             self.local_seeds.append(torch.from_numpy(mine).to(dev))
+        if self.xchg.fake:                 # bench.py --as-rank: stand-in for the peers' share of every frontier merge
+            self.xchg.emulate_peers(self.dg, full, [ids[i * self.batch_size:(i + 1) * self.batch_size] for i in range(self.n_batches)],
+                                    self.lo, self.hi, sharded_type)
         self.ld_w = run._ld_weight_vector()[self.lo:self.hi].contiguous()
         if self.n_pad:
             self.ld_w = torch.cat([self.ld_w, self.ld_w.new_zeros(self.n_pad)])       # pad seeds: loss weight 0
@@ -416,6 +473,7 @@ class ShardedTrainer:
         node_off = np.zeros((sc.NT, L + 2), dtype=np.int64)
         edges, chunks = np.zeros(L, dtype=np.int64), np.zeros(L, dtype=np.int64)
         for i in range(self.n_batches):
+            self.xchg.emu_batch = i
             sample_sharded(self.dg, self.buf, self.seed_table[i], self.seed_type, self.xchg)
             self.buf.ready.synchronize()
             m = self.buf.read_meta()
@@ -470,7 +528,9 @@ class ShardedTrainer:
         # (3) warm-up, eager + staged
         params = [p for p in self.model.parameters()]
         snap = [p.detach().clone() for p in params]
+        self._skip_resample = False                                 # (measure_overlap: the step without a sampler beside it)
         for k in range(3):
+            self.xchg.emu_batch = 0
             self.seeds2[k % 2].copy_(self.seed_table[0])
             self._sample_body(k % 2)
             self._compute_body(k % 2)
@@ -479,8 +539,7 @@ class ShardedTrainer:
                 # the first warm-up step ran the gene-layer shard INLINE (fine outside a capture) -- which also tells whether the
                 # model takes the resident route for the gene features at all; from here on the stages run at this level
                 if gs.last is None:
-                    from . import ops
-                    self.gene_shard = ops.GENE_SHARD = None
+                    self.gene_shard = None
                 else:
                     gs.inline = False
         torch.cuda.synchronize()
@@ -533,7 +592,9 @@ class ShardedTrainer:
         xchg.cuts = []
         for p in self.model.parameters():
             p.grad = None
-        loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, self.s_cap, batch.n_id(self.input_type), self.y, self.ld_w)
+        from . import ops
+        with ops.gene_shard_scope(gs):
+            loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, self.s_cap, batch.n_id(self.input_type), self.y, self.ld_w)
         part = loss * self.loss_const
         # down to the leaves ops.gat_aggregate cut at the exchanged Z.  (retain_graph: parameter-side nodes -- the attention
         # vectors, the FC_output fold -- feed both sides of a cut and are differentiated once per side, each time with the part
@@ -561,6 +622,45 @@ class ShardedTrainer:
         if self.use_graph and int(self.stats[-1]):
             raise _lib.KgwasHipError(f'a batch exceeded the static capacities of the sharded step (error mask {int(self.stats[-1])})')
 
+    def measure_overlap(self, n: int = 20) -> dict:
+        """Did the next batch's sampler really run BESIDE the step?  (A replayed graph runs on the hardware queue of the stream
+        it was captured on: two streams mapped to one queue serialise whatever the program says.)  Times ``n`` steps with the side
+        sampler, ``n`` without it (stale batches) and ``n`` sampler replays alone; overlap = the share of the sampler's own time
+        that did NOT show up in the step.  Every rank calls it (the steps contain collectives).  Leaves the buffers unsampled."""
+        import time
+        if not (self.use_graph and self.overlap):
+            return {'overlapped': False, 'note': 'the sampler is not run beside the step in this configuration'}
+
+        def timed(fn):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for i in range(n):
+                fn(i)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n * 1e3
+
+        def samp(i):
+            with torch.cuda.stream(self._side):
+                self.xchg.emu_batch = i % self.n_batches
+                self.samp_seg[i % 2].replay()
+        k = [0]
+
+        def step(_):
+            self.step(k[0])                                    # (consecutive batch indices: no step samples in the open)
+            k[0] += 1
+        for i in range(2):
+            step(i)
+        both = timed(step)
+        self._skip_resample = True
+        step(0)
+        alone = timed(step)
+        self._skip_resample = False
+        sampler = timed(samp)
+        self._have, self._pending = [-1, -1], [False, False]
+        ratio = (alone + sampler - both) / max(sampler, 1e-9)
+        return {'step_with_side_sampler_ms': both, 'step_alone_ms': alone, 'sampler_alone_ms': sampler, 'overlap_ratio': ratio,
+                'overlapped': bool(ratio > 0.5), 'steps': n}
+
     def describe(self) -> str:
         return (('HIP-graph segments with the collectives between them' if self.use_graph else 'eager launches') + '; per step: 1 frontier all-reduce(MIN), 1 all-gather of partial softmax states + 1 all-reduce of '
                 'their dZ per exchanged layer, 1 flat gradient all-reduce (SUM)' +
@@ -581,6 +681,7 @@ class ShardedTrainer:
     def sample(self, i: int) -> SampledBatch:
         seeds = self.local_seeds[i % self.n_batches]
         dg, buf = self._eager()
+        self.xchg.emu_batch = i % self.n_batches
         sample_sharded(dg, buf, seeds, self.seed_type, self.xchg)
         torch.cuda.current_stream().wait_event(buf.ready)
         buf.ready.synchronize()
@@ -604,7 +705,9 @@ class ShardedTrainer:
         n = batch.batch_size
         for p in self.model.parameters():
             p.grad = None
-        loss, pred = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, n, batch.n_id(self.input_type), self.y, self.ld_w)
+        from . import ops
+        with ops.gene_shard_scope(self.gene_shard):
+            loss, pred = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, n, batch.n_id(self.input_type), self.y, self.ld_w)
         # mean over the rank's seeds -> its share of the batch mean (0 for a rank that owns none of the batch's seeds)
         part = loss * self.loss_scale[i % self.n_batches]
         part.backward()
@@ -668,15 +771,19 @@ class ShardedTrainer:
             main = torch.cuda.current_stream()
             if self._have[cur] != i % nb:                          # first call / non-sequential access: sample it now
                 self.seeds2[cur].copy_(self.seed_table[i % nb])
+                self.xchg.emu_batch = i % nb
                 self.samp_seg[cur].replay()
                 self._have[cur], self._pending[cur] = i % nb, False
-            if self.overlap:
+            if self._skip_resample:
+                self._have[1 - cur] = (i + 1) % nb                 # (timing only: the next step trains on a stale batch)
+            elif self.overlap:
                 # the NEXT batch, on the side stream beside this step (the previous step, reader of that buffer, is enqueued
                 # on the main stream already).  Its frontier all-reduce is issued before this step's collectives on every rank.
                 nxt = (i + 1) % nb
                 self._side.wait_stream(main)
                 with torch.cuda.stream(self._side):
                     self.seeds2[1 - cur].copy_(self.seed_table[nxt])
+                    self.xchg.emu_batch = nxt
                     self.samp_seg[1 - cur].replay()
                     self._sampled[1 - cur].record(self._side)
                 self._have[1 - cur], self._pending[1 - cur] = nxt, True

@@ -195,3 +195,21 @@ def test_loader_on_cached_graph_equals_direct(tiny_kg, tmp_path):
     ea, eb = a.edge_index_dict, b.edge_index_dict
     for et in ea:
         assert torch.equal(ea[et], eb[et])
+
+
+@pytest.mark.parametrize('shift', [12, 14])
+def test_coarse_bucket_sort_plans_build_the_same_structures(shift):
+    """the src-major sort's coarse plans (2^12 rows per bucket, four wavefronts; 2^14, one wavefront) launch
+    k_ts_rows with 64 KB of dynamic LDS + its static words -- above the 64 KB default limit -- and are only chosen above
+    8 M / 65 M src-major rows, which no test graph has.  KGW_TS_MIN_SHIFT forces them (read once per process, hence the
+    subprocess); the structure checks above must hold unchanged."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KGW_TS_MIN_SHIFT=str(shift))
+    p = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', os.path.join(root, 'tests', 'test_gpu_sampler.py'),
+                        '-k', 'block_structures or matches_pyg_semantics'], cwd=root, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert ' passed' in p.stdout

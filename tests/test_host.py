@@ -169,3 +169,59 @@ def test_shard_batches_partitions_every_batch():
         assert np.array_equal(np.sort(got), ids[b * 64:(b + 1) * 64])
     with pytest.raises(ValueError):
         shard_batches(ids, 10, 0, 4)
+
+
+def test_library_is_current_with_its_sources():
+    """The .so the tests load was built from the sources in the tree (content hashes, kgwas_amd/build.py): a stale library
+    would make every other test a statement about some other code."""
+    from kgwas_amd import build as kb
+    assert not kb.needs_build(), 'libkgwas_hip.so is older than its sources: python -c "import __graft_entry__ as g; g.build()"'
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did(monkeypatch):
+    """`python bench.py --gpus N` (N > 1) with no WORLD_SIZE in the environment re-executes itself under
+    torch.distributed.run with N ranks on 127.0.0.1 (the command form the driver uses) instead of refusing to start."""
+    import argparse
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '7', '--warmup', '2'])
+    assert bench.self_launch(argparse.Namespace(gpus=4)) == 0
+    cmd = seen['cmd']
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert '--nnodes=1' in cmd and '--nproc-per-node=4' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, 'bench.py'))
+    assert cmd[i + 1:] == ['--gpus', '4', '--steps', '7', '--warmup', '2']
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_gene_shard_scope_is_not_process_global_state():
+    """ops.GENE_SHARD used to be set by a trainer and never cleared.  It is now active only inside a trainer's own
+    forward passes, bound to ONE (X, W), and a probe records the layer without any collective."""
+    from kgwas_amd import ops
+
+    class Ctx:
+        needs_input_grad = (False, True)
+    X, W, X2 = torch.zeros(4, 4), torch.zeros(2, 4), torch.zeros(4, 4)
+    assert ops.GENE_SHARD is None and ops.active_gene_shard(Ctx, 1, X, W, None) is None
+
+    class GS:
+        last = None
+    gs, seen = GS(), []
+    with ops.gene_shard_scope(gs, seen):
+        assert ops.active_gene_shard(Ctx, 1, X, W, None) is gs
+        gs.last = (X, W, None)
+        assert ops.active_gene_shard(Ctx, 1, X, W, None) is gs
+        assert ops.active_gene_shard(Ctx, 1, X2, W, None) is None      # a second resident layer: computed locally
+        with ops.gene_shard_scope(None):
+            assert ops.active_gene_shard(Ctx, 1, X, W, None) is None
+        assert ops.active_gene_shard(Ctx, 0, X, W, None) is None       # inference: no weight gradient asked
+    assert ops.GENE_SHARD is None and ops.RESIDENT_SEEN is None
+    assert len(seen) == 3 and seen[0][0] is X
