@@ -371,6 +371,25 @@ def main():
         mode = gs.describe()
     setup_s = time.time() - t0
 
+    def collective_counters():
+        """{name: [calls, bytes]} of everything the trainers handed to a collective since the counters were cleared"""
+        src = {k: list(v) for k, v in kdist.COLLECTIVES.items()}
+        if shard:
+            src.update({k: list(v) for k, v in st_.collectives().items()})
+        elif gs is not None and gs.gene_shard is not None:
+            src.update({k: list(v) for k, v in gs.gene_shard.bytes.items() if v[0]})
+        return src
+    # count what the warm-up + timed steps move, not the trainers' set-up passes (capacity dry runs, capture warm-ups)
+    kdist.COLLECTIVES.clear()
+    if shard:
+        st_.xchg.collectives = {}
+        if st_.gene_shard is not None:
+            for v in st_.gene_shard.bytes.values():
+                v[0] = v[1] = 0
+    elif gs is not None and gs.gene_shard is not None:
+        for v in gs.gene_shard.bytes.values():
+            v[0] = v[1] = 0
+
     for i in range(args.warmup):
         do_step(i)
     if gs is not None:
@@ -384,8 +403,7 @@ def main():
         do_step(args.warmup + i)
     sync()
     elapsed = time.perf_counter() - t_start
-    shard_coll = st_.collectives() if shard else None     # (before the untimed edge-counting pass below adds its own)
-    shard_coll = {k: list(v) for k, v in shard_coll.items()} if shard_coll is not None else None
+    coll_src = collective_counters()          # (before the untimed passes below -- edge counting, overlap check -- add their own)
     # products handed to the framework's GEMM library so far (set-up, warm-up, capture, timed steps): must be 0 on the headline
     lib_calls, lib_sites = ops.LIBRARY_GEMM.calls, {f'{k[0]} {k[1]}': v for k, v in ops.LIBRARY_GEMM.by_site.items()}
     seeds = args.steps * (bs if shard else bs_rank)
@@ -472,13 +490,8 @@ def main():
     # what moved between the ranks: every collective of the timed region, by name, per step and rank (world 1: empty)
     coll = {}
     if world > 1 or os.environ.get('KGW_FORCE_MULTIRANK_PATH') == '1':
-        src = dict(kdist.COLLECTIVES)
-        if shard:
-            src.update(shard_coll)
-        elif gs is not None and gs.gene_shard is not None:
-            src.update({k: v for k, v in gs.gene_shard.bytes.items() if v[0]})
         n_all = args.steps + args.warmup
-        coll = {k: {'calls_per_step': v[0] / n_all, 'bytes_per_step': v[1] / n_all} for k, v in src.items()}
+        coll = {k: {'calls_per_step': v[0] / n_all, 'bytes_per_step': v[1] / n_all} for k, v in coll_src.items()}
     comm = {'world_size': world, 'backend': (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
             'rccl': bool(torch.distributed.is_initialized() and torch.distributed.get_backend() == 'nccl'),
             'collectives_per_step_and_rank': coll}

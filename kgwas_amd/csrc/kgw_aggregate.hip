@@ -956,7 +956,11 @@ __device__ __forceinline__ void bwd_src_rider(const LayerTab& T, const AggPtrs& 
     if (is_v) id -= NR * KGW_DUV_SPLIT;
     const int r = id / KGW_DUV_SPLIT, sp = id % KGW_DUV_SPLIT;
     const int col = t & (KGW_C - 1), rg = t >> 7;                 // 128 columns x 2 row groups
-    float acc = 0.f;
+    // Eight independent partial sums per thread, eight loads in flight: the sums used to be ONE dependent load-add chain per
+    // thread (215 iterations for the largest relation of the benchmark's layer 1 at ~240 ns each = 52 us -- hidden under the
+    // row work, but the floor of any faster row pass).  Fixed order: partial q takes elements q, q + 8, ...
+    // of the thread's list, the partials are added as ((0+1)+(2+3))+((4+5)+(6+7)).
+    float pa[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (T.live[r]) {
         if (!is_v) {
             for (int h = 0; h < P.n_duv_hops; ++h) {
@@ -964,7 +968,18 @@ __device__ __forceinline__ void bwd_src_rider(const LayerTab& T, const AggPtrs& 
                 const int c1 = (r + 1 < NR) ? P.seg_chptr[P.meta->seg_off[h][r + 1]] : P.meta->chunk_end[h];
                 const int n = c1 - c0;
                 const int a0 = c0 + (int)((int64_t)n * sp / KGW_DUV_SPLIT), a1 = c0 + (int)((int64_t)n * (sp + 1) / KGW_DUV_SPLIT);
-                for (int c = a0 + rg; c < a1; c += 2) acc += P.part_du[(int64_t)c * KGW_C + col];
+                const float* p = P.part_du + col;
+                int c = a0 + rg;
+                for (; c + 14 < a1; c += 16) {
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = p[(int64_t)(c + 2 * q) * KGW_C];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) pa[q] += v[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (c + 2 * q < a1) pa[q] += p[(int64_t)(c + 2 * q) * KGW_C];
             }
         } else {
             const int rows = P.meta->n_rows[P.layer - 1][T.rel_dst_type[r]];
@@ -972,9 +987,20 @@ __device__ __forceinline__ void bwd_src_rider(const LayerTab& T, const AggPtrs& 
             const float* dd = P.da_dst + T.z0[r];
             const float* hb = P.H + (int64_t)T.dst_hbase[r] * KGW_C + col;
             const int st = T.zstride[r];
-            for (int i = a0 + rg; i < a1; i += 2) acc = fmaf(dd[(int64_t)i * st], hb[(int64_t)i * KGW_C], acc);
+            int i = a0 + rg;
+            for (; i + 14 < a1; i += 16) {
+                float d[8], hv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { d[q] = dd[(int64_t)(i + 2 * q) * st]; hv[q] = hb[(int64_t)(i + 2 * q) * KGW_C]; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) pa[q] = fmaf(d[q], hv[q], pa[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (i + 2 * q < a1) pa[q] = fmaf(dd[(int64_t)(i + 2 * q) * st], hb[(int64_t)(i + 2 * q) * KGW_C], pa[q]);
         }
     }
+    const float acc = ((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pa[4] + pa[5]) + (pa[6] + pa[7]));
     sm[t] = acc;
     __syncthreads();
     if (rg == 0)

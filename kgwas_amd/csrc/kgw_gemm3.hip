@@ -38,6 +38,7 @@ typedef __attribute__((ext_vector_type(4))) float g3_f4;
 typedef __attribute__((ext_vector_type(4))) unsigned g3_u4;
 
 static constexpr int G3_CH_U4 = 1536;          // uint4 per packed chunk of 32 k: 2 steps x 3 pieces x 4 column tiles x 64 lanes
+static constexpr int G3_FLIP = 4;              // chunks (of 32 k) per sign period of the accumulation, a power of two -- see k_g3_gemm
 static constexpr int G3_MAX_ITEMS = 512;       // 128-row blocks resident at once (two per CU on 256 CUs; 256-row blocks: half)
 
 // ---- B operand packing ------------------------------------------------------------------------------------------------------
@@ -63,6 +64,12 @@ __global__ void __launch_bounds__(256) k_g3_pack(const float* __restrict__ S, lo
 #pragma unroll
         for (int i = 0; i < 8; ++i) x[i] = k0 + i < kv ? S[n * lds_ + k0 + i] : 0.f;
     }
+    // sign period of the accumulation (k_g3_gemm): the chunks of every other period are packed NEGATED (exact: the three
+    // pieces of -x are the negated pieces of x, bf16 rounding is symmetric)
+    if ((c / G3_FLIP) & 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = -x[i];
+    }
     uint4 p1, p2, p3;
     kgw_split3x8(x, p1, p2, p3);
     uint4* o = out + ((c * 2 + j) * 3 * 4 + nt) * 64 + lane;
@@ -77,6 +84,13 @@ struct G3Args {
     int nsplit, n_tiles, per_xcd;
 };
 
+// Sign periods (round 4).  The bf16 MFMA's internal add TRUNCATES (toward -inf: the error of a long accumulation has a negative
+// mean whatever the sign of the sum -- measured: K = 5 120, results ~57, mean error -5.2e-6 against -2.4e-7 for the fp32 pipe).
+// The accumulator therefore changes sign every G3_FLIP chunks: it holds s * (partial sum) with s = (-1)^(chunk / G3_FLIP), the
+// packed B of those chunks is negated to match (s a b accumulates onto s S), and the flip itself is an exact sign change of the
+// accumulator registers -- 64 VALU per 4 x 48 MFMAs, no extra registers.  The truncation then pulls the partial sum down in one
+// period and up in the next: the bias of adjacent periods cancels (what remains is about half of one period's).
+//
 // Both LDS tiles are double buffered in SEPARATE arrays (the compiler then knows that the stores of chunk c + 1 do not alias
 // the operand reads of chunk c).  MT = 32-row tiles per wavefront (1: 128-row blocks, two per CU; 2 was measured too -- 256-row
 // blocks, one per CU, each B operand feeding two MFMAs: 157-180 us against 153 -- and is not instantiated).
@@ -181,6 +195,14 @@ __global__ void __launch_bounds__(64 * NW, (8 / NW) / MT) k_g3_gemm(G3Args a) {
     // steady state without branches: chunk indices past the end are clamped (a redundant load of the last chunk into a
     // buffer nobody reads), so the load counters stay exact.  Iteration c: A of chunk c + 2 leaves for registers, chunk
     // c + 1 (registers since iteration c - 1) goes to the other LDS buffers, chunk c is multiplied.
+    auto flip = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mt][nt][i] = -acc[mt][nt][i];
+    };
     const int last = nc - 1;
     load_a(ra, 0);
     load_b(0);
@@ -194,6 +216,7 @@ __global__ void __launch_bounds__(64 * NW, (8 / NW) / MT) k_g3_gemm(G3Args a) {
         store_a(ra, smA1);
         store_b(smB1);
         load_b(min(c + 2, last));
+        if (c && !((c0 + c) & (G3_FLIP - 1))) flip();          // (wavefront-uniform; at c == 0 the accumulator is zero)
         compute(smA0, smB0);
         __syncthreads();
         if (c + 1 >= nc) break;
@@ -201,12 +224,14 @@ __global__ void __launch_bounds__(64 * NW, (8 / NW) / MT) k_g3_gemm(G3Args a) {
         store_a(rb, smA0);
         store_b(smB0);
         load_b(min(c + 3, last));
+        if (!((c0 + c + 1) & (G3_FLIP - 1))) flip();
         compute(smA1, smB1);
         __syncthreads();
     }
 
     // accumulator register r of a 32x32 tile: row 8 (r / 4) + 4 g + r % 4, column lane & 31
     float* wp = a.ws + ((long)split * a.M) * 128 + m;
+    if (((c1 - 1) / G3_FLIP) & 1) flip();      // the sign the accumulator ends in
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

@@ -1004,9 +1004,10 @@ extern "C" int kgw_sample_batch_parts(const KgwGraph* graph, const KgwBatchBuf* 
         static KgwPerDevice attr_once;
         if (attr_once.need()) {
             KGW_HIP(hipFuncSetAttribute((const void*)k_ts_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            // (k_ts_rows: 4 << 12 / 1 << 14 counters = 64 KB of dynamic LDS on top of the kernel's static words)
-            KGW_HIP(hipFuncSetAttribute((const void*)k_ts_rows<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            KGW_HIP(hipFuncSetAttribute((const void*)k_ts_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            // (k_ts_rows: 4 << 12 / 1 << 14 counters = 64 KB of DYNAMIC LDS on top of the kernel's static words -- above the
+            //  64 KB a launch may use by default; the attribute is the dynamic part only, static + dynamic <= 160 KB)
+            KGW_HIP(hipFuncSetAttribute((const void*)k_ts_rows<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            KGW_HIP(hipFuncSetAttribute((const void*)k_ts_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         }
         if (nblk == 128) k_ts_scan_rows<2><<<SG < 1024 ? SG : 1024, KGW_BLK, 0, st>>>(buf->scan_tmp, nl, nb, buf->meta);
         else if (nblk == 256) k_ts_scan_rows<4><<<SG < 1024 ? SG : 1024, KGW_BLK, 0, st>>>(buf->scan_tmp, nl, nb, buf->meta);

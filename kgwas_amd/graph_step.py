@@ -26,6 +26,24 @@ from .sampler import BatchBuffers, NeighborLoader, SampledBatch, sample_into
 SIDE_SAMPLER_GRID = 256
 
 
+def side_stream(device):
+    """The stream the next batch's sampler graph is captured on and replayed on.  KGW_SAMPLER_CU_MASK=<hex words, comma
+    separated, least significant first> confines it to a subset of the compute units (hipExtStreamCreateWithCUMask: bit i of
+    the mask = CU i) -- an experiment knob: a sampler that runs on a few CUs leaves the L1 / LDS / issue slots of the others
+    to the step's kernels (measured: profiles/r4/).  Default: an ordinary stream."""
+    spec = os.environ.get('KGW_SAMPLER_CU_MASK', '')
+    if not spec:
+        return torch.cuda.Stream(device=device)
+    words = [int(w, 16) for w in spec.split(',') if w]
+    hip = C.CDLL('libamdhip64.so')
+    st = C.c_void_p()
+    arr = (C.c_uint32 * len(words))(*words)
+    rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), C.c_uint32(len(words)), arr)
+    if rc != 0:
+        raise _lib.KgwasHipError(f'hipExtStreamCreateWithCUMask failed: {rc}')
+    return torch.cuda.ExternalStream(st.value, device=device)
+
+
 class GraphTrainStep:
     def __init__(self, run, input_nodes, batch_size: int, lr: float = 1e-4, weight_decay: float = 5e-4,
                  margin: float = 1.03, capture_optimizer: bool = True, overlap_sampling: bool = None,
@@ -106,7 +124,7 @@ class GraphTrainStep:
         self.twin = overlap_sampling in ('2', 2)
         self.sample_graphs = [None, None]
         self._sampled = [torch.cuda.Event(), torch.cuda.Event()]
-        self._side = torch.cuda.Stream(device=dev)
+        self._side = side_stream(dev)
         self._have = [-1, -1]                      # batch index currently sampled into each buffer
         # (timing experiments only: train on stale batches to see what the concurrent sampler costs the step)
         self._skip_resample = os.environ.get('KGW_SKIP_RESAMPLE', '0') == '1'

@@ -473,7 +473,7 @@ class HeteroGNN(nn.Module):
                 z0 = int(m.z_base[l - 1][t])
                 if self.aggr in ('min', 'max'):
                     zr = Z[z0:z0 + rows * R].view(rows, R, C).transpose(0, 1)                    # [R, rows, C]
-                    if ops.LIBRARY_GEMM.strict:          # (library-free form: one own-kernel product per relation and term)
+                    if ops.LIBRARY_GEMM.own_first:          # (library-free form: one own-kernel product per relation and term)
                         hr = h[name][:rows].contiguous()
                         zero = torch.zeros(C, device=dev)
                         o = torch.stack([ops.linear_act(zr[r].contiguous(), P.w_l_t[lo + r], P.bias[lo + r], relu=False) +
@@ -486,7 +486,7 @@ class HeteroGNN(nn.Module):
                     continue
                 x = Z[z0:z0 + rows * R].view(rows, R * C)
                 y = ops.linear_act(x, P.w_l_t[lo:hi].reshape(R * C, C), P.bias[lo:hi].sum(0), relu=False)
-                if ops.LIBRARY_GEMM.strict:
+                if ops.LIBRARY_GEMM.own_first:
                     y = y + ops.linear_act(h[name][:rows].contiguous(), P.w_r_t[lo:hi].sum(0), torch.zeros(C, device=dev), relu=False)
                 else:
                     ops.LIBRARY_GEMM.note('sage root term', rows, C, C)
@@ -572,7 +572,7 @@ class HeteroGNN(nn.Module):
                 for (lo, hi, z0, rows) in blocks:
                     R = hi - lo
                     zr = Z[z0:z0 + rows * R].view(rows, R, C).transpose(0, 1)
-                    if ops.LIBRARY_GEMM.strict:
+                    if ops.LIBRARY_GEMM.own_first:
                         o = torch.stack([ops.linear_act(zr[r].contiguous(), Wv[lo + r], P.bias[lo + r], relu=False) for r in range(R)])
                     else:
                         ops.LIBRARY_GEMM.note('gat min/max per-relation outputs', R, rows, C)

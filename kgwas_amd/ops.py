@@ -72,8 +72,18 @@ class LibraryGemmLog:
 
     def __init__(self):
         self.strict = os.environ.get('KGW_STRICT', '0') == '1'
+        # Routing (round 4): this package's own kernel whenever one CAN take the shape -- whatever the row count.  The library
+        # is left with the products no kernel here takes (K > 2 304 on few rows outside the resident first layer) and is an
+        # OPT-IN beyond that: KGW_ALLOW_LIBRARY=1 restores the row thresholds of rounds 1-3, which hand problems of a few
+        # hundred rows to hipBLASLt because one library launch beats a 128-row-tile kernel on a handful of workgroups (a
+        # performance choice for toy graphs, never taken at the sizes of BASELINE.json's configurations).
+        self.allow_library = os.environ.get('KGW_ALLOW_LIBRARY', '0') == '1'
         self.calls = 0
         self.by_site = {}
+
+    @property
+    def own_first(self) -> bool:
+        return self.strict or not self.allow_library
 
     def note(self, site: str, *shape):
         key = (site, tuple(int(v) for v in shape))
@@ -514,8 +524,8 @@ def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask
                                        1 if relu else 0, 1 if w_kn else 0, _p(ws), nws, _p(rows_dev), _lib.stream_ptr()),
                    'kgw_linear_splitk')
         return Y
-    # (strict mode: the package's own kernel whenever it CAN run -- the row thresholds below are performance choices)
-    big = LIBRARY_GEMM.strict or rows >= 8192 or (rows >= 4096 and K <= 128 and N <= 128)
+    # (the package's own kernel whenever it CAN run; with KGW_ALLOW_LIBRARY=1 the row thresholds below apply instead)
+    big = LIBRARY_GEMM.own_first or rows >= 8192 or (rows >= 4096 and K <= 128 and N <= 128)
     if K % 4 and K <= _LIN_MAX_K and X.dtype == torch.float32 and big and rows > 0:
         # a reduction length that is not a multiple of 4 (the 70-wide mode='full' SNP features, kgwas_data.py:167): zero-pad it --
         # an elementwise copy of X and of the (small) weight, then this package's kernel; never the library for this
@@ -789,7 +799,7 @@ def resident_first_weight_grad(dz, X, W, gs=None):
             return gs.weight_grad_partial(X)
         Xt = _resident_copies(X)[1]                      # [K, Np], Np = the node count rounded up to 32, zero columns past it
         return gemm3(Xt, gemm3_pack(dz, Xt.shape[1], True, k_valid=X.shape[0]), transpose_out=True)
-    if LIBRARY_GEMM.strict and 0 < dz.shape[0] and X.dtype == torch.float32:
+    if LIBRARY_GEMM.own_first and 0 < dz.shape[0] and X.dtype == torch.float32:
         return tn_gemm(dz, X)
     LIBRARY_GEMM.note('resident_first_weight_grad', dz.shape[0], dz.shape[1], X.shape[1])
     with _TUNED:
@@ -1191,7 +1201,7 @@ class _LinearAct(torch.autograd.Function):
     def backward(ctx, dy):
         x, y, Wt = ctx.saved_tensors
         dz = torch.ops.aten.threshold_backward(dy.contiguous(), y, 0.0) if ctx.relu else dy.contiguous()
-        if x.shape[0] >= _TN_MIN_ROWS or (LIBRARY_GEMM.strict and x.shape[0] > 0):
+        if x.shape[0] >= _TN_MIN_ROWS or (LIBRARY_GEMM.own_first and x.shape[0] > 0):
             dWt = tn_gemm(x, dz)                                                       # [K,N]
         else:
             LIBRARY_GEMM.note('linear_act.backward', x.shape[0], x.shape[1], dz.shape[1])
@@ -1208,7 +1218,7 @@ def linear_act(x, Wt, b, relu=True):
 def linear_weight_grad(dY: torch.Tensor, X: torch.Tensor, fixed_shape: bool = False, rows_dev: torch.Tensor = None):
     """(dW [out,in], db [out]) of Y = X W^T + b given dY [rows,out], X [rows,in]."""
     rows, K = X.shape
-    if (rows >= _TN_MIN_ROWS and K <= 1024) or (LIBRARY_GEMM.strict and rows > 0 and X.dtype == torch.float32):
+    if (rows >= _TN_MIN_ROWS and K <= 1024) or (LIBRARY_GEMM.own_first and rows > 0 and X.dtype == torch.float32):
         return tn_gemm(dY, X, colsum=True, rows_dev=rows_dev)
     LIBRARY_GEMM.note('linear_weight_grad', rows, dY.shape[1], K)
     if fixed_shape:

@@ -209,13 +209,13 @@ def test_gene_count_not_a_multiple_of_32_stays_on_gemm3():
         batch = next(iter(NeighborLoader_(run, ids)))
         for p in run.model.parameters():
             p.grad = None
-        was = ops.LIBRARY_GEMM.strict
+        was = ops.LIBRARY_GEMM.strict, ops.LIBRARY_GEMM.allow_library
         try:
-            ops.LIBRARY_GEMM.strict = strict
+            ops.LIBRARY_GEMM.strict, ops.LIBRARY_GEMM.allow_library = strict, not strict       # (the library leg: opted in)
             loss, _ = run.model.forward_loss(batch.x_dict, batch.edge_index_dict, BS, batch.n_id('SNP'), batch.dg.y['SNP'], ld_w)
             loss.backward()
         finally:
-            ops.LIBRARY_GEMM.strict = was
+            ops.LIBRARY_GEMM.strict, ops.LIBRARY_GEMM.allow_library = was
         return float(loss), {n: p.grad.clone() for n, p in run.model.named_parameters() if p.grad is not None}
 
     ops.LIBRARY_GEMM.reset()

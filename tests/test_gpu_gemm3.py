@@ -32,7 +32,7 @@ def test_gemm3_matches_float64_as_well_as_fp32(M, K, kn):
     err = ((C.double() - ref).abs() / sc).max().item()
     err32 = (((A @ B).double() - ref).abs() / sc).max().item()
     # u = 2^-24.  A K-term fp32 chain is bounded by K u; both products sit far below that (pairwise / blocked sums)
-    assert err <= max(2.0 * err32, 4 * 2.0 ** -24), (err, err32)
+    assert err <= max(1.25 * err32, 4 * 2.0 ** -24), (err, err32)
     assert err <= 16 * 2.0 ** -24, err
     Ct = ops.gemm3(A, packed, transpose_out=True)
     assert torch.equal(Ct, C.t())
@@ -40,6 +40,31 @@ def test_gemm3_matches_float64_as_well_as_fp32(M, K, kn):
     assert torch.equal(C, C2)                       # deterministic
     C3 = ops.gemm3(ops.gemm3_tile(A), packed, tiled_rows=M)
     assert torch.equal(C, C3)                       # the tiled resident layout: same products in the same order
+
+
+@pytest.mark.parametrize('M,K,kn', [(20032, 5120, False), (5120, 20032, True)])
+def test_gemm3_has_no_one_sided_error(M, K, kn):
+    """VERDICT r3 item 6.  The bf16 MFMA's internal add truncates: accumulating positive products the plain way left a NEGATIVE
+    mean error (K = 5 120, results ~57: -5.2e-6 = 1.3 ulp against -2.4e-7 for the fp32 pipe) -- a one-sided error in the largest
+    product of the step is what an optimiser integrates.  The accumulator now changes sign every 128 k (kgw_gemm3.hip, sign
+    periods) so that the truncation pulls up as often as down.  Benchmark shapes (forward and weight gradient), positive operands
+    (the worst case: every partial sum has one sign): the MEAN error must be within 2x the fp32 product's own, and the mean
+    absolute error no worse than the fp32 product's."""
+    from kgwas_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(3)
+    A = torch.rand(M, K, device='cuda', generator=g)
+    B = torch.rand(K, 128, device='cuda', generator=g) * (2.0 * 57.0 / K * 2.0)       # results ~57
+    S = B if kn else B.t().contiguous()
+    C = ops.gemm3(A, ops.gemm3_pack(S, K, kn))
+    ref = _ref64(A, B)
+    e3 = C.double() - ref
+    e32 = (A @ B).double() - ref
+    mean3, mean32 = e3.mean().item(), e32.mean().item()
+    abs3, abs32 = e3.abs().mean().item(), e32.abs().mean().item()
+    print(f'[gemm3 bias] M={M} K={K}: mean error {mean3:.3e} (fp32 product {mean32:.3e}), mean |error| {abs3:.3e} ({abs32:.3e}), '
+          f'mean result {ref.mean().item():.1f}')
+    assert abs(mean3) <= max(2.0 * abs(mean32), 0.1 * abs3), (mean3, mean32)
+    assert abs3 <= abs32, (abs3, abs32)
 
 
 def test_gemm3_bias_relu_epilogue_and_strides():

@@ -30,19 +30,23 @@ def _model(data, dims, seed=0, L=2, backbone='GAT', aggr='sum', **kw):
     return m
 
 
-@pytest.fixture(params=['default-routes', 'own-kernels-only'])
+@pytest.fixture(params=['default-routes', 'own-kernels-only', 'library-allowed'])
 def gemm_routing(request):
-    """'own-kernels-only': ops.LIBRARY_GEMM.strict -- every product of the step on this package's kernels whatever its
-    shape (the row thresholds that send small problems to hipBLASLt are performance choices), a library GEMM is an error.
-    'default-routes': what a user gets.  Both must match the restatement."""
+    """'default-routes': what a user gets -- this package's kernel whenever one can take the shape (round 4), the library only
+    for shapes none takes.  'own-kernels-only': ops.LIBRARY_GEMM.strict -- in addition, a library GEMM is an error.
+    'library-allowed': the opt-in of KGW_ALLOW_LIBRARY=1 -- problems of a few hundred rows go to hipBLASLt (the default of
+    rounds 1-3).  All three must match the restatement."""
     from kgwas_amd import ops
-    was = ops.LIBRARY_GEMM.strict
+    was = ops.LIBRARY_GEMM.strict, ops.LIBRARY_GEMM.allow_library
     ops.LIBRARY_GEMM.strict = request.param == 'own-kernels-only'
+    ops.LIBRARY_GEMM.allow_library = request.param == 'library-allowed'
     ops.LIBRARY_GEMM.reset()
     yield request.param
     own, calls = ops.LIBRARY_GEMM.strict, ops.LIBRARY_GEMM.calls
-    ops.LIBRARY_GEMM.strict = was
+    ops.LIBRARY_GEMM.strict, ops.LIBRARY_GEMM.allow_library = was
     assert not own or calls == 0
+    if request.param == 'default-routes':
+        assert calls == 0, 'the small oracle cases have no product that needs the library'
 
 
 def _loader(data, ids, bs, L=2):
