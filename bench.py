@@ -228,6 +228,52 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def run_in_step_trace(args, outdir, timeout_s=420):
+    """Durations of the aggregate kernels INSIDE the benchmarked step: the HIP-event figures of the
+    roofline come from an eager pass in which each kernel has the GPU to itself, but in the captured step the next batch's
+    sampler runs beside them.  One more process: `rocprofv3 --kernel-trace -- python bench.py` (20 replayed steps, no eager
+    legs), then per kernel name the layer-1 dispatch of each of the last steps (the longer of a step's two dispatches).
+    Returns ({kernel: {'median_us', 'mean_us', 'n'}}, error or None)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    if shutil.which('rocprofv3') is None:
+        return None, 'rocprofv3 not on PATH'
+    os.makedirs(outdir, exist_ok=True)
+    env = dict(os.environ, TMPDIR='/tmp', KGW_BENCH_OVERLAP_CHECK='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    n_steps = 20
+    cmd = ['rocprofv3', '--kernel-trace', '--output-format', 'csv', '-d', outdir, '-o', 'instep', '--', sys.executable,
+           os.path.abspath(__file__), '--steps', str(n_steps), '--warmup', '3', '--no-cpu-baseline', '--no-pmc', '--no-epoch',
+           '--no-kernel-timing', '--no-in-step', '--batch-size', str(args.batch_size), '--scale', str(args.scale),
+           '--snp-scale', str(args.snp_scale), '--mode', args.mode]
+    try:
+        with open(os.path.join(outdir, 'instep.log'), 'w') as lf:
+            rc = subprocess.run(cmd, cwd='/tmp', env=env, stdout=lf, stderr=subprocess.STDOUT, timeout=timeout_s).returncode
+    except Exception as e:
+        return None, type(e).__name__
+    files = glob.glob(os.path.join(outdir, '**', 'instep_kernel_trace.csv'), recursive=True)
+    if rc != 0 or not files:
+        return None, f'rocprofv3 exit {rc}'
+    by = {}
+    for r in csv.DictReader(open(files[0])):
+        name = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')
+        for key in ('k_agg_fwd<', 'k_agg_bwd_dst', 'k_agg_bwd_src', 'k_g3_gemm', 'k_mlp2_fwd3', 'k_mlp2_bwd_first3'):
+            if name.startswith(key):
+                by.setdefault(key.rstrip('<'), []).append((int(r['Start_Timestamp']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))
+    out = {}
+    for key, v in by.items():
+        v.sort()
+        d = [x[1] for x in v][-2 * n_steps:]                 # two dispatches per step (layer 1 / 2, forward / dW, SNP / gene)
+        big = [max(d[i:i + 2]) for i in range(0, len(d) - 1, 2)]
+        if big:
+            out[key] = {'median_us': float(np.median(big)), 'mean_us': float(np.mean(big)), 'n': len(big)}
+    os.remove(files[0])                                       # (tens of MB: the summary is what is kept)
+    return out, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -249,6 +295,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 counter passes (roofline.traffic = null)')
+    ap.add_argument('--no-in-step', action='store_true', help='skip the kernel-trace pass that times the aggregate kernels inside the replayed step')
     ap.add_argument('--no-epoch', action='store_true', help='skip the measured epoch (956 training steps + validation pass)')
     ap.add_argument('--eager', action='store_true', help='issue every launch from the host instead of replaying one HIP graph per step')
     ap.add_argument('--as-rank', default=None, metavar='R/P',
@@ -521,6 +568,10 @@ def main():
     if not args.no_pmc and single and not args.no_kernel_timing:
         pmc, pmc_err = run_pmc_passes(args, os.path.join(ROOT, 'gpurun_out', 'bench_pmc'))
 
+    in_step, in_step_err = (None, 'skipped')
+    if not args.no_in_step and single and not args.no_kernel_timing and not args.eager:
+        in_step, in_step_err = run_in_step_trace(args, os.path.join(ROOT, 'gpurun_out', 'bench_instep'))
+
     def agg_entry(tag, d):
         entry = {'launches': d['n'], 'avg_ms': d['ms'] / d['n'], 'edges_per_launch': d['edges'] / d['n']}
         alg = {'fwd': algorithmic_bytes_fwd(d['edges'], d['z_rows']), 'bwd_dst': 528 * d['edges'] + 1028 * d['z_rows'],
@@ -585,6 +636,26 @@ def main():
             roof['counter_note'] = f'counter passes unavailable: {pmc_err}'
         if pmc and not ck.get('batch'):
             roof['counter_note'] = 'counter passes ran but no k_agg_fwd dispatch was attributed (kernel renamed?): traffic unknown'
+        # the same kernels INSIDE the replayed step (beside the next batch's sampler): rocprofv3 kernel trace of 20 replays
+        if in_step:
+            ins = {'how': 'rocprofv3 --kernel-trace over a second run of this script (20 replayed steps): per step the layer-1 dispatch '
+                          '(the longer of the two) of each kernel, median over the steps; `frac` = this run\'s counter traffic of the '
+                          'same launch shape / that time / 8 TB/s (the isolated eager launch above: `frac`)'}
+            for key, tag in (('k_agg_fwd', 'k_agg_fwd<false'), ('k_agg_bwd_dst', 'k_agg_bwd_dst'), ('k_agg_bwd_src', 'k_agg_bwd_src')):
+                if key in in_step:
+                    e = dict(in_step[key])
+                    tb = ((pmc or {}).get('kernels', {}).get(tag, {}).get('batch') or {}).get('bytes')
+                    if tb:
+                        e['traffic'] = tb
+                        e['achieved'] = tb / (e['median_us'] * 1e-6) / 1e9
+                        e['frac'] = e['achieved'] / HBM_PEAK_GBS
+                    ins[key] = e
+            for key in ('k_g3_gemm', 'k_mlp2_fwd3', 'k_mlp2_bwd_first3'):
+                if key in in_step:
+                    ins[key] = in_step[key]
+            roof['in_step'] = ins
+        else:
+            roof['in_step'] = {'note': f'kernel-trace pass unavailable: {in_step_err}'}
         hit = roof.get('l2_hit_rate')
         roof['bounded_by'] = ('at batch %d the launch touches %.0f MB of distinct rows (< 256 MiB Infinity Cache): the fabric-side bytes above are '
                               'served by L3 + HBM together, so `frac` is an UPPER bound on HBM utilisation; the binding resource is the per-XCD '

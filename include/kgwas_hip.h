@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KGW_VERSION      115          /* 0.1.5 */
+#define KGW_VERSION      116          /* 0.1.6 */
 #define KGW_MAX_TYPES    8
 #define KGW_MAX_RELS     64
 #define KGW_MAX_LAYERS   4
@@ -128,8 +128,10 @@ typedef struct KgwBatchBuf {
     uint8_t* t_rel[KGW_MAX_LAYERS];   /* [edge_cap] relation id of the entry (optional: NULL = not written)  */
     int32_t* scan_tmp;     /* [scan_cap] >= kgw_sampler_scan_ints(seg_cap, node slots, trow_cap): scan scratch of the hops, then
                               the [layer][bucket][block] counts of the src-major sort                                             */
-    int32_t* t_tmp;        /* [8 * (edge_cap + 1)], 16-B aligned: per layer of a pair (the second behind the first) row key and chunk
-                              of every edge, then the keys and edge ids stably sorted by bucket (the src-major radix sort)          */
+    int32_t* t_tmp;        /* [8 * (edge_cap + 1)], 16-B aligned, four arrays of edge_cap + 1 per layer of a pair (the second layer's
+                              behind the first's): row key of every edge | (first layer's slot only) chunk of every edge, written
+                              hop by hop by the relabelling pass and shared by all layers | keys | edge ids stably sorted by bucket
+                              (the src-major radix sort)                                                                           */
     KgwBatchMeta* meta;    /* device                                                           */
     KgwBatchMeta* meta_host; /* pinned host mirror (async D2H at the end of sampling)          */
     int64_t seg_cap, edge_cap, chunk_cap, multi_cap, trow_cap, scan_cap;

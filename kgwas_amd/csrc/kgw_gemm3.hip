@@ -39,6 +39,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned g3_u4;
 
 static constexpr int G3_CH_U4 = 1536;          // uint4 per packed chunk of 32 k: 2 steps x 3 pieces x 4 column tiles x 64 lanes
 static constexpr int G3_FLIP = 4;              // chunks (of 32 k) per sign period of the accumulation, a power of two -- see k_g3_gemm
+// (KGW_G3_FLIP=<power of two, 0 = never>: A/B runs of the period; packing and product read the same value)
+static int g3_flip() {
+    static const int f = getenv("KGW_G3_FLIP") ? atoi(getenv("KGW_G3_FLIP")) : G3_FLIP;
+    return (f > 0 && !(f & (f - 1))) ? f : 0;
+}
 static constexpr int G3_MAX_ITEMS = 512;       // 128-row blocks resident at once (two per CU on 256 CUs; 256-row blocks: half)
 
 // ---- B operand packing ------------------------------------------------------------------------------------------------------
@@ -46,7 +51,7 @@ static constexpr int G3_MAX_ITEMS = 512;       // 128-row blocks resident at onc
 // column 32 nt + (lane & 31).  One thread per (c, j, nt, lane).  k >= kv reads as zero (S holds kv rows / columns only: a gene
 // count or a feature width that is not a multiple of 32 -- the A operand then carries zero padding there as well).
 template <bool KN>
-__global__ void __launch_bounds__(256) k_g3_pack(const float* __restrict__ S, long lds_, int K, long kv, int vec, uint4* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_g3_pack(const float* __restrict__ S, long lds_, int K, long kv, int vec, uint4* __restrict__ out, int flip) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long)K * 16) return;
     const int lane = (int)(t & 63), nt = (int)((t >> 6) & 3), j = (int)((t >> 8) & 1);
@@ -66,7 +71,7 @@ __global__ void __launch_bounds__(256) k_g3_pack(const float* __restrict__ S, lo
     }
     // sign period of the accumulation (k_g3_gemm): the chunks of every other period are packed NEGATED (exact: the three
     // pieces of -x are the negated pieces of x, bf16 rounding is symmetric)
-    if ((c / G3_FLIP) & 1) {
+    if (flip && ((c / flip) & 1)) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) x[i] = -x[i];
     }
@@ -81,7 +86,7 @@ struct G3Args {
     const float* A; long lda; int M, K;          // lda == 0: A in 32 x 32 tiles, [ceil(M / 32)][K / 32][32][32]
     const uint4* Bp;
     float* ws;
-    int nsplit, n_tiles, per_xcd;
+    int nsplit, n_tiles, per_xcd, flip;
 };
 
 // Sign periods (round 4).  The bf16 MFMA's internal add TRUNCATES (toward -inf: the error of a long accumulation has a negative
@@ -216,7 +221,7 @@ __global__ void __launch_bounds__(64 * NW, (8 / NW) / MT) k_g3_gemm(G3Args a) {
         store_a(ra, smA1);
         store_b(smB1);
         load_b(min(c + 2, last));
-        if (c && !((c0 + c) & (G3_FLIP - 1))) flip();          // (wavefront-uniform; at c == 0 the accumulator is zero)
+        if (a.flip && c && !((c0 + c) & (a.flip - 1))) flip();  // (wavefront-uniform; at c == 0 the accumulator is zero)
         compute(smA0, smB0);
         __syncthreads();
         if (c + 1 >= nc) break;
@@ -224,14 +229,14 @@ __global__ void __launch_bounds__(64 * NW, (8 / NW) / MT) k_g3_gemm(G3Args a) {
         store_a(rb, smA0);
         store_b(smB0);
         load_b(min(c + 3, last));
-        if (!((c0 + c + 1) & (G3_FLIP - 1))) flip();
+        if (a.flip && !((c0 + c + 1) & (a.flip - 1))) flip();
         compute(smA1, smB1);
         __syncthreads();
     }
 
     // accumulator register r of a 32x32 tile: row 8 (r / 4) + 4 g + r % 4, column lane & 31
     float* wp = a.ws + ((long)split * a.M) * 128 + m;
-    if (((c1 - 1) / G3_FLIP) & 1) flip();      // the sign the accumulator ends in
+    if (a.flip && (((c1 - 1) / a.flip) & 1)) flip();      // the sign the accumulator ends in
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -330,8 +335,8 @@ extern "C" int kgw_gemm3_pack(const float* S, int64_t lds_, int64_t K, int64_t k
     hipStream_t st = (hipStream_t)stream_;
     const int64_t nthr = K * 16;
     const int vec = !(lds_ & 3) && !((uintptr_t)S & 15);       // 16-byte loads along k (S = B^T); else element loads
-    if (s_is_kn) k_g3_pack<true><<<(int)((nthr + 255) / 256), 256, 0, st>>>(S, lds_, (int)K, (long)k_valid, 0, (uint4*)packed);
-    else k_g3_pack<false><<<(int)((nthr + 255) / 256), 256, 0, st>>>(S, lds_, (int)K, (long)k_valid, vec, (uint4*)packed);
+    if (s_is_kn) k_g3_pack<true><<<(int)((nthr + 255) / 256), 256, 0, st>>>(S, lds_, (int)K, (long)k_valid, 0, (uint4*)packed, g3_flip());
+    else k_g3_pack<false><<<(int)((nthr + 255) / 256), 256, 0, st>>>(S, lds_, (int)K, (long)k_valid, vec, (uint4*)packed, g3_flip());
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }
@@ -351,7 +356,7 @@ extern "C" int kgw_gemm3(const float* A, int64_t lda, int64_t M, int64_t K, cons
     const int tiles = (int)((M + rt - 1) / rt);
     hipStream_t st = (hipStream_t)stream_;
     const int per_xcd = (tiles * ns + 7) / 8;
-    G3Args a{A, (long)lda, (int)M, (int)K, (const uint4*)packed, workspace, ns, tiles, per_xcd};
+    G3Args a{A, (long)lda, (int)M, (int)K, (const uint4*)packed, workspace, ns, tiles, per_xcd, g3_flip()};
     if (g3_nw() == 8) k_g3_gemm<1, 8><<<per_xcd * 8, 512, 0, st>>>(a);
     else k_g3_gemm<1, 4><<<per_xcd * 8, 256, 0, st>>>(a);
     KGW_LAUNCH_CHECK();

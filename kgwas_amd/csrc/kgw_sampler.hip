@@ -334,21 +334,42 @@ __device__ __forceinline__ int64_t chunk_gpos(const KgwChunk& c) {
     return ((int64_t)c.gpos_hi << 32) | (uint32_t)c.gpos_lo;
 }
 
-// one wavefront per chunk of dst hop h: flag every not-yet-sampled source node
+// one wavefront per FOUR consecutive chunks of dst hop h: flag every not-yet-sampled source node.  (Round 4: a chunk is a
+// chain of three dependent round trips -- chunk record, its column ids, their table entries -- with two loads per lane in
+// flight; beside a training step the launch has 1 024 wavefronts for ~8 k chunks, so the chain, not bandwidth, set its
+// 56 us.  Four chunks per wavefront-iteration put 8 column loads, then 8 table reads, in flight per lane.)
+constexpr int KGW_WALK = 4;
 __global__ void __launch_bounds__(KGW_BLK) k_mark(SampArgs A, int h) {
     const KgwGraph& G = A.G;
     const KgwBatchMeta* M = A.B.meta;
     if (M->error) return;
     const int cb = (h == 0) ? 0 : M->chunk_end[h - 1], ce = M->chunk_end[h];
     const int lane = kgw_lane();
-    for (int c = cb + blockIdx.x * 4 + (threadIdx.x >> 6); c < ce; c += gridDim.x * 4) {
-        const KgwChunk ck = A.B.chunks[c];
-        const int32_t* col = G.g_col + chunk_gpos(ck);
-        int32_t* g2l = A.B.g2l + G.node_base[G.rel_src[ck.rel]];
-        const int n = ck.e1 - ck.e0;
-        for (int t = lane; t < n; t += 64) {
-            int g = col[t];
-            if (g2l[g] == -1) g2l[g] = KGW_PENDING;   // benign race: every writer stores the same value
+    for (int c = cb + (blockIdx.x * 4 + (threadIdx.x >> 6)) * KGW_WALK; c < ce; c += gridDim.x * 4 * KGW_WALK) {
+        KgwChunk ck[KGW_WALK];
+#pragma unroll
+        for (int q = 0; q < KGW_WALK; ++q) ck[q] = A.B.chunks[min(c + q, ce - 1)];
+        int g[KGW_WALK][KGW_CHUNK / 64];
+#pragma unroll
+        for (int q = 0; q < KGW_WALK; ++q) {
+            const int32_t* col = G.g_col + chunk_gpos(ck[q]);
+            const int n = (c + q < ce) ? ck[q].e1 - ck[q].e0 : 0;
+#pragma unroll
+            for (int u = 0; u < KGW_CHUNK / 64; ++u) g[q][u] = (lane + 64 * u < n) ? col[lane + 64 * u] : -1;
+        }
+        int cur[KGW_WALK][KGW_CHUNK / 64];
+#pragma unroll
+        for (int q = 0; q < KGW_WALK; ++q) {
+            const int32_t* g2l = A.B.g2l + G.node_base[G.rel_src[ck[q].rel]];
+#pragma unroll
+            for (int u = 0; u < KGW_CHUNK / 64; ++u) cur[q][u] = g[q][u] >= 0 ? g2l[g[q][u]] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < KGW_WALK; ++q) {
+            int32_t* g2l = A.B.g2l + G.node_base[G.rel_src[ck[q].rel]];
+#pragma unroll
+            for (int u = 0; u < KGW_CHUNK / 64; ++u)
+                if (g[q][u] >= 0 && cur[q][u] == -1) g2l[g[q][u]] = KGW_PENDING;   // benign race: every writer stores the same value
         }
     }
 }
@@ -414,12 +435,35 @@ __global__ void __launch_bounds__(KGW_BLK) k_relabel(SampArgs A, const int32_t* 
     if (M->error) return;
     const int cb = (h == 0) ? 0 : M->chunk_end[h - 1], ce = M->chunk_end[h];
     const int lane = kgw_lane();
-    for (int c = cb + blockIdx.x * 4 + (threadIdx.x >> 6); c < ce; c += gridDim.x * 4) {
-        const KgwChunk ck = A.B.chunks[c];
-        const int32_t* col = G.g_col + chunk_gpos(ck);
-        const int32_t* g2l = A.B.g2l + G.node_base[G.rel_src[ck.rel]];
-        const int n = ck.e1 - ck.e0;
-        for (int t = lane; t < n; t += 64) A.B.col_local[ck.e0 + t] = g2l[col[t]];
+    // (four chunks per wavefront-iteration, like k_mark: 8 column loads, then 8 table reads in flight per lane)
+    int32_t* cE = A.B.t_tmp + (A.B.edge_cap + 1);
+    for (int c = cb + (blockIdx.x * 4 + (threadIdx.x >> 6)) * KGW_WALK; c < ce; c += gridDim.x * 4 * KGW_WALK) {
+        KgwChunk ck[KGW_WALK];
+#pragma unroll
+        for (int q = 0; q < KGW_WALK; ++q) ck[q] = A.B.chunks[min(c + q, ce - 1)];
+        int g[KGW_WALK][KGW_CHUNK / 64];
+#pragma unroll
+        for (int q = 0; q < KGW_WALK; ++q) {
+            const int32_t* col = G.g_col + chunk_gpos(ck[q]);
+            const int n = (c + q < ce) ? ck[q].e1 - ck[q].e0 : 0;
+#pragma unroll
+            for (int u = 0; u < KGW_CHUNK / 64; ++u) g[q][u] = (lane + 64 * u < n) ? col[lane + 64 * u] : -1;
+        }
+        int loc[KGW_WALK][KGW_CHUNK / 64];
+#pragma unroll
+        for (int q = 0; q < KGW_WALK; ++q) {
+            const int32_t* g2l = A.B.g2l + G.node_base[G.rel_src[ck[q].rel]];
+#pragma unroll
+            for (int u = 0; u < KGW_CHUNK / 64; ++u) loc[q][u] = g[q][u] >= 0 ? g2l[g[q][u]] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < KGW_WALK; ++q)
+#pragma unroll
+            for (int u = 0; u < KGW_CHUNK / 64; ++u)
+                if (g[q][u] >= 0) {
+                    A.B.col_local[ck[q].e0 + lane + 64 * u] = loc[q][u];
+                    cE[ck[q].e0 + lane + 64 * u] = c + q;          // chunk of the edge: what k_ts_keys / k_t_end look up
+                }
     }
 }
 
@@ -506,7 +550,7 @@ __global__ void __launch_bounds__(64) k_layer_tables(SampArgs A) {
 //   k_t_end        Z row and relation of every entry looked up from its chunk (independent gathers), octet flags.
 // Measured (512-seed batch of the benchmark graph, sampler alone, 256-block launches): 433 -> 355 us per batch; beside the
 // training step it now costs the step 40 - 50 us instead of 70 - 80 (no global atomics: 1.18 -> 1.155 ms per step).
-// KgwBatchBuf.t_tmp per layer: key[edge], chunk[edge], sorted key, sorted edge -- 4 x (edge_cap + 1) ints; the counts live in
+// KgwBatchBuf.t_tmp per layer: key[edge], (first layer's slot: chunk[edge] of ALL layers, written by k_relabel), sorted key, sorted edge -- 4 x (edge_cap + 1) ints; the counts live in
 // KgwBatchBuf.scan_tmp ([layer][digit][block]); KgwBatchMeta.cur[4 + k] = entries of layer l0 + k.
 // (blocks of k_ts_keys / k_ts_scatter = contiguous edge ranges: 256 beside a training step, 512 when the call has the GPU)
 constexpr int TS_INVALID = 0x7fffffff;
@@ -543,48 +587,38 @@ __global__ void __launch_bounds__(KGW_BLK) k_ts_keys(SampArgs A, int l0, int nl,
         const int l = l0 + k;
         const int n = M->n_edges[l - 1], nc = M->n_chunks[l - 1];
         int32_t* keyE = A.B.t_tmp + (int64_t)k * 4 * E1;
-        int32_t* cE = keyE + E1;
+        const int32_t* cE = A.B.t_tmp + E1;              // chunk of every edge (k_relabel; the same for every layer)
         int32_t* H = A.B.scan_tmp + (int64_t)k * (nb + 1) * gridDim.x;
         for (int d = threadIdx.x; d <= nb; d += KGW_BLK) ts_lds[d] = 0;
         __syncthreads();
         int beg, end;
         ts_block_range(n, blockIdx.x, gridDim.x, beg, end);
-        const int q = (((end - beg) + 3) / 4 + 63) & ~63;          // a wavefront's quarter: whole groups of 64
-        const int wb = min(end, beg + wv * q), we = min(end, wb + q);
-        // chunk of the quarter's first edge: one binary search; after that the chunk list is walked (64 consecutive edges span
-        // at most 64 chunks: their end offsets are one coalesced load, the lane's chunk a 6-step search through shuffles)
-        int c0 = 0;
-        if (wb < we) {
-            int lo = 0, hi = nc;               // chunks[lo].e0 <= wb < chunks[hi].e0
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (A.B.chunks[mid].e0 <= wb) lo = mid; else hi = mid;
-            }
-            c0 = lo;
-        }
-        for (int g = wb; g < we; g += 64) {
-            const int e = g + lane;
-            const bool valid = e < we;
-            const int ce = (c0 + lane < nc) ? A.B.chunks[c0 + lane].e1 : 0x7fffffff;
-            int lo = 0;
+        // the chunk of every edge was written by k_relabel (round 4; until then the chunk list was WALKED here -- one binary
+        // search per wavefront, then the end offsets of 64 chunks and a 6-step search through shuffles per group of 64 edges, each
+        // group starting where the last one ended: a serial chain of ~3 round trips x 16 groups per wavefront, 100 us of the
+        // sampler's 565).  Now every edge is independent: four groups of 64 per iteration, 12 loads in flight per lane.
+        for (int g = beg + threadIdx.x; g < end; g += 4 * KGW_BLK) {
+            int c[4], cl[4], r[4];
 #pragma unroll
-            for (int step = 32; step >= 1; step >>= 1) {
-                const int v = __shfl(ce, lo + step - 1, 64);
-                lo += (v <= e) ? step : 0;
+            for (int u = 0; u < 4; ++u) {
+                const int e = g + u * KGW_BLK;
+                c[u] = e < end ? cE[e] : 0;
+                cl[u] = e < end ? A.B.col_local[e] : 0;
             }
-            const int c = min(c0 + lo, nc - 1);
-            if (valid) {
-                const int r = A.B.chunks[c].rel;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] = A.B.chunks[c[u]].rel;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = g + u * KGW_BLK;
+                if (e >= end) continue;
                 int key = TS_INVALID;
-                if (G.rel_live[l - 1][r]) {
-                    const int sT = G.rel_src[r];
-                    key = M->t_base[l - 1][sT] + A.B.col_local[e] * G.R_src[sT] + G.rel_slot_src[r];
+                if (G.rel_live[l - 1][r[u]]) {
+                    const int sT = G.rel_src[r[u]];
+                    key = M->t_base[l - 1][sT] + cl[u] * G.R_src[sT] + G.rel_slot_src[r[u]];
                 }
                 keyE[e] = key;
-                cE[e] = c;
                 atomicAdd(&ts_lds[key == TS_INVALID ? nb : (key >> sh)], 1);
             }
-            c0 = __shfl(c, 63, 64);            // (lane 63's edge is the group's last: the next group starts in its chunk or later)
         }
         __syncthreads();
         for (int d = threadIdx.x; d <= nb; d += KGW_BLK) H[(int64_t)d * gridDim.x + blockIdx.x] = ts_lds[d];
@@ -829,7 +863,7 @@ __global__ void __launch_bounds__(KGW_BLK) k_t_end(SampArgs A, int l0, int nl) {
         if (!M->error) {
             // Z row and relation of every entry, from the chunk of its edge (independent gathers: this is the parallel half of
             // the placement, k_ts_rows does the ordered half)
-            const int32_t* cE = A.B.t_tmp + (int64_t)k * 4 * E1 + E1;
+            const int32_t* cE = A.B.t_tmp + E1;           // chunk of every edge (k_relabel)
             const int n_ent = M->cur[4 + k];
             const int nthr = gridDim.x * KGW_BLK;
             for (int j0 = blockIdx.x * KGW_BLK + threadIdx.x; j0 < n_ent; j0 += 4 * nthr) {       // (four independent chains in flight)

@@ -33,7 +33,9 @@ def side_stream(device):
     to the step's kernels (measured: profiles/r4/).  Default: an ordinary stream."""
     spec = os.environ.get('KGW_SAMPLER_CU_MASK', '')
     if not spec:
-        return torch.cuda.Stream(device=device)
+        # KGW_SAMPLER_PRIORITY: stream priority of the sampler's queue (a larger number = a LOWER priority; values outside the
+        # device's range are clamped): with a low-priority queue the dispatcher hands free wavefront slots to the step's kernels first
+        return torch.cuda.Stream(device=device, priority=int(os.environ.get('KGW_SAMPLER_PRIORITY', '0')))
     words = [int(w, 16) for w in spec.split(',') if w]
     hip = C.CDLL('libamdhip64.so')
     st = C.c_void_p()
@@ -297,9 +299,15 @@ class GraphTrainStep:
             self.opt.step_dev.zero_()
         self.stats.zero_()
         self.opt.zero_grad(set_to_none=True)
+        # (KGW_STEP_PRIORITY: capture -- hence run, a replayed graph executes on the queue of the stream it was captured on -- the
+        #  step on a stream of this priority; negative = above the sampler's default-priority queue.  Experiment knob.)
+        cap_kw = {}
+        if os.environ.get('KGW_STEP_PRIORITY'):
+            self._cap_stream = torch.cuda.Stream(device=self.seeds.device, priority=int(os.environ['KGW_STEP_PRIORITY']))
+            cap_kw = {'stream': self._cap_stream}
         for cur in (0, 1):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, **cap_kw):
                 self.loss[cur] = self._step_body(cur)
             self.graphs[cur] = g
             if self.split_backward:

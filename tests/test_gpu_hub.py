@@ -183,6 +183,7 @@ def _compare_with_oracle(run, ids, what, min_genes):
     with torch.no_grad():
         for pack in list(model.live_packs) + list(model.dead_packs):
             pack.bias.normal_(0, 0.1)
+        model.lin.bias.fill_(0.5)          # (keep the read-out's ReLU of model.py:86 alive: a dead one zeroes every gradient)
     batch = next(iter(NeighborLoader(run.data.data, [-1, -1], ('SNP', np.asarray(ids)), batch_size=bs, device='cuda:0')))
     assert batch.n_nodes['Gene'] >= min_genes, batch.n_nodes
     ld_w = run._ld_weight_vector()
@@ -215,6 +216,7 @@ def _compare_with_oracle(run, ids, what, min_genes):
         n += 1
     assert n > 40
     gw, rw = grads_by_name(model)['gene_feat_mlp.FC_hidden.weight'].double(), go['gene_feat_mlp.FC_hidden.weight']
+    assert float(rw.norm()) > 0 and int((pred > 0).sum()) >= bs // 2, 'a dead read-out would make this comparison empty'
     assert float((gw - rw).norm() / rw.norm()) < 1e-5, 'the wide layer relative to its own magnitude'
     k = min(8, bs)
     assert torch.equal(torch.topk(pred.cpu().double(), k).indices, torch.topk(out_o.detach().reshape(-1), k).indices)
