@@ -278,6 +278,11 @@ int kgw_accumulate_stats(const KgwBatchMeta* meta_dev, int32_t n_layers, int32_t
 int kgw_accumulate_stats_tick(const KgwBatchMeta* meta_dev, int32_t n_layers, int32_t n_hops, int64_t* stats, int32_t* tick,
                               kgw_stream_t stream);
 
+/* One wavefront that idles for ``us`` microseconds (0 .. 100 000) on ``stream``: a timed offset at the head of the sampler's
+ * side-stream graph, so that the next batch is sampled beside the part of the training step where that costs least
+ * (nothing in the reference to replace: kgwas/kgwas.py:129 samples on the CPU, between steps).                       */
+int kgw_delay(int32_t us, kgw_stream_t stream);
+
 /* Replaces: the index_select feature slicing of the loader (x[n_id], kgwas/kgwas.py:135).      */
 int kgw_gather_rows(const float* src, const int32_t* ids, int64_t n_rows, int32_t width,
                     float* dst, kgw_stream_t stream);

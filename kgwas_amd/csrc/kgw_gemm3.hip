@@ -38,7 +38,7 @@ typedef __attribute__((ext_vector_type(4))) float g3_f4;
 typedef __attribute__((ext_vector_type(4))) unsigned g3_u4;
 
 static constexpr int G3_CH_U4 = 1536;          // uint4 per packed chunk of 32 k: 2 steps x 3 pieces x 4 column tiles x 64 lanes
-static constexpr int G3_FLIP = 4;              // chunks (of 32 k) per sign period of the accumulation, a power of two -- see k_g3_gemm
+static constexpr int G3_FLIP = 16;             // chunks (of 32 k) per sign period of the accumulation, a power of two -- see k_g3_gemm
 // (KGW_G3_FLIP=<power of two, 0 = never>: A/B runs of the period; packing and product read the same value)
 static int g3_flip() {
     static const int f = getenv("KGW_G3_FLIP") ? atoi(getenv("KGW_G3_FLIP")) : G3_FLIP;
@@ -94,7 +94,11 @@ struct G3Args {
 // The accumulator therefore changes sign every G3_FLIP chunks: it holds s * (partial sum) with s = (-1)^(chunk / G3_FLIP), the
 // packed B of those chunks is negated to match (s a b accumulates onto s S), and the flip itself is an exact sign change of the
 // accumulator registers -- 64 VALU per 4 x 48 MFMAs, no extra registers.  The truncation then pulls the partial sum down in one
-// period and up in the next: the bias of adjacent periods cancels (what remains is about half of one period's).
+// period and up in the next: the bias of adjacent periods cancels.  Measured (tests/test_gpu_gemm3.py, positive operands, results
+// ~57, forward / weight-gradient shape): mean error -2.4e-6 / -2.3e-6 without sign periods, -6e-8 / -3e-8 with periods of 4 or 8
+// chunks, +3e-9 / -5e-8 with 16 (the fp32 pipe's own: -3.3e-7 / -1.2e-6); mean |error| 1.07e-5 / 5.8e-6 against the fp32
+// product's 4.1e-5 / 3.9e-5.  Step time: periods of 16 chunks are free, periods of 4 cost 2 - 10 us per step (the flip drains the
+// MFMA pipe) -- hence 16.
 //
 // Both LDS tiles are double buffered in SEPARATE arrays (the compiler then knows that the stores of chunk c + 1 do not alias
 // the operand reads of chunk c).  MT = 32-row tiles per wavefront (1: 128-row blocks, two per CU; 2 was measured too -- 256-row

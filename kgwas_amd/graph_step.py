@@ -24,6 +24,9 @@ from .sampler import BatchBuffers, NeighborLoader, SampledBatch, sample_into
 # (measured, 512-seed steps: 2048 blocks 1.74 ms/step, 512: 1.68, 256: 1.67, 128: 1.66, 64: 2.03 -- there the sampler,
 # 1.0 ms on its own, no longer hides); 256 keeps the sampler at 0.42 ms, under the forward-only eval step too
 SIDE_SAMPLER_GRID = 256
+# microseconds the side sampler's graph idles before its first launch (kgw_delay): which kernels of the step the sampler's
+# launches share the chip with decides what the overlap costs (KGW_SAMPLER_DELAY_US overrides; 0 = start with the step)
+SIDE_SAMPLER_DELAY_US = int(os.environ.get('KGW_SAMPLER_DELAY_US', '0'))
 
 
 def side_stream(device):
@@ -325,8 +328,26 @@ class GraphTrainStep:
                         gs.weight_grad_partial(gs.last[0], out=self._flat_grads[gs.last[1]])
             if self.twin:
                 gs = torch.cuda.CUDAGraph()
+                probe = os.environ.get('KGW_SIDE_PROBE')      # (experiment: what does a side graph cost the step BY ITSELF?)
                 with torch.cuda.graph(gs, stream=self._side):
-                    sample_into(self.dg, self.bufs[cur], self.seeds, self.seed_type, record=False)
+                    if SIDE_SAMPLER_DELAY_US > 0:       # (a timed offset against the step it runs beside, see the constant)
+                        _lib.check(_lib.lib().kgw_delay(SIDE_SAMPLER_DELAY_US, _lib.stream_ptr()), 'kgw_delay')
+                    if probe and probe.startswith('parts:'):
+                        # "parts:<a>:<b>": only parts a..b of the sampling call (kgw_sample_batch_parts: 0 .. 2 hops - 1 the hop
+                        # expansion, 2 hops the layer tables + src-major build) -- WHICH phase costs the step what; the seeds
+                        # are frozen (step()), so the buffers keep holding one consistent batch
+                        a_, b_ = (int(v) for v in probe.split(':')[1:])
+                        _lib.check(_lib.lib().kgw_sample_batch_parts(C.byref(self.dg.kg), C.byref(self.bufs[cur].c), self.seeds.data_ptr(),
+                                                                     int(self.seeds.numel()), self.seed_type, 0, a_, b_, _lib.stream_ptr()),
+                                   'kgw_sample_batch_parts')
+                    elif probe:
+                        # "<n>x<us>": n launches of one idle wavefront each, <us> microseconds long -- launches and queue
+                        # activity without memory traffic or occupancy; the step then trains on stale batches
+                        n_, us_ = (int(v) for v in probe.split('x'))
+                        for _ in range(n_):
+                            _lib.check(_lib.lib().kgw_delay(max(us_, 1), _lib.stream_ptr()), 'kgw_delay')
+                    else:
+                        sample_into(self.dg, self.bufs[cur], self.seeds, self.seed_type, record=False)
                 self.sample_graphs[cur] = gs
         self._have = [-1, -1]
 
@@ -345,7 +366,8 @@ class GraphTrainStep:
             main = torch.cuda.current_stream()
             self._side.wait_stream(main)          # the previous step (reader of bufs[1 - cur], writer of nothing here) is done
             with torch.cuda.stream(self._side):
-                self.seeds.copy_(self.ids[nxt * b:(nxt + 1) * b])
+                if not os.environ.get('KGW_SIDE_PROBE', '').startswith('parts:'):
+                    self.seeds.copy_(self.ids[nxt * b:(nxt + 1) * b])
                 if not self._skip_resample:
                     self.sample_graphs[1 - cur].replay()
                 self._sampled[1 - cur].record(self._side)

@@ -13,8 +13,13 @@
 TOLERANCES, stated (fp32 kernels vs a float64 oracle):
   attention weight          |a - a*| <= 1e-4 a* + 1e-9      (relative: a hub row's weights are ~1e-5 each)
   prediction, activations   |x - x*| <= 1e-5 + 1e-4 |x*| + 1e-5 max|x*|
-  parameter gradients       |g - g*| <= 1e-4 |g*| + max(1e-5, 1e-4 max|g*|) + 1e-5 max|g*|
+  parameter gradients       |g - g*| <= 1e-4 |g*| + max(1e-5, 1e-4 max|g*|) + 1e-5 max|g*|       (hub case)
   (rtol 1e-4 / atol 1e-5 on activations and gradients "summation-order differences over up-to-1e5-degree rows")
+  full-size graph           the same for prediction / loss; parameter gradients  ||g - g*|| <= 1e-3 ||g*||  (norm-wise, every
+                            tensor; the MEDIAN tensor within 1e-5; the test prints the largest) and
+                            |g - g*| <= 1e-4 |g*| + max(1e-5, 1e-3 max|g*|) element-wise: with 16 seeds a weight gradient is a sum over ~1e5
+                            sampled rows of terms of both signs that cancels to a few 1e-2 -- an fp32 sum carries u * sum|terms|,
+                            not u * |result| (measured: 22 of 16 384 elements of one 128 x 128 gradient 6e-4 of its maximum off)
 """
 from collections import OrderedDict
 
@@ -206,15 +211,24 @@ def _compare_with_oracle(run, ids, what, min_genes):
     assert_close(pred, out_o.detach().reshape(-1), RTOL, ATOL, f'{what}: pred')
     assert abs(float(loss) - float(loss_o)) <= 1e-4 * abs(float(loss_o)) + 1e-7
     go = grads_by_name(oracle)
-    n = 0
+    n, nw = 0, []
     for name, g in grads_by_name(model).items():
         ref = go[name]
         if g is None:
             assert ref is None or float(ref.abs().max()) == 0.0, name
             continue
-        assert_close(g, ref, RTOL, max(ATOL, 1e-4 * float(ref.abs().max())), f'{what}: grad {name}')
+        assert_close(g, ref, RTOL, max(ATOL, 1e-3 * float(ref.abs().max())), f'{what}: grad {name}')
+        # (a gradient that is zero in exact arithmetic -- d att_dst of a softmax over ONE destination's logits: adding a constant
+        #  to them changes nothing -- comes out as 1e-19 in float64 and 1e-10 in fp32: only the absolute bound applies to it)
+        if float(ref.norm()) > 1e-6:
+            nw.append((float((g.double() - ref).norm() / ref.norm()), name))
         n += 1
     assert n > 40
+    nw.sort(reverse=True)
+    print(f'[{what}] norm-wise gradient errors, largest first: ' + ', '.join(f'{k} {e:.1e}' for e, k in nw[:4]) +
+          f'; median {nw[len(nw) // 2][0]:.1e} over {len(nw)} tensors')
+    assert nw[0][0] <= 1e-3, nw[0]
+    assert nw[len(nw) // 2][0] <= 1e-5, nw[len(nw) // 2]
     gw, rw = grads_by_name(model)['gene_feat_mlp.FC_hidden.weight'].double(), go['gene_feat_mlp.FC_hidden.weight']
     assert float(rw.norm()) > 0 and int((pred > 0).sum()) >= bs // 2, 'a dead read-out would make this comparison empty'
     assert float((gw - rw).norm() / rw.norm()) < 1e-5, 'the wide layer relative to its own magnitude'
