@@ -29,6 +29,10 @@ Extra keys, all measured by this run:
                gather of known byte count); frac = traffic / time / 8 TB/s; compulsory and algorithmic
                bytes; the same at a batch whose working set exceeds the Infinity Cache; MFMA pipe occupancy
                of the dense kernels
+               roofline.in_step: the aggregate kernels INSIDE the replayed step (beside the next batch's sampler), from one more
+               process under `rocprofv3 --kernel-trace` -- median layer-1 dispatch of the last 20 steps, frac by the same traffic
+  config.sampler_overlap   measured after the timed region: steps with the side sampler, without it, sampler alone; overlap =
+               share of the sampler's time that did not show up in the step (`overlapped` false = the two graphs serialised)
   cpu_baseline the CPU oracle (op-for-op PyG restatement) on this box's host cores, 20 steps after 3 warm-ups
   breakdown    per-kernel event times of the three aggregate kernels
   config.epoch_measured   one whole epoch (956 steps + validation pass), wall clock
