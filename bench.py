@@ -414,8 +414,9 @@ def main():
         mode = 'eager launches'
     else:
         from kgwas_amd.graph_step import GraphTrainStep
-        # (strong scaling: every rank would repeat the batch-independent first gene Linear -- split it by gene rows instead)
-        gs = GraphTrainStep(run, ('SNP', mine), bs_rank, lr=1e-4, weight_decay=5e-4, shard_gene_layer=strong and world >= 4)
+        # (every rank would repeat the batch-independent first gene Linear, weak scaling or strong: split by gene rows over the
+        #  ranks where that pays -- GraphTrainStep's default, ops.gene_layer_split_pays)
+        gs = GraphTrainStep(run, ('SNP', mine), bs_rank, lr=1e-4, weight_decay=5e-4)
 
         def do_step(i):
             gs.step(i)

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import torch
@@ -95,9 +96,12 @@ class GraphTrainStep:
         # multi-rank, optional: the first gene Linear over the resident feature matrix (forward + weight gradient: 0.27 of the
         # step's 1.2 ms, identical work on every rank) split by gene rows over the ranks -- ops.GeneLayerShard in its STAGED form:
         # partial product (captured) | all-gather | the step's graphs | reduce-scatter of dz | partial weight gradient (captured).
-        # Pays when (world - 1) / world of 0.27 ms exceeds two 10 MB collectives + three extra graph boundaries: strong scaling /
-        # many ranks.  KGW_SHARD_GENE_LAYER=1/0 overrides the caller's choice.
+        # Pays when (world - 1) / world of 0.27 ms (x 11 for the 57 742-wide features) exceeds two 10 MB collectives + three extra
+        # graph boundaries -- under weak scaling as much as under strong: the layer's output does not depend on the batch (round 4:
+        # on by default from 4 ranks at width 5 120, from 2 at 57 742).  KGW_SHARD_GENE_LAYER=1/0 overrides.
         env = os.environ.get('KGW_SHARD_GENE_LAYER')
+        if shard_gene_layer is None:                                   # default: where it pays (ops.gene_layer_split_pays)
+            shard_gene_layer = ops.gene_layer_split_pays(self.world, int(getattr(run.data, 'gene_init_dim_size', 0) or 0))
         want = (shard_gene_layer if env is None else env == '1') and self.split_backward
         # (whether the model takes the resident route for the gene features depends on the rank's own batches: probed by a
         #  warm-up step WITHOUT the shard and agreed over the ranks before any collective depends on it -- _capture)
@@ -261,8 +265,12 @@ class GraphTrainStep:
                 seen, self._probe = self._probe, None
                 ok = torch.tensor([1 if len(seen) == 1 else 0], dtype=torch.int32, device=self.seeds.device)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if int(ok[0]):
-                    gs0 = ops.GeneLayerShard(dist.get_rank(), dist.get_world_size(), None, inline=False)
+                gs0 = ops.GeneLayerShard(dist.get_rank(), dist.get_world_size(), None, inline=False) if int(ok[0]) else None
+                if gs0 is not None and not gs0.selftest(self.seeds.device):      # (collective: every rank, same verdict)
+                    print('kgwas_amd: the gene-layer split\'s collectives failed their self-test on this backend: layer kept replicated',
+                          file=sys.stderr)
+                    gs0 = None
+                if gs0 is not None:
                     gs0._setup(seen[0][0])
                     gs0.last = seen[0]
                     self.gene_shard = gs0

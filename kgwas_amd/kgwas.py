@@ -181,7 +181,7 @@ class KGWAS:
             #  Linear is split by gene rows instead of repeated on every rank -- ops.GeneLayerShard)
             graph_step = GraphTrainStep(self, (self.train_loader.input_type, self.train_loader.ids.cpu().numpy()),
                                         self.train_loader.batch_size, lr=lr, weight_decay=weight_decay,
-                                        shard_gene_layer=world >= 4)
+                                        shard_gene_layer=None)
             optimizer = graph_step.opt
         else:
             optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay)   # kgwas.py:116

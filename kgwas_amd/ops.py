@@ -664,6 +664,34 @@ class GeneLayerShard:
         self.last = None                                       # (X, W, b) of the layer this shard was last applied to
         self.bytes = {'all_gather(first gene layer output)': [0, 0], 'reduce_scatter(first gene layer dz)': [0, 0]}
 
+    def selftest(self, device) -> bool:
+        """The two collectives of the split on a few KB, checked against what they must deliver, the verdict agreed over the
+        ranks (MIN): an in-place all-gather or a reduce-scatter that misbehaves on some backend / topology switches the split
+        off on EVERY rank instead of training on garbage.  Every rank calls it (three collectives)."""
+        import torch.distributed as dist
+        w, r = self.world, self.rank
+        keep = self.h_all, self.dz, self.dz_mine, self.n, self.chunk
+        try:
+            self.n, self.chunk = w * 32, 32
+            self.h_all = torch.zeros(w * 32, KGW_C, device=device)
+            self.h_all[r * 32:(r + 1) * 32] = float(r + 1)
+            self.dz = torch.arange(w * 32, device=device, dtype=torch.float32).view(-1, 1).expand(w * 32, KGW_C).contiguous() * (r + 1)
+            self.dz_mine = torch.empty(32, KGW_C, device=device)
+            self.gather()
+            self.scatter()
+            want_h = torch.arange(1, w + 1, device=device, dtype=torch.float32).repeat_interleave(32).view(-1, 1).expand(w * 32, KGW_C)
+            want_d = torch.arange(r * 32, (r + 1) * 32, device=device, dtype=torch.float32).view(-1, 1).expand(32, KGW_C) * (w * (w + 1) / 2)
+            ok = bool(torch.equal(self.h_all, want_h)) and bool(torch.allclose(self.dz_mine, want_d))
+            if self.backend == 'nccl' and dist.get_backend(self.group) == 'fake':
+                ok = True                                   # (bench.py --as-rank: the collectives move nothing by design)
+        finally:
+            self.h_all, self.dz, self.dz_mine, self.n, self.chunk = keep
+            for v in self.bytes.values():
+                v[0] = v[1] = 0
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t[0]))
+
     def _setup(self, X):
         N = X.shape[0]
         if self.h_all is not None and self.n == N:
@@ -722,6 +750,16 @@ class GeneLayerShard:
         if hi <= lo or kin <= 0:
             return out.zero_()
         return gemm3(Xt[:, lo:lo + kin], gemm3_pack(self.dz_mine[:hi - lo], kin, True, k_valid=hi - lo), transpose_out=True, out=out)
+
+
+def gene_layer_split_pays(world: int, width: int) -> bool:
+    """Default of the gene-layer split over the ranks.  Its output does not depend on the batch, so EVERY multi-rank mode -- per-GPU
+    batches (weak) as much as one batch split over the GPUs (strong) -- repeats the same 2 x 26 GFLOP (width 5 120; x 11 at 57 742)
+    on every rank without it.  It costs an all-gather and a reduce-scatter of 10 MB and three more graph boundaries (~0.17 ms
+    together, measured / modelled); it saves (world - 1) / world of 0.275 ms x width / 5 120.  Measured with bench.py --as-rank
+    (profiles/r4): width 5 120 -- rank compute 1.231 -> 1.158 / 1.097 / 1.069 ms at 2 / 4 / 8 ranks; width 57 742 -- 4.185 ->
+    2.855 / 1.661 ms at 2 / 8 ranks."""
+    return world >= 2 and (world - 1) / world * 0.275 * (width / 5120.0) > 0.17
 
 
 GENE_SHARD = None          # the GeneLayerShard of the training step being issued (gene_shard_scope), or None

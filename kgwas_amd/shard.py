@@ -413,7 +413,8 @@ class ShardedTrainer:
         # collectives against (world - 1) / world of 0.27 ms); KGW_SHARD_GENE_LAYER=1/0 overrides.
         from . import ops
         env = os.environ.get('KGW_SHARD_GENE_LAYER')
-        on = self.xchg.multi and (self.world >= 4 if env is None else env == '1')
+        on = self.xchg.multi and (ops.gene_layer_split_pays(self.world, int(getattr(run.data, 'gene_init_dim_size', 0) or 0))
+                                  if env is None else env == '1')
         # (captured form: the STAGED variant -- partial product and all-gather ahead of the forward, reduce-scatter and the partial
         #  weight gradient after the backward, all at the trainer's level where a capture can be cut: _static_body)
         # (the replicated gene type expands the MERGED frontier: its row count -- hence the resident-route decision -- is the same

@@ -79,3 +79,46 @@ def test_seed_sharded_gradients_equal_full_batch(tmp_path):
     for n, gfull in full.items():
         assert torch.equal(r0['grads'][n], r1['grads'][n]), n               # all-reduce: identical on both ranks
         assert torch.allclose(r0['grads'][n], gfull, rtol=1e-9, atol=1e-12), n
+
+
+def _worker_split(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from kgwas_amd import dist as kdist
+        from kgwas_amd import ops
+        gs = ops.GeneLayerShard(rank, world, None, inline=False)
+        ok = gs.selftest(torch.device('cpu'))                  # its two collectives on a few KB, verdict agreed over the ranks
+        assert all(v == [0, 0] for v in gs.bytes.values())    # (the self-test is not counted as traffic of the step)
+        # gradient liveness is RE-agreed when a rank sees a gradient on a parameter the first agreement left out
+        m = torch.nn.Linear(3, 2, bias=True)
+        m.weight.grad = torch.full_like(m.weight, float(rank + 1))
+        kdist.allreduce_grads(m, world)                       # step 1: the bias is dead on every rank
+        first = (m.weight.grad.clone(), m.bias.grad)
+        m.weight.grad = torch.full_like(m.weight, 1.0)
+        if rank == 1:
+            m.bias.grad = torch.full_like(m.bias, 4.0)        # step 2: alive on ONE rank only
+        kdist.allreduce_grads(m, world)
+        torch.save({'ok': ok, 'first_w': first[0], 'first_b': first[1], 'second_b': m.bias.grad}, os.path.join(out_dir, f's{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gene_layer_split_selftest_and_liveness_reagreement(tmp_path):
+    world = 2
+    mp.spawn(_worker_split, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        d = torch.load(tmp_path / f's{r}.pt', weights_only=False)
+        assert d['ok'] is True
+        assert torch.equal(d['first_w'], torch.full((2, 3), 1.5)) and d['first_b'] is None
+        # the parameter that came alive on rank 1 is reduced on BOTH ranks (mean of 0 and 4), not stepped locally on one
+        assert d['second_b'] is not None and torch.equal(d['second_b'], torch.full((2,), 2.0))
+
+
+def test_gene_layer_split_default_follows_what_it_saves():
+    from kgwas_amd import ops
+    assert not ops.gene_layer_split_pays(1, 57742) and not ops.gene_layer_split_pays(2, 5120)
+    assert ops.gene_layer_split_pays(4, 5120) and ops.gene_layer_split_pays(8, 5120)
+    assert ops.gene_layer_split_pays(2, 57742)                # the 57 742-wide features: from two ranks on
+    assert not ops.gene_layer_split_pays(8, 96)               # narrow features never take the resident route anyway
