@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """Predicted multi-GPU step time = measured per-rank compute + modelled xGMI time of the rank's collectives.
 
-Inputs (a directory of bench.py lines, one JSON file each):
-    bench_p1.json                         python bench.py                       (P = 1, the plain single-GPU step)
-    emu_<scaling>_<parallelism>_p<P>.json python bench.py --as-rank 0/P ...     (ONE GPU doing rank 0's work of a P-GPU job,
-                                          every collective a no-op of the right size: ms_per_step = the rank's compute time,
-                                          config.communication.collectives_per_step_and_rank = what it would have sent)
+Inputs: a directory of bench.py lines, one JSON file each (any names; what a line is is read from the line itself):
+    python bench.py [--mode full]             (P = 1, the plain single-GPU step: the baseline of its feature-width mode)
+    python bench.py --as-rank 0/P ...         (ONE GPU doing rank 0's work of a P-GPU job, every collective a no-op of the right
+                                              size: ms_per_step = the rank's compute time,
+                                              config.communication.collectives_per_step_and_rank = what it would have sent)
 Output: a markdown table on stdout (committed as profiles/r4/r4_scale_model.md, quoted in DESIGN.md section 7).
 
 The alpha-beta model of a collective over the xGMI mesh of one MI355X node (every GPU has a direct link to each of the 7
@@ -47,46 +47,52 @@ def load(path):
 
 
 def main(d):
-    p1 = load(os.path.join(d, 'bench_p1.json'))
-    t1 = p1['ms_per_step'] * 1e-3
-    e1 = p1['config']['edges_per_step_kernel']
-    rows = []
-    for f in sorted(glob.glob(os.path.join(d, 'emu_*_p*.json'))):
-        m = re.match(r'emu_(weak|strong)_(seed|shard)_p(\d+)(_r\d+)?\.json', os.path.basename(f))
-        j = load(f)
-        if not m or j is None or m.group(4):
-            continue
-        scaling, par, P = m.group(1), m.group(2), int(m.group(3))
-        comp = j['ms_per_step'] * 1e-3
-        coll = j['config']['communication']['collectives_per_step_and_rank']
-        pred = {}
-        for algo in ('direct', 'ring'):
-            exposed = 0.0
-            for name, v in coll.items():
-                calls = max(1, round(v['calls_per_step']))
-                per_call = v['bytes_per_step'] / v['calls_per_step']
-                t = calls * t_collective(name, per_call, P, algo)
-                if par == 'seed' and 'under the MLPs' in name:
-                    t = max(0.0, t - SECOND_HALF_S)                  # hidden under graph B
-                elif par == 'shard':
-                    t += calls * CUT_S
-                exposed += t
-            pred[algo] = comp + exposed
-        rows.append((scaling, par, P, comp, coll, pred))
-    print('| scaling | parallelism | P | rank compute (measured, ms) | bytes handed to collectives per step and rank (MB) | '
+    lines = [(f, load(f)) for f in sorted(glob.glob(os.path.join(d, '*.json')))]
+    lines = [(f, j) for f, j in lines if j is not None]
+    mode_of = lambda j: 'full' if 'SynthKG-full' in j['config']['workload'] else 'fast'
+    base = {mode_of(j): j for f, j in lines if j['config'].get('emulated_rank') is None and j['n_gpus'] == 1
+            and j['config']['communication']['world_size'] == 1}
+    print('| feature widths | scaling | parallelism | P | rank compute (measured, ms) | bytes handed to collectives per step and rank (MB) | '
           'predicted step, direct / ring (ms) | predicted speed-up over 1 GPU, direct / ring |')
-    print('|---|---|---|---|---|---|---|')
-    print(f'| - | single GPU | 1 | {t1 * 1e3:.3f} | - | {t1 * 1e3:.3f} | 1.00 |')
-    for scaling, par, P, comp, coll, pred in rows:
-        mb = sum(v['bytes_per_step'] / v['calls_per_step'] * max(1, round(v['calls_per_step'])) for v in coll.values()) / 1e6
-        # weak: P batches of 512 seeds per step (edges/s = P x per-rank rate); strong: one 512-seed batch per step
-        sp = [(P * t1 / pred[a]) if scaling == 'weak' else (t1 / pred[a]) for a in ('direct', 'ring')]
-        print(f'| {scaling} | {par} | {P} | {comp * 1e3:.3f} | {mb:.1f} | {pred["direct"] * 1e3:.3f} / {pred["ring"] * 1e3:.3f} | '
-              f'{sp[0]:.2f} / {sp[1]:.2f} |')
+    print('|---|---|---|---|---|---|---|---|')
+    for mode, p1 in sorted(base.items()):
+        t1 = p1['ms_per_step'] * 1e-3
+        print(f'| {mode} | - | single GPU | 1 | {t1 * 1e3:.3f} | - | {t1 * 1e3:.3f} | 1.00 |')
+        rows = []
+        for f, j in lines:
+            er = j['config'].get('emulated_rank')
+            if er is None or er['rank'] != 0 or mode_of(j) != mode:
+                continue
+            P = er['world']
+            scaling = j['scaling']
+            par = 'shard' if j['config']['parallelism'].startswith('snp-shard') else 'seed'
+            comp = j['ms_per_step'] * 1e-3
+            coll = j['config']['communication']['collectives_per_step_and_rank']
+            pred = {}
+            for algo in ('direct', 'ring'):
+                exposed = 0.0
+                for name, v in coll.items():
+                    calls = max(1, round(v['calls_per_step']))
+                    per_call = v['bytes_per_step'] / v['calls_per_step']
+                    t = calls * t_collective(name, per_call, P, algo)
+                    if par == 'seed' and 'under the MLPs' in name:
+                        t = max(0.0, t - SECOND_HALF_S)                  # hidden under graph B
+                    elif par == 'shard':
+                        t += calls * CUT_S
+                    exposed += t
+                pred[algo] = comp + exposed
+            split = any('first gene layer' in k for k in coll)
+            rows.append((scaling != 'weak', par, P, split, comp, coll, pred, scaling))
+        for _, par, P, split, comp, coll, pred, scaling in sorted(rows, key=lambda r: r[:4]):
+            mb = sum(v['bytes_per_step'] / v['calls_per_step'] * max(1, round(v['calls_per_step'])) for v in coll.values()) / 1e6
+            # weak: P batches of 512 seeds per step (edges/s = P x per-rank rate); strong: one 512-seed batch per step
+            sp = [(P * t1 / pred[a]) if scaling == 'weak' else (t1 / pred[a]) for a in ('direct', 'ring')]
+            print(f'| {mode} | {scaling} | {par}{" + gene layer split" if split else ""} | {P} | {comp * 1e3:.3f} | {mb:.1f} | '
+                  f'{pred["direct"] * 1e3:.3f} / {pred["ring"] * 1e3:.3f} | {sp[0]:.2f} / {sp[1]:.2f} |')
     print()
-    print(f'P = 1: {t1 * 1e3:.3f} ms per step, {e1:.0f} edges aggregated per step ({e1 / t1 / 1e6:.0f} M edges/s).  '
-          'Speed-up: weak = P x 512 seeds per step against 512 (whole-job edges/s, what `python bench.py --gpus P` reports by '
-          'default); strong = steps per second on ONE 512-seed batch per step (what KGWAS.train does).')
+    print('Speed-up: weak = P x 512 seeds per step against 512 (whole-job edges/s, what `python bench.py --gpus P` reports by default); '
+          'strong = steps per second on ONE 512-seed batch per step (what KGWAS.train does).  "single GPU" rows: the plain step of '
+          'that box (`python bench.py`).')
 
 
 if __name__ == '__main__':
