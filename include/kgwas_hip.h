@@ -423,6 +423,28 @@ int kgw_linear_splitk_ind(const float* X, int64_t ldx, const float* W, int64_t l
                           float* workspace, int64_t workspace_floats, const int32_t* rows_dev, kgw_stream_t stream);
 int kgw_ind_colsum(const float* seg_stat, const float* dY, int64_t ldy, int64_t rows, int32_t R, float* dgamma,
                    kgw_stream_t stream);
+/* One product of kgw_linear_splitk_multi / one sum of kgw_ind_colsum_multi: the arguments above as a record.  A layer has one
+ * transform per DESTINATION TYPE (kgwas/model.py:74: HeteroConv sums the relations into each type) -- genes and seed SNPs in
+ * layer 1 of a 512-seed batch -- and each of them is a problem of a few hundred rows that leaves most of the chip idle: all of
+ * a layer's forward transforms go in ONE launch, all its dZ twins in one, all its d gamma sums in one.                        */
+typedef struct KgwSplitKJob {
+    const float* X; int64_t ldx;
+    const float* W; int64_t ldw;
+    const float* bias;            /* nullable */
+    float* Y; int64_t ldy;
+    int64_t rows;
+    const float* seg_stat;        /* forward with a per-segment constant (kgw_linear_splitk_ind), else NULL; for
+                                     kgw_ind_colsum_multi: the segment statistics (required)                       */
+    const float* gamma;           /* with seg_stat (forward); kgw_ind_colsum_multi: unused                       */
+    float* dgamma;                /* kgw_ind_colsum_multi: output [K / 128][128]; X / W / bias / gamma unused, Y = dY */
+    int32_t K, N, relu, w_is_kn;
+} KgwSplitKJob;
+/* Up to 4 products in one launch.  Every job must be of the SAME kind: either the forward transform (K > 128 a multiple of
+ * 128, N == 128, w_is_kn = 1: what kgw_linear_splitk / _ind run as ONE launch) or the dZ twin (K == 128, N a multiple of 128,
+ * no seg_stat); anything else: KGW_E_UNSUPPORTED (use the single-product calls).                                           */
+int kgw_linear_splitk_multi(int32_t n_jobs, const KgwSplitKJob* jobs, kgw_stream_t stream);
+/* dgamma of up to 4 transforms in one launch (job: seg_stat, Y = dY, ldy, rows, K = R * 128, dgamma).                        */
+int kgw_ind_colsum_multi(int32_t n_jobs, const KgwSplitKJob* jobs, kgw_stream_t stream);
 
 /* One Adam step (torch.optim.Adam semantics, weight_decay as L2: kgwas/kgwas.py:116,151) over up to 64
  * parameter tensors in a single launch.  The pointer arrays are HOST arrays of device pointers (passed to the

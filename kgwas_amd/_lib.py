@@ -109,6 +109,12 @@ class KgwTnJob(C.Structure):
                 ('M', C.c_int32), ('N', C.c_int32), ('c_transposed', C.c_int32), ('colsum_repeat', C.c_int32)]
 
 
+class KgwSplitKJob(C.Structure):
+    _fields_ = [('X', C.c_void_p), ('ldx', C.c_int64), ('W', C.c_void_p), ('ldw', C.c_int64), ('bias', C.c_void_p),
+                ('Y', C.c_void_p), ('ldy', C.c_int64), ('rows', C.c_int64), ('seg_stat', C.c_void_p), ('gamma', C.c_void_p),
+                ('dgamma', C.c_void_p), ('K', C.c_int32), ('N', C.c_int32), ('relu', C.c_int32), ('w_is_kn', C.c_int32)]
+
+
 class KgwFoldArgs(C.Structure):
     _fields_ = [('n', C.c_int32), ('n_rels', C.c_int32), ('n_mlp', C.c_int32), ('pad_', C.c_int32),
                 ('rel_ids_host', C.c_void_p), ('src_mlp_host', C.c_void_p), ('dst_mlp_host', C.c_void_p),
@@ -121,7 +127,7 @@ class KgwFoldArgs(C.Structure):
 
 
 EXPORTS = ['kgw_version', 'kgw_status_string', 'kgw_struct_sizes', 'kgw_sample_batch', 'kgw_sample_batch_parts', 'kgw_sampler_scan_ints',
-           'kgw_softmax_pack', 'kgw_softmax_merge', 'kgw_scatter_rows', 'kgw_linear_splitk', 'kgw_linear_splitk_workspace_floats', 'kgw_linear_splitk_ind', 'kgw_ind_colsum', 'kgw_fold_fwd', 'kgw_fold_bwd', 'kgw_relation_sums',
+           'kgw_softmax_pack', 'kgw_softmax_merge', 'kgw_scatter_rows', 'kgw_linear_splitk', 'kgw_linear_splitk_workspace_floats', 'kgw_linear_splitk_ind', 'kgw_ind_colsum', 'kgw_linear_splitk_multi', 'kgw_ind_colsum_multi', 'kgw_fold_fwd', 'kgw_fold_bwd', 'kgw_relation_sums',
            'kgw_gat_aggregate_fwd', 'kgw_gat_aggregate_bwd_dst', 'kgw_gat_aggregate_bwd_src',
            'kgw_gather_rows', 'kgw_gather_rows_multi', 'kgw_scatter_relu_rows', 'kgw_scatter_relu_rows_workspace_floats', 'kgw_edge_alpha', 'kgw_debug_reduce', 'kgw_debug_reduce8', 'kgw_tn_gemm', 'kgw_tn_gemm_ex', 'kgw_tn_gemm_multi', 'kgw_tn_gemm_workspace_floats',
            'kgw_linear', 'kgw_mlp2_fwd', 'kgw_mlp2w_fwd', 'kgw_mlp2_bwd_first', 'kgw_mlp2_bwd_first_workspace_floats', 'kgw_gemm3', 'kgw_gemm3_pack', 'kgw_gemm3_packed_bytes', 'kgw_gemm3_workspace_floats', 'kgw_adam', 'kgw_adam_notick', 'kgw_relvec_fwd', 'kgw_relvec_bwd', 'kgw_relvec_bwd_acc', 'kgw_wmse_fwd', 'kgw_wmse_bwd', 'kgw_readout_wmse_fwd', 'kgw_readout_wmse_bwd', 'kgw_readout_wmse_train', 'kgw_accumulate_stats', 'kgw_accumulate_stats_tick', 'kgw_delay']
@@ -203,6 +209,8 @@ def lib():
     L.kgw_linear_splitk_ind.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                         C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.kgw_ind_colsum.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+    L.kgw_linear_splitk_multi.argtypes = [C.c_int32, C.POINTER(KgwSplitKJob), C.c_void_p]
+    L.kgw_ind_colsum_multi.argtypes = [C.c_int32, C.POINTER(KgwSplitKJob), C.c_void_p]
     L.kgw_relation_sums.argtypes = [C.POINTER(KgwLayerArgs), C.c_void_p, C.c_void_p, C.c_void_p]
     L.kgw_fold_fwd.argtypes = [C.POINTER(KgwFoldArgs), C.c_void_p]
     L.kgw_fold_bwd.argtypes = [C.POINTER(KgwFoldArgs), C.c_void_p]

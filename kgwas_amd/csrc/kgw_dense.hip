@@ -2109,12 +2109,24 @@ __device__ __forceinline__ int64_t sk_rows_eff(const SplitKArgs& a) {
     return r < 0 ? 0 : (r < a.rows ? r : a.rows);
 }
 
+// Up to four products of one kind per launch (kgw_linear_splitk_multi): the grid's x dimension is the concatenation of the jobs'
+// blocks; a single product is a table of one.
+constexpr int SK_MAX_JOBS = 4;
+struct SplitKJobs { SplitKArgs j[SK_MAX_JOBS]; int blk0[SK_MAX_JOBS + 1]; int n; };
+struct ColsumJobs { const float* seg_stat[SK_MAX_JOBS]; const float* dY[SK_MAX_JOBS]; float* dgamma[SK_MAX_JOBS];
+                    int64_t ldy[SK_MAX_JOBS], rows[SK_MAX_JOBS]; int R[SK_MAX_JOBS]; int blk0[SK_MAX_JOBS + 1]; int n; };
+
 template <bool WKN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_linear_splitk(SplitKArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_linear_splitk(SplitKJobs J) {
     __shared__ __attribute__((aligned(16))) float Xs[2][32 * SK_LD];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lk = lane >> 5, w = tid >> 6;
+    int jq = 0;
+    while (jq + 1 < J.n && (int)blockIdx.x >= J.blk0[jq + 1]) ++jq;
+    const SplitKArgs& a = J.j[jq];
     const bool ksplit = a.KS > 1;
-    const int slab = blockIdx.x, g = blockIdx.y;
+    const int nslab_ = ksplit ? a.KS : a.NS;
+    const int bx = (int)blockIdx.x - J.blk0[jq];
+    const int slab = bx % nslab_, g = bx / nslab_;
     const int64_t rows_eff = sk_rows_eff(a);
     const int kx0 = ksplit ? slab * 128 : 0;           // first K column of the X tiles
     const int n0 = (ksplit ? 0 : slab * 128) + 32 * w; // first output column of this wavefront
@@ -2209,10 +2221,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 // reads of the MFMA layout; no block barrier: a wavefront's LDS operations execute in order), the weights come straight
 // from global memory (coalesced) -- and the eight accumulators are added through LDS in wavefront order, with bias, the
 // per-segment constants of a folded FC_output and ReLU applied on the way out.  No partial buffer, no second launch.
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_linear_splitk_fused(SplitKArgs a) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_linear_splitk_fused(SplitKJobs J) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lk = lane >> 5, w = tid >> 6;
-    const int rt = blockIdx.x % a.RT, cb = blockIdx.x / a.RT;
+    int jq = 0;
+    while (jq + 1 < J.n && (int)blockIdx.x >= J.blk0[jq + 1]) ++jq;
+    const SplitKArgs& a = J.j[jq];
+    const int bx = (int)blockIdx.x - J.blk0[jq];
+    const int rt = bx % a.RT, cb = bx / a.RT;
     const int64_t rows_eff = sk_rows_eff(a);
     const int64_t r0 = (int64_t)rt * 32;
     float* my = lds + w * (32 * SK_LD);
@@ -2317,12 +2333,19 @@ extern "C" int64_t kgw_linear_splitk_workspace_floats(int64_t rows, int32_t K, i
 }
 
 namespace {
-__global__ void __launch_bounds__(1024) k_ind_colsum(const float* __restrict__ seg_stat, const float* __restrict__ dY, int64_t ldy,
-                                                     int64_t rows, int R, float* __restrict__ dgamma) {
+__global__ void __launch_bounds__(1024) k_ind_colsum(ColsumJobs J) {
     // block = (relation slot r, group of 32 columns); thread = (row phase 0..31, column): rows ph, ph + 32, ... added in
     // order, four independent loads in flight per thread; the phases are folded through LDS in phase order (deterministic)
     __shared__ float sm[32][32];
-    const int r = blockIdx.x >> 2, c = (blockIdx.x & 3) * 32 + (threadIdx.x & 31), ph = threadIdx.x >> 5;
+    int jq = 0;
+    while (jq + 1 < J.n && (int)blockIdx.x >= J.blk0[jq + 1]) ++jq;
+    const float* __restrict__ seg_stat = J.seg_stat[jq];
+    const float* __restrict__ dY = J.dY[jq];
+    float* __restrict__ dgamma = J.dgamma[jq];
+    const int64_t ldy = J.ldy[jq], rows = J.rows[jq];
+    const int R = J.R[jq];
+    const int bx = (int)blockIdx.x - J.blk0[jq];
+    const int r = bx >> 2, c = (bx & 3) * 32 + (threadIdx.x & 31), ph = threadIdx.x >> 5;
     float s = 0.f;
     int64_t i = ph;
     for (; i + 96 < rows; i += 128) {
@@ -2349,14 +2372,32 @@ int splitk_launch(const float* X, int64_t ldx, const float* W, int64_t ldw, cons
                   const int32_t* rows_dev, const float* seg_stat, const float* gamma, kgw_stream_t stream_);
 }  // namespace
 
+extern "C" int kgw_ind_colsum_multi(int32_t n_jobs, const KgwSplitKJob* jobs, kgw_stream_t stream_) {
+    if (n_jobs <= 0) return KGW_OK;
+    if (!jobs) return KGW_E_NULL;
+    if (n_jobs > SK_MAX_JOBS) return KGW_E_RANGE;
+    ColsumJobs J{};
+    int blk = 0;
+    for (int q = 0; q < n_jobs; ++q) {
+        const KgwSplitKJob& D = jobs[q];
+        if (!D.seg_stat || !D.Y || !D.dgamma) return KGW_E_NULL;
+        if (D.rows < 0 || D.K <= 0 || (D.K & 127)) return KGW_E_RANGE;
+        J.seg_stat[q] = D.seg_stat; J.dY[q] = D.Y; J.dgamma[q] = D.dgamma; J.ldy[q] = D.ldy; J.rows[q] = D.rows; J.R[q] = D.K / 128;
+        J.blk0[q] = blk;
+        blk += 4 * (D.K / 128);
+    }
+    J.blk0[n_jobs] = blk; J.n = n_jobs;
+    k_ind_colsum<<<blk, 1024, 0, (hipStream_t)stream_>>>(J);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
 extern "C" int kgw_ind_colsum(const float* seg_stat, const float* dY, int64_t ldy, int64_t rows, int32_t R, float* dgamma,
                               kgw_stream_t stream_) {
     if (R <= 0) return KGW_OK;
-    if (!seg_stat || !dY || !dgamma) return KGW_E_NULL;
-    if (rows < 0) return KGW_E_RANGE;
-    k_ind_colsum<<<4 * R, 1024, 0, (hipStream_t)stream_>>>(seg_stat, dY, ldy, rows, R, dgamma);
-    KGW_LAUNCH_CHECK();
-    return KGW_OK;
+    KgwSplitKJob j{};
+    j.seg_stat = seg_stat; j.Y = const_cast<float*>(dY); j.ldy = ldy; j.rows = rows; j.K = R * 128; j.dgamma = dgamma;
+    return kgw_ind_colsum_multi(1, &j, stream_);
 }
 
 extern "C" int kgw_linear_splitk(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
@@ -2378,6 +2419,17 @@ extern "C" int kgw_linear_splitk_ind(const float* X, int64_t ldx, const float* W
 }
 
 namespace {
+int splitk_fused_launch(const SplitKJobs& J, hipStream_t st) {
+    const size_t lds_bytes = (size_t)8 * 32 * SK_LD * sizeof(float);
+    static KgwPerDevice attr_once;
+    if (attr_once.need()) {
+        KGW_HIP(hipFuncSetAttribute((const void*)k_linear_splitk_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    }
+    k_linear_splitk_fused<<<J.blk0[J.n], 512, lds_bytes, st>>>(J);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
 int splitk_launch(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy, int64_t rows,
                   int32_t K, int32_t N, int32_t relu, int32_t w_is_kn, float* workspace, int64_t workspace_floats,
                   const int32_t* rows_dev, const float* seg_stat, const float* gamma, kgw_stream_t stream_) {
@@ -2392,14 +2444,9 @@ int splitk_launch(const float* X, int64_t ldx, const float* W, int64_t ldw, cons
     const int nslab = a.KS > 1 ? a.KS : a.NS;
     static const int fused = getenv("KGW_SPLITK_FUSED") ? atoi(getenv("KGW_SPLITK_FUSED")) : 1;
     if (fused && a.KS > 1 && w_is_kn && N == 128) {        // forward transform: one launch
-        const size_t lds_bytes = (size_t)8 * 32 * SK_LD * sizeof(float);
-        static KgwPerDevice attr_once;
-        if (attr_once.need()) {
-            KGW_HIP(hipFuncSetAttribute((const void*)k_linear_splitk_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        }
-        k_linear_splitk_fused<<<a.RT * 4, 512, lds_bytes, (hipStream_t)stream_>>>(a);
-        KGW_LAUNCH_CHECK();
-        return KGW_OK;
+        SplitKJobs J{};
+        J.j[0] = a; J.n = 1; J.blk0[0] = 0; J.blk0[1] = a.RT * 4;
+        return splitk_fused_launch(J, (hipStream_t)stream_);
     }
     if (a.KS > 1 && (!workspace || workspace_floats < kgw_linear_splitk_workspace_floats(rows, K, N))) return KGW_E_NULL;
     // row-tile groups per slab: about two blocks per CU in total, at most one tile... at least one tile per block
@@ -2409,9 +2456,10 @@ int splitk_launch(const float* X, int64_t ldx, const float* W, int64_t ldw, cons
     if (G < 1) G = 1;
     a.G = G;
     hipStream_t st = (hipStream_t)stream_;
-    dim3 grid((unsigned)nslab, (unsigned)G);
-    if (w_is_kn) k_linear_splitk<true><<<grid, 256, 0, st>>>(a);
-    else k_linear_splitk<false><<<grid, 256, 0, st>>>(a);
+    SplitKJobs J{};
+    J.j[0] = a; J.n = 1; J.blk0[0] = 0; J.blk0[1] = nslab * G;
+    if (w_is_kn) k_linear_splitk<true><<<nslab * G, 256, 0, st>>>(J);
+    else k_linear_splitk<false><<<nslab * G, 256, 0, st>>>(J);
     KGW_LAUNCH_CHECK();
     if (a.KS > 1 || rows_dev) {
         int64_t g = (rows * (N / 4) + 255) / 256;
@@ -2422,6 +2470,50 @@ int splitk_launch(const float* X, int64_t ldx, const float* W, int64_t ldw, cons
     return KGW_OK;
 }
 }  // namespace
+
+extern "C" int kgw_linear_splitk_multi(int32_t n_jobs, const KgwSplitKJob* jobs, kgw_stream_t stream_) {
+    if (n_jobs <= 0) return KGW_OK;
+    if (!jobs) return KGW_E_NULL;
+    if (n_jobs > SK_MAX_JOBS) return KGW_E_RANGE;
+    SplitKJobs J{};
+    int blk = 0, kind = -1, n = 0;                       // kind 0: forward transform (fused kernel); 1: dZ twin (K == 128)
+    for (int q = 0; q < n_jobs; ++q) {
+        const KgwSplitKJob& D = jobs[q];
+        if (D.rows == 0) continue;
+        if (!D.X || !D.W || !D.Y) return KGW_E_NULL;
+        if (D.rows < 0 || D.K <= 0 || D.N <= 0) return KGW_E_RANGE;
+        if ((D.K & 127) || (D.N & 127) || (D.ldx & 3) || (D.ldw & 3) || (D.ldy & 3) || !aligned16(D.X) || !aligned16(D.W) ||
+            !aligned16(D.Y) || (D.bias && !aligned16(D.bias)) || (D.gamma && !aligned16(D.gamma)))
+            return KGW_E_UNSUPPORTED;
+        const int k = (D.K > 128 && D.N == 128 && D.w_is_kn) ? 0 : ((D.K == 128 && !D.seg_stat) ? 1 : -1);
+        if (k < 0 || (kind >= 0 && k != kind) || (n > 0 && (D.w_is_kn != 0) != (J.j[0].w_kn != 0))) return KGW_E_UNSUPPORTED;
+        if (D.seg_stat && !D.gamma) return KGW_E_NULL;
+        kind = k;
+        SplitKArgs a{D.X, D.ldx, D.W, D.ldw, D.bias, D.Y, D.ldy, nullptr, D.rows, D.K, D.N, D.relu, D.w_is_kn,
+                     (int)((D.rows + 31) / 32), D.K / 128, D.N / 128, 1, nullptr, D.seg_stat, D.gamma};
+        J.blk0[n] = blk;
+        if (k == 0) {
+            blk += a.RT * 4;
+        } else {
+            // row-tile groups per slab: the jobs together aim at about two blocks per CU
+            static const int target = getenv("KGW_SPLITK_BLOCKS") ? atoi(getenv("KGW_SPLITK_BLOCKS")) : 512;
+            int G = (target + a.NS - 1) / a.NS;
+            if (G > a.RT) G = a.RT;
+            if (G < 1) G = 1;
+            a.G = G;
+            blk += a.NS * G;
+        }
+        J.j[n++] = a;
+    }
+    if (n == 0) return KGW_OK;
+    J.blk0[n] = blk; J.n = n;
+    hipStream_t st = (hipStream_t)stream_;
+    if (kind == 0) return splitk_fused_launch(J, st);
+    if (J.j[0].w_kn) k_linear_splitk<true><<<blk, 256, 0, st>>>(J);
+    else k_linear_splitk<false><<<blk, 256, 0, st>>>(J);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
 
 // ======================================================================================================
 // kgw_scatter_relu_rows: backward of "rows ids of relu(X W^T + b) computed on a RESIDENT matrix" (the 5120-wide gene

@@ -1365,6 +1365,38 @@ def rel_vectors(pack, blocks=None, zero=None, pass_weights=False):
     return _RelVectors.apply(pack.w_src_t, pack.w_dst_t, pack.att_src, pack.att_dst, pack, tab, len(blocks), zero, pass_weights)
 
 
+_MULTI_TRANSFORM = os.environ.get('KGW_MULTI_TRANSFORM', '1') != '0'     # (A/B: one launch per destination type as before)
+
+
+def _transform_multi_forward(w_src_t, Z, blocks, bsum, out_blocks, gamma, stat, C):
+    """All forward transforms of a layer through ONE kgw_linear_splitk_multi launch, or None when the layer does not qualify
+    (a single destination type, a single relation into one, an unaligned operand, too many rows for the few-rows kernel)."""
+    live = [(k, b) for k, b in enumerate(blocks) if b[3] > 0]
+    if not _MULTI_TRANSFORM or len(live) < 2 or len(live) > 4 or len(live) != len(blocks):
+        return None
+    if any((hi - lo) < 2 or rows >= _SPLITK_MAX_ROWS for _, (lo, hi, z0, rows) in live):
+        return None
+    if Z.dtype != torch.float32 or Z.data_ptr() % 16 or w_src_t.data_ptr() % 16 or bsum.data_ptr() % 16 or (gamma is not None and stat is None):
+        return None
+    jobs = (_lib.KgwSplitKJob * len(live))()
+    outs = []
+    for j, (k, (lo, hi, z0, rows)) in zip(jobs, live):
+        R = hi - lo
+        x = Z[z0:z0 + rows * R].view(rows, R * C)
+        ob = out_blocks[k] if out_blocks is not None else None
+        y = ob.view() if ob is not None and ob.n == rows else torch.empty(rows, C, device=Z.device)
+        W = w_src_t[lo:hi].view(R * C, C)
+        if x.data_ptr() % 16 or y.data_ptr() % 16 or y.stride(0) % 4 or (gamma is not None and gamma[lo:hi].data_ptr() % 16):
+            return None
+        j.X, j.ldx, j.W, j.ldw, j.bias = x.data_ptr(), x.stride(0), W.data_ptr(), W.stride(0), bsum[k].data_ptr()
+        j.Y, j.ldy, j.rows, j.K, j.N, j.relu, j.w_is_kn = y.data_ptr(), y.stride(0), rows, R * C, C, 1, 1
+        if gamma is not None:
+            j.seg_stat, j.gamma = stat.data_ptr() + 8 * z0, gamma[lo:hi].data_ptr()
+        outs.append(y)
+    _lib.check(_lib.lib().kgw_linear_splitk_multi(len(live), jobs, _lib.stream_ptr()), 'kgw_linear_splitk_multi')
+    return outs
+
+
 class _LayerTransform(torch.autograd.Function):
     """h_d = relu([Z[:, r0] | Z[:, r1] | ...] @ [W_r0^T ; W_r1^T ; ...] + sum_r bias_r) for every destination
     type of a layer (lin_src of kgwas/conv.py:138/142 + bias :190 + HeteroConv sum model.py:74 + ReLU :75).
@@ -1375,6 +1407,15 @@ class _LayerTransform(torch.autograd.Function):
     def forward(ctx, w_src_t, bias, Z, blocks, bsum, out_blocks, premasked=False, gamma=None, stat=None):
         C = bias.shape[1]
         outs, ys = [], []
+        # every destination type's transform of the layer in ONE launch (kgw_linear_splitk_multi) when there are several and
+        # all are of the fused-forward kind: K = R * 128 > 128 rows-few problems that each leave most of the chip idle
+        multi = _transform_multi_forward(w_src_t, Z, blocks, bsum, out_blocks, gamma, stat, C)
+        if multi is not None:
+            ctx.save_for_backward(w_src_t, Z, gamma, stat, *multi)
+            ctx.blocks = blocks
+            ctx.n_bias = bias.shape[0]
+            ctx.premasked = premasked
+            return tuple(multi)
         # bsum [n blocks, C]: bias of every relation into a type, summed (rel_vectors computes it in its launch)
         for k, (lo, hi, z0, rows) in enumerate(blocks):
             R = hi - lo
@@ -1437,6 +1478,26 @@ class _LayerTransform(torch.autograd.Function):
         if not _tn_gemm_group([(dz, x, dW[lo:hi].view(R * C, C), db[lo:hi]) for lo, hi, z0, rows, R, x, dz in live_blocks]):
             for lo, hi, z0, rows, R, x, dz in live_blocks:
                 tn_gemm(dz, x, out=dW[lo:hi].view(R * C, C), transpose_out=True, colsum_out=db[lo:hi])
+        if len(live_blocks) > 1 and len(live_blocks) <= 4 and _MULTI_TRANSFORM:
+            # the dZ twins of all destination types in one launch, the d gamma sums in another
+            L = _lib.lib()
+            if need_dz and all(0 < rows < _SPLITK_MAX_ROWS and dz.stride(1) == 1 and dz.stride(0) % 4 == 0 and dz.data_ptr() % 16 == 0
+                               for lo, hi, z0, rows, R, x, dz in live_blocks):
+                jobs = (_lib.KgwSplitKJob * len(live_blocks))()
+                for j, (lo, hi, z0, rows, R, x, dz) in zip(jobs, live_blocks):
+                    W = w_src_t[lo:hi].view(R * C, C)
+                    y = dZ[z0:z0 + rows * R].view(rows, R * C)
+                    j.X, j.ldx, j.W, j.ldw, j.bias = dz.data_ptr(), dz.stride(0), W.data_ptr(), W.stride(0), None
+                    j.Y, j.ldy, j.rows, j.K, j.N, j.relu, j.w_is_kn = y.data_ptr(), y.stride(0), rows, C, R * C, 0, 0
+                _lib.check(L.kgw_linear_splitk_multi(len(live_blocks), jobs, _lib.stream_ptr()), 'kgw_linear_splitk_multi')
+                need_dz = False
+            if gamma is not None:
+                jobs = (_lib.KgwSplitKJob * len(live_blocks))()
+                for j, (lo, hi, z0, rows, R, x, dz) in zip(jobs, live_blocks):
+                    j.seg_stat, j.Y, j.ldy, j.rows, j.K = stat.data_ptr() + 8 * z0, dz.data_ptr(), dz.stride(0), rows, R * C
+                    j.dgamma = dgamma[lo:hi].data_ptr()
+                _lib.check(L.kgw_ind_colsum_multi(len(live_blocks), jobs, _lib.stream_ptr()), 'kgw_ind_colsum_multi')
+                gamma = None
         for lo, hi, z0, rows, R, x, dz in live_blocks:
             if need_dz:
                 linear(dz, w_src_t[lo:hi].view(R * C, C), out=dZ[z0:z0 + rows * R].view(rows, R * C))

@@ -402,3 +402,62 @@ def test_fused_wide_gathered_mlp_matches_unfused():
     (yb * G * (yb > 0)).sum().backward()
     for a, t, nm in zip(ga, (W1, b1, W2, b2), 'W1 b1 W2 b2'.split()):
         assert_close(a, t.grad, 1e-4, 1e-6, 'grad ' + nm, rel_to_max=1e-5)
+
+
+def test_layer_transforms_of_all_destination_types_in_one_launch():
+    """kgw_linear_splitk_multi / kgw_ind_colsum_multi (round 4): the forward transforms of a layer's destination types (genes
+    [1171, 17 x 128], seed SNPs [512, 6 x 128] at the benchmark's shapes; a third, ragged one), their dZ twins and their d gamma
+    sums, each group in ONE launch -- bit for bit what the per-type launches give (the per-element arithmetic is the same code),
+    and the whole autograd node (ops.layer_transform) equal with the switch on and off."""
+    import ctypes as C
+    from kgwas_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(4)
+    shapes = [(1171, 17), (512, 6), (77, 3)]
+    Xs = [torch.randn(r, R * 128, generator=g).cuda() for r, R in shapes]
+    Ws = [(torch.randn(R * 128, 128, generator=g) * 0.05).cuda() for r, R in shapes]
+    bs = [torch.randn(128, generator=g).cuda() for _ in shapes]
+    gam = [torch.randn(R, 128, generator=g).cuda() for r, R in shapes]
+    stat = [torch.stack([torch.randn(r * R, generator=g), (torch.rand(r * R, generator=g) > 0.3).float()], 1).cuda() for r, R in shapes]
+    st = _lib.stream_ptr()
+    # forward with the per-segment constant: multi vs kgw_linear_splitk_ind per job
+    Ym = [torch.empty(r, 128, device='cuda') for r, R in shapes]
+    jobs = (_lib.KgwSplitKJob * 3)()
+    for j, X, W, b, y, gm, s_, (r, R) in zip(jobs, Xs, Ws, bs, Ym, gam, stat, shapes):
+        j.X, j.ldx, j.W, j.ldw, j.bias, j.Y, j.ldy, j.rows = X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0), b.data_ptr(), y.data_ptr(), 128, r
+        j.K, j.N, j.relu, j.w_is_kn, j.seg_stat, j.gamma = R * 128, 128, 1, 1, s_.data_ptr(), gm.data_ptr()
+    _lib.check(L.kgw_linear_splitk_multi(3, jobs, st), 'multi')
+    for X, W, b, y, gm, s_, (r, R) in zip(Xs, Ws, bs, Ym, gam, stat, shapes):
+        y1 = torch.empty(r, 128, device='cuda')
+        _lib.check(L.kgw_linear_splitk_ind(X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0), b.data_ptr(), y1.data_ptr(), 128, r, R * 128, 1,
+                                           s_.data_ptr(), gm.data_ptr(), None, 0, None, st), 'single')
+        assert torch.equal(y, y1)
+        ref = (X.double() @ W.double() + b.double() + ((s_[:, 1] > 0).double().view(r, R, 1) * gm.double().view(1, R, 128)).sum(1)).relu()
+        assert_close(y, ref, 1e-5, 1e-5, 'multi transform vs fp64', rel_to_max=2e-6)
+    # dZ twins: [rows, 128] x [128, R * 128] with W as [N, K]
+    dys = [torch.randn(r, 128, generator=g).cuda() for r, R in shapes]
+    dZm = [torch.empty(r, R * 128, device='cuda') for r, R in shapes]
+    jobs = (_lib.KgwSplitKJob * 3)()
+    for j, dy, W, dz, (r, R) in zip(jobs, dys, Ws, dZm, shapes):
+        j.X, j.ldx, j.W, j.ldw, j.bias, j.Y, j.ldy, j.rows = dy.data_ptr(), 128, W.data_ptr(), W.stride(0), None, dz.data_ptr(), dz.stride(0), r
+        j.K, j.N, j.relu, j.w_is_kn = 128, R * 128, 0, 0
+    _lib.check(L.kgw_linear_splitk_multi(3, jobs, st), 'multi twin')
+    for dy, W, dz in zip(dys, Ws, dZm):
+        assert torch.equal(dz, ops.linear(dy, W))
+    # d gamma sums
+    dgm = [torch.empty(R, 128, device='cuda') for r, R in shapes]
+    jobs = (_lib.KgwSplitKJob * 3)()
+    for j, dy, s_, dg, (r, R) in zip(jobs, dys, stat, dgm, shapes):
+        j.seg_stat, j.Y, j.ldy, j.rows, j.K, j.dgamma = s_.data_ptr(), dy.data_ptr(), 128, r, R * 128, dg.data_ptr()
+    _lib.check(L.kgw_ind_colsum_multi(3, jobs, st), 'multi colsum')
+    for dy, s_, dg, (r, R) in zip(dys, stat, dgm, shapes):
+        d1 = torch.empty(R, 128, device='cuda')
+        _lib.check(L.kgw_ind_colsum(s_.data_ptr(), dy.data_ptr(), 128, r, R, d1.data_ptr(), st), 'single colsum')
+        assert torch.equal(dg, d1)
+    # mixed kinds, too many jobs: refused before any launch
+    jobs = (_lib.KgwSplitKJob * 2)()
+    for j, X, W, y, (r, R) in zip(jobs, Xs, Ws, Ym, shapes):
+        j.X, j.ldx, j.W, j.ldw, j.Y, j.ldy, j.rows, j.K, j.N, j.w_is_kn = X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0), y.data_ptr(), 128, r, R * 128, 128, 1
+    jobs[1].K, jobs[1].N, jobs[1].w_is_kn = 128, 768, 0
+    assert L.kgw_linear_splitk_multi(2, jobs, st) == -3
+    assert L.kgw_linear_splitk_multi(5, jobs, st) == -2
