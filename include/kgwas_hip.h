@@ -476,6 +476,23 @@ int kgw_relvec_bwd(int32_t n_live, const int32_t* rel_ids, const int32_t* bip_po
                    const float* w_dst_t, const float* att_src, const float* att_dst, const float* dU_full,
                    const float* dV, float* dw_src_t, float* dw_dst_t, float* datt_src, float* datt_dst,
                    int32_t v_by_rel, kgw_stream_t stream);
+/* The relation vectors of SEVERAL layers in one launch (and their backward in one): they depend on the parameters only, a
+ * model has one pack per layer (kgwas/model.py:47: one HeteroConv per layer), and each launch is ~30 blocks of latency.  A job =
+ * the arguments of kgw_relvec_fwd (v_by_rel = 1) / kgw_relvec_bwd_acc as a record; the forward reads the first group of fields,
+ * the backward the second.  Up to KGW_MAX_LAYERS jobs.                                                                  */
+typedef struct KgwRelvecJob {
+    int32_t n_rels_total, n_live, n_blk, pad_;
+    const int32_t* live_of_rel; const int32_t* rel_ids; const int32_t* bip_pos;
+    const float* w_src_t; const float* w_dst_t; const float* att_src; const float* att_dst;
+    /* forward */
+    float* U_full; float* V; const float* bias; const int32_t* blk_of_live; float* bias_sum;
+    float* zero_buf; int64_t zero_floats;
+    /* backward (dU_full / dV / dw_src_acc nullable = zero) */
+    const float* dU_full; const float* dV; const float* dw_src_acc;
+    float* dw_src_t; float* dw_dst_t; float* datt_src; float* datt_dst;
+} KgwRelvecJob;
+int kgw_relvec_fwd_multi(int32_t n_jobs, const KgwRelvecJob* jobs, kgw_stream_t stream);
+int kgw_relvec_bwd_multi(int32_t n_jobs, const KgwRelvecJob* jobs, kgw_stream_t stream);
 /* _bwd_acc: the same with (a) dw_src_acc (nullable): a gradient of w_src_t that reached the caller by another path -- the
  * layer's transform GEMM (conv.py:138-144) or the FC_output fold use the same weights -- and is added into dw_src_t here
  * instead of by a separate launch; (b) dU_full / dV nullable = zero.                                              */

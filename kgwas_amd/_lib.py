@@ -115,6 +115,16 @@ class KgwSplitKJob(C.Structure):
                 ('dgamma', C.c_void_p), ('K', C.c_int32), ('N', C.c_int32), ('relu', C.c_int32), ('w_is_kn', C.c_int32)]
 
 
+class KgwRelvecJob(C.Structure):
+    _fields_ = [('n_rels_total', C.c_int32), ('n_live', C.c_int32), ('n_blk', C.c_int32), ('pad_', C.c_int32),
+                ('live_of_rel', C.c_void_p), ('rel_ids', C.c_void_p), ('bip_pos', C.c_void_p),
+                ('w_src_t', C.c_void_p), ('w_dst_t', C.c_void_p), ('att_src', C.c_void_p), ('att_dst', C.c_void_p),
+                ('U_full', C.c_void_p), ('V', C.c_void_p), ('bias', C.c_void_p), ('blk_of_live', C.c_void_p), ('bias_sum', C.c_void_p),
+                ('zero_buf', C.c_void_p), ('zero_floats', C.c_int64),
+                ('dU_full', C.c_void_p), ('dV', C.c_void_p), ('dw_src_acc', C.c_void_p),
+                ('dw_src_t', C.c_void_p), ('dw_dst_t', C.c_void_p), ('datt_src', C.c_void_p), ('datt_dst', C.c_void_p)]
+
+
 class KgwFoldArgs(C.Structure):
     _fields_ = [('n', C.c_int32), ('n_rels', C.c_int32), ('n_mlp', C.c_int32), ('pad_', C.c_int32),
                 ('rel_ids_host', C.c_void_p), ('src_mlp_host', C.c_void_p), ('dst_mlp_host', C.c_void_p),
@@ -130,7 +140,7 @@ EXPORTS = ['kgw_version', 'kgw_status_string', 'kgw_struct_sizes', 'kgw_sample_b
            'kgw_softmax_pack', 'kgw_softmax_merge', 'kgw_scatter_rows', 'kgw_linear_splitk', 'kgw_linear_splitk_workspace_floats', 'kgw_linear_splitk_ind', 'kgw_ind_colsum', 'kgw_linear_splitk_multi', 'kgw_ind_colsum_multi', 'kgw_fold_fwd', 'kgw_fold_bwd', 'kgw_relation_sums',
            'kgw_gat_aggregate_fwd', 'kgw_gat_aggregate_bwd_dst', 'kgw_gat_aggregate_bwd_src',
            'kgw_gather_rows', 'kgw_gather_rows_multi', 'kgw_scatter_relu_rows', 'kgw_scatter_relu_rows_workspace_floats', 'kgw_edge_alpha', 'kgw_debug_reduce', 'kgw_debug_reduce8', 'kgw_tn_gemm', 'kgw_tn_gemm_ex', 'kgw_tn_gemm_multi', 'kgw_tn_gemm_workspace_floats',
-           'kgw_linear', 'kgw_mlp2_fwd', 'kgw_mlp2w_fwd', 'kgw_mlp2_bwd_first', 'kgw_mlp2_bwd_first_workspace_floats', 'kgw_gemm3', 'kgw_gemm3_pack', 'kgw_gemm3_packed_bytes', 'kgw_gemm3_workspace_floats', 'kgw_adam', 'kgw_adam_notick', 'kgw_relvec_fwd', 'kgw_relvec_bwd', 'kgw_relvec_bwd_acc', 'kgw_wmse_fwd', 'kgw_wmse_bwd', 'kgw_readout_wmse_fwd', 'kgw_readout_wmse_bwd', 'kgw_readout_wmse_train', 'kgw_accumulate_stats', 'kgw_accumulate_stats_tick', 'kgw_delay']
+           'kgw_linear', 'kgw_mlp2_fwd', 'kgw_mlp2w_fwd', 'kgw_mlp2_bwd_first', 'kgw_mlp2_bwd_first_workspace_floats', 'kgw_gemm3', 'kgw_gemm3_pack', 'kgw_gemm3_packed_bytes', 'kgw_gemm3_workspace_floats', 'kgw_adam', 'kgw_adam_notick', 'kgw_relvec_fwd', 'kgw_relvec_bwd', 'kgw_relvec_bwd_acc', 'kgw_relvec_fwd_multi', 'kgw_relvec_bwd_multi', 'kgw_wmse_fwd', 'kgw_wmse_bwd', 'kgw_readout_wmse_fwd', 'kgw_readout_wmse_bwd', 'kgw_readout_wmse_train', 'kgw_accumulate_stats', 'kgw_accumulate_stats_tick', 'kgw_delay']
 
 _lib = None
 
@@ -219,6 +229,8 @@ def lib():
     L.kgw_adam_notick.argtypes = L.kgw_adam.argtypes
     L.kgw_relvec_fwd.argtypes = [C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.kgw_relvec_fwd_multi.argtypes = [C.c_int32, C.POINTER(KgwRelvecJob), C.c_void_p]
+    L.kgw_relvec_bwd_multi.argtypes = [C.c_int32, C.POINTER(KgwRelvecJob), C.c_void_p]
     L.kgw_relvec_bwd.argtypes = [C.c_int32] + [C.c_void_p] * 12 + [C.c_int32, C.c_void_p]
     L.kgw_relvec_bwd_acc.argtypes = [C.c_int32] + [C.c_void_p] * 13 + [C.c_int32, C.c_void_p]
     L.kgw_tn_gemm.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,

@@ -2994,19 +2994,44 @@ extern "C" int kgw_readout_wmse_train(const float* H, const float* w_lin, const 
 // ======================================================================================================
 namespace {
 
-__global__ void __launch_bounds__(128) k_relvec_fwd(int NR, const int32_t* __restrict__ live_of_rel,
-                                                    const int32_t* __restrict__ bip_pos, const float* __restrict__ wsT,
-                                                    const float* __restrict__ wdT, const float* __restrict__ att_src,
-                                                    const float* __restrict__ att_dst, float* __restrict__ U_full,
-                                                    float* __restrict__ V, int v_by_rel, int n_live,
-                                                    const float* __restrict__ bias, const int32_t* __restrict__ blk_of_live,
-                                                    int n_blk, float* __restrict__ bsum, int n_main,
-                                                    float* __restrict__ zero_buf, int64_t zero_f4) {
+struct RvFwdJob {
+    int NR, n_live, n_blk, n_main, blk0, nblk;
+    const int32_t* live_of_rel; const int32_t* bip_pos;
+    const float* wsT; const float* wdT; const float* att_src; const float* att_dst;
+    float* U_full; float* V; const float* bias; const int32_t* blk_of_live; float* bsum; float* zero_buf; int64_t zero_f4;
+};
+struct RvFwdJobs { RvFwdJob j[KGW_MAX_LAYERS]; int n; };
+struct RvBwdJob {
+    int blk0, v_by_rel;
+    const int32_t* rel_ids; const int32_t* bip_pos;
+    const float* wsT; const float* wdT; const float* att_src; const float* att_dst; const float* dU_full; const float* dV;
+    float* dwsT; float* dwdT; float* datt_src; float* datt_dst; const float* dws_acc;
+};
+struct RvBwdJobs { RvBwdJob j[KGW_MAX_LAYERS]; int blk_end; int n; };
+
+__global__ void __launch_bounds__(128) k_relvec_fwd(RvFwdJobs J, int v_by_rel) {
+    int jq = 0;
+    while (jq + 1 < J.n && (int)blockIdx.x >= J.j[jq + 1].blk0) ++jq;
+    const RvFwdJob& T = J.j[jq];
+    const int NR = T.NR, n_live = T.n_live, n_blk = T.n_blk, n_main = T.n_main;
+    const int32_t* __restrict__ live_of_rel = T.live_of_rel;
+    const int32_t* __restrict__ bip_pos = T.bip_pos;
+    const float* __restrict__ wsT = T.wsT;
+    const float* __restrict__ wdT = T.wdT;
+    const float* __restrict__ att_src = T.att_src;
+    const float* __restrict__ att_dst = T.att_dst;
+    float* __restrict__ U_full = T.U_full;
+    float* __restrict__ V = T.V;
+    const float* __restrict__ bias = T.bias;
+    const int32_t* __restrict__ blk_of_live = T.blk_of_live;
+    float* __restrict__ bsum = T.bsum;
+    float* __restrict__ zero_buf = T.zero_buf;
+    const int64_t zero_f4 = T.zero_f4;
     __shared__ float as[KGW_C], ad[KGW_C];
-    const int r = blockIdx.x, k = threadIdx.x;
+    const int r = (int)blockIdx.x - T.blk0, k = threadIdx.x;
     if (r >= n_main) {      // extra blocks: clear the aggregate's workspace (Z, stat, d a_dst) in this launch
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t i = (int64_t)(r - n_main) * 128 + k; i < zero_f4; i += (int64_t)(gridDim.x - n_main) * 128)
+        for (int64_t i = (int64_t)(r - n_main) * 128 + k; i < zero_f4; i += (int64_t)(T.nblk - n_main) * 128)
             ((float4*)zero_buf)[i] = z4;
         return;
     }
@@ -3053,16 +3078,27 @@ __global__ void __launch_bounds__(128) k_relvec_fwd(int NR, const int32_t* __res
 // One block per packed relation, 8 x 128 threads: thread (q, c) takes the rows k = q, q + 8, ... of the 128 x 128 weight
 // slab (16 independent iterations, loads batched eight at a time -- with one thread per column the 128 iterations of
 // dependent-latency loads made this 23-block launch take 14-38 us); the eight partial sums of d att are added in a fixed order.
-__global__ void __launch_bounds__(1024) k_relvec_bwd(const int32_t* __restrict__ rel_ids, const int32_t* __restrict__ bip_pos,
-                                                    const float* __restrict__ wsT, const float* __restrict__ wdT,
-                                                    const float* __restrict__ att_src, const float* __restrict__ att_dst,
-                                                    const float* __restrict__ dU_full, const float* __restrict__ dV,
-                                                    float* __restrict__ dwsT, float* __restrict__ dwdT,
-                                                    float* __restrict__ datt_src, float* __restrict__ datt_dst,
-                                                    int v_by_rel, const float* __restrict__ dws_acc) {
+__global__ void __launch_bounds__(1024) k_relvec_bwd(RvBwdJobs J) {
+    int jq = 0;
+    while (jq + 1 < J.n && (int)blockIdx.x >= J.j[jq + 1].blk0) ++jq;
+    const RvBwdJob& T = J.j[jq];
+    const int32_t* __restrict__ rel_ids = T.rel_ids;
+    const int32_t* __restrict__ bip_pos = T.bip_pos;
+    const float* __restrict__ wsT = T.wsT;
+    const float* __restrict__ wdT = T.wdT;
+    const float* __restrict__ att_src = T.att_src;
+    const float* __restrict__ att_dst = T.att_dst;
+    const float* __restrict__ dU_full = T.dU_full;
+    const float* __restrict__ dV = T.dV;
+    float* __restrict__ dwsT = T.dwsT;
+    float* __restrict__ dwdT = T.dwdT;
+    float* __restrict__ datt_src = T.datt_src;
+    float* __restrict__ datt_dst = T.datt_dst;
+    const float* __restrict__ dws_acc = T.dws_acc;
+    const int v_by_rel = T.v_by_rel;
     __shared__ float du[KGW_C], dv[KGW_C];
     __shared__ float ps[8][KGW_C], pd[8][KGW_C];
-    const int i = blockIdx.x, c = threadIdx.x & (KGW_C - 1), q = threadIdx.x >> 7;
+    const int i = (int)blockIdx.x - T.blk0, c = threadIdx.x & (KGW_C - 1), q = threadIdx.x >> 7;
     const int r = rel_ids[i], j = bip_pos[i];
     if (q == 0) {
         du[c] = dU_full ? dU_full[(int64_t)r * KGW_C + c] : 0.f;
@@ -3110,23 +3146,82 @@ __global__ void __launch_bounds__(1024) k_relvec_bwd(const int32_t* __restrict__
 
 }  // namespace
 
+namespace {
+int relvec_fwd_launch(int n_jobs, const KgwRelvecJob* jobs, int v_by_rel, hipStream_t st) {
+    RvFwdJobs J{};
+    int blk = 0, n = 0;
+    for (int q = 0; q < n_jobs; ++q) {
+        const KgwRelvecJob& D = jobs[q];
+        if (D.n_rels_total <= 0) continue;
+        if (!D.live_of_rel || !D.bip_pos || !D.w_src_t || !D.att_src || !D.att_dst || !D.U_full || !D.V) return KGW_E_NULL;
+        if (D.zero_buf && ((D.zero_floats & 3) || D.zero_floats < 0 || !aligned16(D.zero_buf))) return KGW_E_UNSUPPORTED;
+        const bool with_bias = D.bias && D.blk_of_live && D.bias_sum && D.n_blk > 0 && D.n_blk <= KGW_MAX_TYPES;
+        RvFwdJob& T = J.j[n++];
+        T.NR = D.n_rels_total; T.n_live = D.n_live; T.n_blk = with_bias ? D.n_blk : 0;
+        T.n_main = D.n_rels_total + (with_bias ? 1 : 0);
+        T.zero_f4 = D.zero_buf ? D.zero_floats / 4 : 0;
+        int64_t zblk = (T.zero_f4 + 128 * 8 - 1) / (128 * 8);          // ~8 float4 per thread
+        if (zblk > 2048) zblk = 2048;
+        T.blk0 = blk; T.nblk = T.n_main + (int)zblk;
+        blk += T.nblk;
+        T.live_of_rel = D.live_of_rel; T.bip_pos = D.bip_pos; T.wsT = D.w_src_t; T.wdT = D.w_dst_t; T.att_src = D.att_src;
+        T.att_dst = D.att_dst; T.U_full = D.U_full; T.V = D.V; T.bias = D.bias; T.blk_of_live = D.blk_of_live; T.bsum = D.bias_sum;
+        T.zero_buf = D.zero_buf;
+    }
+    if (n == 0) return KGW_OK;
+    J.n = n;
+    k_relvec_fwd<<<blk, 128, 0, st>>>(J, v_by_rel);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+int relvec_bwd_launch(int n_jobs, const KgwRelvecJob* jobs, int v_by_rel, hipStream_t st) {
+    RvBwdJobs J{};
+    int blk = 0, n = 0;
+    for (int q = 0; q < n_jobs; ++q) {
+        const KgwRelvecJob& D = jobs[q];
+        if (D.n_live <= 0) continue;
+        if (!D.rel_ids || !D.bip_pos || !D.w_src_t || !D.att_src || !D.att_dst || !D.dw_src_t || !D.datt_src || !D.datt_dst)
+            return KGW_E_NULL;
+        RvBwdJob& T = J.j[n++];
+        T.blk0 = blk; T.v_by_rel = v_by_rel;
+        blk += D.n_live;
+        T.rel_ids = D.rel_ids; T.bip_pos = D.bip_pos; T.wsT = D.w_src_t; T.wdT = D.w_dst_t; T.att_src = D.att_src;
+        T.att_dst = D.att_dst; T.dU_full = D.dU_full; T.dV = D.dV; T.dwsT = D.dw_src_t; T.dwdT = D.dw_dst_t;
+        T.datt_src = D.datt_src; T.datt_dst = D.datt_dst; T.dws_acc = D.dw_src_acc;
+    }
+    if (n == 0) return KGW_OK;
+    J.n = n; J.blk_end = blk;
+    k_relvec_bwd<<<blk, 1024, 0, st>>>(J);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+}  // namespace
+
+extern "C" int kgw_relvec_fwd_multi(int32_t n_jobs, const KgwRelvecJob* jobs, kgw_stream_t stream_) {
+    if (n_jobs <= 0) return KGW_OK;
+    if (!jobs) return KGW_E_NULL;
+    if (n_jobs > KGW_MAX_LAYERS) return KGW_E_RANGE;
+    return relvec_fwd_launch(n_jobs, jobs, 1, (hipStream_t)stream_);
+}
+
+extern "C" int kgw_relvec_bwd_multi(int32_t n_jobs, const KgwRelvecJob* jobs, kgw_stream_t stream_) {
+    if (n_jobs <= 0) return KGW_OK;
+    if (!jobs) return KGW_E_NULL;
+    if (n_jobs > KGW_MAX_LAYERS) return KGW_E_RANGE;
+    return relvec_bwd_launch(n_jobs, jobs, 1, (hipStream_t)stream_);
+}
+
 extern "C" int kgw_relvec_fwd(int32_t n_rels_total, const int32_t* live_of_rel, const int32_t* bip_pos, const float* w_src_t,
                               const float* w_dst_t, const float* att_src, const float* att_dst, float* U_full, float* V,
                               int32_t v_by_rel, int32_t n_live, const float* bias, const int32_t* blk_of_live,
                               int32_t n_blk, float* bias_sum, float* zero_buf, int64_t zero_floats, kgw_stream_t stream_) {
     if (n_rels_total <= 0) return KGW_OK;
-    if (!live_of_rel || !bip_pos || !w_src_t || !att_src || !att_dst || !U_full || !V) return KGW_E_NULL;
-    if (zero_buf && ((zero_floats & 3) || zero_floats < 0 || !aligned16(zero_buf))) return KGW_E_UNSUPPORTED;
-    const bool with_bias = bias && blk_of_live && bias_sum && n_blk > 0 && n_blk <= KGW_MAX_TYPES;
-    const int n_main = n_rels_total + (with_bias ? 1 : 0);
-    const int64_t zero_f4 = zero_buf ? zero_floats / 4 : 0;
-    int64_t zblk = (zero_f4 + 128 * 8 - 1) / (128 * 8);          // ~8 float4 per thread
-    if (zblk > 2048) zblk = 2048;
-    k_relvec_fwd<<<n_main + (int)zblk, 128, 0, (hipStream_t)stream_>>>(
-        n_rels_total, live_of_rel, bip_pos, w_src_t, w_dst_t, att_src, att_dst, U_full, V, v_by_rel, n_live, bias,
-        blk_of_live, n_blk, bias_sum, n_main, zero_buf, zero_f4);
-    KGW_LAUNCH_CHECK();
-    return KGW_OK;
+    KgwRelvecJob j{};
+    j.n_rels_total = n_rels_total; j.n_live = n_live; j.n_blk = n_blk; j.live_of_rel = live_of_rel; j.bip_pos = bip_pos;
+    j.w_src_t = w_src_t; j.w_dst_t = w_dst_t; j.att_src = att_src; j.att_dst = att_dst; j.U_full = U_full; j.V = V; j.bias = bias;
+    j.blk_of_live = blk_of_live; j.bias_sum = bias_sum; j.zero_buf = zero_buf; j.zero_floats = zero_floats;
+    return relvec_fwd_launch(1, &j, v_by_rel, (hipStream_t)stream_);
 }
 
 extern "C" int kgw_relvec_bwd_acc(int32_t n_live, const int32_t* rel_ids, const int32_t* bip_pos, const float* w_src_t,
@@ -3134,11 +3229,11 @@ extern "C" int kgw_relvec_bwd_acc(int32_t n_live, const int32_t* rel_ids, const 
                                   const float* dV, const float* dw_src_acc, float* dw_src_t, float* dw_dst_t, float* datt_src,
                                   float* datt_dst, int32_t v_by_rel, kgw_stream_t stream_) {
     if (n_live <= 0) return KGW_OK;
-    if (!rel_ids || !bip_pos || !w_src_t || !att_src || !att_dst || !dw_src_t || !datt_src || !datt_dst) return KGW_E_NULL;
-    k_relvec_bwd<<<n_live, 1024, 0, (hipStream_t)stream_>>>(rel_ids, bip_pos, w_src_t, w_dst_t, att_src, att_dst, dU_full, dV,
-                                                           dw_src_t, dw_dst_t, datt_src, datt_dst, v_by_rel, dw_src_acc);
-    KGW_LAUNCH_CHECK();
-    return KGW_OK;
+    KgwRelvecJob j{};
+    j.n_live = n_live; j.rel_ids = rel_ids; j.bip_pos = bip_pos; j.w_src_t = w_src_t; j.w_dst_t = w_dst_t; j.att_src = att_src;
+    j.att_dst = att_dst; j.dU_full = dU_full; j.dV = dV; j.dw_src_acc = dw_src_acc; j.dw_src_t = dw_src_t; j.dw_dst_t = dw_dst_t;
+    j.datt_src = datt_src; j.datt_dst = datt_dst;
+    return relvec_bwd_launch(1, &j, v_by_rel, (hipStream_t)stream_);
 }
 
 extern "C" int kgw_relvec_bwd(int32_t n_live, const int32_t* rel_ids, const int32_t* bip_pos, const float* w_src_t,

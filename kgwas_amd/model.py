@@ -28,6 +28,7 @@ reference their gradient is None and Adam (incl. its weight decay) never touches
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
@@ -37,6 +38,8 @@ import torch.nn as nn
 from . import ops
 from .graph import GraphSchema, HeteroGraph
 from .sampler import SampledBatch, gather_rows_multi, sample_full_graph
+
+_RELVEC_ALL = os.environ.get('KGW_RELVEC_ALL', '1') != '0'      # (A/B: one relation-vector launch per layer as before)
 
 EdgeType = Tuple[str, str, str]
 GO_TYPES = ('CellularComponent', 'BiologicalProcess', 'MolecularFunction')
@@ -497,7 +500,21 @@ class HeteroGNN(nn.Module):
             h = h_next
         return h, []
 
-    def _layer_params(self, batch: SampledBatch, l: int, folded: bool):
+    def _all_layer_params(self, batch: SampledBatch, folded: bool):
+        """_layer_params for every layer with the relation vectors of ALL layers from one launch (ops.rel_vectors_all): they
+        depend on the parameters only.  Their backward then is one launch too, after the first layer's."""
+        sc, m = self.schema, batch.meta
+        dev = self.lin.weight.device
+        blocks_all, zeros = [], []
+        for l in range(1, self.num_layers + 1):
+            rng = self._dst_range[l - 1]
+            tys = [t for t in range(sc.NT) if int(m.lay_rows[l - 1][t])]
+            blocks_all.append([(rng[t][0], rng[t][1], int(m.z_base[l - 1][t]), int(m.lay_rows[l - 1][t])) for t in tys])
+            zeros.append(ops.aggregate_workspace(batch, l, dev))
+        rv = ops.rel_vectors_all([self.live_packs[l] for l in range(self.num_layers)], blocks_all, zeros)
+        return [self._layer_params(batch, l, folded, relvec=rv[l - 1], zbuf=zeros[l - 1]) for l in range(1, self.num_layers + 1)]
+
+    def _layer_params(self, batch: SampledBatch, l: int, folded: bool, relvec=None, zbuf=None):
         """Everything layer l needs that depends on the PARAMETERS only (and on the batch's static row counts): the destination
         blocks, the zeroed aggregate workspace, u_r / v_r / summed biases (ops.rel_vectors) and, for a folded layer 1, the
         fold of FC_output into them.  No activation enters: the captured step runs this on a side branch beside the feature
@@ -513,7 +530,11 @@ class HeteroGNN(nn.Module):
         # ... and the zero fill of the aggregate's workspace rides in the same launch
         zws = ops.aggregate_workspace(batch, l, self.lin.weight.device)
         # (the weights reach the transform / the fold THROUGH that node: their gradient is added inside its backward kernel)
-        U, V, bsum, Wv = ops.rel_vectors(P, blocks, zero=zws, pass_weights=True)
+        if relvec is not None:                          # (all layers' vectors came out of ONE launch: _all_layer_params)
+            U, V, bsum, Wv = relvec
+            zws = zbuf
+        else:
+            U, V, bsum, Wv = ops.rel_vectors(P, blocks, zero=zws, pass_weights=True)
         Wp = gam = kap = None
         if folded and l == 1:
             # (an MLP no live layer-1 relation touches -- the GO one of a 1-layer model -- stays out of the graph: like
@@ -541,6 +562,8 @@ class HeteroGNN(nn.Module):
         C = self.hidden
         dev = self.lin.weight.device
         attn = []
+        if prep is None and self.num_layers > 1 and _RELVEC_ALL:
+            prep = self._all_layer_params(batch, folded)
         for l in range(1, self.num_layers + 1):
             P: RelationPack = self.live_packs[l - 1]
             tys, blocks, zws, U, V, bsum, Wv, kap, Wp, gam = prep[l - 1] if prep is not None else self._layer_params(batch, l, folded)

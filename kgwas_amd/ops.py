@@ -1342,6 +1342,98 @@ class _RelVectors(torch.autograd.Function):
         return dws, dwd, das, dad, None, None, None, None, None
 
 
+class _RelVectorsMulti(torch.autograd.Function):
+    """_RelVectors for ALL layers of the model as one node (round 4): the vectors depend on the parameters only, so the layers'
+    kgw_relvec_fwd launches (~30 blocks of latency each) become ONE launch ahead of the first layer, and -- a node's backward
+    runs once, when the gradients of all its outputs have arrived -- the layers' kgw_relvec_bwd_acc launches ONE launch after the
+    first layer's backward.  Per layer the outputs are (U, V, summed biases, w_src_t as seen through this node); the inputs
+    (w_src_t, w_dst_t, att_src, att_dst)."""
+
+    @staticmethod
+    def forward(ctx, packs, tabs, n_blks, zeros, *params):
+        n = len(packs)
+        jobs = (_lib.KgwRelvecJob * n)()
+        outs, keep = [], []
+        for l, (pack, j) in enumerate(zip(packs, jobs)):
+            w_src_t, w_dst_t, att_src, att_dst = params[4 * l:4 * l + 4]
+            C = att_src.shape[1]
+            dev = att_src.device
+            zero = zeros[l]
+            if zero is not None:
+                assert zero.dtype == torch.float32 and zero.is_contiguous() and zero.numel() % 4 == 0
+            U = torch.empty(pack.n_rels_total, C, device=dev)
+            V = torch.empty(pack.n_rels_total, C, device=dev)
+            bsum = torch.empty(max(n_blks[l], 1), C, device=dev)
+            bias = pack.bias.detach()
+            keep.append(bias)
+            j.n_rels_total, j.n_live, j.n_blk = pack.n_rels_total, att_src.shape[0], n_blks[l]
+            j.live_of_rel, j.bip_pos = pack.live_of_rel_i32.data_ptr(), pack.bip_pos_i32.data_ptr()
+            j.w_src_t, j.w_dst_t = w_src_t.data_ptr(), (w_dst_t.data_ptr() if w_dst_t.numel() else None)
+            j.att_src, j.att_dst, j.U_full, j.V = att_src.data_ptr(), att_dst.data_ptr(), U.data_ptr(), V.data_ptr()
+            j.bias, j.blk_of_live, j.bias_sum = bias.data_ptr(), tabs[l].data_ptr(), bsum.data_ptr()
+            j.zero_buf, j.zero_floats = (zero.data_ptr(), zero.numel()) if zero is not None else (None, 0)
+            outs += [U, V, bsum, w_src_t.detach()]       # (same storage; not a tracked view: no as_strided replay in the backward)
+        ctx.mark_non_differentiable(*outs[2::4])         # (the summed biases: layer_transform produces d bias itself)
+        _lib.check(_lib.lib().kgw_relvec_fwd_multi(n, jobs, _lib.stream_ptr()), 'kgw_relvec_fwd_multi')
+        ctx.save_for_backward(*params)
+        ctx.packs = packs
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        params = ctx.saved_tensors
+        packs = ctx.packs
+        n = len(packs)
+        jobs = (_lib.KgwRelvecJob * n)()
+        ret, keep, live = [], [], 0
+        for l, pack in enumerate(packs):
+            w_src_t, w_dst_t, att_src, att_dst = params[4 * l:4 * l + 4]
+            dU, dV, _, dW_in = grads[4 * l:4 * l + 4]
+            if dU is None and dV is None:                 # (no gradient reaches the layer's attention: only the transform's share)
+                ret += [dW_in, None, None, None]
+                continue
+            dU = dU.contiguous() if dU is not None else None
+            dV = dV.contiguous() if dV is not None else None
+            dW_in = dW_in.contiguous() if dW_in is not None else None
+            dws, dwd = torch.empty_like(w_src_t), torch.empty_like(w_dst_t)
+            das, dad = torch.empty_like(att_src), torch.empty_like(att_dst)
+            keep += [dU, dV, dW_in]
+            j = jobs[live]
+            live += 1
+            j.n_live, j.rel_ids, j.bip_pos = att_src.shape[0], pack.rel_ids_i32.data_ptr(), pack.bip_pos_i32.data_ptr()
+            j.w_src_t, j.w_dst_t = w_src_t.data_ptr(), (w_dst_t.data_ptr() if w_dst_t.numel() else None)
+            j.att_src, j.att_dst = att_src.data_ptr(), att_dst.data_ptr()
+            j.dU_full, j.dV, j.dw_src_acc = _p(dU), _p(dV), _p(dW_in)
+            j.dw_src_t, j.dw_dst_t = dws.data_ptr(), (dwd.data_ptr() if dwd.numel() else None)
+            j.datt_src, j.datt_dst = das.data_ptr(), dad.data_ptr()
+            ret += [dws, dwd, das, dad]
+        if live:
+            _lib.check(_lib.lib().kgw_relvec_bwd_multi(live, jobs, _lib.stream_ptr()), 'kgw_relvec_bwd_multi')
+        return (None, None, None, None) + tuple(ret)
+
+
+def rel_vectors_all(packs, blocks_per_layer, zeros):
+    """[(U, V, summed biases, w_src_t through the node)] for every layer in ONE launch (see _RelVectorsMulti); ``zeros``: per
+    layer the aggregate workspace to clear in the same launch (or None)."""
+    tabs, n_blks, params = [], [], []
+    for pack, blocks in zip(packs, blocks_per_layer):
+        key = ('blk',) + _block_key(blocks)
+        tab = pack._sel_cache.get(key)
+        if tab is None:
+            blk = [-1] * pack.bias.shape[0]
+            for b, (lo, hi) in enumerate(key[1:]):
+                for i in range(lo, hi):
+                    blk[i] = b
+            tab = torch.tensor(blk, dtype=torch.int32, device=pack.bias.device)
+            pack._sel_cache[key] = tab
+        tabs.append(tab)
+        n_blks.append(len(blocks))
+        params += [pack.w_src_t, pack.w_dst_t, pack.att_src, pack.att_dst]
+    outs = _RelVectorsMulti.apply(tuple(packs), tuple(tabs), tuple(n_blks), tuple(zeros), *params)
+    return [tuple(outs[4 * l:4 * l + 4]) for l in range(len(packs))]
+
+
 def _block_key(blocks):
     return tuple((lo, hi) for lo, hi, *_ in blocks)
 

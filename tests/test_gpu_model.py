@@ -598,3 +598,31 @@ def test_more_than_32_relations_match_reference_restatement():
         n_live += 1
         assert_close(gr, ref, RTOL, max(ATOL, 1e-4 * float(ref.abs().max())), f'grad {name}')
     assert n_live > 100
+
+
+def test_relation_vectors_of_all_layers_in_one_launch_equal_per_layer_launches(small_kg):
+    """ops.rel_vectors_all (round 4): the relation vectors of every layer from ONE kgw_relvec_fwd_multi launch, their backward from
+    ONE kgw_relvec_bwd_multi launch after the first layer's -- against the per-layer nodes (KGW_RELVEC_ALL=0): the same kernels
+    on the same operands, so predictions and every gradient are bit-identical."""
+    from kgwas_amd import model as kmodel
+    data = small_kg.data
+    dims = (small_kg.snp_init_dim_size, small_kg.gene_init_dim_size, small_kg.go_init_dim_size)
+    ids = np.random.default_rng(3).choice(data['SNP'].x.shape[0], size=48, replace=False)
+    batch = next(iter(_loader(data, ids, 48, 2)))
+    res = {}
+    was = kmodel._RELVEC_ALL
+    try:
+        for flag in (True, False):
+            kmodel._RELVEC_ALL = flag
+            m = _model(data, dims, seed=5, L=2)
+            out = m(batch.x_dict, batch.edge_index_dict, 48)
+            (out ** 2).sum().backward()
+            res[flag] = (out.detach().clone(), {k: (v.clone() if v is not None else None) for k, v in grads_by_name(m).items()})
+    finally:
+        kmodel._RELVEC_ALL = was
+    assert torch.equal(res[True][0], res[False][0])
+    for k, g in res[True][1].items():
+        g0 = res[False][1][k]
+        assert (g is None) == (g0 is None), k
+        if g is not None:
+            assert torch.equal(g, g0), k
