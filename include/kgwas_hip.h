@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KGW_VERSION      116          /* 0.1.6 */
+#define KGW_VERSION      117          /* 0.1.7 */
 #define KGW_MAX_TYPES    8
 #define KGW_MAX_RELS     64
 #define KGW_MAX_LAYERS   4
@@ -397,9 +397,11 @@ int64_t kgw_gemm3_workspace_floats(int64_t M, int64_t K);
 int kgw_gemm3_pack(const float* S, int64_t lds, int64_t K, int64_t k_valid, int32_t s_is_kn, void* packed, kgw_stream_t stream);
 int kgw_gemm3(const float* A, int64_t lda, int64_t M, int64_t K, const void* packed, float* workspace, int64_t workspace_floats,
               const float* bias, int32_t relu, float* out, int64_t ldo, int32_t transpose_out, const int32_t* row_map,
-              float* out_rows, int64_t ld_rows, kgw_stream_t stream);
+              float* out_rows, int64_t ld_rows, int64_t out_rows_n, const int32_t* out_rows_real, kgw_stream_t stream);
 /* row_map (nullable, not with transpose_out) [M]: row m of the result is ALSO written to out_rows[row_map[m]] when
- * row_map[m] >= 0 -- the loader's x[n_id] slicing of the layer's output (kgwas/kgwas.py:135) without a gather launch.    */
+ * row_map[m] >= 0 -- the loader's x[n_id] slicing of the layer's output (kgwas/kgwas.py:135) without a gather launch.
+ * out_rows_real (nullable, device int32) with out_rows_n (<= M): out_rows is a row block of out_rows_n rows of which only the
+ * first *out_rows_real are the batch's (static capacity of a captured step); the rest is written as zeros by the same launch. */
 
 /* The same product for FEW rows when one of K, N is 128 and the other a multiple of 128 -- the per-relation transform
  * of a layer after aggregate-then-transform, [N_dst, R*128] x [R*128, 128] with N_dst ~ 0.5-1.2 k destination rows of a

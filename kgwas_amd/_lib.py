@@ -206,7 +206,7 @@ def lib():
     L.kgw_gemm3_workspace_floats.argtypes = [C.c_int64, C.c_int64]
     L.kgw_gemm3_pack.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     L.kgw_gemm3.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
-                            C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+                            C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     L.kgw_mlp2_bwd_first_workspace_floats.restype = C.c_int64
     L.kgw_mlp2_bwd_first_workspace_floats.argtypes = [C.c_int64]
     L.kgw_mlp2_bwd_first.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32,

@@ -2978,6 +2978,8 @@ extern "C" int kgw_readout_wmse_train(const float* H, const float* w_lin, const 
         return KGW_E_NULL;
     if (n <= 0 || rows < n) return KGW_E_RANGE;
     hipStream_t st = (hipStream_t)stream_;
+    // (round 4, measured and dropped: the whole node as ONE block of 16 wavefronts walking the 512 rows -- no partial buffer, no
+    //  fold launch -- ran the step 40 - 45 us SLOWER: 32 dependent row trips per wavefront instead of one)
     k_readout_wmse_train<<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(H, w_lin, b_lin, n_id, y, w, n, rows, relu, pred, terms, dH,
                                                                       scratch);
     KGW_LAUNCH_CHECK();

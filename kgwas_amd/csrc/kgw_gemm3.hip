@@ -256,8 +256,16 @@ __global__ void __launch_bounds__(64 * NW, (8 / NW) / MT) k_g3_gemm(G3Args a) {
 // out[row, :] = act(sum_s ws[s, row, :] + bias), splits added in index order
 __global__ void __launch_bounds__(256) k_g3_reduce(const float* __restrict__ ws, int nsplit, long M, const float* __restrict__ bias,
                                                    int relu, float* __restrict__ out, long ldo, const int32_t* __restrict__ row_map,
-                                                   float* __restrict__ out_rows, long ld_rows) {
+                                                   float* __restrict__ out_rows, long ld_rows, long out_rows_n,
+                                                   const int32_t* __restrict__ out_rows_real) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (out_rows_real) {
+        // rows [*out_rows_real, out_rows_n) of the batch's row block: the padding of a static layout, which no resident row maps to
+        // -- zeroed here instead of by a fill launch over the whole block ahead of the product
+        const long real = *out_rows_real < 0 ? 0 : *out_rows_real;
+        const long zr = real + (t >> 5);
+        if (zr < out_rows_n) *(float4*)(out_rows + zr * ld_rows + 4 * (t & 31)) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (t >= M * 32) return;
     const long row = t >> 5;
     const int c4 = (int)(t & 31);
@@ -347,8 +355,10 @@ extern "C" int kgw_gemm3_pack(const float* S, int64_t lds_, int64_t K, int64_t k
 
 extern "C" int kgw_gemm3(const float* A, int64_t lda, int64_t M, int64_t K, const void* packed, float* workspace,
                          int64_t workspace_floats, const float* bias, int32_t relu, float* out, int64_t ldo, int32_t transpose_out,
-                         const int32_t* row_map, float* out_rows, int64_t ld_rows, kgw_stream_t stream_) {
+                         const int32_t* row_map, float* out_rows, int64_t ld_rows, int64_t out_rows_n, const int32_t* out_rows_real,
+                         kgw_stream_t stream_) {
     if (!A || !packed || !workspace || !out) return KGW_E_NULL;
+    if (out_rows_real && (!row_map || out_rows_n < 0 || out_rows_n > M)) return KGW_E_RANGE;   // (the padding is at most M rows)
     if (M <= 0 || K <= 0 || M > (1 << 30) || K > (1 << 30)) return KGW_E_RANGE;
     if (K % 32 || lda < 0 || (lda & 3) || ((uintptr_t)A & 15) || ((uintptr_t)packed & 15) || ((uintptr_t)workspace & 15)) return KGW_E_UNSUPPORTED;
     if (!transpose_out && ((ldo & 3) || ((uintptr_t)out & 15) || (bias && ((uintptr_t)bias & 15)))) return KGW_E_UNSUPPORTED;
@@ -365,7 +375,8 @@ extern "C" int kgw_gemm3(const float* A, int64_t lda, int64_t M, int64_t K, cons
     else k_g3_gemm<1, 4><<<per_xcd * 8, 256, 0, st>>>(a);
     KGW_LAUNCH_CHECK();
     if (transpose_out) k_g3_reduce_t<<<dim3((unsigned)((M + 31) / 32), 4), 256, 0, st>>>(workspace, ns, (long)M, out, (long)ldo);
-    else k_g3_reduce<<<(int)((M * 32 + 255) / 256), 256, 0, st>>>(workspace, ns, (long)M, bias, relu, out, (long)ldo, row_map, out_rows, (long)ld_rows);
+    else k_g3_reduce<<<(int)((M * 32 + 255) / 256), 256, 0, st>>>(workspace, ns, (long)M, bias, relu, out, (long)ldo, row_map, out_rows, (long)ld_rows,
+                                                                  (long)out_rows_n, out_rows_real);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }

@@ -363,8 +363,10 @@ class HeteroGNN(nn.Module):
                 i = dg.schema.type_id[t]
                 g2l = batch.buf.g2l[dg.node_base[i]:dg.node_base[i] + X.shape[0]]
                 if fold and ops.resident_mlp2_ok(X, mlp.FC_hidden.weight, mlp.FC_hidden2.weight, n):
+                    # (static layout: the block is padded to its capacity; the count of real rows lives on the device)
+                    real = batch.rows_dev(t) if n == batch.lay_src(1, i) else None
                     return ops.resident_mlp2(X, mlp.FC_hidden.weight, mlp.FC_hidden.bias, mlp.FC_hidden2.weight,
-                                             mlp.FC_hidden2.bias, batch.n_id(t), g2l, out)
+                                             mlp.FC_hidden2.bias, batch.n_id(t), g2l, out, rows_real=real)
                 h1 = ops.resident_linear_relu_rows(X, mlp.FC_hidden.weight, mlp.FC_hidden.bias, batch.n_id(t), g2l)
                 return mlp.tail2(h1, out) if fold else mlp.tail(h1, out)
         # static layout: the row block is padded to its capacity; the kernels skip the padding (count on the device)

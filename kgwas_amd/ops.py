@@ -580,11 +580,13 @@ def gemm3_tile(A: torch.Tensor) -> torch.Tensor:
 
 
 def gemm3(A: torch.Tensor, packed: torch.Tensor, bias=None, relu: bool = False, transpose_out: bool = False, out=None, tiled_rows: int = 0,
-          row_map=None, out_rows=None):
+          row_map=None, out_rows=None, out_rows_real=None):
     """act(A [M, K] @ B [K, 128] + bias) -> [M, 128], or its transpose [128, M] (``transpose_out``): the tall resident product
     of the first gene Linear on the bf16 matrix pipe with fp32 error (three exact bf16 pieces per operand, kgw_gemm3).
     ``tiled_rows`` = M when A is a gemm3_tile() copy.  ``row_map`` [M] int32 + ``out_rows``: row m also goes to
-    out_rows[row_map[m]] where row_map[m] >= 0 (the batch's rows of a resident layer output, no gather launch)."""
+    out_rows[row_map[m]] where row_map[m] >= 0 (the batch's rows of a resident layer output, no gather launch);
+    ``out_rows_real`` (device int32): how many rows of ``out_rows`` are the batch's -- the rest (padding of a static layout) is
+    zeroed by the same launch."""
     if tiled_rows:
         M, K, lda = tiled_rows, A.shape[1] * 32, 0
         assert A.dim() == 4 and A.shape[2:] == (32, 32) and A.is_contiguous() and A.shape[0] * 32 >= M
@@ -601,7 +603,8 @@ def gemm3(A: torch.Tensor, packed: torch.Tensor, bias=None, relu: bool = False, 
     _route('kgw_gemm3')
     _lib.check(L.kgw_gemm3(_p(A), lda, M, K, _p(packed), _p(ws), nws, _p(bias), 1 if relu else 0, _p(out), out.stride(0),
                            1 if transpose_out else 0, _p(row_map), _p(out_rows), out_rows.stride(0) if out_rows is not None else 0,
-                           _lib.stream_ptr()), 'kgw_gemm3')
+                           out_rows.shape[0] if (out_rows is not None and out_rows_real is not None) else 0,
+                           _p(out_rows_real) if out_rows is not None else None, _lib.stream_ptr()), 'kgw_gemm3')
     return out
 
 
@@ -788,7 +791,7 @@ class gene_shard_scope:
         return False
 
 
-def resident_first_linear(X, W, b, g2l=None, rows_out=None, gs=None):
+def resident_first_linear(X, W, b, g2l=None, rows_out=None, gs=None, rows_real=None):
     """relu(X W^T + b) over ALL rows of a resident wide feature matrix (kgwas/model.py:19 on the gene features).  ``g2l`` +
     ``rows_out``: the batch's rows (rows_out[g2l[r]] = row r where g2l[r] >= 0) are written by the same launch; returns
     (h, True) then, (h, False) when the caller still has to gather them."""
@@ -803,7 +806,7 @@ def resident_first_linear(X, W, b, g2l=None, rows_out=None, gs=None):
         fused = g2l is not None and rows_out is not None and rows_out.numel() > 0
         # (a width that is not a multiple of 32: the packing kernel reads the weight's real columns and pads with zeros)
         h = gemm3(Xf, gemm3_pack(W, Kp, False, k_valid=W.shape[1]), bias=b, relu=True, row_map=g2l if fused else None,
-                  out_rows=rows_out if fused else None)
+                  out_rows=rows_out if fused else None, out_rows_real=rows_real if fused else None)
         return h, fused
     return linear(X, W, b, relu=True, fixed_shape=True), False
 
@@ -1183,11 +1186,16 @@ class _ResidentMLP2(torch.autograd.Function):
     whose backward applies the ReLU mask of its input (KGW_F_RELU_INPUT); tests/test_gpu_gemm3.py checks it against float64."""
 
     @staticmethod
-    def forward(ctx, X, W1, b1, W2, b2, ids, g2l, out):
+    def forward(ctx, X, W1, b1, W2, b2, ids, g2l, out, rows_real=None):
         n = int(ids.numel())
-        h1g = torch.zeros(n, KGW_C, device=X.device) if _resident_ok(X, W1) else torch.empty(n, KGW_C, device=X.device)   # (see _ResidentLinearReLURows)
         ctx.shard = active_gene_shard(ctx, 1, X, W1, b1) if _resident_ok(X, W1) else None
-        h, done = resident_first_linear(X, W1, b1, g2l, h1g, ctx.shard)
+        # the rows past the batch's real node count (static capacity of a captured step) are written by nobody on the fused
+        # route and must be zero (see _ResidentLinearReLURows): with ``rows_real`` (their count on the device) the product's
+        # range-sum launch zeroes exactly those rows itself -- no fill launch over the whole block
+        in_kernel = rows_real is not None and n > 0 and ctx.shard is None and _resident_ok(X, W1)
+        h1g = (torch.zeros(n, KGW_C, device=X.device) if (_resident_ok(X, W1) and not in_kernel)
+               else torch.empty(n, KGW_C, device=X.device))
+        h, done = resident_first_linear(X, W1, b1, g2l, h1g, ctx.shard, rows_real if in_kernel else None)
         if n and not done:
             _lib.check(_lib.lib().kgw_gather_rows(_p(h), _p(ids), n, h.shape[1], _p(h1g), _lib.stream_ptr()), 'kgw_gather_rows')
         h2 = linear(h1g, W2, b2, relu=True, out=out.view() if out is not None else None)
@@ -1208,11 +1216,11 @@ class _ResidentMLP2(torch.autograd.Function):
                                         _p(db1), _p(ws), nws, _p(g2l), _p(dz), dz.stride(0), _lib.stream_ptr()), 'kgw_mlp2_bwd_first')
         dW1 = resident_first_weight_grad(dz, X, W1, ctx.shard)
         dW2, db2 = linear_weight_grad(dh2, h1g)
-        return None, dW1, db1, dW2, db2, None, None, None
+        return None, dW1, db1, dW2, db2, None, None, None, None
 
 
-def resident_mlp2(X, W1, b1, W2, b2, ids, g2l, out=None):
-    return _ResidentMLP2.apply(X, W1, b1, W2, b2, ids, g2l, out)
+def resident_mlp2(X, W1, b1, W2, b2, ids, g2l, out=None, rows_real=None):
+    return _ResidentMLP2.apply(X, W1, b1, W2, b2, ids, g2l, out, rows_real)
 
 
 def resident_mlp2_ok(X, W1, W2, n_local: int) -> bool:

@@ -461,3 +461,30 @@ def test_layer_transforms_of_all_destination_types_in_one_launch():
     jobs[1].K, jobs[1].N, jobs[1].w_is_kn = 128, 768, 0
     assert L.kgw_linear_splitk_multi(2, jobs, st) == -3
     assert L.kgw_linear_splitk_multi(5, jobs, st) == -2
+
+
+@pytest.mark.parametrize('n,rows', [(512, 512), (500, 576), (1, 1), (5000, 5120)])
+def test_readout_loss_training_node_matches_autograd(n, rows):
+    """kgw_readout_wmse_train (unit loss gradient: forward + backward of the read-out + LD-weighted MSE node together, the
+    blocks' partials + a fold launch) against fp64 autograd, ragged and large row counts."""
+    from kgwas_amd import ops
+    g = torch.Generator().manual_seed(n + rows)
+    N = 300 + rows
+    H = torch.relu(torch.randn(rows, 128, generator=g))
+    wl = torch.randn(1, 128, generator=g) * 0.2; bl = torch.randn(1, generator=g) + 0.5
+    y_all = torch.rand(N, generator=g); w_all = torch.rand(N, generator=g, dtype=torch.float64) + 0.1
+    n_id = torch.randperm(N, generator=g)[:rows].to(torch.int32)
+    Hd, wd, bd = (t.cuda().requires_grad_(True) for t in (H, wl, bl))
+    loss, pred = ops.readout_weighted_mse(Hd, wd, bd, n_id.cuda(), y_all.cuda(), w_all.cuda(), n, relu=True, h_is_relu=True, unit_grad=True)
+    loss.backward(gradient=ops.unit_gradient(torch.device('cuda:0')))
+    Ho, wo, bo = (t.double().requires_grad_(True) for t in (H, wl, bl))
+    p = torch.relu((Ho[:n] @ wo.t() + bo).reshape(-1))
+    ids = n_id[:n].long()
+    lo = torch.mean(w_all[ids] * (p - y_all[ids].double()) ** 2)
+    lo.backward()
+    assert_close(pred, p.detach(), 1e-5, 1e-6, 'pred')
+    assert abs(float(loss) - float(lo)) <= 1e-9 + 2e-6 * abs(float(lo))
+    assert_close(Hd.grad, Ho.grad * (H.double() > 0), 1e-4, 1e-7, 'dH', rel_to_max=1e-5)
+    assert float(Hd.grad[n:].abs().sum()) == 0.0
+    assert_close(wd.grad, wo.grad, 1e-4, 1e-7, 'd lin.weight', rel_to_max=1e-5)
+    assert_close(bd.grad, bo.grad, 1e-4, 1e-7, 'd lin.bias', rel_to_max=1e-5)
