@@ -3011,7 +3011,10 @@ struct RvBwdJob {
 };
 struct RvBwdJobs { RvBwdJob j[KGW_MAX_LAYERS]; int blk_end; int n; };
 
-__global__ void __launch_bounds__(128) k_relvec_fwd(RvFwdJobs J, int v_by_rel) {
+// (round 4: 1 024 threads per block.  A relation's two 128 x 128 slabs are read ROW by row, a wavefront per 8 rows, two floats per
+//  lane -- 512 contiguous bytes per load, 16 loads in flight, one wave-wide sum per row; with one thread per row every load touched
+//  64 different rows and the 29-block launch took 12 - 18 us for 6 MB)
+__global__ void __launch_bounds__(1024) k_relvec_fwd(RvFwdJobs J, int v_by_rel) {
     int jq = 0;
     while (jq + 1 < J.n && (int)blockIdx.x >= J.j[jq + 1].blk0) ++jq;
     const RvFwdJob& T = J.j[jq];
@@ -3029,15 +3032,15 @@ __global__ void __launch_bounds__(128) k_relvec_fwd(RvFwdJobs J, int v_by_rel) {
     float* __restrict__ bsum = T.bsum;
     float* __restrict__ zero_buf = T.zero_buf;
     const int64_t zero_f4 = T.zero_f4;
-    __shared__ float as[KGW_C], ad[KGW_C];
     const int r = (int)blockIdx.x - T.blk0, k = threadIdx.x;
     if (r >= n_main) {      // extra blocks: clear the aggregate's workspace (Z, stat, d a_dst) in this launch
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t i = (int64_t)(r - n_main) * 128 + k; i < zero_f4; i += (int64_t)(T.nblk - n_main) * 128)
+        for (int64_t i = (int64_t)(r - n_main) * 1024 + k; i < zero_f4; i += (int64_t)(T.nblk - n_main) * 1024)
             ((float4*)zero_buf)[i] = z4;
         return;
     }
     if (r == NR) {          // extra block: bias of every relation into a destination type, summed in packed order
+        if (k >= KGW_C) return;
         float acc[KGW_MAX_TYPES];
 #pragma unroll
         for (int b = 0; b < KGW_MAX_TYPES; ++b) acc[b] = 0.f;
@@ -3055,25 +3058,34 @@ __global__ void __launch_bounds__(128) k_relvec_fwd(RvFwdJobs J, int v_by_rel) {
     }
     const int i = live_of_rel[r];
     if (i < 0) {
-        U_full[(int64_t)r * KGW_C + k] = 0.f;
-        if (v_by_rel) V[(int64_t)r * KGW_C + k] = 0.f;
+        if (k < KGW_C) {
+            U_full[(int64_t)r * KGW_C + k] = 0.f;
+            if (v_by_rel) V[(int64_t)r * KGW_C + k] = 0.f;
+        }
         return;
     }
-    as[k] = att_src[(int64_t)i * KGW_C + k];
-    ad[k] = att_dst[(int64_t)i * KGW_C + k];
-    __syncthreads();
+    const int lane = k & 63, wave = k >> 6;
+    const float2 as2 = ((const float2*)(att_src + (int64_t)i * KGW_C))[lane];
+    const float2 ad2 = ((const float2*)(att_dst + (int64_t)i * KGW_C))[lane];
     const int j = bip_pos[i];
-    const float4* ws = (const float4*)(wsT + ((int64_t)i * KGW_C + k) * KGW_C);
-    const float4* wd = j >= 0 ? (const float4*)(wdT + ((int64_t)j * KGW_C + k) * KGW_C) : ws;
-    float u = 0.f, v = 0.f;
-#pragma unroll 8
-    for (int c4 = 0; c4 < KGW_C / 4; ++c4) {
-        const float4 a = ws[c4], b = wd[c4];
-        u = fmaf(a.x, as[4 * c4], fmaf(a.y, as[4 * c4 + 1], fmaf(a.z, as[4 * c4 + 2], fmaf(a.w, as[4 * c4 + 3], u))));
-        v = fmaf(b.x, ad[4 * c4], fmaf(b.y, ad[4 * c4 + 1], fmaf(b.z, ad[4 * c4 + 2], fmaf(b.w, ad[4 * c4 + 3], v))));
+    const float* ws = wsT + ((int64_t)i * KGW_C + wave * 8) * KGW_C;
+    const float* wd = j >= 0 ? wdT + ((int64_t)j * KGW_C + wave * 8) * KGW_C : ws;
+    float2 a[8], b[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        a[q] = ((const float2*)(ws + q * KGW_C))[lane];
+        b[q] = ((const float2*)(wd + q * KGW_C))[lane];
     }
-    U_full[(int64_t)r * KGW_C + k] = u;
-    V[(int64_t)(v_by_rel ? r : i) * KGW_C + k] = v;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float u = kgw_wave_allsum(fmaf(a[q].x, as2.x, a[q].y * as2.y));
+        const float v = kgw_wave_allsum(fmaf(b[q].x, ad2.x, b[q].y * ad2.y));
+        if (lane == 0) {
+            const int row = wave * 8 + q;
+            U_full[(int64_t)r * KGW_C + row] = u;
+            V[(int64_t)(v_by_rel ? r : i) * KGW_C + row] = v;
+        }
+    }
 }
 
 // one block per live relation i; thread c owns column c of the [k][c] matrices
@@ -3098,13 +3110,16 @@ __global__ void __launch_bounds__(1024) k_relvec_bwd(RvBwdJobs J) {
     float* __restrict__ datt_dst = T.datt_dst;
     const float* __restrict__ dws_acc = T.dws_acc;
     const int v_by_rel = T.v_by_rel;
+    // (round 4: FOUR blocks per relation, each owns 32 of the 128 columns -- the sums over k are per column, so the split needs no
+    //  combine -- 52 relations then fill 208 CUs instead of 52; thread (q, c): rows k = q, q + 32, q + 64, q + 96)
     __shared__ float du[KGW_C], dv[KGW_C];
-    __shared__ float ps[8][KGW_C], pd[8][KGW_C];
-    const int i = (int)blockIdx.x - T.blk0, c = threadIdx.x & (KGW_C - 1), q = threadIdx.x >> 7;
+    __shared__ float ps[32][33], pd[32][33];
+    const int bx = (int)blockIdx.x - T.blk0;
+    const int i = bx >> 2, cl = threadIdx.x & 31, c = (bx & 3) * 32 + cl, q = threadIdx.x >> 5;
     const int r = rel_ids[i], j = bip_pos[i];
-    if (q == 0) {
-        du[c] = dU_full ? dU_full[(int64_t)r * KGW_C + c] : 0.f;
-        dv[c] = dV ? dV[(int64_t)(v_by_rel ? r : i) * KGW_C + c] : 0.f;
+    if (threadIdx.x < KGW_C) {
+        du[threadIdx.x] = dU_full ? dU_full[(int64_t)r * KGW_C + threadIdx.x] : 0.f;
+        dv[threadIdx.x] = dV ? dV[(int64_t)(v_by_rel ? r : i) * KGW_C + threadIdx.x] : 0.f;
     }
     __syncthreads();
     const float as = att_src[(int64_t)i * KGW_C + c], ad = att_dst[(int64_t)i * KGW_C + c];
@@ -3116,33 +3131,37 @@ __global__ void __launch_bounds__(1024) k_relvec_bwd(RvBwdJobs J) {
     const float* wd = j >= 0 ? wdT + (int64_t)j * KGW_C * KGW_C : nullptr;
     float* dwd = j >= 0 ? dwdT + (int64_t)j * KGW_C * KGW_C : nullptr;
     float gs = 0.f, gd = 0.f;
-    for (int k0 = q; k0 < KGW_C; k0 += 64) {
-        float w[8], w2[8], a[8];
+    float w[4], w2[4], a[4];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int k = k0 + 8 * t;
-            w[t] = ws[k * KGW_C + c];
-            w2[t] = wd ? wd[k * KGW_C + c] : w[t];
-            a[t] = acc ? acc[k * KGW_C + c] : 0.f;
-        }
+    for (int t = 0; t < 4; ++t) {
+        const int k = q + 32 * t;
+        w[t] = ws[k * KGW_C + c];
+        w2[t] = wd ? wd[k * KGW_C + c] : w[t];
+        a[t] = acc ? acc[k * KGW_C + c] : 0.f;
+    }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int k = k0 + 8 * t;
-            gs = fmaf(w[t], du[k], gs);
-            gd = fmaf(w2[t], dv[k], gd);
-            if (wd) {
-                dws[k * KGW_C + c] = fmaf(du[k], as, a[t]);
-                dwd[k * KGW_C + c] = dv[k] * ad;
-            } else {
-                dws[k * KGW_C + c] = fmaf(du[k], as, dv[k] * ad) + a[t];
-            }
+    for (int t = 0; t < 4; ++t) {
+        const int k = q + 32 * t;
+        gs = fmaf(w[t], du[k], gs);
+        gd = fmaf(w2[t], dv[k], gd);
+        if (wd) {
+            dws[k * KGW_C + c] = fmaf(du[k], as, a[t]);
+            dwd[k * KGW_C + c] = dv[k] * ad;
+        } else {
+            dws[k * KGW_C + c] = fmaf(du[k], as, dv[k] * ad) + a[t];
         }
     }
-    ps[q][c] = gs; pd[q][c] = gd;
+    ps[q][cl] = gs; pd[q][cl] = gd;
     __syncthreads();
     if (q == 0) {
-        datt_src[(int64_t)i * KGW_C + c] = ((ps[0][c] + ps[1][c]) + (ps[2][c] + ps[3][c])) + ((ps[4][c] + ps[5][c]) + (ps[6][c] + ps[7][c]));
-        datt_dst[(int64_t)i * KGW_C + c] = ((pd[0][c] + pd[1][c]) + (pd[2][c] + pd[3][c])) + ((pd[4][c] + pd[5][c]) + (pd[6][c] + pd[7][c]));
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; g += 4) {
+            s0 += ps[g][cl]; s1 += ps[g + 1][cl]; s2 += ps[g + 2][cl]; s3 += ps[g + 3][cl];
+            d0 += pd[g][cl]; d1 += pd[g + 1][cl]; d2 += pd[g + 2][cl]; d3 += pd[g + 3][cl];
+        }
+        datt_src[(int64_t)i * KGW_C + c] = (s0 + s1) + (s2 + s3);
+        datt_dst[(int64_t)i * KGW_C + c] = (d0 + d1) + (d2 + d3);
     }
 }
 
@@ -3162,8 +3181,8 @@ int relvec_fwd_launch(int n_jobs, const KgwRelvecJob* jobs, int v_by_rel, hipStr
         T.NR = D.n_rels_total; T.n_live = D.n_live; T.n_blk = with_bias ? D.n_blk : 0;
         T.n_main = D.n_rels_total + (with_bias ? 1 : 0);
         T.zero_f4 = D.zero_buf ? D.zero_floats / 4 : 0;
-        int64_t zblk = (T.zero_f4 + 128 * 8 - 1) / (128 * 8);          // ~8 float4 per thread
-        if (zblk > 2048) zblk = 2048;
+        int64_t zblk = (T.zero_f4 + 1024 * 4 - 1) / (1024 * 4);        // ~4 float4 per thread
+        if (zblk > 1024) zblk = 1024;
         T.blk0 = blk; T.nblk = T.n_main + (int)zblk;
         blk += T.nblk;
         T.live_of_rel = D.live_of_rel; T.bip_pos = D.bip_pos; T.wsT = D.w_src_t; T.wdT = D.w_dst_t; T.att_src = D.att_src;
@@ -3172,7 +3191,7 @@ int relvec_fwd_launch(int n_jobs, const KgwRelvecJob* jobs, int v_by_rel, hipStr
     }
     if (n == 0) return KGW_OK;
     J.n = n;
-    k_relvec_fwd<<<blk, 128, 0, st>>>(J, v_by_rel);
+    k_relvec_fwd<<<blk, 1024, 0, st>>>(J, v_by_rel);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
 }
@@ -3187,7 +3206,7 @@ int relvec_bwd_launch(int n_jobs, const KgwRelvecJob* jobs, int v_by_rel, hipStr
             return KGW_E_NULL;
         RvBwdJob& T = J.j[n++];
         T.blk0 = blk; T.v_by_rel = v_by_rel;
-        blk += D.n_live;
+        blk += 4 * D.n_live;
         T.rel_ids = D.rel_ids; T.bip_pos = D.bip_pos; T.wsT = D.w_src_t; T.wdT = D.w_dst_t; T.att_src = D.att_src;
         T.att_dst = D.att_dst; T.dU_full = D.dU_full; T.dV = D.dV; T.dwsT = D.dw_src_t; T.dwdT = D.dw_dst_t;
         T.datt_src = D.datt_src; T.datt_dst = D.datt_dst; T.dws_acc = D.dw_src_acc;
