@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(512) k_fold_bwd(FoldTab T, FoldPtrs P, int par
             vs[h2] = vsum;
         }
         const int k = 32 * tn + col, h0 = 32 * tm + (t >> 5);
-#pragma unroll 4
+#pragma unroll 8
         for (int i = 0; i < T.n; ++i) {                    // rank-1 terms, relation order; loads unconditional (independent)
             const int r = T.rel_id[i];
             const float fs = T.src_m[i] == m ? 1.f : 0.f, fd = T.dst_m[i] == m ? 1.f : 0.f;
@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(512) k_fold_bwd(FoldTab T, FoldPtrs P, int par
 #pragma unroll
             for (int w8 = 0; w8 < 8; ++w8) s += redb[w8][t] + redb[w8][32 + t];      // the two k halves of every wavefront
             const int h = 32 * tm + t;
-#pragma unroll 4
+#pragma unroll 8
             for (int i = 0; i < T.n; ++i) {
                 const int r = T.rel_id[i];
                 const float dk = P.dkappa[r];
@@ -251,25 +251,33 @@ __global__ void __launch_bounds__(512) k_fold_bwd(FoldTab T, FoldPtrs P, int par
     {
         // ---- C: dU[r][c] = sum_k T[k][c] dU'[r][k] + dkappa_r c_src[c]   (fcw[c][k]: thread c reads its own row)
         if (!(parts & 4)) return;
+        // (round 4: the rows of FC_output.weight are read ROW by row, a wavefront per 16 rows, two floats per lane -- 512 contiguous
+        //  bytes per load, 32 loads in flight, one wave-wide sum per row; with one thread per row every load touched 64 rows)
         const int r = b - nA - nB;
         const int i = T.live_of[r];
-        if (t >= 128) return;
-        if (i < 0) { P.dU[r * FC + t] = 0.f; P.dV[r * FC + t] = 0.f; return; }
-        const int ms = T.src_m[i], md = T.dst_m[i];
-        const float* ws = P.fcw[ms] + t * FC;
-        const float* wd = P.fcw[md] + t * FC;
-        const float* du = P.dUp + r * FC;
-        const float* dv = P.dVp + r * FC;
-        float su = 0.f, sv = 0.f;
-        for (int k = 0; k < FC; k += 4) {
-            const float4 a4 = *(const float4*)(ws + k), b4 = *(const float4*)(wd + k);
-            const float4 u4 = *(const float4*)(du + k), v4 = *(const float4*)(dv + k);
-            su = fmaf(a4.x, u4.x, su); su = fmaf(a4.y, u4.y, su); su = fmaf(a4.z, u4.z, su); su = fmaf(a4.w, u4.w, su);
-            sv = fmaf(b4.x, v4.x, sv); sv = fmaf(b4.y, v4.y, sv); sv = fmaf(b4.z, v4.z, sv); sv = fmaf(b4.w, v4.w, sv);
+        if (i < 0) {
+            if (t < 128) { P.dU[r * FC + t] = 0.f; P.dV[r * FC + t] = 0.f; }
+            return;
         }
+        const int ms = T.src_m[i], md = T.dst_m[i];
+        const float2 du2 = ((const float2*)(P.dUp + r * FC))[lane], dv2 = ((const float2*)(P.dVp + r * FC))[lane];
         const float dk = P.dkappa[r];
-        P.dU[r * FC + t] = su + dk * P.fcb[ms][t];
-        P.dV[r * FC + t] = sv + dk * P.fcb[md][t];
+        const int c0 = wave * 16;
+        float2 a[16], bq[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            a[q] = ((const float2*)(P.fcw[ms] + (c0 + q) * FC))[lane];
+            bq[q] = ((const float2*)(P.fcw[md] + (c0 + q) * FC))[lane];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float su = kgw_wave_allsum(fmaf(a[q].x, du2.x, a[q].y * du2.y));
+            const float sv = kgw_wave_allsum(fmaf(bq[q].x, dv2.x, bq[q].y * dv2.y));
+            if (lane == 0) {
+                P.dU[r * FC + c0 + q] = su + dk * P.fcb[ms][c0 + q];
+                P.dV[r * FC + c0 + q] = sv + dk * P.fcb[md][c0 + q];
+            }
+        }
     }
 }
 
