@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KGW_VERSION      117          /* 0.1.7 */
+#define KGW_VERSION      118          /* 0.1.8 */
 #define KGW_MAX_TYPES    8
 #define KGW_MAX_RELS     64
 #define KGW_MAX_LAYERS   4
@@ -304,6 +304,20 @@ int kgw_scatter_relu_rows(const float* g, const int32_t* g2l, const float* h, in
  * kgwas/conv.py:192-196; kgwas/utils.py:446-461).                                             */
 int kgw_edge_alpha(const KgwLayerArgs* args, float* alpha_out, kgw_stream_t stream);
 
+/* Where a gradient tensor's values are when its producer left the last reduction to the optimiser's launch
+ * (kgw_adam_fused): DIRECT = in the gradient tensor itself; the other kinds = per-block partial sums in a workspace, added by
+ * kgw_adam_fused in exactly the order the producer's own second launch (k_tn_reduce / k_mlp2_bwd_fold) uses -- bit-identical
+ * gradients, one launch less per product.  Filled by kgw_tn_gemm_partial / kgw_tn_gemm_multi_partial /
+ * kgw_mlp2_bwd_first_partial; the caller only carries the record to kgw_adam_fused.  (Weight / bias gradients of the Linears of
+ * kgwas/model.py:13-21 on their way to the Adam update of kgwas/kgwas.py:116,151.)                                             */
+enum { KGW_GRAD_DIRECT = 0, KGW_GRAD_TN = 1, KGW_GRAD_TN_COLSUM = 2, KGW_GRAD_MLP2_W = 3, KGW_GRAD_MLP2_B = 4 };
+typedef struct KgwGradSrc {
+    const float* ws;                 /* first partial record                                                     */
+    int32_t kind, nblk;              /* KGW_GRAD_*; partial records per output element                           */
+    int32_t M, N, MT, NT, gy, gz;    /* TN kinds: product shape and tiling                                        */
+    int32_t K1, c_transposed;        /* MLP2 kinds: width of the first layer's input; TN: C stored transposed     */
+} KgwGradSrc;
+
 /* C[M,N] = A[rows,M]^T * B[rows,N] (row-major, leading dimensions lda/ldb/ldc), optionally
  * colsum_a[M] = column sums of A.  Split-K over the rows on fp32 MFMA, deterministic.  Replaces the
  * weight / bias gradient GEMMs autograd runs for the Linear layers of the path
@@ -337,6 +351,15 @@ int kgw_tn_gemm_ex(const float* A, int64_t lda, int32_t M, const float* B, int64
                    int64_t rows, float* C, int64_t ldc, int32_t c_transposed, float* colsum_a,
                    int32_t colsum_repeat, int64_t colsum_ld, float* workspace, int64_t workspace_floats,
                    const int32_t* rows_dev, kgw_stream_t stream);
+
+/* The first launch of kgw_tn_gemm_ex / kgw_tn_gemm_multi only (colsum_repeat 1, dense C): src[0] / src[1] (per job: src[2q],
+ * src[2q + 1]) describe the partial sums of the product / of the column sums for kgw_adam_fused; C and colsum_a are the
+ * gradient tensors that launch will also fill.                                                                            */
+int kgw_tn_gemm_partial(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
+                        int64_t rows, float* C, int64_t ldc, int32_t c_transposed, float* colsum_a,
+                        float* workspace, int64_t workspace_floats, const int32_t* rows_dev, KgwGradSrc* src,
+                        kgw_stream_t stream);
+int kgw_tn_gemm_multi_partial(int32_t n_jobs, const KgwTnJob* jobs, KgwGradSrc* src, kgw_stream_t stream);
 
 /* Y[rows,N] = act(X[rows,K] * Wop + bias) * (mask > 0): the Linear layers of the path on fp32 MFMA.
  * w_is_kn = 0: W is [N,K] (nn.Linear / PyG Linear forward, kgwas/model.py:13-21,50; kgwas/conv.py:138,142);
@@ -378,6 +401,13 @@ int kgw_mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2, int64_t l
                        const float* X, int64_t ldx, int32_t K1, int64_t rows, const int32_t* rows_dev, float* dW1,
                        int64_t ldw1, float* db1, float* workspace, int64_t workspace_floats, const int32_t* in_ids, float* dZ,
                        int64_t ldz, kgw_stream_t stream);
+
+/* The same without the second launch (the fold of the blocks' partial d W1 / d b1): src[0] describes d W1's partial sums,
+ * src[1] d b1's, for kgw_adam_fused (ldw1 must be K1: a dense gradient tensor).                                             */
+int kgw_mlp2_bwd_first_partial(const float* dH2, int64_t ldd, const float* W2, int64_t ldw2, const float* H1, int64_t ldh1,
+                               const float* X, int64_t ldx, int32_t K1, int64_t rows, const int32_t* rows_dev, float* dW1,
+                               int64_t ldw1, float* db1, float* workspace, int64_t workspace_floats, const int32_t* in_ids,
+                               float* dZ, int64_t ldz, KgwGradSrc* src, kgw_stream_t stream);
 
 /* C[M, 128] = A[M, K] B[K, 128] for a tall RESIDENT fp32 matrix A -- the first gene Linear, kgwas/model.py:13,19 over the
  * 5 120-wide gene features (kgwas_data.py:236,244): forward with A = X [genes, K], B = W1^T (out = relu(C + bias)), and its
@@ -458,6 +488,19 @@ int kgw_adam(int32_t n_tensors, float* const* params, const float* const* grads,
 int kgw_adam_notick(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                     float* const* exp_avg_sq, const int64_t* numel, int32_t* step_dev, float lr, float beta1,
                     float beta2, float eps, float weight_decay, kgw_stream_t stream);
+
+/* The optimiser launch of a captured training step: kgw_adam_notick over up to KGW_ADAM_FUSED_MAX tensors, and in the SAME launch
+ * (a) the last reduction of every gradient whose producer left partial sums (src[i].kind != KGW_GRAD_DIRECT, at most
+ *     KGW_ADAM_FUSED_SRC of them; src == NULL: all direct) -- the sums are taken in the producers' own order and also written
+ *     to grads[i], so the gradient tensors hold what the unfused path leaves in them;
+ * (b) kgw_accumulate_stats_tick (meta_dev != NULL: the running totals; the step counter advances in any case) -- done by the
+ *     block that finishes last (done_counters: KGW_ADAM_FUSED_COUNTERS device int32 the caller zeroes once; the launch leaves
+ *     them at zero).                                                                                                         */
+enum { KGW_ADAM_FUSED_MAX = 40, KGW_ADAM_FUSED_SRC = 12, KGW_ADAM_FUSED_COUNTERS = 65 * 32 };
+int kgw_adam_fused(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                   float* const* exp_avg_sq, const int64_t* numel, const KgwGradSrc* src, int32_t* step_dev, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, const KgwBatchMeta* meta_dev, int32_t n_layers,
+                   int32_t n_hops, int64_t* stats, int32_t* done_counters, kgw_stream_t stream);
 
 /* Attention vectors of all relations of a layer (kgwas/conv.py:138-151 reduced to what the path consumes):
  * U_full[r] = W_src^T att_src for every relation id r the layer computes (live_of_rel[r] = its index i in the

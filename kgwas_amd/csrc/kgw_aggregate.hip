@@ -1380,9 +1380,10 @@ extern "C" const char* kgw_status_string(int status) {
 
 extern "C" int kgw_struct_sizes(int64_t* out, int n) {
     if (!out) return KGW_E_NULL;
-    const int64_t v[6] = {(int64_t)sizeof(KgwGraph), (int64_t)sizeof(KgwBatchMeta), (int64_t)sizeof(KgwChunk),
-                          (int64_t)sizeof(KgwBatchBuf), (int64_t)sizeof(KgwLayerArgs), (int64_t)sizeof(KgwTnJob)};
-    for (int i = 0; i < n && i < 6; ++i) out[i] = v[i];
+    const int64_t v[7] = {(int64_t)sizeof(KgwGraph), (int64_t)sizeof(KgwBatchMeta), (int64_t)sizeof(KgwChunk),
+                          (int64_t)sizeof(KgwBatchBuf), (int64_t)sizeof(KgwLayerArgs), (int64_t)sizeof(KgwTnJob),
+                          (int64_t)sizeof(KgwGradSrc)};
+    for (int i = 0; i < n && i < 7; ++i) out[i] = v[i];
     return KGW_OK;
 }
 

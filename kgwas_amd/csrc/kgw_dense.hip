@@ -296,8 +296,10 @@ struct TnDesc {      // one product as the C ABI describes it
     float* colsum; int cs_rep; int64_t cs_ld; float* ws; int64_t ws_floats; const int32_t* rows_dev;
 };
 
+// ``defer`` (nullable, 2 n records: [product, column sums] of every job): the second launch is left to kgw_adam_fused, which
+// adds the row blocks' partials in k_tn_reduce's order while it updates the parameter the gradient belongs to.
 template <int MT, int NT>
-int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st) {
+int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st, KgwGradSrc* defer = nullptr) {
     constexpr int FRAG = MT * NT * 16 * 64;
     TnJobs J{};
     J.n = n;
@@ -329,6 +331,22 @@ int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st) {
         T.lda = D.lda; T.ldb = D.ldb; T.rows = D.rows; T.rpw = rpw;
         T.c_rs = D.c_t ? 1 : D.ldc; T.c_cs = D.c_t ? D.ldc : 1; T.cs_ld = D.cs_ld;
         T.M = D.M; T.N = D.N; T.nblk = (int)nblk; T.blk0 = blk; T.gy = gy; T.gz = gz; T.cs_rep = D.cs_rep;
+        if (defer) {
+            // (the fused consumer walks the gradient tensor in its own linear order: it must be dense)
+            if (D.ldc != (D.c_t ? D.M : D.N) || (D.colsum && D.cs_rep != 1)) return KGW_E_UNSUPPORTED;
+            KgwGradSrc& W = defer[2 * q];
+            KgwGradSrc& Bc = defer[2 * q + 1];
+            W = KgwGradSrc{};
+            Bc = KgwGradSrc{};
+            if (nblk > 1) {
+                W.kind = KGW_GRAD_TN; W.nblk = (int)nblk; W.ws = D.ws; W.M = D.M; W.N = D.N; W.MT = MT; W.NT = NT; W.gy = gy; W.gz = gz;
+                W.c_transposed = D.c_t ? 1 : 0;
+                if (D.colsum) {
+                    Bc = W;
+                    Bc.kind = KGW_GRAD_TN_COLSUM; Bc.ws = T.ws_cs;
+                }
+            }
+        }
         blk += (int)nblk;
         gy_max = gy > gy_max ? gy : gy_max;
         gz_max = gz > gz_max ? gz : gz_max;
@@ -341,7 +359,7 @@ int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st) {
     }
     kern<<<dim3((unsigned)blk, gy_max, gz_max), 256, lds_bytes, st>>>(J);
     KGW_LAUNCH_CHECK();
-    if (all_direct) return KGW_OK;                     // every product wrote its result itself
+    if (all_direct || defer) return KGW_OK;            // every product wrote its result itself / the sums are taken later
     k_tn_reduce<MT, NT><<<dim3(FRAG / 64, gy_max, gz_max * n), 256, 0, st>>>(J, gz_max);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
@@ -350,9 +368,9 @@ int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st) {
 template <int MT, int NT>
 int launch_tn(const float* A, int64_t lda, int M, const float* B, int64_t ldb, int N, int64_t rows, float* C,
               int64_t ldc, bool c_t, float* colsum, int cs_rep, int64_t cs_ld, float* ws, int64_t ws_floats,
-              const int32_t* rows_dev, hipStream_t st) {
+              const int32_t* rows_dev, hipStream_t st, KgwGradSrc* defer = nullptr) {
     const TnDesc d{A, lda, M, B, ldb, N, rows, C, ldc, c_t, colsum, cs_rep, cs_ld, ws, ws_floats, rows_dev};
-    return launch_tn_jobs<MT, NT>(&d, 1, st);
+    return launch_tn_jobs<MT, NT>(&d, 1, st, defer);
 }
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -368,10 +386,10 @@ extern "C" int64_t kgw_tn_gemm_workspace_floats(int64_t rows, int M, int N) {
     return nblk * gy1 * gz1 * 1024 + nblk * gy1 * 32 + 4096;   // 1024 floats per 32x32 tile per row-block
 }
 
-extern "C" int kgw_tn_gemm_ex(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
-                              int64_t rows, float* C, int64_t ldc, int32_t c_transposed, float* colsum_a,
-                              int32_t colsum_repeat, int64_t colsum_ld, float* workspace, int64_t workspace_floats,
-                              const int32_t* rows_dev, kgw_stream_t stream_) {
+static int tn_gemm_ex(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
+                      int64_t rows, float* C, int64_t ldc, int32_t c_transposed, float* colsum_a,
+                      int32_t colsum_repeat, int64_t colsum_ld, float* workspace, int64_t workspace_floats,
+                      const int32_t* rows_dev, kgw_stream_t stream_, KgwGradSrc* defer) {
     if (!A || !B || !C || !workspace) return KGW_E_NULL;
     if (M <= 0 || N <= 0 || rows <= 0 || lda < M || ldb < N || ldc < (c_transposed ? M : N)) return KGW_E_RANGE;
     if (colsum_a && (colsum_repeat < 1 || (colsum_repeat > 1 && colsum_ld < M))) return KGW_E_RANGE;
@@ -385,7 +403,7 @@ extern "C" int kgw_tn_gemm_ex(const float* A, int64_t lda, int32_t M, const floa
     // 64x64 accumulators per wavefront (MT = NT = 2) and up to two blocks per CU rather than one 128x128 accumulator:
     // a quarter of the per-block LDS reduction / partial-slab traffic and twice the row blocks in flight -- 51 vs 72 us
     // at 123 k x 128 x 128, 21 vs 26 us at 20 k rows (each A / B element is read by two blocks, the second time from L2)
-#define KGW_TN_ARGS A, lda, M, B, ldb, N, rows, C, ldc, ct, colsum_a, rep, colsum_ld, workspace, workspace_floats, rows_dev, st
+#define KGW_TN_ARGS A, lda, M, B, ldb, N, rows, C, ldc, ct, colsum_a, rep, colsum_ld, workspace, workspace_floats, rows_dev, st, defer
     if (a2 && b2) return launch_tn<2, 2>(KGW_TN_ARGS);
     if (a2)       return launch_tn<2, 1>(KGW_TN_ARGS);       // narrow B (the 20-wide SNP feature layer)
     if (b4)       return launch_tn<1, 4>(KGW_TN_ARGS);       // narrow A (d a_src of a few relations)
@@ -394,7 +412,26 @@ extern "C" int kgw_tn_gemm_ex(const float* A, int64_t lda, int32_t M, const floa
 #undef KGW_TN_ARGS
 }
 
-extern "C" int kgw_tn_gemm_multi(int32_t n_jobs, const KgwTnJob* jobs, kgw_stream_t stream_) {
+extern "C" int kgw_tn_gemm_ex(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
+                              int64_t rows, float* C, int64_t ldc, int32_t c_transposed, float* colsum_a,
+                              int32_t colsum_repeat, int64_t colsum_ld, float* workspace, int64_t workspace_floats,
+                              const int32_t* rows_dev, kgw_stream_t stream_) {
+    return tn_gemm_ex(A, lda, M, B, ldb, N, rows, C, ldc, c_transposed, colsum_a, colsum_repeat, colsum_ld, workspace,
+                      workspace_floats, rows_dev, stream_, nullptr);
+}
+
+// The product's first launch only: the row blocks' partial sums stay in the workspace and src[0] (the product) / src[1] (the
+// column sums) say how kgw_adam_fused finds them.  A product with a single row block is complete (kind KGW_GRAD_DIRECT).
+extern "C" int kgw_tn_gemm_partial(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
+                                   int64_t rows, float* C, int64_t ldc, int32_t c_transposed, float* colsum_a,
+                                   float* workspace, int64_t workspace_floats, const int32_t* rows_dev, KgwGradSrc* src,
+                                   kgw_stream_t stream_) {
+    if (!src) return KGW_E_NULL;
+    return tn_gemm_ex(A, lda, M, B, ldb, N, rows, C, ldc, c_transposed, colsum_a, 1, M, workspace, workspace_floats, rows_dev,
+                      stream_, src);
+}
+
+static int tn_gemm_multi(int32_t n_jobs, const KgwTnJob* jobs, kgw_stream_t stream_, KgwGradSrc* defer) {
     if (n_jobs == 0) return KGW_OK;
     if (!jobs) return KGW_E_NULL;
     if (n_jobs < 0 || n_jobs > TN_MAX_JOBS) return KGW_E_RANGE;
@@ -410,7 +447,17 @@ extern "C" int kgw_tn_gemm_multi(int32_t n_jobs, const KgwTnJob* jobs, kgw_strea
         d[q] = TnDesc{j.A, j.lda, j.M, j.B, j.ldb, j.N, j.rows, j.C, j.ldc, j.c_transposed != 0, j.colsum_a,
                       j.colsum_a ? j.colsum_repeat : 0, j.colsum_ld, j.workspace, j.workspace_floats, j.rows_dev};
     }
-    return launch_tn_jobs<2, 2>(d, n_jobs, (hipStream_t)stream_);
+    return launch_tn_jobs<2, 2>(d, n_jobs, (hipStream_t)stream_, defer);
+}
+
+extern "C" int kgw_tn_gemm_multi(int32_t n_jobs, const KgwTnJob* jobs, kgw_stream_t stream_) {
+    return tn_gemm_multi(n_jobs, jobs, stream_, nullptr);
+}
+
+// ... and of kgw_tn_gemm_multi: src holds 2 n_jobs records, [product, column sums] of every job
+extern "C" int kgw_tn_gemm_multi_partial(int32_t n_jobs, const KgwTnJob* jobs, KgwGradSrc* src, kgw_stream_t stream_) {
+    if (n_jobs > 0 && !src) return KGW_E_NULL;
+    return tn_gemm_multi(n_jobs, jobs, stream_, src);
 }
 
 extern "C" int kgw_tn_gemm(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
@@ -2031,11 +2078,12 @@ extern "C" int64_t kgw_mlp2_bwd_first_workspace_floats(int64_t rows) {
     return nblk * 4096;
 }
 
-extern "C" int kgw_mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2, int64_t ldw2, const float* H1, int64_t ldh1,
-                                  const float* X, int64_t ldx, int32_t K1, int64_t rows, const int32_t* rows_dev, float* dW1,
-                                  int64_t ldw1, float* db1, float* workspace, int64_t workspace_floats, const int32_t* in_ids,
-                                  float* dZ, int64_t ldz, kgw_stream_t stream_) {
+static int mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2, int64_t ldw2, const float* H1, int64_t ldh1,
+                          const float* X, int64_t ldx, int32_t K1, int64_t rows, const int32_t* rows_dev, float* dW1,
+                          int64_t ldw1, float* db1, float* workspace, int64_t workspace_floats, const int32_t* in_ids,
+                          float* dZ, int64_t ldz, kgw_stream_t stream_, KgwGradSrc* defer) {
     if (!dH2 || !W2 || !H1 || !db1 || !workspace) return KGW_E_NULL;
+    if (defer && K1 > 0 && ldw1 != K1) return KGW_E_UNSUPPORTED;
     if (rows <= 0 || K1 < 0) return KGW_E_RANGE;
     if (K1 > 0 && (!X || !dW1)) return KGW_E_NULL;
     if (dZ && ((ldz & 3) || !aligned16(dZ))) return KGW_E_UNSUPPORTED;
@@ -2063,9 +2111,34 @@ extern "C" int kgw_mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2
         k_mlp2_bwd_first<<<(int)nblk, 256, lds, st>>>(a);
     }
     KGW_LAUNCH_CHECK();
+    if (defer) {                  // the blocks' partials are added by kgw_adam_fused, in k_mlp2_bwd_fold's order
+        defer[0] = KgwGradSrc{};
+        defer[1] = KgwGradSrc{};
+        if (K1 > 0) { defer[0].ws = workspace; defer[0].kind = KGW_GRAD_MLP2_W; defer[0].nblk = (int)nblk; defer[0].K1 = K1; }
+        defer[1].ws = workspace; defer[1].kind = KGW_GRAD_MLP2_B; defer[1].nblk = (int)nblk; defer[1].K1 = K1;
+        return KGW_OK;
+    }
     k_mlp2_bwd_fold<<<4096 / 64, 1024, 0, st>>>(workspace, (int)nblk, K1, dW1, ldw1, db1);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
+}
+
+extern "C" int kgw_mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2, int64_t ldw2, const float* H1, int64_t ldh1,
+                                  const float* X, int64_t ldx, int32_t K1, int64_t rows, const int32_t* rows_dev, float* dW1,
+                                  int64_t ldw1, float* db1, float* workspace, int64_t workspace_floats, const int32_t* in_ids,
+                                  float* dZ, int64_t ldz, kgw_stream_t stream_) {
+    return mlp2_bwd_first(dH2, ldd, W2, ldw2, H1, ldh1, X, ldx, K1, rows, rows_dev, dW1, ldw1, db1, workspace, workspace_floats,
+                          in_ids, dZ, ldz, stream_, nullptr);
+}
+
+extern "C" int kgw_mlp2_bwd_first_partial(const float* dH2, int64_t ldd, const float* W2, int64_t ldw2, const float* H1,
+                                          int64_t ldh1, const float* X, int64_t ldx, int32_t K1, int64_t rows,
+                                          const int32_t* rows_dev, float* dW1, int64_t ldw1, float* db1, float* workspace,
+                                          int64_t workspace_floats, const int32_t* in_ids, float* dZ, int64_t ldz, KgwGradSrc* src,
+                                          kgw_stream_t stream_) {
+    if (!src) return KGW_E_NULL;
+    return mlp2_bwd_first(dH2, ldd, W2, ldw2, H1, ldh1, X, ldx, K1, rows, rows_dev, dW1, ldw1, db1, workspace, workspace_floats,
+                          in_ids, dZ, ldz, stream_, src);
 }
 
 // ======================================================================================================
@@ -2608,6 +2681,19 @@ struct AdamTab {
     int n;
 };
 
+// One element's update.  Contraction is switched off and the one fused multiply-add written out, so that every place this is
+// inlined (vector and scalar paths of k_adam, both paths of k_adam_fused) rounds identically: the fused launch must leave the
+// same bits as the unfused one.
+__device__ __forceinline__ void adam_update(float& p, float g0, float& m, float& v, float wd, float b1, float b2, float eps,
+                                            float step_size, float bc2_sqrt) {
+#pragma clang fp contract(off)
+    const float g = fmaf(wd, p, g0);
+    m = m + (1.0f - b1) * (g - m);
+    v = v * b2 + (1.0f - b2) * g * g;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = p - step_size * (m / denom);
+}
+
 // Work unit = 1024 consecutive elements of ONE tensor (256 threads x float4); the tensor of a unit is found once per
 // unit with wave-uniform (scalar) comparisons, not per element.
 __global__ void __launch_bounds__(256) k_adam(AdamTab T, int32_t* step, float lr, float b1, float b2, float eps, float wd) {
@@ -2631,25 +2717,14 @@ __global__ void __launch_bounds__(256) k_adam(AdamTab T, int32_t* step, float lr
             const float4 g0 = *(const float4*)(G + j);
             float pe[4] = {p.x, p.y, p.z, p.w}, ge[4] = {g0.x, g0.y, g0.z, g0.w}, me[4] = {m.x, m.y, m.z, m.w}, ve[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float g = fmaf(wd, pe[e], ge[e]);
-                me[e] = me[e] + (1.0f - b1) * (g - me[e]);
-                ve[e] = ve[e] * b2 + (1.0f - b2) * g * g;
-                const float denom = sqrtf(ve[e]) / bc2_sqrt + eps;
-                pe[e] = pe[e] - step_size * (me[e] / denom);
-            }
+            for (int e = 0; e < 4; ++e) adam_update(pe[e], ge[e], me[e], ve[e], wd, b1, b2, eps, step_size, bc2_sqrt);
             *(float4*)(M + j) = make_float4(me[0], me[1], me[2], me[3]);
             *(float4*)(V + j) = make_float4(ve[0], ve[1], ve[2], ve[3]);
             *(float4*)(P + j) = make_float4(pe[0], pe[1], pe[2], pe[3]);
         } else {
             for (int64_t i = j; i < n && i < j + 4; ++i) {
-                float p = P[i];
-                const float g = fmaf(wd, p, G[i]);
-                float m = M[i], v = V[i];
-                m = m + (1.0f - b1) * (g - m);
-                v = v * b2 + (1.0f - b2) * g * g;
-                const float denom = sqrtf(v) / bc2_sqrt + eps;
-                p = p - step_size * (m / denom);
+                float p = P[i], m = M[i], v = V[i];
+                adam_update(p, G[i], m, v, wd, b1, b2, eps, step_size, bc2_sqrt);
                 M[i] = m; V[i] = v; P[i] = p;
             }
         }
@@ -2703,6 +2778,244 @@ extern "C" int kgw_adam_notick(int32_t n_tensors, float* const* params, const fl
                                float beta2, float eps, float weight_decay, kgw_stream_t stream_) {
     return adam_launch(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, step_dev, lr, beta1, beta2, eps, weight_decay, false,
                        stream_);
+}
+
+// ======================================================================================================
+// kgw_adam_fused: the optimiser launch of a captured step.  On top of k_adam:
+//   * gradients whose producers stopped after their first launch (kgw_tn_gemm_partial, kgw_mlp2_bwd_first_partial) are
+//     finished here: a work unit of such a tensor is 64 of its elements x 4 groups of partial records, added in the SAME order
+//     as k_tn_reduce / k_mlp2_bwd_fold (bit-identical gradients), then updated by the lanes that hold the sums.  Five
+//     ~7 us launches of the 47-launch step disappear into this one;
+//   * the block that finishes last (a device counter) advances the step counter and accumulates the running totals of
+//     kgw_accumulate_stats_tick -- every other block has read the counter by then.
+// ======================================================================================================
+namespace {
+
+struct AdamFTab {
+    float* p[KGW_ADAM_FUSED_MAX]; float* g[KGW_ADAM_FUSED_MAX]; float* m[KGW_ADAM_FUSED_MAX]; float* v[KGW_ADAM_FUSED_MAX];
+    int64_t off[KGW_ADAM_FUSED_MAX + 1];
+    int64_t coff[KGW_ADAM_FUSED_MAX + 1];     // prefix sums of work units (1024 elements of a direct tensor, 64 of a sourced one)
+    unsigned char vec[KGW_ADAM_FUSED_MAX];
+    unsigned char src_of[KGW_ADAM_FUSED_MAX]; // index into src, 255 = the gradient tensor holds the gradient
+    KgwGradSrc src[KGW_ADAM_FUSED_SRC];
+    int n;
+};
+struct AdamTail { const KgwBatchMeta* meta; int64_t* stats; int32_t* done; int n_layers, n_hops; };
+
+// sum over the partial records of element i of a sourced gradient; every thread of the block calls it (fl = element within the
+// unit, G = group of records); the value is returned to the threads with G == 0
+__device__ __forceinline__ float adam_src_sum(const KgwGradSrc& S, int64_t i, bool valid, int fl, int G, float* sm) {
+    const int nblk = S.nblk;
+    if (S.kind == KGW_GRAD_TN) {
+        const int MT = S.MT, NT = S.NT;
+        const int64_t FRAG = (int64_t)MT * NT * 1024;
+        int m, n;
+        if (!S.c_transposed) { m = (int)(i / S.N); n = (int)(i - (int64_t)m * S.N); }
+        else                 { n = (int)(i / S.M); m = (int)(i - (int64_t)n * S.M); }
+        const int by = m / (32 * MT), rm = m - by * 32 * MT, ta = rm % MT, ti = rm / MT;
+        const int bz = n / (32 * NT), rn = n - bz * 32 * NT, tb = rn % NT, tj = rn / NT;
+        const int lane = tj + 32 * ((ti >> 2) & 1), e = (ti & 3) + 4 * (ti >> 3);
+        const float* p = S.ws + ((int64_t)bz * S.gy + by) * nblk * FRAG + ((ta * NT + tb) * 16 + e) * 64 + lane;
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            int b = G;
+            for (; b + 28 < nblk; b += 32) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s8[q] += p[(int64_t)(b + 4 * q) * FRAG];
+            }
+            for (int q = 0; b < nblk; b += 4, ++q) s8[q & 7] += p[(int64_t)b * FRAG];
+        }
+        sm[G * 64 + fl] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+        __syncthreads();
+        return (sm[fl] + sm[64 + fl]) + (sm[128 + fl] + sm[192 + fl]);
+    }
+    if (S.kind == KGW_GRAD_TN_COLSUM) {
+        const int NC = 32 * S.MT, NG = 256 / NC;
+        const int m = (int)i, by = m / NC, c = m - by * NC;
+        const float* p = S.ws + (int64_t)by * nblk * NC + c;
+        for (int gq = G; gq < NG; gq += 4) {
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (valid) {
+                int b = gq;
+                for (; b + 3 * NG < nblk; b += 4 * NG) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) s4[q] += p[(int64_t)(b + q * NG) * NC];
+                }
+                for (int q = 0; b < nblk; b += NG, ++q) s4[q & 3] += p[(int64_t)b * NC];
+            }
+            sm[gq * 64 + fl] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        }
+        __syncthreads();
+        float t = 0.f;
+        for (int q = 0; q < NG; ++q) t += sm[q * 64 + fl];
+        return t;
+    }
+    // KGW_GRAD_MLP2_W / _B: fragment (t * 16 + e) * 64 + lane of a block's 4096-float record holds
+    // C[k = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)][col = 32 t + (lane & 31)]; d W1[col][k] for k < K1, d b1[col] at k == K1
+    {
+        int col, k;
+        if (S.kind == KGW_GRAD_MLP2_W) { col = (int)(i / S.K1); k = (int)(i - (int64_t)col * S.K1); }
+        else                           { col = (int)i; k = S.K1; }
+        const int t = col >> 5, lane = (col & 31) + 32 * ((k >> 2) & 1), e = (k & 3) + 4 * (k >> 3);
+        const float* p = S.ws + (t * 16 + e) * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int gg = G + 4 * u;
+            // (k_mlp2_bwd_fold's order -- accumulator j takes records gg + 16 j, gg + 16 (j + 4), ... -- with the four loads of a
+            //  round independent of each other: written as ``s4[q & 3]`` the loop is one dependent load after the other)
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (valid) {
+                int b = gg;
+                for (; b + 48 < nblk; b += 64) {
+                    float x[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[j] = p[(int64_t)(b + 16 * j) * 4096];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s4[j] += x[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (b + 16 * j < nblk) s4[j] += p[(int64_t)(b + 16 * j) * 4096];
+            }
+            sm[gg * 64 + fl] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        }
+        __syncthreads();
+        float sv = 0.f;
+#pragma unroll
+        for (int k4 = 0; k4 < 16; k4 += 4) sv += (sm[k4 * 64 + fl] + sm[(k4 + 1) * 64 + fl]) + (sm[(k4 + 2) * 64 + fl] + sm[(k4 + 3) * 64 + fl]);
+        return sv;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_adam_fused(AdamFTab T, AdamTail Z, int32_t* step, float lr, float b1, float b2, float eps,
+                                                    float wd) {
+    __shared__ float sm[16 * 64];
+    const int t_now = *step + 1;                       // (the counter moves only after every block has arrived at the end)
+    const float bc1 = 1.0f - powf(b1, (float)t_now);
+    const float bc2 = 1.0f - powf(b2, (float)t_now);
+    const float step_size = lr / bc1;
+    const float bc2_sqrt = sqrtf(bc2);
+    const int64_t units = T.coff[T.n];
+    const int fl = threadIdx.x & 63, G = threadIdx.x >> 6;
+    for (int64_t c = blockIdx.x; c < units; c += gridDim.x) {
+        int lo = 0, hi = T.n;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (T.coff[mid] <= c) lo = mid; else hi = mid; }
+        const int64_t n = T.off[lo + 1] - T.off[lo];
+        float* __restrict__ P = T.p[lo];
+        float* __restrict__ Gr = T.g[lo];
+        float* __restrict__ M = T.m[lo];
+        float* __restrict__ V = T.v[lo];
+        const int si = T.src_of[lo];
+        if (si != 255) {
+            const int64_t i = (c - T.coff[lo]) * 64 + fl;
+            const bool valid = i < n;
+            const float gs = adam_src_sum(T.src[si], i, valid, fl, G, sm);
+            if (G == 0 && valid) {
+                Gr[i] = gs;
+                float p = P[i], m = M[i], v = V[i];
+                adam_update(p, gs, m, v, wd, b1, b2, eps, step_size, bc2_sqrt);
+                M[i] = m; V[i] = v; P[i] = p;
+            }
+            __syncthreads();                           // (sm is reused by the block's next unit)
+            continue;
+        }
+        const int64_t j = (c - T.coff[lo]) * 1024 + (int64_t)threadIdx.x * 4;
+        if (j + 4 <= n && T.vec[lo]) {
+            float4 p = *(float4*)(P + j), m = *(float4*)(M + j), v = *(float4*)(V + j);
+            const float4 g0 = *(const float4*)(Gr + j);
+            float pe[4] = {p.x, p.y, p.z, p.w}, ge[4] = {g0.x, g0.y, g0.z, g0.w}, me[4] = {m.x, m.y, m.z, m.w}, ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) adam_update(pe[e], ge[e], me[e], ve[e], wd, b1, b2, eps, step_size, bc2_sqrt);
+            *(float4*)(M + j) = make_float4(me[0], me[1], me[2], me[3]);
+            *(float4*)(V + j) = make_float4(ve[0], ve[1], ve[2], ve[3]);
+            *(float4*)(P + j) = make_float4(pe[0], pe[1], pe[2], pe[3]);
+        } else {
+            for (int64_t i = j; i < n && i < j + 4; ++i) {
+                float p = P[i], m = M[i], v = V[i];
+                adam_update(p, Gr[i], m, v, wd, b1, b2, eps, step_size, bc2_sqrt);
+                M[i] = m; V[i] = v; P[i] = p;
+            }
+        }
+    }
+    // the last block to get here: step counter + running totals (k_accumulate_stats).  Two levels of counters, each on a
+    // 128-byte line of its own: same-address device atomics are served one at a time (~20 ns each: 2 600 blocks on ONE counter
+    // made this launch 55 us long), 64 first-level counters take <= grid / 64 arrivals each and the block that completes one moves
+    // on to the top counter (64 arrivals).  Relaxed on purpose -- an acquire / release at agent scope is an L2 write-back +
+    // invalidate per block on this multi-die part (135 us for the launch); nothing is published through the counters: the only
+    // ordering needed is "every block has READ *step before the last one writes it", each block's read was consumed before its
+    // atomic is issued, and the last block's store depends on the values its atomics return.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int slot = (int)(blockIdx.x & 63), in_slot = ((int)gridDim.x - slot + 63) >> 6;
+        const int n_slots = (int)gridDim.x < 64 ? (int)gridDim.x : 64;
+        int32_t* c1 = Z.done + 32 * (1 + slot);
+        if (__hip_atomic_fetch_add(c1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_slot - 1) {
+            __hip_atomic_store(c1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(Z.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_slots - 1) {
+                __hip_atomic_store(Z.done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *step = t_now;
+                if (Z.meta) {
+                    const KgwBatchMeta* Mt = Z.meta;
+                    for (int t = 0; t < Z.n_layers; ++t) Z.stats[t] += Mt->n_edges[t];
+                    Z.stats[Z.n_layers] += Mt->edge_end[Z.n_hops - 1];
+                    Z.stats[Z.n_layers + 1] |= Mt->error;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int kgw_adam_fused(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                              float* const* exp_avg_sq, const int64_t* numel, const KgwGradSrc* src, int32_t* step_dev, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, const KgwBatchMeta* meta_dev,
+                              int32_t n_layers, int32_t n_hops, int64_t* stats, int32_t* done_counter, kgw_stream_t stream_) {
+    if (n_tensors < 0 || n_tensors > KGW_ADAM_FUSED_MAX) return KGW_E_RANGE;
+    if (!step_dev || !done_counter) return KGW_E_NULL;
+    if (n_tensors > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numel)) return KGW_E_NULL;
+    if (meta_dev && (!stats || n_layers < 1 || n_layers > KGW_MAX_LAYERS || n_hops < 1 || n_hops > n_layers)) return KGW_E_RANGE;
+    AdamFTab T;
+    T.n = n_tensors;
+    T.off[0] = 0;
+    T.coff[0] = 0;
+    int nsrc = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] < 0) return KGW_E_NULL;
+        T.p[i] = params[i]; T.g[i] = grads[i]; T.m[i] = exp_avg[i]; T.v[i] = exp_avg_sq[i];
+        T.src_of[i] = 255;
+        int64_t per = 1024;
+        if (src && src[i].kind != KGW_GRAD_DIRECT) {
+            const KgwGradSrc& S = src[i];
+            if (nsrc >= KGW_ADAM_FUSED_SRC) return KGW_E_RANGE;
+            if (!S.ws || S.nblk < 1) return KGW_E_NULL;
+            // the record must describe exactly this tensor
+            if (S.kind == KGW_GRAD_TN) {
+                if (S.MT < 1 || S.NT < 1 || S.MT * S.NT > 16 || (256 % (32 * S.MT)) || (int64_t)S.M * S.N != numel[i]) return KGW_E_RANGE;
+            } else if (S.kind == KGW_GRAD_TN_COLSUM) {
+                if (S.MT < 1 || (256 % (32 * S.MT)) || S.M != numel[i]) return KGW_E_RANGE;
+            } else if (S.kind == KGW_GRAD_MLP2_W) {
+                if (S.K1 < 1 || S.K1 > 31 || (int64_t)128 * S.K1 != numel[i]) return KGW_E_RANGE;
+            } else if (S.kind == KGW_GRAD_MLP2_B) {
+                if (S.K1 < 0 || S.K1 > 31 || numel[i] != 128) return KGW_E_RANGE;
+            } else {
+                return KGW_E_RANGE;
+            }
+            T.src[nsrc] = S;
+            T.src_of[i] = (unsigned char)nsrc++;
+            per = 64;
+        }
+        T.off[i + 1] = T.off[i] + numel[i];
+        T.coff[i + 1] = T.coff[i] + (numel[i] + per - 1) / per;
+        T.vec[i] = (((uintptr_t)params[i] | (uintptr_t)grads[i] | (uintptr_t)exp_avg[i] | (uintptr_t)exp_avg_sq[i]) & 15) == 0;
+    }
+    AdamTail Z{meta_dev, stats, done_counter, n_layers, n_hops};
+    int64_t g = T.coff[n_tensors];
+    if (g > 4 * KGW_GRID) g = 4 * KGW_GRID;
+    if (g < 1) g = 1;
+    k_adam_fused<<<(int)g, 256, 0, (hipStream_t)stream_>>>(T, Z, step_dev, lr, beta1, beta2, eps, weight_decay);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
 }
 
 // ======================================================================================================

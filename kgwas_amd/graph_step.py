@@ -92,6 +92,10 @@ class GraphTrainStep:
         # first half (every relation pack, the read-out, the folded FC_output: ~3.9 MB) are all-reduced on a side stream
         # while the second half (the MLPs' backward: ~45 % of the backward's time, incl. the 5120-wide gene dW product)
         # runs; only the MLPs' own bucket (~2.7 MB) is reduced in the open.
+        # single GPU, optimiser inside the graph: the partial-sum folds of the weight gradients, Adam and the statistics as one launch
+        self.fused_adam = (ops._FUSED_ADAM and self.capture_optimizer and not self._multi and
+                           sum(1 for p in self.model.parameters() if p.requires_grad) <= _lib.ADAM_FUSED_MAX)
+        self.deferred_gradients = 0
         self.split_backward = self._multi and os.environ.get('KGW_SPLIT_BACKWARD', '1') == '1'
         # multi-rank, optional: the first gene Linear over the resident feature matrix (forward + weight gradient: 0.27 of the
         # step's 1.2 ms, identical work on every rank) split by gene rows over the ranks -- ops.GeneLayerShard in its STAGED form:
@@ -181,7 +185,19 @@ class GraphTrainStep:
             loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id(self.input_type),
                                               self.dg.y[self.input_type], self.ld_w, unit_grad=True,
                                               param_branch=self.param_branch)                # kgwas.py:137-145
-            loss.backward(gradient=self._unit)                         # (a resident 1.0: no ones_like fill per step)
+            # fused optimiser launch: the weight-gradient products that feed only Adam stop after their first launch, their last
+            # sums, the update, the step counter and the running totals are ONE launch (ops.GradSink, kgw_adam_fused)
+            sink = ops.GradSink() if self.fused_adam else None
+            with ops.grad_sink_scope(sink):
+                loss.backward(gradient=self._unit)                     # (a resident 1.0: no ones_like fill per step)
+            if sink is not None:
+                self.deferred_gradients = len(sink.records)            # (gradients whose last sums the optimiser launch takes)
+                self.opt.step_fused(sink, buf.meta.data_ptr(), self.run.gnn_num_layers, self.dg.n_hops, self.stats)
+                if self.overlap:
+                    main.wait_stream(self._side)                       # join
+                elif not self.twin:
+                    sample_into(self.dg, self.bufs[1 - cur], self.seeds, self.seed_type, record=False)
+                return loss
         ticked = False
         if self.capture_optimizer:
             self.opt.step(tick=False)                                  # (the counter advances in the statistics launch below)
@@ -280,7 +296,13 @@ class GraphTrainStep:
                 if gs is not None:
                     gs.forward_partial(*gs.last)
                     gs.gather()
-                self._step_body(k % 2)
+                try:
+                    self._step_body(k % 2)
+                except ops.GradSinkMismatch as e:             # (raised before the optimiser launch: nothing was updated)
+                    print(f'kgwas_amd: fused optimiser launch not used ({e})', file=sys.stderr)
+                    self.fused_adam = False
+                    self.opt.zero_grad(set_to_none=True)
+                    self._step_body(k % 2)
                 if self.split_backward:
                     self._step_body_b(k % 2)
                 if gs is not None:

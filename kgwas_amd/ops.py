@@ -151,6 +151,54 @@ class KernelTimer:
 TIMER = KernelTimer()
 
 
+class GradSinkMismatch(RuntimeError):
+    """A gradient whose last reduction was left to the optimiser's launch did not arrive at a parameter as the tensor its producer
+    wrote the record for (autograd copied or accumulated it): the fused optimiser launch cannot be used for this model."""
+
+
+class GradSink:
+    """While one is active (``grad_sink_scope``: the backward pass of a captured single-GPU training step), the weight-gradient
+    products that feed NOTHING but the optimiser stop after their first launch and leave a KgwGradSrc record here, keyed by the
+    address of the gradient tensor they return to autograd; ``FusedAdam.step_fused`` looks every parameter's ``.grad`` up, finishes
+    the sums inside the optimiser's own launch (kgw_adam_fused: same order, bit-identical values, the gradient tensors filled in
+    as a by-product) and fails loudly if a record is left over.  The records keep the partial-sum workspaces alive -- inside a
+    graph capture a freed block would be handed to the next allocation of the same capture."""
+
+    def __init__(self):
+        self.records = {}           # data_ptr of the gradient tensor -> (KgwGradSrc, numel, workspace)
+
+    def add(self, grad: torch.Tensor, src, ws: torch.Tensor):
+        if src.kind != 0:           # (KGW_GRAD_DIRECT: the producer finished the tensor itself)
+            rec = _lib.KgwGradSrc()
+            C.memmove(C.byref(rec), C.byref(src), C.sizeof(rec))
+            self.records[grad.data_ptr()] = (rec, grad.numel(), ws)      # (NOT the tensor: autograd must be able to steal it)
+
+    def take(self, grad: torch.Tensor):
+        rec = self.records.pop(grad.data_ptr(), None)
+        if rec is not None and rec[1] != grad.numel():
+            raise GradSinkMismatch('a deferred gradient record does not describe the tensor found at its address')
+        return rec
+
+
+GRAD_SINK = None           # the GradSink of the backward pass being issued, or None (every product finishes its own sums)
+_FUSED_ADAM = os.environ.get('KGW_FUSED_ADAM', '1') != '0'         # 0: k_tn_reduce / k_mlp2_bwd_fold / stats as launches of their own
+
+
+class grad_sink_scope:
+    def __init__(self, sink):
+        self.sink = sink
+
+    def __enter__(self):
+        global GRAD_SINK
+        self.prev, GRAD_SINK = GRAD_SINK, self.sink
+        return self.sink
+
+    def __exit__(self, *exc):
+        global GRAD_SINK
+        GRAD_SINK = self.prev
+        return False
+
+
 _MLP2_FUSED = os.environ.get('KGW_MLP2_FUSED', '1') != '0'        # 0: the two hidden layers of a narrow MLP as two launches
 _TN_GROUP = os.environ.get('KGW_TN_GROUP', '1') != '0'             # 0: one launch pair per destination type in the transform's backward
 _DUV_RIDERS = os.environ.get('KGW_DUV_RIDERS', '1') != '0'        # 0: d u_r / d v_r through the [d a_src | d a_dst] rows + product
@@ -366,7 +414,7 @@ _TN_MIN_ROWS = 1024       # below this a library GEMM is fine
 
 
 def tn_gemm(A: torch.Tensor, B: torch.Tensor, colsum: bool = False, out: torch.Tensor = None,
-            transpose_out: bool = False, colsum_out: torch.Tensor = None, rows_dev: torch.Tensor = None):
+            transpose_out: bool = False, colsum_out: torch.Tensor = None, rows_dev: torch.Tensor = None, defer: bool = False):
     """C = A^T @ B for tall row-major A [rows, M], B [rows, N] (fp32, inner stride 1); optionally also the
     column sums of A.  Deterministic split-K on fp32 MFMA.  ``out``: write C (or C^T with ``transpose_out``) into
     this row-major 2-D view instead of a new tensor; ``colsum_out`` [q, M]: write the column sums into each of its
@@ -398,6 +446,18 @@ def tn_gemm(A: torch.Tensor, B: torch.Tensor, colsum: bool = False, out: torch.T
     L = _lib.lib()
     nws = int(L.kgw_tn_gemm_workspace_floats(rows, M, N))
     ws = torch.empty(nws, device=dev)
+    sink = GRAD_SINK
+    if defer and sink is not None and colsum_out is None and out.is_contiguous():
+        # ``defer``: the caller hands (out, cs) to autograd as the gradients of two parameters and nothing else reads them before
+        # the optimiser: the row blocks' partial sums are added inside its launch (GradSink)
+        src = (_lib.KgwGradSrc * 2)()
+        _lib.check(L.kgw_tn_gemm_partial(_p(A), A.stride(0), M, _p(B), B.stride(0), N, rows, _p(out), out.stride(0),
+                                         1 if transpose_out else 0, _p(cs), _p(ws), nws, _p(rows_dev), src, _lib.stream_ptr()),
+                   'kgw_tn_gemm_partial')
+        sink.add(out, src[0], ws)
+        if cs is not None:
+            sink.add(cs, src[1], ws)
+        return (out, cs) if colsum else out
     _lib.check(L.kgw_tn_gemm_ex(_p(A), A.stride(0), M, _p(B), B.stride(0), N, rows, _p(out), out.stride(0),
                                 1 if transpose_out else 0, _p(cs), rep, cs_ld, _p(ws), nws, _p(rows_dev), _lib.stream_ptr()),
                'kgw_tn_gemm_ex')
@@ -461,6 +521,14 @@ def weight_grads(pairs, rows_dev: torch.Tensor = None):
         j.workspace, j.workspace_floats, j.rows_dev = _p(ws), nws, _p(rows_dev)
         j.M, j.N, j.c_transposed, j.colsum_repeat = M, N, 0, 1
         outs.append((dW, db))
+    sink = GRAD_SINK
+    if sink is not None:            # (every caller returns these to autograd as parameter gradients: see tn_gemm(defer=True))
+        src = (_lib.KgwGradSrc * (2 * len(pairs)))()
+        _lib.check(L.kgw_tn_gemm_multi_partial(len(pairs), jobs, src, _lib.stream_ptr()), 'kgw_tn_gemm_multi_partial')
+        for q, (dW, db) in enumerate(outs):
+            sink.add(dW, src[2 * q], keep[q])
+            sink.add(db, src[2 * q + 1], keep[q])
+        return outs
     _lib.check(L.kgw_tn_gemm_multi(len(pairs), jobs, _lib.stream_ptr()), 'kgw_tn_gemm_multi')
     return outs
 
@@ -1030,8 +1098,17 @@ class _MLP2(torch.autograd.Function):
             db1 = torch.empty(KGW_C, device=x.device)
             nws = int(L.kgw_mlp2_bwd_first_workspace_floats(rows))
             ws = torch.empty(nws, device=x.device)
-            _lib.check(L.kgw_mlp2_bwd_first(_p(dh2), dh2.stride(0), _p(W2), W2.stride(0), _p(h1), h1.stride(0), _p(x), x.stride(0), K1,
-                                            rows, _p(rd), _p(dW1), K1, _p(db1), _p(ws), nws, None, None, 0, _lib.stream_ptr()), 'kgw_mlp2_bwd_first')
+            sink = GRAD_SINK
+            if sink is not None:        # the blocks' partial d W1 / d b1 are added inside the optimiser's launch (GradSink)
+                src = (_lib.KgwGradSrc * 2)()
+                _lib.check(L.kgw_mlp2_bwd_first_partial(_p(dh2), dh2.stride(0), _p(W2), W2.stride(0), _p(h1), h1.stride(0), _p(x), x.stride(0),
+                                                        K1, rows, _p(rd), _p(dW1), K1, _p(db1), _p(ws), nws, None, None, 0, src,
+                                                        _lib.stream_ptr()), 'kgw_mlp2_bwd_first_partial')
+                sink.add(dW1, src[0], ws)
+                sink.add(db1, src[1], ws)
+            else:
+                _lib.check(L.kgw_mlp2_bwd_first(_p(dh2), dh2.stride(0), _p(W2), W2.stride(0), _p(h1), h1.stride(0), _p(x), x.stride(0), K1,
+                                                rows, _p(rd), _p(dW1), K1, _p(db1), _p(ws), nws, None, None, 0, _lib.stream_ptr()), 'kgw_mlp2_bwd_first')
             dW2, db2 = linear_weight_grad(dh2, h1, rows_dev=rd)
             return None, dW1, db1, dW2, db2, None, None, None
         dh1 = linear(dh2, W2, mask=h1, w_kn=True, rows_dev=rd)   # (dh2 @ W2) * (h1 > 0)
@@ -1212,8 +1289,16 @@ class _ResidentMLP2(torch.autograd.Function):
         db1 = torch.empty(KGW_C, device=h.device)
         nws = int(L.kgw_mlp2_bwd_first_workspace_floats(N))
         ws = torch.empty(nws, device=h.device)
-        _lib.check(L.kgw_mlp2_bwd_first(_p(dh2), dh2.stride(0), _p(W2), W2.stride(0), _p(h), h.stride(0), None, 0, 0, N, None, None, 0,
-                                        _p(db1), _p(ws), nws, _p(g2l), _p(dz), dz.stride(0), _lib.stream_ptr()), 'kgw_mlp2_bwd_first')
+        sink = GRAD_SINK
+        if sink is not None:
+            src = (_lib.KgwGradSrc * 2)()
+            _lib.check(L.kgw_mlp2_bwd_first_partial(_p(dh2), dh2.stride(0), _p(W2), W2.stride(0), _p(h), h.stride(0), None, 0, 0, N, None,
+                                                    None, 0, _p(db1), _p(ws), nws, _p(g2l), _p(dz), dz.stride(0), src, _lib.stream_ptr()),
+                       'kgw_mlp2_bwd_first_partial')
+            sink.add(db1, src[1], ws)
+        else:
+            _lib.check(L.kgw_mlp2_bwd_first(_p(dh2), dh2.stride(0), _p(W2), W2.stride(0), _p(h), h.stride(0), None, 0, 0, N, None, None, 0,
+                                            _p(db1), _p(ws), nws, _p(g2l), _p(dz), dz.stride(0), _lib.stream_ptr()), 'kgw_mlp2_bwd_first')
         dW1 = resident_first_weight_grad(dz, X, W1, ctx.shard)
         dW2, db2 = linear_weight_grad(dh2, h1g)
         return None, dW1, db1, dW2, db2, None, None, None, None
@@ -1265,7 +1350,7 @@ def linear_weight_grad(dY: torch.Tensor, X: torch.Tensor, fixed_shape: bool = Fa
     """(dW [out,in], db [out]) of Y = X W^T + b given dY [rows,out], X [rows,in]."""
     rows, K = X.shape
     if (rows >= _TN_MIN_ROWS and K <= 1024) or (LIBRARY_GEMM.own_first and rows > 0 and X.dtype == torch.float32):
-        return tn_gemm(dY, X, colsum=True, rows_dev=rows_dev)
+        return tn_gemm(dY, X, colsum=True, rows_dev=rows_dev, defer=True)      # (callers: parameter gradients only)
     LIBRARY_GEMM.note('linear_weight_grad', rows, dY.shape[1], K)
     if fixed_shape:
         with _TUNED:

@@ -39,6 +39,47 @@ class FusedAdam:
                 self._state(p)
 
     @torch.no_grad()
+    def step_fused(self, sink, meta_ptr=None, n_layers=0, n_hops=0, stats=None):
+        """The optimiser launch of a captured single-GPU step (kgw_adam_fused): the update of every parameter that has a gradient,
+        the last reduction of the gradients whose producers left partial sums with ``sink`` (ops.GradSink), the step counter and
+        -- ``meta_ptr``: device KgwBatchMeta of the batch, ``stats``: the trainer's int64 totals -- kgw_accumulate_stats_tick, in ONE
+        launch.  Raises ops.GradSinkMismatch (nothing launched) when the fused form does not apply; the caller then runs the
+        unfused step."""
+        from . import ops
+        live = [p for p in self.params if p.grad is not None]
+        recs = {}
+        for p in live:
+            r = sink.take(p.grad) if sink is not None else None
+            if r is not None:
+                recs[p] = r
+        if sink is not None and sink.records:
+            n = len(sink.records)
+            sink.records.clear()
+            raise ops.GradSinkMismatch(f'{n} deferred gradient(s) did not reach a parameter as written')
+        if len(live) > _lib.ADAM_FUSED_MAX or len(recs) > _lib.ADAM_FUSED_SRC:
+            raise ops.GradSinkMismatch(f'{len(live)} tensors / {len(recs)} deferred gradients exceed the fused launch\'s tables')
+        live.sort(key=lambda p: 0 if p in recs else 1)           # the longer work units first
+        n = len(live)
+        if not hasattr(self, 'done_dev'):
+            self.done_dev = torch.zeros(_lib.ADAM_FUSED_COUNTERS, dtype=torch.int32, device=self.step_dev.device)
+        P = (C.c_void_p * n)(); G = (C.c_void_p * n)(); M = (C.c_void_p * n)(); V = (C.c_void_p * n)()
+        N = (C.c_int64 * n)()
+        S = (_lib.KgwGradSrc * max(n, 1))()
+        for k, p in enumerate(live):
+            g = p.grad
+            if not (p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32 and g.dtype == torch.float32):
+                raise _lib.KgwasHipError('FusedAdam needs contiguous fp32 parameters and gradients')
+            st = self._state(p)
+            P[k], G[k], M[k], V[k], N[k] = p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel()
+            if p in recs:
+                C.memmove(C.byref(S[k]), C.byref(recs[p][0]), C.sizeof(_lib.KgwGradSrc))
+        rc = _lib.lib().kgw_adam_fused(n, P, G, M, V, N, S, self.step_dev.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps,
+                                       self.weight_decay, meta_ptr, n_layers, n_hops, stats.data_ptr() if stats is not None else None,
+                                       self.done_dev.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, 'kgw_adam_fused')
+        # (``recs`` -- and with it the partial-sum workspaces -- lives until here: the launch that reads them is enqueued)
+
+    @torch.no_grad()
     def step(self, grads=None, tick=True):
         """``grads``: optional {parameter: gradient tensor} to use instead of ``p.grad`` (the all-reduced bucket's
         views in the multi-GPU step); parameters missing from it are skipped.  ``tick=False``: the caller advances

@@ -1,0 +1,157 @@
+"""-m gpu: the fused optimiser launch (kgw_adam_fused; kgwas/kgwas.py:116,151 = torch.optim.Adam with L2 weight decay).
+
+The weight-gradient products that feed only Adam (the Linears of kgwas/model.py:13-21) may stop after their first launch and
+leave per-block partial sums; kgw_adam_fused finishes the sums in the producers' own order while it updates the parameters.  The
+bar is BIT-IDENTITY with the unfused path (kgw_tn_gemm_ex / kgw_mlp2_bwd_first + kgw_adam): gradients left in the gradient
+tensors, parameters, both Adam moments, the step counter -- and, one level up, the whole captured training step."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+
+
+def _adam_pair(shapes, seed):
+    from kgwas_amd.optim import FusedAdam
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    a = [torch.randn(*s, generator=g).to(DEV).requires_grad_() for s in shapes]
+    b = [p.detach().clone().requires_grad_() for p in a]
+    return a, b, FusedAdam(a, lr=1e-2, weight_decay=5e-4), FusedAdam(b, lr=1e-2, weight_decay=5e-4)
+
+
+def _same_state(pa, pb, oa, ob):
+    for k, (x, y) in enumerate(zip(pa, pb)):
+        assert torch.equal(x.grad, y.grad), (k, float((x.grad - y.grad).abs().max()), int((x.grad != y.grad).sum()))
+        assert torch.equal(x, y), (k, float((x - y).abs().max()), int((x != y).sum()))
+        assert torch.equal(oa.state[x]['exp_avg'], ob.state[y]['exp_avg'])
+        assert torch.equal(oa.state[x]['exp_avg_sq'], ob.state[y]['exp_avg_sq'])
+    assert int(oa.step_dev) == int(ob.step_dev)
+
+
+# rows x M x N of C = A^T B: the step's own shapes (122 k sampled SNPs, 20 k genes: 128 x 128 on the <2,2> tiling), a narrow B
+# (<2,1>), a narrow A (<1,4>, <1,2>), odd sizes (<1,1>), a product with a single row block (finished by its producer)
+@pytest.mark.parametrize('rows,M,N,tr', [(122880, 128, 128, False), (20032, 128, 128, True), (40000, 128, 20, False),
+                                         (30000, 6, 128, False), (30000, 6, 66, True), (9000, 5, 7, False), (200, 128, 128, False)])
+def test_tn_partial_sums_finished_by_adam(rows, M, N, tr):
+    from kgwas_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(rows + M)
+    A = torch.randn(rows, M, generator=g).to(DEV)
+    B = torch.randn(rows, N, generator=g).to(DEV)
+    shape = (N, M) if tr else (M, N)
+    pa, pb, oa, ob = _adam_pair([shape, (M,)], 3)
+    for step in range(3):
+        ref, ref_cs = ops.tn_gemm(A, B, colsum=True, transpose_out=tr)
+        sink = ops.GradSink()
+        with ops.grad_sink_scope(sink):
+            out, cs = ops.tn_gemm(A, B, colsum=True, transpose_out=tr, defer=True)
+        if rows > 1024:
+            assert len(sink.records) == 2                 # both gradients wait for the optimiser
+        pa[0].grad, pa[1].grad = out, cs
+        pb[0].grad, pb[1].grad = ref, ref_cs
+        oa.step_fused(sink)
+        ob.step()
+        assert not sink.records
+        _same_state(pa, pb, oa, ob)
+        A = A * 0.5 + 0.1
+    assert int(oa.step_dev) == 3 and int(oa.done_dev.abs().sum()) == 0
+
+
+def test_grouped_products_and_leftover_record():
+    from kgwas_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(5)
+    rows = 9000
+    dY1, X1 = torch.randn(rows, 128, generator=g).to(DEV), torch.randn(rows, 128, generator=g).to(DEV)
+    dY2, X2 = torch.randn(rows, 128, generator=g).to(DEV), torch.randn(rows, 64, generator=g).to(DEV)
+    pa, pb, oa, ob = _adam_pair([(128, 128), (128,), (128, 64), (128,)], 9)
+    ref = ops.weight_grads([(dY1, X1), (dY2, X2)])
+    sink = ops.GradSink()
+    with ops.grad_sink_scope(sink):
+        got = ops.weight_grads([(dY1, X1), (dY2, X2)])
+    assert len(sink.records) == 4
+    for k in range(2):
+        pa[2 * k].grad, pa[2 * k + 1].grad = got[k]
+        pb[2 * k].grad, pb[2 * k + 1].grad = ref[k]
+    oa.step_fused(sink)
+    ob.step()
+    _same_state(pa, pb, oa, ob)
+    # a record nobody claims (autograd copied the gradient, or it never reached a parameter): loud, and nothing is launched
+    sink = ops.GradSink()
+    with ops.grad_sink_scope(sink):
+        out, cs = ops.tn_gemm(dY1, X1, colsum=True, defer=True)
+    before = [p.detach().clone() for p in pa]
+    pa[0].grad, pa[1].grad = out.clone(), cs
+    with pytest.raises(ops.GradSinkMismatch):
+        oa.step_fused(sink)
+    for p, q in zip(pa, before):
+        assert torch.equal(p, q)
+
+
+@pytest.mark.parametrize('rows,K1', [(40000, 20), (16384, 4), (122880, 20)])
+def test_mlp2_first_layer_partials_finished_by_adam(rows, K1):
+    """_MLP2's backward (kgwas/model.py:18-20 on the 20-wide SNP features): d W1 / d b1 from kgw_mlp2_bwd_first's block partials,
+    d W2 / d b2 from the split-K product's -- all four finished inside kgw_adam_fused."""
+    from kgwas_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(rows)
+    x = torch.rand(rows, K1, generator=g).to(DEV)
+    dh2 = (torch.randn(rows, 128, generator=g) * (torch.rand(rows, 128, generator=g) > 0.5)).to(DEV)
+    shapes = [(128, K1), (128,), (128, 128), (128,)]
+    pa, pb, oa, ob = _adam_pair(shapes, 21)
+    with torch.no_grad():
+        for ps in (pa, pb):
+            ps[0].mul_(0.3); ps[2].mul_(0.1)
+    for step in range(2):
+        for ps, opt, fused in ((pa, oa, True), (pb, ob, False)):
+            opt.zero_grad(set_to_none=True)
+            h2 = ops.mlp2(x, *ps)
+            sink = ops.GradSink() if fused else None
+            with ops.grad_sink_scope(sink):
+                h2.backward(dh2)
+            if fused:
+                assert len(sink.records) == 4
+                opt.step_fused(sink)
+            else:
+                opt.step()
+        _same_state(pa, pb, oa, ob)
+
+
+@pytest.mark.parametrize('size', ['small', 'medium'])
+def test_fused_step_equals_unfused_step(small_kg, monkeypatch, size):
+    """The captured training step with the fused optimiser launch == the same step with the folds, Adam and the statistics as
+    launches of their own: losses, every parameter, the running totals -- bit for bit.  ``medium`` (10 % of the benchmark graph,
+    256 seeds: tens of thousands of sampled SNP rows) makes the MLPs' weight gradients multi-block products, so the deferred sums
+    are really taken by the optimiser's launch; ``small`` has single-block products (only the counters move into the launch)."""
+    from kgwas_amd import ops
+    from kgwas_amd.graph_step import GraphTrainStep
+    from kgwas_amd.kgwas import KGWAS
+    from kgwas_amd.kgwas_data import KGWAS_Data
+    from tests.helpers import params_by_name
+    if size == 'medium':
+        small_kg = KGWAS_Data.from_synthetic(scale=0.1, seed=1, data_path='/tmp/kgwas_synth_medium')
+    bs, nsteps = (64, 6) if size == 'small' else (256, 4)
+    ids = np.asarray(small_kg.train_input_nodes[1][:bs * 8])
+    runs, steps = [], []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, '_FUSED_ADAM', fused)
+        run = KGWAS(small_kg, device=DEV, seed=11)
+        run.initialize_model()
+        if runs:
+            run.model.load_state_dict(runs[0].model.state_dict())
+        runs.append(run)
+        gs = GraphTrainStep(run, ('SNP', ids), bs, lr=1e-3, weight_decay=5e-4)
+        assert gs.fused_adam == fused
+        if fused and size == 'medium':
+            assert gs.deferred_gradients >= 4, gs.deferred_gradients
+        steps.append(gs)
+    # (the first trainer was built before the second copied its weights: both start from the same state)
+    losses = [[], []]
+    for k, gs in enumerate(steps):
+        for i in range(nsteps):
+            losses[k].append(float(gs.step(i)))
+    assert losses[0] == losses[1]
+    assert steps[0].check() == steps[1].check()
+    assert int(steps[0].opt.step_dev) == int(steps[1].opt.step_dev) == nsteps
+    pa, pb = params_by_name(runs[0].model), params_by_name(runs[1].model)
+    for n in pa:
+        assert torch.equal(pa[n], pb[n]), n

@@ -19,7 +19,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in kgwas_hip.h but not exported'
     assert sorted(_lib.EXPORTS) == declared
-    assert lib.kgw_version() == 117
+    assert lib.kgw_version() == 118
     assert lib.kgw_status_string(-1) == b'null pointer argument'
 
 
@@ -45,10 +45,12 @@ def test_sampler_scratch_size_covers_every_sort_plan():
 def test_abi_struct_sizes_and_argument_checks():
     from kgwas_amd import _lib
     lib = _lib.lib()
-    sizes = (C.c_int64 * 6)()
-    assert lib.kgw_struct_sizes(sizes, 6) == 0
+    sizes = (C.c_int64 * 7)()
+    assert lib.kgw_struct_sizes(sizes, 7) == 0
     assert list(sizes) == [C.sizeof(_lib.KgwGraph), C.sizeof(_lib.KgwBatchMeta), C.sizeof(_lib.KgwChunk),
-                           C.sizeof(_lib.KgwBatchBuf), C.sizeof(_lib.KgwLayerArgs), C.sizeof(_lib.KgwTnJob)]
+                           C.sizeof(_lib.KgwBatchBuf), C.sizeof(_lib.KgwLayerArgs), C.sizeof(_lib.KgwTnJob),
+                           C.sizeof(_lib.KgwGradSrc)]
+    assert C.sizeof(_lib.KgwGradSrc) == 48
     assert C.sizeof(_lib.KgwChunk) == 32
     # argument errors are reported as negative status codes before any launch
     assert lib.kgw_sample_batch(None, None, None, 0, 0, 0, None) == -1
@@ -67,6 +69,12 @@ def test_abi_struct_sizes_and_argument_checks():
     jobs = (_lib.KgwTnJob * 5)()
     assert lib.kgw_tn_gemm_multi(5, jobs, None) == -2
     assert lib.kgw_tn_gemm_multi(1, jobs, None) == -1                                   # null operands
+    # the fused optimiser launch and the partial products that feed it: argument checks before any launch
+    assert lib.kgw_tn_gemm_multi_partial(2, jobs, None, None) == -1
+    assert lib.kgw_tn_gemm_partial(None, 0, 0, None, 0, 0, 0, None, 0, 0, None, None, 0, None, None, None) == -1
+    assert lib.kgw_adam_fused(0, None, None, None, None, None, None, None, 1e-4, 0.9, 0.999, 1e-8, 0.0, None, 0, 0, None, None, None) == -1
+    assert lib.kgw_adam_fused(_lib.ADAM_FUSED_MAX + 1, None, None, None, None, None, None, None, 1e-4, 0.9, 0.999, 1e-8, 0.0, None, 0, 0, None,
+                              None, None) == -2
     assert lib.kgw_scatter_relu_rows(None, None, None, 8, None, None, None, None) == -1
     assert lib.kgw_scatter_relu_rows_workspace_floats(20032) == 256 * 128
     assert lib.kgw_tn_gemm_workspace_floats(1000, 128, 128) > 0
