@@ -262,7 +262,17 @@ def run_in_step_trace(args, outdir, timeout_s=420):
     if rc != 0 or not files:
         return None, f'rocprofv3 exit {rc}'
     by = {}
-    for r in csv.DictReader(open(files[0])):
+    SAMPLER = ('k_fill_i32', 'k_init', 'k_hop_', 'k_seg_deg', 'k_scan_', 'k_fill_chunks', 'k_mark', 'k_count_pending', 'k_assign', 'k_relabel',
+               'k_layer_tables', 'k_ts_', 'k_t_end', 'k_meta_to_host', '__amd_rocclr')
+    adam_t, starts = [], []
+    rows_all = list(csv.DictReader(open(files[0])))
+    for r in rows_all:
+        name = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')
+        if name.startswith('k_adam'):
+            adam_t.append(int(r['Start_Timestamp']))
+        elif not any(name.startswith(k) for k in SAMPLER):
+            starts.append(int(r['Start_Timestamp']))
+    for r in rows_all:
         name = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')
         for key in ('k_agg_fwd<', 'k_agg_bwd_dst', 'k_agg_bwd_src', 'k_g3_gemm', 'k_mlp2_fwd3', 'k_mlp2_bwd_first3'):
             if name.startswith(key):
@@ -274,6 +284,12 @@ def run_in_step_trace(args, outdir, timeout_s=420):
         big = [max(d[i:i + 2]) for i in range(0, len(d) - 1, 2)]
         if big:
             out[key] = {'median_us': float(np.median(big)), 'mean_us': float(np.mean(big)), 'n': len(big)}
+    # launches of one replayed step on its own queue = the step's kernels between two consecutive optimiser launches (the last
+    # kernel of a step), the optimiser launch included; the side sampler's launches are not counted
+    adam_t.sort()
+    if len(adam_t) >= 3:
+        a, b = adam_t[-2], adam_t[-1]
+        out['launches_per_step'] = sum(1 for t in starts if a < t < b) + 1
     os.remove(files[0])                                       # (tens of MB: the summary is what is kept)
     return out, None
 
@@ -655,7 +671,7 @@ def main():
                         e['achieved'] = tb / (e['median_us'] * 1e-6) / 1e9
                         e['frac'] = e['achieved'] / HBM_PEAK_GBS
                     ins[key] = e
-            for key in ('k_g3_gemm', 'k_mlp2_fwd3', 'k_mlp2_bwd_first3'):
+            for key in ('k_g3_gemm', 'k_mlp2_fwd3', 'k_mlp2_bwd_first3', 'launches_per_step'):
                 if key in in_step:
                     ins[key] = in_step[key]
             roof['in_step'] = ins

@@ -310,12 +310,17 @@ int kgw_edge_alpha(const KgwLayerArgs* args, float* alpha_out, kgw_stream_t stre
  * gradients, one launch less per product.  Filled by kgw_tn_gemm_partial / kgw_tn_gemm_multi_partial /
  * kgw_mlp2_bwd_first_partial; the caller only carries the record to kgw_adam_fused.  (Weight / bias gradients of the Linears of
  * kgwas/model.py:13-21 on their way to the Adam update of kgwas/kgwas.py:116,151.)                                             */
-enum { KGW_GRAD_DIRECT = 0, KGW_GRAD_TN = 1, KGW_GRAD_TN_COLSUM = 2, KGW_GRAD_MLP2_W = 3, KGW_GRAD_MLP2_B = 4 };
+enum { KGW_GRAD_DIRECT = 0, KGW_GRAD_TN = 1, KGW_GRAD_TN_COLSUM = 2, KGW_GRAD_MLP2_W = 3, KGW_GRAD_MLP2_B = 4, KGW_GRAD_G3T = 5 };
 typedef struct KgwGradSrc {
     const float* ws;                 /* first partial record                                                     */
     int32_t kind, nblk;              /* KGW_GRAD_*; partial records per output element                           */
-    int32_t M, N, MT, NT, gy, gz;    /* TN kinds: product shape and tiling                                        */
+    int32_t M, N, MT, NT, gy, gz;    /* TN kinds: product shape and tiling; G3T: M = rows of the kgw_gemm3 product */
     int32_t K1, c_transposed;        /* MLP2 kinds: width of the first layer's input; TN: C stored transposed     */
+    /* G3T only, set by the CALLER of kgw_adam_fused (NULL: off): the kgw_gemm3 operand image of the UPDATED parameter
+     * ([128, M] = the B^T of the layer's forward product) is written by the same launch -- what kgw_gemm3_pack(S = parameter,
+     * K = M, k_valid = M, s_is_kn = 0) would produce for the next forward, without that launch.                          */
+    void* packed;
+    int32_t flip, pad_;              /* sign period of the image in 32-k chunks (kgw_gemm3_flip()), 0 = none      */
 } KgwGradSrc;
 
 /* C[M,N] = A[rows,M]^T * B[rows,N] (row-major, leading dimensions lda/ldb/ldc), optionally
@@ -488,6 +493,13 @@ int kgw_adam(int32_t n_tensors, float* const* params, const float* const* grads,
 int kgw_adam_notick(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                     float* const* exp_avg_sq, const int64_t* numel, int32_t* step_dev, float lr, float beta1,
                     float beta2, float eps, float weight_decay, kgw_stream_t stream);
+
+/* The weight-gradient form of kgw_gemm3 (transpose_out: out [128, M], ldo == M, M a multiple of 32) without its range-sum
+ * launch: src describes the K ranges' partial products for kgw_adam_fused.  kgw_gemm3_flip(): the sign period kgw_gemm3_pack
+ * builds its images with (KgwGradSrc.flip).                                                                                */
+int kgw_gemm3_partial(const float* A, int64_t lda, int64_t M, int64_t K, const void* packed, float* workspace,
+                      int64_t workspace_floats, float* out, int64_t ldo, KgwGradSrc* src, kgw_stream_t stream);
+int kgw_gemm3_flip(void);
 
 /* The optimiser launch of a captured training step: kgw_adam_notick over up to KGW_ADAM_FUSED_MAX tensors, and in the SAME launch
  * (a) the last reduction of every gradient whose producer left partial sums (src[i].kind != KGW_GRAD_DIRECT, at most

@@ -2889,7 +2889,7 @@ __device__ __forceinline__ float adam_src_sum(const KgwGradSrc& S, int64_t i, bo
 
 __global__ void __launch_bounds__(256) k_adam_fused(AdamFTab T, AdamTail Z, int32_t* step, float lr, float b1, float b2, float eps,
                                                     float wd) {
-    __shared__ float sm[16 * 64];
+    __shared__ float sm[32 * 33];                       // 16 x 64 partial sums of a sourced unit / one 32 x 33 tile (G3T)
     const int t_now = *step + 1;                       // (the counter moves only after every block has arrived at the end)
     const float bc1 = 1.0f - powf(b1, (float)t_now);
     const float bc2 = 1.0f - powf(b2, (float)t_now);
@@ -2906,6 +2906,77 @@ __global__ void __launch_bounds__(256) k_adam_fused(AdamFTab T, AdamTail Z, int3
         float* __restrict__ M = T.m[lo];
         float* __restrict__ V = T.v[lo];
         const int si = T.src_of[lo];
+        if (si != 255 && T.src[si].kind == KGW_GRAD_G3T) {
+            // the weight gradient of the first gene Linear, out[col][row] = sum over K ranges of ws[s][row][col]: one 32 x 32 tile
+            // per unit through LDS exactly like k_g3_reduce_t (same order), then the update of the tile's 1024 parameters, and --
+            // S.packed -- the three bf16 pieces of the UPDATED values in kgw_gemm3's operand image (k_g3_pack<false>'s layout):
+            // the next forward product finds its B operand ready
+            const KgwGradSrc& S = T.src[si];
+            const int64_t u = c - T.coff[lo];
+            const int64_t Mr = S.M, r0 = (u >> 2) * 32;
+            const int cb = (int)(u & 3) * 32;
+            float (*tl)[33] = (float (*)[33])sm;
+            {
+                const int r = threadIdx.x >> 3, c4 = threadIdx.x & 7;
+                const float4* w = (const float4*)S.ws + (r0 + r) * 32 + (cb >> 2) + c4;
+                // (k_g3_reduce_t's order, K range after K range; four loads in flight)
+                const int64_t ks = Mr * 32;
+                float4 a4 = w[0];
+                int k = 1;
+                for (; k + 3 < S.nblk; k += 4) {
+                    float4 x[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[q] = w[(int64_t)(k + q) * ks];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { a4.x += x[q].x; a4.y += x[q].y; a4.z += x[q].z; a4.w += x[q].w; }
+                }
+                for (; k < S.nblk; ++k) {
+                    const float4 x = w[(int64_t)k * ks];
+                    a4.x += x.x; a4.y += x.y; a4.z += x.z; a4.w += x.w;
+                }
+                tl[r][4 * c4] = a4.x; tl[r][4 * c4 + 1] = a4.y; tl[r][4 * c4 + 2] = a4.z; tl[r][4 * c4 + 3] = a4.w;
+            }
+            __syncthreads();
+            {
+                const int r = threadIdx.x & 31;
+                float pq[4], mq[4], vq[4], gq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                  // (all loads of the thread's four elements first)
+                    const int col = (threadIdx.x >> 5) + 8 * q;
+                    const int64_t i = (int64_t)(cb + col) * Mr + r0 + r;
+                    gq[q] = tl[r][col];
+                    pq[q] = P[i]; mq[q] = M[i]; vq[q] = V[i];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = (threadIdx.x >> 5) + 8 * q;
+                    const int64_t i = (int64_t)(cb + col) * Mr + r0 + r;
+                    adam_update(pq[q], gq[q], mq[q], vq[q], wd, b1, b2, eps, step_size, bc2_sqrt);
+                    Gr[i] = gq[q]; M[i] = mq[q]; V[i] = vq[q]; P[i] = pq[q];
+                    tl[r][col] = pq[q];
+                }
+            }
+            __syncthreads();
+            if (S.packed && threadIdx.x < 128) {
+                // image index (((c * 2 + j) * 3 + piece) * 4 + nt) * 64 + lane: the eight bf16 of a piece for
+                // k = 32 c + 16 j + 8 (lane >> 5) + i, column 32 nt + (lane & 31); here k = the tile's rows, column = its columns
+                const int j = threadIdx.x >> 6, lane = threadIdx.x & 63;
+                const int64_t ch = r0 >> 5;
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = tl[16 * j + 8 * (lane >> 5) + e][lane & 31];
+                if (S.flip && ((ch / S.flip) & 1)) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = -x[e];
+                }
+                uint4 p1, p2, p3;
+                kgw_split3x8(x, p1, p2, p3);
+                uint4* o = (uint4*)S.packed + ((ch * 2 + j) * 3 * 4 + (cb >> 5)) * 64 + lane;
+                o[0] = p1; o[4 * 64] = p2; o[8 * 64] = p3;
+            }
+            __syncthreads();
+            continue;
+        }
         if (si != 255) {
             const int64_t i = (c - T.coff[lo]) * 64 + fl;
             const bool valid = i < n;
@@ -2998,12 +3069,15 @@ extern "C" int kgw_adam_fused(int32_t n_tensors, float* const* params, float* co
                 if (S.K1 < 1 || S.K1 > 31 || (int64_t)128 * S.K1 != numel[i]) return KGW_E_RANGE;
             } else if (S.kind == KGW_GRAD_MLP2_B) {
                 if (S.K1 < 0 || S.K1 > 31 || numel[i] != 128) return KGW_E_RANGE;
+            } else if (S.kind == KGW_GRAD_G3T) {
+                if (S.M < 32 || (S.M & 31) || (int64_t)128 * S.M != numel[i] || S.flip < 0 || (S.flip & (S.flip - 1))) return KGW_E_RANGE;
+                if (((uintptr_t)S.ws | (uintptr_t)S.packed) & 15) return KGW_E_UNSUPPORTED;
             } else {
                 return KGW_E_RANGE;
             }
             T.src[nsrc] = S;
             T.src_of[i] = (unsigned char)nsrc++;
-            per = 64;
+            per = S.kind == KGW_GRAD_G3T ? 1024 : 64;          // (a 32 x 32 tile per unit)
         }
         T.off[i + 1] = T.off[i] + numel[i];
         T.coff[i + 1] = T.coff[i] + (numel[i] + per - 1) / per;

@@ -353,6 +353,30 @@ extern "C" int kgw_gemm3_pack(const float* S, int64_t lds_, int64_t K, int64_t k
     return KGW_OK;
 }
 
+extern "C" int kgw_gemm3_flip(void) { return g3_flip(); }
+
+// transpose_out product without k_g3_reduce_t: kgw_adam_fused adds the K ranges (same order) tile by tile while it updates the
+// parameter the gradient belongs to
+extern "C" int kgw_gemm3_partial(const float* A, int64_t lda, int64_t M, int64_t K, const void* packed, float* workspace,
+                                 int64_t workspace_floats, float* out, int64_t ldo, KgwGradSrc* src, kgw_stream_t stream_) {
+    if (!A || !packed || !workspace || !out || !src) return KGW_E_NULL;
+    if (M <= 0 || K <= 0 || M > (1 << 30) || K > (1 << 30)) return KGW_E_RANGE;
+    if (K % 32 || M % 32 || ldo != M || lda < 0 || (lda & 3) || ((uintptr_t)A & 15) || ((uintptr_t)packed & 15) || ((uintptr_t)workspace & 15))
+        return KGW_E_UNSUPPORTED;
+    const int ns = g3_splits(M, K);
+    if (workspace_floats < (int64_t)ns * M * 128) return KGW_E_RANGE;
+    const int rt = 32 * g3_nw();
+    const int tiles = (int)((M + rt - 1) / rt);
+    const int per_xcd = (tiles * ns + 7) / 8;
+    G3Args a{A, (long)lda, (int)M, (int)K, (const uint4*)packed, workspace, ns, tiles, per_xcd, g3_flip()};
+    if (g3_nw() == 8) k_g3_gemm<1, 8><<<per_xcd * 8, 512, 0, (hipStream_t)stream_>>>(a);
+    else k_g3_gemm<1, 4><<<per_xcd * 8, 256, 0, (hipStream_t)stream_>>>(a);
+    KGW_LAUNCH_CHECK();
+    *src = KgwGradSrc{};
+    src->ws = workspace; src->kind = KGW_GRAD_G3T; src->nblk = ns; src->M = (int32_t)M; src->N = 128;
+    return KGW_OK;
+}
+
 extern "C" int kgw_gemm3(const float* A, int64_t lda, int64_t M, int64_t K, const void* packed, float* workspace,
                          int64_t workspace_floats, const float* bias, int32_t relu, float* out, int64_t ldo, int32_t transpose_out,
                          const int32_t* row_map, float* out_rows, int64_t ld_rows, int64_t out_rows_n, const int32_t* out_rows_real,

@@ -96,6 +96,7 @@ class GraphTrainStep:
         self.fused_adam = (ops._FUSED_ADAM and self.capture_optimizer and not self._multi and
                            sum(1 for p in self.model.parameters() if p.requires_grad) <= _lib.ADAM_FUSED_MAX)
         self.deferred_gradients = 0
+        self._images, self._image_params, self._image_version, self._pack_probe = {}, [], {}, None
         self.split_backward = self._multi and os.environ.get('KGW_SPLIT_BACKWARD', '1') == '1'
         # multi-rank, optional: the first gene Linear over the resident feature matrix (forward + weight gradient: 0.27 of the
         # step's 1.2 ms, identical work on every rank) split by gene rows over the ranks -- ops.GeneLayerShard in its STAGED form:
@@ -149,9 +150,33 @@ class GraphTrainStep:
 
     # train on the batch held by bufs[cur]; concurrently sample ``self.seeds`` into bufs[1 - cur]
     def _step_body(self, cur: int):
-        # (the shard is active for the forward passes THIS trainer issues and for nothing else in the process)
-        with ops.gene_shard_scope(self.gene_shard, self._probe):
+        # (the shard is active for the forward passes THIS trainer issues and for nothing else in the process; so are the operand
+        #  images its optimiser launch keeps current)
+        with ops.gene_shard_scope(self.gene_shard, self._probe), ops.packed_scope(self._images, self._pack_probe):
             return self._step_body_inner(cur)
+
+    # ---- operand images of packed weights (the first gene Linear on kgw_gemm3) ---------------------------------------------------
+    # With the fused optimiser launch the image of the UPDATED weight is written by that launch, so the next step's forward does not
+    # pack (one launch less).  The trainer owns the image: it packs it once itself, and again whenever the weight was changed by
+    # anything but its own optimiser launch (load_state_dict, a copy_ between steps: the tensor's version counter moves -- the HIP
+    # launches do not move it).
+    def _adopt_images(self, seen):
+        byptr = {p.data_ptr(): p for p in self.model.parameters()}
+        for W in seen:
+            p = byptr.get(W.data_ptr())
+            if p is None or p.data_ptr() in self._images or not p.requires_grad or p.shape[1] % 32:
+                continue
+            img = torch.empty(int(_lib.lib().kgw_gemm3_packed_bytes(p.shape[1])), dtype=torch.uint8, device=p.device)
+            self._images[p.data_ptr()] = img
+            self.opt.packed_images[p] = img
+            self._image_params.append(p)
+        self._refresh_images(force=True)
+
+    def _refresh_images(self, force=False):
+        for p in self._image_params:
+            if force or self._image_version.get(p) != p._version:
+                ops.gemm3_pack(p.detach(), p.shape[1], False, out=self._images[p.data_ptr()])
+                self._image_version[p] = p._version
 
     def _step_body_inner(self, cur: int):
         bs = self.batch_size
@@ -296,6 +321,8 @@ class GraphTrainStep:
                 if gs is not None:
                     gs.forward_partial(*gs.last)
                     gs.gather()
+                if k == 0 and self.fused_adam and os.environ.get('KGW_ADAM_PACKS', '1') != '0':
+                    self._pack_probe = []                      # which weights does the forward pack for kgw_gemm3?
                 try:
                     self._step_body(k % 2)
                 except ops.GradSinkMismatch as e:             # (raised before the optimiser launch: nothing was updated)
@@ -303,6 +330,10 @@ class GraphTrainStep:
                     self.fused_adam = False
                     self.opt.zero_grad(set_to_none=True)
                     self._step_body(k % 2)
+                if self._pack_probe is not None:
+                    seen, self._pack_probe = self._pack_probe, None
+                    if self.fused_adam:
+                        self._adopt_images(seen)
                 if self.split_backward:
                     self._step_body_b(k % 2)
                 if gs is not None:
@@ -330,6 +361,7 @@ class GraphTrainStep:
                     if torch.is_tensor(v):
                         v.zero_()
             self.opt.step_dev.zero_()
+        self._refresh_images(force=True)                       # (the warm-up's updates are undone: so are their images)
         self.stats.zero_()
         self.opt.zero_grad(set_to_none=True)
         # (KGW_STEP_PRIORITY: capture -- hence run, a replayed graph executes on the queue of the stream it was captured on -- the
@@ -385,6 +417,8 @@ class GraphTrainStep:
         """Train on batch ``i`` of the loader's fixed order (and pre-sample batch i+1); returns the (device,
         float64) loss tensor."""
         cur = i % 2
+        if self._image_params:
+            self._refresh_images()               # (a weight changed by anything but this trainer's own optimiser launch: re-pack)
         if self._have[cur] != i:                 # first call / non-sequential access: sample it now
             self._sample_now(cur, i)
         nxt = (i + 1) % self.n_batches
@@ -481,7 +515,11 @@ class GraphTrainStep:
             return ('HIP graphs: forward + first half of the backward | second half (feature MLPs); the first half\'s gradient bucket '
                     'is all-reduced (RCCL) on a side stream under the second graph, the MLPs\' bucket after it, then one Adam launch' +
                     ('; next batch sampled by a third graph on a side stream' if self.twin else ''))
-        return ('HIP graphs: step graph (fwd + bwd' + (' + Adam)' if self.capture_optimizer else '), RCCL all-reduce + Adam eager') +
+        adam = ' + Adam)'
+        if self.fused_adam:
+            adam = (f' + one optimiser launch that also finishes the partial sums of {self.deferred_gradients} weight gradients' +
+                    (', writes the first gene Linear\'s bf16 operand image' if self._image_params else '') + ' and keeps the step counters)')
+        return ('HIP graphs: step graph (fwd + bwd' + (adam if self.capture_optimizer else '), RCCL all-reduce + Adam eager') +
                 (' with the next batch sampled by a second graph on a side stream' if self.twin else ', sampling inside it'))
 
     def grads_ready(self):

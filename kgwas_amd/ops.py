@@ -625,14 +625,45 @@ def gemm3_ok(M: int, K: int) -> bool:
     return _GEMM3 and K % 32 == 0 and M >= 2048 and K >= 1024
 
 
-def gemm3_pack(S: torch.Tensor, K: int, s_is_kn: bool, k_valid: int = None) -> torch.Tensor:
+# Operand images that somebody ELSE keeps current: {data_ptr of an nn.Linear weight [128, K]: its packed image}, set (packed_scope)
+# by a trainer whose optimiser launch rewrites the image whenever it updates the weight (kgw_adam_fused, KgwGradSrc.packed) and
+# which re-packs it itself when the weight is changed behind its back (GraphTrainStep._refresh_images).  Inside the scope
+# gemm3_pack returns the image without a launch.  PACK_PROBE: a list while the trainer finds out which weights are packed at all.
+PACKED_W = None
+PACK_PROBE = None
+
+
+class packed_scope:
+    def __init__(self, images, probe=None):
+        self.images, self.probe = images, probe
+
+    def __enter__(self):
+        global PACKED_W, PACK_PROBE
+        self.prev = (PACKED_W, PACK_PROBE)
+        PACKED_W, PACK_PROBE = self.images, self.probe
+
+    def __exit__(self, *exc):
+        global PACKED_W, PACK_PROBE
+        PACKED_W, PACK_PROBE = self.prev
+        return False
+
+
+def gemm3_pack(S: torch.Tensor, K: int, s_is_kn: bool, k_valid: int = None, out: torch.Tensor = None) -> torch.Tensor:
     """B [K, 128] of a kgw_gemm3 product, split into its three bf16 pieces in the kernel's operand image.  ``s_is_kn``: S is
     B itself ([k_valid, 128]); else S = B^T ([128, k_valid], an nn.Linear weight).  ``k_valid`` < K (default K): S stops there,
-    the rows of B up to K -- a multiple of 32 -- are zero."""
+    the rows of B up to K -- a multiple of 32 -- are zero.  ``out``: write the image there."""
     kv = K if k_valid is None else int(k_valid)
     assert S.dtype == torch.float32 and S.stride(1) == 1 and (S.shape == (kv, KGW_C) if s_is_kn else S.shape == (KGW_C, kv))
     L = _lib.lib()
-    packed = torch.empty(int(L.kgw_gemm3_packed_bytes(K)), dtype=torch.uint8, device=S.device)
+    if not s_is_kn and kv == K and S.is_contiguous() and out is None:
+        if PACKED_W is not None:
+            img = PACKED_W.get(S.data_ptr())
+            if img is not None:
+                return img                                  # (kept current by the scope's owner: no launch)
+        if PACK_PROBE is not None:
+            PACK_PROBE.append(S)
+    packed = out if out is not None else torch.empty(int(L.kgw_gemm3_packed_bytes(K)), dtype=torch.uint8, device=S.device)
+    assert packed.numel() == int(L.kgw_gemm3_packed_bytes(K)) and packed.dtype == torch.uint8
     _lib.check(L.kgw_gemm3_pack(_p(S), S.stride(0), K, kv, 1 if s_is_kn else 0, _p(packed), _lib.stream_ptr()), 'kgw_gemm3_pack')
     return packed
 
@@ -648,7 +679,7 @@ def gemm3_tile(A: torch.Tensor) -> torch.Tensor:
 
 
 def gemm3(A: torch.Tensor, packed: torch.Tensor, bias=None, relu: bool = False, transpose_out: bool = False, out=None, tiled_rows: int = 0,
-          row_map=None, out_rows=None, out_rows_real=None):
+          row_map=None, out_rows=None, out_rows_real=None, defer: bool = False):
     """act(A [M, K] @ B [K, 128] + bias) -> [M, 128], or its transpose [128, M] (``transpose_out``): the tall resident product
     of the first gene Linear on the bf16 matrix pipe with fp32 error (three exact bf16 pieces per operand, kgw_gemm3).
     ``tiled_rows`` = M when A is a gemm3_tile() copy.  ``row_map`` [M] int32 + ``out_rows``: row m also goes to
@@ -669,6 +700,15 @@ def gemm3(A: torch.Tensor, packed: torch.Tensor, bias=None, relu: bool = False, 
     nws = int(L.kgw_gemm3_workspace_floats(M, K))
     ws = torch.empty(nws, device=A.device)
     _route('kgw_gemm3')
+    sink = GRAD_SINK
+    if defer and sink is not None and transpose_out and M % 32 == 0 and out.is_contiguous() and bias is None and not relu and row_map is None:
+        # ``defer``: ``out`` goes to autograd as a parameter's gradient and to nothing else: the K ranges are added tile by tile
+        # inside the optimiser's launch (GradSink, KGW_GRAD_G3T)
+        src = _lib.KgwGradSrc()
+        _lib.check(L.kgw_gemm3_partial(_p(A), lda, M, K, _p(packed), _p(ws), nws, _p(out), out.stride(0), C.byref(src), _lib.stream_ptr()),
+                   'kgw_gemm3_partial')
+        sink.add(out, src, ws)
+        return out
     _lib.check(L.kgw_gemm3(_p(A), lda, M, K, _p(packed), _p(ws), nws, _p(bias), 1 if relu else 0, _p(out), out.stride(0),
                            1 if transpose_out else 0, _p(row_map), _p(out_rows), out_rows.stride(0) if out_rows is not None else 0,
                            out_rows.shape[0] if (out_rows is not None and out_rows_real is not None) else 0,
@@ -907,7 +947,7 @@ def resident_first_weight_grad(dz, X, W, gs=None):
             gs.scatter()
             return gs.weight_grad_partial(X)
         Xt = _resident_copies(X)[1]                      # [K, Np], Np = the node count rounded up to 32, zero columns past it
-        return gemm3(Xt, gemm3_pack(dz, Xt.shape[1], True, k_valid=X.shape[0]), transpose_out=True)
+        return gemm3(Xt, gemm3_pack(dz, Xt.shape[1], True, k_valid=X.shape[0]), transpose_out=True, defer=True)
     if LIBRARY_GEMM.own_first and 0 < dz.shape[0] and X.dtype == torch.float32:
         return tn_gemm(dz, X)
     LIBRARY_GEMM.note('resident_first_weight_grad', dz.shape[0], dz.shape[1], X.shape[1])

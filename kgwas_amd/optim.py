@@ -16,6 +16,7 @@ class FusedAdam:
         self.state = {}
         dev = self.params[0].device if self.params else torch.device('cuda')
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.packed_images = {}        # parameter -> persistent kgw_gemm3 operand image its fused update keeps current (step_fused)
         self.param_groups = [{'params': self.params, 'lr': lr, 'betas': betas, 'eps': eps, 'weight_decay': weight_decay}]
 
     def zero_grad(self, set_to_none: bool = True):
@@ -73,6 +74,9 @@ class FusedAdam:
             P[k], G[k], M[k], V[k], N[k] = p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel()
             if p in recs:
                 C.memmove(C.byref(S[k]), C.byref(recs[p][0]), C.sizeof(_lib.KgwGradSrc))
+                img = self.packed_images.get(p)
+                if img is not None and S[k].kind == 5:               # KGW_GRAD_G3T: the updated weight's operand image rides along
+                    S[k].packed, S[k].flip = img.data_ptr(), int(_lib.lib().kgw_gemm3_flip())
         rc = _lib.lib().kgw_adam_fused(n, P, G, M, V, N, S, self.step_dev.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps,
                                        self.weight_decay, meta_ptr, n_layers, n_hops, stats.data_ptr() if stats is not None else None,
                                        self.done_dev.data_ptr(), _lib.stream_ptr())

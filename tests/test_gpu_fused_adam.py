@@ -119,17 +119,19 @@ def test_mlp2_first_layer_partials_finished_by_adam(rows, K1):
 @pytest.mark.parametrize('size', ['small', 'medium'])
 def test_fused_step_equals_unfused_step(small_kg, monkeypatch, size):
     """The captured training step with the fused optimiser launch == the same step with the folds, Adam and the statistics as
-    launches of their own: losses, every parameter, the running totals -- bit for bit.  ``medium`` (10 % of the benchmark graph,
-    256 seeds: tens of thousands of sampled SNP rows) makes the MLPs' weight gradients multi-block products, so the deferred sums
-    are really taken by the optimiser's launch; ``small`` has single-block products (only the counters move into the launch)."""
+    launches of their own: losses, every parameter, the running totals -- bit for bit.  ``medium`` (21 % of the benchmark graph,
+    256 seeds: 4 200 genes with the 5 120-wide features, tens of thousands of sampled SNP rows) puts the first gene Linear on
+    kgw_gemm3 and makes the MLPs' weight gradients multi-block products: the deferred sums are really taken by the optimiser's
+    launch and the gene weight's operand image is written by it; ``small`` has single-block products (only the counters move into
+    the launch).  Half way the gene weight is changed behind the trainers' backs: the image must follow."""
     from kgwas_amd import ops
     from kgwas_amd.graph_step import GraphTrainStep
     from kgwas_amd.kgwas import KGWAS
     from kgwas_amd.kgwas_data import KGWAS_Data
     from tests.helpers import params_by_name
     if size == 'medium':
-        small_kg = KGWAS_Data.from_synthetic(scale=0.1, seed=1, data_path='/tmp/kgwas_synth_medium')
-    bs, nsteps = (64, 6) if size == 'small' else (256, 4)
+        small_kg = KGWAS_Data.from_synthetic(scale=0.21, seed=1, data_path='/tmp/kgwas_synth_medium')
+    bs, nsteps = (64, 6) if size == 'small' else (256, 6)
     ids = np.asarray(small_kg.train_input_nodes[1][:bs * 8])
     runs, steps = [], []
     for fused in (True, False):
@@ -142,16 +144,56 @@ def test_fused_step_equals_unfused_step(small_kg, monkeypatch, size):
         gs = GraphTrainStep(run, ('SNP', ids), bs, lr=1e-3, weight_decay=5e-4)
         assert gs.fused_adam == fused
         if fused and size == 'medium':
-            assert gs.deferred_gradients >= 4, gs.deferred_gradients
+            assert gs.deferred_gradients >= 5, gs.deferred_gradients          # (incl. the gene layer's kgw_gemm3 weight gradient)
+            assert len(gs._image_params) == 1 and gs._image_params[0] is run.model.gene_feat_mlp.FC_hidden.weight
+        if not fused:
+            assert not gs._image_params
         steps.append(gs)
     # (the first trainer was built before the second copied its weights: both start from the same state)
     losses = [[], []]
     for k, gs in enumerate(steps):
         for i in range(nsteps):
+            if i == nsteps // 2:
+                with torch.no_grad():
+                    runs[k].model.gene_feat_mlp.FC_hidden.weight.mul_(1.03125)
             losses[k].append(float(gs.step(i)))
     assert losses[0] == losses[1]
+    assert len(set(losses[0])) == nsteps
     assert steps[0].check() == steps[1].check()
     assert int(steps[0].opt.step_dev) == int(steps[1].opt.step_dev) == nsteps
     pa, pb = params_by_name(runs[0].model), params_by_name(runs[1].model)
     for n in pa:
         assert torch.equal(pa[n], pb[n]), n
+    if size == 'medium':
+        # the image the optimiser launch left == what kgw_gemm3_pack makes of the final weight
+        gs = steps[0]
+        W = gs._image_params[0]
+        ref = ops.gemm3_pack(W.detach(), W.shape[1], False)
+        assert torch.equal(ref, gs._images[W.data_ptr()])
+
+
+@pytest.mark.parametrize('M,K', [(5120, 20032), (1024, 4096), (96, 2048)])
+def test_gemm3_weight_gradient_finished_by_adam(M, K):
+    """d W1 [128, M] = (A [M, K] B [K, 128])^T on kgw_gemm3 with its K ranges added by kgw_adam_fused (KGW_GRAD_G3T) + the
+    updated weight's operand image written by the same launch: gradient, parameter, moments and image bit-identical to
+    kgw_gemm3(transpose_out) + kgw_adam + kgw_gemm3_pack."""
+    from kgwas_amd import _lib, ops
+    g = torch.Generator(device='cpu').manual_seed(M)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    B = (torch.randn(K, 128, generator=g) * 0.1).to(DEV)
+    pa, pb, oa, ob = _adam_pair([(128, M)], 4)
+    img = torch.empty(int(_lib.lib().kgw_gemm3_packed_bytes(M)), dtype=torch.uint8, device=DEV)
+    oa.packed_images[pa[0]] = img
+    for step in range(3):
+        packed = ops.gemm3_pack(B, K, True)
+        ref = ops.gemm3(A, packed, transpose_out=True)
+        sink = ops.GradSink()
+        with ops.grad_sink_scope(sink):
+            out = ops.gemm3(A, packed, transpose_out=True, defer=True)
+        assert len(sink.records) == 1
+        pa[0].grad, pb[0].grad = out, ref
+        oa.step_fused(sink)
+        ob.step()
+        _same_state(pa, pb, oa, ob)
+        assert torch.equal(img, ops.gemm3_pack(pb[0].detach(), M, False))
+        B = B * 0.5

@@ -50,7 +50,7 @@ def test_abi_struct_sizes_and_argument_checks():
     assert list(sizes) == [C.sizeof(_lib.KgwGraph), C.sizeof(_lib.KgwBatchMeta), C.sizeof(_lib.KgwChunk),
                            C.sizeof(_lib.KgwBatchBuf), C.sizeof(_lib.KgwLayerArgs), C.sizeof(_lib.KgwTnJob),
                            C.sizeof(_lib.KgwGradSrc)]
-    assert C.sizeof(_lib.KgwGradSrc) == 48
+    assert C.sizeof(_lib.KgwGradSrc) == 64
     assert C.sizeof(_lib.KgwChunk) == 32
     # argument errors are reported as negative status codes before any launch
     assert lib.kgw_sample_batch(None, None, None, 0, 0, 0, None) == -1
@@ -72,6 +72,8 @@ def test_abi_struct_sizes_and_argument_checks():
     # the fused optimiser launch and the partial products that feed it: argument checks before any launch
     assert lib.kgw_tn_gemm_multi_partial(2, jobs, None, None) == -1
     assert lib.kgw_tn_gemm_partial(None, 0, 0, None, 0, 0, 0, None, 0, 0, None, None, 0, None, None, None) == -1
+    assert lib.kgw_gemm3_partial(None, 0, 0, 0, None, None, 0, None, 0, None, None) == -1
+    assert lib.kgw_gemm3_flip() in (0, 1, 2, 4, 8, 16, 32, 64)
     assert lib.kgw_adam_fused(0, None, None, None, None, None, None, None, 1e-4, 0.9, 0.999, 1e-8, 0.0, None, 0, 0, None, None, None) == -1
     assert lib.kgw_adam_fused(_lib.ADAM_FUSED_MAX + 1, None, None, None, None, None, None, None, 1e-4, 0.9, 0.999, 1e-8, 0.0, None, 0, 0, None,
                               None, None) == -2
