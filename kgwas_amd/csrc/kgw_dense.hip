@@ -1933,11 +1933,10 @@ int launch_wreg(const LinArgs& a, hipStream_t st) {
     static const int64_t half_max = getenv("KGW_WREG_HALF_MAX_TILES") ? atoll(getenv("KGW_WREG_HALF_MAX_TILES")) : 512;
     // (measured in the step: 1.648 ms with the half-tile kernel up to 512 tiles, 1.653 up to 1024, 1.671 without it)
     if (ntiles <= half_max) {                                 // few tiles: one (tile, column half) per wavefront, all resident
-        static bool attr_half = false;
-        if (!attr_half) {
+        static KgwPerDevice attr_half;
+        if (attr_half.need()) {
             KGW_HIP(hipFuncSetAttribute((const void*)k_linear_wreg_half<WKN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             KGW_HIP(hipFuncSetAttribute((const void*)k_linear_wreg_half<WKN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_half = true;
         }
         const int grid = (int)((ntiles + 1) / 2);
         if (a.mask) k_linear_wreg_half<WKN, true><<<grid, 256, lds, st>>>(a);
@@ -2023,10 +2022,9 @@ extern "C" int kgw_mlp2_fwd(const float* X, int64_t ldx, int32_t K1, const float
     static const bool split3 = !(getenv("KGW_MLP2_SPLIT") && getenv("KGW_MLP2_SPLIT")[0] == '0');
     if (split3) {           // second product on the bf16 pipe (three exact pieces per operand)
         const size_t lds3 = (size_t)M3_W2_U4 * 16 + (size_t)(128 * 24 + 128) * sizeof(float);
-        static bool attr3_set = false;
-        if (!attr3_set) {
+        static KgwPerDevice attr3_set;
+        if (attr3_set.need()) {
             KGW_HIP(hipFuncSetAttribute((const void*)k_mlp2_fwd3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-            attr3_set = true;
         }
         const int64_t nblk3 = ((rows + 31) / 32 + 7) / 8;
         k_mlp2_fwd3<<<(int)(nblk3 < 256 ? nblk3 : 256), 512, lds3, (hipStream_t)stream_>>>(a);
@@ -2101,10 +2099,9 @@ static int mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2, int64_
     static const bool split3 = !(getenv("KGW_MLP2_SPLIT") && getenv("KGW_MLP2_SPLIT")[0] == '0');
     if (split3) {
         const size_t lds3 = (size_t)M3_W2_U4 * 16 + (size_t)(4 * 32 * TS2) * sizeof(float);
-        static bool attr3_set = false;
-        if (!attr3_set) {
+        static KgwPerDevice attr3_set;
+        if (attr3_set.need()) {
             KGW_HIP(hipFuncSetAttribute((const void*)k_mlp2_bwd_first3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-            attr3_set = true;
         }
         k_mlp2_bwd_first3<<<(int)nblk, 256, lds3, st>>>(a);
     } else {

@@ -24,7 +24,7 @@ from .sampler import BatchBuffers, NeighborLoader, SampledBatch, sample_into
 # blocks per launch of a sampler that runs beside a step graph: small launches disturb the step's kernels least
 # (measured, 512-seed steps: 2048 blocks 1.74 ms/step, 512: 1.68, 256: 1.67, 128: 1.66, 64: 2.03 -- there the sampler,
 # 1.0 ms on its own, no longer hides); 256 keeps the sampler at 0.42 ms, under the forward-only eval step too
-SIDE_SAMPLER_GRID = 256
+SIDE_SAMPLER_GRID = int(os.environ.get('KGW_SIDE_SAMPLER_GRID', '256'))       # (the knob: re-measured whenever the sampler changes)
 # microseconds the side sampler's graph idles before its first launch (kgw_delay): which kernels of the step the sampler's
 # launches share the chip with decides what the overlap costs (KGW_SAMPLER_DELAY_US overrides; 0 = start with the step)
 SIDE_SAMPLER_DELAY_US = int(os.environ.get('KGW_SAMPLER_DELAY_US', '0'))

@@ -211,6 +211,17 @@ def _compare_with_oracle(run, ids, what, min_genes):
     assert_close(pred, out_o.detach().reshape(-1), RTOL, ATOL, f'{what}: pred')
     assert abs(float(loss) - float(loss_o)) <= 1e-4 * abs(float(loss_o)) + 1e-7
     go = grads_by_name(oracle)
+    # The yardstick for gradients that are SMALL DIFFERENCES OF LARGE TERMS: the same oracle in float32 (the reference's own
+    # arithmetic, kgwas/conv.py on PyG in fp32).  d a_dst of a destination row is zero in exact arithmetic wherever the row's
+    # logits sit on one branch of the leaky ReLU (a_dst shifts all of them alike and the softmax of conv.py:223 does not see a common
+    # shift), so everything that hangs on it alone -- lin_dst / att_dst of the relations into the seed SNPs, and through the seeds'
+    # layer-1 rows the lin_src of the same relations one layer down -- is cancellation residue: the float32 oracle is ~1e-3 off
+    # float64 there itself, and which 1e-3 depends on the order of every sum upstream.
+    oracle32 = oracle_from_product(model, dtype=torch.float32)
+    x32, ei32 = batch_cpu(batch, dtype=torch.float32)
+    loss32 = weighted_mse(oracle32(x32, ei32, bs), run.data.data['SNP'].y[s].float(), ld_w[s.cuda()].cpu())
+    loss32.backward()
+    go32 = grads_by_name(oracle32)
     n, nw = 0, []
     for name, g in grads_by_name(model).items():
         ref = go[name]
@@ -221,13 +232,20 @@ def _compare_with_oracle(run, ids, what, min_genes):
         # (a gradient that is zero in exact arithmetic -- d att_dst of a softmax over ONE destination's logits: adding a constant
         #  to them changes nothing -- comes out as 1e-19 in float64 and 1e-10 in fp32: only the absolute bound applies to it)
         if float(ref.norm()) > 1e-6:
-            nw.append((float((g.double() - ref).norm() / ref.norm()), name))
+            e32 = float((go32[name].double() - ref).norm() / ref.norm()) if go32.get(name) is not None else 0.0
+            nw.append((float((g.double() - ref).norm() / ref.norm()), name, e32))
         n += 1
     assert n > 40
     nw.sort(reverse=True)
-    print(f'[{what}] norm-wise gradient errors, largest first: ' + ', '.join(f'{k} {e:.1e}' for e, k in nw[:4]) +
-          f'; median {nw[len(nw) // 2][0]:.1e} over {len(nw)} tensors')
-    assert nw[0][0] <= 1e-3, nw[0]
+    print(f'[{what}] norm-wise gradient errors, largest first (this path / the float32 oracle): ' +
+          ', '.join(f'{k} {e:.1e} / {e32:.1e}' for e, k, e32 in nw[:4]) + f'; median {nw[len(nw) // 2][0]:.1e} over {len(nw)} tensors')
+    # every tensor within 1e-3 of float64 norm-wise, or -- the cancellation residues above -- within 10 x of what the reference
+    # arithmetic itself is off, never more than 2e-2.  Measured over six 64-seed batches of this graph (round 4): the float32 oracle
+    # 8e-7 ... 2.6e-3 off float64 on these tensors depending on the batch, this path 1 - 7 x that (it forms sum_j alpha_j d alpha_j
+    # of a row from the stored fp32 aggregate, <dZ_i, z_i>, not edge by edge: one more rounding that does not cancel); two kernels
+    # that merely changed the order of the sums in u_r / v_r moved the first batch from 1.4 x to 6.3 x.
+    for e, name, e32 in nw:
+        assert e <= max(1e-3, min(10.0 * e32, 2e-2)), (name, e, e32)
     assert nw[len(nw) // 2][0] <= 1e-5, nw[len(nw) // 2]
     gw, rw = grads_by_name(model)['gene_feat_mlp.FC_hidden.weight'].double(), go['gene_feat_mlp.FC_hidden.weight']
     assert float(rw.norm()) > 0 and int((pred > 0).sum()) >= bs // 2, 'a dead read-out would make this comparison empty'
