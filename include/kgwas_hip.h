@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KGW_VERSION      118          /* 0.1.8 */
+#define KGW_VERSION      119          /* 0.1.9 */
 #define KGW_MAX_TYPES    8
 #define KGW_MAX_RELS     64
 #define KGW_MAX_LAYERS   4
@@ -482,6 +482,14 @@ typedef struct KgwSplitKJob {
 int kgw_linear_splitk_multi(int32_t n_jobs, const KgwSplitKJob* jobs, kgw_stream_t stream);
 /* dgamma of up to 4 transforms in one launch (job: seg_stat, Y = dY, ldy, rows, K = R * 128, dgamma).                        */
 int kgw_ind_colsum_multi(int32_t n_jobs, const KgwSplitKJob* jobs, kgw_stream_t stream);
+
+/* The backward of a layer's relation transform (kgwas/conv.py:138-144,190 + kgwas/model.py:74-75 under loss.backward()) in ONE
+ * launch (+ the split-K products' second): everything that is a function of d(output) alone -- the weight / bias gradients of
+ * every destination type (tn_jobs: the records of kgw_tn_gemm_multi), the dZ twins (sk_jobs: kgw_linear_splitk_multi's K == 128
+ * records with [N, K] weights) and the d gamma sums of a folded layer (cs_jobs: kgw_ind_colsum_multi's records) -- as blocks of
+ * one grid; values identical to the three separate calls.  Any of the three lists may be empty.                              */
+int kgw_transform_bwd(int32_t n_tn, const KgwTnJob* tn_jobs, int32_t n_sk, const KgwSplitKJob* sk_jobs, int32_t n_cs,
+                      const KgwSplitKJob* cs_jobs, kgw_stream_t stream);
 
 /* One Adam step (torch.optim.Adam semantics, weight_decay as L2: kgwas/kgwas.py:116,151) over up to 64
  * parameter tensors in a single launch.  The pointer arrays are HOST arrays of device pointers (passed to the

@@ -78,13 +78,9 @@ struct TnJob {
 struct TnJobs { TnJob j[TN_MAX_JOBS]; int n; };
 
 // ws layout per block: [MT][NT][16][64] floats (fragment order) ; colsum ws per block: [32*MT]
+// (the body of k_tn_gemm: block (bxg = row block over all jobs, by, bz); also inlined into k_transform_bwd)
 template <int MT, int NT>
-__global__ void __launch_bounds__(256, 1) k_tn_gemm(TnJobs J) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    int jq = 0;
-    while (jq + 1 < J.n && (int)blockIdx.x >= J.j[jq + 1].blk0) ++jq;
-    const TnJob& T = J.j[jq];
-    if ((int)blockIdx.y >= T.gy || (int)blockIdx.z >= T.gz) return;       // (before any barrier: whole blocks)
+__device__ __forceinline__ void tn_gemm_block(const TnJob& T, const int bx, const int by, const int bz, float* lds) {
     const float* __restrict__ A = T.A;
     const float* __restrict__ B = T.B;
     const int64_t lda = T.lda, ldb = T.ldb;
@@ -92,10 +88,10 @@ __global__ void __launch_bounds__(256, 1) k_tn_gemm(TnJobs J) {
     int64_t rows = T.rows, rows_per_wave = T.rpw;
     float* __restrict__ ws = T.ws;
     float* __restrict__ ws_colsum = T.ws_cs;
-    const int bx = (int)blockIdx.x - T.blk0, nbx = T.nblk;
+    const int nbx = T.nblk;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = lane >> 5, i = lane & 31;
-    const int m0 = blockIdx.y * 32 * MT, n0 = blockIdx.z * 32 * NT;
+    const int m0 = by * 32 * MT, n0 = bz * 32 * NT;
     const int ca = m0 + MT * i, cb = n0 + NT * i;
     const int cas = ca < M ? ca : 0, cbs = cb < N ? cb : 0;
     const int64_t wg = (int64_t)bx * 4 + wave;
@@ -207,7 +203,7 @@ __global__ void __launch_bounds__(256, 1) k_tn_gemm(TnJobs J) {
                 if (m < M && n < N) Cq[(int64_t)m * T.c_rs + (int64_t)n * T.c_cs] = v[q];
             }
         }
-        if (T.colsum && blockIdx.z == 0 && threadIdx.x < 32 * MT) {
+        if (T.colsum && bz == 0 && threadIdx.x < 32 * MT) {
             const int c = threadIdx.x;
             const float t = (cs[c] + cs[2 * 32 * MT + c]) + (cs[32 * MT + c] + cs[3 * 32 * MT + c]);
             if (m0 + c < M)
@@ -215,17 +211,27 @@ __global__ void __launch_bounds__(256, 1) k_tn_gemm(TnJobs J) {
         }
         return;
     }
-    const int64_t blk = ((int64_t)blockIdx.z * T.gy + blockIdx.y) * nbx + bx;
+    const int64_t blk = ((int64_t)bz * T.gy + by) * nbx + bx;
     float* out = ws + blk * FRAG;
     for (int f = threadIdx.x * 4; f < FRAG; f += 256 * 4) {
         const float4 x = *(const float4*)(reg0 + f), y = *(const float4*)(reg1 + f);
         *(float4*)(out + f) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
     }
-    if (ws_colsum && blockIdx.z == 0 && threadIdx.x < 32 * MT) {
+    if (ws_colsum && bz == 0 && threadIdx.x < 32 * MT) {
         const int c = threadIdx.x;
         const float t = (cs[c] + cs[2 * 32 * MT + c]) + (cs[32 * MT + c] + cs[3 * 32 * MT + c]);
-        ws_colsum[((int64_t)blockIdx.y * nbx + bx) * 32 * MT + c] = t;
+        ws_colsum[((int64_t)by * nbx + bx) * 32 * MT + c] = t;
     }
+}
+
+template <int MT, int NT>
+__global__ void __launch_bounds__(256, 1) k_tn_gemm(TnJobs J) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int jq = 0;
+    while (jq + 1 < J.n && (int)blockIdx.x >= J.j[jq + 1].blk0) ++jq;
+    const TnJob& T = J.j[jq];
+    if ((int)blockIdx.y >= T.gy || (int)blockIdx.z >= T.gz) return;       // (before any barrier: whole blocks)
+    tn_gemm_block<MT, NT>(T, (int)blockIdx.x - T.blk0, (int)blockIdx.y, (int)blockIdx.z, lds);
 }
 
 // C[m][n] = sum over row-blocks of the partial fragments (fixed order); also the column sums.
@@ -298,8 +304,10 @@ struct TnDesc {      // one product as the C ABI describes it
 
 // ``defer`` (nullable, 2 n records: [product, column sums] of every job): the second launch is left to kgw_adam_fused, which
 // adds the row blocks' partials in k_tn_reduce's order while it updates the parameter the gradient belongs to.
+// ``plan`` (nullable): fill it with the job table and return without launching anything (k_transform_bwd runs the blocks)
+struct TnPlan { TnJobs J; int blk, gy_max, gz_max; bool all_direct; };
 template <int MT, int NT>
-int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st, KgwGradSrc* defer = nullptr) {
+int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st, KgwGradSrc* defer = nullptr, TnPlan* plan = nullptr) {
     constexpr int FRAG = MT * NT * 16 * 64;
     TnJobs J{};
     J.n = n;
@@ -351,6 +359,7 @@ int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st, KgwGradSrc* defer = n
         gy_max = gy > gy_max ? gy : gy_max;
         gz_max = gz > gz_max ? gz : gz_max;
     }
+    if (plan) { plan->J = J; plan->blk = blk; plan->gy_max = gy_max; plan->gz_max = gz_max; plan->all_direct = all_direct; return KGW_OK; }
     const size_t lds_bytes = (size_t)(2 * FRAG + 4 * 32 * MT) * sizeof(float);
     auto kern = k_tn_gemm<MT, NT>;
     static KgwPerDevice attr_once;
@@ -2186,16 +2195,17 @@ struct SplitKJobs { SplitKArgs j[SK_MAX_JOBS]; int blk0[SK_MAX_JOBS + 1]; int n;
 struct ColsumJobs { const float* seg_stat[SK_MAX_JOBS]; const float* dY[SK_MAX_JOBS]; float* dgamma[SK_MAX_JOBS];
                     int64_t ldy[SK_MAX_JOBS], rows[SK_MAX_JOBS]; int R[SK_MAX_JOBS]; int blk0[SK_MAX_JOBS + 1]; int n; };
 
+// (the body of k_linear_splitk for block ``bxg`` of the jobs' concatenated grid; Xs: 2 x 32 x SK_LD floats of LDS; also inlined
+//  into k_transform_bwd)
 template <bool WKN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_linear_splitk(SplitKJobs J) {
-    __shared__ __attribute__((aligned(16))) float Xs[2][32 * SK_LD];
+__device__ __forceinline__ void splitk_block(const SplitKJobs& J, const int bxg, float (*Xs)[32 * SK_LD]) {
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lk = lane >> 5, w = tid >> 6;
     int jq = 0;
-    while (jq + 1 < J.n && (int)blockIdx.x >= J.blk0[jq + 1]) ++jq;
+    while (jq + 1 < J.n && bxg >= J.blk0[jq + 1]) ++jq;
     const SplitKArgs& a = J.j[jq];
     const bool ksplit = a.KS > 1;
     const int nslab_ = ksplit ? a.KS : a.NS;
-    const int bx = (int)blockIdx.x - J.blk0[jq];
+    const int bx = bxg - J.blk0[jq];
     const int slab = bx % nslab_, g = bx / nslab_;
     const int64_t rows_eff = sk_rows_eff(a);
     const int kx0 = ksplit ? slab * 128 : 0;           // first K column of the X tiles
@@ -2283,6 +2293,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (more) stage(buf ^ 1);
         __syncthreads();
     }
+}
+
+template <bool WKN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_linear_splitk(SplitKJobs J) {
+    __shared__ __attribute__((aligned(16))) float Xs[2][32 * SK_LD];
+    splitk_block<WKN>(J, (int)blockIdx.x, Xs);
 }
 
 // Forward transform in ONE launch (K = R * 128 > 128, N == 128, packed [K, N] weights): a block of EIGHT wavefronts owns a
@@ -2437,6 +2453,87 @@ __global__ void __launch_bounds__(1024) k_ind_colsum(ColsumJobs J) {
     }
 }
 
+// k_ind_colsum's work of block ``bxg`` on 256 threads: thread (phase group pg = 0..7, column): the four phases pg, pg + 8, pg + 16,
+// pg + 24 one after the other, each exactly as a thread of k_ind_colsum adds it; the 32 phase sums folded in the same order -- the
+// same bits
+__device__ __forceinline__ void ind_colsum_block256(const ColsumJobs& J, const int bxg, float* lds) {
+    float (*sm)[32] = (float (*)[32])lds;
+    int jq = 0;
+    while (jq + 1 < J.n && bxg >= J.blk0[jq + 1]) ++jq;
+    const float* __restrict__ seg_stat = J.seg_stat[jq];
+    const float* __restrict__ dY = J.dY[jq];
+    float* __restrict__ dgamma = J.dgamma[jq];
+    const int64_t ldy = J.ldy[jq], rows = J.rows[jq];
+    const int R = J.R[jq];
+    const int bx = bxg - J.blk0[jq];
+    const int cl = threadIdx.x & 31, r = bx >> 2, c = (bx & 3) * 32 + cl, pg = threadIdx.x >> 5;
+    // (the four phases advance together, sixteen loads in flight; every phase still adds its own rows in its own order)
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    int64_t t = 0;
+    for (; t + pg + 96 < rows; t += 128) {               // (phase pg, the thread's first, has the longest main loop)
+        float d[4][4], v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = t + pg + 8 * u;
+            const bool on = i + 96 < rows;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t row = on ? i + 32 * q : 0;
+                d[u][q] = seg_stat[2 * (row * R + r) + 1]; v[u][q] = dY[row * ldy + c];
+                if (!on) d[u][q] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[u] += d[u][q] > 0.f ? v[u][q] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        // where phase ph's main loop stopped: the first multiple of 128 (from ph) with i + 96 >= rows
+        const int ph = pg + 8 * u;
+        int64_t i = ph;
+        if (rows > ph + 96) i = ph + ((rows - ph - 97) / 128 + 1) * 128;
+        for (; i < rows; i += 32)
+            if (seg_stat[2 * (i * R + r) + 1] > 0.f) s[u] += dY[i * ldy + c];
+        sm[ph][cl] = s[u];
+    }
+    __syncthreads();
+    if (pg == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) tot += sm[q][cl];
+        dgamma[r * 128 + c] = tot;
+    }
+}
+
+// The backward of a layer's relation transform in ONE launch: everything that is a function of d(output) alone --
+//   the weight / bias gradients  dW^T = Z^T dY  (k_tn_gemm<2,2>'s row-block partials; k_tn_reduce follows as before),
+//   the dZ twins                 dZ = dY W^T    (k_linear_splitk<false>),
+//   the d gamma sums of a folded layer          (k_ind_colsum)
+// -- as blocks of one grid.  They are independent of each other, each is a few hundred latency-bound blocks at two per CU, and as
+// three launches one after the other each waits for the last block of the one before it.  Same code per block, same values.
+struct TransformBwdIdx { int tn_flat0[TN_MAX_JOBS + 1]; int n_sk, n_tn, n_cs; };
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_transform_bwd(TnJobs JT, SplitKJobs JS, ColsumJobs JC, TransformBwdIdx X) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // (the column-sum blocks first: few, and the longest -- a row walk per block; then the products' row blocks, then the twins)
+    const int b = (int)blockIdx.x;
+    if (b < X.n_cs) {
+        ind_colsum_block256(JC, b, lds);
+    } else if (b < X.n_cs + X.n_tn) {
+        const int t = b - X.n_cs;
+        int jq = 0;
+        while (jq + 1 < JT.n && t >= X.tn_flat0[jq + 1]) ++jq;
+        const TnJob& T = JT.j[jq];
+        const int l = t - X.tn_flat0[jq];
+        const int bx = l % T.nblk, rest = l / T.nblk;
+        tn_gemm_block<2, 2>(T, bx, rest % T.gy, rest / T.gy, lds);
+    } else {
+        splitk_block<false>(JS, b - X.n_cs - X.n_tn, (float (*)[32 * SK_LD])lds);
+    }
+}
+
 int splitk_launch(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy, int64_t rows,
                   int32_t K, int32_t N, int32_t relu, int32_t w_is_kn, float* workspace, int64_t workspace_floats,
                   const int32_t* rows_dev, const float* seg_stat, const float* gamma, kgw_stream_t stream_);
@@ -2459,6 +2556,84 @@ extern "C" int kgw_ind_colsum_multi(int32_t n_jobs, const KgwSplitKJob* jobs, kg
     J.blk0[n_jobs] = blk; J.n = n_jobs;
     k_ind_colsum<<<blk, 1024, 0, (hipStream_t)stream_>>>(J);
     KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+extern "C" int kgw_transform_bwd(int32_t n_tn, const KgwTnJob* tn_jobs, int32_t n_sk, const KgwSplitKJob* sk_jobs, int32_t n_cs,
+                                 const KgwSplitKJob* cs_jobs, kgw_stream_t stream_) {
+    if (n_tn < 0 || n_sk < 0 || n_cs < 0 || n_tn > TN_MAX_JOBS || n_sk > SK_MAX_JOBS || n_cs > SK_MAX_JOBS) return KGW_E_RANGE;
+    if ((n_tn && !tn_jobs) || (n_sk && !sk_jobs) || (n_cs && !cs_jobs)) return KGW_E_NULL;
+    if (n_tn + n_sk + n_cs == 0) return KGW_OK;
+    hipStream_t st = (hipStream_t)stream_;
+    auto aligned8 = [](const void* p) { return ((uintptr_t)p & 7) == 0; };
+    // weight-gradient products: kgw_tn_gemm_multi's checks and plan (64 x 64-per-wavefront tiling)
+    TnPlan P{};
+    if (n_tn) {
+        TnDesc d[TN_MAX_JOBS];
+        for (int q = 0; q < n_tn; ++q) {
+            const KgwTnJob& j = tn_jobs[q];
+            if (!j.A || !j.B || !j.C || !j.workspace) return KGW_E_NULL;
+            if (j.M <= 0 || j.N <= 0 || j.rows <= 0 || j.lda < j.M || j.ldb < j.N || j.ldc < (j.c_transposed ? j.M : j.N)) return KGW_E_RANGE;
+            if (j.colsum_a && (j.colsum_repeat < 1 || (j.colsum_repeat > 1 && j.colsum_ld < j.M))) return KGW_E_RANGE;
+            if ((j.M & 1) || (j.lda & 1) || !aligned8(j.A) || (j.N & 1) || (j.ldb & 1) || !aligned8(j.B)) return KGW_E_UNSUPPORTED;
+            d[q] = TnDesc{j.A, j.lda, j.M, j.B, j.ldb, j.N, j.rows, j.C, j.ldc, j.c_transposed != 0, j.colsum_a,
+                          j.colsum_a ? j.colsum_repeat : 0, j.colsum_ld, j.workspace, j.workspace_floats, j.rows_dev};
+        }
+        const int rc = launch_tn_jobs<2, 2>(d, n_tn, st, nullptr, &P);
+        if (rc != KGW_OK) return rc;
+    }
+    TransformBwdIdx X{};
+    X.tn_flat0[0] = 0;
+    for (int q = 0; q < n_tn; ++q) X.tn_flat0[q + 1] = X.tn_flat0[q] + P.J.j[q].nblk * P.J.j[q].gy * P.J.j[q].gz;
+    X.n_tn = X.tn_flat0[n_tn];
+    // dZ twins: kgw_linear_splitk_multi's K == 128 kind with [N, K] weights
+    SplitKJobs JS{};
+    int blk = 0, n = 0;
+    for (int q = 0; q < n_sk; ++q) {
+        const KgwSplitKJob& D = sk_jobs[q];
+        if (D.rows == 0) continue;
+        if (!D.X || !D.W || !D.Y) return KGW_E_NULL;
+        if (D.rows < 0 || D.N <= 0) return KGW_E_RANGE;
+        if (D.K != 128 || D.seg_stat || D.w_is_kn || (D.N & 127) || (D.ldx & 3) || (D.ldw & 3) || (D.ldy & 3) || !aligned16(D.X) ||
+            !aligned16(D.W) || !aligned16(D.Y) || (D.bias && !aligned16(D.bias)))
+            return KGW_E_UNSUPPORTED;
+        SplitKArgs a{D.X, D.ldx, D.W, D.ldw, D.bias, D.Y, D.ldy, nullptr, D.rows, D.K, D.N, D.relu, D.w_is_kn,
+                     (int)((D.rows + 31) / 32), D.K / 128, D.N / 128, 1, nullptr, nullptr, nullptr};
+        static const int target = getenv("KGW_SPLITK_BLOCKS") ? atoi(getenv("KGW_SPLITK_BLOCKS")) : 512;
+        int G = (target + a.NS - 1) / a.NS;
+        if (G > a.RT) G = a.RT;
+        if (G < 1) G = 1;
+        a.G = G;
+        JS.blk0[n] = blk;
+        blk += a.NS * G;
+        JS.j[n++] = a;
+    }
+    JS.blk0[n] = blk; JS.n = n;
+    X.n_sk = blk;
+    ColsumJobs JC{};
+    blk = 0;
+    for (int q = 0; q < n_cs; ++q) {
+        const KgwSplitKJob& D = cs_jobs[q];
+        if (!D.seg_stat || !D.Y || !D.dgamma) return KGW_E_NULL;
+        if (D.rows < 0 || D.K <= 0 || (D.K & 127)) return KGW_E_RANGE;
+        JC.seg_stat[q] = D.seg_stat; JC.dY[q] = D.Y; JC.dgamma[q] = D.dgamma; JC.ldy[q] = D.ldy; JC.rows[q] = D.rows; JC.R[q] = D.K / 128;
+        JC.blk0[q] = blk;
+        blk += 4 * (D.K / 128);
+    }
+    JC.blk0[n_cs] = blk; JC.n = n_cs;
+    X.n_cs = blk;
+    constexpr int FRAG = 2 * 2 * 16 * 64;
+    constexpr size_t lds_bytes = (size_t)(2 * FRAG + 4 * 32 * 2) * sizeof(float);
+    static_assert(lds_bytes >= 2 * 32 * SK_LD * sizeof(float) && lds_bytes >= 32 * 32 * sizeof(float), "one LDS buffer serves the three block kinds");
+    const int total = X.n_sk + X.n_tn + X.n_cs;
+    if (total > 0) {
+        k_transform_bwd<<<total, 256, lds_bytes, st>>>(P.J, JS, JC, X);
+        KGW_LAUNCH_CHECK();
+    }
+    if (n_tn && !P.all_direct) {
+        k_tn_reduce<2, 2><<<dim3(FRAG / 64, P.gy_max, P.gz_max * n_tn), 256, 0, st>>>(P.J, P.gz_max);
+        KGW_LAUNCH_CHECK();
+    }
     return KGW_OK;
 }
 

@@ -1622,6 +1622,56 @@ def _transform_multi_forward(w_src_t, Z, blocks, bsum, out_blocks, gamma, stat, 
     return outs
 
 
+_MERGED_TRANSFORM_BWD = os.environ.get('KGW_MERGED_TRANSFORM_BWD', '1') != '0'     # (A/B: the three launches one after the other)
+
+
+def _transform_bwd_merged(live_blocks, dW, db, dZ, w_src_t, gamma, stat, dgamma, C) -> bool:
+    """_LayerTransform.backward's three kinds of work in one kgw_transform_bwd call; False (nothing launched) when a shape is
+    outside what the merged kernel's blocks take."""
+    n = len(live_blocks)
+    if not 1 <= n <= 4:
+        return False
+    L = _lib.lib()
+    tn = (_lib.KgwTnJob * n)()
+    sk = (_lib.KgwSplitKJob * n)()
+    cs = (_lib.KgwSplitKJob * n)()
+    keep = []
+    for q, (lo, hi, z0, rows, R, x, dz) in enumerate(live_blocks):
+        out, bs = dW[lo:hi].view(R * C, C), db[lo:hi]
+        A, B = dz, x                                         # C^T = (A^T B)^T with column sums of A: see _tn_gemm_group
+        if not (A.dtype == torch.float32 and B.dtype == torch.float32 and A.stride(1) == 1 and B.stride(1) == 1 and out.stride(1) == 1 and
+                bs.stride(1) == 1 and A.shape[0] == B.shape[0] and A.shape[0] > 0 and A.shape[1] % 2 == 0 and B.shape[1] % 2 == 0 and
+                A.shape[1] >= 64 and B.shape[1] >= 64 and A.stride(0) % 2 == 0 and B.stride(0) % 2 == 0 and A.data_ptr() % 8 == 0 and
+                B.data_ptr() % 8 == 0):
+            return False
+        if not (rows < _SPLITK_MAX_ROWS and dz.stride(0) % 4 == 0 and dz.data_ptr() % 16 == 0 and C == KGW_C):
+            return False
+        M, N = A.shape[1], B.shape[1]
+        nws = int(L.kgw_tn_gemm_workspace_floats(rows, M, N))
+        ws = torch.empty(nws, device=A.device)
+        keep.append(ws)
+        j = tn[q]
+        j.A, j.lda, j.B, j.ldb, j.rows = _p(A), A.stride(0), _p(B), B.stride(0), rows
+        j.C, j.ldc, j.colsum_a, j.colsum_ld = _p(out), out.stride(0), _p(bs), bs.stride(0)
+        j.workspace, j.workspace_floats, j.rows_dev = _p(ws), nws, None
+        j.M, j.N, j.c_transposed, j.colsum_repeat = M, N, 1, bs.shape[0]
+        if dZ is not None:
+            W = w_src_t[lo:hi].view(R * C, C)
+            y = dZ[z0:z0 + rows * R].view(rows, R * C)
+            if W.stride(0) % 4 or W.data_ptr() % 16 or y.stride(0) % 4 or y.data_ptr() % 16:
+                return False
+            k = sk[q]
+            k.X, k.ldx, k.W, k.ldw, k.bias = dz.data_ptr(), dz.stride(0), W.data_ptr(), W.stride(0), None
+            k.Y, k.ldy, k.rows, k.K, k.N, k.relu, k.w_is_kn = y.data_ptr(), y.stride(0), rows, C, R * C, 0, 0
+        if gamma is not None:
+            g = cs[q]
+            g.seg_stat, g.Y, g.ldy, g.rows, g.K = stat.data_ptr() + 8 * z0, dz.data_ptr(), dz.stride(0), rows, R * C
+            g.dgamma = dgamma[lo:hi].data_ptr()
+    _lib.check(L.kgw_transform_bwd(n, tn, n if dZ is not None else 0, sk, n if gamma is not None else 0, cs, _lib.stream_ptr()),
+               'kgw_transform_bwd')
+    return True
+
+
 class _LayerTransform(torch.autograd.Function):
     """h_d = relu([Z[:, r0] | Z[:, r1] | ...] @ [W_r0^T ; W_r1^T ; ...] + sum_r bias_r) for every destination
     type of a layer (lin_src of kgwas/conv.py:138/142 + bias :190 + HeteroConv sum model.py:74 + ReLU :75).
@@ -1698,6 +1748,10 @@ class _LayerTransform(torch.autograd.Function):
             # (premasked: the consumer of y already multiplied its gradient by (y > 0))
             dz = dy.contiguous() if ctx.premasked else torch.ops.aten.threshold_backward(dy.contiguous(), ys[k], 0.0)
             live_blocks.append((lo, hi, z0, rows, R, x, dz))
+        # everything that is a function of dz alone -- weight / bias gradients, dZ twins, d gamma sums, of every destination type -- as
+        # blocks of ONE launch (+ the split-K products' second) where the kernels' shape conditions hold (kgw_transform_bwd)
+        if _MERGED_TRANSFORM_BWD and _transform_bwd_merged(live_blocks, dW, db, dZ if need_dz else None, w_src_t, gamma, stat, dgamma, C):
+            return dW, db, dZ, None, None, None, None, dgamma, None
         # dWt = x^T dz lands transposed in place (the pack keeps [in, out]); db = colsum(dz) for each relation: the
         # destination types' products in ONE launch pair when the grouped kernel takes them
         if not _tn_gemm_group([(dz, x, dW[lo:hi].view(R * C, C), db[lo:hi]) for lo, hi, z0, rows, R, x, dz in live_blocks]):

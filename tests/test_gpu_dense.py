@@ -463,6 +463,80 @@ def test_layer_transforms_of_all_destination_types_in_one_launch():
     assert L.kgw_linear_splitk_multi(5, jobs, st) == -2
 
 
+@pytest.mark.parametrize('shapes', [[(1171, 17), (512, 6), (77, 3)], [(512, 6)], [(4000, 2), (33, 1)]])
+@pytest.mark.parametrize('with_dz,with_gamma', [(True, True), (True, False), (False, True)])
+def test_transform_backward_in_one_launch(shapes, with_dz, with_gamma):
+    """kgw_transform_bwd: the weight / bias gradients (Z^T dY, column sums), the dZ twins (dY W^T) and the d gamma sums of a layer's
+    destination types as blocks of ONE launch -- bit for bit what kgw_tn_gemm_multi + kgw_linear_splitk_multi + kgw_ind_colsum_multi
+    give one after the other (the same code per block), and close to float64."""
+    from kgwas_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(len(shapes) * 7 + shapes[0][0])
+    st = _lib.stream_ptr()
+    n = len(shapes)
+    Zs = [torch.randn(r, R * 128, generator=g).cuda() for r, R in shapes]
+    Ws = [(torch.randn(R * 128, 128, generator=g) * 0.05).cuda() for r, R in shapes]
+    dys = [torch.randn(r, 128, generator=g).cuda() for r, R in shapes]
+    stat = [torch.stack([torch.randn(r * R, generator=g), (torch.rand(r * R, generator=g) > 0.3).float()], 1).cuda() for r, R in shapes]
+
+    def run(merged):
+        dW = [torch.full((R * 128, 128), float('nan'), device='cuda') for r, R in shapes]
+        db = [torch.full((R, 128), float('nan'), device='cuda') for r, R in shapes]
+        dZ = [torch.full((r, R * 128), float('nan'), device='cuda') for r, R in shapes]
+        dg = [torch.full((R, 128), float('nan'), device='cuda') for r, R in shapes]
+        tn = (_lib.KgwTnJob * n)(); sk = (_lib.KgwSplitKJob * n)(); cs = (_lib.KgwSplitKJob * n)()
+        keep = []
+        for q, (r, R) in enumerate(shapes):
+            nws = int(L.kgw_tn_gemm_workspace_floats(r, 128, R * 128))
+            ws = torch.empty(nws, device='cuda'); keep.append(ws)
+            j = tn[q]
+            j.A, j.lda, j.B, j.ldb, j.rows = dys[q].data_ptr(), 128, Zs[q].data_ptr(), Zs[q].stride(0), r
+            j.C, j.ldc, j.colsum_a, j.colsum_ld = dW[q].data_ptr(), 128, db[q].data_ptr(), 128
+            j.workspace, j.workspace_floats, j.rows_dev = ws.data_ptr(), nws, None
+            j.M, j.N, j.c_transposed, j.colsum_repeat = 128, R * 128, 1, R
+            k = sk[q]
+            k.X, k.ldx, k.W, k.ldw, k.bias, k.Y, k.ldy, k.rows = dys[q].data_ptr(), 128, Ws[q].data_ptr(), 128, None, dZ[q].data_ptr(), R * 128, r
+            k.K, k.N, k.relu, k.w_is_kn = 128, R * 128, 0, 0
+            c = cs[q]
+            c.seg_stat, c.Y, c.ldy, c.rows, c.K, c.dgamma = stat[q].data_ptr(), dys[q].data_ptr(), 128, r, R * 128, dg[q].data_ptr()
+        if merged:
+            _lib.check(L.kgw_transform_bwd(n, tn, n if with_dz else 0, sk, n if with_gamma else 0, cs, st), 'kgw_transform_bwd')
+        else:
+            if n > 1:
+                _lib.check(L.kgw_tn_gemm_multi(n, tn, st), 'tn multi')
+            else:
+                j = tn[0]
+                _lib.check(L.kgw_tn_gemm_ex(j.A, j.lda, j.M, j.B, j.ldb, j.N, j.rows, j.C, j.ldc, 1, j.colsum_a, j.colsum_repeat, j.colsum_ld,
+                                            j.workspace, j.workspace_floats, None, st), 'tn single')
+            if with_dz:
+                _lib.check(L.kgw_linear_splitk_multi(n, sk, st), 'twin multi')
+            if with_gamma:
+                _lib.check(L.kgw_ind_colsum_multi(n, cs, st), 'colsum multi')
+        torch.cuda.synchronize()
+        return dW, db, dZ, dg
+
+    a, b = run(True), run(False)
+    for q, (r, R) in enumerate(shapes):
+        assert torch.equal(a[0][q], b[0][q]) and torch.equal(a[1][q], b[1][q])
+        assert_close(a[0][q], Zs[q].double().t() @ dys[q].double(), 1e-4, 1e-5, 'dW^T vs fp64', rel_to_max=1e-5)
+        assert_close(a[1][q], dys[q].double().sum(0).expand(R, 128), 1e-4, 1e-5, 'db vs fp64', rel_to_max=1e-5)
+        if with_dz:
+            assert torch.equal(a[2][q], b[2][q])
+            assert_close(a[2][q], dys[q].double() @ Ws[q].double().t(), 1e-4, 1e-5, 'dZ vs fp64', rel_to_max=1e-5)
+        else:
+            assert bool(torch.isnan(a[2][q]).all())
+        if with_gamma:
+            assert torch.equal(a[3][q], b[3][q])
+            ref = ((stat[q][:, 1] > 0).double().view(r, R, 1) * dys[q].double().view(r, 1, 128)).sum(0)
+            assert_close(a[3][q], ref, 1e-4, 1e-5, 'd gamma vs fp64', rel_to_max=1e-5)
+        else:
+            assert bool(torch.isnan(a[3][q]).all())
+    # argument checks before any launch
+    assert L.kgw_transform_bwd(5, None, 0, None, 0, None, st) == -2
+    assert L.kgw_transform_bwd(1, None, 0, None, 0, None, st) == -1
+    assert L.kgw_transform_bwd(0, None, 0, None, 0, None, st) == 0
+
+
 @pytest.mark.parametrize('n,rows', [(512, 512), (500, 576), (1, 1), (5000, 5120)])
 def test_readout_loss_training_node_matches_autograd(n, rows):
     """kgw_readout_wmse_train (unit loss gradient: forward + backward of the read-out + LD-weighted MSE node together, the
