@@ -216,7 +216,7 @@ class GraphTrainStep:
             with ops.grad_sink_scope(sink):
                 loss.backward(gradient=self._unit)                     # (a resident 1.0: no ones_like fill per step)
             if sink is not None:
-                self.deferred_gradients = len(sink.records)            # (gradients whose last sums the optimiser launch takes)
+                self.deferred_gradients = len(sink.records) + 2 * len(sink.products)   # (gradients whose last sums the optimiser launch takes)
                 self.opt.step_fused(sink, buf.meta.data_ptr(), self.run.gnn_num_layers, self.dg.n_hops, self.stats)
                 if self.overlap:
                     main.wait_stream(self._side)                       # join

@@ -47,11 +47,13 @@ class FusedAdam:
         launch.  Raises ops.GradSinkMismatch (nothing launched) when the fused form does not apply; the caller then runs the
         unfused step."""
         from . import ops
+        if sink is not None:
+            sink.flush()                     # the deferred weight-gradient products: one launch, just ahead of this one
         live = [p for p in self.params if p.grad is not None]
         recs = {}
         for p in live:
             r = sink.take(p.grad) if sink is not None else None
-            if r is not None:
+            if r is not None and r[0] is not None:           # (r[0] None: a deferred product that came out complete -- only matched)
                 recs[p] = r
         if sink is not None and sink.records:
             n = len(sink.records)

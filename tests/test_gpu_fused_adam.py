@@ -58,8 +58,9 @@ def test_tn_partial_sums_finished_by_adam(rows, M, N, tr):
     assert int(oa.step_dev) == 3 and int(oa.done_dev.abs().sum()) == 0
 
 
-def test_grouped_products_and_leftover_record():
+def test_grouped_products_and_leftover_record(monkeypatch):
     from kgwas_amd import ops
+    monkeypatch.setattr(ops, '_DEFER_PRODUCTS', False)
     g = torch.Generator(device='cpu').manual_seed(5)
     rows = 9000
     dY1, X1 = torch.randn(rows, 128, generator=g).to(DEV), torch.randn(rows, 128, generator=g).to(DEV)
@@ -88,11 +89,15 @@ def test_grouped_products_and_leftover_record():
         assert torch.equal(p, q)
 
 
-@pytest.mark.parametrize('rows,K1', [(40000, 20), (16384, 4), (122880, 20)])
-def test_mlp2_first_layer_partials_finished_by_adam(rows, K1):
+@pytest.mark.parametrize('rows,K1,defer_products', [(40000, 20, False), (16384, 4, False), (122880, 20, False), (40000, 20, True),
+                                                   (200, 20, True)])
+def test_mlp2_first_layer_partials_finished_by_adam(rows, K1, defer_products, monkeypatch):
     """_MLP2's backward (kgwas/model.py:18-20 on the 20-wide SNP features): d W1 / d b1 from kgw_mlp2_bwd_first's block partials,
     d W2 / d b2 from the split-K product's -- all four finished inside kgw_adam_fused."""
     from kgwas_amd import ops
+    # (defer_products: the experiment knob KGW_DEFER_PRODUCTS -- the d W2 product itself is launched by step_fused, grouped with
+    #  whatever else was deferred; 200 rows: a product with one row block, complete after its first launch, still matched)
+    monkeypatch.setattr(ops, '_DEFER_PRODUCTS', defer_products)
     g = torch.Generator(device='cpu').manual_seed(rows)
     x = torch.rand(rows, K1, generator=g).to(DEV)
     dh2 = (torch.randn(rows, 128, generator=g) * (torch.rand(rows, 128, generator=g) > 0.5)).to(DEV)
@@ -109,7 +114,9 @@ def test_mlp2_first_layer_partials_finished_by_adam(rows, K1):
             with ops.grad_sink_scope(sink):
                 h2.backward(dh2)
             if fused:
-                assert len(sink.records) == 4
+                if rows >= 16384:
+                    assert len(sink.records) + 2 * len(sink.products) == 4    # (products: only with KGW_DEFER_PRODUCTS=1)
+                    assert len(sink.products) == (1 if defer_products else 0)
                 opt.step_fused(sink)
             else:
                 opt.step()
