@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KGW_VERSION      119          /* 0.1.9 */
+#define KGW_VERSION      120          /* 0.2.0 */
 #define KGW_MAX_TYPES    8
 #define KGW_MAX_RELS     64
 #define KGW_MAX_LAYERS   4
@@ -521,6 +521,13 @@ int kgw_adam_fused(int32_t n_tensors, float* const* params, float* const* grads,
                    float* const* exp_avg_sq, const int64_t* numel, const KgwGradSrc* src, int32_t* step_dev, float lr,
                    float beta1, float beta2, float eps, float weight_decay, const KgwBatchMeta* meta_dev, int32_t n_layers,
                    int32_t n_hops, int64_t* stats, int32_t* done_counters, kgw_stream_t stream);
+
+/* The same work units WITHOUT the update, for the multi-GPU step (the ranks' gradients must be complete before the all-reduce):
+ * dst[i] (the tensor's slot in a flat gradient bucket) = the finished gradient of tensor i -- a copy of grads[i] where src[i] is
+ * KGW_GRAD_DIRECT (or src NULL), the sum of the producer's partial records otherwise (then also stored into grads[i]).  One launch
+ * instead of the producers' second launches + the bucket's concatenation.                                                      */
+int kgw_grad_finish(int32_t n_tensors, float* const* dst, float* const* grads, const int64_t* numel, const KgwGradSrc* src,
+                    kgw_stream_t stream);
 
 /* Attention vectors of all relations of a layer (kgwas/conv.py:138-151 reduced to what the path consumes):
  * U_full[r] = W_src^T att_src for every relation id r the layer computes (live_of_rel[r] = its index i in the

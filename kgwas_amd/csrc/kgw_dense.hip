@@ -3059,10 +3059,13 @@ __device__ __forceinline__ float adam_src_sum(const KgwGradSrc& S, int64_t i, bo
     }
 }
 
+// UPD = false (kgw_grad_finish): no update -- the finished gradient goes to T.p[i], here the tensor's slot in a flat all-reduce
+// bucket (and into the gradient tensor itself where it was a sum of partial records); no counters, nothing read from ``step``.
+template <bool UPD>
 __global__ void __launch_bounds__(256) k_adam_fused(AdamFTab T, AdamTail Z, int32_t* step, float lr, float b1, float b2, float eps,
                                                     float wd) {
     __shared__ float sm[32 * 33];                       // 16 x 64 partial sums of a sourced unit / one 32 x 33 tile (G3T)
-    const int t_now = *step + 1;                       // (the counter moves only after every block has arrived at the end)
+    const int t_now = UPD ? *step + 1 : 1;             // (the counter moves only after every block has arrived at the end)
     const float bc1 = 1.0f - powf(b1, (float)t_now);
     const float bc2 = 1.0f - powf(b2, (float)t_now);
     const float step_size = lr / bc1;
@@ -3112,6 +3115,17 @@ __global__ void __launch_bounds__(256) k_adam_fused(AdamFTab T, AdamTail Z, int3
             {
                 const int r = threadIdx.x & 31;
                 float pq[4], mq[4], vq[4], gq[4];
+                if constexpr (!UPD) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int col = (threadIdx.x >> 5) + 8 * q;
+                        const int64_t i = (int64_t)(cb + col) * Mr + r0 + r;
+                        const float g = tl[r][col];
+                        Gr[i] = g; P[i] = g;
+                    }
+                    __syncthreads();
+                    continue;
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {                  // (all loads of the thread's four elements first)
                     const int col = (threadIdx.x >> 5) + 8 * q;
@@ -3155,14 +3169,23 @@ __global__ void __launch_bounds__(256) k_adam_fused(AdamFTab T, AdamTail Z, int3
             const float gs = adam_src_sum(T.src[si], i, valid, fl, G, sm);
             if (G == 0 && valid) {
                 Gr[i] = gs;
-                float p = P[i], m = M[i], v = V[i];
-                adam_update(p, gs, m, v, wd, b1, b2, eps, step_size, bc2_sqrt);
-                M[i] = m; V[i] = v; P[i] = p;
+                if constexpr (UPD) {
+                    float p = P[i], m = M[i], v = V[i];
+                    adam_update(p, gs, m, v, wd, b1, b2, eps, step_size, bc2_sqrt);
+                    M[i] = m; V[i] = v; P[i] = p;
+                } else {
+                    P[i] = gs;
+                }
             }
             __syncthreads();                           // (sm is reused by the block's next unit)
             continue;
         }
         const int64_t j = (c - T.coff[lo]) * 1024 + (int64_t)threadIdx.x * 4;
+        if constexpr (!UPD) {                          // a complete gradient: copied to its slot
+            if (j + 4 <= n && T.vec[lo]) *(float4*)(P + j) = *(const float4*)(Gr + j);
+            else for (int64_t i = j; i < n && i < j + 4; ++i) P[i] = Gr[i];
+            continue;
+        }
         if (j + 4 <= n && T.vec[lo]) {
             float4 p = *(float4*)(P + j), m = *(float4*)(M + j), v = *(float4*)(V + j);
             const float4 g0 = *(const float4*)(Gr + j);
@@ -3187,6 +3210,7 @@ __global__ void __launch_bounds__(256) k_adam_fused(AdamFTab T, AdamTail Z, int3
     // invalidate per block on this multi-die part (135 us for the launch); nothing is published through the counters: the only
     // ordering needed is "every block has READ *step before the last one writes it", each block's read was consumed before its
     // atomic is issued, and the last block's store depends on the values its atomics return.
+    if constexpr (!UPD) return;
     __syncthreads();
     if (threadIdx.x == 0) {
         const int slot = (int)(blockIdx.x & 63), in_slot = ((int)gridDim.x - slot + 63) >> 6;
@@ -3210,6 +3234,9 @@ __global__ void __launch_bounds__(256) k_adam_fused(AdamFTab T, AdamTail Z, int3
 
 }  // namespace
 
+static int adam_fused_table(AdamFTab& T, int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                            float* const* exp_avg_sq, const int64_t* numel, const KgwGradSrc* src);
+
 extern "C" int kgw_adam_fused(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                               float* const* exp_avg_sq, const int64_t* numel, const KgwGradSrc* src, int32_t* step_dev, float lr,
                               float beta1, float beta2, float eps, float weight_decay, const KgwBatchMeta* meta_dev,
@@ -3219,6 +3246,40 @@ extern "C" int kgw_adam_fused(int32_t n_tensors, float* const* params, float* co
     if (n_tensors > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numel)) return KGW_E_NULL;
     if (meta_dev && (!stats || n_layers < 1 || n_layers > KGW_MAX_LAYERS || n_hops < 1 || n_hops > n_layers)) return KGW_E_RANGE;
     AdamFTab T;
+    const int rc = adam_fused_table(T, n_tensors, params, grads, exp_avg, exp_avg_sq, numel, src);
+    if (rc != KGW_OK) return rc;
+    AdamTail Z{meta_dev, stats, done_counter, n_layers, n_hops};
+    int64_t g = T.coff[n_tensors];
+    if (g > 4 * KGW_GRID) g = 4 * KGW_GRID;
+    if (g < 1) g = 1;
+    k_adam_fused<true><<<(int)g, 256, 0, (hipStream_t)stream_>>>(T, Z, step_dev, lr, beta1, beta2, eps, weight_decay);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+// The gradients of a multi-GPU step on their way into the all-reduce bucket: dst[i] = the finished gradient of tensor i -- a copy of
+// grads[i] where that is complete, the sum of its producer's partial records where src[i] says so (also stored into grads[i]) --
+// in ONE launch: k_adam_fused's work units without the update.
+extern "C" int kgw_grad_finish(int32_t n_tensors, float* const* dst, float* const* grads, const int64_t* numel, const KgwGradSrc* src,
+                               kgw_stream_t stream_) {
+    if (n_tensors < 0 || n_tensors > KGW_ADAM_FUSED_MAX) return KGW_E_RANGE;
+    if (n_tensors == 0) return KGW_OK;
+    if (!dst || !grads || !numel) return KGW_E_NULL;
+    AdamFTab T;
+    const int rc = adam_fused_table(T, n_tensors, dst, grads, dst, dst, numel, src);
+    if (rc != KGW_OK) return rc;
+    for (int i = 0; i < n_tensors; ++i)
+        if (src && src[i].kind == KGW_GRAD_G3T && src[i].packed) return KGW_E_UNSUPPORTED;      // (no update, no image)
+    AdamTail Z{};
+    int64_t g = T.coff[n_tensors];
+    if (g > 4 * KGW_GRID) g = 4 * KGW_GRID;
+    k_adam_fused<false><<<(int)g, 256, 0, (hipStream_t)stream_>>>(T, Z, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+static int adam_fused_table(AdamFTab& T, int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                            float* const* exp_avg_sq, const int64_t* numel, const KgwGradSrc* src) {
     T.n = n_tensors;
     T.off[0] = 0;
     T.coff[0] = 0;
@@ -3255,12 +3316,6 @@ extern "C" int kgw_adam_fused(int32_t n_tensors, float* const* params, float* co
         T.coff[i + 1] = T.coff[i] + (numel[i] + per - 1) / per;
         T.vec[i] = (((uintptr_t)params[i] | (uintptr_t)grads[i] | (uintptr_t)exp_avg[i] | (uintptr_t)exp_avg_sq[i]) & 15) == 0;
     }
-    AdamTail Z{meta_dev, stats, done_counter, n_layers, n_hops};
-    int64_t g = T.coff[n_tensors];
-    if (g > 4 * KGW_GRID) g = 4 * KGW_GRID;
-    if (g < 1) g = 1;
-    k_adam_fused<<<(int)g, 256, 0, (hipStream_t)stream_>>>(T, Z, step_dev, lr, beta1, beta2, eps, weight_decay);
-    KGW_LAUNCH_CHECK();
     return KGW_OK;
 }
 

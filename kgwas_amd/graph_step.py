@@ -96,8 +96,10 @@ class GraphTrainStep:
         self.fused_adam = (ops._FUSED_ADAM and self.capture_optimizer and not self._multi and
                            sum(1 for p in self.model.parameters() if p.requires_grad) <= _lib.ADAM_FUSED_MAX)
         self.deferred_gradients = 0
+        self.finish_fused = False          # (set below: multi-rank split backward)
         self._images, self._image_params, self._image_version, self._pack_probe = {}, [], {}, None
         self.split_backward = self._multi and os.environ.get('KGW_SPLIT_BACKWARD', '1') == '1'
+        self.finish_fused = ops._FUSED_ADAM and self.split_backward
         # multi-rank, optional: the first gene Linear over the resident feature matrix (forward + weight gradient: 0.27 of the
         # step's 1.2 ms, identical work on every rank) split by gene rows over the ranks -- ops.GeneLayerShard in its STAGED form:
         # partial product (captured) | all-gather | the step's graphs | reduce-scatter of dz | partial weight gradient (captured).
@@ -263,7 +265,12 @@ class GraphTrainStep:
         """Second half of the split backward: from the feature MLPs' outputs down to their weights."""
         hs, dhs = self._cut[cur]
         keep = [(h, d) for h, d in zip(hs, dhs) if d is not None]
-        torch.autograd.backward([h for h, _ in keep], grad_tensors=[d for _, d in keep])
+        # (finish_fused: the MLPs' weight-gradient products stop after their first launch and ONE launch writes every finished
+        #  gradient of this half into its slot of the bucket -- kgw_grad_finish: the fused optimiser launch's work units without the
+        #  update, which has to wait for the all-reduce here)
+        sink = ops.GradSink() if self.finish_fused else None
+        with ops.grad_sink_scope(sink):
+            torch.autograd.backward([h for h, _ in keep], grad_tensors=[d for _, d in keep])
         late = self._late_params()
         live = [p for p in self.model.parameters() if id(p) in late and p.grad is not None]
         gs = self.gene_shard
@@ -278,7 +285,26 @@ class GraphTrainStep:
                 off += p.numel()
             if staged:
                 self._flat_grads[w1] = self._flat_b[off:off + w1.numel()].view_as(w1)
-        torch.cat([p.grad.reshape(-1) for p in live], out=self._flat_b[:n_live])
+        if sink is not None:
+            self.deferred_gradients = len(sink.records) + 2 * len(sink.products)
+            self.opt.finish_into(sink, [(p, self._flat_grads[p]) for p in live])
+        else:
+            torch.cat([p.grad.reshape(-1) for p in live], out=self._flat_b[:n_live])
+
+    def _warm_step(self, k: int):
+        """One eager step of the capture warm-up; a fused form that does not apply to this model (ops.GradSinkMismatch, raised before
+        the launch that would have used it) is switched off and the step issued again."""
+        try:
+            self._step_body(k)
+            if self.split_backward:
+                self._step_body_b(k)
+        except ops.GradSinkMismatch as e:
+            print(f'kgwas_amd: fused gradient-finishing launch not used ({e})', file=sys.stderr)
+            self.fused_adam = self.finish_fused = False
+            self.opt.zero_grad(set_to_none=True)
+            self._step_body(k)
+            if self.split_backward:
+                self._step_body_b(k)
 
     def _sample_now(self, which: int, i: int):
         b = self.batch_size
@@ -300,9 +326,7 @@ class GraphTrainStep:
                 # and then directly in its staged form: no collective is ever issued from inside an autograd node here
                 import torch.distributed as dist
                 self._probe = []
-                self._step_body(0)
-                if self.split_backward:
-                    self._step_body_b(0)
+                self._warm_step(0)
                 seen, self._probe = self._probe, None
                 ok = torch.tensor([1 if len(seen) == 1 else 0], dtype=torch.int32, device=self.seeds.device)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -323,19 +347,11 @@ class GraphTrainStep:
                     gs.gather()
                 if k == 0 and self.fused_adam and os.environ.get('KGW_ADAM_PACKS', '1') != '0':
                     self._pack_probe = []                      # which weights does the forward pack for kgw_gemm3?
-                try:
-                    self._step_body(k % 2)
-                except ops.GradSinkMismatch as e:             # (raised before the optimiser launch: nothing was updated)
-                    print(f'kgwas_amd: fused optimiser launch not used ({e})', file=sys.stderr)
-                    self.fused_adam = False
-                    self.opt.zero_grad(set_to_none=True)
-                    self._step_body(k % 2)
+                self._warm_step(k % 2)                         # (a fused form that does not apply is switched off here)
                 if self._pack_probe is not None:
                     seen, self._pack_probe = self._pack_probe, None
                     if self.fused_adam:
                         self._adopt_images(seen)
-                if self.split_backward:
-                    self._step_body_b(k % 2)
                 if gs is not None:
                     gs.scatter()
                     gs.weight_grad_partial(gs.last[0], out=self._flat_grads[gs.last[1]])

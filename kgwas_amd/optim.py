@@ -86,6 +86,41 @@ class FusedAdam:
         # (``recs`` -- and with it the partial-sum workspaces -- lives until here: the launch that reads them is enqueued)
 
     @torch.no_grad()
+    def finish_into(self, sink, pairs):
+        """Multi-GPU step: ``pairs`` = [(parameter, its slot in a flat all-reduce bucket)].  One launch (kgw_grad_finish) writes every
+        parameter's FINISHED gradient into its slot -- a copy of ``p.grad`` where that is complete, the sum of the partial records its
+        producer left with ``sink`` otherwise -- instead of the producers' second launches + the bucket's concatenation.  Raises
+        ops.GradSinkMismatch (nothing launched) like step_fused."""
+        from . import ops
+        sink.flush()
+        recs = {}
+        for p, _ in pairs:
+            r = sink.take(p.grad)
+            if r is not None and r[0] is not None:
+                recs[p] = r
+        if sink.records:
+            n = len(sink.records)
+            sink.records.clear()
+            raise ops.GradSinkMismatch(f'{n} deferred gradient(s) did not reach a parameter as written')
+        if len(recs) > _lib.ADAM_FUSED_SRC:
+            raise ops.GradSinkMismatch(f'{len(recs)} deferred gradients exceed the fused launch\'s table')
+        pairs = sorted(pairs, key=lambda pd: 0 if pd[0] in recs else 1)
+        for i in range(0, len(pairs), _lib.ADAM_FUSED_MAX):
+            chunk = pairs[i:i + _lib.ADAM_FUSED_MAX]
+            n = len(chunk)
+            D = (C.c_void_p * n)(); G = (C.c_void_p * n)(); N = (C.c_int64 * n)()
+            S = (_lib.KgwGradSrc * n)()
+            for k, (p, dst) in enumerate(chunk):
+                g = p.grad
+                if not (g.is_contiguous() and dst.is_contiguous() and g.dtype == torch.float32 and dst.dtype == torch.float32 and
+                        dst.numel() == g.numel()):
+                    raise _lib.KgwasHipError('finish_into needs contiguous fp32 gradients and bucket slots of the same size')
+                D[k], G[k], N[k] = dst.data_ptr(), g.data_ptr(), g.numel()
+                if p in recs:
+                    C.memmove(C.byref(S[k]), C.byref(recs[p][0]), C.sizeof(_lib.KgwGradSrc))
+            _lib.check(_lib.lib().kgw_grad_finish(n, D, G, N, S, _lib.stream_ptr()), 'kgw_grad_finish')
+
+    @torch.no_grad()
     def step(self, grads=None, tick=True):
         """``grads``: optional {parameter: gradient tensor} to use instead of ``p.grad`` (the all-reduced bucket's
         views in the multi-GPU step); parameters missing from it are skipped.  ``tick=False``: the caller advances

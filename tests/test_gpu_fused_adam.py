@@ -204,3 +204,46 @@ def test_gemm3_weight_gradient_finished_by_adam(M, K):
         _same_state(pa, pb, oa, ob)
         assert torch.equal(img, ops.gemm3_pack(pb[0].detach(), M, False))
         B = B * 0.5
+
+
+def test_finish_into_flat_bucket():
+    """kgw_grad_finish (multi-GPU step: the gradients must be complete BEFORE the all-reduce, so the optimiser's launch cannot take the
+    last sums): one launch writes every finished gradient into its slot of a flat bucket -- bit-identical to the producers' own second
+    launches followed by the concatenation, for copied (complete) gradients, split-K sums, first-layer partials and the kgw_gemm3
+    weight gradient alike."""
+    from kgwas_amd import ops
+    from kgwas_amd.optim import FusedAdam
+    g = torch.Generator(device='cpu').manual_seed(77)
+    rows, K1, M3, K3 = 40000, 20, 1024, 4096
+    x = torch.rand(rows, K1, generator=g).to(DEV)
+    dh2 = (torch.randn(rows, 128, generator=g) * (torch.rand(rows, 128, generator=g) > 0.5)).to(DEV)
+    A3 = torch.randn(M3, K3, generator=g).to(DEV)
+    B3 = (torch.randn(K3, 128, generator=g) * 0.1).to(DEV)
+    shapes = [(128, K1), (128,), (128, 128), (128,), (128, M3), (33, 7)]
+    ps = [torch.randn(*s_, generator=g).to(DEV).requires_grad_() for s_ in shapes]
+    with torch.no_grad():
+        ps[0].mul_(0.3); ps[2].mul_(0.1)
+    extra = torch.randn(33, 7, generator=g).to(DEV)                 # a complete gradient: copied
+
+    def grads(sink):
+        for p in ps:
+            p.grad = None
+        h2 = ops.mlp2(x, *ps[:4])
+        with ops.grad_sink_scope(sink):
+            h2.backward(dh2)
+            ps[4].grad = ops.gemm3(A3, ops.gemm3_pack(B3, K3, True), transpose_out=True, defer=True)
+        ps[5].grad = extra.clone()
+
+    grads(None)
+    ref = torch.cat([p.grad.reshape(-1) for p in ps])
+    sink = ops.GradSink()
+    grads(sink)
+    assert len(sink.records) == 5
+    flat = torch.full_like(ref, float('nan'))
+    views, off = [], 0
+    for p in ps:
+        views.append(flat[off:off + p.numel()].view_as(p)); off += p.numel()
+    FusedAdam(ps).finish_into(sink, list(zip(ps, views)))
+    assert not sink.records
+    assert torch.equal(flat, ref)
+    assert torch.equal(torch.cat([p.grad.reshape(-1) for p in ps]), ref)        # the gradient tensors hold the sums too

@@ -19,7 +19,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in kgwas_hip.h but not exported'
     assert sorted(_lib.EXPORTS) == declared
-    assert lib.kgw_version() == 119
+    assert lib.kgw_version() == 120
     assert lib.kgw_status_string(-1) == b'null pointer argument'
 
 
@@ -77,6 +77,9 @@ def test_abi_struct_sizes_and_argument_checks():
     assert lib.kgw_adam_fused(0, None, None, None, None, None, None, None, 1e-4, 0.9, 0.999, 1e-8, 0.0, None, 0, 0, None, None, None) == -1
     assert lib.kgw_adam_fused(_lib.ADAM_FUSED_MAX + 1, None, None, None, None, None, None, None, 1e-4, 0.9, 0.999, 1e-8, 0.0, None, 0, 0, None,
                               None, None) == -2
+    assert lib.kgw_grad_finish(3, None, None, None, None, None) == -1
+    assert lib.kgw_grad_finish(_lib.ADAM_FUSED_MAX + 1, None, None, None, None, None) == -2
+    assert lib.kgw_grad_finish(0, None, None, None, None, None) == 0
     assert lib.kgw_scatter_relu_rows(None, None, None, 8, None, None, None, None) == -1
     assert lib.kgw_scatter_relu_rows_workspace_floats(20032) == 256 * 128
     assert lib.kgw_tn_gemm_workspace_floats(1000, 128, 128) > 0
