@@ -528,7 +528,9 @@ class GraphTrainStep:
 
     def describe(self) -> str:
         if self.split_backward:
-            return ('HIP graphs: forward + first half of the backward | second half (feature MLPs); the first half\'s gradient bucket '
+            return ('HIP graphs: forward + first half of the backward | second half (feature MLPs' +
+                    (', its gradients finished and written into their bucket by one launch' if self.finish_fused else '') +
+                    '); the first half\'s gradient bucket '
                     'is all-reduced (RCCL) on a side stream under the second graph, the MLPs\' bucket after it, then one Adam launch' +
                     ('; next batch sampled by a third graph on a side stream' if self.twin else ''))
         adam = ' + Adam)'
