@@ -176,7 +176,9 @@ class GradSink:
         kernel's (the caller launches it itself)."""
         rows, M = dY.shape
         N = X.shape[1]
-        if not (_DEFER_PRODUCTS and rows > 0 and X.shape[0] == rows and dY.dtype == torch.float32 and X.dtype == torch.float32 and
+        # (a tall product -- the SNP MLP's 122 k rows: 512 blocks that fill the chip for 43 us -- is launched where it is: grouped with
+        #  it the short ones queue behind its blocks, KGW_DEFER_TALL=1 to see)
+        if not (_DEFER_PRODUCTS and 0 < rows < (1 << 62 if _DEFER_TALL else 32768) and X.shape[0] == rows and dY.dtype == torch.float32 and X.dtype == torch.float32 and
                 dY.stride(1) == 1 and X.stride(1) == 1 and M % 2 == 0 and N % 2 == 0 and M >= 64 and N >= 64 and dY.stride(0) % 2 == 0 and
                 X.stride(0) % 2 == 0 and dY.data_ptr() % 8 == 0 and X.data_ptr() % 8 == 0):
             return None
@@ -233,11 +235,14 @@ class GradSink:
 
 GRAD_SINK = None           # the GradSink of the backward pass being issued, or None (every product finishes its own sums)
 _FUSED_ADAM = os.environ.get('KGW_FUSED_ADAM', '1') != '0'         # 0: k_tn_reduce / k_mlp2_bwd_fold / stats as launches of their own
-# 1: the MLPs' weight-gradient products (gene, SNP, GO x 2) not launched where their backward passes end but as ONE grouped launch ahead
-# of the optimiser's (GradSink.defer_product).  Measured: 1.0830 / 1.0838 ms with, 1.0832 / 1.0834 without -- the grouped launch takes
-# 83 us against 16.8 + 43.7 + 16.7 apart: the tall product's 512 blocks already fill the chip for 43 us, the short products' blocks of
-# the later tiles queue behind them, and what two launches cost is what the worse packing costs.  Off.
-_DEFER_PRODUCTS = os.environ.get('KGW_DEFER_PRODUCTS', '0') == '1'
+# The SHORT weight-gradient products of the MLPs (gene 20 k rows, GO 2 x 7 k: 316 + 448 blocks, neither fills the chip's 512 slots)
+# are not launched where their backward passes end but as ONE grouped launch ahead of the optimiser's (GradSink.defer_product):
+# 29.7 us against 16.8 + 17.2 in two launches, step 1.1142 / 1.1173 against 1.1218 / 1.1201 ms (A/B on one box).  With the TALL
+# product of the SNP MLP in the group too (KGW_DEFER_TALL=1) nothing is gained -- 1.0830 / 1.0838 against 1.0832 / 1.0834, the grouped
+# launch 83 us against 16.8 + 43.7 + 16.7: its 512 blocks already fill the chip for 43 us and the short products' blocks of the later
+# tiles queue behind them.  KGW_DEFER_PRODUCTS=0: every product where it is.
+_DEFER_PRODUCTS = os.environ.get('KGW_DEFER_PRODUCTS', '1') != '0'
+_DEFER_TALL = os.environ.get('KGW_DEFER_TALL', '0') == '1'
 
 
 class grad_sink_scope:

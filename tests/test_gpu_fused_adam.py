@@ -89,14 +89,14 @@ def test_grouped_products_and_leftover_record(monkeypatch):
         assert torch.equal(p, q)
 
 
-@pytest.mark.parametrize('rows,K1,defer_products', [(40000, 20, False), (16384, 4, False), (122880, 20, False), (40000, 20, True),
+@pytest.mark.parametrize('rows,K1,defer_products', [(40000, 20, False), (16384, 4, False), (122880, 20, False), (20000, 20, True),
                                                    (200, 20, True)])
 def test_mlp2_first_layer_partials_finished_by_adam(rows, K1, defer_products, monkeypatch):
     """_MLP2's backward (kgwas/model.py:18-20 on the 20-wide SNP features): d W1 / d b1 from kgw_mlp2_bwd_first's block partials,
     d W2 / d b2 from the split-K product's -- all four finished inside kgw_adam_fused."""
     from kgwas_amd import ops
-    # (defer_products: the experiment knob KGW_DEFER_PRODUCTS -- the d W2 product itself is launched by step_fused, grouped with
-    #  whatever else was deferred; 200 rows: a product with one row block, complete after its first launch, still matched)
+    # (defer_products: a SHORT d W2 product -- under 32 768 rows -- is launched by step_fused, grouped with whatever else was
+    #  deferred; 200 rows: a product with one row block, complete after its first launch, still matched)
     monkeypatch.setattr(ops, '_DEFER_PRODUCTS', defer_products)
     g = torch.Generator(device='cpu').manual_seed(rows)
     x = torch.rand(rows, K1, generator=g).to(DEV)
