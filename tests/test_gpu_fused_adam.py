@@ -247,3 +247,17 @@ def test_finish_into_flat_bucket():
     assert not sink.records
     assert torch.equal(flat, ref)
     assert torch.equal(torch.cat([p.grad.reshape(-1) for p in ps]), ref)        # the gradient tensors hold the sums too
+
+
+def test_full_size_trajectory_identical_with_and_without_the_launch_merges():
+    """tools/fused_vs_unfused.py: 120 captured steps on the benchmark workload (full-size fast-mode graph, batch 512) with every round-4
+    launch merge on -- fused optimiser launch + operand image, merged transform backward, grouped short products -- and with all of them
+    off: losses and every parameter bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fused_vs_unfused.py'), '120'], cwd=root, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'losses identical True' in r.stdout and ' state tensors bit-identical' in r.stdout
