@@ -1134,8 +1134,11 @@ inline int grid_for_waves(int64_t n_waves) {
 // launch every wavefront drew ~2 of them and the longest draws set the kernel's tail: measured 74 -> 64 us (k_agg_fwd),
 // 72 -> 65 us (k_agg_bwd_dst), 163 -> 154 us (k_agg_bwd_src).  (32768 blocks: k_agg_bwd_src back to 164 us -- the
 // per-wavefront prologue shows; exactly one resident round -- occupancy x CUs blocks -- : k_agg_fwd 78 us.)
+// Round 4, re-measured with today's kernels (cap 8192 / 12288 / 16384, layer 1): batch 512 flat (forward 56.0 / 56.3 / 56.0 us,
+// backward-dst 57.1 / 58.0 / 57.6, backward-src 108.4 / 106.8 / 109.3 -- only the src-major pass reaches the cap there), batch 4096
+// (6.2 M edges, 15 k blocks of chunks) 329.6 / 308.1 / 298.7, 343.5 / 326.5 / 325.3, 566.0 / 538.8 / 535.8: 16384.
 inline int grid_fine(int64_t n_items) {
-    static const int64_t cap = getenv("KGW_AGG_GRID_CAP") ? atoll(getenv("KGW_AGG_GRID_CAP")) : 8192;
+    static const int64_t cap = getenv("KGW_AGG_GRID_CAP") ? atoll(getenv("KGW_AGG_GRID_CAP")) : 16384;
     int64_t g = (n_items + 3) / 4;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
