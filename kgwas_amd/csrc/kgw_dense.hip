@@ -319,7 +319,8 @@ int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st, KgwGradSrc* defer = n
         const int gy = (D.M + 32 * MT - 1) / (32 * MT), gz = (D.N + 32 * NT - 1) / (32 * NT);
         // one block per CU at most; at least 64 rows per wavefront
         int64_t nblk = (D.rows + 4 * 64 - 1) / (4 * 64);
-        int64_t cap = ((MT * NT <= 4) ? 512 : 256) / ((int64_t)gy * gz);      // (small accumulators: two blocks per CU)
+        static const int64_t cap_small = getenv("KGW_TN_CAP") ? atoll(getenv("KGW_TN_CAP")) : 512;
+        int64_t cap = ((MT * NT <= 4) ? cap_small : 256) / ((int64_t)gy * gz);      // (small accumulators: two blocks per CU)
         if (cap < 1) cap = 1;
         if (nblk > cap) nblk = cap;
         if (nblk < 1) nblk = 1;
