@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KGW_VERSION      120          /* 0.2.0 */
+#define KGW_VERSION      121          /* 0.2.1 */
 #define KGW_MAX_TYPES    8
 #define KGW_MAX_RELS     64
 #define KGW_MAX_LAYERS   4
@@ -37,6 +37,9 @@ extern "C" {
 
 #define KGW_F_RAW_WEIGHTS 1           /* KgwLayerArgs.flags: no softmax (the reference's attention export,
                                          kgwas/utils.py:446-461 with return_raw_attention_weights)      */
+#define KGW_F_DUV_PIECES  4           /* bwd_src with dU / dV riders: leave d u_r / d v_r as their eight level-1 pieces in duv_ws
+                                         ([2][n_rels][8][128]: k_duv_fold is not launched, dU / dV are not written) -- the consumer
+                                         adds them: KgwRelvecJob.duv_pieces / KgwFoldArgs.duv_pieces                              */
 #define KGW_F_RELU_INPUT  2           /* bwd_src: H is the output of a ReLU (model.py:75) whose backward is folded
                                          into this pass: dH *= (H > 0)                                   */
 
@@ -553,7 +556,9 @@ int kgw_relvec_bwd(int32_t n_live, const int32_t* rel_ids, const int32_t* bip_po
  * the arguments of kgw_relvec_fwd (v_by_rel = 1) / kgw_relvec_bwd_acc as a record; the forward reads the first group of fields,
  * the backward the second.  Up to KGW_MAX_LAYERS jobs.                                                                  */
 typedef struct KgwRelvecJob {
-    int32_t n_rels_total, n_live, n_blk, pad_;
+    int32_t n_rels_total, n_live, n_blk;
+    int32_t duv_pieces;              /* backward, != 0: dU_full / dV point at [rows][8][128] pieces (KGW_F_DUV_PIECES), added here
+                                        in k_duv_fold's order                                                                 */
     const int32_t* live_of_rel; const int32_t* rel_ids; const int32_t* bip_pos;
     const float* w_src_t; const float* w_dst_t; const float* att_src; const float* att_dst;
     /* forward */
@@ -584,7 +589,8 @@ int kgw_relvec_bwd_acc(int32_t n_live, const int32_t* rel_ids, const int32_t* bi
  * _bwd fills dU, dV (feed kgw_relvec_bwd), dws (the fold's share of d W_i^T), d_fc_weight[m], d_fc_bias[m] from dUp, dVp,
  * dkappa, dWp, dgamma -- every element written, fixed summation order.  *_host arrays are host int32 arrays.          */
 typedef struct KgwFoldArgs {
-    int32_t n, n_rels, n_mlp, pad_;
+    int32_t n, n_rels, n_mlp;
+    int32_t duv_pieces;              /* kgw_fold_bwd, != 0: dUp / dVp point at [n_rels][8][128] pieces (KGW_F_DUV_PIECES)        */
     const int32_t* rel_ids_host; const int32_t* src_mlp_host; const int32_t* dst_mlp_host;
     const float* w_src_t;            /* [n][128][128]                                   */
     const float* fc_weight[4];       /* FC_output.weight [128 out][128 in] of MLP m     */

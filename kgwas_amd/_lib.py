@@ -125,7 +125,7 @@ class KgwSplitKJob(C.Structure):
 
 
 class KgwRelvecJob(C.Structure):
-    _fields_ = [('n_rels_total', C.c_int32), ('n_live', C.c_int32), ('n_blk', C.c_int32), ('pad_', C.c_int32),
+    _fields_ = [('n_rels_total', C.c_int32), ('n_live', C.c_int32), ('n_blk', C.c_int32), ('duv_pieces', C.c_int32),
                 ('live_of_rel', C.c_void_p), ('rel_ids', C.c_void_p), ('bip_pos', C.c_void_p),
                 ('w_src_t', C.c_void_p), ('w_dst_t', C.c_void_p), ('att_src', C.c_void_p), ('att_dst', C.c_void_p),
                 ('U_full', C.c_void_p), ('V', C.c_void_p), ('bias', C.c_void_p), ('blk_of_live', C.c_void_p), ('bias_sum', C.c_void_p),
@@ -135,7 +135,7 @@ class KgwRelvecJob(C.Structure):
 
 
 class KgwFoldArgs(C.Structure):
-    _fields_ = [('n', C.c_int32), ('n_rels', C.c_int32), ('n_mlp', C.c_int32), ('pad_', C.c_int32),
+    _fields_ = [('n', C.c_int32), ('n_rels', C.c_int32), ('n_mlp', C.c_int32), ('duv_pieces', C.c_int32),
                 ('rel_ids_host', C.c_void_p), ('src_mlp_host', C.c_void_p), ('dst_mlp_host', C.c_void_p),
                 ('w_src_t', C.c_void_p), ('fc_weight', C.c_void_p * 4), ('fc_bias', C.c_void_p * 4),
                 ('U', C.c_void_p), ('V', C.c_void_p),

@@ -1216,7 +1216,7 @@ extern "C" int kgw_gat_aggregate_bwd_src(const KgwLayerArgs* a, kgw_stream_t str
     k_agg_bwd_src<<<gmain + n_riders, KGW_BLK, 0, (hipStream_t)stream_>>>(T, P, a->n_src_rows, gmain, n_riders, a->rel_sums);
     KGW_LAUNCH_CHECK();
     if (a->ev_after) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_after, (hipStream_t)stream_));
-    if (duv) {
+    if (duv && !(a->flags & KGW_F_DUV_PIECES)) {        // (pieces: the consumer of d u_r / d v_r adds the eight pieces itself)
         k_duv_fold<<<dim3(T.n_rels, 2), KGW_C, 0, (hipStream_t)stream_>>>(T.n_rels, a->duv_ws, a->dU, a->dV);
         KGW_LAUNCH_CHECK();
     }

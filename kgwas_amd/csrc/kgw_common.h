@@ -152,6 +152,11 @@ __device__ __forceinline__ void kgw_split3x8(const float (&x)[8], uint4& p1, uin
     p3 = make_uint4(c[0], c[1], c[2], c[3]);
 }
 
+// the eight level-1 pieces of a d u_r / d v_r value (KGW_F_DUV_PIECES: p[s * 128], s = 0..7), added in k_duv_fold's order
+__device__ __forceinline__ float kgw_duv_sum8(const float* __restrict__ p) {
+    return ((p[0] + p[128]) + (p[2 * 128] + p[3 * 128])) + ((p[4 * 128] + p[5 * 128]) + (p[6 * 128] + p[7 * 128]));
+}
+
 // block-wide exclusive scan of one int per thread (256 threads); returns exclusive prefix,
 // *total receives the block sum.  sm must hold 256 ints.
 __device__ __forceinline__ int kgw_block_exscan(int v, int* sm, int* total) {

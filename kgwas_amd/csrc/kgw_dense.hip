@@ -3619,7 +3619,7 @@ struct RvFwdJob {
 };
 struct RvFwdJobs { RvFwdJob j[KGW_MAX_LAYERS]; int n; };
 struct RvBwdJob {
-    int blk0, v_by_rel;
+    int blk0, v_by_rel, pieces, pad_;
     const int32_t* rel_ids; const int32_t* bip_pos;
     const float* wsT; const float* wdT; const float* att_src; const float* att_dst; const float* dU_full; const float* dV;
     float* dwsT; float* dwdT; float* datt_src; float* datt_dst; const float* dws_acc;
@@ -3733,8 +3733,13 @@ __global__ void __launch_bounds__(1024) k_relvec_bwd(RvBwdJobs J) {
     const int i = bx >> 2, cl = threadIdx.x & 31, c = (bx & 3) * 32 + cl, q = threadIdx.x >> 5;
     const int r = rel_ids[i], j = bip_pos[i];
     if (threadIdx.x < KGW_C) {
-        du[threadIdx.x] = dU_full ? dU_full[(int64_t)r * KGW_C + threadIdx.x] : 0.f;
-        dv[threadIdx.x] = dV ? dV[(int64_t)(v_by_rel ? r : i) * KGW_C + threadIdx.x] : 0.f;
+        if (T.pieces) {             // (d u_r / d v_r as the aggregate's riders left them: eight pieces per value)
+            du[threadIdx.x] = dU_full ? kgw_duv_sum8(dU_full + (int64_t)r * 8 * KGW_C + threadIdx.x) : 0.f;
+            dv[threadIdx.x] = dV ? kgw_duv_sum8(dV + (int64_t)(v_by_rel ? r : i) * 8 * KGW_C + threadIdx.x) : 0.f;
+        } else {
+            du[threadIdx.x] = dU_full ? dU_full[(int64_t)r * KGW_C + threadIdx.x] : 0.f;
+            dv[threadIdx.x] = dV ? dV[(int64_t)(v_by_rel ? r : i) * KGW_C + threadIdx.x] : 0.f;
+        }
     }
     __syncthreads();
     const float as = att_src[(int64_t)i * KGW_C + c], ad = att_dst[(int64_t)i * KGW_C + c];
@@ -3820,7 +3825,7 @@ int relvec_bwd_launch(int n_jobs, const KgwRelvecJob* jobs, int v_by_rel, hipStr
         if (!D.rel_ids || !D.bip_pos || !D.w_src_t || !D.att_src || !D.att_dst || !D.dw_src_t || !D.datt_src || !D.datt_dst)
             return KGW_E_NULL;
         RvBwdJob& T = J.j[n++];
-        T.blk0 = blk; T.v_by_rel = v_by_rel;
+        T.blk0 = blk; T.v_by_rel = v_by_rel; T.pieces = D.duv_pieces;
         blk += 4 * D.n_live;
         T.rel_ids = D.rel_ids; T.bip_pos = D.bip_pos; T.wsT = D.w_src_t; T.wdT = D.w_dst_t; T.att_src = D.att_src;
         T.att_dst = D.att_dst; T.dU_full = D.dU_full; T.dV = D.dV; T.dwsT = D.dw_src_t; T.dwdT = D.dw_dst_t;

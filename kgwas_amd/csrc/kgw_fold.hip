@@ -46,6 +46,7 @@ struct FoldPtrs {
     float* Up; float* Vp; float* kappa;         // [n_rels][128], [n_rels][128], [n_rels]
     float* Wp; float* gamma;                    // [n][128][128], [n][128]
     const float* dUp; const float* dVp; const float* dkappa; const float* dWp; const float* dgamma;
+    int duv_pieces;                             // dUp / dVp are [n_rels][8][128] pieces (KGW_F_DUV_PIECES)
     float* dU; float* dV;                       // [n_rels][128]
     float* dws;                                 // [n][128][128]
     float* dfcw[FOLD_MAX_MLP]; float* dfcb[FOLD_MAX_MLP];
@@ -171,6 +172,14 @@ __global__ void __launch_bounds__(512) k_fold_bwd(FoldTab T, FoldPtrs P, int par
         //         (column-tile 0 also:) dfcb_m[h] = sum_{i: src_m = m} ( sum_o w_i[h][o] dgamma_i[o] + dkappa_i U_i[h] )
         //                                          + sum_{i: dst_m = m} dkappa_i V_i[h]
         const int q = b - nA, m = q >> 4, tile = q & 15, tm = tile >> 2, tn = tile & 3;
+        // d U'_i[k], d V'_i[k] of the tile's 32 columns for every relation, once per block (requested here, read by the rank-1 loop
+        // after the products): with KGW_F_DUV_PIECES each value is eight pieces -- added on the way in, in k_duv_fold's order
+        __shared__ float dus[KGW_MAX_RELS][32], dvs[KGW_MAX_RELS][32];
+        for (int idx = t; idx < T.n * 32; idx += 512) {
+            const int i = idx >> 5, c = idx & 31, r = T.rel_id[i], kk = 32 * tn + c;
+            dus[i][c] = P.duv_pieces ? kgw_duv_sum8(P.dUp + r * 8 * FC + kk) : P.dUp[r * FC + kk];
+            dvs[i][c] = P.duv_pieces ? kgw_duv_sum8(P.dVp + r * 8 * FC + kk) : P.dVp[r * FC + kk];
+        }
         f32x16 acc0, acc1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
@@ -226,7 +235,7 @@ __global__ void __launch_bounds__(512) k_fold_bwd(FoldTab T, FoldPtrs P, int par
         for (int i = 0; i < T.n; ++i) {                    // rank-1 terms, relation order; loads unconditional (independent)
             const int r = T.rel_id[i];
             const float fs = T.src_m[i] == m ? 1.f : 0.f, fd = T.dst_m[i] == m ? 1.f : 0.f;
-            const float du = P.dUp[r * FC + k] * fs, dv = P.dVp[r * FC + k] * fd;
+            const float du = dus[i][col] * fs, dv = dvs[i][col] * fd;
             vs[0] = fmaf(P.U[r * FC + h0], du, vs[0]);      vs[0] = fmaf(P.V[r * FC + h0], dv, vs[0]);
             vs[1] = fmaf(P.U[r * FC + h0 + 16], du, vs[1]); vs[1] = fmaf(P.V[r * FC + h0 + 16], dv, vs[1]);
         }
@@ -260,7 +269,13 @@ __global__ void __launch_bounds__(512) k_fold_bwd(FoldTab T, FoldPtrs P, int par
             return;
         }
         const int ms = T.src_m[i], md = T.dst_m[i];
-        const float2 du2 = ((const float2*)(P.dUp + r * FC))[lane], dv2 = ((const float2*)(P.dVp + r * FC))[lane];
+        float2 du2, dv2;
+        if (P.duv_pieces) {
+            du2 = make_float2(kgw_duv_sum8(P.dUp + r * 8 * FC + 2 * lane), kgw_duv_sum8(P.dUp + r * 8 * FC + 2 * lane + 1));
+            dv2 = make_float2(kgw_duv_sum8(P.dVp + r * 8 * FC + 2 * lane), kgw_duv_sum8(P.dVp + r * 8 * FC + 2 * lane + 1));
+        } else {
+            du2 = ((const float2*)(P.dUp + r * FC))[lane]; dv2 = ((const float2*)(P.dVp + r * FC))[lane];
+        }
         const float dk = P.dkappa[r];
         const int c0 = wave * 16;
         float2 a[16], bq[16];
@@ -301,6 +316,7 @@ int build(const KgwFoldArgs* a, FoldTab* T, FoldPtrs* P) {
     }
     P->Up = a->Up; P->Vp = a->Vp; P->kappa = a->kappa; P->Wp = a->Wp; P->gamma = a->gamma;
     P->dUp = a->dUp; P->dVp = a->dVp; P->dkappa = a->dkappa; P->dWp = a->dWp; P->dgamma = a->dgamma;
+    P->duv_pieces = a->duv_pieces;
     P->dU = a->dU; P->dV = a->dV; P->dws = a->dws;
     return KGW_OK;
 }

@@ -100,6 +100,7 @@ class GraphTrainStep:
         self._images, self._image_params, self._image_version, self._pack_probe = {}, [], {}, None
         self.split_backward = self._multi and os.environ.get('KGW_SPLIT_BACKWARD', '1') == '1'
         self.finish_fused = ops._FUSED_ADAM and self.split_backward
+        self.duv_pieces = ops._DUV_PIECES and self.fused_adam           # (single GPU, whole backward in one autograd pass)
         # multi-rank, optional: the first gene Linear over the resident feature matrix (forward + weight gradient: 0.27 of the
         # step's 1.2 ms, identical work on every rank) split by gene rows over the ranks -- ops.GeneLayerShard in its STAGED form:
         # partial product (captured) | all-gather | the step's graphs | reduce-scatter of dz | partial weight gradient (captured).
@@ -215,8 +216,11 @@ class GraphTrainStep:
             # fused optimiser launch: the weight-gradient products that feed only Adam stop after their first launch, their last
             # sums, the update, the step counter and the running totals are ONE launch (ops.GradSink, kgw_adam_fused)
             sink = ops.GradSink() if self.fused_adam else None
-            with ops.grad_sink_scope(sink):
+            pieces = {} if self.duv_pieces else None                   # (d u_r / d v_r stay eight pieces: their consumers add them)
+            with ops.grad_sink_scope(sink), ops.duv_pieces_scope(pieces):
                 loss.backward(gradient=self._unit)                     # (a resident 1.0: no ones_like fill per step)
+            if pieces:
+                raise ops.GradSinkMismatch(f'{len(pieces)} d u_r / d v_r tensor(s) left in pieces reached no consumer that adds them')
             if sink is not None:
                 self.deferred_gradients = len(sink.records) + 2 * len(sink.products)   # (gradients whose last sums the optimiser launch takes)
                 self.opt.step_fused(sink, buf.meta.data_ptr(), self.run.gnn_num_layers, self.dg.n_hops, self.stats)
@@ -300,7 +304,7 @@ class GraphTrainStep:
                 self._step_body_b(k)
         except ops.GradSinkMismatch as e:
             print(f'kgwas_amd: fused gradient-finishing launch not used ({e})', file=sys.stderr)
-            self.fused_adam = self.finish_fused = False
+            self.fused_adam = self.finish_fused = self.duv_pieces = False
             self.opt.zero_grad(set_to_none=True)
             self._step_body(k)
             if self.split_backward:

@@ -151,6 +151,37 @@ class KernelTimer:
 TIMER = KernelTimer()
 
 
+# d u_r / d v_r left as their eight level-1 pieces by the aggregate's backward (KGW_F_DUV_PIECES: no k_duv_fold launch): inside a
+# ``duv_pieces_scope`` (a captured training step) _GatAggregate.backward hands autograd UNWRITTEN dU / dV tensors and notes here, by
+# their addresses, where the pieces are; the two consumers that can add them on the fly (_FoldFC.backward -> k_fold_bwd,
+# _RelVectorsMulti.backward -> k_relvec_bwd) look their incoming gradients up and take the entry.  An entry still here when the
+# backward pass is over means a gradient went somewhere else: the trainer then switches the scheme off (GradSinkMismatch).
+DUV_PIECES = None
+_DUV_PIECES = os.environ.get('KGW_DUV_PIECES', '1') != '0'
+
+
+class duv_pieces_scope:
+    def __init__(self, table):
+        self.table = table
+
+    def __enter__(self):
+        global DUV_PIECES
+        self.prev, DUV_PIECES = DUV_PIECES, self.table
+        return self.table
+
+    def __exit__(self, *exc):
+        global DUV_PIECES
+        DUV_PIECES = self.prev
+        return False
+
+
+def _take_pieces(t):
+    """(pointer to the [rows][8][128] pieces, keep-alive) if ``t`` is an unwritten d u_r / d v_r tensor of the active scope."""
+    if DUV_PIECES is None or t is None:
+        return None
+    return DUV_PIECES.pop(t.data_ptr(), None)
+
+
 class GradSinkMismatch(RuntimeError):
     """A gradient whose last reduction was left to the optimiser's launch did not arrive at a parameter as the tensor its producer
     wrote the record for (autograd copied or accumulated it): the fused optimiser launch cannot be used for this model."""
@@ -396,6 +427,11 @@ class _GatAggregate(torch.autograd.Function):
             da_src = torch.empty(max(n_src, 1), 2 * ld_da, device=dev)   # [node row, (d a_src | d a_dst) by relation id]
             a.da_src = _p(da_src)
         a.flags = 2 if ctx.relu_input else 0       # KGW_F_RELU_INPUT: fold the ReLU that produced H into dH
+        pieces = riders and DUV_PIECES is not None
+        if pieces:
+            a.flags |= 4                           # KGW_F_DUV_PIECES: dU / dV stay UNWRITTEN, their consumers add the pieces
+            DUV_PIECES[dU.data_ptr()] = (duv_ws.data_ptr(), duv_ws)
+            DUV_PIECES[dV.data_ptr()] = (duv_ws.data_ptr() + sc.NR * 8 * KGW_C * 4, duv_ws)
         L = _lib.lib()
         TIMER.attach(a, 'bwd_dst', layer, n_edges, z_rows, n_src)
         _lib.check(L.kgw_gat_aggregate_bwd_dst(C.byref(a), _lib.stream_ptr()), 'kgw_gat_aggregate_bwd_dst')
@@ -1607,6 +1643,12 @@ class _RelVectorsMulti(torch.autograd.Function):
             j.w_src_t, j.w_dst_t = w_src_t.data_ptr(), (w_dst_t.data_ptr() if w_dst_t.numel() else None)
             j.att_src, j.att_dst = att_src.data_ptr(), att_dst.data_ptr()
             j.dU_full, j.dV, j.dw_src_acc = _p(dU), _p(dV), _p(dW_in)
+            pu, pv = _take_pieces(dU), _take_pieces(dV)
+            if (pu is None) != (pv is None):
+                raise GradSinkMismatch('d u_r and d v_r of a layer must both be pieces or both be complete')
+            if pu is not None:                      # (the aggregate left eight pieces per value: added inside k_relvec_bwd)
+                j.dU_full, j.dV, j.duv_pieces = pu[0], pv[0], 1
+                keep += [pu[1], pv[1]]
             j.dw_src_t, j.dw_dst_t = dws.data_ptr(), (dwd.data_ptr() if dwd.numel() else None)
             j.datt_src, j.datt_dst = das.data_ptr(), dad.data_ptr()
             ret += [dws, dwd, das, dad]
@@ -1922,6 +1964,11 @@ class _FoldFC(torch.autograd.Function):
             a.fc_weight[m], a.fc_bias[m] = _p(fc[2 * m]), _p(fc[2 * m + 1])
             a.d_fc_weight[m], a.d_fc_bias[m] = _p(dfc[2 * m]), _p(dfc[2 * m + 1])
         a.dUp, a.dVp, a.dkappa, a.dWp, a.dgamma = _p(dUp), _p(dVp), _p(dkappa), _p(dWp), _p(dgamma)
+        pu, pv = _take_pieces(dUp), _take_pieces(dVp)
+        if (pu is None) != (pv is None):
+            raise GradSinkMismatch('d u_r and d v_r of a layer must both be pieces or both be complete')
+        if pu is not None:                          # the aggregate left eight pieces per value: added inside k_fold_bwd
+            a.dUp, a.dVp, a.duv_pieces = pu[0], pv[0], 1
         a.dU, a.dV, a.dws = _p(dU), _p(dV), _p(dws)
         _lib.check(_lib.lib().kgw_fold_bwd(C.byref(a), _lib.stream_ptr()), 'kgw_fold_bwd')
         return (dws, dU, dV, None, None) + tuple(dfc)
