@@ -115,3 +115,71 @@ def test_folded_model_equals_unfolded_model(small_kg):
         assert (g0 is None) == (g1 is None), k
         if g0 is not None:
             assert_close(g1, g0, 1e-4, max(1e-5, 1e-4 * float(g0.abs().max())), f'grad {k}')
+
+
+def test_duv_pieces_added_by_their_consumers():
+    """KGW_F_DUV_PIECES: d u_r / d v_r handed to kgw_fold_bwd (layer 1) and kgw_relvec_bwd_multi (layer 2) as the eight level-1
+    pieces the aggregate's riders leave ([rows][8][128]) instead of complete [rows][128] tensors -- both kernels add the pieces in
+    k_duv_fold's order as they read: every output bit for bit what the complete tensors give."""
+    import ctypes as C
+    from kgwas_amd import _lib, ops
+    from kgwas_amd.model import RelationPack
+    g = torch.Generator().manual_seed(5)
+    NR, Cc = 29, 128
+    edge_types = [(f's{r % 3}', f'r{r}', f'd{(r * 2) % 3}') for r in range(NR)]
+    rel_ids = [3, 4, 5, 9, 10, 11, 12, 0, 1, 2, 20, 21, 28]
+    pack = RelationPack(edge_types, rel_ids, Cc).cuda()
+    n = len(rel_ids)
+    pieces = torch.randn(2, NR, 8, Cc, generator=g).cuda()
+    p = pieces
+    summed = ((p[:, :, 0] + p[:, :, 1]) + (p[:, :, 2] + p[:, :, 3])) + ((p[:, :, 4] + p[:, :, 5]) + (p[:, :, 6] + p[:, :, 7]))
+    dU, dV = summed[0].contiguous(), summed[1].contiguous()
+    # ---- kgw_fold_bwd
+    sm = np.array([r % 3 for r in rel_ids], dtype=np.int32)
+    dm = np.array([(r * 2) % 3 for r in rel_ids], dtype=np.int32)
+    rid = np.asarray(rel_ids, dtype=np.int32)
+    fc = [(torch.randn(Cc, Cc, generator=g) * 0.1).cuda() if k % 2 == 0 else (torch.randn(Cc, generator=g) * 0.1).cuda() for k in range(6)]
+    U, V = torch.randn(NR, Cc, generator=g).cuda(), torch.randn(NR, Cc, generator=g).cuda()
+    dkappa, dWp, dgamma = torch.randn(NR, generator=g).cuda(), torch.randn(n, Cc, Cc, generator=g).cuda(), torch.randn(n, Cc, generator=g).cuda()
+    w = pack.w_src_t.detach()
+
+    def fold_bwd(use_pieces):
+        outs = [torch.full_like(U, float('nan')), torch.full_like(V, float('nan')), torch.full_like(w, float('nan'))] + \
+               [torch.full_like(t, float('nan')) for t in fc]
+        a = _lib.KgwFoldArgs()
+        a.n, a.n_rels, a.n_mlp = n, NR, 3
+        a.rel_ids_host, a.src_mlp_host, a.dst_mlp_host = rid.ctypes.data, sm.ctypes.data, dm.ctypes.data
+        a.w_src_t, a.U, a.V = w.data_ptr(), U.data_ptr(), V.data_ptr()
+        for m in range(3):
+            a.fc_weight[m], a.fc_bias[m] = fc[2 * m].data_ptr(), fc[2 * m + 1].data_ptr()
+            a.d_fc_weight[m], a.d_fc_bias[m] = outs[3 + 2 * m].data_ptr(), outs[4 + 2 * m].data_ptr()
+        a.dkappa, a.dWp, a.dgamma = dkappa.data_ptr(), dWp.data_ptr(), dgamma.data_ptr()
+        if use_pieces:
+            a.dUp, a.dVp, a.duv_pieces = pieces[0].data_ptr(), pieces[1].data_ptr(), 1
+        else:
+            a.dUp, a.dVp = dU.data_ptr(), dV.data_ptr()
+        a.dU, a.dV, a.dws = outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr()
+        _lib.check(_lib.lib().kgw_fold_bwd(C.byref(a), _lib.stream_ptr()), 'kgw_fold_bwd')
+        torch.cuda.synchronize()
+        return outs
+    for x, y in zip(fold_bwd(True), fold_bwd(False)):
+        assert torch.equal(x, y) and not bool(torch.isnan(x).any())
+    # ---- kgw_relvec_bwd_multi (one job)
+    def relvec_bwd(use_pieces):
+        outs = [torch.full_like(pack.w_src_t, float('nan')), torch.full_like(pack.w_dst_t, float('nan')),
+                torch.full_like(pack.att_src, float('nan')), torch.full_like(pack.att_dst, float('nan'))]
+        j = (_lib.KgwRelvecJob * 1)()
+        j[0].n_live, j[0].rel_ids, j[0].bip_pos = pack.att_src.shape[0], pack.rel_ids_i32.data_ptr(), pack.bip_pos_i32.data_ptr()
+        j[0].w_src_t, j[0].w_dst_t = pack.w_src_t.data_ptr(), (pack.w_dst_t.data_ptr() if pack.w_dst_t.numel() else None)
+        j[0].att_src, j[0].att_dst = pack.att_src.data_ptr(), pack.att_dst.data_ptr()
+        if use_pieces:
+            j[0].dU_full, j[0].dV, j[0].duv_pieces = pieces[0].data_ptr(), pieces[1].data_ptr(), 1
+        else:
+            j[0].dU_full, j[0].dV = dU.data_ptr(), dV.data_ptr()
+        j[0].dw_src_t, j[0].dw_dst_t = outs[0].data_ptr(), (outs[1].data_ptr() if outs[1].numel() else None)
+        j[0].datt_src, j[0].datt_dst = outs[2].data_ptr(), outs[3].data_ptr()
+        _lib.check(_lib.lib().kgw_relvec_bwd_multi(1, j, _lib.stream_ptr()), 'kgw_relvec_bwd_multi')
+        torch.cuda.synchronize()
+        return outs
+    for x, y in zip(relvec_bwd(True), relvec_bwd(False)):
+        assert torch.equal(x, y)
