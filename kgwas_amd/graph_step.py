@@ -305,6 +305,8 @@ class GraphTrainStep:
         except ops.GradSinkMismatch as e:
             print(f'kgwas_amd: fused gradient-finishing launch not used ({e})', file=sys.stderr)
             self.fused_adam = self.finish_fused = self.duv_pieces = False
+            # (nobody keeps an operand image current without the fused optimiser launch: the forward packs again)
+            self._images.clear(); self._image_params.clear(); self._image_version.clear(); self.opt.packed_images.clear()
             self.opt.zero_grad(set_to_none=True)
             self._step_body(k)
             if self.split_backward:
