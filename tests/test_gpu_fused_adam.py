@@ -261,3 +261,49 @@ def test_full_size_trajectory_identical_with_and_without_the_launch_merges():
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'losses identical True' in r.stdout and ' state tensors bit-identical' in r.stdout
+
+
+def test_fallback_when_a_deferred_gradient_does_not_reach_its_parameter(monkeypatch, capsys):
+    """A model for which the fused launches do not apply (here: forced -- GradSink.take loses one record, as if autograd had copied a
+    gradient) must notice in the capture warm-up, BEFORE any update, switch every fused form off (incl. the operand images) and train
+    exactly like the unfused step."""
+    from kgwas_amd import ops
+    from kgwas_amd.graph_step import GraphTrainStep
+    from kgwas_amd.kgwas import KGWAS
+    from kgwas_amd.kgwas_data import KGWAS_Data
+    from tests.helpers import params_by_name
+    data = KGWAS_Data.from_synthetic(scale=0.21, seed=1, data_path='/tmp/kgwas_synth_medium')
+    ids = np.asarray(data.train_input_nodes[1][:256 * 6])
+    runs, steps = [], []
+    real_take = ops.GradSink.take
+    for broken in (True, False):
+        if broken:
+            lost = []
+
+            def take(self, grad):
+                r = real_take(self, grad)
+                if r is not None and r[0] is not None and not lost:
+                    lost.append(1)
+                    self.records[grad.data_ptr()] = r          # (put it back: nobody will claim it)
+                    return None
+                return r
+            monkeypatch.setattr(ops.GradSink, 'take', take)
+        else:
+            monkeypatch.setattr(ops.GradSink, 'take', real_take)
+            monkeypatch.setattr(ops, '_FUSED_ADAM', False)
+        run = KGWAS(data, device=DEV, seed=11)
+        run.initialize_model()
+        if runs:
+            run.model.load_state_dict(runs[0].model.state_dict(), strict=False)
+        runs.append(run)
+        gs = GraphTrainStep(run, ('SNP', ids), 256, lr=1e-3, weight_decay=5e-4)
+        assert not gs.fused_adam and not gs._image_params and not gs.opt.packed_images
+        steps.append(gs)
+    assert 'not used' in capsys.readouterr().err
+    for gs in steps:
+        for i in range(4):
+            gs.step(i)
+    assert steps[0].check() == steps[1].check()
+    pa, pb = params_by_name(runs[0].model), params_by_name(runs[1].model)
+    for n in pa:
+        assert torch.equal(pa[n], pb[n]), n
