@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KGW_VERSION      121          /* 0.2.1 */
+#define KGW_VERSION      122          /* 0.2.2 */
 #define KGW_MAX_TYPES    8
 #define KGW_MAX_RELS     64
 #define KGW_MAX_LAYERS   4
@@ -173,7 +173,7 @@ typedef struct KgwLayerArgs {
     const float* dZ;               /* [z rows][128]                                            */
     float* adp;                    /* [n_edges][2]   (alpha, d pre-activation) per local edge  */
     float* da_dst;                 /* [z rows]                                                 */
-    float* part_da;                /* [n_chunks]                                               */
+    float* part_da;                /* [n_chunks][4], 16-byte aligned: per-chunk sums of a multi-chunk row's d a_dst */
     const int32_t* t_ptr; const int32_t* t_edge; const int32_t* t_zrow;
     float* dH;                     /* [n_src_rows][128]                                        */
     /* optional profiling hooks (NULL = off): hipEvent_t handles owned by the caller, recorded on `stream`
@@ -186,16 +186,12 @@ typedef struct KgwLayerArgs {
                                       (FC_output folded into the layer-1 relation parameters: the feature MLP's last Linear
                                       H = h2 T + c enters conv.py:150-152 only through <H, u_r> and <H, v_r>, whose constant
                                       parts <c_src, u_r> + <c_dst, v_r> land here while T is multiplied into U and V)     */
-    const int32_t* chunk_perm;     /* optional (NULL = chunk list order): XCD-aware work order of k_agg_fwd / k_agg_bwd_dst.
-                                      Entry p = the chunk wavefront p % 4 of block p / 4 processes, -1 = none; blocks are
-                                      dealt to the 8 XCDs round-robin, so the entries with (p / 4) % 8 == x form the work
-                                      list of XCD x -- built so that an XCD gathers from ONE part of the source rows and its
-                                      private L2 holds that part (kgw_sample_batch writes it; KgwBatchBuf.chunk_perm)      */
-    const int32_t* chunk_perm_len; /* device: number of entries of chunk_perm that are in use                           */
     uint64_t partial_rels;         /* forward: bit r set => the segments of relation r are written as PARTIAL online-softmax
                                       states -- Z = sum_j exp(e_ij - m) h_j (not divided), stat = (m, sum_j exp(e_ij - m)) --
                                       for the caller to merge across GPUs (SNP-sharded mode: a rank holds only its own SNP
-                                      sources of a SNP->Gene relation; kgw_softmax_merge) before anything reads them   */
+                                      sources of a SNP->Gene relation; kgw_softmax_merge) before anything reads them;
+                                      backward (dst pass): d a_dst of these rows is the plain sum over this rank's edges (the
+                                      ranks' values are added), without the row-consistent correction of whole rows          */
     const uint8_t* t_rel;          /* optional (NULL = off), backward src pass: relation id of every src-major entry
                                       (KgwBatchBuf.t_rel) and                                                              */
     const int32_t* oct_flags;      /* one flag per group of 8 consecutive source rows (row index / 8; KgwBatchBuf.t_cnt[layer-1]
@@ -280,11 +276,6 @@ int kgw_accumulate_stats(const KgwBatchMeta* meta_dev, int32_t n_layers, int32_t
  * captured step (one single-thread launch less per step).                                                           */
 int kgw_accumulate_stats_tick(const KgwBatchMeta* meta_dev, int32_t n_layers, int32_t n_hops, int64_t* stats, int32_t* tick,
                               kgw_stream_t stream);
-
-/* One wavefront that idles for ``us`` microseconds (0 .. 100 000) on ``stream``: a timed offset at the head of the sampler's
- * side-stream graph, so that the next batch is sampled beside the part of the training step where that costs least
- * (nothing in the reference to replace: kgwas/kgwas.py:129 samples on the CPU, between steps).                       */
-int kgw_delay(int32_t us, kgw_stream_t stream);
 
 /* Replaces: the index_select feature slicing of the loader (x[n_id], kgwas/kgwas.py:135).      */
 int kgw_gather_rows(const float* src, const int32_t* ids, int64_t n_rows, int32_t width,

@@ -85,8 +85,6 @@ struct AggPtrs {
     const int32_t* multi;
     int64_t multi_cap;
     const KgwBatchMeta* meta;     // device: actual counts of the batch
-    const int32_t* perm;          // XCD-aware work order (nullable)
-    const int32_t* perm_len;
     int layer;
     int raw;                      // forward: raw-logit weights (attention export)
     int relu_in;                  // bwd_src: dH *= (H > 0)
@@ -213,10 +211,8 @@ template <bool RAW, bool PIPE>
 __global__ void __launch_bounds__(KGW_BLK) k_agg_fwd(LayerTab T, AggPtrs P, float slope, float inv_temp) {
     const int lane = kgw_lane(), half = lane >> 5, hl = lane & 31;
     const int nw = gridDim.x * 4;
-    const int n_items = P.perm ? *P.perm_len : P.meta->n_chunks[P.layer - 1];
-    for (int g = blockIdx.x * 4 + (threadIdx.x >> 6); g < n_items; g += nw) {
-        const int c = P.perm ? P.perm[g] : g;
-        if (c < 0) continue;
+    const int n_items = P.meta->n_chunks[P.layer - 1];
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < n_items; c += nw) {
         const KgwChunk ck = load_chunk(P.chunks, c);
         const int r = ck.rel;
         if (!T.live[r]) continue;
@@ -366,7 +362,7 @@ template <int G>
 __device__ __forceinline__ void bwd_group(const float4* __restrict__ Hb4, int colv, float evin, int q0, int hn,
                                           int nb, int half, int hl, const float4& dz4, float cdot, float M,
                                           float inv_den, float slope, float inv_temp, float& av, float& dv,
-                                          float& dsum, float4& ua) {
+                                          float& dsum, float4& ua, float& esum, float& bsum, float& ssum) {
     float4 x[G];
     float t[G];
 #pragma unroll
@@ -384,10 +380,12 @@ __device__ __forceinline__ void bwd_group(const float4* __restrict__ Hb4, int co
         const float dalpha = kgw_half_allsum(dot4(x[p], dz4));
         const float alpha = __expf(t[p] * inv_temp - M) * inv_den;
         const float dlogit = alpha * (dalpha - cdot);
-        const float dpre = dlogit * inv_temp * (t[p] > 0.f ? 1.0f : slope);
+        const float sfac = inv_temp * (t[p] > 0.f ? 1.0f : slope);
+        const float dpre = dlogit * sfac;
         av = (hl == q0 + p) ? alpha : av;
         dv = (hl == q0 + p) ? dpre : dv;
         dsum += dpre;
+        esum += dlogit; bsum += alpha * sfac; ssum += alpha;       // (the row's consistent d a_dst: see k_agg_bwd_dst)
         fma4(ua, dpre, x[p]);                      // d u_r += d pre-activation * h_src (every lane has the edge's dpre here)
     }
 }
@@ -396,7 +394,8 @@ __device__ __forceinline__ void bwd_group(const float4* __restrict__ Hb4, int co
 // here collects only the lane's OWN edges; the caller folds the 8 residues once per chunk (kgw_sum8).
 __device__ __forceinline__ void bwd_grp8_compute(const float4 (&x)[8], float evin, int q0, int hn, int nb, int half, int hl,
                                                  const float4& dz4, float cdot, float M, float inv_den, float slope,
-                                                 float inv_temp, float& av, float& dv, float& dsum_own, float4& ua) {
+                                                 float inv_temp, float& av, float& dv, float& dsum_own, float4& ua,
+                                                 float& esum_own, float& bsum_own, float& ssum_own) {
     float part[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) part[p] = dot4(x[p], dz4);
@@ -407,11 +406,15 @@ __device__ __forceinline__ void bwd_grp8_compute(const float4 (&x)[8], float evi
     const float dalpha = kgw_half_reduce8(part, hl);
     const float alpha = __expf(t * inv_temp - M) * inv_den;
     const float dlogit = alpha * (dalpha - cdot);
-    const float dpre = dlogit * inv_temp * (t > 0.f ? 1.0f : slope);
+    const float sfac = inv_temp * (t > 0.f ? 1.0f : slope);
+    const float dpre = dlogit * sfac;
     const bool mine = (hl == qm);
     av = mine ? alpha : av;
     dv = mine ? dpre : dv;
     dsum_own += (hl < 8) ? dpre : 0.f;          // one copy per edge: the 8 residues of the first 8-lane group
+    esum_own += (hl < 8) ? dlogit : 0.f;
+    bsum_own += (hl < 8) ? alpha * sfac : 0.f;
+    ssum_own += (hl < 8) ? alpha : 0.f;
     // d u_r += d pre-activation(edge) * h_src(edge): lane p of the half owns edge q0 + p's value (0 for a padding edge)
     // (two scalar lane reads + a select per edge instead of a cross-lane permute through the LDS crossbar)
     const int dbits = __builtin_bit_cast(int, dpre);
@@ -426,31 +429,38 @@ __device__ __forceinline__ void bwd_grp8_compute(const float4 (&x)[8], float evi
 __device__ __forceinline__ void bwd_group8(const float4* __restrict__ Hb4, int colv, float evin, int q0, int hn,
                                            int nb, int half, int hl, const float4& dz4, float cdot, float M,
                                            float inv_den, float slope, float inv_temp, float& av, float& dv,
-                                           float& dsum_own, float4& ua) {
+                                           float& dsum_own, float4& ua, float& esum_own, float& bsum_own, float& ssum_own) {
     float4 x[8];
     grp8_load(Hb4, colv, q0, hn, nb, half, hl, x);
-    bwd_grp8_compute(x, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own, ua);
+    bwd_grp8_compute(x, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own, ua,
+                     esum_own, bsum_own, ssum_own);
 }
 
 template <bool PIPE>
 __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_dst(LayerTab T, AggPtrs P, float slope, float inv_temp) {
     const int lane = kgw_lane(), half = lane >> 5, hl = lane & 31;
     const int nw = gridDim.x * 4;
-    const int n_items = P.perm ? *P.perm_len : P.meta->n_chunks[P.layer - 1];
-    for (int g = blockIdx.x * 4 + (threadIdx.x >> 6); g < n_items; g += nw) {
-        const int c = P.perm ? P.perm[g] : g;
-        if (c < 0) continue;
+    const int n_items = P.meta->n_chunks[P.layer - 1];
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < n_items; c += nw) {
         const KgwChunk ck = load_chunk(P.chunks, c);
         const int r = ck.rel;
         if (!T.live[r]) continue;
         const int zrow = T.z0[r] + ck.row * T.zstride[r];
         const float4 dz4 = ((const float4*)(P.dZ + (int64_t)zrow * KGW_C))[hl];
         const float4 z4 = ((const float4*)(P.Z + (int64_t)zrow * KGW_C))[hl];
-        const float cdot = kgw_half_allsum(dot4(dz4, z4));     // sum_k alpha_ik dalpha_ik = <dz_i, z_i>
+        // sum_k alpha_ik dalpha_ik = <dz_i, z_i>: from the STORED fp32 aggregate -- one rounding away from the sum the edges below
+        // would give, which is all that is left of d a_dst = sum_e dpre_e wherever a row's logits sit on one branch of the leaky
+        // ReLU (it is 0 in exact arithmetic: the softmax of conv.py:223 does not see a common shift).  Round 5: the per-edge values
+        // keep this provisional c0 (they are not cancellation residues), the ROW SUM is made consistent with the edges' own
+        // d alpha: with E = sum a_e (dalpha_e - c0), B = sum a_e s_e, S = sum a_e (s_e = leaky slope / T of the edge),
+        //     d a_dst = sum_e a_e s_e (dalpha_e - c0) - (E / S) B  =  sum_e a_e s_e (dalpha_e - c*),  c* = sum a_e dalpha_e / sum a_e
+        // -- what autograd of the reference's softmax computes, edge by edge, in differences (dalpha_e - c0) that are small.
+        const float cdot = kgw_half_allsum(dot4(dz4, z4));
         const float M = P.stat[2 * (int64_t)zrow];
         const float inv_den = 1.0f / P.stat[2 * (int64_t)zrow + 1];
         const float4* Hb4 = (const float4*)(P.H + (int64_t)T.src_base[r] * KGW_C);
         float dsum = 0.f, dsum_own = 0.f;
+        float esum = 0.f, bsum = 0.f, ssum = 0.f, esum_own = 0.f, bsum_own = 0.f, ssum_own = 0.f;
         float4 ua = make_float4(0.f, 0.f, 0.f, 0.f);          // this chunk's part of d u_r: sum_e dpre_e h_src(e) (a half's edges)
         const int n = ck.e1 - ck.e0;
         int colv_next = (PIPE && lane < min(64, n)) ? P.col_local[ck.e0 + lane] : 0;
@@ -485,22 +495,24 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_dst(LayerTab T, AggPtrs P, 
                     const int q1 = q0 + 8;
                     const bool more1 = hn - q1 > 4;
                     if (more1) grp8_load(Hb4, colv, q1, hn, nb, half, hl, x1);
-                    bwd_grp8_compute(x0, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own, ua);
+                    bwd_grp8_compute(x0, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own, ua,
+                                     esum_own, bsum_own, ssum_own);
                     q0 = q1;
                     if (!more1) break;
                     const int q2 = q1 + 8;
                     const bool more2 = hn - q2 > 4;
                     if (more2) grp8_load(Hb4, colv, q2, hn, nb, half, hl, x0);
-                    bwd_grp8_compute(x1, evin, q1, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own, ua);
+                    bwd_grp8_compute(x1, evin, q1, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own, ua,
+                                     esum_own, bsum_own, ssum_own);
                     q0 = q2;
                     if (!more2) break;
                 }
             }
             for (; q0 < hn;) {
                 const int rem = hn - q0;
-                if (rem > 4)      { bwd_group8(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own, ua); q0 += 8; }
-                else if (rem > 2) { bwd_group<4>(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum, ua); q0 += 4; }
-                else              { bwd_group<2>(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum, ua); q0 += 2; }
+                if (rem > 4)      { bwd_group8(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum_own, ua, esum_own, bsum_own, ssum_own); q0 += 8; }
+                else if (rem > 2) { bwd_group<4>(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum, ua, esum, bsum, ssum); q0 += 4; }
+                else              { bwd_group<2>(Hb4, colv, evin, q0, hn, nb, half, hl, dz4, cdot, M, inv_den, slope, inv_temp, av, dv, dsum, ua, esum, bsum, ssum); q0 += 2; }
             }
             if (mine) ((float2*)P.adp)[ck.e0 + b + i] = make_float2(av, dv);
         }
@@ -509,9 +521,15 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_dst(LayerTab T, AggPtrs P, 
             ua.x += kgw_xhalf(ua.x); ua.y += kgw_xhalf(ua.y); ua.z += kgw_xhalf(ua.z); ua.w += kgw_xhalf(ua.w);
             if (half == 0) ((float4*)(P.part_du + (int64_t)c * KGW_C))[hl] = ua;
         }
+        esum += kgw_sum8(esum_own); bsum += kgw_sum8(bsum_own); ssum += kgw_sum8(ssum_own);
         const float tot = dsum + kgw_xhalf(dsum);
+        const float te = esum + kgw_xhalf(esum), tb = bsum + kgw_xhalf(bsum), ts = ssum + kgw_xhalf(ssum);
         if (lane == 0) {
-            if (ck.nch == 1) P.da_dst[zrow] = tot; else P.part_da[c] = tot;
+            // (a relation whose segments hold only THIS rank's part of the edges -- SNP-sharded mode -- keeps the plain sum: c* is
+            //  a property of the whole row, and the ranks' d a_dst are added as they are)
+            const bool partial = (T.partial >> r) & 1ull;
+            if (ck.nch == 1) P.da_dst[zrow] = partial ? tot : tot - (te / ts) * tb;
+            else ((float4*)P.part_da)[c] = make_float4(tot, te, tb, ts);
         }
     }
 }
@@ -526,11 +544,14 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_combine(LayerTab T, AggPtrs
         const int first = mm[4 * k], nch = mm[4 * k + 1], row = mm[4 * k + 2], r = mm[4 * k + 3];
         if (!T.live[r]) continue;
         const int zrow = T.z0[r] + row * T.zstride[r];
-        // fixed-order tree: lane-strided partial sums, then butterfly
-        float s = 0.f;
-        for (int c = lane; c < nch; c += 64) s += P.part_da[first + c];
-        s = wave_allsum_slow(s);
-        if (lane == 0) P.da_dst[zrow] = s;
+        // fixed-order tree: lane-strided partial sums, then butterfly -- of the four per-chunk sums (D0, E, B, S) of k_agg_bwd_dst
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = lane; c < nch; c += 64) {
+            const float4 p = ((const float4*)P.part_da)[first + c];
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+        s.x = wave_allsum_slow(s.x); s.y = wave_allsum_slow(s.y); s.z = wave_allsum_slow(s.z); s.w = wave_allsum_slow(s.w);
+        if (lane == 0) P.da_dst[zrow] = ((T.partial >> r) & 1ull) ? s.x : s.x - (s.y / s.w) * s.z;
     }
   }
 }
@@ -1017,7 +1038,7 @@ __global__ void __launch_bounds__(KGW_C) k_duv_fold(int n_rels, const float* __r
 }
 
 __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, int n_src_rows, int main_blocks, int n_riders,
-                                                         float* __restrict__ rel_sums) {
+                                                         float* __restrict__ rel_sums, int xcd_ranges) {
     __shared__ float s_dp[KGW_BLK];                           // 64 floats per wavefront (bwd_src_row_pair)
     if ((int)blockIdx.x < n_riders) {
         bwd_src_rider(T, P, (int)blockIdx.x, rel_sums, s_dp);
@@ -1041,7 +1062,25 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, 
         bwd_src_one_row(T, P, u);
         if (u + 1 < n_src_rows) bwd_src_one_row(T, P, u + 1);
     }
-    for (int o = nw - 1 - w0; o < (T.oct_rows >> 3); o += nw)
+    if (!xcd_ranges) {
+        for (int o = nw - 1 - w0; o < (T.oct_rows >> 3); o += nw)
+            if (P.oct_flags[o]) bwd_src_octet(T, P, 8 * o);
+        return;
+    }
+    // Round 5: every XCD takes a CONTIGUOUS eighth of the octets.  Workgroups are dealt to the eight XCDs round-robin and each XCD
+    // has an L2 of its own (4 MB); the short rows are laid out by ascending node id -- genome order for the SNPs, whose edges
+    // reach the genes of their neighbourhood -- so neighbouring octets gather the same few dZ rows.  Dealt round-robin, every L2
+    // sees all 11.8 MB of dZ (most gathers go to the fabric); with a range per XCD an L2 holds the ~1/8 of the rows its SNPs
+    // point at.  An octet is uniform work (8 rows x ~2 entries), so the static partition costs no balance -- unlike the chunk
+    // lists of the dst-major kernels (chunk_perm, round 2).  The rows' values do not depend on who computes them.
+    const int n_oct = T.oct_rows >> 3;
+    const int x = (int)blockIdx.x & 7;
+    const int first = n_riders + ((x - n_riders) & 7);              // first row-work block of this XCD class
+    const int cnt = ((int)gridDim.x - first + 7) >> 3;              // row-work blocks of the class
+    if (cnt <= 0) return;
+    const int wi = (((int)blockIdx.x - first) >> 3) * 4 + (threadIdx.x >> 6), nwx = cnt * 4;
+    const int lo = (int)(((int64_t)n_oct * x) >> 3), hi = (int)(((int64_t)n_oct * (x + 1)) >> 3);
+    for (int o = lo + (nwx - 1 - wi); o < hi; o += nwx)
         if (P.oct_flags[o]) bwd_src_octet(T, P, 8 * o);
 }
 
@@ -1117,7 +1156,6 @@ AggPtrs build_ptrs(const KgwLayerArgs* a) {
     P.t_zrow = a->t_zrow; P.t_rel = a->t_rel; P.oct_flags = a->oct_flags; P.part_du = a->part_du; P.seg_chptr = a->seg_chptr; P.duv_ws = a->duv_ws;
     P.n_duv_hops = a->n_multi_hops; P.dH = a->dH; P.da_src = a->da_src; P.multi = a->multi; P.multi_cap = a->multi_cap;
     P.meta = a->meta_dev; P.layer = a->layer;
-    P.perm = a->chunk_perm_len ? a->chunk_perm : nullptr; P.perm_len = a->chunk_perm_len;
     P.lbias = a->logit_bias;
     return P;
 }
@@ -1213,7 +1251,9 @@ extern "C" int kgw_gat_aggregate_bwd_src(const KgwLayerArgs* a, kgw_stream_t str
     const bool duv = a->dU && a->dV && a->part_du && a->duv_ws && a->seg_chptr;
     const int n_riders = (a->rel_sums ? T.n_rels : 0) + (duv ? 2 * KGW_DUV_SPLIT * T.n_rels : 0);
     if (!duv) P.duv_ws = nullptr;
-    k_agg_bwd_src<<<gmain + n_riders, KGW_BLK, 0, (hipStream_t)stream_>>>(T, P, a->n_src_rows, gmain, n_riders, a->rel_sums);
+    static const int xcd_ranges = getenv("KGW_SRC_XCD") ? atoi(getenv("KGW_SRC_XCD")) : 1;
+    k_agg_bwd_src<<<gmain + n_riders, KGW_BLK, 0, (hipStream_t)stream_>>>(T, P, a->n_src_rows, gmain, n_riders, a->rel_sums,
+                                                                          xcd_ranges && gmain >= 64);
     KGW_LAUNCH_CHECK();
     if (a->ev_after) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_after, (hipStream_t)stream_));
     if (duv && !(a->flags & KGW_F_DUV_PIECES)) {        // (pieces: the consumer of d u_r / d v_r adds the eight pieces itself)

@@ -1095,25 +1095,6 @@ extern "C" int kgw_accumulate_stats_tick(const KgwBatchMeta* meta_dev, int32_t n
     return KGW_OK;
 }
 
-// ---- a timed offset on a stream ------------------------------------------------------------------------------------------
-// One wavefront that sleeps until ``us`` microseconds of the 100 MHz wall clock have passed.  At the head of the sampler's graph
-// on its side stream it shifts the next batch's sampling against the training step it runs beside: WHICH of the step's kernels
-// the sampler's launches share the chip with decides what the overlap costs.
-namespace {
-__global__ void __launch_bounds__(64) k_delay(long long ticks) {
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-}
-}  // namespace
-
-extern "C" int kgw_delay(int32_t us, kgw_stream_t stream_) {
-    if (us < 0 || us > 100000) return KGW_E_RANGE;
-    if (us == 0) return KGW_OK;
-    k_delay<<<1, 64, 0, (hipStream_t)stream_>>>((long long)us * 100);
-    KGW_LAUNCH_CHECK();
-    return KGW_OK;
-}
-
 extern "C" int kgw_accumulate_stats(const KgwBatchMeta* meta_dev, int32_t n_layers, int32_t n_hops, int64_t* stats,
                                     kgw_stream_t stream_) {
     return kgw_accumulate_stats_tick(meta_dev, n_layers, n_hops, stats, nullptr, stream_);

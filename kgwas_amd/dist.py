@@ -62,6 +62,12 @@ def allreduce_flat(flat: torch.Tensor, world: int, what: str = 'parameter gradie
 
 
 _LIVE = weakref.WeakKeyDictionary()   # model -> liveness of its requires_grad parameters, as agreed over the ranks
+_FLAG = weakref.WeakKeyDictionary()   # model -> (pinned host copy of the last bucket's "new live parameter" flag, its event)
+
+
+class _Done:
+    def synchronize(self):
+        pass
 
 
 def allreduce_grads(model, world: int):
@@ -82,11 +88,15 @@ def allreduce_grads(model, world: int):
     # liveness is agreed at the first reduction and RE-agreed whenever a rank sees a gradient on a parameter the agreement left
     # out (a node type or relation absent from every rank's first batch that a later batch reaches): one 1-element MAX
     # all-reduce per step keeps the decision to re-agree itself collective -- every rank runs the same sequence
+    # (round 5: the "somebody saw a new live parameter" flag rides as one more element of the gradient bucket and is read back
+    #  WITHOUT stalling the step -- an asynchronous copy, looked at by the next call: no extra collective, no host sync per step;
+    #  the re-agreement happens one step after the event, on every rank at the same step since the flag is the reduced one)
     fresh = live is None or len(live) != len(params)
-    if not fresh:
-        t1 = torch.tensor([1 if any(h and not l for h, l in zip(had, live)) else 0], dtype=torch.int32, device=params[0].device)
-        dist.all_reduce(t1, op=dist.ReduceOp.MAX)
-        fresh = bool(int(t1[0]))
+    pend = _FLAG.get(model)
+    if not fresh and pend is not None:
+        pend[1].synchronize()                      # (the copy of the PREVIOUS step's flag: long finished)
+        fresh = bool(float(pend[0][0]) > 0.0)
+    mine_new = (not fresh) and any(h and not l for h, l in zip(had, live))
     if fresh:
         t = torch.tensor([h or (live is not None and len(live) == len(params) and live[i]) for i, h in enumerate(had)],
                          dtype=torch.int32, device=params[0].device)
@@ -98,8 +108,15 @@ def allreduce_grads(model, world: int):
             p.grad = None            # (never stepped on a local, unreduced gradient)
     if not sel:
         return
-    flat = torch.cat([p.grad.reshape(-1) if p.grad is not None else p.new_zeros(p.numel()) for p in sel])
+    flat = torch.cat([p.grad.reshape(-1) if p.grad is not None else p.new_zeros(p.numel()) for p in sel] +
+                     [sel[0].new_full((1,), 1.0 if mine_new else 0.0)])
     allreduce_flat(flat, world)
+    host = pend[0] if pend is not None else (torch.zeros(1, dtype=flat.dtype).pin_memory() if flat.is_cuda else torch.zeros(1, dtype=flat.dtype))
+    host.copy_(flat[-1:], non_blocking=True)
+    ev = torch.cuda.Event() if flat.is_cuda else None
+    if ev is not None:
+        ev.record()
+    _FLAG[model] = (host, ev if ev is not None else _Done())
     off = 0
     for p in sel:
         n = p.numel()

@@ -25,29 +25,11 @@ from .sampler import BatchBuffers, NeighborLoader, SampledBatch, sample_into
 # (measured, 512-seed steps: 2048 blocks 1.74 ms/step, 512: 1.68, 256: 1.67, 128: 1.66, 64: 2.03 -- there the sampler,
 # 1.0 ms on its own, no longer hides); 256 keeps the sampler at 0.42 ms, under the forward-only eval step too
 SIDE_SAMPLER_GRID = int(os.environ.get('KGW_SIDE_SAMPLER_GRID', '256'))       # (the knob: re-measured whenever the sampler changes)
-# microseconds the side sampler's graph idles before its first launch (kgw_delay): which kernels of the step the sampler's
-# launches share the chip with decides what the overlap costs (KGW_SAMPLER_DELAY_US overrides; 0 = start with the step)
-SIDE_SAMPLER_DELAY_US = int(os.environ.get('KGW_SAMPLER_DELAY_US', '0'))
-
-
 def side_stream(device):
-    """The stream the next batch's sampler graph is captured on and replayed on.  KGW_SAMPLER_CU_MASK=<hex words, comma
-    separated, least significant first> confines it to a subset of the compute units (hipExtStreamCreateWithCUMask: bit i of
-    the mask = CU i) -- an experiment knob: a sampler that runs on a few CUs leaves the L1 / LDS / issue slots of the others
-    to the step's kernels (measured: profiles/r4/).  Default: an ordinary stream."""
-    spec = os.environ.get('KGW_SAMPLER_CU_MASK', '')
-    if not spec:
-        # KGW_SAMPLER_PRIORITY: stream priority of the sampler's queue (a larger number = a LOWER priority; values outside the
-        # device's range are clamped): with a low-priority queue the dispatcher hands free wavefront slots to the step's kernels first
-        return torch.cuda.Stream(device=device, priority=int(os.environ.get('KGW_SAMPLER_PRIORITY', '0')))
-    words = [int(w, 16) for w in spec.split(',') if w]
-    hip = C.CDLL('libamdhip64.so')
-    st = C.c_void_p()
-    arr = (C.c_uint32 * len(words))(*words)
-    rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), C.c_uint32(len(words)), arr)
-    if rc != 0:
-        raise _lib.KgwasHipError(f'hipExtStreamCreateWithCUMask failed: {rc}')
-    return torch.cuda.ExternalStream(st.value, device=device)
+    """The stream the next batch's sampler graph is captured on and replayed on: an ordinary stream.  (Round 4 measured a CU-masked
+    stream -- the two graphs then ran strictly one after the other --, stream priorities and a timed offset at the head of the
+    sampler's graph: none helped, profiles/r4/r4_sampler_interference_experiments.txt; the knobs are gone.)"""
+    return torch.cuda.Stream(device=device)
 
 
 class GraphTrainStep:
@@ -146,9 +128,8 @@ class GraphTrainStep:
         # (timing experiments only: train on stale batches to see what the concurrent sampler costs the step)
         self._skip_resample = os.environ.get('KGW_SKIP_RESAMPLE', '0') == '1'
         self._twin_pending = [False, False]        # the side stream holds an unfinished sample of this buffer
-        # (parameter-only kernels on a parallel branch of the captured step: measured 1.403 ms on one box and 1.85 ms on three
-        # others -- HIP-graph branch scheduling is bimodal here -- against 1.414 without: off)
-        self.param_branch = os.environ.get('KGW_PARAM_BRANCH', '0') == '1'
+        # (parameter-only kernels on a parallel branch of the captured step: measured again in round 5 -- 1.397 ms against 1.081, and
+        #  the branch's queue displaces the side sampler's, overlap ratio -0.14 -- HIP-graph branches are not a tool here; removed)
         self._capture()
 
     # train on the batch held by bufs[cur]; concurrently sample ``self.seeds`` into bufs[1 - cur]
@@ -194,8 +175,7 @@ class GraphTrainStep:
         if self.split_backward:
             mlp_out = []
             loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id(self.input_type),
-                                              self.dg.y[self.input_type], self.ld_w, mlp_out=mlp_out, unit_grad=True,
-                                              param_branch=self.param_branch)
+                                              self.dg.y[self.input_type], self.ld_w, mlp_out=mlp_out, unit_grad=True)
             hs = [h for h in mlp_out if h.requires_grad]
             late = self._late_params()
             early = [p for p in self.model.parameters() if p.requires_grad and id(p) not in late]
@@ -211,8 +191,7 @@ class GraphTrainStep:
             self._cut[cur] = (hs, list(g[:len(hs)]))
         else:
             loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id(self.input_type),
-                                              self.dg.y[self.input_type], self.ld_w, unit_grad=True,
-                                              param_branch=self.param_branch)                # kgwas.py:137-145
+                                              self.dg.y[self.input_type], self.ld_w, unit_grad=True)      # kgwas.py:137-145
             # fused optimiser launch: the weight-gradient products that feed only Adam stop after their first launch, their last
             # sums, the update, the step counter and the running totals are ONE launch (ops.GradSink, kgw_adam_fused)
             sink = ops.GradSink() if self.fused_adam else None
@@ -386,15 +365,9 @@ class GraphTrainStep:
         self._refresh_images(force=True)                       # (the warm-up's updates are undone: so are their images)
         self.stats.zero_()
         self.opt.zero_grad(set_to_none=True)
-        # (KGW_STEP_PRIORITY: capture -- hence run, a replayed graph executes on the queue of the stream it was captured on -- the
-        #  step on a stream of this priority; negative = above the sampler's default-priority queue.  Experiment knob.)
-        cap_kw = {}
-        if os.environ.get('KGW_STEP_PRIORITY'):
-            self._cap_stream = torch.cuda.Stream(device=self.seeds.device, priority=int(os.environ['KGW_STEP_PRIORITY']))
-            cap_kw = {'stream': self._cap_stream}
         for cur in (0, 1):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, **cap_kw):
+            with torch.cuda.graph(g):
                 self.loss[cur] = self._step_body(cur)
             self.graphs[cur] = g
             if self.split_backward:
@@ -412,26 +385,8 @@ class GraphTrainStep:
                         gs.weight_grad_partial(gs.last[0], out=self._flat_grads[gs.last[1]])
             if self.twin:
                 gs = torch.cuda.CUDAGraph()
-                probe = os.environ.get('KGW_SIDE_PROBE')      # (experiment: what does a side graph cost the step BY ITSELF?)
                 with torch.cuda.graph(gs, stream=self._side):
-                    if SIDE_SAMPLER_DELAY_US > 0:       # (a timed offset against the step it runs beside, see the constant)
-                        _lib.check(_lib.lib().kgw_delay(SIDE_SAMPLER_DELAY_US, _lib.stream_ptr()), 'kgw_delay')
-                    if probe and probe.startswith('parts:'):
-                        # "parts:<a>:<b>": only parts a..b of the sampling call (kgw_sample_batch_parts: 0 .. 2 hops - 1 the hop
-                        # expansion, 2 hops the layer tables + src-major build) -- WHICH phase costs the step what; the seeds
-                        # are frozen (step()), so the buffers keep holding one consistent batch
-                        a_, b_ = (int(v) for v in probe.split(':')[1:])
-                        _lib.check(_lib.lib().kgw_sample_batch_parts(C.byref(self.dg.kg), C.byref(self.bufs[cur].c), self.seeds.data_ptr(),
-                                                                     int(self.seeds.numel()), self.seed_type, 0, a_, b_, _lib.stream_ptr()),
-                                   'kgw_sample_batch_parts')
-                    elif probe:
-                        # "<n>x<us>": n launches of one idle wavefront each, <us> microseconds long -- launches and queue
-                        # activity without memory traffic or occupancy; the step then trains on stale batches
-                        n_, us_ = (int(v) for v in probe.split('x'))
-                        for _ in range(n_):
-                            _lib.check(_lib.lib().kgw_delay(max(us_, 1), _lib.stream_ptr()), 'kgw_delay')
-                    else:
-                        sample_into(self.dg, self.bufs[cur], self.seeds, self.seed_type, record=False)
+                    sample_into(self.dg, self.bufs[cur], self.seeds, self.seed_type, record=False)
                 self.sample_graphs[cur] = gs
         self._have = [-1, -1]
 
@@ -452,8 +407,7 @@ class GraphTrainStep:
             main = torch.cuda.current_stream()
             self._side.wait_stream(main)          # the previous step (reader of bufs[1 - cur], writer of nothing here) is done
             with torch.cuda.stream(self._side):
-                if not os.environ.get('KGW_SIDE_PROBE', '').startswith('parts:'):
-                    self.seeds.copy_(self.ids[nxt * b:(nxt + 1) * b])
+                self.seeds.copy_(self.ids[nxt * b:(nxt + 1) * b])
                 if not self._skip_resample:
                     self.sample_graphs[1 - cur].replay()
                 self._sampled[1 - cur].record(self._side)
@@ -496,10 +450,17 @@ class GraphTrainStep:
         graph runs on the queue of the stream it was captured on: two streams that share a queue serialise whatever the program
         says.  Times ``n`` steps with the side sampler, ``n`` without it (stale batches) and ``n`` sampler replays alone; overlap =
         the share of the sampler's own time that did NOT show up in the step.  Every rank calls it (multi-rank steps contain
-        collectives).  Leaves the buffers unsampled (the next step() samples its batch itself)."""
+        collectives).  Leaves the buffers unsampled (the next step() samples its batch itself) and the model, the optimiser state
+        and the running totals as it found them."""
         import time
         if not self.twin:
             return {'overlapped': False, 'note': 'the sampler is not run beside the step in this configuration'}
+        # the measurement runs real training steps (half of them on stale batches): parameters, optimiser state, step counter and
+        # the running totals are put back afterwards -- a measurement must not move the trajectory (ADVICE r4)
+        params = [p for p in self.model.parameters()]
+        snap = [p.detach().clone() for p in params]
+        ostate = {p: {k: v.clone() for k, v in st.items() if torch.is_tensor(v)} for p, st in self.opt.state.items()}
+        step0, stats0 = self.opt.step_dev.clone(), self.stats.clone()
 
         def timed(fn):
             torch.cuda.synchronize()
@@ -527,7 +488,18 @@ class GraphTrainStep:
         self._skip_resample = keep
         sampler = timed(samp)
         torch.cuda.current_stream().wait_stream(self._side)
+        torch.cuda.synchronize()
         self._have, self._twin_pending = [-1, -1], [False, False]
+        with torch.no_grad():
+            for p, q in zip(params, snap):
+                p.copy_(q)
+            for p, st in self.opt.state.items():
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        v.copy_(ostate[p][k]) if p in ostate and k in ostate[p] else v.zero_()
+            self.opt.step_dev.copy_(step0)
+            self.stats.copy_(stats0)
+        self._refresh_images(force=True)                        # (the operand images follow the restored weights)
         ratio = (alone + sampler - both) / max(sampler, 1e-9)
         return {'step_with_side_sampler_ms': both, 'step_alone_ms': alone, 'sampler_alone_ms': sampler, 'overlap_ratio': ratio,
                 'overlapped': bool(ratio > 0.5), 'steps': n}

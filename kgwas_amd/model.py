@@ -112,7 +112,6 @@ class SimpleMLP(nn.Module):
                         self.FC_output.weight, self.FC_output.bias, out, rows_dev)
 
 
-_PARAM_STREAMS = {}          # device -> side stream of forward_loss(param_branch=True)
 
 
 class RelationPack(nn.Module):
@@ -519,8 +518,7 @@ class HeteroGNN(nn.Module):
     def _layer_params(self, batch: SampledBatch, l: int, folded: bool, relvec=None, zbuf=None):
         """Everything layer l needs that depends on the PARAMETERS only (and on the batch's static row counts): the destination
         blocks, the zeroed aggregate workspace, u_r / v_r / summed biases (ops.rel_vectors) and, for a folded layer 1, the
-        fold of FC_output into them.  No activation enters: the captured step runs this on a side branch beside the feature
-        MLPs (``forward_loss(param_branch=True)``)."""
+        fold of FC_output into them.  No activation enters."""
         sc, m = self.schema, batch.meta
         P: RelationPack = self.live_packs[l - 1]
         rng = self._dst_range[l - 1]
@@ -655,45 +653,24 @@ class HeteroGNN(nn.Module):
         _, attn = self._fused_layers(batch, h, want_attention=True, hbuf=hbuf, folded=self.fold_fc)
         return attn
 
-    def forward_loss(self, x_dict, edge_index_dict, batch_size, n_id, y_all, w_all, mlp_out=None, unit_grad=False,
-                     param_branch=False):
+    def forward_loss(self, x_dict, edge_index_dict, batch_size, n_id, y_all, w_all, mlp_out=None, unit_grad=False):
         """The training step's forward (kgwas/kgwas.py:137-145): HeteroGNN.forward followed by
         mean(w_all[n_id] * (pred - y_all[n_id])**2), with the read-out Linear + ReLU (model.py:86) and the loss fused
         into one node.  Returns (loss [float64 scalar], pred [batch_size]).  ``mlp_out`` (list): receives the feature MLPs'
         output tensors -- the cut between the two halves of a backward pass whose first half's gradients are all-reduced
         while the second half runs (multi-GPU GraphTrainStep).  ``unit_grad``: the caller will backpropagate exactly
-        ``loss.backward()`` (gradient 1): the read-out node then does its forward and backward in two launches.
-        ``param_branch``: the kernels that depend on the parameters only (attention vectors, FC_output fold, workspace
-        clears: tiny grids, ~30 us forward and ~45 us backward on the critical path) run on a side stream beside the feature
-        MLPs -- inside a captured step a parallel branch of the graph; autograd runs their backward on that stream too."""
+        ``loss.backward()`` (gradient 1): the read-out node then does its forward and backward in two launches."""
         batch: Optional[SampledBatch] = getattr(x_dict, 'kgw_batch', None) or getattr(edge_index_dict, 'kgw_batch', None)
         if batch is None:
             batch = self._block_from_coo(x_dict, edge_index_dict)
         if self.lin.out_features != 1:
             raise NotImplementedError('the fused read-out + loss is for out_channels == 1 (kgwas/kgwas.py:52)')
         hbuf, blocks = self._layer_input(batch, 1)
-        prep = None
-        if param_branch and self.backbone == 'GAT':
-            main = torch.cuda.current_stream()
-            dev_key = str(self.lin.weight.device)                           # (not on the module: deepcopy(model) pickles it)
-            side = _PARAM_STREAMS.get(dev_key)
-            if side is None:
-                side = _PARAM_STREAMS[dev_key] = torch.cuda.Stream(device=self.lin.weight.device)
-            side.wait_stream(main)                                          # fork
-            with torch.cuda.stream(side):
-                prep = [self._layer_params(batch, l, self.fold_fc) for l in range(1, self.num_layers + 1)]
-                if not torch.cuda.is_current_stream_capturing():            # (a captured graph owns its memory pool)
-                    for pr in prep:
-                        for t in pr[2:]:
-                            if torch.is_tensor(t):
-                                t.record_stream(main)
         h = self._embed_all(batch, x_dict, blocks, fold=self.fold_fc)
         if mlp_out is not None:
             mlp_out.extend(h.values())
-        if prep is not None:
-            torch.cuda.current_stream().wait_stream(side)                   # join
         gat = self.backbone == 'GAT' and self.aggr in ('sum', 'mean')
-        h, _ = self._fused_layers(batch, h, hbuf=hbuf, last_premasked=gat, folded=self.fold_fc, prep=prep)
+        h, _ = self._fused_layers(batch, h, hbuf=hbuf, last_premasked=gat, folded=self.fold_fc)
         return ops.readout_weighted_mse(h['SNP'], self.lin.weight, self.lin.bias, n_id, y_all, w_all, batch_size,
                                         relu=not self.no_relu, h_is_relu=gat, unit_grad=unit_grad)
 

@@ -208,8 +208,8 @@ class GradSink:
         rows, M = dY.shape
         N = X.shape[1]
         # (a tall product -- the SNP MLP's 122 k rows: 512 blocks that fill the chip for 43 us -- is launched where it is: grouped with
-        #  it the short ones queue behind its blocks, KGW_DEFER_TALL=1 to see)
-        if not (_DEFER_PRODUCTS and 0 < rows < (1 << 62 if _DEFER_TALL else 32768) and X.shape[0] == rows and dY.dtype == torch.float32 and X.dtype == torch.float32 and
+        #  it the short ones queue behind its blocks, measured in round 4)
+        if not (_DEFER_PRODUCTS and 0 < rows < 32768 and X.shape[0] == rows and dY.dtype == torch.float32 and X.dtype == torch.float32 and
                 dY.stride(1) == 1 and X.stride(1) == 1 and M % 2 == 0 and N % 2 == 0 and M >= 64 and N >= 64 and dY.stride(0) % 2 == 0 and
                 X.stride(0) % 2 == 0 and dY.data_ptr() % 8 == 0 and X.data_ptr() % 8 == 0):
             return None
@@ -255,7 +255,10 @@ class GradSink:
         if src.kind != 0:           # (KGW_GRAD_DIRECT: the producer finished the tensor itself)
             rec = _lib.KgwGradSrc()
             C.memmove(C.byref(rec), C.byref(src), C.sizeof(rec))
-            self.records[grad.data_ptr()] = (rec, grad.numel(), ws)      # (NOT the tensor: autograd must be able to steal it)
+            # (NOT the tensor: autograd must be able to steal it -- but its STORAGE, like defer_product: were autograd to clone the
+            #  gradient and drop the original, the caching allocator could hand the block to another gradient of the same size,
+            #  which would then inherit this record; with the block held a clone is noticed as a left-over record)
+            self.records[grad.data_ptr()] = (rec, grad.numel(), ws, grad.untyped_storage())
 
     def take(self, grad: torch.Tensor):
         rec = self.records.pop(grad.data_ptr(), None)
@@ -269,11 +272,10 @@ _FUSED_ADAM = os.environ.get('KGW_FUSED_ADAM', '1') != '0'         # 0: k_tn_red
 # The SHORT weight-gradient products of the MLPs (gene 20 k rows, GO 2 x 7 k: 316 + 448 blocks, neither fills the chip's 512 slots)
 # are not launched where their backward passes end but as ONE grouped launch ahead of the optimiser's (GradSink.defer_product):
 # 29.7 us against 16.8 + 17.2 in two launches, step 1.1142 / 1.1173 against 1.1218 / 1.1201 ms (A/B on one box).  With the TALL
-# product of the SNP MLP in the group too (KGW_DEFER_TALL=1) nothing is gained -- 1.0830 / 1.0838 against 1.0832 / 1.0834, the grouped
+# product of the SNP MLP in the group too (round 4, knob removed) nothing is gained -- 1.0830 / 1.0838 against 1.0832 / 1.0834, the grouped
 # launch 83 us against 16.8 + 43.7 + 16.7: its 512 blocks already fill the chip for 43 us and the short products' blocks of the later
 # tiles queue behind them.  KGW_DEFER_PRODUCTS=0: every product where it is.
 _DEFER_PRODUCTS = os.environ.get('KGW_DEFER_PRODUCTS', '1') != '0'
-_DEFER_TALL = os.environ.get('KGW_DEFER_TALL', '0') == '1'
 
 
 class grad_sink_scope:
@@ -324,9 +326,6 @@ def _layer_args(batch, layer: int, neg_slope: float, inv_temp: float) -> KgwLaye
     if _SHORT_ROWS:
         a.t_rel = _p(buf.t_rel[layer - 1])          # relation id per src-major entry: the 8-rows-per-wavefront backward path
         a.oct_flags = _p(buf.t_cnt[layer - 1])      # (the histogram scratch holds the sampler's octet flags afterwards)
-    perm = getattr(batch, 'chunk_perm', None)          # XCD-aware work order of the dst-major kernels (optional)
-    if perm is not None and perm.get(layer) is not None:
-        a.chunk_perm, a.chunk_perm_len = _p(perm[layer][0]), _p(perm[layer][1])
     return a
 
 
@@ -408,13 +407,15 @@ class _GatAggregate(torch.autograd.Function):
         da_dst, ctx.da_dst = ctx.da_dst, None            # zeroed with Z in forward; consumed once
         if da_dst is None:
             da_dst = torch.zeros(max(z_rows, 1), device=dev)
-        part_da = torch.empty(max(n_chunks, 1), device=dev)
+        part_da = torch.empty(4 * max(n_chunks, 1), device=dev)      # (per chunk of a hub row: the four sums of k_agg_bwd_dst)
         dH = torch.empty(max(n_src, 1), KGW_C, device=dev)
         ld_da = (sc.NR + 3) & ~3
         a = _layer_args(batch, layer, ctx.neg_slope, ctx.inv_temp)
         a.H, a.U, a.V, a.Z, a.stat, a.e_edge = _p(H), _p(U), _p(V), _p(Z), _p(stat), _p(e_edge)
         a.dZ, a.adp, a.da_dst, a.part_da = _p(dZf), _p(adp), _p(da_dst), _p(part_da)
         a.dH = _p(dH)
+        if xchg is not None:
+            a.partial_rels = xchg.mask[layer]      # (their rows' d a_dst stay plain sums over this rank's edges: kgw_gat_aggregate_bwd_dst)
         riders = _DUV_RIDERS and n_src > 0 and n_chunks > 0
         if riders:
             # d u_r / d v_r from per-chunk sums the dst-major pass leaves and extra blocks of the src-major launch -- no
@@ -969,7 +970,10 @@ def gene_layer_split_pays(world: int, width: int) -> bool:
     together, measured / modelled); it saves (world - 1) / world of 0.275 ms x width / 5 120.  Measured with bench.py --as-rank
     (profiles/r4): width 5 120 -- rank compute 1.231 -> 1.158 / 1.097 / 1.069 ms at 2 / 4 / 8 ranks; width 57 742 -- 4.185 ->
     2.855 / 1.661 ms at 2 / 8 ranks."""
-    return world >= 2 and (world - 1) / world * 0.275 * (width / 5120.0) > 0.17
+    if width <= 0:                     # (feature width unknown -- a data object without gene_init_dim_size: the measured 5 120-wide rule)
+        return world >= 4
+    # break-even 0.19 ms: on from 4 ranks at width 5 120 (0.206 saved; 3 ranks: 0.183, measured a wash), from 2 at 57 742
+    return world >= 2 and (world - 1) / world * 0.275 * (width / 5120.0) > 0.19
 
 
 GENE_SHARD = None          # the GeneLayerShard of the training step being issued (gene_shard_scope), or None

@@ -59,6 +59,13 @@ class FusedAdam:
             n = len(sink.records)
             sink.records.clear()
             raise ops.GradSinkMismatch(f'{n} deferred gradient(s) did not reach a parameter as written')
+        # a weight whose kgw_gemm3 operand image this launch keeps current must arrive as a KGW_GRAD_G3T record: updated from any other
+        # kind of gradient (a complete tensor, a TN product, something autograd accumulated) the weight would change and the image the
+        # next forward reads would not -- the HIP launches do not move the tensor's version counter, so nobody would notice
+        for p in live:
+            if p in self.packed_images and (p not in recs or recs[p][0].kind != 5):
+                raise ops.GradSinkMismatch('the gradient of a weight with a persistent kgw_gemm3 operand image did not arrive as the '
+                                           'partial sums of kgw_gemm3_partial: its image would go stale')
         if len(live) > _lib.ADAM_FUSED_MAX or len(recs) > _lib.ADAM_FUSED_SRC:
             raise ops.GradSinkMismatch(f'{len(live)} tensors / {len(recs)} deferred gradients exceed the fused launch\'s tables')
         live.sort(key=lambda p: 0 if p in recs else 1)           # the longer work units first

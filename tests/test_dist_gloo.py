@@ -100,7 +100,13 @@ def _worker_split(rank, world, port, out_dir):
         if rank == 1:
             m.bias.grad = torch.full_like(m.bias, 4.0)        # step 2: alive on ONE rank only
         kdist.allreduce_grads(m, world)
-        torch.save({'ok': ok, 'first_w': first[0], 'first_b': first[1], 'second_b': m.bias.grad}, os.path.join(out_dir, f's{rank}.pt'))
+        second_b = m.bias.grad                               # (round 5: the flag rides in the bucket and is looked at one call later)
+        m.weight.grad = torch.full_like(m.weight, 1.0)
+        if rank == 1:
+            m.bias.grad = torch.full_like(m.bias, 4.0)
+        kdist.allreduce_grads(m, world)                       # step 3: re-agreed on every rank at the same step
+        torch.save({'ok': ok, 'first_w': first[0], 'first_b': first[1], 'second_b': second_b, 'third_b': m.bias.grad},
+                   os.path.join(out_dir, f's{rank}.pt'))
     finally:
         dist.destroy_process_group()
 
@@ -112,8 +118,11 @@ def test_gene_layer_split_selftest_and_liveness_reagreement(tmp_path):
         d = torch.load(tmp_path / f's{r}.pt', weights_only=False)
         assert d['ok'] is True
         assert torch.equal(d['first_w'], torch.full((2, 3), 1.5)) and d['first_b'] is None
-        # the parameter that came alive on rank 1 is reduced on BOTH ranks (mean of 0 and 4), not stepped locally on one
-        assert d['second_b'] is not None and torch.equal(d['second_b'], torch.full((2,), 2.0))
+        # the parameter that came alive on rank 1 is never stepped locally on one rank: the step that sees it drops the local
+        # gradient on every rank (the flag travels in the gradient bucket, no extra collective / host sync per step) and the next
+        # one reduces it on BOTH ranks (mean of 0 and 4)
+        assert d['second_b'] is None
+        assert d['third_b'] is not None and torch.equal(d['third_b'], torch.full((2,), 2.0))
 
 
 def test_gene_layer_split_default_follows_what_it_saves():
@@ -122,3 +131,6 @@ def test_gene_layer_split_default_follows_what_it_saves():
     assert ops.gene_layer_split_pays(4, 5120) and ops.gene_layer_split_pays(8, 5120)
     assert ops.gene_layer_split_pays(2, 57742)                # the 57 742-wide features: from two ranks on
     assert not ops.gene_layer_split_pays(8, 96)               # narrow features never take the resident route anyway
+    # the decision table as documented -- width 5 120: from FOUR ranks (three is a wash), width unknown: the same rule
+    assert not ops.gene_layer_split_pays(3, 5120)
+    assert [ops.gene_layer_split_pays(w, 0) for w in (1, 2, 3, 4, 8)] == [False, False, False, True, True]

@@ -309,3 +309,27 @@ def test_fallback_when_a_deferred_gradient_does_not_reach_its_parameter(monkeypa
     pa, pb = params_by_name(runs[0].model), params_by_name(runs[1].model)
     for n in pa:
         assert torch.equal(pa[n], pb[n]), n
+
+
+def test_image_owning_weight_updated_from_another_kind_of_gradient_is_refused():
+    """``step_fused`` rewrites a weight's persistent kgw_gemm3 operand image only when the weight's gradient arrives as
+    a KGW_GRAD_G3T record.  Any other kind of gradient (here: a complete tensor) would change the weight and leave the image the
+    next forward reads stale, silently -- the launch must be refused (GradSinkMismatch, nothing launched: the trainer's warm-up
+    then falls back to the unfused step, which packs in the forward)."""
+    from kgwas_amd import ops
+    from kgwas_amd.optim import FusedAdam
+    w = torch.nn.Parameter(torch.randn(128, 256, device=DEV))
+    b = torch.nn.Parameter(torch.randn(128, device=DEV))
+    opt = FusedAdam([w, b], lr=1e-3)
+    opt.packed_images[w] = torch.zeros(16, dtype=torch.uint8, device=DEV)
+    w.grad, b.grad = torch.randn_like(w), torch.randn_like(b)
+    w0, b0 = w.detach().clone(), b.detach().clone()
+    with pytest.raises(ops.GradSinkMismatch, match='operand image'):
+        opt.step_fused(ops.GradSink())
+    torch.cuda.synchronize()
+    assert torch.equal(w.detach(), w0) and torch.equal(b.detach(), b0) and int(opt.step_dev[0]) == 0
+    # without an image the same gradients are an ordinary fused update
+    opt.packed_images.clear()
+    opt.step_fused(ops.GradSink())
+    torch.cuda.synchronize()
+    assert not torch.equal(w.detach(), w0) and int(opt.step_dev[0]) == 1

@@ -96,3 +96,40 @@ def test_graph_eval_equals_eager_eval(small_kg, drop_last, monkeypatch):
     assert a['pred'].shape == b['pred'].shape == (n,)
     assert np.array_equal(a['truth'], b['truth'])
     np.testing.assert_allclose(a['pred'], b['pred'], rtol=1e-5, atol=1e-6)
+
+
+def test_measure_overlap_leaves_the_training_state_alone(small_kg):
+    """GraphTrainStep.measure_overlap (what bench.py calls before its epoch measurement) runs real training steps, half
+    of them on stale batches -- parameters, optimiser moments, step counter and running totals must be what they were, and the
+    trajectory after it the one of a trainer that never measured."""
+    from kgwas_amd.graph_step import GraphTrainStep
+    from kgwas_amd.kgwas import KGWAS
+    bs = 64
+    ids = np.asarray(small_kg.train_input_nodes[1][:bs * 8])
+    runs, outs = [], []
+    for measure in (True, False):
+        run = KGWAS(small_kg, device='cuda:0', seed=31)
+        run.initialize_model()
+        if runs:
+            run.model.load_state_dict(sd0)
+        else:
+            sd0 = copy.deepcopy(run.model.state_dict())
+        gs = GraphTrainStep(run, ('SNP', ids), bs, lr=1e-3, weight_decay=5e-4)
+        runs.append(run)
+        run.model.train()
+        for i in range(3):
+            gs.step(i)
+        if measure:
+            before = params_by_name(run.model)
+            step_before, stats_before = int(gs.opt.step_dev[0]), gs.stats.clone()
+            res = gs.measure_overlap(4)
+            assert 'overlap_ratio' in res
+            for n, p in params_by_name(run.model).items():
+                assert torch.equal(p, before[n]), n
+            assert int(gs.opt.step_dev[0]) == step_before and torch.equal(gs.stats, stats_before)
+        for i in range(3, 6):
+            gs.step(i)
+        outs.append((params_by_name(run.model), gs.check()))
+    for n in outs[0][0]:
+        assert torch.equal(outs[0][0][n], outs[1][0][n]), n
+    assert outs[0][1] == outs[1][1]

@@ -28,7 +28,7 @@ import pytest
 import torch
 
 from oracle.gat_oracle import weighted_mse
-from tests.helpers import assert_close, batch_cpu, grads_by_name, oracle_from_product
+from tests.helpers import assert_close, batch_cpu, grads_by_name, oracle_from_product, params_by_name
 
 pytestmark = pytest.mark.gpu
 
@@ -239,13 +239,16 @@ def _compare_with_oracle(run, ids, what, min_genes):
     nw.sort(reverse=True)
     print(f'[{what}] norm-wise gradient errors, largest first (this path / the float32 oracle): ' +
           ', '.join(f'{k} {e:.1e} / {e32:.1e}' for e, k, e32 in nw[:4]) + f'; median {nw[len(nw) // 2][0]:.1e} over {len(nw)} tensors')
-    # every tensor within 1e-3 of float64 norm-wise, or -- the cancellation residues above -- within 10 x of what the reference
-    # arithmetic itself is off, never more than 2e-2.  Measured over six 64-seed batches of this graph (round 4): the float32 oracle
-    # 8e-7 ... 2.6e-3 off float64 on these tensors depending on the batch, this path 1 - 7 x that (it forms sum_j alpha_j d alpha_j
-    # of a row from the stored fp32 aggregate, <dZ_i, z_i>, not edge by edge: one more rounding that does not cancel); two kernels
-    # that merely changed the order of the sums in u_r / v_r moved the first batch from 1.4 x to 6.3 x.
+    # every tensor within 1e-3 of float64 norm-wise, or -- the cancellation residues above -- within 2 x of what the reference
+    # arithmetic itself is off (no other cap).  Round 4 measured this path at 1 - 7 x the float32 oracle's own error on these tensors
+    # (8e-7 ... 2.6e-3 depending on the batch) and held it to 10 x, at most 2e-2: k_agg_bwd_dst took sum_j alpha_j d alpha_j of a row
+    # from the stored fp32 aggregate, <dZ_i, z_i> -- one more rounding that does not cancel in d a_dst.  Round 5: the row sum d a_dst is
+    # formed consistently with the edges' own d alpha (kgw_aggregate.hip, k_agg_bwd_dst: sum of a_e s_e (dalpha_e - c*) with
+    # c* = sum a_e dalpha_e / sum a_e, in small differences), as autograd of the reference's softmax (conv.py:223) does.
+    worst = max((e / max(e32, 1e-30), name, e, e32) for e, name, e32 in nw if e > 1e-3) if any(e > 1e-3 for e, _, _ in nw) else None
+    print(f'[{what}] worst tensor above 1e-3 relative to the float32 oracle: {worst}')
     for e, name, e32 in nw:
-        assert e <= max(1e-3, min(10.0 * e32, 2e-2)), (name, e, e32)
+        assert e <= max(1e-3, 2.0 * e32), (name, e, e32)
     assert nw[len(nw) // 2][0] <= 1e-5, nw[len(nw) // 2]
     gw, rw = grads_by_name(model)['gene_feat_mlp.FC_hidden.weight'].double(), go['gene_feat_mlp.FC_hidden.weight']
     assert float(rw.norm()) > 0 and int((pred > 0).sum()) >= bs // 2, 'a dead read-out would make this comparison empty'
@@ -265,6 +268,77 @@ def test_full_size_graph_against_the_oracle_for_a_few_seeds(full_c1, first):
     # the degree distribution is the real one: some sampled destination row has thousands of in-edges
     sp = batch.buf.seg_ptr[:int(batch.meta.seg_end[batch.dg.n_hops - 1]) + 1].cpu().numpy()
     assert int(np.diff(sp).max()) >= 1000
+
+
+def test_captured_training_steps_at_full_size_track_the_oracle(full_c1):
+    """VERDICT r4 (missing #3): the CAPTURED training step itself -- GraphTrainStep: HIP graph, fused optimiser launch, next batch
+    sampled by the side graph -- on full-size configs[1] at the benchmark's batch size, beside the float64 oracle trained from the
+    same initial state on the same batches (kgwas/kgwas.py:129-151: forward, LD-weighted loss, backward, Adam with L2): per-step
+    loss, the parameter update after the last step, and the ranking of the next batch's seeds."""
+    import time
+    from kgwas_amd.graph_step import GraphTrainStep
+    from oracle.sampler_np import FullNeighborSamplerNP
+    run = full_c1
+    model = run.model
+    bs, n_steps, lr, wd = 512, 8, 1e-3, 5e-4                 # (lr 10 x the reference's default, as the small trajectory test: a visible update)
+    ids = np.asarray(run.data.train_input_nodes[1])[:(n_steps + 1) * bs]
+    gs = GraphTrainStep(run, ('SNP', ids), bs, lr=lr, weight_decay=wd)
+    assert gs.fused_adam and gs.twin, 'the shipped single-GPU configuration: fused optimiser launch, side sampler'
+    oracle = oracle_from_product(model, dtype=torch.float64)
+    oracle0 = oracle_from_product(model, dtype=torch.float64)          # (stays at the initial state)
+    p0 = params_by_name(model)
+    model.train()
+    losses = []
+    for i in range(n_steps):
+        losses.append(float(gs.step(i)))
+    gs.check()
+    g = run.data.data
+    smp = FullNeighborSamplerNP(g.edge_index_dict, g.num_nodes_dict, 2)
+    opt = torch.optim.Adam(oracle.parameters(), lr=lr, weight_decay=wd)
+    y_all = g['SNP'].y.double()
+    w_all = run._ld_weight_vector().cpu()
+    t0 = time.time()
+    losses_o = []
+    for i in range(n_steps):
+        n_id, ei = smp.sample('SNP', ids[i * bs:(i + 1) * bs])
+        x = {t: g[t].x[n_id[t]].double() for t in g.node_types}
+        opt.zero_grad()
+        lo = weighted_mse(oracle(x, ei, bs), y_all[n_id['SNP'][:bs]], w_all[n_id['SNP'][:bs]])
+        lo.backward()
+        opt.step()
+        losses_o.append(float(lo))
+    print(f'[captured trajectory] {n_steps} oracle steps in {time.time() - t0:.0f} s; losses {losses} vs {losses_o}')
+    for a, b in zip(losses, losses_o):
+        assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, (losses, losses_o)
+    # the parameter UPDATE, norm-wise (Adam turns fp32-noise gradients into +-lr steps: tests/test_gpu_model.py's trajectory bound)
+    po = dict(oracle.named_parameters())
+    num = den = 0.0
+    for n, p in params_by_name(model).items():
+        if n not in po:
+            continue
+        d_hip, d_ref = p - p0[n], po[n].detach() - p0[n]
+        num += float((d_hip - d_ref).pow(2).sum()); den += float(d_ref.pow(2).sum())
+        assert float((d_hip - d_ref).abs().max()) <= 2.5 * lr * n_steps, n
+    assert den > 0 and (num / den) ** 0.5 < 2e-2, f'relative update error {(num / den) ** 0.5:.3e}'
+    print(f'[captured trajectory] relative update error after {n_steps} steps: {(num / den) ** 0.5:.3e}')
+    # the next batch through both: predictions and the order of the strongest seeds
+    from kgwas_amd.sampler import NeighborLoader
+    nxt = ids[n_steps * bs:(n_steps + 1) * bs]
+    batch = next(iter(NeighborLoader(g, [-1, -1], ('SNP', nxt), batch_size=bs, device='cuda:0')))
+    with torch.no_grad():
+        pred = model(batch.x_dict, batch.edge_index_dict, bs).reshape(-1)
+        n_id, ei = smp.sample('SNP', nxt)
+        x = {t: g[t].x[n_id[t]].double() for t in g.node_types}
+        pred_o = oracle(x, ei, bs).reshape(-1)
+        pred_0 = oracle0(x, ei, bs).reshape(-1)
+    # Adam turns gradient coordinates that are rounding noise into +-lr steps, differently in fp32 and fp64 (the 2e-2 of the update
+    # above): predictions are held to a twentieth of what the eight steps moved them, on top of the forward tolerance
+    moved = float((pred_o - pred_0).abs().max())
+    err = float((pred.cpu().double() - pred_o).abs().max())
+    print(f'[captured trajectory] next batch: the steps moved the predictions by up to {moved:.3e}, this path differs from the oracle by up to {err:.3e}')
+    assert moved > 1e-2, 'the steps must have changed the predictions for this comparison to mean anything'
+    assert_close(pred, pred_o, 1e-3, 1e-4 + 0.05 * moved, 'prediction after the captured steps')
+    assert torch.equal(torch.topk(pred.cpu().double(), 8).indices, torch.topk(pred_o, 8).indices)
 
 
 def test_full_mode_widths_against_the_oracle_at_a_reduced_gene_count():

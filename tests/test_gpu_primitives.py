@@ -57,23 +57,3 @@ def test_transposed_eight_way_reduction_primitives():
     assert torch.equal(out[3], grp[:, 3].repeat_interleave(8))
     assert torch.equal(out[4], v0[lanes ^ 4])
     assert torch.equal(out[5], v0[lanes ^ 8])
-
-
-def test_delay_idles_a_stream_for_the_requested_time():
-    """kgw_delay: one wavefront that sleeps on the 100 MHz wall clock -- a timed offset on a stream, nothing else."""
-    import ctypes as C
-    from kgwas_amd import _lib
-    L = _lib.lib()
-    assert L.kgw_delay(-1, None) == -2 and L.kgw_delay(200000, None) == -2      # out of range: before any launch
-    st = torch.cuda.current_stream()
-    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-    _lib.check(L.kgw_delay(50, C.c_void_p(st.cuda_stream)), 'kgw_delay')         # warm-up (code object load)
-    torch.cuda.synchronize()
-    e0.record()
-    _lib.check(L.kgw_delay(0, C.c_void_p(st.cuda_stream)), 'kgw_delay')          # 0: no launch at all
-    e1.record()
-    _lib.check(L.kgw_delay(400, C.c_void_p(st.cuda_stream)), 'kgw_delay')
-    e2.record()
-    torch.cuda.synchronize()
-    assert e0.elapsed_time(e1) < 0.2
-    assert 0.38 <= e1.elapsed_time(e2) <= 0.8, e1.elapsed_time(e2)

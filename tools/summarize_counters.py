@@ -30,7 +30,7 @@ def main():
     ctrs = []
     for n in names:
         ctrs += [c for c in res[n] if c not in ctrs]
-    print('rocprofv3 --pmc <group> --kernel-trace -- python tools/xcd_experiment.py none  (one process per group; batch 512, benchmark')
+    print('rocprofv3 --pmc <group> --kernel-trace -- python tools/agg_layer_runner.py  (one process per group; batch 512, benchmark')
     print('graph; per kernel the launches of its largest grid = layer 1; mean over the dispatches counted in the last line)')
     print()
     print('%-34s' % 'counter' + ''.join('%22s' % n[:21] for n in names))
