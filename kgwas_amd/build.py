@@ -52,6 +52,34 @@ def _stamp():
         return {}
 
 
+# host-side helpers (no GPU code: g++): the result-table writer of KGWAS.train()'s last step, csrc/host/*.cpp
+HOST_OUT = os.path.join(CSRC, 'libkgwas_host.so')
+HOST_DIR = os.path.join(CSRC, 'host')
+
+
+def _host_sources():
+    return sorted(os.path.join(HOST_DIR, f) for f in os.listdir(HOST_DIR) if f.endswith('.cpp')) if os.path.isdir(HOST_DIR) else []
+
+
+def build_host(force: bool = False, verbose: bool = True) -> str:
+    srcs = _host_sources()
+    if not srcs:
+        return HOST_OUT
+    want = _digest(srcs, 'g++ -O2 -std=c++17')
+    st = _stamp()
+    if not force and os.path.exists(HOST_OUT) and st.get('host') == want:
+        return HOST_OUT
+    cmd = [os.environ.get('CXX', 'g++'), '-O2', '-std=c++17', '-fPIC', '-shared', *srcs, '-o', HOST_OUT]
+    if verbose:
+        print(' '.join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.makedirs(OBJ, exist_ok=True)
+    st['host'] = want
+    with open(STAMP, 'w') as f:
+        json.dump(st, f)
+    return HOST_OUT
+
+
 def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
@@ -61,6 +89,7 @@ def needs_build() -> bool:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
+        build_host(False, verbose)
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     os.makedirs(OBJ, exist_ok=True)
@@ -81,8 +110,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + '.o') for s in sources()]
     run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', OUT])
+    st = _stamp()
+    st.update({'objects': want, 'lib_size': os.path.getsize(OUT)})
     with open(STAMP, 'w') as f:
-        json.dump({'objects': want, 'lib_size': os.path.getsize(OUT)}, f)
+        json.dump(st, f)
+    build_host(force, verbose)
     return OUT
 
 

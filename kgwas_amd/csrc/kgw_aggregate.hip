@@ -1038,7 +1038,7 @@ __global__ void __launch_bounds__(KGW_C) k_duv_fold(int n_rels, const float* __r
 }
 
 __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, int n_src_rows, int main_blocks, int n_riders,
-                                                         float* __restrict__ rel_sums, int xcd_ranges) {
+                                                         float* __restrict__ rel_sums) {
     __shared__ float s_dp[KGW_BLK];                           // 64 floats per wavefront (bwd_src_row_pair)
     if ((int)blockIdx.x < n_riders) {
         bwd_src_rider(T, P, (int)blockIdx.x, rel_sums, s_dp);
@@ -1062,25 +1062,11 @@ __global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_src(LayerTab T, AggPtrs P, 
         bwd_src_one_row(T, P, u);
         if (u + 1 < n_src_rows) bwd_src_one_row(T, P, u + 1);
     }
-    if (!xcd_ranges) {
-        for (int o = nw - 1 - w0; o < (T.oct_rows >> 3); o += nw)
-            if (P.oct_flags[o]) bwd_src_octet(T, P, 8 * o);
-        return;
-    }
-    // Round 5: every XCD takes a CONTIGUOUS eighth of the octets.  Workgroups are dealt to the eight XCDs round-robin and each XCD
-    // has an L2 of its own (4 MB); the short rows are laid out by ascending node id -- genome order for the SNPs, whose edges
-    // reach the genes of their neighbourhood -- so neighbouring octets gather the same few dZ rows.  Dealt round-robin, every L2
-    // sees all 11.8 MB of dZ (most gathers go to the fabric); with a range per XCD an L2 holds the ~1/8 of the rows its SNPs
-    // point at.  An octet is uniform work (8 rows x ~2 entries), so the static partition costs no balance -- unlike the chunk
-    // lists of the dst-major kernels (chunk_perm, round 2).  The rows' values do not depend on who computes them.
-    const int n_oct = T.oct_rows >> 3;
-    const int x = (int)blockIdx.x & 7;
-    const int first = n_riders + ((x - n_riders) & 7);              // first row-work block of this XCD class
-    const int cnt = ((int)gridDim.x - first + 7) >> 3;              // row-work blocks of the class
-    if (cnt <= 0) return;
-    const int wi = (((int)blockIdx.x - first) >> 3) * 4 + (threadIdx.x >> 6), nwx = cnt * 4;
-    const int lo = (int)(((int64_t)n_oct * x) >> 3), hi = (int)(((int64_t)n_oct * (x + 1)) >> 3);
-    for (int o = lo + (nwx - 1 - wi); o < hi; o += nwx)
+    // (Round 5, measured and dropped: every XCD taking a CONTIGUOUS eighth of the octets -- neighbouring SNPs gather the dZ rows
+    //  of the same few genes, so an XCD's private L2 would hold its share instead of every L2 seeing all 11.8 MB of dZ.  Same
+    //  values, 104.0 / 104.5 us round-robin against 105.9 / 106.2 with ranges on one box: the short rows are not what waits on
+    //  the fabric.)
+    for (int o = nw - 1 - w0; o < (T.oct_rows >> 3); o += nw)
         if (P.oct_flags[o]) bwd_src_octet(T, P, 8 * o);
 }
 
@@ -1251,9 +1237,7 @@ extern "C" int kgw_gat_aggregate_bwd_src(const KgwLayerArgs* a, kgw_stream_t str
     const bool duv = a->dU && a->dV && a->part_du && a->duv_ws && a->seg_chptr;
     const int n_riders = (a->rel_sums ? T.n_rels : 0) + (duv ? 2 * KGW_DUV_SPLIT * T.n_rels : 0);
     if (!duv) P.duv_ws = nullptr;
-    static const int xcd_ranges = getenv("KGW_SRC_XCD") ? atoi(getenv("KGW_SRC_XCD")) : 1;
-    k_agg_bwd_src<<<gmain + n_riders, KGW_BLK, 0, (hipStream_t)stream_>>>(T, P, a->n_src_rows, gmain, n_riders, a->rel_sums,
-                                                                          xcd_ranges && gmain >= 64);
+    k_agg_bwd_src<<<gmain + n_riders, KGW_BLK, 0, (hipStream_t)stream_>>>(T, P, a->n_src_rows, gmain, n_riders, a->rel_sums);
     KGW_LAUNCH_CHECK();
     if (a->ev_after) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_after, (hipStream_t)stream_));
     if (duv && !(a->flags & KGW_F_DUV_PIECES)) {        // (pieces: the consumer of d u_r / d v_r adds the eight pieces itself)

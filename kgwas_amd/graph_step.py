@@ -530,22 +530,31 @@ class GraphTrainStep:
         return [int(v) for v in self.stats[:-1]]
 
 
+# seeds per captured evaluation batch.  A seed's prediction does not depend on its batch mates (tests/test_gpu_fullsize.py), so the
+# evaluation loops need not keep the loaders' 512 (kgwas/kgwas.py:104-113): every 512-seed batch of the benchmark graph pulls in all
+# 20 032 genes and recomputes the whole gene side of layer 1 (the 26 GFLOP first Linear, ~0.7 M gene-to-gene edges) -- 1 061 times
+# over for the whole-genome inference pass.  ONE batch of all 542 758 labelled SNPs aggregates ~21 M edges instead of 1.1 G.
+EVAL_BATCH = int(os.environ.get('KGW_EVAL_BATCH', str(1 << 20)))
+
+
 class GraphEvalStep:
     """Forward-only twin of GraphTrainStep for the evaluation / inference loops (kgwas/utils.py:20-39 driven by the
     val / test / infer loaders of kgwas/kgwas.py:104-113): one captured forward graph per buffer parity, the next
-    batch sampled by its own graph on a side stream.  The loaders keep partial last batches (drop_last=False): the
-    id list is padded to a whole number of batches with ids from its head (distinct from the tail's) and the padded
-    outputs are dropped."""
+    batch sampled by its own graph on a side stream.  The nodes are evaluated in batches of ``eval_batch`` seeds (default
+    EVAL_BATCH, never below the loader's own batch size): up to that many nodes are ONE batch; beyond, the id list is padded to a
+    whole number of batches with ids from its head (distinct from the tail's) and the padded outputs are dropped."""
 
-    def __init__(self, model, graph, num_layers: int, input_nodes, batch_size: int, device, margin: float = 1.03):
+    def __init__(self, model, graph, num_layers: int, input_nodes, batch_size: int, device, margin: float = 1.03,
+                 eval_batch: int = None):
         self.model = model
-        self.batch_size = bs = int(batch_size)
         dev = torch.device(device)
         self.input_type, ids = input_nodes
         ids = np.asarray(ids.cpu() if torch.is_tensor(ids) else ids, dtype=np.int64).reshape(-1)
         self.n = len(ids)
-        if self.n < 2 * bs:
-            raise ValueError('too few evaluation nodes for the captured path')
+        if self.n < 1:
+            raise ValueError('no evaluation nodes')
+        big = max(int(batch_size), int(EVAL_BATCH if eval_batch is None else eval_batch))
+        self.batch_size = bs = self.n if self.n <= big else big
         self.n_batches = (self.n + bs - 1) // bs
         pad = self.n_batches * bs - self.n
         ids_p = np.concatenate([ids, ids[:pad]])
@@ -555,7 +564,9 @@ class GraphEvalStep:
         self.dg = probe.dg.with_static_caps(self.caps)
         self.seed_type = probe.seed_type
         self.ids = probe.ids
-        self.bufs = [BatchBuffers(self.dg, SIDE_SAMPLER_GRID), BatchBuffers(self.dg, SIDE_SAMPLER_GRID)]
+        # (a single batch has nothing to run beside: its sampler takes the whole GPU, and one buffer is enough)
+        grid = SIDE_SAMPLER_GRID if self.n_batches > 1 else 0
+        self.bufs = [BatchBuffers(self.dg, grid) for _ in range(2 if self.n_batches > 1 else 1)]
         self.meta = self.dg.static_meta()
         self.seeds = torch.zeros(bs, dtype=torch.int64, device=dev)
         self.out = torch.zeros(self.n_batches * bs, device=dev)
@@ -577,19 +588,20 @@ class GraphEvalStep:
         sample_into(self.dg, self.bufs[which], self.seeds, self.seed_type, record=False)
 
     def _capture(self):
+        nb = len(self.bufs)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for k in range(3):
-                self._sample_now(k % 2, 0)
-                self._forward(k % 2)
+            for k in range(3 if nb > 1 else 2):
+                self._sample_now(k % nb, 0)
+                self._forward(k % nb)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         for b in self.bufs:
             err = int(b.read_meta().error)
             if err:
                 raise _lib.KgwasHipError(f'static layout does not fit the sampler buffers (error mask {err})')
-        for cur in (0, 1):
+        for cur in range(nb):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self.pred[cur] = self._forward(cur)
@@ -607,7 +619,7 @@ class GraphEvalStep:
         meta_err = [bf.meta.view(torch.int32)[_lib.KgwBatchMeta.error.offset // 4:][:1] for bf in self.bufs]
         pending = [False, False]
         for i in range(self.n_batches):
-            cur = i % 2
+            cur = i % len(self.bufs)
             if i + 1 < self.n_batches:
                 self._side.wait_stream(main)
                 with torch.cuda.stream(self._side):

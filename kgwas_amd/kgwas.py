@@ -25,7 +25,7 @@ from . import dist as kdist
 from . import ops
 from .model import HeteroGNN
 from .sampler import NeighborLoader
-from .utils import (compute_metrics, evaluate_minibatch_clean, get_network_weight, load_pretrained, print_sys,
+from .utils import (compute_metrics, evaluate_minibatch_clean, get_network_weight, load_pretrained, print_sys, write_tsv,
                     save_model)
 
 
@@ -264,9 +264,9 @@ class KGWAS:
             return
         try:
             os.makedirs(out_dir, exist_ok=True)
-            lr_uni_to_save.to_csv(os.path.join(out_dir, save_name + '_pred.csv'), index=False, sep='\t')
+            write_tsv(lr_uni_to_save, os.path.join(out_dir, save_name + '_pred.csv'))      # (= to_csv(index=False, sep='\t'), same bytes)
             print('KGWAS prediction and p-values saved to ' + os.path.join(out_dir, save_name + '_pred.csv'))
             if save_best_model:
-                lr_uni_to_save.to_csv(os.path.join(self.data_path, 'model', save_name, 'pred.csv'), index=False, sep='\t')
+                write_tsv(lr_uni_to_save, os.path.join(self.data_path, 'model', save_name, 'pred.csv'))
         except OSError as e:   # read-only data_path: keep results in memory
             print_sys(f'could not write predictions: {e}')

@@ -77,11 +77,15 @@ def test_static_capacity_overflow_is_reported(small_kg):
     assert overflow or caps_equal
 
 
+@pytest.mark.parametrize('eval_batch', [64, 1 << 20])
 @pytest.mark.parametrize('drop_last', [False, True])
-def test_graph_eval_equals_eager_eval(small_kg, drop_last, monkeypatch):
+def test_graph_eval_equals_eager_eval(small_kg, drop_last, eval_batch, monkeypatch):
     """evaluate_minibatch_clean through the captured forward (GraphEvalStep) == the eager per-batch loop, including
-    the partial last batch of a drop_last=False loader."""
+    the partial last batch of a drop_last=False loader -- in batches of the loader's own size (padded last batch, two buffers,
+    side sampler) and as ONE batch of all nodes (the default: a seed's prediction does not depend on its batch mates)."""
+    from kgwas_amd import graph_step
     from kgwas_amd.kgwas import KGWAS
+    monkeypatch.setattr(graph_step, 'EVAL_BATCH', eval_batch)
     from kgwas_amd.sampler import NeighborLoader
     from kgwas_amd.utils import evaluate_minibatch_clean
     run = KGWAS(small_kg, device='cuda:0', seed=4)

@@ -278,9 +278,11 @@ def test_captured_training_steps_at_full_size_track_the_oracle(full_c1):
     import time
     from kgwas_amd.graph_step import GraphTrainStep
     from oracle.sampler_np import FullNeighborSamplerNP
-    run = full_c1
+    from kgwas_amd.kgwas import KGWAS
+    run = KGWAS(full_c1.data, device='cuda:0', seed=5)     # (a model of its own: the fixture's has been re-biased by the tests above)
+    run.initialize_model()
     model = run.model
-    bs, n_steps, lr, wd = 512, 8, 1e-3, 5e-4                 # (lr 10 x the reference's default, as the small trajectory test: a visible update)
+    bs, n_steps, lr, wd = 512, 8, 1e-4, 5e-4                 # the reference's training configuration (kgwas/kgwas.py:85-87,116)
     ids = np.asarray(run.data.train_input_nodes[1])[:(n_steps + 1) * bs]
     gs = GraphTrainStep(run, ('SNP', ids), bs, lr=lr, weight_decay=wd)
     assert gs.fused_adam and gs.twin, 'the shipped single-GPU configuration: fused optimiser launch, side sampler'
@@ -336,7 +338,7 @@ def test_captured_training_steps_at_full_size_track_the_oracle(full_c1):
     moved = float((pred_o - pred_0).abs().max())
     err = float((pred.cpu().double() - pred_o).abs().max())
     print(f'[captured trajectory] next batch: the steps moved the predictions by up to {moved:.3e}, this path differs from the oracle by up to {err:.3e}')
-    assert moved > 1e-2, 'the steps must have changed the predictions for this comparison to mean anything'
+    assert moved > 1e-3, 'the steps must have changed the predictions for this comparison to mean anything'
     assert_close(pred, pred_o, 1e-3, 1e-4 + 0.05 * moved, 'prediction after the captured steps')
     assert torch.equal(torch.topk(pred.cpu().double(), 8).indices, torch.topk(pred_o, 8).indices)
 
