@@ -466,11 +466,22 @@ def main():
     else:
         stats_e[0] = stats_e[1] = 0
     sync()
+    # (N > 1: every collective of the timed steps also timed by HIP events on its stream -- two event records per call, no sync)
+    ctimer = kdist.CollectiveTimer() if (world > 1 and emulated is None) or os.environ.get('KGW_FORCE_MULTIRANK_PATH') == '1' else None
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t_start = time.perf_counter()
-    for i in range(args.steps):
-        do_step(args.warmup + i)
+    ev0.record()
+    if ctimer is not None:
+        with ctimer:
+            for i in range(args.steps):
+                do_step(args.warmup + i)
+    else:
+        for i in range(args.steps):
+            do_step(args.warmup + i)
+    ev1.record()
     sync()
     elapsed = time.perf_counter() - t_start
+    rank_ms = ev0.elapsed_time(ev1) / args.steps          # this rank's own device time per step (no barrier inside)
     coll_src = collective_counters()          # (before the untimed passes below -- edge counting, overlap check -- add their own)
     # products handed to the framework's GEMM library so far (set-up, warm-up, capture, timed steps): must be 0 on the headline
     lib_calls, lib_sites = ops.LIBRARY_GEMM.calls, {f'{k[0]} {k[1]}': v for k, v in ops.LIBRARY_GEMM.by_site.items()}
@@ -577,12 +588,37 @@ def main():
                         'process group); ms_per_step is the rank\'s compute time, value the rank\'s own throughput; '
                         'tools/scale_model.py adds the xGMI time of the collectives' % (rank, world))
     stats = torch.tensor([elapsed, float(edges_kernel), float(edges_ref), float(seeds)], dtype=torch.float64, device=dev)
+    if ctimer is not None:
+        # measured device time of each collective, next to what the alpha-beta model of tools/scale_model.py gives for the same
+        # message on P GPUs over xGMI (direct / ring): ONE driver SCALE record calibrates its two constants
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        from scale_model import A_HOP, A_PHASE, BETA, t_collective
+        meas = ctimer.summary(args.steps)
+        for k, v in meas.items():
+            nbytes = int(k[k.index('(') + 1:k.index(' B)')])
+            v['model_ms_per_call_direct'] = t_collective(k, nbytes, world, 'direct') * 1e3
+            v['model_ms_per_call_ring'] = t_collective(k, nbytes, world, 'ring') * 1e3
+        comm['collectives_measured'] = meas
+        comm['collectives_measured_note'] = ('HIP events on the calling stream around every torch.distributed collective of the timed steps '
+                                             '(this rank); model_*: tools/scale_model.py, alpha %.0f us per phase / %.0f us per ring hop, beta %.0f GB/s '
+                                             'per link' % (A_PHASE * 1e6, A_HOP * 1e6, BETA / 1e9))
+    comm['per_rank_ms'] = {'this_rank': rank_ms}
     if world > 1 and emulated is None:
         tmax = stats[:1].clone()
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         tot = stats[1:].clone()
         torch.distributed.all_reduce(tot, op=torch.distributed.ReduceOp.SUM)
         elapsed = float(tmax[0]); edges_kernel, edges_ref, seeds = (float(x) for x in tot)
+        # every rank's own event-timed ms per step, and the rank count as the collective backend itself sees it (a sum of ones)
+        mine_ms = torch.tensor([rank_ms], dtype=torch.float64, device=dev)
+        all_ms = [torch.zeros_like(mine_ms) for _ in range(world)]
+        torch.distributed.all_gather(all_ms, mine_ms)
+        all_ms = [float(t[0]) for t in all_ms]
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        torch.distributed.all_reduce(ones, op=torch.distributed.ReduceOp.SUM)
+        comm['per_rank_ms'] = {'min': min(all_ms), 'max': max(all_ms), 'by_rank': all_ms,
+                               'note': 'HIP-event time of the timed steps / steps on each rank\'s own stream; ms_per_step is the barrier-to-barrier wall clock, max over ranks'}
+        comm['ranks_seen_by_the_backend'] = int(round(float(ones[0])))
 
     if torch.distributed.is_initialized():
         if emulated is None:
@@ -699,6 +735,12 @@ def main():
         'metric': 'edges aggregated/sec (full fast-mode KG minibatch training; epoch time in config)',
         'value': edges_kernel / elapsed, 'unit': 'edges/s', 'n_gpus': 1 if emulated is not None else world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
+        'scaling_note': ('weak: every GPU trains on its own 512-seed batches of the reference\'s order against a replicated graph, one '
+                         'all-reduce of the parameter gradients per step (SURVEY 8e-i) -- the default of --gpus N and the mode that scales: '
+                         'a 784 k-SNP graph fits one MI355X many times over.  The partitioning north_star prescribes (--parallelism shard: '
+                         'SNP rows by id range, Gene / GO replicated, partial-softmax exchange) is built and tested but is predicted BELOW '
+                         '1x at this graph size (profiles/r4/r4_j_scale_model.md: 0.65 - 0.95x at 8 GPUs; strong seed-parallel 1.2 - 1.6x): '
+                         'every rank repeats the gene / GO side, which is 70 % of a batch\'s edges'),
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': ('SynthKG-fast full KG (784256 SNP / 20032 Gene / ~20.6M directed edges; features '
                                 '20/5120/128) + causal-simulation GWAS seed=1, batch 512 seeds %s, 2-layer GAT-128, '

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KGW_VERSION      122          /* 0.2.2 */
+#define KGW_VERSION      123          /* 0.2.3 */
 #define KGW_MAX_TYPES    8
 #define KGW_MAX_RELS     64
 #define KGW_MAX_LAYERS   4
@@ -594,6 +594,20 @@ typedef struct KgwFoldArgs {
 } KgwFoldArgs;
 int kgw_fold_fwd(const KgwFoldArgs* args, kgw_stream_t stream);
 int kgw_fold_bwd(const KgwFoldArgs* args, kgw_stream_t stream);
+
+/* kgw_gemm3 with RIDERS: the launch carries the step's parameter-only forward work as extra blocks on the compute units the
+ * product leaves idle (the benchmark's forward product: 240 one-CU blocks on 256 CUs for ~145 us) -- what kgw_relvec_fwd_multi
+ * (n_relvec jobs: the relation vectors of every layer, summed biases, the aggregates' zero fills; kgwas/conv.py:138-151) and
+ * kgw_fold_fwd (fold, nullable: FC_output into the relations of job fold_job, kgwas/model.py:15,21; its U / V must be that
+ * job's U_full / V) compute, with the same arithmetic (bit-identical values), one wavefront per task, no launch of their own.
+ * kgw_gemm3_rider_blocks(M, K): the idle compute units such a launch has (0: none worth using -- kgw_gemm3_riders then returns
+ * KGW_E_UNSUPPORTED before launching anything and the caller runs the riders' own kernels).                                   */
+int kgw_gemm3_rider_blocks(int64_t M, int64_t K);
+
+int kgw_gemm3_riders(const float* A, int64_t lda, int64_t M, int64_t K, const void* packed, float* workspace, int64_t workspace_floats,
+                     const float* bias, int32_t relu, float* out, int64_t ldo, int32_t transpose_out, const int32_t* row_map,
+                     float* out_rows, int64_t ld_rows, int64_t out_rows_n, const int32_t* out_rows_real, int32_t n_relvec,
+                     const KgwRelvecJob* relvec, const KgwFoldArgs* fold, int32_t fold_job, kgw_stream_t stream);
 
 /* LD-score weighted MSE over the seed rows (kgwas/kgwas.py:139-145): loss = mean_i w[n_id[i]] * (pred[i] - y[n_id[i]])^2,
  * float32 residual / square, float64 weight and mean; _bwd: dpred[i] = grad_loss * d loss / d pred[i].

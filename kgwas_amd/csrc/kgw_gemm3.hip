@@ -30,6 +30,7 @@
 // Partial products go to a workspace [split][M][128]; kgw_gemm3 ends with a fixed-order reduction (+ bias, ReLU, or a
 // transposed store for the weight gradient).  Deterministic: no atomics, fixed K ranges.
 #include "kgw_common.h"
+#include "kgw_riders.h"
 #include <stdlib.h>
 
 typedef kgw_bf8 g3_bf8;
@@ -103,8 +104,11 @@ struct G3Args {
 // Both LDS tiles are double buffered in SEPARATE arrays (the compiler then knows that the stores of chunk c + 1 do not alias
 // the operand reads of chunk c).  MT = 32-row tiles per wavefront (1: 128-row blocks, two per CU; 2 was measured too -- 256-row
 // blocks, one per CU, each B operand feeding two MFMAs: 157-180 us against 153 -- and is not instantiated).
+struct G3KArgs { G3Args a; G3Riders R; };     // ONE kernel argument: the riders' tables are read where they lie, in the kernarg segment
+
 template <int MT, int NW = 4>
-__global__ void __launch_bounds__(64 * NW, (8 / NW) / MT) k_g3_gemm(G3Args a) {
+__global__ void __launch_bounds__(64 * NW, (8 / NW) / MT) k_g3_gemm(G3KArgs ka_) {
+    const G3Args& a = ka_.a;
     constexpr int NT = 64 * NW, NB = G3_CH_U4 / NT;   // threads, B staging registers (uint4) per thread
     constexpr int NQ = 4 * MT;                 // A load instructions per chunk (8 rows x 128 B each)
     constexpr int AT = 256 * MT;               // 16-byte slots per wavefront-private A tile
@@ -114,6 +118,16 @@ __global__ void __launch_bounds__(64 * NW, (8 / NW) / MT) k_g3_gemm(G3Args a) {
     // block -> work item: workgroups go round-robin to the 8 XCDs (blockIdx % 8), and XCD x takes the contiguous range
     // [x per_xcd, (x + 1) per_xcd) of the items in (K range, row tile) order -- one or two K ranges per XCD, so the packed B
     // of a range (1.3 MB of the 15 MB in the weight-gradient product) is fetched into that XCD's L2 once and hit by the rest
+    // rider blocks (kgw_riders.h): the launch's blocks beyond the product's own take the step's parameter-only forward work on
+    // the compute units the product leaves idle (240 blocks of one CU each on 256 CUs at the benchmark shape)
+    if ((int)blockIdx.x >= a.per_xcd * 8) {
+        // (the rider functions are real calls -- their registers are their own, the product's loop keeps its allocation -- and
+        //  take their tables by ADDRESS in the kernarg segment: a by-value struct whose address escapes would be copied to scratch)
+        const char* kseg = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+        const G3Riders* R = (const G3Riders*)(kseg + __builtin_offsetof(G3KArgs, R));
+        if (ka_.R.n_blocks) g3_param_riders<NW>(*R, (int)blockIdx.x - a.per_xcd * 8);
+        return;
+    }
     const int item = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= a.per_xcd || item >= a.n_tiles * a.nsplit) return;
     const int split = item / a.n_tiles, tile = item - split * a.n_tiles;
@@ -369,18 +383,40 @@ extern "C" int kgw_gemm3_partial(const float* A, int64_t lda, int64_t M, int64_t
     const int tiles = (int)((M + rt - 1) / rt);
     const int per_xcd = (tiles * ns + 7) / 8;
     G3Args a{A, (long)lda, (int)M, (int)K, (const uint4*)packed, workspace, ns, tiles, per_xcd, g3_flip()};
-    if (g3_nw() == 8) k_g3_gemm<1, 8><<<per_xcd * 8, 512, 0, (hipStream_t)stream_>>>(a);
-    else k_g3_gemm<1, 4><<<per_xcd * 8, 256, 0, (hipStream_t)stream_>>>(a);
+    const G3Riders none{};
+    if (g3_nw() == 8) k_g3_gemm<1, 8><<<per_xcd * 8, 512, 0, (hipStream_t)stream_>>>(G3KArgs{a, none});
+    else k_g3_gemm<1, 4><<<per_xcd * 8, 256, 0, (hipStream_t)stream_>>>(G3KArgs{a, none});
     KGW_LAUNCH_CHECK();
     *src = KgwGradSrc{};
     src->ws = workspace; src->kind = KGW_GRAD_G3T; src->nblk = ns; src->M = (int32_t)M; src->N = 128;
     return KGW_OK;
 }
 
-extern "C" int kgw_gemm3(const float* A, int64_t lda, int64_t M, int64_t K, const void* packed, float* workspace,
-                         int64_t workspace_floats, const float* bias, int32_t relu, float* out, int64_t ldo, int32_t transpose_out,
-                         const int32_t* row_map, float* out_rows, int64_t ld_rows, int64_t out_rows_n, const int32_t* out_rows_real,
-                         kgw_stream_t stream_) {
+// compute units the product of an [M, K] x [K, 128] launch leaves idle (one 512-thread block per CU): where rider blocks run for
+// free.  0: none worth using (the 256-thread variant, a grid that fills the chip, fewer than 8 idle CUs).
+static int g3_free_cus(int64_t M, int64_t K) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n_cu = p.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    if (g3_nw() != 8 || M <= 0 || K <= 0) return 0;
+    const int ns = g3_splits(M, K);
+    const int tiles = (int)((M + 255) / 256);
+    const int grid = ((tiles * ns + 7) / 8) * 8;
+    int idle = n_cu - grid;
+    if (idle > 16) idle = 16;
+    return idle >= 8 ? idle : 0;
+}
+
+extern "C" int kgw_gemm3_rider_blocks(int64_t M, int64_t K) { return g3_free_cus(M, K); }
+
+static int gemm3_launch(const float* A, int64_t lda, int64_t M, int64_t K, const void* packed, float* workspace,
+                        int64_t workspace_floats, const float* bias, int32_t relu, float* out, int64_t ldo, int32_t transpose_out,
+                        const int32_t* row_map, float* out_rows, int64_t ld_rows, int64_t out_rows_n, const int32_t* out_rows_real,
+                        const G3Riders& R, kgw_stream_t stream_) {
     if (!A || !packed || !workspace || !out) return KGW_E_NULL;
     if (out_rows_real && (!row_map || out_rows_n < 0 || out_rows_n > M)) return KGW_E_RANGE;   // (the padding is at most M rows)
     if (M <= 0 || K <= 0 || M > (1 << 30) || K > (1 << 30)) return KGW_E_RANGE;
@@ -395,12 +431,35 @@ extern "C" int kgw_gemm3(const float* A, int64_t lda, int64_t M, int64_t K, cons
     hipStream_t st = (hipStream_t)stream_;
     const int per_xcd = (tiles * ns + 7) / 8;
     G3Args a{A, (long)lda, (int)M, (int)K, (const uint4*)packed, workspace, ns, tiles, per_xcd, g3_flip()};
-    if (g3_nw() == 8) k_g3_gemm<1, 8><<<per_xcd * 8, 512, 0, st>>>(a);
-    else k_g3_gemm<1, 4><<<per_xcd * 8, 256, 0, st>>>(a);
+    if (g3_nw() == 8) k_g3_gemm<1, 8><<<per_xcd * 8 + R.n_blocks, 512, 0, st>>>(G3KArgs{a, R});
+    else k_g3_gemm<1, 4><<<per_xcd * 8 + R.n_blocks, 256, 0, st>>>(G3KArgs{a, R});
     KGW_LAUNCH_CHECK();
     if (transpose_out) k_g3_reduce_t<<<dim3((unsigned)((M + 31) / 32), 4), 256, 0, st>>>(workspace, ns, (long)M, out, (long)ldo);
     else k_g3_reduce<<<(int)((M * 32 + 255) / 256), 256, 0, st>>>(workspace, ns, (long)M, bias, relu, out, (long)ldo, row_map, out_rows, (long)ld_rows,
                                                                   (long)out_rows_n, out_rows_real);
     KGW_LAUNCH_CHECK();
     return KGW_OK;
+}
+
+extern "C" int kgw_gemm3(const float* A, int64_t lda, int64_t M, int64_t K, const void* packed, float* workspace,
+                         int64_t workspace_floats, const float* bias, int32_t relu, float* out, int64_t ldo, int32_t transpose_out,
+                         const int32_t* row_map, float* out_rows, int64_t ld_rows, int64_t out_rows_n, const int32_t* out_rows_real,
+                         kgw_stream_t stream_) {
+    const G3Riders none{};
+    return gemm3_launch(A, lda, M, K, packed, workspace, workspace_floats, bias, relu, out, ldo, transpose_out, row_map, out_rows, ld_rows,
+                        out_rows_n, out_rows_real, none, stream_);
+}
+
+extern "C" int kgw_gemm3_riders(const float* A, int64_t lda, int64_t M, int64_t K, const void* packed, float* workspace,
+                                int64_t workspace_floats, const float* bias, int32_t relu, float* out, int64_t ldo, int32_t transpose_out,
+                                const int32_t* row_map, float* out_rows, int64_t ld_rows, int64_t out_rows_n, const int32_t* out_rows_real,
+                                int32_t n_relvec, const KgwRelvecJob* relvec, const KgwFoldArgs* fold, int32_t fold_job,
+                                kgw_stream_t stream_) {
+    const int nb = g3_free_cus(M, K);
+    if (nb <= 0) return KGW_E_UNSUPPORTED;                  // (no idle compute unit: the caller launches the riders' own kernels)
+    G3Riders R;
+    int rc = g3_riders_build(n_relvec, relvec, fold, fold_job, nb, &R);
+    if (rc) return rc;
+    return gemm3_launch(A, lda, M, K, packed, workspace, workspace_floats, bias, relu, out, ldo, transpose_out, row_map, out_rows, ld_rows,
+                        out_rows_n, out_rows_real, R, stream_);
 }

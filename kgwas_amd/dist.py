@@ -49,6 +49,56 @@ def count_collective(name: str, nbytes: int):
     c[1] += int(nbytes)
 
 
+class CollectiveTimer:
+    """``with CollectiveTimer() as ct:`` -- device time of every torch.distributed collective issued inside, by HIP events on the
+    stream the call is made on (a synchronous collective makes that stream wait for the backend's own: the second event lands
+    after the data has).  bench.py wraps its timed steps in one so that an N > 1 line carries MEASURED milliseconds per collective
+    next to the bytes; nothing else uses it.  Keys: '<op>(<bytes of the tensor handed in> B)'."""
+    OPS = ('all_reduce', 'all_gather', 'all_gather_into_tensor', 'reduce_scatter_tensor', 'broadcast')
+
+    def __init__(self):
+        self.events, self._orig = [], {}
+
+    def __enter__(self):
+        for op in self.OPS:
+            fn = getattr(dist, op, None)
+            if fn is None:
+                continue
+            self._orig[op] = fn
+            setattr(dist, op, self._wrap(op, fn))
+        return self
+
+    def _wrap(self, op, fn):
+        def timed(*a, **k):
+            t = next((x for x in a if torch.is_tensor(x)), None)
+            if t is None and a and isinstance(a[0], (list, tuple)) and a[0] and torch.is_tensor(a[0][0]):
+                t = a[1] if len(a) > 1 and torch.is_tensor(a[1]) else a[0][0]
+            if t is None or not t.is_cuda or k.get('async_op'):
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            self.events.append((f'{op}({t.numel() * t.element_size()} B)', e0, e1))
+            return r
+        return timed
+
+    def __exit__(self, *exc):
+        for op, fn in self._orig.items():
+            setattr(dist, op, fn)
+        return False
+
+    def summary(self, per: int = 1):
+        """{key: {'calls_per_step', 'ms_per_call', 'ms_per_step'}} with ``per`` = the number of steps the block ran."""
+        torch.cuda.synchronize()
+        out = {}
+        for key, e0, e1 in self.events:
+            d = out.setdefault(key, [0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+        return {k: {'calls_per_step': n / per, 'ms_per_call': ms / n, 'ms_per_step': ms / per} for k, (n, ms) in out.items()}
+
+
 def allreduce_flat(flat: torch.Tensor, world: int, what: str = 'parameter gradients'):
     """Average ``flat`` over the ranks in place: ONE collective (RCCL's AVG where the backend has it)."""
     if world <= 1 and not (os.environ.get('KGW_FORCE_MULTIRANK_PATH') == '1' and dist.is_initialized()):

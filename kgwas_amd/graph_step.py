@@ -203,6 +203,8 @@ class GraphTrainStep:
             if sink is not None:
                 self.deferred_gradients = len(sink.records) + 2 * len(sink.products)   # (gradients whose last sums the optimiser launch takes)
                 self.opt.step_fused(sink, buf.meta.data_ptr(), self.run.gnn_num_layers, self.dg.n_hops, self.stats)
+                # (launches of the step that carried its parameter-only forward work as rider blocks: the gene layer's kgw_gemm3)
+                self.riders_taken = getattr(self.model, 'last_riders_taken', 0)
                 if self.overlap:
                     main.wait_stream(self._side)                       # join
                 elif not self.twin:
@@ -520,6 +522,26 @@ class GraphTrainStep:
 
     def grads_ready(self):
         return [p.grad for p in self.model.parameters() if p.grad is not None]
+
+    def poll(self):
+        """Non-blocking form of ``check`` for the middle of an epoch: looks at the sticky error bit as it was when the PREVIOUS
+        poll asked for it (an asynchronous copy into pinned memory) and asks again -- no stream sync, so the queue of replayed
+        steps never drains (KGWAS.train polled with a blocking check every 128 steps: ~3 % of an epoch).  An overflow is reported
+        one poll late; ``check`` at the end of the epoch is exact."""
+        pend = getattr(self, '_poll', None)
+        if pend is not None and pend[1].query():
+            err = int(pend[0][0])
+            self._poll = pend = None
+            if err:
+                raise _lib.KgwasHipError(f'a batch exceeded the static capacities (error mask {err}); raise `margin`')
+        if pend is None:
+            host = getattr(self, '_poll_host', None)
+            if host is None:
+                host = self._poll_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+            host.copy_(self.stats[-1:], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._poll = (host, ev)
 
     def check(self):
         """Synchronise and verify that no batch overflowed the static capacities."""

@@ -195,8 +195,8 @@ class KGWAS:
             for item in steps:
                 if graph_step is not None:
                     step, loss = item, graph_step.step(item)
-                    if step % 128 == 127:                    # a batch that outgrew the static layout: stop at once, not at
-                        graph_step.check()                   # the end of the epoch (one stream sync per 128 steps)
+                    if step % 128 == 127:                    # a batch that outgrew the static layout: stop soon, not at the end
+                        graph_step.poll()                    # of the epoch (no stream sync: the answer is read one poll later)
                 else:
                     step, batch = item
                     loss = self.train_step(batch, optimizer, ld_w, world)

@@ -666,11 +666,20 @@ class HeteroGNN(nn.Module):
         if self.lin.out_features != 1:
             raise NotImplementedError('the fused read-out + loss is for out_channels == 1 (kgwas/kgwas.py:52)')
         hbuf, blocks = self._layer_input(batch, 1)
-        h = self._embed_all(batch, x_dict, blocks, fold=self.fold_fc)
+        gat = self.backbone == 'GAT' and self.aggr in ('sum', 'mean')
+        prep = None
+        # what depends on the parameters only -- the relation vectors of all layers, the FC_output fold -- is prepared FIRST and
+        # handed to the first gene Linear's kgw_gemm3 launch as rider blocks (ops.ParamRiders); whatever no launch took is
+        # launched the ordinary way when the scope closes, before the layers read it
+        riders = ops.ParamRiders() if (ops._G3_RIDERS and self.backbone == 'GAT' and self.num_layers > 1 and _RELVEC_ALL) else None
+        with ops.param_riders_scope(riders):
+            if riders is not None:
+                prep = self._all_layer_params(batch, self.fold_fc)
+            h = self._embed_all(batch, x_dict, blocks, fold=self.fold_fc)
+        self.last_riders_taken = riders.taken if riders is not None else 0
         if mlp_out is not None:
             mlp_out.extend(h.values())
-        gat = self.backbone == 'GAT' and self.aggr in ('sum', 'mean')
-        h, _ = self._fused_layers(batch, h, hbuf=hbuf, last_premasked=gat, folded=self.fold_fc)
+        h, _ = self._fused_layers(batch, h, hbuf=hbuf, last_premasked=gat, folded=self.fold_fc, prep=prep)
         return ops.readout_weighted_mse(h['SNP'], self.lin.weight, self.lin.bias, n_id, y_all, w_all, batch_size,
                                         relu=not self.no_relu, h_is_relu=gat, unit_grad=unit_grad)
 

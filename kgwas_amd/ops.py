@@ -748,6 +748,57 @@ class packed_scope:
         return False
 
 
+class ParamRiders:
+    """The parameter-only forward launches of a training step -- the relation vectors of all layers (kgw_relvec_fwd_multi) and the
+    FC_output fold (kgw_fold_fwd) -- handed to the first gene Linear's kgw_gemm3 launch as RIDER blocks (kgw_gemm3_riders: they run on
+    the compute units that product leaves idle, ~20 us off the step's critical path and two launches fewer).  While a queue is
+    active (``param_riders_scope``: HeteroGNN.forward_loss computes the layers' parameters BEFORE the feature MLPs), the two
+    autograd nodes allocate their outputs, record their job structs here and do not launch; ``gemm3`` takes what is pending with
+    the layer's forward product; ``flush`` -- called before anything reads the outputs -- launches whatever no product took (a
+    model whose gene layer does not take the resident route, a product without idle compute units) the ordinary way."""
+
+    def __init__(self):
+        self.relvec = None          # (n, jobs array, keep-alive)
+        self.fold = None            # (KgwFoldArgs, fold_job, keep-alive)
+        self.taken = 0              # launches that rode along (tests / bench)
+
+    def pending(self):
+        return self.relvec is not None or self.fold is not None
+
+    def take(self):
+        r, f = self.relvec, self.fold
+        self.relvec = self.fold = None
+        return r, f
+
+    def flush(self):
+        r, f = self.take()
+        if r is not None:
+            _lib.check(_lib.lib().kgw_relvec_fwd_multi(r[0], r[1], _lib.stream_ptr()), 'kgw_relvec_fwd_multi')
+        if f is not None:
+            _lib.check(_lib.lib().kgw_fold_fwd(C.byref(f[0]), _lib.stream_ptr()), 'kgw_fold_fwd')
+
+
+PARAM_RIDERS = None        # the ParamRiders of the forward pass being issued, or None (every launch where it is)
+_G3_RIDERS = os.environ.get('KGW_G3_RIDERS', '1') != '0'          # 0: relvec / fold as launches of their own (A/B, fallback tests)
+
+
+class param_riders_scope:
+    def __init__(self, q):
+        self.q = q
+
+    def __enter__(self):
+        global PARAM_RIDERS
+        self.prev, PARAM_RIDERS = PARAM_RIDERS, self.q
+        return self.q
+
+    def __exit__(self, *exc):
+        global PARAM_RIDERS
+        q, PARAM_RIDERS = PARAM_RIDERS, self.prev
+        if q is not None and exc[0] is None:
+            q.flush()
+        return False
+
+
 def gemm3_pack(S: torch.Tensor, K: int, s_is_kn: bool, k_valid: int = None, out: torch.Tensor = None) -> torch.Tensor:
     """B [K, 128] of a kgw_gemm3 product, split into its three bf16 pieces in the kernel's operand image.  ``s_is_kn``: S is
     B itself ([k_valid, 128]); else S = B^T ([128, k_valid], an nn.Linear weight).  ``k_valid`` < K (default K): S stops there,
@@ -809,10 +860,19 @@ def gemm3(A: torch.Tensor, packed: torch.Tensor, bias=None, relu: bool = False, 
                    'kgw_gemm3_partial')
         sink.add(out, src, ws)
         return out
-    _lib.check(L.kgw_gemm3(_p(A), lda, M, K, _p(packed), _p(ws), nws, _p(bias), 1 if relu else 0, _p(out), out.stride(0),
-                           1 if transpose_out else 0, _p(row_map), _p(out_rows), out_rows.stride(0) if out_rows is not None else 0,
-                           out_rows.shape[0] if (out_rows is not None and out_rows_real is not None) else 0,
-                           _p(out_rows_real) if out_rows is not None else None, _lib.stream_ptr()), 'kgw_gemm3')
+    args = (_p(A), lda, M, K, _p(packed), _p(ws), nws, _p(bias), 1 if relu else 0, _p(out), out.stride(0),
+            1 if transpose_out else 0, _p(row_map), _p(out_rows), out_rows.stride(0) if out_rows is not None else 0,
+            out_rows.shape[0] if (out_rows is not None and out_rows_real is not None) else 0,
+            _p(out_rows_real) if out_rows is not None else None)
+    q = PARAM_RIDERS
+    if q is not None and q.pending() and not transpose_out and int(L.kgw_gemm3_rider_blocks(M, K)) > 0:
+        r, f = q.take()                     # (the step's parameter-only forward work rides on this launch's idle compute units)
+        rc = L.kgw_gemm3_riders(*args, r[0] if r is not None else 0, r[1] if r is not None else None,
+                                C.byref(f[0]) if f is not None else None, f[1] if f is not None else 0, _lib.stream_ptr())
+        _lib.check(rc, 'kgw_gemm3_riders')
+        q.taken += 1
+        return out
+    _lib.check(L.kgw_gemm3(*args, _lib.stream_ptr()), 'kgw_gemm3')
     return out
 
 
@@ -1616,7 +1676,11 @@ class _RelVectorsMulti(torch.autograd.Function):
             j.zero_buf, j.zero_floats = (zero.data_ptr(), zero.numel()) if zero is not None else (None, 0)
             outs += [U, V, bsum, w_src_t.detach()]       # (same storage; not a tracked view: no as_strided replay in the backward)
         ctx.mark_non_differentiable(*outs[2::4])         # (the summed biases: layer_transform produces d bias itself)
-        _lib.check(_lib.lib().kgw_relvec_fwd_multi(n, jobs, _lib.stream_ptr()), 'kgw_relvec_fwd_multi')
+        q = PARAM_RIDERS
+        if q is not None and q.relvec is None:           # (rides on the gene layer's kgw_gemm3 launch: ParamRiders)
+            q.relvec = (n, jobs, (keep, outs, params, zeros))
+        else:
+            _lib.check(_lib.lib().kgw_relvec_fwd_multi(n, jobs, _lib.stream_ptr()), 'kgw_relvec_fwd_multi')
         ctx.save_for_backward(*params)
         ctx.packs = packs
         ctx.set_materialize_grads(False)
@@ -1939,7 +2003,19 @@ class _FoldFC(torch.autograd.Function):
         for m in range(n_mlp):
             a.fc_weight[m], a.fc_bias[m] = _p(fc[2 * m]), _p(fc[2 * m + 1])
         a.Up, a.Vp, a.kappa, a.Wp, a.gamma = _p(Up), _p(Vp), _p(kappa), _p(Wp), _p(gamma)
-        _lib.check(_lib.lib().kgw_fold_fwd(C.byref(a), _lib.stream_ptr()), 'kgw_fold_fwd')
+        q = PARAM_RIDERS
+        job = None
+        if q is not None and q.fold is None and q.relvec is not None:
+            # the fold rides with the relation vectors it reads: its U / V must BE the U_full / V of one of the pending jobs
+            n_rv, jobs = q.relvec[0], q.relvec[1]
+            job = next((k for k in range(n_rv) if jobs[k].U_full == U.data_ptr() and jobs[k].V == V.data_ptr() and
+                        jobs[k].n_rels_total == NR), None)
+        if job is not None:
+            q.fold = (a, job, (w_src_t, U, V, fc, Up, Vp, kappa, Wp, gamma, tab))
+        else:
+            if q is not None:
+                q.flush()                                # (its inputs are pending: launch them first, the ordinary way)
+            _lib.check(_lib.lib().kgw_fold_fwd(C.byref(a), _lib.stream_ptr()), 'kgw_fold_fwd')
         ctx.save_for_backward(w_src_t, U, V, *fc)
         ctx.tab, ctx.n_mlp = tab, n_mlp
         ctx.set_materialize_grads(False)

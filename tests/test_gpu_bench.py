@@ -51,6 +51,16 @@ def test_bench_starts_its_own_ranks(extra):
         assert 'SHARE' in comm['note'] and out['config']['rccl_world_size'] == 0
     assert out['value'] > 0 and out['ms_per_step'] > 0
     assert out['scaling'] == ('weak' if not extra else 'strong')
+    # a first real N > 1 run explains itself -- measured ms of every collective next to the alpha-beta model's,
+    # every rank's own event-timed step, the rank count as the backend's own collective sees it, the scaling statement
+    meas = comm['collectives_measured']
+    assert meas and all(v['ms_per_call'] > 0 and v['calls_per_step'] > 0 and v['model_ms_per_call_direct'] > 0 and
+                        v['model_ms_per_call_ring'] > 0 for v in meas.values()), meas
+    assert any(k.startswith('all_reduce(') for k in meas)
+    pr = comm['per_rank_ms']
+    assert len(pr['by_rank']) == 2 and 0 < pr['min'] <= pr['max'] <= 1.5 * out['ms_per_step'] + 1.0
+    assert comm['ranks_seen_by_the_backend'] == 2
+    assert 'north_star' in out['scaling_note'] and 'weak' in out['scaling_note']
 
 
 @pytest.mark.parametrize('extra', [[], ['--scaling', 'strong'], ['--parallelism', 'shard']], ids=['weak-seed', 'strong-seed', 'shard'])
