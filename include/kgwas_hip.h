@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KGW_VERSION      123          /* 0.2.3 */
+#define KGW_VERSION      124          /* 0.2.4 */
 #define KGW_MAX_TYPES    8
 #define KGW_MAX_RELS     64
 #define KGW_MAX_LAYERS   4
@@ -594,6 +594,16 @@ typedef struct KgwFoldArgs {
 } KgwFoldArgs;
 int kgw_fold_fwd(const KgwFoldArgs* args, kgw_stream_t stream);
 int kgw_fold_bwd(const KgwFoldArgs* args, kgw_stream_t stream);
+
+/* The END of a captured step's backward pass as ONE launch: the deferred weight-gradient products of the MLPs (n_tn jobs + their
+ * 2 n_tn records: kgw_tn_gemm_multi_partial's arguments), kgw_fold_bwd (fold, nullable) and kgw_relvec_bwd_multi (n_relvec jobs) as
+ * the blocks of one grid -- parameter-only work that nothing but the optimiser waits for and of which no launch fills the chip.
+ * Job fold_job of relvec is the fold's layer: its dU_full / dV / dw_src_acc are NOT read -- the blocks of that layer compute the
+ * fold's d U_r, d V_r and d W share themselves and hand them on through LDS -- and fold->dU / dV / dws are not written.  Every value
+ * is computed with the expressions and in the order of the kernel it comes from (bit-identical to the three launches).
+ * KGW_E_UNSUPPORTED (nothing launched): a product outside the 64 x 64-per-wavefront tiling, an empty job.                       */
+int kgw_param_tail(int32_t n_tn, const KgwTnJob* tn_jobs, KgwGradSrc* src, const KgwFoldArgs* fold, int32_t n_relvec,
+                   const KgwRelvecJob* relvec, int32_t fold_job, kgw_stream_t stream);
 
 /* kgw_gemm3 with RIDERS: the launch carries the step's parameter-only forward work as extra blocks on the compute units the
  * product leaves idle (the benchmark's forward product: 240 one-CU blocks on 256 CUs for ~145 us) -- what kgw_relvec_fwd_multi

@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(512) k_fold_bwd(FoldTab T, FoldPtrs P, int par
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int row = (e & 3) + 8 * (e >> 2) + 4 * lk;
-            out[row * FC] = acc0[e] + acc1[e] + P.fcb[ms][32 * tm + row] * dg;
+            out[row * FC] = fmaf(P.fcb[ms][32 * tm + row], dg, acc0[e] + acc1[e]);      // (written out: k_param_tail's copy rounds the same way)
         }
         return;
     }
@@ -233,8 +233,8 @@ __global__ void __launch_bounds__(512) k_fold_bwd(FoldTab T, FoldPtrs P, int par
             const float su = kgw_wave_allsum(fmaf(a[q].x, du2.x, a[q].y * du2.y));
             const float sv = kgw_wave_allsum(fmaf(bq[q].x, dv2.x, bq[q].y * dv2.y));
             if (lane == 0) {
-                P.dU[r * FC + c0 + q] = su + dk * P.fcb[ms][c0 + q];
-                P.dV[r * FC + c0 + q] = sv + dk * P.fcb[md][c0 + q];
+                P.dU[r * FC + c0 + q] = fmaf(dk, P.fcb[ms][c0 + q], su);
+                P.dV[r * FC + c0 + q] = fmaf(dk, P.fcb[md][c0 + q], sv);
             }
         }
     }

@@ -205,6 +205,7 @@ class GraphTrainStep:
                 self.opt.step_fused(sink, buf.meta.data_ptr(), self.run.gnn_num_layers, self.dg.n_hops, self.stats)
                 # (launches of the step that carried its parameter-only forward work as rider blocks: the gene layer's kgw_gemm3)
                 self.riders_taken = getattr(self.model, 'last_riders_taken', 0)
+                self.tail_taken = sink.tail_taken          # (kgw_param_tail: the backward's parameter-only end inside the deferred products' launch)
                 if self.overlap:
                     main.wait_stream(self._side)                       # join
                 elif not self.twin:

@@ -198,6 +198,11 @@ class GradSink:
     def __init__(self):
         self.records = {}           # data_ptr of the gradient tensor -> (KgwGradSrc, numel, workspace)
         self.products = []          # weight-gradient products not launched yet, see defer_product
+        # the parameter-only END of the backward pass -- kgw_fold_bwd and kgw_relvec_bwd_multi: they feed nothing but the optimiser --
+        # not launched where autograd reaches them but by ``flush``, as blocks of the deferred products' launch (kgw_param_tail)
+        self.fold_bwd = None        # (KgwFoldArgs, keep-alive, [(address, numel, storage) of the leaf gradients it writes])
+        self.relvec_bwd = None      # (n jobs, jobs, keep-alive, [(address, numel, storage)])
+        self.tail_taken = 0         # kgw_param_tail launches issued
 
     def defer_product(self, dY: torch.Tensor, X: torch.Tensor, rows_dev=None):
         """(dW [out, in], db [out]) = (dY^T X, column sums of dY) of a Linear whose gradients feed only the optimiser -- not launched
@@ -220,26 +225,74 @@ class GradSink:
         self.products.append((dY, X, dW.data_ptr(), db.data_ptr(), dW.untyped_storage(), db.untyped_storage(), rows_dev))
         return dW, db
 
+    def _tn_jobs(self, chunk):
+        L = _lib.lib()
+        jobs = (_lib.KgwTnJob * max(len(chunk), 1))()
+        src = (_lib.KgwGradSrc * max(2 * len(chunk), 1))()
+        keep = []
+        for j, (dY, X, dW_ptr, db_ptr, _sw, _sb, rows_dev) in zip(jobs, chunk):
+            rows, M = dY.shape
+            N = X.shape[1]
+            nws = int(L.kgw_tn_gemm_workspace_floats(rows, M, N))
+            ws = torch.empty(nws, device=dY.device)
+            keep.append(ws)
+            j.A, j.lda, j.B, j.ldb, j.rows = _p(dY), dY.stride(0), _p(X), X.stride(0), rows
+            j.C, j.ldc, j.colsum_a, j.colsum_ld = dW_ptr, N, db_ptr, M
+            j.workspace, j.workspace_floats, j.rows_dev = _p(ws), nws, _p(rows_dev)
+            j.M, j.N, j.c_transposed, j.colsum_repeat = M, N, 0, 1
+        return jobs, src, keep
+
+    def launch_pending_tail(self):
+        """kgw_fold_bwd / kgw_relvec_bwd_multi left pending, as launches of their own, in that order (a consumer of their outputs is
+        about to be launched, or the merged launch does not take them)."""
+        L = _lib.lib()
+        fb, rb = self.fold_bwd, self.relvec_bwd
+        self.fold_bwd = self.relvec_bwd = None
+        if fb is not None:
+            _lib.check(L.kgw_fold_bwd(C.byref(fb[0]), _lib.stream_ptr()), 'kgw_fold_bwd')
+        if rb is not None:
+            _lib.check(L.kgw_relvec_bwd_multi(rb[0], rb[1], _lib.stream_ptr()), 'kgw_relvec_bwd_multi')
+        for t in (fb, rb):
+            if t is not None:
+                for ptr, numel, st in t[-1]:
+                    self.records[ptr] = (None, numel, st)
+
     def flush(self):
-        """Launch the deferred products (first launch only: their row blocks' partial sums are taken by the optimiser's launch)."""
+        """Launch the deferred products (first launch only: their row blocks' partial sums are taken by the optimiser's launch) and,
+        in the same launch, the parameter-only end of the backward pass (kgw_param_tail)."""
         L = _lib.lib()
         todo, self.products = sorted(self.products, key=lambda p: -p[0].shape[0]), []       # the tall ones first in the grid
-        for i in range(0, len(todo), 4):
-            chunk = todo[i:i + 4]
-            jobs = (_lib.KgwTnJob * len(chunk))()
-            src = (_lib.KgwGradSrc * (2 * len(chunk)))()
-            keep = []
-            for j, (dY, X, dW_ptr, db_ptr, _sw, _sb, rows_dev) in zip(jobs, chunk):
-                rows, M = dY.shape
-                N = X.shape[1]
-                nws = int(L.kgw_tn_gemm_workspace_floats(rows, M, N))
-                ws = torch.empty(nws, device=dY.device)
-                keep.append(ws)
-                j.A, j.lda, j.B, j.ldb, j.rows = _p(dY), dY.stride(0), _p(X), X.stride(0), rows
-                j.C, j.ldc, j.colsum_a, j.colsum_ld = dW_ptr, N, db_ptr, M
-                j.workspace, j.workspace_floats, j.rows_dev = _p(ws), nws, _p(rows_dev)
-                j.M, j.N, j.c_transposed, j.colsum_repeat = M, N, 0, 1
-            _lib.check(L.kgw_tn_gemm_multi_partial(len(chunk), jobs, src, _lib.stream_ptr()), 'kgw_tn_gemm_multi_partial')
+        chunks = [todo[i:i + 4] for i in range(0, len(todo), 4)]
+        fb, rb = self.fold_bwd, self.relvec_bwd
+        if (fb is not None or rb is not None) and not chunks:
+            chunks = [[]]
+        for ci, chunk in enumerate(chunks):
+            jobs, src, keep = self._tn_jobs(chunk)
+            merged = False
+            if ci == 0 and rb is not None:
+                # (the fold's outputs must BE the inputs of one of the relation-vector jobs: that job's blocks then compute them)
+                fold_job = -1
+                if fb is not None:
+                    a = fb[0]
+                    fold_job = next((k for k in range(rb[0]) if rb[1][k].dU_full == a.dU and rb[1][k].dV == a.dV and
+                                     rb[1][k].dw_src_acc == a.dws and not rb[1][k].duv_pieces), -1)
+                if fb is None or fold_job >= 0:
+                    rc = L.kgw_param_tail(len(chunk), jobs, src, C.byref(fb[0]) if fb is not None else None, rb[0], rb[1], fold_job,
+                                          _lib.stream_ptr())
+                    if rc != _lib.KGW_E_UNSUPPORTED:
+                        _lib.check(rc, 'kgw_param_tail')
+                        merged = True
+                        self.tail_taken += 1
+                        for t in (fb, rb):
+                            if t is not None:
+                                for ptr, numel, st in t[-1]:
+                                    self.records[ptr] = (None, numel, st)
+                        self._tail_keep = (fb, rb)           # (operands alive until the optimiser's launch is enqueued)
+                        self.fold_bwd = self.relvec_bwd = None
+            if ci == 0 and not merged:
+                self.launch_pending_tail()
+            if not merged and chunk:
+                _lib.check(L.kgw_tn_gemm_multi_partial(len(chunk), jobs, src, _lib.stream_ptr()), 'kgw_tn_gemm_multi_partial')
             for q, (dY, X, dW_ptr, db_ptr, _sw, _sb, rows_dev) in enumerate(chunk):
                 M, N = dY.shape[1], X.shape[1]
                 for ptr, numel, rec_src in ((dW_ptr, M * N, src[2 * q]), (db_ptr, M, src[2 * q + 1])):
@@ -250,6 +303,8 @@ class GradSink:
                         rec = _lib.KgwGradSrc()
                         C.memmove(C.byref(rec), C.byref(rec_src), C.sizeof(rec))
                     self.records[ptr] = (rec, numel, keep[q])
+        if self.fold_bwd is not None or self.relvec_bwd is not None:      # (a fold without relation vectors behind it)
+            self.launch_pending_tail()
 
     def add(self, grad: torch.Tensor, src, ws: torch.Tensor):
         if src.kind != 0:           # (KGW_GRAD_DIRECT: the producer finished the tensor itself)
@@ -276,6 +331,10 @@ _FUSED_ADAM = os.environ.get('KGW_FUSED_ADAM', '1') != '0'         # 0: k_tn_red
 # launch 83 us against 16.8 + 43.7 + 16.7: its 512 blocks already fill the chip for 43 us and the short products' blocks of the later
 # tiles queue behind them.  KGW_DEFER_PRODUCTS=0: every product where it is.
 _DEFER_PRODUCTS = os.environ.get('KGW_DEFER_PRODUCTS', '1') != '0'
+# The parameter-only END of the backward pass (kgw_fold_bwd 28 us, kgw_relvec_bwd_multi 9 us: neither fills the chip, each waits for the
+# one before) is not launched where autograd reaches it but as blocks of the deferred products' launch (kgw_param_tail, round 5).
+# KGW_PARAM_TAIL=0: every launch where it is.
+_PARAM_TAIL = os.environ.get('KGW_PARAM_TAIL', '1') != '0'
 
 
 class grad_sink_scope:
@@ -1692,7 +1751,7 @@ class _RelVectorsMulti(torch.autograd.Function):
         packs = ctx.packs
         n = len(packs)
         jobs = (_lib.KgwRelvecJob * n)()
-        ret, keep, live = [], [], 0
+        ret, keep, made, live = [], [], [], 0
         for l, pack in enumerate(packs):
             w_src_t, w_dst_t, att_src, att_dst = params[4 * l:4 * l + 4]
             dU, dV, _, dW_in = grads[4 * l:4 * l + 4]
@@ -1720,8 +1779,19 @@ class _RelVectorsMulti(torch.autograd.Function):
             j.dw_src_t, j.dw_dst_t = dws.data_ptr(), (dwd.data_ptr() if dwd.numel() else None)
             j.datt_src, j.datt_dst = das.data_ptr(), dad.data_ptr()
             ret += [dws, dwd, das, dad]
+            made += [dws, dwd, das, dad]
         if live:
-            _lib.check(_lib.lib().kgw_relvec_bwd_multi(live, jobs, _lib.stream_ptr()), 'kgw_relvec_bwd_multi')
+            sink = GRAD_SINK
+            if sink is not None and _PARAM_TAIL and _DEFER_PRODUCTS and sink.relvec_bwd is None:
+                # (feeds only the optimiser: launched by GradSink.flush.  The OUTPUT tensors are kept alive through their storages
+                #  only: a second reference to a gradient tensor would make autograd's accumulation clone it -- before the deferred
+                #  launch has written it -- instead of adopting it)
+                outs = [(t.data_ptr(), t.numel(), t.untyped_storage()) for t in made if t.numel()]
+                sink.relvec_bwd = (live, jobs, (keep, params), outs)
+            else:
+                if sink is not None:
+                    sink.launch_pending_tail()           # (a fold still pending feeds this launch)
+                _lib.check(_lib.lib().kgw_relvec_bwd_multi(live, jobs, _lib.stream_ptr()), 'kgw_relvec_bwd_multi')
         return (None, None, None, None) + tuple(ret)
 
 
@@ -2050,7 +2120,16 @@ class _FoldFC(torch.autograd.Function):
         if pu is not None:                          # the aggregate left eight pieces per value: added inside k_fold_bwd
             a.dUp, a.dVp, a.duv_pieces = pu[0], pv[0], 1
         a.dU, a.dV, a.dws = _p(dU), _p(dV), _p(dws)
-        _lib.check(_lib.lib().kgw_fold_bwd(C.byref(a), _lib.stream_ptr()), 'kgw_fold_bwd')
+        sink = GRAD_SINK
+        if sink is not None and _PARAM_TAIL and _DEFER_PRODUCTS and sink.fold_bwd is None and sink.relvec_bwd is None:
+            # its outputs reach the relation vectors' backward (queued the same way, behind it) and the optimiser, nothing else:
+            # launched by GradSink.flush (outputs: storages only, see _RelVectorsMulti.backward)
+            keep = (dUp, dVp, dkappa, dWp, dgamma, w_src_t, U, V, fc, tab, pu, pv, [t.untyped_storage() for t in (dU, dV, dws)])
+            sink.fold_bwd = (a, keep, [(t.data_ptr(), t.numel(), t.untyped_storage()) for t in dfc])
+        else:
+            if sink is not None:
+                sink.launch_pending_tail()
+            _lib.check(_lib.lib().kgw_fold_bwd(C.byref(a), _lib.stream_ptr()), 'kgw_fold_bwd')
         return (dws, dU, dV, None, None) + tuple(dfc)
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Full-size check of the launch merges of rounds 4-5: N captured training steps on the benchmark workload with every merge on (fused
 optimiser launch + operand image, merged transform backward, grouped short products, the parameter-only forward work as rider blocks of the
-gene product) against the same steps with all of them off --
+gene product, the parameter-only end of the backward pass inside the grouped products' launch) against the same steps with all of them off --
 losses and every parameter must be IDENTICAL bit for bit.  usage: python tools/fused_vs_unfused.py [steps]"""
 import os
 import sys
@@ -20,7 +20,7 @@ data = KGWAS_Data.from_synthetic(scale=1.0, seed=1, mode='fast', gwas_kind='caus
 ids = np.asarray(data.train_input_nodes[1])
 out = []
 for on in (True, False):
-    ops._FUSED_ADAM = ops._MERGED_TRANSFORM_BWD = ops._DEFER_PRODUCTS = ops._DUV_PIECES = ops._G3_RIDERS = on
+    ops._FUSED_ADAM = ops._MERGED_TRANSFORM_BWD = ops._DEFER_PRODUCTS = ops._DUV_PIECES = ops._G3_RIDERS = ops._PARAM_TAIL = on
     run = KGWAS(data, device='cuda:0', seed=1)
     run.initialize_model()
     init = lambda v: not isinstance(v, torch.nn.parameter.UninitializedParameter)      # (lazy PyG-style placeholders: never used)
