@@ -360,6 +360,25 @@ int kgw_tn_gemm_partial(const float* A, int64_t lda, int32_t M, const float* B, 
                         kgw_stream_t stream);
 int kgw_tn_gemm_multi_partial(int32_t n_jobs, const KgwTnJob* jobs, KgwGradSrc* src, kgw_stream_t stream);
 
+/* A product group's SECOND launch (the sums over its row blocks: k_tn_reduce) that has not been issued.  The gradients it
+ * finishes -- the relation transform's d W^T / d bias, kgwas/conv.py:138,190 -- feed nothing before the end of the backward pass,
+ * so in a captured step its few blocks ride in a later launch instead of being one of their own (5 - 8 us each):
+ *   kgw_transform_bwd_ex(.., ride_in, defer_out, ..)  kgw_transform_bwd that (ride_in, nullable) carries a pending plan's blocks
+ *                                                      and (defer_out, nullable) leaves its own second launch as a plan;
+ *   kgw_tn_gemm_partial_ride(.., ride_in, ..)          kgw_tn_gemm_partial that carries a pending plan's blocks;
+ *   kgw_tn_reduce_launch(plan)                          the plan as a launch of its own (nothing came by to carry it).
+ * Same blocks, same code, same order of additions wherever they run.  plan->valid == 0: nothing pending (a group whose products
+ * all had one row block).  The plan points into the products' workspaces and outputs: keep them alive until it has run.
+ * Riding pays for a SMALL plan only: the blocks take the carrier kernel's registers and LDS, so a carrier built for one or two
+ * blocks per CU runs thousands of them a few at a time (measured: layer 1's 9 088 blocks in the SNP product's launch, 78 us against
+ * 8 + 47 apart) -- ``blocks`` is there for the caller to decide.                                                               */
+typedef struct KgwTnReducePlan { int32_t valid; int32_t blocks /* 256-thread blocks of the launch */; int32_t reserved[2]; int64_t opaque[96]; } KgwTnReducePlan;
+int kgw_tn_reduce_launch(const KgwTnReducePlan* plan, kgw_stream_t stream);
+int kgw_tn_gemm_partial_ride(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N, int64_t rows,
+                             float* C, int64_t ldc, int32_t c_transposed, float* colsum_a, float* workspace,
+                             int64_t workspace_floats, const int32_t* rows_dev, KgwGradSrc* src, const KgwTnReducePlan* ride_in,
+                             kgw_stream_t stream);
+
 /* Y[rows,N] = act(X[rows,K] * Wop + bias) * (mask > 0): the Linear layers of the path on fp32 MFMA.
  * w_is_kn = 0: W is [N,K] (nn.Linear / PyG Linear forward, kgwas/model.py:13-21,50; kgwas/conv.py:138,142);
  * w_is_kn = 1: W is [K,N] (the dX = dY * W product of their backward).  bias, mask may be NULL; relu 0/1.
@@ -484,6 +503,11 @@ int kgw_ind_colsum_multi(int32_t n_jobs, const KgwSplitKJob* jobs, kgw_stream_t 
  * one grid; values identical to the three separate calls.  Any of the three lists may be empty.                              */
 int kgw_transform_bwd(int32_t n_tn, const KgwTnJob* tn_jobs, int32_t n_sk, const KgwSplitKJob* sk_jobs, int32_t n_cs,
                       const KgwSplitKJob* cs_jobs, kgw_stream_t stream);
+/* ... with the pending second launch of an EARLIER product group riding as extra blocks (ride_in) and / or this call's own second
+ * launch left pending (defer_out): see KgwTnReducePlan.                                                                         */
+int kgw_transform_bwd_ex(int32_t n_tn, const KgwTnJob* tn_jobs, int32_t n_sk, const KgwSplitKJob* sk_jobs, int32_t n_cs,
+                         const KgwSplitKJob* cs_jobs, const KgwTnReducePlan* ride_in, KgwTnReducePlan* defer_out,
+                         kgw_stream_t stream);
 
 /* One Adam step (torch.optim.Adam semantics, weight_decay as L2: kgwas/kgwas.py:116,151) over up to 64
  * parameter tensors in a single launch.  The pointer arrays are HOST arrays of device pointers (passed to the

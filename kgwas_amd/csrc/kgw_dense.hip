@@ -237,12 +237,13 @@ __global__ void __launch_bounds__(256, 1) k_tn_gemm(TnJobs J) {
 
 // C[m][n] = sum over row-blocks of the partial fragments (fixed order); also the column sums.
 // Block = 64 fragment elements x 4 groups of row-blocks; every thread keeps 8 loads in flight.
+// (the body of k_tn_reduce: block (bx = 64 fragment elements, by, bzz = job * gz_max + bz); sm: 256 floats of LDS.  Also the
+//  reduce blocks that ride in a later launch: k_transform_bwd, k_tn_gemm_ride)
 template <int MT, int NT>
-__global__ void __launch_bounds__(256) k_tn_reduce(TnJobs J, int gz_max) {
+__device__ __forceinline__ void tn_reduce_block(const TnJobs& J, const int gz_max, const int bx_, const int by, const int bzz, float* sm) {
     constexpr int FRAG = MT * NT * 16 * 64;
-    __shared__ float sm[256];
-    const TnJob& T = J.j[blockIdx.z / gz_max];
-    const int by = blockIdx.y, bz = blockIdx.z % gz_max;
+    const TnJob& T = J.j[bzz / gz_max];
+    const int bz = bzz % gz_max;
     if (by >= T.gy || bz >= T.gz) return;
     if (T.nblk == 1) return;                 // single row block: k_tn_gemm wrote C and the column sums itself
     const float* __restrict__ ws = T.ws;
@@ -253,7 +254,7 @@ __global__ void __launch_bounds__(256) k_tn_reduce(TnJobs J, int gz_max) {
     const int64_t c_rs = T.c_rs, c_cs = T.c_cs, cs_ld = T.cs_ld;
     const int m0 = by * 32 * MT, n0 = bz * 32 * NT;
     const int fl = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int f = blockIdx.x * 64 + fl;
+    const int f = bx_ * 64 + fl;
     {
         const float* p = ws + ((int64_t)bz * gy + by) * nblk * FRAG + f;
         float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(256) k_tn_reduce(TnJobs J, int gz_max) {
         const int m = m0 + MT * ti + ta, n = n0 + NT * tj + tb;
         if (m < M && n < N) C[(int64_t)m * c_rs + (int64_t)n * c_cs] = s;
     }
-    if (colsum && bz == 0 && blockIdx.x == 0) {
+    if (colsum && bz == 0 && bx_ == 0) {
         // 32*MT columns x (256 / (32*MT)) groups of row-blocks, 4 loads in flight per thread, fixed order
         constexpr int NC = 32 * MT, NG = 256 / NC;
         __syncthreads();
@@ -298,6 +299,40 @@ __global__ void __launch_bounds__(256) k_tn_reduce(TnJobs J, int gz_max) {
     }
 }
 
+template <int MT, int NT>
+__global__ void __launch_bounds__(256) k_tn_reduce(TnJobs J, int gz_max) {
+    __shared__ float sm[256];
+    tn_reduce_block<MT, NT>(J, gz_max, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, sm);
+}
+
+// A product group's second launch (k_tn_reduce<2,2>) that has not been issued: the C ABI's KgwTnReducePlan.  The gradients it
+// finishes feed nothing before the end of the backward pass, so its blocks ride in a later launch of this file instead
+// (kgw_transform_bwd_ex, kgw_tn_gemm_partial_ride) or are launched by kgw_tn_reduce_launch.
+struct TnReducePlan { int32_t valid, blocks, gy_max, gz_max; int32_t n, pad_[3]; TnJobs J; };     // (valid, blocks: KgwTnReducePlan's public fields)
+static_assert(sizeof(TnReducePlan) <= sizeof(KgwTnReducePlan), "KgwTnReducePlan holds a TnReducePlan");
+constexpr int TN22_FRAG = 2 * 2 * 16 * 64;
+inline int tn_reduce_plan_blocks(const TnReducePlan& R) { return R.valid ? (TN22_FRAG / 64) * R.gy_max * R.gz_max * R.n : 0; }
+// flat block index b of a plan's grid (TN22_FRAG / 64, gy_max, gz_max * n)
+__device__ __forceinline__ void tn_reduce_plan_block(const TnJobs& J, int gy_max, int gz_max, int b, float* sm) {
+    constexpr int NX = TN22_FRAG / 64;
+    tn_reduce_block<2, 2>(J, gz_max, b % NX, (b / NX) % gy_max, b / (NX * gy_max), sm);
+}
+
+// k_tn_gemm<2,2> with the reduce blocks of an earlier product group in front (flat grid; the product's blocks in the 3-D grid's order)
+struct TnRideIdx { int n_rd, rd_gy, rd_gz, blk, gy_max, gz_max; };
+__global__ void __launch_bounds__(256, 1) k_tn_gemm_ride(TnJobs J, TnJobs JR, TnRideIdx X) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = (int)blockIdx.x;
+    if (b < X.n_rd) { tn_reduce_plan_block(JR, X.rd_gy, X.rd_gz, b, lds); return; }
+    const int l = b - X.n_rd;
+    const int bx = l % X.blk, by = (l / X.blk) % X.gy_max, bz = l / (X.blk * X.gy_max);
+    int jq = 0;
+    while (jq + 1 < J.n && bx >= J.j[jq + 1].blk0) ++jq;
+    const TnJob& T = J.j[jq];
+    if (by >= T.gy || bz >= T.gz) return;
+    tn_gemm_block<2, 2>(T, bx - T.blk0, by, bz, lds);
+}
+
 struct TnDesc {      // one product as the C ABI describes it
     const float* A; int64_t lda; int M; const float* B; int64_t ldb; int N; int64_t rows; float* C; int64_t ldc; bool c_t;
     float* colsum; int cs_rep; int64_t cs_ld; float* ws; int64_t ws_floats; const int32_t* rows_dev;
@@ -308,7 +343,8 @@ struct TnDesc {      // one product as the C ABI describes it
 // ``plan`` (nullable): fill it with the job table and return without launching anything (k_transform_bwd runs the blocks)
 struct TnPlan { TnJobs J; int blk, gy_max, gz_max; bool all_direct; };
 template <int MT, int NT>
-int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st, KgwGradSrc* defer = nullptr, TnPlan* plan = nullptr) {
+int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st, KgwGradSrc* defer = nullptr, TnPlan* plan = nullptr,
+                   const TnReducePlan* ride = nullptr) {
     constexpr int FRAG = MT * NT * 16 * 64;
     TnJobs J{};
     J.n = n;
@@ -368,8 +404,28 @@ int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st, KgwGradSrc* defer = n
     if (lds_bytes > 64 * 1024 && attr_once.need()) {
         KGW_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
-    kern<<<dim3((unsigned)blk, gy_max, gz_max), 256, lds_bytes, st>>>(J);
-    KGW_LAUNCH_CHECK();
+    if (ride && !ride->valid) ride = nullptr;
+    bool rode = false;
+    if constexpr (MT == 2 && NT == 2) {
+        if (ride) {         // the pending second launch of an earlier product group: its blocks in front of this product's
+            const TnRideIdx X{tn_reduce_plan_blocks(*ride), ride->gy_max, ride->gz_max, blk, gy_max, gz_max};
+            static KgwPerDevice attr_ride;
+            if (lds_bytes > 64 * 1024 && attr_ride.need()) {
+                KGW_HIP(hipFuncSetAttribute((const void*)k_tn_gemm_ride, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            }
+            k_tn_gemm_ride<<<X.n_rd + blk * gy_max * gz_max, 256, lds_bytes, st>>>(J, ride->J, X);
+            KGW_LAUNCH_CHECK();
+            rode = true;
+        }
+    }
+    if (!rode) {
+        if (ride) {
+            k_tn_reduce<2, 2><<<dim3(TN22_FRAG / 64, ride->gy_max, ride->gz_max * ride->n), 256, 0, st>>>(ride->J, ride->gz_max);
+            KGW_LAUNCH_CHECK();
+        }
+        kern<<<dim3((unsigned)blk, gy_max, gz_max), 256, lds_bytes, st>>>(J);
+        KGW_LAUNCH_CHECK();
+    }
     if (all_direct || defer) return KGW_OK;            // every product wrote its result itself / the sums are taken later
     k_tn_reduce<MT, NT><<<dim3(FRAG / 64, gy_max, gz_max * n), 256, 0, st>>>(J, gz_max);
     KGW_LAUNCH_CHECK();
@@ -379,9 +435,9 @@ int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st, KgwGradSrc* defer = n
 template <int MT, int NT>
 int launch_tn(const float* A, int64_t lda, int M, const float* B, int64_t ldb, int N, int64_t rows, float* C,
               int64_t ldc, bool c_t, float* colsum, int cs_rep, int64_t cs_ld, float* ws, int64_t ws_floats,
-              const int32_t* rows_dev, hipStream_t st, KgwGradSrc* defer = nullptr) {
+              const int32_t* rows_dev, hipStream_t st, KgwGradSrc* defer = nullptr, const TnReducePlan* ride = nullptr) {
     const TnDesc d{A, lda, M, B, ldb, N, rows, C, ldc, c_t, colsum, cs_rep, cs_ld, ws, ws_floats, rows_dev};
-    return launch_tn_jobs<MT, NT>(&d, 1, st, defer);
+    return launch_tn_jobs<MT, NT>(&d, 1, st, defer, nullptr, ride);
 }
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -400,7 +456,7 @@ extern "C" int64_t kgw_tn_gemm_workspace_floats(int64_t rows, int M, int N) {
 static int tn_gemm_ex(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
                       int64_t rows, float* C, int64_t ldc, int32_t c_transposed, float* colsum_a,
                       int32_t colsum_repeat, int64_t colsum_ld, float* workspace, int64_t workspace_floats,
-                      const int32_t* rows_dev, kgw_stream_t stream_, KgwGradSrc* defer) {
+                      const int32_t* rows_dev, kgw_stream_t stream_, KgwGradSrc* defer, const TnReducePlan* ride = nullptr) {
     if (!A || !B || !C || !workspace) return KGW_E_NULL;
     if (M <= 0 || N <= 0 || rows <= 0 || lda < M || ldb < N || ldc < (c_transposed ? M : N)) return KGW_E_RANGE;
     if (colsum_a && (colsum_repeat < 1 || (colsum_repeat > 1 && colsum_ld < M))) return KGW_E_RANGE;
@@ -414,7 +470,7 @@ static int tn_gemm_ex(const float* A, int64_t lda, int32_t M, const float* B, in
     // 64x64 accumulators per wavefront (MT = NT = 2) and up to two blocks per CU rather than one 128x128 accumulator:
     // a quarter of the per-block LDS reduction / partial-slab traffic and twice the row blocks in flight -- 51 vs 72 us
     // at 123 k x 128 x 128, 21 vs 26 us at 20 k rows (each A / B element is read by two blocks, the second time from L2)
-#define KGW_TN_ARGS A, lda, M, B, ldb, N, rows, C, ldc, ct, colsum_a, rep, colsum_ld, workspace, workspace_floats, rows_dev, st, defer
+#define KGW_TN_ARGS A, lda, M, B, ldb, N, rows, C, ldc, ct, colsum_a, rep, colsum_ld, workspace, workspace_floats, rows_dev, st, defer, ride
     if (a2 && b2) return launch_tn<2, 2>(KGW_TN_ARGS);
     if (a2)       return launch_tn<2, 1>(KGW_TN_ARGS);       // narrow B (the 20-wide SNP feature layer)
     if (b4)       return launch_tn<1, 4>(KGW_TN_ARGS);       // narrow A (d a_src of a few relations)
@@ -440,6 +496,18 @@ extern "C" int kgw_tn_gemm_partial(const float* A, int64_t lda, int32_t M, const
     if (!src) return KGW_E_NULL;
     return tn_gemm_ex(A, lda, M, B, ldb, N, rows, C, ldc, c_transposed, colsum_a, 1, M, workspace, workspace_floats, rows_dev,
                       stream_, src);
+}
+
+// kgw_tn_gemm_partial with the pending second launch of an earlier product group (ride_in, nullable) as blocks of its own launch
+// -- or, where the product does not run on the 64 x 64-per-wavefront tiling, as a launch of its own just ahead of it: the plan is
+// consumed either way.
+extern "C" int kgw_tn_gemm_partial_ride(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N,
+                                        int64_t rows, float* C, int64_t ldc, int32_t c_transposed, float* colsum_a,
+                                        float* workspace, int64_t workspace_floats, const int32_t* rows_dev, KgwGradSrc* src,
+                                        const KgwTnReducePlan* ride_in, kgw_stream_t stream_) {
+    if (!src) return KGW_E_NULL;
+    return tn_gemm_ex(A, lda, M, B, ldb, N, rows, C, ldc, c_transposed, colsum_a, 1, M, workspace, workspace_floats, rows_dev,
+                      stream_, src, (const TnReducePlan*)ride_in);
 }
 
 static int tn_gemm_multi(int32_t n_jobs, const KgwTnJob* jobs, kgw_stream_t stream_, KgwGradSrc* defer) {
@@ -2515,13 +2583,16 @@ __device__ __forceinline__ void ind_colsum_block256(const ColsumJobs& J, const i
 //   the d gamma sums of a folded layer          (k_ind_colsum)
 // -- as blocks of one grid.  They are independent of each other, each is a few hundred latency-bound blocks at two per CU, and as
 // three launches one after the other each waits for the last block of the one before it.  Same code per block, same values.
-struct TransformBwdIdx { int tn_flat0[TN_MAX_JOBS + 1]; int n_sk, n_tn, n_cs; };
+// (round 5: + the reduce blocks of an EARLIER product group whose second launch was left pending -- JR, X.n_rd: the last blocks)
+struct TransformBwdIdx { int tn_flat0[TN_MAX_JOBS + 1]; int n_sk, n_tn, n_cs, n_rd, rd_gy, rd_gz; };
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_transform_bwd(TnJobs JT, SplitKJobs JS, ColsumJobs JC, TransformBwdIdx X) {
+k_transform_bwd(TnJobs JT, SplitKJobs JS, ColsumJobs JC, TnJobs JR, TransformBwdIdx X) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // (the column-sum blocks first: few, and the longest -- a row walk per block; then the products' row blocks, then the twins)
     const int b = (int)blockIdx.x;
-    if (b < X.n_cs) {
+    if (b >= X.n_cs + X.n_tn + X.n_sk) {
+        tn_reduce_plan_block(JR, X.rd_gy, X.rd_gz, b - X.n_cs - X.n_tn - X.n_sk, lds);
+    } else if (b < X.n_cs) {
         ind_colsum_block256(JC, b, lds);
     } else if (b < X.n_cs + X.n_tn) {
         const int t = b - X.n_cs;
@@ -2561,11 +2632,24 @@ extern "C" int kgw_ind_colsum_multi(int32_t n_jobs, const KgwSplitKJob* jobs, kg
     return KGW_OK;
 }
 
-extern "C" int kgw_transform_bwd(int32_t n_tn, const KgwTnJob* tn_jobs, int32_t n_sk, const KgwSplitKJob* sk_jobs, int32_t n_cs,
-                                 const KgwSplitKJob* cs_jobs, kgw_stream_t stream_) {
+extern "C" int kgw_tn_reduce_launch(const KgwTnReducePlan* plan, kgw_stream_t stream_) {
+    if (!plan) return KGW_E_NULL;
+    const TnReducePlan& R = *(const TnReducePlan*)plan;
+    if (!R.valid) return KGW_OK;
+    k_tn_reduce<2, 2><<<dim3(TN22_FRAG / 64, R.gy_max, R.gz_max * R.n), 256, 0, (hipStream_t)stream_>>>(R.J, R.gz_max);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
+
+extern "C" int kgw_transform_bwd_ex(int32_t n_tn, const KgwTnJob* tn_jobs, int32_t n_sk, const KgwSplitKJob* sk_jobs, int32_t n_cs,
+                                    const KgwSplitKJob* cs_jobs, const KgwTnReducePlan* ride_in, KgwTnReducePlan* defer_out,
+                                    kgw_stream_t stream_) {
+    if (defer_out) ((TnReducePlan*)defer_out)->valid = 0;
     if (n_tn < 0 || n_sk < 0 || n_cs < 0 || n_tn > TN_MAX_JOBS || n_sk > SK_MAX_JOBS || n_cs > SK_MAX_JOBS) return KGW_E_RANGE;
     if ((n_tn && !tn_jobs) || (n_sk && !sk_jobs) || (n_cs && !cs_jobs)) return KGW_E_NULL;
-    if (n_tn + n_sk + n_cs == 0) return KGW_OK;
+    const TnReducePlan* RI = (const TnReducePlan*)ride_in;
+    if (RI && !RI->valid) RI = nullptr;
+    if (n_tn + n_sk + n_cs == 0) return RI ? kgw_tn_reduce_launch(ride_in, stream_) : KGW_OK;
     hipStream_t st = (hipStream_t)stream_;
     auto aligned8 = [](const void* p) { return ((uintptr_t)p & 7) == 0; };
     // weight-gradient products: kgw_tn_gemm_multi's checks and plan (64 x 64-per-wavefront tiling)
@@ -2627,16 +2711,29 @@ extern "C" int kgw_transform_bwd(int32_t n_tn, const KgwTnJob* tn_jobs, int32_t 
     constexpr int FRAG = 2 * 2 * 16 * 64;
     constexpr size_t lds_bytes = (size_t)(2 * FRAG + 4 * 32 * 2) * sizeof(float);
     static_assert(lds_bytes >= 2 * 32 * SK_LD * sizeof(float) && lds_bytes >= 32 * 32 * sizeof(float), "one LDS buffer serves the three block kinds");
-    const int total = X.n_sk + X.n_tn + X.n_cs;
+    TnJobs JRd{};
+    if (RI) { JRd = RI->J; X.n_rd = tn_reduce_plan_blocks(*RI); X.rd_gy = RI->gy_max; X.rd_gz = RI->gz_max; }
+    const int total = X.n_sk + X.n_tn + X.n_cs + X.n_rd;
     if (total > 0) {
-        k_transform_bwd<<<total, 256, lds_bytes, st>>>(P.J, JS, JC, X);
+        k_transform_bwd<<<total, 256, lds_bytes, st>>>(P.J, JS, JC, JRd, X);
         KGW_LAUNCH_CHECK();
     }
     if (n_tn && !P.all_direct) {
-        k_tn_reduce<2, 2><<<dim3(FRAG / 64, P.gy_max, P.gz_max * n_tn), 256, 0, st>>>(P.J, P.gz_max);
-        KGW_LAUNCH_CHECK();
+        if (defer_out) {
+            TnReducePlan& R = *(TnReducePlan*)defer_out;
+            R.valid = 1; R.gy_max = P.gy_max; R.gz_max = P.gz_max; R.n = n_tn; R.J = P.J;
+            R.blocks = tn_reduce_plan_blocks(R);
+        } else {
+            k_tn_reduce<2, 2><<<dim3(FRAG / 64, P.gy_max, P.gz_max * n_tn), 256, 0, st>>>(P.J, P.gz_max);
+            KGW_LAUNCH_CHECK();
+        }
     }
     return KGW_OK;
+}
+
+extern "C" int kgw_transform_bwd(int32_t n_tn, const KgwTnJob* tn_jobs, int32_t n_sk, const KgwSplitKJob* sk_jobs, int32_t n_cs,
+                                 const KgwSplitKJob* cs_jobs, kgw_stream_t stream_) {
+    return kgw_transform_bwd_ex(n_tn, tn_jobs, n_sk, sk_jobs, n_cs, cs_jobs, nullptr, nullptr, stream_);
 }
 
 extern "C" int kgw_ind_colsum(const float* seg_stat, const float* dY, int64_t ldy, int64_t rows, int32_t R, float* dgamma,

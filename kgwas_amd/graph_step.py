@@ -201,10 +201,11 @@ class GraphTrainStep:
             if pieces:
                 raise ops.GradSinkMismatch(f'{len(pieces)} d u_r / d v_r tensor(s) left in pieces reached no consumer that adds them')
             if sink is not None:
-                self.deferred_gradients = len(sink.records) + 2 * len(sink.products)   # (gradients whose last sums the optimiser launch takes)
+                self.deferred_gradients = sum(1 for r in sink.records.values() if r[0] is not None) + 2 * len(sink.products)   # (gradients whose last sums the optimiser launch takes)
                 self.opt.step_fused(sink, buf.meta.data_ptr(), self.run.gnn_num_layers, self.dg.n_hops, self.stats)
                 # (launches of the step that carried its parameter-only forward work as rider blocks: the gene layer's kgw_gemm3)
                 self.riders_taken = getattr(self.model, 'last_riders_taken', 0)
+                self.reduces_ridden = sink.reduces_ridden    # (second launches of product groups that rode in a later launch)
                 self.tail_taken = sink.tail_taken          # (kgw_param_tail: the backward's parameter-only end inside the deferred products' launch)
                 if self.overlap:
                     main.wait_stream(self._side)                       # join
@@ -272,7 +273,7 @@ class GraphTrainStep:
             if staged:
                 self._flat_grads[w1] = self._flat_b[off:off + w1.numel()].view_as(w1)
         if sink is not None:
-            self.deferred_gradients = len(sink.records) + 2 * len(sink.products)
+            self.deferred_gradients = sum(1 for r in sink.records.values() if r[0] is not None) + 2 * len(sink.products)
             self.opt.finish_into(sink, [(p, self._flat_grads[p]) for p in live])
         else:
             torch.cat([p.grad.reshape(-1) for p in live], out=self._flat_b[:n_live])

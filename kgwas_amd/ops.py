@@ -203,6 +203,9 @@ class GradSink:
         self.fold_bwd = None        # (KgwFoldArgs, keep-alive, [(address, numel, storage) of the leaf gradients it writes])
         self.relvec_bwd = None      # (n jobs, jobs, keep-alive, [(address, numel, storage)])
         self.tail_taken = 0         # kgw_param_tail launches issued
+        self.pending_reduce = None  # (KgwTnReducePlan, keep-alive) of a product group whose second launch is waiting for a carrier
+        self.reduces_ridden = 0     # plans that rode in a later launch
+        self.keep = []              # operands of launches issued on behalf of others: alive until the optimiser's launch is enqueued
 
     def defer_product(self, dY: torch.Tensor, X: torch.Tensor, rows_dev=None):
         """(dW [out, in], db [out]) = (dY^T X, column sums of dY) of a Linear whose gradients feed only the optimiser -- not launched
@@ -242,12 +245,26 @@ class GradSink:
             j.M, j.N, j.c_transposed, j.colsum_repeat = M, N, 0, 1
         return jobs, src, keep
 
+    def take_reduce(self):
+        """The pending reduce plan for a launch that will carry it (or None); the caller reports with ``rode``."""
+        r, self.pending_reduce = self.pending_reduce, None
+        if r is not None:
+            self.keep.append(r)
+        return r
+
+    def launch_pending_reduce(self):
+        r = self.take_reduce()
+        if r is not None:
+            _lib.check(_lib.lib().kgw_tn_reduce_launch(C.byref(r[0]), _lib.stream_ptr()), 'kgw_tn_reduce_launch')
+
     def launch_pending_tail(self):
         """kgw_fold_bwd / kgw_relvec_bwd_multi left pending, as launches of their own, in that order (a consumer of their outputs is
         about to be launched, or the merged launch does not take them)."""
         L = _lib.lib()
         fb, rb = self.fold_bwd, self.relvec_bwd
         self.fold_bwd = self.relvec_bwd = None
+        if fb is not None or rb is not None:
+            self.launch_pending_reduce()                 # (they read the transform's weight gradient)
         if fb is not None:
             _lib.check(L.kgw_fold_bwd(C.byref(fb[0]), _lib.stream_ptr()), 'kgw_fold_bwd')
         if rb is not None:
@@ -261,6 +278,7 @@ class GradSink:
         """Launch the deferred products (first launch only: their row blocks' partial sums are taken by the optimiser's launch) and,
         in the same launch, the parameter-only end of the backward pass (kgw_param_tail)."""
         L = _lib.lib()
+        self.launch_pending_reduce()                     # (nothing came by to carry it: the tail reads what it finishes)
         todo, self.products = sorted(self.products, key=lambda p: -p[0].shape[0]), []       # the tall ones first in the grid
         chunks = [todo[i:i + 4] for i in range(0, len(todo), 4)]
         fb, rb = self.fold_bwd, self.relvec_bwd
@@ -335,6 +353,14 @@ _DEFER_PRODUCTS = os.environ.get('KGW_DEFER_PRODUCTS', '1') != '0'
 # one before) is not launched where autograd reaches it but as blocks of the deferred products' launch (kgw_param_tail, round 5).
 # KGW_PARAM_TAIL=0: every launch where it is.
 _PARAM_TAIL = os.environ.get('KGW_PARAM_TAIL', '1') != '0'
+# The SECOND launch of the relation transform's weight-gradient products (k_tn_reduce: 5 - 8 us for a few dozen blocks, once per
+# layer) finishes gradients that nothing reads before the end of the backward pass: in a captured step it is not issued but left as
+# a KgwTnReducePlan whose blocks ride in the next launch that can carry them -- layer 2's 1 536 blocks in layer 1's kgw_transform_bwd
+# (round 5: -4 us, one launch less).  A plan of more than _RIDE_MAX_BLOCKS blocks is launched where it is: layer 1's 9 088 blocks riding
+# in the SNP MLP's tall weight-gradient product took the carrier's registers and LDS and ran two per CU -- 78.5 us against 8.3 + 47.1.
+# KGW_DEFER_REDUCE=0: every second launch where it is.
+_DEFER_REDUCE = os.environ.get('KGW_DEFER_REDUCE', '1') != '0'
+_RIDE_MAX_BLOCKS = int(os.environ.get('KGW_RIDE_MAX_BLOCKS', '2048'))
 
 
 class grad_sink_scope:
@@ -608,9 +634,16 @@ def tn_gemm(A: torch.Tensor, B: torch.Tensor, colsum: bool = False, out: torch.T
         # ``defer``: the caller hands (out, cs) to autograd as the gradients of two parameters and nothing else reads them before
         # the optimiser: the row blocks' partial sums are added inside its launch (GradSink)
         src = (_lib.KgwGradSrc * 2)()
-        _lib.check(L.kgw_tn_gemm_partial(_p(A), A.stride(0), M, _p(B), B.stride(0), N, rows, _p(out), out.stride(0),
-                                         1 if transpose_out else 0, _p(cs), _p(ws), nws, _p(rows_dev), src, _lib.stream_ptr()),
-                   'kgw_tn_gemm_partial')
+        ride = sink.take_reduce()
+        if ride is not None:           # (a product group's pending second launch rides in this product's: GradSink.pending_reduce)
+            _lib.check(L.kgw_tn_gemm_partial_ride(_p(A), A.stride(0), M, _p(B), B.stride(0), N, rows, _p(out), out.stride(0),
+                                                  1 if transpose_out else 0, _p(cs), _p(ws), nws, _p(rows_dev), src, C.byref(ride[0]),
+                                                  _lib.stream_ptr()), 'kgw_tn_gemm_partial_ride')
+            sink.reduces_ridden += 1
+        else:
+            _lib.check(L.kgw_tn_gemm_partial(_p(A), A.stride(0), M, _p(B), B.stride(0), N, rows, _p(out), out.stride(0),
+                                             1 if transpose_out else 0, _p(cs), _p(ws), nws, _p(rows_dev), src, _lib.stream_ptr()),
+                       'kgw_tn_gemm_partial')
         sink.add(out, src[0], ws)
         if cs is not None:
             sink.add(cs, src[1], ws)
@@ -1791,6 +1824,7 @@ class _RelVectorsMulti(torch.autograd.Function):
             else:
                 if sink is not None:
                     sink.launch_pending_tail()           # (a fold still pending feeds this launch)
+                    sink.launch_pending_reduce()         # (so does the transform's weight gradient)
                 _lib.check(_lib.lib().kgw_relvec_bwd_multi(live, jobs, _lib.stream_ptr()), 'kgw_relvec_bwd_multi')
         return (None, None, None, None) + tuple(ret)
 
@@ -1916,6 +1950,25 @@ def _transform_bwd_merged(live_blocks, dW, db, dZ, w_src_t, gamma, stat, dgamma,
             g = cs[q]
             g.seg_stat, g.Y, g.ldy, g.rows, g.K = stat.data_ptr() + 8 * z0, dz.data_ptr(), dz.stride(0), rows, R * C
             g.dgamma = dgamma[lo:hi].data_ptr()
+    sink = GRAD_SINK
+    if sink is not None and _DEFER_REDUCE:
+        # the second launch of these products is left pending (the gradients it finishes wait for the end of the backward pass
+        # anyway) and the one an earlier layer left rides in this launch
+        ride = sink.take_reduce()
+        plan = _lib.KgwTnReducePlan()
+        _lib.check(L.kgw_transform_bwd_ex(n, tn, n if dZ is not None else 0, sk, n if gamma is not None else 0, cs,
+                                          _lib.C.byref(ride[0]) if ride is not None else None, _lib.C.byref(plan), _lib.stream_ptr()),
+                   'kgw_transform_bwd_ex')         # (``C`` is the channel count here)
+        if ride is not None:
+            sink.reduces_ridden += 1
+        if plan.valid and plan.blocks > _RIDE_MAX_BLOCKS:
+            # (too many blocks to ride: they would run a few at a time with the carrier's registers and LDS -- launched here)
+            _lib.check(L.kgw_tn_reduce_launch(_lib.C.byref(plan), _lib.stream_ptr()), 'kgw_tn_reduce_launch')
+        elif plan.valid:
+            # (workspaces + the STORAGES of the gradients it writes: see _RelVectorsMulti.backward)
+            sink.pending_reduce = (plan, keep, dW.untyped_storage(), db.untyped_storage())
+            sink.records[db.data_ptr()] = (None, db.numel(), db.untyped_storage())      # (d bias goes straight to its parameter: a copy made on the way must be noticed)
+        return True
     _lib.check(L.kgw_transform_bwd(n, tn, n if dZ is not None else 0, sk, n if gamma is not None else 0, cs, _lib.stream_ptr()),
                'kgw_transform_bwd')
     return True
@@ -2129,6 +2182,7 @@ class _FoldFC(torch.autograd.Function):
         else:
             if sink is not None:
                 sink.launch_pending_tail()
+                sink.launch_pending_reduce()
             _lib.check(_lib.lib().kgw_fold_bwd(C.byref(a), _lib.stream_ptr()), 'kgw_fold_bwd')
         return (dws, dU, dV, None, None) + tuple(dfc)
 

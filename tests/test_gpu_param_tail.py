@@ -1,4 +1,5 @@
-"""-m gpu: the parameter-only END of a captured step's backward pass as ONE launch (round 5, kgw_param_tail, ops.GradSink.flush):
+"""-m gpu: the parameter-only END of a captured step's backward pass as ONE launch (round 5, kgw_param_tail, ops.GradSink.flush)
+and the relation transforms' second launches riding in later launches (KgwTnReducePlan, ops._DEFER_REDUCE):
 the deferred weight-gradient products of the MLPs, the backward of the FC_output fold (kgw_fold_bwd; kgwas/model.py:15,21 folded
 into layer 1) and the backward of the relation vectors of every layer (kgw_relvec_bwd_multi; kgwas/conv.py:138-151) as the blocks
 of one grid.  Every block computes with the expressions and in the order of the kernel it replaces => every gradient, every
@@ -37,12 +38,13 @@ def _fresh(kg, sd0, seed=21):
     return run, sd0
 
 
-def _eager_fused_steps(kg, bs, tail, monkeypatch, sd0, n_steps=3, no_products=False):
+def _eager_fused_steps(kg, bs, tail, monkeypatch, sd0, n_steps=3, no_products=False, defer_reduce=None):
     """``n_steps`` eager steps the way the captured step issues them (GradSink + FusedAdam.step_fused) on one batch."""
     from kgwas_amd import ops
     from kgwas_amd.optim import FusedAdam
     from kgwas_amd.sampler import NeighborLoader
     monkeypatch.setattr(ops, '_PARAM_TAIL', tail)
+    monkeypatch.setattr(ops, '_DEFER_REDUCE', tail if defer_reduce is None else defer_reduce)
     if no_products:
         monkeypatch.setattr(ops.GradSink, 'defer_product', lambda self, *a, **k: None)
     run, sd0 = _fresh(kg, sd0)
@@ -52,7 +54,7 @@ def _eager_fused_steps(kg, bs, tail, monkeypatch, sd0, n_steps=3, no_products=Fa
     ld_w = run._ld_weight_vector()
     opt = FusedAdam(m.parameters(), lr=1e-3, weight_decay=5e-4)
     m.train()
-    losses, taken, grads = [], 0, None
+    losses, taken, grads, ridden = [], 0, None, 0
     for _ in range(n_steps):
         opt.zero_grad()
         loss, _ = m.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id('SNP'), batch.dg.y['SNP'], ld_w)
@@ -63,6 +65,8 @@ def _eager_fused_steps(kg, bs, tail, monkeypatch, sd0, n_steps=3, no_products=Fa
         opt.step_fused(sink)
         assert not sink.records and sink.fold_bwd is None and sink.relvec_bwd is None
         taken += sink.tail_taken
+        ridden += sink.reduces_ridden
+        assert sink.pending_reduce is None
         losses.append(float(loss.detach()))
         if grads is None:
             torch.cuda.synchronize()
@@ -70,15 +74,17 @@ def _eager_fused_steps(kg, bs, tail, monkeypatch, sd0, n_steps=3, no_products=Fa
     torch.cuda.synchronize()
     state = {n: (p.detach().clone(), opt.state[p]['exp_avg'].clone(), opt.state[p]['exp_avg_sq'].clone())
              for n, p in m.named_parameters() if p in opt.state}
-    return losses, grads, state, taken, sd0
+    return losses, grads, state, (taken, ridden), sd0
 
 
-@pytest.mark.parametrize('which,bs,no_products', [('small', 64, False), ('wide', 256, False), ('small', 64, True)])
+@pytest.mark.parametrize('which,bs,no_products', [('small', 64, False), ('wide', 600, False), ('small', 64, True)])
 def test_merged_tail_is_bit_identical_to_the_three_launches(small_kg, wide_kg, which, bs, no_products, monkeypatch):
     kg = small_kg if which == 'small' else wide_kg
     la, ga, sa, ta, sd0 = _eager_fused_steps(kg, bs, True, monkeypatch, None, no_products=no_products)
     lb, gb, sb, tb, _ = _eager_fused_steps(kg, bs, False, monkeypatch, sd0, no_products=no_products)
-    assert ta == 3 and tb == 0, (ta, tb)
+    assert ta[0] == 3 and tb == (0, 0), (ta, tb)
+    if bs > 512:                    # (more than two row blocks of 256 seeds: layer 2's products have a second launch, and it must
+        assert ta[1] == 3, ta       #  have ridden in layer 1's kgw_transform_bwd, every step)
     assert la == lb and any(l > 0 for l in la)
     assert ga.keys() == gb.keys()
     # the tensors the merged launch writes must be among them, and alive
@@ -91,6 +97,21 @@ def test_merged_tail_is_bit_identical_to_the_three_launches(small_kg, wide_kg, w
     for n in sa:
         for x, y, what in zip(sa[n], sb[n], ('parameter', 'exp_avg', 'exp_avg_sq')):
             assert torch.equal(x, y), (n, what)
+
+
+@pytest.mark.parametrize('tail,reduce_', [(False, True), (True, False)])
+def test_each_merge_alone_is_bit_identical_too(wide_kg, tail, reduce_, monkeypatch):
+    """The pending second launches without the merged tail (kgw_fold_bwd / kgw_relvec_bwd_multi then launch them first: they read
+    what the sums finish) and the merged tail without pending second launches."""
+    la, ga, sa, ta, sd0 = _eager_fused_steps(wide_kg, 600, tail, monkeypatch, None, defer_reduce=reduce_)
+    lb, gb, sb, tb, _ = _eager_fused_steps(wide_kg, 600, False, monkeypatch, sd0, defer_reduce=False)
+    assert ta[0] == (3 if tail else 0) and ta[1] == (3 if reduce_ else 0) and tb == (0, 0), (ta, tb)
+    assert la == lb
+    for n in ga:
+        assert torch.equal(ga[n], gb[n]), n
+    for n in sa:
+        for x, y in zip(sa[n], sb[n]):
+            assert torch.equal(x, y), n
 
 
 def test_a_clone_of_a_tail_gradient_is_noticed(small_kg, monkeypatch):
@@ -120,7 +141,7 @@ def test_a_clone_of_a_tail_gradient_is_noticed(small_kg, monkeypatch):
         torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize('which,bs', [('small', 64), ('wide', 256)])
+@pytest.mark.parametrize('which,bs', [('small', 64), ('wide', 600)])
 def test_captured_step_with_the_merged_tail_equals_the_step_without(small_kg, wide_kg, which, bs, monkeypatch):
     from kgwas_amd import ops
     from kgwas_amd.graph_step import GraphTrainStep
@@ -130,6 +151,7 @@ def test_captured_step_with_the_merged_tail_equals_the_step_without(small_kg, wi
     outs, sd0 = [], None
     for tail in (True, False):
         monkeypatch.setattr(ops, '_PARAM_TAIL', tail)
+        monkeypatch.setattr(ops, '_DEFER_REDUCE', tail)
         run, sd0 = _fresh(kg, sd0, seed=13)
         gs = GraphTrainStep(run, ('SNP', ids), bs, lr=1e-3, weight_decay=5e-4)
         assert gs.fused_adam
@@ -137,6 +159,7 @@ def test_captured_step_with_the_merged_tail_equals_the_step_without(small_kg, wi
         losses = [float(gs.step(i)) for i in range(5)]
         totals = gs.check()
         assert gs.tail_taken == (1 if tail else 0), gs.tail_taken
+        assert gs.reduces_ridden == (1 if tail and bs > 512 else 0), gs.reduces_ridden
         outs.append((losses, params_by_name(run.model), totals))
     assert outs[0][0] == outs[1][0] and outs[0][2] == outs[1][2]
     assert any(l > 0 for l in outs[0][0])
