@@ -372,6 +372,15 @@ int kgw_tn_gemm_multi_partial(int32_t n_jobs, const KgwTnJob* jobs, KgwGradSrc* 
  * Riding pays for a SMALL plan only: the blocks take the carrier kernel's registers and LDS, so a carrier built for one or two
  * blocks per CU runs thousands of them a few at a time (measured: layer 1's 9 088 blocks in the SNP product's launch, 78 us against
  * 8 + 47 apart) -- ``blocks`` is there for the caller to decide.                                                               */
+/* The read-out node's SECOND launch in a training step (kgw_readout_wmse_train: the single-block fold of the per-block partial sums
+ * into d w_lin, d b_lin and the loss), not issued: nothing reads the three before the optimiser / the host, so in a captured step the
+ * fold is one more block of the launch that follows (kgw_transform_bwd_ex's fold_in) instead of a 5 us launch of one block.
+ * Filled by kgw_readout_wmse_train_parts; kgw_readout_train_fold runs it as a launch of its own.                                */
+typedef struct KgwReadoutFold {
+    const float* scratch; const double* terms; float* dw_lin; float* db_lin; double* loss;
+    int32_t nb, n;
+} KgwReadoutFold;
+
 typedef struct KgwTnReducePlan { int32_t valid; int32_t blocks /* 256-thread blocks of the launch */; int32_t reserved[2]; int64_t opaque[96]; } KgwTnReducePlan;
 int kgw_tn_reduce_launch(const KgwTnReducePlan* plan, kgw_stream_t stream);
 int kgw_tn_gemm_partial_ride(const float* A, int64_t lda, int32_t M, const float* B, int64_t ldb, int32_t N, int64_t rows,
@@ -507,7 +516,7 @@ int kgw_transform_bwd(int32_t n_tn, const KgwTnJob* tn_jobs, int32_t n_sk, const
  * launch left pending (defer_out): see KgwTnReducePlan.                                                                         */
 int kgw_transform_bwd_ex(int32_t n_tn, const KgwTnJob* tn_jobs, int32_t n_sk, const KgwSplitKJob* sk_jobs, int32_t n_cs,
                          const KgwSplitKJob* cs_jobs, const KgwTnReducePlan* ride_in, KgwTnReducePlan* defer_out,
-                         kgw_stream_t stream);
+                         const KgwReadoutFold* fold_in /* nullable: see KgwReadoutFold */, kgw_stream_t stream);
 
 /* One Adam step (torch.optim.Adam semantics, weight_decay as L2: kgwas/kgwas.py:116,151) over up to 64
  * parameter tensors in a single launch.  The pointer arrays are HOST arrays of device pointers (passed to the
@@ -672,6 +681,12 @@ int kgw_readout_wmse_bwd(const float* H, const float* w_lin, const float* pred, 
 int kgw_readout_wmse_train(const float* H, const float* w_lin, const float* b_lin, const int32_t* n_id, const float* y,
                            const double* w, int32_t n, int64_t rows, int32_t relu, float* pred, double* loss, float* dH,
                            float* dw_lin, float* db_lin, double* terms, float* scratch, kgw_stream_t stream);
+/* kgw_readout_wmse_train's first launch only; *fold_out describes the second (KgwReadoutFold).                                 */
+int kgw_readout_wmse_train_parts(const float* H, const float* w_lin, const float* b_lin, const int32_t* n_id, const float* y,
+                                 const double* w, int32_t n, int64_t rows, int32_t relu, float* pred, double* loss, float* dH,
+                                 float* dw_lin, float* db_lin, double* terms, float* scratch, KgwReadoutFold* fold_out,
+                                 kgw_stream_t stream);
+int kgw_readout_train_fold(const KgwReadoutFold* fold, kgw_stream_t stream);
 
 /* Self-test of the cross-lane reductions used by the aggregate kernels (one wavefront):
  * out_half[l] = sum over l's 32-lane half, out_wave[l] = sum over the wavefront,

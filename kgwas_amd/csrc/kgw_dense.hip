@@ -2583,14 +2583,76 @@ __device__ __forceinline__ void ind_colsum_block256(const ColsumJobs& J, const i
 //   the d gamma sums of a folded layer          (k_ind_colsum)
 // -- as blocks of one grid.  They are independent of each other, each is a few hundred latency-bound blocks at two per CU, and as
 // three launches one after the other each waits for the last block of the one before it.  Same code per block, same values.
+// k_readout_train_fold (one block of 1 024 threads: thread = (c, g), 129 x 7) on a 256-thread block that walks the same (c, g) pairs:
+// the step's read-out fold as ONE MORE block of the launch that follows it (kgw_transform_bwd_ex's fold_in).  lds: >= 1.5 k floats
+__device__ __forceinline__ void readout_train_fold_block256(const KgwReadoutFold& F, float* lds) {
+    float (*sm)[KGW_C + 1] = (float (*)[KGW_C + 1])lds;            // [7][129]
+    double* sd = (double*)(lds + 1024);                            // [256] (8-byte aligned: the LDS base is 16-byte aligned)
+    const float* __restrict__ part = F.scratch;
+    const int nb = F.nb, n = F.n;
+    {   // the thread's (up to) four (c, g) pairs side by side: 16 loads in flight instead of 4 (one pair after the other made this
+        // block's latency 3 x the 1 024-thread kernel's -- longer than the launch it rides in)
+        int cc[4], gg[4];
+        bool ok[4];
+        float a0[4], a1[4], a2[4], a3[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = threadIdx.x + 256 * k;
+            ok[k] = idx < 7 * (KGW_C + 1);
+            cc[k] = ok[k] ? idx % (KGW_C + 1) : 0; gg[k] = ok[k] ? idx / (KGW_C + 1) : 0;
+            a0[k] = a1[k] = a2[k] = a3[k] = 0.f;
+        }
+        // (every pair walks q = g, g + 7, ...: the trip counts differ by at most one between the groups -- the common part unrolled
+        //  over the four pairs, the rest pair by pair, every accumulator in the 1 024-thread kernel's order)
+        int qn = 0;                                            // full rounds of 28 every pair has
+        while (6 + 28 * qn + 21 < nb) ++qn;
+        for (int r = 0; r < qn; ++r) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int q = gg[k] + 28 * r;
+                const float* p = part + (int64_t)q * (KGW_C + 1) + cc[k];
+                a0[k] += p[0]; a1[k] += p[7 * (KGW_C + 1)]; a2[k] += p[14 * (KGW_C + 1)]; a3[k] += p[21 * (KGW_C + 1)];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int q = gg[k] + 28 * qn;
+            for (; q + 21 < nb; q += 28) {
+                a0[k] += part[(int64_t)q * (KGW_C + 1) + cc[k]];        a1[k] += part[(int64_t)(q + 7) * (KGW_C + 1) + cc[k]];
+                a2[k] += part[(int64_t)(q + 14) * (KGW_C + 1) + cc[k]]; a3[k] += part[(int64_t)(q + 21) * (KGW_C + 1) + cc[k]];
+            }
+            for (; q < nb; q += 7) a0[k] += part[(int64_t)q * (KGW_C + 1) + cc[k]];
+            if (ok[k]) sm[gg[k]][cc[k]] = (a0[k] + a1[k]) + (a2[k] + a3[k]);
+        }
+    }
+    {
+        double acc = 0.0;
+        for (int q = threadIdx.x; q < n; q += 256) acc += F.terms[q];
+        sd[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sd[threadIdx.x] += sd[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) F.loss[0] = sd[0] / (double)n;
+    if (threadIdx.x <= KGW_C) {
+        const int c = threadIdx.x;
+        const float t = ((sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c])) + ((sm[4][c] + sm[5][c]) + sm[6][c]);
+        if (c < KGW_C) F.dw_lin[c] = t; else F.db_lin[0] = t;
+    }
+}
+
 // (round 5: + the reduce blocks of an EARLIER product group whose second launch was left pending -- JR, X.n_rd: the last blocks)
-struct TransformBwdIdx { int tn_flat0[TN_MAX_JOBS + 1]; int n_sk, n_tn, n_cs, n_rd, rd_gy, rd_gz; };
+struct TransformBwdIdx { int tn_flat0[TN_MAX_JOBS + 1]; int n_sk, n_tn, n_cs, n_rd, rd_gy, rd_gz, has_fold; KgwReadoutFold fold; };
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_transform_bwd(TnJobs JT, SplitKJobs JS, ColsumJobs JC, TnJobs JR, TransformBwdIdx X) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // (the column-sum blocks first: few, and the longest -- a row walk per block; then the products' row blocks, then the twins)
     const int b = (int)blockIdx.x;
-    if (b >= X.n_cs + X.n_tn + X.n_sk) {
+    if (b >= X.n_cs + X.n_tn + X.n_sk + X.n_rd) {
+        readout_train_fold_block256(X.fold, lds);             // (the very last block, when there is one)
+    } else if (b >= X.n_cs + X.n_tn + X.n_sk) {
         tn_reduce_plan_block(JR, X.rd_gy, X.rd_gz, b - X.n_cs - X.n_tn - X.n_sk, lds);
     } else if (b < X.n_cs) {
         ind_colsum_block256(JC, b, lds);
@@ -2643,13 +2705,18 @@ extern "C" int kgw_tn_reduce_launch(const KgwTnReducePlan* plan, kgw_stream_t st
 
 extern "C" int kgw_transform_bwd_ex(int32_t n_tn, const KgwTnJob* tn_jobs, int32_t n_sk, const KgwSplitKJob* sk_jobs, int32_t n_cs,
                                     const KgwSplitKJob* cs_jobs, const KgwTnReducePlan* ride_in, KgwTnReducePlan* defer_out,
-                                    kgw_stream_t stream_) {
+                                    const KgwReadoutFold* fold_in, kgw_stream_t stream_) {
     if (defer_out) ((TnReducePlan*)defer_out)->valid = 0;
+    if (fold_in && (!fold_in->scratch || !fold_in->terms || !fold_in->dw_lin || !fold_in->db_lin || !fold_in->loss)) return KGW_E_NULL;
+    if (fold_in && (fold_in->n <= 0 || fold_in->nb <= 0)) return KGW_E_RANGE;
     if (n_tn < 0 || n_sk < 0 || n_cs < 0 || n_tn > TN_MAX_JOBS || n_sk > SK_MAX_JOBS || n_cs > SK_MAX_JOBS) return KGW_E_RANGE;
     if ((n_tn && !tn_jobs) || (n_sk && !sk_jobs) || (n_cs && !cs_jobs)) return KGW_E_NULL;
     const TnReducePlan* RI = (const TnReducePlan*)ride_in;
     if (RI && !RI->valid) RI = nullptr;
-    if (n_tn + n_sk + n_cs == 0) return RI ? kgw_tn_reduce_launch(ride_in, stream_) : KGW_OK;
+    if (n_tn + n_sk + n_cs == 0) {
+        if (fold_in) { const int rc = kgw_readout_train_fold(fold_in, stream_); if (rc) return rc; }
+        return RI ? kgw_tn_reduce_launch(ride_in, stream_) : KGW_OK;
+    }
     hipStream_t st = (hipStream_t)stream_;
     auto aligned8 = [](const void* p) { return ((uintptr_t)p & 7) == 0; };
     // weight-gradient products: kgw_tn_gemm_multi's checks and plan (64 x 64-per-wavefront tiling)
@@ -2713,7 +2780,8 @@ extern "C" int kgw_transform_bwd_ex(int32_t n_tn, const KgwTnJob* tn_jobs, int32
     static_assert(lds_bytes >= 2 * 32 * SK_LD * sizeof(float) && lds_bytes >= 32 * 32 * sizeof(float), "one LDS buffer serves the three block kinds");
     TnJobs JRd{};
     if (RI) { JRd = RI->J; X.n_rd = tn_reduce_plan_blocks(*RI); X.rd_gy = RI->gy_max; X.rd_gz = RI->gz_max; }
-    const int total = X.n_sk + X.n_tn + X.n_cs + X.n_rd;
+    if (fold_in) { X.has_fold = 1; X.fold = *fold_in; }
+    const int total = X.n_sk + X.n_tn + X.n_cs + X.n_rd + X.has_fold;
     if (total > 0) {
         k_transform_bwd<<<total, 256, lds_bytes, st>>>(P.J, JS, JC, JRd, X);
         KGW_LAUNCH_CHECK();
@@ -2733,7 +2801,7 @@ extern "C" int kgw_transform_bwd_ex(int32_t n_tn, const KgwTnJob* tn_jobs, int32
 
 extern "C" int kgw_transform_bwd(int32_t n_tn, const KgwTnJob* tn_jobs, int32_t n_sk, const KgwSplitKJob* sk_jobs, int32_t n_cs,
                                  const KgwSplitKJob* cs_jobs, kgw_stream_t stream_) {
-    return kgw_transform_bwd_ex(n_tn, tn_jobs, n_sk, sk_jobs, n_cs, cs_jobs, nullptr, nullptr, stream_);
+    return kgw_transform_bwd_ex(n_tn, tn_jobs, n_sk, sk_jobs, n_cs, cs_jobs, nullptr, nullptr, nullptr, stream_);
 }
 
 extern "C" int kgw_ind_colsum(const float* seg_stat, const float* dY, int64_t ldy, int64_t rows, int32_t R, float* dgamma,
@@ -3653,6 +3721,28 @@ __global__ void __launch_bounds__(1024) k_readout_train_fold(const float* __rest
 }
 
 }  // namespace
+
+extern "C" int kgw_readout_wmse_train_parts(const float* H, const float* w_lin, const float* b_lin, const int32_t* n_id,
+                                            const float* y, const double* w, int32_t n, int64_t rows, int32_t relu, float* pred,
+                                            double* loss, float* dH, float* dw_lin, float* db_lin, double* terms, float* scratch,
+                                            KgwReadoutFold* fold_out, kgw_stream_t stream_) {
+    if (!H || !w_lin || !b_lin || !n_id || !y || !w || !pred || !loss || !dH || !dw_lin || !db_lin || !terms || !scratch || !fold_out)
+        return KGW_E_NULL;
+    if (n <= 0 || rows < n) return KGW_E_RANGE;
+    k_readout_wmse_train<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream_>>>(H, w_lin, b_lin, n_id, y, w, n, rows, relu, pred,
+                                                                                        terms, dH, scratch);
+    KGW_LAUNCH_CHECK();
+    *fold_out = KgwReadoutFold{scratch, terms, dw_lin, db_lin, loss, (n + 3) / 4, n};
+    return KGW_OK;
+}
+
+extern "C" int kgw_readout_train_fold(const KgwReadoutFold* f, kgw_stream_t stream_) {
+    if (!f || !f->scratch || !f->terms || !f->dw_lin || !f->db_lin || !f->loss) return KGW_E_NULL;
+    if (f->n <= 0 || f->nb <= 0) return KGW_E_RANGE;
+    k_readout_train_fold<<<1, 1024, 0, (hipStream_t)stream_>>>(f->scratch, f->nb, f->terms, f->n, f->dw_lin, f->db_lin, f->loss);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
+}
 
 extern "C" int kgw_readout_wmse_fwd(const float* H, const float* w_lin, const float* b_lin, const int32_t* n_id,
                                     const float* y, const double* w, int32_t n, int32_t relu, float* pred,

@@ -206,6 +206,7 @@ class GraphTrainStep:
                 # (launches of the step that carried its parameter-only forward work as rider blocks: the gene layer's kgw_gemm3)
                 self.riders_taken = getattr(self.model, 'last_riders_taken', 0)
                 self.reduces_ridden = sink.reduces_ridden    # (second launches of product groups that rode in a later launch)
+                self.folds_ridden = sink.folds_ridden
                 self.tail_taken = sink.tail_taken          # (kgw_param_tail: the backward's parameter-only end inside the deferred products' launch)
                 if self.overlap:
                     main.wait_stream(self._side)                       # join

@@ -206,6 +206,8 @@ class GradSink:
         self.pending_reduce = None  # (KgwTnReducePlan, keep-alive) of a product group whose second launch is waiting for a carrier
         self.reduces_ridden = 0     # plans that rode in a later launch
         self.keep = []              # operands of launches issued on behalf of others: alive until the optimiser's launch is enqueued
+        self.pending_fold = None    # (KgwReadoutFold, keep-alive): the read-out node's second launch, waiting for a carrier
+        self.folds_ridden = 0
 
     def defer_product(self, dY: torch.Tensor, X: torch.Tensor, rows_dev=None):
         """(dW [out, in], db [out]) = (dY^T X, column sums of dY) of a Linear whose gradients feed only the optimiser -- not launched
@@ -252,6 +254,17 @@ class GradSink:
             self.keep.append(r)
         return r
 
+    def take_fold(self):
+        f, self.pending_fold = self.pending_fold, None
+        if f is not None:
+            self.keep.append(f)
+        return f
+
+    def launch_pending_fold(self):
+        f = self.take_fold()
+        if f is not None:
+            _lib.check(_lib.lib().kgw_readout_train_fold(C.byref(f[0]), _lib.stream_ptr()), 'kgw_readout_train_fold')
+
     def launch_pending_reduce(self):
         r = self.take_reduce()
         if r is not None:
@@ -279,6 +292,7 @@ class GradSink:
         in the same launch, the parameter-only end of the backward pass (kgw_param_tail)."""
         L = _lib.lib()
         self.launch_pending_reduce()                     # (nothing came by to carry it: the tail reads what it finishes)
+        self.launch_pending_fold()
         todo, self.products = sorted(self.products, key=lambda p: -p[0].shape[0]), []       # the tall ones first in the grid
         chunks = [todo[i:i + 4] for i in range(0, len(todo), 4)]
         fb, rb = self.fold_bwd, self.relvec_bwd
@@ -361,6 +375,10 @@ _PARAM_TAIL = os.environ.get('KGW_PARAM_TAIL', '1') != '0'
 # KGW_DEFER_REDUCE=0: every second launch where it is.
 _DEFER_REDUCE = os.environ.get('KGW_DEFER_REDUCE', '1') != '0'
 _RIDE_MAX_BLOCKS = int(os.environ.get('KGW_RIDE_MAX_BLOCKS', '2048'))
+# The read-out node's second launch in a training step (one block that folds the partial sums into d w_lin, d b_lin and the loss: 5 us)
+# is one more block of the launch that follows it in a captured step (layer 2's kgw_transform_bwd_ex).  KGW_DEFER_READOUT_FOLD=0: a
+# launch of its own.
+_DEFER_READOUT_FOLD = os.environ.get('KGW_DEFER_READOUT_FOLD', '1') != '0'
 
 
 class grad_sink_scope:
@@ -1951,17 +1969,21 @@ def _transform_bwd_merged(live_blocks, dW, db, dZ, w_src_t, gamma, stat, dgamma,
             g.seg_stat, g.Y, g.ldy, g.rows, g.K = stat.data_ptr() + 8 * z0, dz.data_ptr(), dz.stride(0), rows, R * C
             g.dgamma = dgamma[lo:hi].data_ptr()
     sink = GRAD_SINK
-    if sink is not None and _DEFER_REDUCE:
+    if sink is not None and (_DEFER_REDUCE or sink.pending_fold is not None):
         # the second launch of these products is left pending (the gradients it finishes wait for the end of the backward pass
         # anyway) and the one an earlier layer left rides in this launch
         ride = sink.take_reduce()
+        fold = sink.take_fold()                    # (the read-out node's second launch: one more block of this one)
         plan = _lib.KgwTnReducePlan()
         _lib.check(L.kgw_transform_bwd_ex(n, tn, n if dZ is not None else 0, sk, n if gamma is not None else 0, cs,
-                                          _lib.C.byref(ride[0]) if ride is not None else None, _lib.C.byref(plan), _lib.stream_ptr()),
+                                          _lib.C.byref(ride[0]) if ride is not None else None, _lib.C.byref(plan),
+                                          _lib.C.byref(fold[0]) if fold is not None else None, _lib.stream_ptr()),
                    'kgw_transform_bwd_ex')         # (``C`` is the channel count here)
         if ride is not None:
             sink.reduces_ridden += 1
-        if plan.valid and plan.blocks > _RIDE_MAX_BLOCKS:
+        if fold is not None:
+            sink.folds_ridden += 1
+        if plan.valid and (plan.blocks > _RIDE_MAX_BLOCKS or not _DEFER_REDUCE):
             # (too many blocks to ride: they would run a few at a time with the carrier's registers and LDS -- launched here)
             _lib.check(L.kgw_tn_reduce_launch(_lib.C.byref(plan), _lib.stream_ptr()), 'kgw_tn_reduce_launch')
         elif plan.valid:
@@ -2268,10 +2290,21 @@ class _ReadoutWeightedMSE(torch.autograd.Function):
             # the caller backpropagates a loss gradient of exactly 1: everything the backward returns is computed here
             dH, dw, db = torch.empty_like(H), torch.empty_like(w_lin), torch.empty(1, device=dev)
             part = torch.empty(((H.shape[0] + 3) // 4) * (KGW_C + 1), device=dev)
-            _lib.check(_lib.lib().kgw_readout_wmse_train(_p(H), _p(w_lin), _p(b_lin), _p(n_id), _p(y_all), _p(w_all), n, H.shape[0],
-                                                         (1 if relu else 0) | (2 if h_is_relu else 0), _p(pred), _p(loss), _p(dH),
-                                                         _p(dw), _p(db), _p(terms), _p(part), _lib.stream_ptr()),
-                       'kgw_readout_wmse_train')
+            ctx.fold = None
+            if _DEFER_READOUT_FOLD:
+                # first launch only: the fold of the partial sums waits for the backward pass, where it rides in the next launch
+                # of a captured step (GradSink.pending_fold) or is launched first thing otherwise
+                f = _lib.KgwReadoutFold()
+                _lib.check(_lib.lib().kgw_readout_wmse_train_parts(_p(H), _p(w_lin), _p(b_lin), _p(n_id), _p(y_all), _p(w_all), n,
+                                                                   H.shape[0], (1 if relu else 0) | (2 if h_is_relu else 0), _p(pred),
+                                                                   _p(loss), _p(dH), _p(dw), _p(db), _p(terms), _p(part), C.byref(f),
+                                                                   _lib.stream_ptr()), 'kgw_readout_wmse_train_parts')
+                ctx.fold = (f, (part, terms, loss))
+            else:
+                _lib.check(_lib.lib().kgw_readout_wmse_train(_p(H), _p(w_lin), _p(b_lin), _p(n_id), _p(y_all), _p(w_all), n, H.shape[0],
+                                                             (1 if relu else 0) | (2 if h_is_relu else 0), _p(pred), _p(loss), _p(dH),
+                                                             _p(dw), _p(db), _p(terms), _p(part), _lib.stream_ptr()),
+                           'kgw_readout_wmse_train')
             ctx.ready = (dH, dw, db)
             return loss, pred
         _lib.check(_lib.lib().kgw_readout_wmse_fwd(_p(H), _p(w_lin), _p(b_lin), _p(n_id), _p(y_all), _p(w_all), n,
@@ -2288,7 +2321,18 @@ class _ReadoutWeightedMSE(torch.autograd.Function):
             dH, dw, db = ctx.ready
             ctx.ready = None
             unit = _UNIT_GRADS.get(gloss.device)
-            if unit is None or gloss.data_ptr() != unit.data_ptr():
+            is_unit = unit is not None and gloss.data_ptr() == unit.data_ptr()
+            fold, ctx.fold = getattr(ctx, 'fold', None), None
+            if fold is not None:
+                sink = GRAD_SINK
+                if sink is not None and is_unit and sink.pending_fold is None:
+                    # (d w_lin / d b_lin go straight to their parameters: storages only + a record, see _RelVectorsMulti.backward)
+                    sink.pending_fold = (fold[0], fold[1], dw.untyped_storage(), db.untyped_storage())
+                    sink.records[dw.data_ptr()] = (None, dw.numel(), dw.untyped_storage())
+                    sink.records[db.data_ptr()] = (None, db.numel(), db.untyped_storage())
+                else:
+                    _lib.check(_lib.lib().kgw_readout_train_fold(C.byref(fold[0]), _lib.stream_ptr()), 'kgw_readout_train_fold')
+            if not is_unit:
                 # the caller did NOT backpropagate the resident 1.0 (a scaled loss, gradient accumulation, plain loss.backward()
                 # with its ones_like): the precomputed gradients are for a loss gradient of 1 -- scale them
                 k = gloss.to(torch.float32)

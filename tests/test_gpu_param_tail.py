@@ -1,5 +1,6 @@
 """-m gpu: the parameter-only END of a captured step's backward pass as ONE launch (round 5, kgw_param_tail, ops.GradSink.flush)
-and the relation transforms' second launches riding in later launches (KgwTnReducePlan, ops._DEFER_REDUCE):
+and the second launches of the relation transforms' products and of the read-out node riding in later launches (KgwTnReducePlan,
+KgwReadoutFold; ops._DEFER_REDUCE, ops._DEFER_READOUT_FOLD):
 the deferred weight-gradient products of the MLPs, the backward of the FC_output fold (kgw_fold_bwd; kgwas/model.py:15,21 folded
 into layer 1) and the backward of the relation vectors of every layer (kgw_relvec_bwd_multi; kgwas/conv.py:138-151) as the blocks
 of one grid.  Every block computes with the expressions and in the order of the kernel it replaces => every gradient, every
@@ -45,6 +46,7 @@ def _eager_fused_steps(kg, bs, tail, monkeypatch, sd0, n_steps=3, no_products=Fa
     from kgwas_amd.sampler import NeighborLoader
     monkeypatch.setattr(ops, '_PARAM_TAIL', tail)
     monkeypatch.setattr(ops, '_DEFER_REDUCE', tail if defer_reduce is None else defer_reduce)
+    monkeypatch.setattr(ops, '_DEFER_READOUT_FOLD', tail if defer_reduce is None else defer_reduce)
     if no_products:
         monkeypatch.setattr(ops.GradSink, 'defer_product', lambda self, *a, **k: None)
     run, sd0 = _fresh(kg, sd0)
@@ -54,19 +56,20 @@ def _eager_fused_steps(kg, bs, tail, monkeypatch, sd0, n_steps=3, no_products=Fa
     ld_w = run._ld_weight_vector()
     opt = FusedAdam(m.parameters(), lr=1e-3, weight_decay=5e-4)
     m.train()
-    losses, taken, grads, ridden = [], 0, None, 0
+    losses, taken, grads, ridden, folds = [], 0, None, 0, 0
     for _ in range(n_steps):
         opt.zero_grad()
-        loss, _ = m.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id('SNP'), batch.dg.y['SNP'], ld_w)
+        loss, _ = m.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id('SNP'), batch.dg.y['SNP'], ld_w, unit_grad=True)
         sink = ops.GradSink()
         with ops.grad_sink_scope(sink):
-            loss.backward()
+            loss.backward(gradient=ops.unit_gradient(loss.device))
         assert (sink.fold_bwd is not None and sink.relvec_bwd is not None) == tail
         opt.step_fused(sink)
         assert not sink.records and sink.fold_bwd is None and sink.relvec_bwd is None
         taken += sink.tail_taken
         ridden += sink.reduces_ridden
-        assert sink.pending_reduce is None
+        folds += sink.folds_ridden
+        assert sink.pending_reduce is None and sink.pending_fold is None
         losses.append(float(loss.detach()))
         if grads is None:
             torch.cuda.synchronize()
@@ -74,7 +77,7 @@ def _eager_fused_steps(kg, bs, tail, monkeypatch, sd0, n_steps=3, no_products=Fa
     torch.cuda.synchronize()
     state = {n: (p.detach().clone(), opt.state[p]['exp_avg'].clone(), opt.state[p]['exp_avg_sq'].clone())
              for n, p in m.named_parameters() if p in opt.state}
-    return losses, grads, state, (taken, ridden), sd0
+    return losses, grads, state, (taken, ridden, folds), sd0
 
 
 @pytest.mark.parametrize('which,bs,no_products', [('small', 64, False), ('wide', 600, False), ('small', 64, True)])
@@ -82,7 +85,7 @@ def test_merged_tail_is_bit_identical_to_the_three_launches(small_kg, wide_kg, w
     kg = small_kg if which == 'small' else wide_kg
     la, ga, sa, ta, sd0 = _eager_fused_steps(kg, bs, True, monkeypatch, None, no_products=no_products)
     lb, gb, sb, tb, _ = _eager_fused_steps(kg, bs, False, monkeypatch, sd0, no_products=no_products)
-    assert ta[0] == 3 and tb == (0, 0), (ta, tb)
+    assert ta[0] == 3 and ta[2] == 3 and tb == (0, 0, 0), (ta, tb)      # (merged tail and the read-out fold as a rider, every step)
     if bs > 512:                    # (more than two row blocks of 256 seeds: layer 2's products have a second launch, and it must
         assert ta[1] == 3, ta       #  have ridden in layer 1's kgw_transform_bwd, every step)
     assert la == lb and any(l > 0 for l in la)
@@ -105,7 +108,7 @@ def test_each_merge_alone_is_bit_identical_too(wide_kg, tail, reduce_, monkeypat
     what the sums finish) and the merged tail without pending second launches."""
     la, ga, sa, ta, sd0 = _eager_fused_steps(wide_kg, 600, tail, monkeypatch, None, defer_reduce=reduce_)
     lb, gb, sb, tb, _ = _eager_fused_steps(wide_kg, 600, False, monkeypatch, sd0, defer_reduce=False)
-    assert ta[0] == (3 if tail else 0) and ta[1] == (3 if reduce_ else 0) and tb == (0, 0), (ta, tb)
+    assert ta[0] == (3 if tail else 0) and ta[1] == (3 if reduce_ else 0) and ta[2] == (3 if reduce_ else 0) and tb == (0, 0, 0), (ta, tb)
     assert la == lb
     for n in ga:
         assert torch.equal(ga[n], gb[n]), n
@@ -152,6 +155,7 @@ def test_captured_step_with_the_merged_tail_equals_the_step_without(small_kg, wi
     for tail in (True, False):
         monkeypatch.setattr(ops, '_PARAM_TAIL', tail)
         monkeypatch.setattr(ops, '_DEFER_REDUCE', tail)
+        monkeypatch.setattr(ops, '_DEFER_READOUT_FOLD', tail)
         run, sd0 = _fresh(kg, sd0, seed=13)
         gs = GraphTrainStep(run, ('SNP', ids), bs, lr=1e-3, weight_decay=5e-4)
         assert gs.fused_adam
@@ -160,6 +164,7 @@ def test_captured_step_with_the_merged_tail_equals_the_step_without(small_kg, wi
         totals = gs.check()
         assert gs.tail_taken == (1 if tail else 0), gs.tail_taken
         assert gs.reduces_ridden == (1 if tail and bs > 512 else 0), gs.reduces_ridden
+        assert gs.folds_ridden == (1 if tail else 0), gs.folds_ridden
         outs.append((losses, params_by_name(run.model), totals))
     assert outs[0][0] == outs[1][0] and outs[0][2] == outs[1][2]
     assert any(l > 0 for l in outs[0][0])
