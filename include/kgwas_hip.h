@@ -435,6 +435,14 @@ int kgw_mlp2_bwd_first_partial(const float* dH2, int64_t ldd, const float* W2, i
                                const float* X, int64_t ldx, int32_t K1, int64_t rows, const int32_t* rows_dev, float* dW1,
                                int64_t ldw1, float* db1, float* workspace, int64_t workspace_floats, const int32_t* in_ids,
                                float* dZ, int64_t ldz, KgwGradSrc* src, kgw_stream_t stream);
+/* ... that ALSO writes the masked dh1 rows as kgw_gemm3's B operand image (packed: kgw_gemm3_packed_bytes(rows rounded up to 32)
+ * bytes, the s_is_kn form of kgw_gemm3_pack; flip = kgw_gemm3_flip()): the resident first layer's weight gradient
+ * (kgwas/model.py:13 under loss.backward(), dW1 = dh1^T X on kgw_gemm3) then needs neither the kgw_gemm3_pack launch nor the fp32
+ * rows -- dZ may be null.  src nullable (null: the fold launch runs here).  KGW_E_UNSUPPORTED: the fp32-pipe variant is selected.  */
+int kgw_mlp2_bwd_first_packed(const float* dH2, int64_t ldd, const float* W2, int64_t ldw2, const float* H1, int64_t ldh1,
+                              const float* X, int64_t ldx, int32_t K1, int64_t rows, float* dW1, int64_t ldw1, float* db1,
+                              float* workspace, int64_t workspace_floats, const int32_t* in_ids, float* dZ, int64_t ldz,
+                              void* packed, int32_t flip, KgwGradSrc* src, kgw_stream_t stream);
 
 /* C[M, 128] = A[M, K] B[K, 128] for a tall RESIDENT fp32 matrix A -- the first gene Linear, kgwas/model.py:13,19 over the
  * 5 120-wide gene features (kgwas_data.py:236,244): forward with A = X [genes, K], B = W1^T (out = relu(C + bias)), and its

@@ -1540,6 +1540,9 @@ struct Mlp2BwdArgs {
     const int32_t* in_ids;              // nullable: row r of the product reads dH2[in_ids[r]]; in_ids[r] < 0 => dh1 row r is zero
     float* dZ; int64_t ldz;             // nullable: the masked dh1 rows are ALSO written here (a wide first layer's own
                                         // weight gradient is a library product over them); K1 = 0 then leaves just d b1
+    uint4* packed; int flip;            // nullable (k_mlp2_bwd_first3 only): the masked dh1 rows ALSO as kgw_gemm3's B operand image
+                                        // ([rows rounded up to 32][128] in three bf16 pieces, kgw_gemm3_pack's s_is_kn form, sign
+                                        // periods of `flip` chunks) -- the wavefront packs the tile it has in LDS anyway
 };
 
 constexpr int TST = 132;                // LDS row stride of the transposing tile
@@ -1855,6 +1858,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     if (a.dZ && row < rows) *(f32x4*)(a.dZ + row * a.ldz + t * 32 + 8 * g + 4 * lk) = v;
                 }
             __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (a.packed) {
+                // k_g3_pack<true>'s work for this half tile: chunk c = tile, item (j, nt, lane) = the eight rows
+                // k = 16 j + 8 (lane >> 5) + i of column 32 nt + (lane & 31); same values, same three pieces, same image index
+                const bool neg = a.flip && ((tile / a.flip) & 1);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int ntl = it & 1, j = it >> 1;
+                    const float* tp = Tw + (16 * j + 8 * lk) * TS2 + 32 * ntl + li;
+                    float x[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[i] = neg ? -tp[i * TS2] : tp[i * TS2];
+                    uint4 p1, p2, p3;
+                    kgw_split3x8(x, p1, p2, p3);
+                    uint4* o = a.packed + (((int64_t)tile * 2 + j) * 3 * 4 + (2 * hh + ntl)) * 64 + lane;
+                    o[0] = p1; o[4 * 64] = p2; o[8 * 64] = p3;
+                }
+            }
 #pragma unroll
             for (int s2 = 0; s2 < 16; ++s2) {
                 const float* tp = Tw + (2 * s2 + lk) * TS2 + li;
@@ -2158,7 +2178,7 @@ extern "C" int64_t kgw_mlp2_bwd_first_workspace_floats(int64_t rows) {
 static int mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2, int64_t ldw2, const float* H1, int64_t ldh1,
                           const float* X, int64_t ldx, int32_t K1, int64_t rows, const int32_t* rows_dev, float* dW1,
                           int64_t ldw1, float* db1, float* workspace, int64_t workspace_floats, const int32_t* in_ids,
-                          float* dZ, int64_t ldz, kgw_stream_t stream_, KgwGradSrc* defer) {
+                          float* dZ, int64_t ldz, kgw_stream_t stream_, KgwGradSrc* defer, void* packed = nullptr, int flip = 0) {
     if (!dH2 || !W2 || !H1 || !db1 || !workspace) return KGW_E_NULL;
     if (defer && K1 > 0 && ldw1 != K1) return KGW_E_UNSUPPORTED;
     if (rows <= 0 || K1 < 0) return KGW_E_RANGE;
@@ -2168,7 +2188,7 @@ static int mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2, int64_
     int64_t nblk = ((rows + 31) / 32 + 3) / 4;
     if (nblk > 256) nblk = 256;
     if (workspace_floats < nblk * 4096) return KGW_E_RANGE;
-    Mlp2BwdArgs a{dH2, ldd, W2, ldw2, H1, ldh1, X, ldx, workspace, rows, K1, rows_dev, in_ids, dZ, ldz};
+    Mlp2BwdArgs a{dH2, ldd, W2, ldw2, H1, ldh1, X, ldx, workspace, rows, K1, rows_dev, in_ids, dZ, ldz, (uint4*)packed, flip};
     const size_t lds = (size_t)(128 * WST + 4 * 32 * TST) * sizeof(float);
     static KgwPerDevice attr_once;
     if (attr_once.need()) {
@@ -2176,6 +2196,7 @@ static int mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2, int64_
     }
     hipStream_t st = (hipStream_t)stream_;
     static const bool split3 = !(getenv("KGW_MLP2_SPLIT") && getenv("KGW_MLP2_SPLIT")[0] == '0');
+    if (packed && (!split3 || rows_dev || ((uintptr_t)packed & 15))) return KGW_E_UNSUPPORTED;     // (the image is written by k_mlp2_bwd_first3 only; every chunk)
     if (split3) {
         const size_t lds3 = (size_t)M3_W2_U4 * 16 + (size_t)(4 * 32 * TS2) * sizeof(float);
         static KgwPerDevice attr3_set;
@@ -2215,6 +2236,20 @@ extern "C" int kgw_mlp2_bwd_first_partial(const float* dH2, int64_t ldd, const f
     if (!src) return KGW_E_NULL;
     return mlp2_bwd_first(dH2, ldd, W2, ldw2, H1, ldh1, X, ldx, K1, rows, rows_dev, dW1, ldw1, db1, workspace, workspace_floats,
                           in_ids, dZ, ldz, stream_, src);
+}
+
+// ... with the masked dh1 rows written as kgw_gemm3's B operand image as well (packed: kgw_gemm3_packed_bytes(rows rounded up to
+// 32) bytes; flip: kgw_gemm3_flip()) -- the k_g3_pack launch of the resident first layer's weight gradient and the fp32 rows it
+// would read disappear (dZ may then be null).  src nullable: null finishes d b1 (/ d W1) with the fold launch.
+extern "C" int kgw_mlp2_bwd_first_packed(const float* dH2, int64_t ldd, const float* W2, int64_t ldw2, const float* H1,
+                                         int64_t ldh1, const float* X, int64_t ldx, int32_t K1, int64_t rows, float* dW1,
+                                         int64_t ldw1, float* db1, float* workspace, int64_t workspace_floats,
+                                         const int32_t* in_ids, float* dZ, int64_t ldz, void* packed, int32_t flip, KgwGradSrc* src,
+                                         kgw_stream_t stream_) {
+    if (!packed) return KGW_E_NULL;
+    if (flip < 0 || (flip & (flip - 1))) return KGW_E_RANGE;
+    return mlp2_bwd_first(dH2, ldd, W2, ldw2, H1, ldh1, X, ldx, K1, rows, nullptr, dW1, ldw1, db1, workspace, workspace_floats,
+                          in_ids, dZ, ldz, stream_, src, packed, flip);
 }
 
 // ======================================================================================================

@@ -375,6 +375,9 @@ _PARAM_TAIL = os.environ.get('KGW_PARAM_TAIL', '1') != '0'
 # KGW_DEFER_REDUCE=0: every second launch where it is.
 _DEFER_REDUCE = os.environ.get('KGW_DEFER_REDUCE', '1') != '0'
 _RIDE_MAX_BLOCKS = int(os.environ.get('KGW_RIDE_MAX_BLOCKS', '2048'))
+# The resident first layer's backward writes d(pre-activation) directly as the kgw_gemm3 operand image of the weight gradient
+# (kgw_mlp2_bwd_first_packed): the kgw_gemm3_pack launch (7 us) and the fp32 rows it read disappear.  KGW_PACK_FUSED=0: as before.
+_PACK_FUSED = os.environ.get('KGW_PACK_FUSED', '1') != '0'
 # The read-out node's second launch in a training step (one block that folds the partial sums into d w_lin, d b_lin and the loss: 5 us)
 # is one more block of the launch that follows it in a captured step (layer 2's kgw_transform_bwd_ex).  KGW_DEFER_READOUT_FOLD=0: a
 # launch of its own.
@@ -1598,11 +1601,27 @@ class _ResidentMLP2(torch.autograd.Function):
         dh2 = dh2.contiguous()
         N = h.shape[0]
         L = _lib.lib()
-        dz = _dz_buffer(h, ctx.shard)
         db1 = torch.empty(KGW_C, device=h.device)
         nws = int(L.kgw_mlp2_bwd_first_workspace_floats(N))
         ws = torch.empty(nws, device=h.device)
         sink = GRAD_SINK
+        if _PACK_FUSED and ctx.shard is None and _resident_ok(X, W1):
+            # the masked dh1 rows leave the kernel as kgw_gemm3's B operand image (the weight gradient's): no fp32 rows, no
+            # kgw_gemm3_pack launch
+            Xt = _resident_copies(X)[1]                  # [K, Np], Np = the node count rounded up to 32
+            packed = torch.empty(int(L.kgw_gemm3_packed_bytes(Xt.shape[1])), dtype=torch.uint8, device=h.device)
+            src = (_lib.KgwGradSrc * 2)()
+            rc = L.kgw_mlp2_bwd_first_packed(_p(dh2), dh2.stride(0), _p(W2), W2.stride(0), _p(h), h.stride(0), None, 0, 0, N, None, 0,
+                                             _p(db1), _p(ws), nws, _p(g2l), None, 0, _p(packed), int(L.kgw_gemm3_flip()),
+                                             src if sink is not None else None, _lib.stream_ptr())
+            if rc != _lib.KGW_E_UNSUPPORTED:
+                _lib.check(rc, 'kgw_mlp2_bwd_first_packed')
+                if sink is not None:
+                    sink.add(db1, src[1], ws)
+                dW1 = gemm3(Xt, packed, transpose_out=True, defer=True)
+                dW2, db2 = linear_weight_grad(dh2, h1g)
+                return None, dW1, db1, dW2, db2, None, None, None, None
+        dz = _dz_buffer(h, ctx.shard)
         if sink is not None:
             src = (_lib.KgwGradSrc * 2)()
             _lib.check(L.kgw_mlp2_bwd_first_partial(_p(dh2), dh2.stride(0), _p(W2), W2.stride(0), _p(h), h.stride(0), None, 0, 0, N, None,

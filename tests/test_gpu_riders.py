@@ -160,3 +160,48 @@ def test_forward_rider_outputs_equal_the_standalone_kernels_tensor_by_tensor(wid
                     assert float(ta.abs().max()) > 0 or name in ('kappa',), (l + 1, name)
                 checked += 1
     assert checked >= 12
+
+
+def test_operand_image_written_by_the_backward_kernel_equals_the_pack_launch(wide_kg, monkeypatch):
+    """Round 5: the resident first layer's backward (kgw_mlp2_bwd_first_packed) writes d(pre-activation) as kgw_gemm3's B operand
+    image itself -- same values, same three bf16 pieces, same sign periods as kgw_gemm3_pack over the fp32 rows: the weight
+    gradient of FC_hidden (kgwas/model.py:13) and everything else must be bit-identical with and without the fused pack, eagerly
+    and in the captured step's fused form (GradSink)."""
+    from kgwas_amd import ops
+    from kgwas_amd.kgwas import KGWAS
+    from kgwas_amd.optim import FusedAdam
+    from kgwas_amd.sampler import NeighborLoader
+    run = KGWAS(wide_kg, device='cuda:0', seed=9)
+    run.initialize_model()
+    m = run.model
+    with torch.no_grad():
+        for pack in list(m.live_packs):
+            pack.bias.normal_(0, 0.1)
+        m.lin.bias.fill_(0.5)
+    ids = np.asarray(wide_kg.train_input_nodes[1][:256])
+    batch = next(iter(NeighborLoader(wide_kg.data, [-1, -1], ('SNP', ids), batch_size=256, device='cuda:0')))
+    ld_w = run._ld_weight_vector()
+    m.train()
+
+    def grads(fused_pack, with_sink):
+        monkeypatch.setattr(ops, '_PACK_FUSED', fused_pack)
+        for p in m.parameters():
+            p.grad = None
+        packs = ops.ROUTES.get('kgw_gemm3_pack', 0)
+        loss, _ = m.forward_loss(batch.x_dict, batch.edge_index_dict, 256, batch.n_id('SNP'), batch.dg.y['SNP'], ld_w)
+        sink = ops.GradSink() if with_sink else None
+        with ops.grad_sink_scope(sink):
+            loss.backward()
+        if sink is not None:
+            # (finish the deferred sums the way the captured step does, without moving the parameters: lr = 0)
+            FusedAdam(m.parameters(), lr=0.0).step_fused(sink)
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    for with_sink in (False, True):
+        ga, gb = grads(True, with_sink), grads(False, with_sink)
+        assert ga.keys() == gb.keys()
+        w1 = [n for n in ga if 'gene_feat_mlp.FC_hidden.weight' in n]
+        assert w1 and float(ga[w1[0]].abs().max()) > 0
+        for n in ga:
+            assert torch.equal(ga[n], gb[n]), (with_sink, n, float((ga[n] - gb[n]).abs().max()))

@@ -20,7 +20,7 @@ data = KGWAS_Data.from_synthetic(scale=1.0, seed=1, mode='fast', gwas_kind='caus
 ids = np.asarray(data.train_input_nodes[1])
 out = []
 for on in (True, False):
-    ops._FUSED_ADAM = ops._MERGED_TRANSFORM_BWD = ops._DEFER_PRODUCTS = ops._DUV_PIECES = ops._G3_RIDERS = ops._PARAM_TAIL = ops._DEFER_REDUCE = ops._DEFER_READOUT_FOLD = on
+    ops._FUSED_ADAM = ops._MERGED_TRANSFORM_BWD = ops._DEFER_PRODUCTS = ops._DUV_PIECES = ops._G3_RIDERS = ops._PARAM_TAIL = ops._DEFER_REDUCE = ops._DEFER_READOUT_FOLD = ops._PACK_FUSED = on
     run = KGWAS(data, device='cuda:0', seed=1)
     run.initialize_model()
     init = lambda v: not isinstance(v, torch.nn.parameter.UninitializedParameter)      # (lazy PyG-style placeholders: never used)
