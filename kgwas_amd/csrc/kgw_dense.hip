@@ -1714,6 +1714,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 // of 16 384 MFMA cycles per 32-row tile.  The masked tile goes through LDS 64 columns at a time (35 KB for the four wavefronts).
 constexpr int TS2 = 68;                 // LDS row stride of the half-width transposing tile
 
+// (PACK: also write the tile as kgw_gemm3's operand image -- a template so that the variant without it keeps its schedule)
+template <bool PACK>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) k_mlp2_bwd_first3(Mlp2BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     uint4* W2p = (uint4*)lds;                                // W2^T operand image: [8 steps][3 pieces][4 column tiles][64 lanes]
@@ -1858,7 +1860,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     if (a.dZ && row < rows) *(f32x4*)(a.dZ + row * a.ldz + t * 32 + 8 * g + 4 * lk) = v;
                 }
             __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (a.packed) {
+            if (PACK) {
                 // k_g3_pack<true>'s work for this half tile: chunk c = tile, item (j, nt, lane) = the eight rows
                 // k = 16 j + 8 (lane >> 5) + i of column 32 nt + (lane & 31); same values, same three pieces, same image index
                 const bool neg = a.flip && ((tile / a.flip) & 1);
@@ -2201,9 +2203,11 @@ static int mlp2_bwd_first(const float* dH2, int64_t ldd, const float* W2, int64_
         const size_t lds3 = (size_t)M3_W2_U4 * 16 + (size_t)(4 * 32 * TS2) * sizeof(float);
         static KgwPerDevice attr3_set;
         if (attr3_set.need()) {
-            KGW_HIP(hipFuncSetAttribute((const void*)k_mlp2_bwd_first3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+            KGW_HIP(hipFuncSetAttribute((const void*)k_mlp2_bwd_first3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+            KGW_HIP(hipFuncSetAttribute((const void*)k_mlp2_bwd_first3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
         }
-        k_mlp2_bwd_first3<<<(int)nblk, 256, lds3, st>>>(a);
+        if (packed) k_mlp2_bwd_first3<true><<<(int)nblk, 256, lds3, st>>>(a);
+        else k_mlp2_bwd_first3<false><<<(int)nblk, 256, lds3, st>>>(a);
     } else {
         k_mlp2_bwd_first<<<(int)nblk, 256, lds, st>>>(a);
     }
