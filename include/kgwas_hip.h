@@ -359,6 +359,13 @@ int kgw_tn_gemm_partial(const float* A, int64_t lda, int32_t M, const float* B, 
                         float* workspace, int64_t workspace_floats, const int32_t* rows_dev, KgwGradSrc* src,
                         kgw_stream_t stream);
 int kgw_tn_gemm_multi_partial(int32_t n_jobs, const KgwTnJob* jobs, KgwGradSrc* src, kgw_stream_t stream);
+/* The products that run on the 64 x 64-per-wavefront tiling (M, N, lda, ldb even, 8-byte aligned operands: every weight-gradient
+ * product of the step but the narrow ones) use the BF16 matrix pipe with fp32 error since round 5: each operand value is split
+ * exactly into three bf16 pieces and the six piece products of weight >= 2^-16 are accumulated in fp32 (the scheme of kgw_gemm3;
+ * the dropped products are below the rounding of one fp32 multiply-add), 24 MFMAs of 32 cycles per 16 rows against 32 of 64 on
+ * the fp32 pipe.  kgw_tn_split(0 / 1) selects the fp32 / bf16 pipe for later calls and returns the previous setting (< 0: query);
+ * the environment variable KGW_TN_SPLIT=0 sets the initial value.                                                              */
+int kgw_tn_split(int on);
 
 /* A product group's SECOND launch (the sums over its row blocks: k_tn_reduce) that has not been issued.  The gradients it
  * finishes -- the relation transform's d W^T / d bias, kgwas/conv.py:138,190 -- feed nothing before the end of the backward pass,

@@ -68,6 +68,14 @@ __device__ __forceinline__ void tn_mma(const Stage<MT, NT>& s, f32x16 (&acc)[MT]
     }
 }
 
+// which matrix pipe the 64 x 64-per-wavefront tiling uses: 1 = bf16 with three exact pieces per operand (default), 0 = fp32
+// (KGW_TN_SPLIT=0, or kgw_tn_split(0): the A/B of tests/test_gpu_dense.py and the fallback)
+static int g_tn_split = -1;
+static bool tn_split_on() {
+    if (g_tn_split < 0) g_tn_split = !(getenv("KGW_TN_SPLIT") && getenv("KGW_TN_SPLIT")[0] == '0');
+    return g_tn_split != 0;
+}
+
 // Up to four products of one tiling per launch (the weight gradients of one MLP: same rows, different operands): the
 // x dimension of the grid is the concatenation of the jobs' row blocks.
 constexpr int TN_MAX_JOBS = 4;
@@ -79,6 +87,74 @@ struct TnJob {
 struct TnJobs { TnJob j[TN_MAX_JOBS]; int n; };
 
 // ws layout per block: [MT][NT][16][64] floats (fragment order) ; colsum ws per block: [32*MT]
+// Rows [r0, r1) of a wavefront's 64 x 64 accumulator on the BF16 matrix pipe with fp32 error (round 5): every operand value is split
+// EXACTLY into three bf16 pieces (kgw_split3x8, as in kgw_gemm3.hip / k_mlp2_bwd_first3) and the six piece products of weight
+// >= 2^-16 are accumulated in fp32 -- the three dropped ones are below the rounding of one fp32 multiply-add.  An MFMA step
+// takes 16 rows (lane group kg the rows 8 kg .. 8 kg + 7, eight float2 loads per operand: the lane's two columns of a row):
+// 24 MFMAs of 32 cycles per 16 rows against 32 of 64 on the fp32 pipe.  The bf16 MFMA's internal add truncates (a small negative
+// mean error): wavefronts with ``neg`` multiply their A values NEGATED (exact) and the caller negates their accumulator back, so
+// the means of the four wavefronts of a block cancel.  sa: the plain column sums of A (fp32 VALU, as before).
+struct TnStage3 { float2 a[8], b[8]; };
+__device__ __forceinline__ void tn_mma3(const TnStage3& s, const unsigned sgn, f32x16 (&acc)[2][2], float (&sa)[2]) {
+    float xa0[8], xa1[8], xb0[8], xb1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sa[0] += s.a[j].x; sa[1] += s.a[j].y;
+        xa0[j] = kgw_fxor(s.a[j].x, sgn); xa1[j] = kgw_fxor(s.a[j].y, sgn);
+        xb0[j] = s.b[j].x; xb1[j] = s.b[j].y;
+    }
+    uint4 pa0[3], pa1[3], pb0[3], pb1[3];
+    kgw_split3x8(xa0, pa0[0], pa0[1], pa0[2]);
+    kgw_split3x8(xa1, pa1[0], pa1[1], pa1[2]);
+    kgw_split3x8(xb0, pb0[0], pb0[1], pb0[2]);
+    kgw_split3x8(xb1, pb1[0], pb1[1], pb1[2]);
+    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};       // (piece of A, piece of B), smallest products first
+#pragma unroll
+    for (int t6 = 0; t6 < 6; ++t6) {
+        const kgw_bf8 a0 = __builtin_bit_cast(kgw_bf8, pa0[TA[t6]]), a1 = __builtin_bit_cast(kgw_bf8, pa1[TA[t6]]);
+        const kgw_bf8 b0 = __builtin_bit_cast(kgw_bf8, pb0[TB[t6]]), b1 = __builtin_bit_cast(kgw_bf8, pb1[TB[t6]]);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void tn_rows_split3(const float* __restrict__ A, const int64_t lda, const int cas, const float* __restrict__ B,
+                                               const int64_t ldb, const int cbs, const int64_t r0, const int64_t r1, const int kg,
+                                               const unsigned sgn, f32x16 (&acc)[2][2], float (&sa)[2]) {
+    const int64_t nfull = (r1 - r0) / 16;                  // steps made of valid rows only
+    const float* pa = A + (r0 + 8 * kg) * lda + cas;
+    const float* pb = B + (r0 + 8 * kg) * ldb + cbs;
+    if (nfull > 0) {
+        TnStage3 cur, nxt;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { cur.a[j] = *(const float2*)(pa + j * lda); cur.b[j] = *(const float2*)(pb + j * ldb); }
+        for (int64_t it = 1; it < nfull; ++it) {
+            pa += 16 * lda; pb += 16 * ldb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { nxt.a[j] = *(const float2*)(pa + j * lda); nxt.b[j] = *(const float2*)(pb + j * ldb); }
+            tn_mma3(cur, sgn, acc, sa);                     // (the next stage's loads in flight under the 24 MFMAs)
+            cur = nxt;
+        }
+        tn_mma3(cur, sgn, acc, sa);
+    }
+    const int64_t rt = r0 + nfull * 16;
+    if (rt < r1) {                                         // tail: < 16 rows, masked per row (loads clamped to the last valid row)
+        TnStage3 t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t row = rt + 8 * kg + j;
+            const bool ok = row < r1;
+            const int64_t rc = ok ? row : (r1 - 1);
+            const float2 va = *(const float2*)(A + rc * lda + cas), vb = *(const float2*)(B + rc * ldb + cbs);
+            t.a[j] = ok ? va : make_float2(0.f, 0.f);
+            t.b[j] = ok ? vb : make_float2(0.f, 0.f);
+        }
+        tn_mma3(t, sgn, acc, sa);
+    }
+}
+
 // (the body of k_tn_gemm: block (bxg = row block over all jobs, by, bz); also inlined into k_transform_bwd)
 template <int MT, int NT>
 __device__ __forceinline__ void tn_gemm_block(const TnJob& T, const int bx, const int by, const int bz, float* lds) {
@@ -115,7 +191,15 @@ __device__ __forceinline__ void tn_gemm_block(const TnJob& T, const int bx, cons
 #pragma unroll
     for (int a = 0; a < MT; ++a) sa[a] = 0.f;
 
-    if (r0 < r1) {
+    unsigned flipm = 0u;                                    // sign of this wavefront's accumulator (the bf16 path's odd wavefronts)
+    bool split3 = false;
+    if constexpr (MT == 2 && NT == 2) split3 = T.pad_ != 0;
+    if (split3) {
+        if constexpr (MT == 2 && NT == 2) {
+            flipm = (wg & 1) ? 0x80000000u : 0u;
+            if (r0 < r1) tn_rows_split3(A, lda, cas, B, ldb, cbs, r0, r1, k, flipm, acc, sa);
+        }
+    } else if (r0 < r1) {
         constexpr int STEP = 2 * TN_U;                      // rows per stage
         const int64_t nfull = (r1 - r0) / STEP;             // stages made of valid rows only
         const float* pa = A + (r0 + k) * lda + cas;
@@ -168,7 +252,7 @@ __device__ __forceinline__ void tn_gemm_block(const TnJob& T, const int bx, cons
 #pragma unroll
             for (int b = 0; b < NT; ++b) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) dst[((a * NT + b) * 16 + e) * 64 + lane] = acc[a][b][e];
+                for (int e = 0; e < 16; ++e) dst[((a * NT + b) * 16 + e) * 64 + lane] = kgw_fxor(acc[a][b][e], flipm);
                 __builtin_amdgcn_sched_barrier(0);
             }
     }
@@ -182,7 +266,7 @@ __device__ __forceinline__ void tn_gemm_block(const TnJob& T, const int bx, cons
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int idx = ((a * NT + b) * 16 + e) * 64 + lane;
-                    dst[idx] = acc[a][b][e] + dst[idx];
+                    dst[idx] = kgw_fxor(acc[a][b][e], flipm) + dst[idx];
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -377,6 +461,9 @@ int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st, KgwGradSrc* defer = n
         T.lda = D.lda; T.ldb = D.ldb; T.rows = D.rows; T.rpw = rpw;
         T.c_rs = D.c_t ? 1 : D.ldc; T.c_cs = D.c_t ? D.ldc : 1; T.cs_ld = D.cs_ld;
         T.M = D.M; T.N = D.N; T.nblk = (int)nblk; T.blk0 = blk; T.gy = gy; T.gz = gz; T.cs_rep = D.cs_rep;
+        // (round 5: the 64 x 64-per-wavefront tiling runs on the bf16 pipe with three exact pieces per operand, tn_rows_split3;
+        //  KGW_TN_SPLIT=0: the fp32 pipe as before)
+        T.pad_ = (MT == 2 && NT == 2 && tn_split_on() && (D.lda & 1) == 0 && (D.ldb & 1) == 0) ? 1 : 0;
         if (defer) {
             // (the fused consumer walks the gradient tensor in its own linear order: it must be dense)
             if (D.ldc != (D.c_t ? D.M : D.N) || (D.colsum && D.cs_rep != 1)) return KGW_E_UNSUPPORTED;
@@ -443,6 +530,12 @@ int launch_tn(const float* A, int64_t lda, int M, const float* B, int64_t ldb, i
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
+
+extern "C" int kgw_tn_split(int on) {
+    const int was = tn_split_on() ? 1 : 0;
+    if (on >= 0) g_tn_split = on ? 1 : 0;
+    return was;
+}
 
 extern "C" int64_t kgw_tn_gemm_workspace_floats(int64_t rows, int M, int N) {
     // upper bound over every tiling the dispatcher may choose

@@ -26,6 +26,65 @@ def test_tn_gemm_matches_fp64(rows, M, N):
     assert_close(cs, A.double().sum(0), 1e-5, 1e-6, 'colsum', rel_to_max=2e-6)
 
 
+@pytest.mark.parametrize('rows,M,N', [(122880, 128, 128), (20032, 128, 128), (7000, 128, 768), (1700, 128, 1408), (300, 64, 64)])
+def test_tn_gemm_on_the_bf16_pipe_is_as_close_to_float64_as_on_the_fp32_pipe(rows, M, N):
+    """Round 5: the 64 x 64-per-wavefront tiling (every weight-gradient product of the step but the narrow ones: dW = dY^T X of the
+    MLPs' Linears, kgwas/model.py:13-21, and of the relation transforms, kgwas/conv.py:138) runs on the bf16 matrix pipe with each
+    operand split exactly into three bf16 pieces (tn_rows_split3).  Against float64, operands spread over 2^-12 .. 2^12 so that
+    every piece carries signal: the error relative to sum |a||b| must be no worse than 1.25 x the fp32 pipe's on the same data
+    (kgw_tn_split(0)) and far below the K u bound; results are deterministic; the column sums are untouched."""
+    from kgwas_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator(device='cuda').manual_seed(rows + N)
+    A = torch.randn(rows, M, device='cuda', generator=g) * torch.exp2(torch.randint(-12, 13, (rows, M), device='cuda', generator=g).float())
+    B = torch.randn(rows, N, device='cuda', generator=g) * torch.exp2(torch.randint(-6, 7, (rows, N), device='cuda', generator=g).float())
+    ref = A.double().t() @ B.double()
+    sc = A.double().abs().t() @ B.double().abs()
+    was = L.kgw_tn_split(1)
+    try:
+        C3, cs3 = ops.tn_gemm(A, B, colsum=True)
+        C3b = ops.tn_gemm(A, B)
+        L.kgw_tn_split(0)
+        C32, cs32 = ops.tn_gemm(A, B, colsum=True)
+    finally:
+        L.kgw_tn_split(was)
+    assert torch.equal(C3, C3b)
+    e3 = ((C3.double() - ref).abs() / sc).max().item()
+    e32 = ((C32.double() - ref).abs() / sc).max().item()
+    print(f'[tn split] {rows}x{M}x{N}: max error / sum|a||b| bf16x3 {e3:.3e}, fp32 pipe {e32:.3e}')
+    assert e3 <= max(1.25 * e32, 4 * 2.0 ** -24), (e3, e32)
+    assert e3 <= 16 * 2.0 ** -24, e3
+    assert float((C3 - C32).abs().max()) > 0 or rows < 64, 'the two pipes were not both exercised'
+    assert_close(cs3, A.double().sum(0), 1e-5, 1e-6, 'colsum', rel_to_max=2e-6)
+
+
+@pytest.mark.parametrize('rows', [122880, 20032])
+def test_tn_gemm_on_the_bf16_pipe_has_no_one_sided_error(rows):
+    """The bf16 MFMA's internal add truncates (a negative mean error, see tests/test_gpu_gemm3.py): a weight gradient with a
+    one-sided error is what an optimiser integrates.  Odd wavefronts therefore accumulate the NEGATED product and are negated
+    back (exact), so the means cancel inside every block.  Positive operands (every partial sum has one sign: the worst case), the
+    step's tall shapes: the mean error must be within 2 x the fp32 pipe's own or a tenth of the mean absolute error, and the mean
+    absolute error no worse than the fp32 pipe's."""
+    from kgwas_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator(device='cuda').manual_seed(7)
+    A = torch.rand(rows, 128, device='cuda', generator=g)
+    B = torch.rand(rows, 128, device='cuda', generator=g) * (4.0 * 57.0 / rows)            # results ~57
+    ref = A.double().t() @ B.double()
+    was = L.kgw_tn_split(1)
+    try:
+        C3 = ops.tn_gemm(A, B)
+        L.kgw_tn_split(0)
+        C32 = ops.tn_gemm(A, B)
+    finally:
+        L.kgw_tn_split(was)
+    e3, e32 = C3.double() - ref, C32.double() - ref
+    m3, m32, a3, a32 = e3.mean().item(), e32.mean().item(), e3.abs().mean().item(), e32.abs().mean().item()
+    print(f'[tn split bias] rows={rows}: mean error {m3:.3e} (fp32 pipe {m32:.3e}), mean |error| {a3:.3e} ({a32:.3e}), mean result {ref.mean().item():.1f}')
+    assert abs(m3) <= max(2.0 * abs(m32), 0.1 * a3), (m3, m32)
+    assert a3 <= 1.25 * a32, (a3, a32)
+
+
 def test_tn_gemm_strided_inputs_and_determinism():
     from kgwas_amd import ops
     g = torch.Generator().manual_seed(0)
