@@ -1853,6 +1853,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
         for (int q = 0; q < 16; ++q) xa[q] = *(const f32x4*)(xp + 4 * q);
     }
+    // ReLU mask of this lane's row (columns 32 t + 8 g + 4 lk + c) as bits.  Round 5: the NEXT tile's mask rows are requested at the
+    // start of a tile's first product and turned into bits after its second (with one wavefront per SIMD nothing else hides the
+    // latency: fetched in four groups inside the product that consumes them, 50 % of the kernel's cycles were s_waitcnt).
+#define KGW_MLPB_BITS(MV, MB)                                                                            \
+    _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) _Pragma("unroll") for (int g = 0; g < 4; ++g) {    \
+        const int b0 = (t_ & 1) * 16 + 4 * g;                                                            \
+        MB[t_ >> 1] |= (MV[t_][g].x > 0.f ? 1u : 0u) << (b0 + 0);                                        \
+        MB[t_ >> 1] |= (MV[t_][g].y > 0.f ? 1u : 0u) << (b0 + 1);                                        \
+        MB[t_ >> 1] |= (MV[t_][g].z > 0.f ? 1u : 0u) << (b0 + 2);                                        \
+        MB[t_ >> 1] |= (MV[t_][g].w > 0.f ? 1u : 0u) << (b0 + 3);                                        \
+    }
+    unsigned mb[2] = {0u, 0u};
+    {
+        int64_t r = (int64_t)(tile < ntiles ? tile : ntiles - 1) * 32 + li;
+        if (r >= rows) r = rows - 1;
+        const float* mp = a.H1 + r * a.ldm + 4 * lk;
+        f32x4 mv[4][4];
+#pragma unroll
+        for (int t_ = 0; t_ < 4; ++t_)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mv[t_][g] = *(const f32x4*)(mp + t_ * 32 + 8 * g);
+        KGW_MLPB_BITS(mv, mb)
+    }
     for (; tile < ntiles; tile += nw) {
         const int64_t r0 = (int64_t)tile * 32;
         const int64_t row = r0 + li;
@@ -1877,19 +1900,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             if (rr < rows) v = li < K1 ? a.X[rr * a.ldx + li] : (li == K1 ? 1.f : 0.f);
             xs[s2] = v;
         }
-        // ReLU mask of this lane's row (columns 32 t + 8 g + 4 lk + c), fetched under the MFMAs, kept as bits
-        const float* mp = a.H1 + rc * a.ldm + 4 * lk;
-        unsigned mb[2] = {0u, 0u};
-        f32x4 mv[4];
-#define KGW_MLPB_MFETCH(T)                                                                                \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) mv[g] = *(const f32x4*)(mp + (T) * 32 + 8 * g);
-#define KGW_MLPB_MBITS(T)                                                                                 \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                  \
-            const int b0 = ((T) & 1) * 16 + 4 * g;                                                        \
-            mb[(T) >> 1] |= (mv[g].x > 0.f ? 1u : 0u) << (b0 + 0);                                        \
-            mb[(T) >> 1] |= (mv[g].y > 0.f ? 1u : 0u) << (b0 + 1);                                        \
-            mb[(T) >> 1] |= (mv[g].z > 0.f ? 1u : 0u) << (b0 + 2);                                        \
-            mb[(T) >> 1] |= (mv[g].w > 0.f ? 1u : 0u) << (b0 + 3);                                        \
+        // the NEXT tile's mask rows: requested now, read after this tile's second product
+        f32x4 mvn[4][4];
+        {
+            int nt = tile + nw;
+            if (nt >= ntiles) nt = ntiles - 1;
+            int64_t r = (int64_t)nt * 32 + li;
+            if (r >= rows) r = rows - 1;
+            const float* mpn = a.H1 + r * a.ldm + 4 * lk;
+#pragma unroll
+            for (int t_ = 0; t_ < 4; ++t_)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) mvn[t_][g] = *(const f32x4*)(mpn + t_ * 32 + 8 * g);
         }
         f32x16 acc[4];
 #pragma unroll
@@ -1899,11 +1921,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         // first product on the bf16 pipe (three exact pieces per operand): 8 steps x 6 piece products x 4 column tiles
 #pragma unroll
         for (int s_ = 0; s_ < 8; ++s_) {
-            if (s_ == 0) { KGW_MLPB_MFETCH(0) }
-            if (s_ == 1) { KGW_MLPB_MBITS(0) KGW_MLPB_MFETCH(1) }
-            if (s_ == 3) { KGW_MLPB_MBITS(1) KGW_MLPB_MFETCH(2) }
-            if (s_ == 5) { KGW_MLPB_MBITS(2) KGW_MLPB_MFETCH(3) }
-            if (s_ == 7) { KGW_MLPB_MBITS(3) }
             const f32x4 u = xa[2 * s_], v = xa[2 * s_ + 1];
             // odd rows are multiplied NEGATED (exact) and their result negated back: the bf16 MFMA's internal addition truncates
             // (a small negative mean error), and dW1 / db1 sum dh1 over the rows -- with alternating signs the means cancel
@@ -1930,8 +1947,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-#undef KGW_MLPB_MFETCH
-#undef KGW_MLPB_MBITS
         if (!live) { mb[0] = 0u; mb[1] = 0u; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1979,7 +1994,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             }
             __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the tile is rewritten next)
         }
+        mb[0] = 0u; mb[1] = 0u;
+        KGW_MLPB_BITS(mvn, mb)
     }
+#undef KGW_MLPB_BITS
     // the block's four partial C's through LDS (fragment order), added in wavefront order
     __syncthreads();
     float* R = lds;                                           // 4 x 4096 floats over the operand image (done with)

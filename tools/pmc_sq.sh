@@ -3,7 +3,7 @@
 out=gpurun_out/pmc_sq
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-.}
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $out -o sq -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing > $out/sq.json 2> $out/sq.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $out -o sq -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-pmc --no-epoch > $out/sq.json 2> $out/sq.err
 python - "$out" <<'PY'
 import csv, sys, collections
 out = sys.argv[1]
@@ -11,7 +11,7 @@ rows = list(csv.DictReader(open(out + '/sq_counter_collection.csv')))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')[:34]
-    if any(t in k for t in ('k_agg', 'k_linear_wreg', 'k_tn_gemm')):
+    if any(t in k for t in ('k_agg', 'k_linear_wreg', 'k_tn_gemm', 'k_mlp2', 'k_param_tail', 'k_adam', 'k_transform', 'k_linear_splitk', 'k_g3')):
         agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in agg.items():
     # the largest dispatch of each kernel (layer 1)
