@@ -157,7 +157,7 @@ class KgwFoldArgs(C.Structure):
 EXPORTS = ['kgw_version', 'kgw_status_string', 'kgw_struct_sizes', 'kgw_sample_batch', 'kgw_sample_batch_parts', 'kgw_sampler_scan_ints',
            'kgw_softmax_pack', 'kgw_softmax_merge', 'kgw_scatter_rows', 'kgw_linear_splitk', 'kgw_linear_splitk_workspace_floats', 'kgw_linear_splitk_ind', 'kgw_ind_colsum', 'kgw_linear_splitk_multi', 'kgw_ind_colsum_multi', 'kgw_fold_fwd', 'kgw_fold_bwd', 'kgw_relation_sums',
            'kgw_gat_aggregate_fwd', 'kgw_gat_aggregate_bwd_dst', 'kgw_gat_aggregate_bwd_src',
-           'kgw_gather_rows', 'kgw_gather_rows_multi', 'kgw_scatter_relu_rows', 'kgw_scatter_relu_rows_workspace_floats', 'kgw_edge_alpha', 'kgw_debug_reduce', 'kgw_debug_reduce8', 'kgw_tn_gemm', 'kgw_tn_gemm_ex', 'kgw_tn_gemm_multi', 'kgw_tn_gemm_workspace_floats', 'kgw_tn_gemm_partial', 'kgw_tn_gemm_multi_partial', 'kgw_tn_split', 'kgw_param_tail', 'kgw_tn_reduce_launch', 'kgw_tn_gemm_partial_ride', 'kgw_transform_bwd_ex', 'kgw_mlp2_bwd_first_partial', 'kgw_mlp2_bwd_first_packed', 'kgw_adam_fused', 'kgw_gemm3_partial', 'kgw_gemm3_flip', 'kgw_transform_bwd', 'kgw_grad_finish',
+           'kgw_gather_rows', 'kgw_gather_rows_multi', 'kgw_scatter_relu_rows', 'kgw_scatter_relu_rows_workspace_floats', 'kgw_edge_alpha', 'kgw_debug_reduce', 'kgw_debug_reduce8', 'kgw_tn_gemm', 'kgw_tn_gemm_ex', 'kgw_tn_gemm_multi', 'kgw_tn_gemm_workspace_floats', 'kgw_tn_gemm_partial', 'kgw_tn_gemm_multi_partial', 'kgw_tn_split', 'kgw_tn_direct_rows', 'kgw_param_tail', 'kgw_tn_reduce_launch', 'kgw_tn_gemm_partial_ride', 'kgw_transform_bwd_ex', 'kgw_mlp2_bwd_first_partial', 'kgw_mlp2_bwd_first_packed', 'kgw_adam_fused', 'kgw_gemm3_partial', 'kgw_gemm3_flip', 'kgw_transform_bwd', 'kgw_grad_finish',
            'kgw_linear', 'kgw_mlp2_fwd', 'kgw_mlp2w_fwd', 'kgw_mlp2_bwd_first', 'kgw_mlp2_bwd_first_workspace_floats', 'kgw_gemm3', 'kgw_gemm3_riders', 'kgw_gemm3_rider_blocks', 'kgw_gemm3_pack', 'kgw_gemm3_packed_bytes', 'kgw_gemm3_workspace_floats', 'kgw_adam', 'kgw_adam_notick', 'kgw_relvec_fwd', 'kgw_relvec_bwd', 'kgw_relvec_bwd_acc', 'kgw_relvec_fwd_multi', 'kgw_relvec_bwd_multi', 'kgw_wmse_fwd', 'kgw_wmse_bwd', 'kgw_readout_wmse_fwd', 'kgw_readout_wmse_bwd', 'kgw_readout_wmse_train', 'kgw_readout_wmse_train_parts', 'kgw_readout_train_fold', 'kgw_accumulate_stats', 'kgw_accumulate_stats_tick']
 
 _lib = None
@@ -278,6 +278,8 @@ def lib():
                                     C.c_void_p]
     L.kgw_transform_bwd_ex.argtypes = L.kgw_transform_bwd.argtypes[:-1] + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.kgw_tn_reduce_launch.argtypes = [C.c_void_p, C.c_void_p]
+    L.kgw_tn_direct_rows.restype = C.c_int64
+    L.kgw_tn_direct_rows.argtypes = [C.c_int64]
     L.kgw_tn_gemm_partial_ride.argtypes = L.kgw_tn_gemm_partial.argtypes[:-1] + [C.c_void_p, C.c_void_p]
     L.kgw_wmse_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_void_p, C.c_void_p]
     L.kgw_wmse_bwd.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]

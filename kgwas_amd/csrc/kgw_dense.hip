@@ -76,6 +76,12 @@ static bool tn_split_on() {
     return g_tn_split != 0;
 }
 
+static int64_t g_tn_direct = -1;
+static int64_t tn_direct_rows() {
+    if (g_tn_direct < 0) g_tn_direct = getenv("KGW_TN_DIRECT_ROWS") ? atoll(getenv("KGW_TN_DIRECT_ROWS")) : 0;
+    return g_tn_direct;
+}
+
 // Up to four products of one tiling per launch (the weight gradients of one MLP: same rows, different operands): the
 // x dimension of the grid is the concatenation of the jobs' row blocks.
 constexpr int TN_MAX_JOBS = 4;
@@ -445,10 +451,14 @@ int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st, KgwGradSrc* defer = n
         if (cap < 1) cap = 1;
         if (nblk > cap) nblk = cap;
         if (nblk < 1) nblk = 1;
-        // (forcing ONE row block for up to ~2 k rows to save the second launch was measured and lost: the step went
-        // 1.491 -> 1.501 ms at 640 rows, 1.513 at 2048 -- the serial row loop costs more than the launch; a product that has
-        // a single row block anyway writes its result directly)
-        static const int64_t direct_max = getenv("KGW_TN_DIRECT_ROWS") ? atoll(getenv("KGW_TN_DIRECT_ROWS")) : 0;
+        // (ONE row block for a product of up to n rows and >= 16 tiles -- its blocks write the result directly, no partial slabs, no
+        //  second launch -- is NOT the default.  On the fp32 pipe it lost: 1.491 -> 1.501 ms at 640 rows, 1.513 at 2048, the serial
+        //  row loop cost more than the launch.  On the bf16 pipe it wins a little -- layer 1's transform products, 1 171 rows x 68
+        //  tiles, without their 9 088-block k_tn_reduce: 1.0594 / 1.0559 against 1.0600 / 1.0619 ms, 26 -> 25 launches -- but a
+        //  wavefront then accumulates ~27 MFMA steps in one accumulator and the truncating add shows: max error / sum|a||b| 4.2e-7
+        //  against the fp32 pipe's 2.0e-7 at 1 700 x 128 x 1 408, outside the 1.25 x this build holds the bf16 pipe to
+        //  (tests/test_gpu_dense.py).  kgw_tn_direct_rows(n) / KGW_TN_DIRECT_ROWS=n turn it on.)
+        const int64_t direct_max = tn_direct_rows();
         if (D.rows <= direct_max && (int64_t)gy * gz >= 16) nblk = 1;
         all_direct = all_direct && nblk == 1;
         int64_t rpw = (D.rows + nblk * 4 - 1) / (nblk * 4);
@@ -530,6 +540,12 @@ int launch_tn(const float* A, int64_t lda, int M, const float* B, int64_t ldb, i
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
+
+extern "C" int64_t kgw_tn_direct_rows(int64_t rows) {
+    const int64_t was = tn_direct_rows();
+    if (rows >= 0) g_tn_direct = rows;
+    return was;
+}
 
 extern "C" int kgw_tn_split(int on) {
     const int was = tn_split_on() ? 1 : 0;

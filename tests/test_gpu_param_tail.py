@@ -14,6 +14,16 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[0, 2048], ids=['two_launch_products', 'direct_products'])
+def direct_rows(request):
+    """Layer 2's transform products have a second launch (the one that rides in layer 1's kgw_transform_bwd) only when products of a
+    few hundred rows are NOT run as one row block: both settings of kgw_tn_direct_rows (the shipped 0; 2 048)."""
+    from kgwas_amd import _lib
+    was = _lib.lib().kgw_tn_direct_rows(request.param)
+    yield request.param
+    _lib.lib().kgw_tn_direct_rows(was)
+
+
 @pytest.fixture(scope='module')
 def wide_kg():
     from kgwas_amd.kgwas_data import KGWAS_Data
@@ -81,12 +91,12 @@ def _eager_fused_steps(kg, bs, tail, monkeypatch, sd0, n_steps=3, no_products=Fa
 
 
 @pytest.mark.parametrize('which,bs,no_products', [('small', 64, False), ('wide', 600, False), ('small', 64, True)])
-def test_merged_tail_is_bit_identical_to_the_three_launches(small_kg, wide_kg, which, bs, no_products, monkeypatch):
+def test_merged_tail_is_bit_identical_to_the_three_launches(small_kg, wide_kg, which, bs, no_products, monkeypatch, direct_rows):
     kg = small_kg if which == 'small' else wide_kg
     la, ga, sa, ta, sd0 = _eager_fused_steps(kg, bs, True, monkeypatch, None, no_products=no_products)
     lb, gb, sb, tb, _ = _eager_fused_steps(kg, bs, False, monkeypatch, sd0, no_products=no_products)
     assert ta[0] == 3 and ta[2] == 3 and tb == (0, 0, 0), (ta, tb)      # (merged tail and the read-out fold as a rider, every step)
-    if bs > 512:                    # (more than two row blocks of 256 seeds: layer 2's products have a second launch, and it must
+    if bs > 512 and direct_rows == 0:   # (more than two row blocks of 256 seeds: layer 2's products have a second launch, and it must
         assert ta[1] == 3, ta       #  have ridden in layer 1's kgw_transform_bwd, every step)
     assert la == lb and any(l > 0 for l in la)
     assert ga.keys() == gb.keys()
@@ -103,12 +113,12 @@ def test_merged_tail_is_bit_identical_to_the_three_launches(small_kg, wide_kg, w
 
 
 @pytest.mark.parametrize('tail,reduce_', [(False, True), (True, False)])
-def test_each_merge_alone_is_bit_identical_too(wide_kg, tail, reduce_, monkeypatch):
+def test_each_merge_alone_is_bit_identical_too(wide_kg, tail, reduce_, monkeypatch, direct_rows):
     """The pending second launches without the merged tail (kgw_fold_bwd / kgw_relvec_bwd_multi then launch them first: they read
     what the sums finish) and the merged tail without pending second launches."""
     la, ga, sa, ta, sd0 = _eager_fused_steps(wide_kg, 600, tail, monkeypatch, None, defer_reduce=reduce_)
     lb, gb, sb, tb, _ = _eager_fused_steps(wide_kg, 600, False, monkeypatch, sd0, defer_reduce=False)
-    assert ta[0] == (3 if tail else 0) and ta[1] == (3 if reduce_ else 0) and ta[2] == (3 if reduce_ else 0) and tb == (0, 0, 0), (ta, tb)
+    assert ta[0] == (3 if tail else 0) and ta[1] == (3 if reduce_ and direct_rows == 0 else 0) and ta[2] == (3 if reduce_ else 0) and tb == (0, 0, 0), (ta, tb)
     assert la == lb
     for n in ga:
         assert torch.equal(ga[n], gb[n]), n
@@ -145,7 +155,7 @@ def test_a_clone_of_a_tail_gradient_is_noticed(small_kg, monkeypatch):
 
 
 @pytest.mark.parametrize('which,bs', [('small', 64), ('wide', 600)])
-def test_captured_step_with_the_merged_tail_equals_the_step_without(small_kg, wide_kg, which, bs, monkeypatch):
+def test_captured_step_with_the_merged_tail_equals_the_step_without(small_kg, wide_kg, which, bs, monkeypatch, direct_rows):
     from kgwas_amd import ops
     from kgwas_amd.graph_step import GraphTrainStep
     from tests.helpers import params_by_name
@@ -163,7 +173,7 @@ def test_captured_step_with_the_merged_tail_equals_the_step_without(small_kg, wi
         losses = [float(gs.step(i)) for i in range(5)]
         totals = gs.check()
         assert gs.tail_taken == (1 if tail else 0), gs.tail_taken
-        assert gs.reduces_ridden == (1 if tail and bs > 512 else 0), gs.reduces_ridden
+        assert gs.reduces_ridden == (1 if tail and bs > 512 and direct_rows == 0 else 0), gs.reduces_ridden
         assert gs.folds_ridden == (1 if tail else 0), gs.folds_ridden
         outs.append((losses, params_by_name(run.model), totals))
     assert outs[0][0] == outs[1][0] and outs[0][2] == outs[1][2]
