@@ -80,6 +80,23 @@ def test_abi_struct_sizes_and_argument_checks():
     assert lib.kgw_grad_finish(3, None, None, None, None, None) == -1
     assert lib.kgw_grad_finish(_lib.ADAM_FUSED_MAX + 1, None, None, None, None, None) == -2
     assert lib.kgw_grad_finish(0, None, None, None, None, None) == 0
+    # round 5's launch merges: range / null checks before any launch, the plan / fold records' sizes, the pipe and row-block knobs
+    assert lib.kgw_param_tail(-1, None, None, None, 0, None, 0, None) == -2
+    assert lib.kgw_param_tail(2, None, None, None, 0, None, 0, None) == -1
+    assert lib.kgw_param_tail(0, None, None, None, 0, None, 0, None) == 0                 # nothing to do
+    assert lib.kgw_tn_reduce_launch(None, None) == -1
+    plan = _lib.KgwTnReducePlan()
+    assert C.sizeof(plan) == 16 + 96 * 8 and lib.kgw_tn_reduce_launch(C.byref(plan), None) == 0      # valid == 0: nothing pending
+    assert lib.kgw_transform_bwd_ex(0, None, 0, None, 0, None, C.byref(plan), None, None, None) == 0
+    assert lib.kgw_transform_bwd_ex(5, None, 0, None, 0, None, None, None, None, None) == -2
+    fold = _lib.KgwReadoutFold()
+    assert C.sizeof(fold) == 48 and lib.kgw_readout_train_fold(None, None) == -1 and lib.kgw_readout_train_fold(C.byref(fold), None) == -1
+    assert lib.kgw_transform_bwd_ex(0, None, 0, None, 0, None, None, None, C.byref(fold), None) == -1     # a fold record without pointers
+    assert lib.kgw_mlp2_bwd_first_packed(None, 0, None, 0, None, 0, None, 0, 0, 64, None, 0, None, None, 0, None, None, 0, None, 16, None,
+                                         None) == -1
+    assert lib.kgw_tn_split(-1) in (0, 1) and lib.kgw_tn_direct_rows(-1) >= 0
+    was = lib.kgw_tn_split(0)
+    assert lib.kgw_tn_split(was) == 0 and lib.kgw_tn_split(-1) == was
     assert lib.kgw_scatter_relu_rows(None, None, None, 8, None, None, None, None) == -1
     assert lib.kgw_scatter_relu_rows_workspace_floats(20032) == 256 * 128
     assert lib.kgw_tn_gemm_workspace_floats(1000, 128, 128) > 0
