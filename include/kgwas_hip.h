@@ -367,9 +367,9 @@ int kgw_tn_gemm_multi_partial(int32_t n_jobs, const KgwTnJob* jobs, KgwGradSrc* 
  * the environment variable KGW_TN_SPLIT=0 sets the initial value.                                                              */
 int kgw_tn_split(int on);
 /* Products of up to this many rows (and at least 16 output tiles) run as ONE row block whose blocks write the result directly: no
- * partial slabs, no second launch.  Default 0 (never): measured -3 us per step and one launch less at 2 048, but the long
- * in-accumulator sums of the bf16 pipe then show twice the fp32 pipe's error.  Sets the limit for later calls (< 0: query), returns
- * the previous one; KGW_TN_DIRECT_ROWS sets the initial value.                                                                  */
+ * partial slabs, no second launch.  Default 0 (never): measured -3 us per step and one launch less at 2 048, but a wavefront's
+ * seven-times longer sum then shows twice the error of the row-blocked form (on either pipe).  Sets the limit for later calls
+ * (< 0: query), returns the previous one; KGW_TN_DIRECT_ROWS sets the initial value.                                           */
 int64_t kgw_tn_direct_rows(int64_t rows);
 
 /* A product group's SECOND launch (the sums over its row blocks: k_tn_reduce) that has not been issued.  The gradients it

@@ -126,9 +126,22 @@ __device__ __forceinline__ void tn_mma3(const TnStage3& s, const unsigned sgn, f
     }
 }
 
+// (sign periods, as in kgw_gemm3: every TN3_FLIP steps the accumulator and the sign of the A operand flip together -- exact -- so
+//  that the truncation pulls the running sum down in one period and up in the next, also WITHIN a long row range; sgn: in = the
+//  wavefront's starting sign, out = the sign the accumulator is left with)
+constexpr int TN3_FLIP = 4;
+__device__ __forceinline__ void tn3_flip(unsigned& sgn, f32x16 (&acc)[2][2]) {
+    sgn ^= 0x80000000u;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = -acc[a][b][e];
+}
 __device__ __forceinline__ void tn_rows_split3(const float* __restrict__ A, const int64_t lda, const int cas, const float* __restrict__ B,
                                                const int64_t ldb, const int cbs, const int64_t r0, const int64_t r1, const int kg,
-                                               const unsigned sgn, f32x16 (&acc)[2][2], float (&sa)[2]) {
+                                               unsigned& sgn, f32x16 (&acc)[2][2], float (&sa)[2]) {
     const int64_t nfull = (r1 - r0) / 16;                  // steps made of valid rows only
     const float* pa = A + (r0 + 8 * kg) * lda + cas;
     const float* pb = B + (r0 + 8 * kg) * ldb + cbs;
@@ -141,6 +154,7 @@ __device__ __forceinline__ void tn_rows_split3(const float* __restrict__ A, cons
 #pragma unroll
             for (int j = 0; j < 8; ++j) { nxt.a[j] = *(const float2*)(pa + j * lda); nxt.b[j] = *(const float2*)(pb + j * ldb); }
             tn_mma3(cur, sgn, acc, sa);                     // (the next stage's loads in flight under the 24 MFMAs)
+            if ((it & (TN3_FLIP - 1)) == 0) tn3_flip(sgn, acc);
             cur = nxt;
         }
         tn_mma3(cur, sgn, acc, sa);
@@ -455,9 +469,9 @@ int launch_tn_jobs(const TnDesc* d, int n, hipStream_t st, KgwGradSrc* defer = n
         //  second launch -- is NOT the default.  On the fp32 pipe it lost: 1.491 -> 1.501 ms at 640 rows, 1.513 at 2048, the serial
         //  row loop cost more than the launch.  On the bf16 pipe it wins a little -- layer 1's transform products, 1 171 rows x 68
         //  tiles, without their 9 088-block k_tn_reduce: 1.0594 / 1.0559 against 1.0600 / 1.0619 ms, 26 -> 25 launches -- but a
-        //  wavefront then accumulates ~27 MFMA steps in one accumulator and the truncating add shows: max error / sum|a||b| 4.2e-7
-        //  against the fp32 pipe's 2.0e-7 at 1 700 x 128 x 1 408, outside the 1.25 x this build holds the bf16 pipe to
-        //  (tests/test_gpu_dense.py).  kgw_tn_direct_rows(n) / KGW_TN_DIRECT_ROWS=n turn it on.)
+        //  wavefront then adds ~430 rows into one accumulator instead of ~60 and the longer chain shows: max error / sum|a||b|
+        //  4.2e-7 (the fp32 pipe in the same structure: 6.1e-7) against 2.1e-7 / 2.0e-7 with row blocks at 1 700 x 128 x 1 408.
+        //  Twice the error for 3 us: off.  kgw_tn_direct_rows(n) / KGW_TN_DIRECT_ROWS=n turn it on.)
         const int64_t direct_max = tn_direct_rows();
         if (D.rows <= direct_max && (int64_t)gy * gz >= 16) nblk = 1;
         all_direct = all_direct && nblk == 1;
