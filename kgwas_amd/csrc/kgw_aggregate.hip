@@ -437,7 +437,7 @@ __device__ __forceinline__ void bwd_group8(const float4* __restrict__ Hb4, int c
 }
 
 template <bool PIPE>
-__global__ void __launch_bounds__(KGW_BLK) k_agg_bwd_dst(LayerTab T, AggPtrs P, float slope, float inv_temp) {
+__global__ void __launch_bounds__(KGW_BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_agg_bwd_dst(LayerTab T, AggPtrs P, float slope, float inv_temp) {
     const int lane = kgw_lane(), half = lane >> 5, hl = lane & 31;
     const int nw = gridDim.x * 4;
     const int n_items = P.meta->n_chunks[P.layer - 1];
