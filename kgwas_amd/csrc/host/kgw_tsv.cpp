@@ -34,7 +34,10 @@ inline char* fmt_float(char* p, F x) {
     int ex = 0;
     { const char* q = e + 1; bool neg = (*q == '-'); if (*q == '+' || *q == '-') ++q; while (q < r.ptr) ex = ex * 10 + (*q++ - '0'); if (neg) ex = -ex; }
     const int decpt = ex + 1;                              // value = 0.DIGITS x 10^decpt
-    if (decpt <= -4 || decpt > 16) {                        // exponent form: d[.ddd]e[+-]XX, at least two exponent digits
+    // (float32: numpy decides by the VALUE -- float32(1e-4) = 9.9999997e-05 < 1e-4 prints "1e-04" although its shortest digits
+    //  "1" sit at the 1e-4 position; for float64 the two rules agree)
+    const bool small32 = sizeof(F) == 4 && decpt == -3 && (double)(x < 0 ? -x : x) < 1e-4;
+    if (decpt <= -4 || decpt > 16 || small32) {                        // exponent form: d[.ddd]e[+-]XX, at least two exponent digits
         *p++ = dig[0];
         if (nd > 1) { *p++ = '.'; memcpy(p, dig + 1, nd - 1); p += nd - 1; }
         *p++ = 'e';

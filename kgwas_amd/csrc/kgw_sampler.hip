@@ -1032,7 +1032,8 @@ extern "C" int kgw_sample_batch_parts(const KgwGraph* graph, const KgwBatchBuf* 
         }
         int sh, nb, nbits;
         if (ts_plan(trows, &sh, &nb, &nbits)) return KGW_E_UNSUPPORTED;  // (> 147 M src-major rows in one block)
-        const int nblk = SG >= 2048 ? 512 : (SG >= 256 ? 256 : 128);
+        static const int nblk_env = getenv("KGW_TS_NBLK") ? atoi(getenv("KGW_TS_NBLK")) : 0;       // (experiment knob: 128 / 256 / 512)
+        const int nblk = (nblk_env == 128 || nblk_env == 256 || nblk_env == 512) ? nblk_env : (SG >= 2048 ? 512 : (SG >= 256 ? 256 : 128));
         if ((int64_t)nl * (nb + 1) * nblk + (int64_t)nl * (nb + 2) > buf->scan_cap) return KGW_E_RANGE;
         k_ts_keys<<<nblk, KGW_BLK, (size_t)(nb + 1) * sizeof(int), st>>>(A, l0, nl, sh, nb);
         static KgwPerDevice attr_once;

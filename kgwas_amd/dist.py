@@ -113,6 +113,7 @@ def allreduce_flat(flat: torch.Tensor, world: int, what: str = 'parameter gradie
 
 _LIVE = weakref.WeakKeyDictionary()   # model -> liveness of its requires_grad parameters, as agreed over the ranks
 _FLAG = weakref.WeakKeyDictionary()   # model -> (pinned host copy of the last bucket's "new live parameter" flag, its event)
+_SEEN = weakref.WeakKeyDictionary()   # model -> parameters that had a gradient on THIS rank since the last agreement (sticky)
 
 
 class _Done:
@@ -147,11 +148,18 @@ def allreduce_grads(model, world: int):
         pend[1].synchronize()                      # (the copy of the PREVIOUS step's flag: long finished)
         fresh = bool(float(pend[0][0]) > 0.0)
     mine_new = (not fresh) and any(h and not l for h, l in zip(had, live))
+    # (the re-agreement runs one step AFTER the step that raised the flag and votes with that later step's gradients: the parameter
+    #  that raised it is remembered here -- a relation that shows up on non-consecutive batches would otherwise never become live)
+    seen = _SEEN.get(model)
+    if seen is None or len(seen) != len(params):
+        seen = [False] * len(params)
+    seen = _SEEN[model] = [s or h for s, h in zip(seen, had)]
     if fresh:
-        t = torch.tensor([h or (live is not None and len(live) == len(params) and live[i]) for i, h in enumerate(had)],
+        t = torch.tensor([seen[i] or (live is not None and len(live) == len(params) and live[i]) for i in range(len(params))],
                          dtype=torch.int32, device=params[0].device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         live = _LIVE[model] = [bool(v) for v in t.cpu().tolist()]
+        _SEEN[model] = [False] * len(params)
     sel = [p for p, l in zip(params, live) if l]
     for p, l in zip(params, live):
         if not l:

@@ -174,8 +174,9 @@ class GraphTrainStep:
         self.opt.zero_grad(set_to_none=True)
         if self.split_backward:
             mlp_out = []
-            loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id(self.input_type),
-                                              self.dg.y[self.input_type], self.ld_w, mlp_out=mlp_out, unit_grad=True)
+            with ops.readout_fold_deferred():
+                loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id(self.input_type),
+                                                  self.dg.y[self.input_type], self.ld_w, mlp_out=mlp_out, unit_grad=True)
             hs = [h for h in mlp_out if h.requires_grad]
             late = self._late_params()
             early = [p for p in self.model.parameters() if p.requires_grad and id(p) not in late]
@@ -190,8 +191,9 @@ class GraphTrainStep:
             torch.cat([gi.reshape(-1) for _, gi in live], out=self._flat_a)
             self._cut[cur] = (hs, list(g[:len(hs)]))
         else:
-            loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id(self.input_type),
-                                              self.dg.y[self.input_type], self.ld_w, unit_grad=True)      # kgwas.py:137-145
+            with ops.readout_fold_deferred():                          # (the backward pass below always runs)
+                loss, _ = self.model.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id(self.input_type),
+                                                  self.dg.y[self.input_type], self.ld_w, unit_grad=True)      # kgwas.py:137-145
             # fused optimiser launch: the weight-gradient products that feed only Adam stop after their first launch, their last
             # sums, the update, the step counter and the running totals are ONE launch (ops.GradSink, kgw_adam_fused)
             sink = ops.GradSink() if self.fused_adam else None

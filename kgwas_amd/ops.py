@@ -382,6 +382,23 @@ _PACK_FUSED = os.environ.get('KGW_PACK_FUSED', '1') != '0'
 # is one more block of the launch that follows it in a captured step (layer 2's kgw_transform_bwd_ex).  KGW_DEFER_READOUT_FOLD=0: a
 # launch of its own.
 _DEFER_READOUT_FOLD = os.environ.get('KGW_DEFER_READOUT_FOLD', '1') != '0'
+READOUT_FOLD_DEFERRED = False      # set by ``readout_fold_deferred`` (a trainer that ALWAYS runs the backward pass: GraphTrainStep)
+
+
+class readout_fold_deferred:
+    """Inside this scope the fused read-out node (``unit_grad=True``) leaves its fold -- and with it the loss value, d w_lin and
+    d b_lin -- to the backward pass.  Outside (KGWAS.train_step, tests, any caller that may read or log the loss before calling
+    backward, or never call it) the node finishes everything in its forward."""
+
+    def __enter__(self):
+        global READOUT_FOLD_DEFERRED
+        self.prev, READOUT_FOLD_DEFERRED = READOUT_FOLD_DEFERRED, True
+        return self
+
+    def __exit__(self, *exc):
+        global READOUT_FOLD_DEFERRED
+        READOUT_FOLD_DEFERRED = self.prev
+        return False
 
 
 class grad_sink_scope:
@@ -982,9 +999,13 @@ def gemm3(A: torch.Tensor, packed: torch.Tensor, bias=None, relu: bool = False, 
         r, f = q.take()                     # (the step's parameter-only forward work rides on this launch's idle compute units)
         rc = L.kgw_gemm3_riders(*args, r[0] if r is not None else 0, r[1] if r is not None else None,
                                 C.byref(f[0]) if f is not None else None, f[1] if f is not None else 0, _lib.stream_ptr())
-        _lib.check(rc, 'kgw_gemm3_riders')
-        q.taken += 1
-        return out
+        if rc != _lib.KGW_E_UNSUPPORTED:
+            _lib.check(rc, 'kgw_gemm3_riders')
+            q.taken += 1
+            return out
+        # (the riders' tables did not fit this launch -- an unaligned clear, a fold that is not the relation job's: nothing was
+        #  launched.  The jobs go back into the queue, whose flush launches their own kernels, and the product runs plain)
+        q.relvec, q.fold = r, f
     _lib.check(L.kgw_gemm3(*args, _lib.stream_ptr()), 'kgw_gemm3')
     return out
 
@@ -1766,6 +1787,13 @@ class _RelVectors(torch.autograd.Function):
         dwd = torch.empty_like(w_dst_t)
         das = torch.empty_like(att_src)
         dad = torch.empty_like(att_dst)
+        sink = GRAD_SINK
+        if sink is not None:
+            # (inside a captured step a fold's kgw_fold_bwd or a transform's k_tn_reduce may still be PENDING in the sink -- parked
+            #  there for _RelVectorsMulti / k_param_tail -- and this launch reads what they write: dU, dV, dW_in.  The per-layer node
+            #  is the one a 1-layer model or KGW_RELVEC_ALL=0 takes: tests/test_gpu_fallbacks.py)
+            sink.launch_pending_tail()
+            sink.launch_pending_reduce()
         _lib.check(_lib.lib().kgw_relvec_bwd_acc(n, _p(pack.rel_ids_i32), _p(pack.bip_pos_i32), _p(w_src_t),
                                                  _p(w_dst_t) if w_dst_t.numel() else 0, _p(att_src), _p(att_dst), _p(dU), _p(dV),
                                                  _p(dW_in), _p(dws), _p(dwd) if dwd.numel() else 0, _p(das), _p(dad), 1,
@@ -2310,9 +2338,10 @@ class _ReadoutWeightedMSE(torch.autograd.Function):
             dH, dw, db = torch.empty_like(H), torch.empty_like(w_lin), torch.empty(1, device=dev)
             part = torch.empty(((H.shape[0] + 3) // 4) * (KGW_C + 1), device=dev)
             ctx.fold = None
-            if _DEFER_READOUT_FOLD:
+            if _DEFER_READOUT_FOLD and READOUT_FOLD_DEFERRED:
                 # first launch only: the fold of the partial sums waits for the backward pass, where it rides in the next launch
-                # of a captured step (GradSink.pending_fold) or is launched first thing otherwise
+                # of a captured step (GradSink.pending_fold) or is launched first thing otherwise.  The loss is NOT written until
+                # then -- only a caller that always runs the backward takes this form (``readout_fold_deferred``)
                 f = _lib.KgwReadoutFold()
                 _lib.check(_lib.lib().kgw_readout_wmse_train_parts(_p(H), _p(w_lin), _p(b_lin), _p(n_id), _p(y_all), _p(w_all), n,
                                                                    H.shape[0], (1 if relu else 0) | (2 if h_is_relu else 0), _p(pred),

@@ -51,6 +51,9 @@ def write_tsv(df, path):
     L = _host_lib()
     n, cols = len(df), list(df.columns)
     ok = bool(L) and n > 0 and len(cols) > 0 and all(isinstance(c, str) and not (set(c) & set('\t"\n\r')) and c for c in cols)
+    # (duplicate column names make df[c] two-dimensional; extension dtypes -- nullable Int64, categoricals, ... -- have their own
+    #  text form: both go through pandas)
+    ok = ok and df.columns.is_unique and all(isinstance(df[c].dtype, np.dtype) for c in cols)
     keep, kinds, ptrs, offs = [], [], [], []
     if ok:
         for c in cols:
@@ -91,6 +94,10 @@ def write_tsv(df, path):
         if rc == 0:
             return
         if rc == -3:
+            try:
+                os.remove(path)                          # (no truncated table left behind)
+            except OSError:
+                pass
             raise OSError(f'could not write {path}')
     df.to_csv(path, index=False, sep='\t')
 

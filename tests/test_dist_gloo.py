@@ -102,11 +102,16 @@ def _worker_split(rank, world, port, out_dir):
         kdist.allreduce_grads(m, world)
         second_b = m.bias.grad                               # (round 5: the flag rides in the bucket and is looked at one call later)
         m.weight.grad = torch.full_like(m.weight, 1.0)
+        m.bias.grad = None                                    # step 3: NO rank has the bias gradient (a relation that shows up on
+        kdist.allreduce_grads(m, world)                       # non-consecutive batches): re-agreed all the same -- ADVICE r5
+        third_b = m.bias.grad
+        m.weight.grad = torch.full_like(m.weight, 1.0)
+        m.bias.grad = None
         if rank == 1:
             m.bias.grad = torch.full_like(m.bias, 4.0)
-        kdist.allreduce_grads(m, world)                       # step 3: re-agreed on every rank at the same step
-        torch.save({'ok': ok, 'first_w': first[0], 'first_b': first[1], 'second_b': second_b, 'third_b': m.bias.grad},
-                   os.path.join(out_dir, f's{rank}.pt'))
+        kdist.allreduce_grads(m, world)                       # step 4: its next appearance is reduced on both ranks
+        torch.save({'ok': ok, 'first_w': first[0], 'first_b': first[1], 'second_b': second_b, 'third_b': third_b,
+                    'fourth_b': m.bias.grad}, os.path.join(out_dir, f's{rank}.pt'))
     finally:
         dist.destroy_process_group()
 
@@ -120,9 +125,11 @@ def test_gene_layer_split_selftest_and_liveness_reagreement(tmp_path):
         assert torch.equal(d['first_w'], torch.full((2, 3), 1.5)) and d['first_b'] is None
         # the parameter that came alive on rank 1 is never stepped locally on one rank: the step that sees it drops the local
         # gradient on every rank (the flag travels in the gradient bucket, no extra collective / host sync per step) and the next
-        # one reduces it on BOTH ranks (mean of 0 and 4)
+        # one makes it live on BOTH ranks -- although no rank has a gradient for it at THAT step (the rank that raised the flag
+        # remembers which parameter it was): zeros there, and the mean of 0 and 4 at its next appearance
         assert d['second_b'] is None
-        assert d['third_b'] is not None and torch.equal(d['third_b'], torch.full((2,), 2.0))
+        assert d['third_b'] is not None and torch.equal(d['third_b'], torch.zeros(2))
+        assert d['fourth_b'] is not None and torch.equal(d['fourth_b'], torch.full((2,), 2.0))
 
 
 def test_gene_layer_split_default_follows_what_it_saves():

@@ -596,10 +596,13 @@ def test_transform_backward_in_one_launch(shapes, with_dz, with_gamma):
     assert L.kgw_transform_bwd(0, None, 0, None, 0, None, st) == 0
 
 
+@pytest.mark.parametrize('deferred', [False, True])
 @pytest.mark.parametrize('n,rows', [(512, 512), (500, 576), (1, 1), (5000, 5120)])
-def test_readout_loss_training_node_matches_autograd(n, rows):
+def test_readout_loss_training_node_matches_autograd(n, rows, deferred):
     """kgw_readout_wmse_train (unit loss gradient: forward + backward of the read-out + LD-weighted MSE node together, the
-    blocks' partials + a fold launch) against fp64 autograd, ragged and large row counts."""
+    blocks' partials + a fold launch) against fp64 autograd, ragged and large row counts.  ``deferred``: the fold launch left to
+    the backward pass (ops.readout_fold_deferred, what a captured step does); otherwise the loss is complete after the forward."""
+    import contextlib
     from kgwas_amd import ops
     g = torch.Generator().manual_seed(n + rows)
     N = 300 + rows
@@ -608,12 +611,15 @@ def test_readout_loss_training_node_matches_autograd(n, rows):
     y_all = torch.rand(N, generator=g); w_all = torch.rand(N, generator=g, dtype=torch.float64) + 0.1
     n_id = torch.randperm(N, generator=g)[:rows].to(torch.int32)
     Hd, wd, bd = (t.cuda().requires_grad_(True) for t in (H, wl, bl))
-    loss, pred = ops.readout_weighted_mse(Hd, wd, bd, n_id.cuda(), y_all.cuda(), w_all.cuda(), n, relu=True, h_is_relu=True, unit_grad=True)
-    loss.backward(gradient=ops.unit_gradient(torch.device('cuda:0')))
+    with (ops.readout_fold_deferred() if deferred else contextlib.nullcontext()):
+        loss, pred = ops.readout_weighted_mse(Hd, wd, bd, n_id.cuda(), y_all.cuda(), w_all.cuda(), n, relu=True, h_is_relu=True, unit_grad=True)
     Ho, wo, bo = (t.double().requires_grad_(True) for t in (H, wl, bl))
     p = torch.relu((Ho[:n] @ wo.t() + bo).reshape(-1))
     ids = n_id[:n].long()
     lo = torch.mean(w_all[ids] * (p - y_all[ids].double()) ** 2)
+    if not deferred:            # (an eager caller may read the loss before -- or without -- calling backward)
+        assert abs(float(loss) - float(lo)) <= 1e-9 + 2e-6 * abs(float(lo))
+    loss.backward(gradient=ops.unit_gradient(torch.device('cuda:0')))
     lo.backward()
     assert_close(pred, p.detach(), 1e-5, 1e-6, 'pred')
     assert abs(float(loss) - float(lo)) <= 1e-9 + 2e-6 * abs(float(lo))

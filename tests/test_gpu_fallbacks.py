@@ -14,7 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MERGES_OFF = {'KGW_FUSED_ADAM': '0', 'KGW_MERGED_TRANSFORM_BWD': '0', 'KGW_DEFER_PRODUCTS': '0', 'KGW_DUV_PIECES': '0',
               'KGW_RELVEC_ALL': '0', 'KGW_MULTI_TRANSFORM': '0', 'KGW_ADAM_PACKS': '0', 'KGW_G3_RIDERS': '0', 'KGW_PARAM_TAIL': '0', 'KGW_DEFER_REDUCE': '0', 'KGW_DEFER_READOUT_FOLD': '0', 'KGW_PACK_FUSED': '0'}
 VARIANTS = {'all_merges_off': MERGES_OFF, 'strict': {'KGW_STRICT': '1'}, 'unfolded_fc': {'KGW_FOLD_FC': '0'},
-            'general_rows_only': {'KGW_SHORT_ROWS': '0', 'KGW_DUV_RIDERS': '0'}}
+            'general_rows_only': {'KGW_SHORT_ROWS': '0', 'KGW_DUV_RIDERS': '0'},
+            # (ONE switch off: the per-layer relation-vector node beside every other merge -- deferred fold backward, riding second
+            #  launches -- still on)
+            'relvec_per_layer': {'KGW_RELVEC_ALL': '0'}}
 
 
 @pytest.mark.parametrize('variant', sorted(VARIANTS))

@@ -69,7 +69,8 @@ def _eager_fused_steps(kg, bs, tail, monkeypatch, sd0, n_steps=3, no_products=Fa
     losses, taken, grads, ridden, folds = [], 0, None, 0, 0
     for _ in range(n_steps):
         opt.zero_grad()
-        loss, _ = m.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id('SNP'), batch.dg.y['SNP'], ld_w, unit_grad=True)
+        with ops.readout_fold_deferred():        # (as GraphTrainStep issues it: the read-out's fold is left to the backward pass)
+            loss, _ = m.forward_loss(batch.x_dict, batch.edge_index_dict, bs, batch.n_id('SNP'), batch.dg.y['SNP'], ld_w, unit_grad=True)
         sink = ops.GradSink()
         with ops.grad_sink_scope(sink):
             loss.backward(gradient=ops.unit_gradient(loss.device))

@@ -18,7 +18,8 @@ def _frame(n, seed=0):
     k = min(n, len(special))
     p[:k] = special[:k]
     f32 = rng.standard_normal(n).astype(np.float32)
-    f32[:min(n, 8)] = np.array([0, -0.0, 1e-5, 1e16, np.nan, 3.4028235e38, 1e-45, 16777216.0], dtype=np.float32)[:min(n, 8)]
+    f32s = np.array([0, -0.0, 1e-5, 1e16, np.nan, 3.4028235e38, 1e-45, 16777216.0, 1e-4, -1e-4, 1.0000001e-4, 9.999999e-5, 2e-4, 1e-3], dtype=np.float32)
+    f32[:min(n, len(f32s))] = f32s[:min(n, len(f32s))]
     return pd.DataFrame({'#CHROM': 1, 'ID': [f'rs{i}' for i in range(n)], 'P': p, 'N': 5000.0, 'POS': rng.integers(-2 ** 62, 2 ** 62, n),
                          'small': rng.integers(0, 100, n).astype(np.int32), 'flag': rng.uniform(size=n) > 0.5, 'pred': f32,
                          'KGWAS_P': rng.uniform(size=n)})
@@ -51,3 +52,9 @@ def test_fallbacks_keep_the_output(tmp_path):
     d3['when'] = pd.Timestamp('2024-01-01')
     assert _same(d3, tmp_path)
     assert _same(df.iloc[:0], tmp_path)
+    # duplicate column names, nullable integers with a missing value
+    d4 = pd.concat([df[['P']], df[['N']].rename(columns={'N': 'P'})], axis=1)
+    assert _same(d4, tmp_path)
+    d5 = df.copy()
+    d5['nullable'] = pd.array([1, None] * 25, dtype='Int64')
+    assert _same(d5, tmp_path)

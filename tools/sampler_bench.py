@@ -18,7 +18,7 @@ with contextlib.redirect_stdout(sys.stderr):
 ids = np.asarray(data.train_input_nodes[1])[:512 * (n + 8)]
 probe = NeighborLoader(data.data, [-1, -1], ('SNP', ids), batch_size=512, drop_last=True, device='cuda:0', prefetch=False)
 dg = probe.dg.with_static_caps(probe.measure_caps(1.03))
-for grid in (256, 0):
+for grid in [int(g) for g in os.environ.get('KGW_SB_GRIDS', '256,0').split(',')]:      # (0: the whole-GPU default)
     buf = BatchBuffers(dg, grid)
     seeds = torch.zeros(512, dtype=torch.int64, device='cuda:0')
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
