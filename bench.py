@@ -571,6 +571,32 @@ def main():
                  'the validation pass of kgwas.py:157 (val_s: first use, includes measuring its static capacities and capturing its '
                  'forward graph; val_s_later_epochs: the same pass again, as every later epoch runs it)'}
         del ge
+        # a SECOND, separately labelled figure (the headline and the epoch above sample every batch live): what KGWAS.train's epochs
+        # >= 2 cost -- the loader's batch order is fixed (kgwas/kgwas.py:93-101), so the batches sampled in epoch 1 are kept in HBM and
+        # put back by one copy launch each instead of being sampled again (graph_step.BatchCache)
+        try:
+            gc_ = GraphTrainStep(run, ('SNP', ids), bs, lr=1e-4, weight_decay=5e-4, cache_batches=True)
+            if gc_.cache is not None:
+                torch.cuda.synchronize()
+                te = time.perf_counter()
+                for i in range(gc_.n_batches):
+                    gc_.step(i)
+                gc_.check()
+                t_fill = time.perf_counter() - te
+                te = time.perf_counter()
+                for i in range(gc_.n_batches):
+                    gc_.step(i)
+                gc_.check()
+                t_cached = time.perf_counter() - te
+                epoch['cached_batches'] = {
+                    'train_s_epoch_1_sampling_and_keeping': t_fill, 'train_s_epoch_2_from_the_cache': t_cached,
+                    'ms_per_step_from_the_cache': t_cached / gc_.n_batches * 1e3, 'cache_gib': gc_.cache.slots.numel() / 2 ** 30,
+                    'mb_per_batch': gc_.cache.slot_bytes / 1e6,
+                    'note': 'NOT the headline: what epochs >= 2 of KGWAS.train(epoch > 1) cost (batches of epoch 1 kept in HBM, '
+                            'bit-identical training: tests/test_gpu_graph.py); value / ms_per_step / epoch_s above sample every batch live'}
+            del gc_
+        except Exception as e:                                  # (never let the second figure take the line down)
+            epoch['cached_batches'] = {'error': repr(e)}
 
     # what moved between the ranks: every collective of the timed region, by name, per step and rank (world 1: empty)
     coll = {}

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KGW_VERSION      124          /* 0.2.4 */
+#define KGW_VERSION      125          /* 0.2.5 */
 #define KGW_MAX_TYPES    8
 #define KGW_MAX_RELS     64
 #define KGW_MAX_LAYERS   4
@@ -139,8 +139,8 @@ typedef struct KgwBatchBuf {
     KgwBatchMeta* meta_host; /* pinned host mirror (async D2H at the end of sampling)          */
     int64_t seg_cap, edge_cap, chunk_cap, multi_cap, trow_cap, scan_cap;
     int32_t grid_blocks;   /* blocks of the sampler's grid-stride launches; 0 = default (2048: the call has the GPU to
-                              itself).  A sampler replayed BESIDE a training step (second HIP graph on a side stream)
-                              should stay small -- 256 measured best: -4 % step time vs 2048, +0.1 ms sampler time    */
+                              itself).  A sampler replayed BESIDE a training step (second HIP graph on a side stream):
+                              1024 -- what it costs the step is how long each of its kernels stays resident */
     int32_t pad_;
 } KgwBatchBuf;
 
@@ -276,6 +276,23 @@ int kgw_accumulate_stats(const KgwBatchMeta* meta_dev, int32_t n_layers, int32_t
  * captured step (one single-thread launch less per step).                                                           */
 int kgw_accumulate_stats_tick(const KgwBatchMeta* meta_dev, int32_t n_layers, int32_t n_hops, int64_t* stats, int32_t* tick,
                               kgw_stream_t stream);
+
+/* A sampled batch kept for later epochs.  The reference's training loader has a fixed batch order (NeighborLoader without
+ * shuffle, kgwas/kgwas.py:93-101), so epoch >= 2 asks the sampler for exactly the structures of epoch 1.  kgw_segments_copy moves
+ * up to KGW_SEGCOPY_MAX device segments (the arrays of a KgwBatchBuf the training step reads) to slot *slot_index of a resident
+ * cache (to_slot != 0) or back, in ONE launch; the slot index is read on the DEVICE, so the launch is captured once.  Pointers,
+ * slot offsets and the stride are 16-byte aligned; units = 16-byte units of the segment.                                      */
+#define KGW_SEGCOPY_MAX 40
+typedef struct KgwSegCopy {
+    int32_t n, to_slot;
+    void* ptr[KGW_SEGCOPY_MAX];
+    int64_t units[KGW_SEGCOPY_MAX];
+    int64_t slot_off[KGW_SEGCOPY_MAX];
+    uint8_t* slots;                  /* [n slots][slot_stride] */
+    int64_t slot_stride;
+    const int64_t* slot_index;       /* device */
+} KgwSegCopy;
+int kgw_segments_copy(const KgwSegCopy* plan, int32_t grid_blocks /* 0: default */, kgw_stream_t stream);
 
 /* Replaces: the index_select feature slicing of the loader (x[n_id], kgwas/kgwas.py:135).      */
 int kgw_gather_rows(const float* src, const int32_t* ids, int64_t n_rows, int32_t width,

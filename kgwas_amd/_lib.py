@@ -115,6 +115,14 @@ class KgwGradSrc(C.Structure):
                 ('packed', C.c_void_p), ('flip', C.c_int32), ('pad_', C.c_int32)]
 
 
+KGW_SEGCOPY_MAX = 40
+
+
+class KgwSegCopy(C.Structure):
+    _fields_ = [('n', C.c_int32), ('to_slot', C.c_int32), ('ptr', C.c_void_p * KGW_SEGCOPY_MAX), ('units', C.c_int64 * KGW_SEGCOPY_MAX),
+                ('slot_off', C.c_int64 * KGW_SEGCOPY_MAX), ('slots', C.c_void_p), ('slot_stride', C.c_int64), ('slot_index', C.c_void_p)]
+
+
 ADAM_FUSED_MAX, ADAM_FUSED_SRC, ADAM_FUSED_COUNTERS = 40, 12, 65 * 32     # include/kgwas_hip.h: KGW_ADAM_FUSED_*
 
 
@@ -154,7 +162,7 @@ class KgwFoldArgs(C.Structure):
                 ('d_fc_weight', C.c_void_p * 4), ('d_fc_bias', C.c_void_p * 4)]
 
 
-EXPORTS = ['kgw_version', 'kgw_status_string', 'kgw_struct_sizes', 'kgw_sample_batch', 'kgw_sample_batch_parts', 'kgw_sampler_scan_ints',
+EXPORTS = ['kgw_version', 'kgw_status_string', 'kgw_struct_sizes', 'kgw_sample_batch', 'kgw_sample_batch_parts', 'kgw_sampler_scan_ints', 'kgw_segments_copy',
            'kgw_softmax_pack', 'kgw_softmax_merge', 'kgw_scatter_rows', 'kgw_linear_splitk', 'kgw_linear_splitk_workspace_floats', 'kgw_linear_splitk_ind', 'kgw_ind_colsum', 'kgw_linear_splitk_multi', 'kgw_ind_colsum_multi', 'kgw_fold_fwd', 'kgw_fold_bwd', 'kgw_relation_sums',
            'kgw_gat_aggregate_fwd', 'kgw_gat_aggregate_bwd_dst', 'kgw_gat_aggregate_bwd_src',
            'kgw_gather_rows', 'kgw_gather_rows_multi', 'kgw_scatter_relu_rows', 'kgw_scatter_relu_rows_workspace_floats', 'kgw_edge_alpha', 'kgw_debug_reduce', 'kgw_debug_reduce8', 'kgw_tn_gemm', 'kgw_tn_gemm_ex', 'kgw_tn_gemm_multi', 'kgw_tn_gemm_workspace_floats', 'kgw_tn_gemm_partial', 'kgw_tn_gemm_multi_partial', 'kgw_tn_split', 'kgw_tn_direct_rows', 'kgw_param_tail', 'kgw_tn_reduce_launch', 'kgw_tn_gemm_partial_ride', 'kgw_transform_bwd_ex', 'kgw_mlp2_bwd_first_partial', 'kgw_mlp2_bwd_first_packed', 'kgw_adam_fused', 'kgw_gemm3_partial', 'kgw_gemm3_flip', 'kgw_transform_bwd', 'kgw_grad_finish',
@@ -193,6 +201,7 @@ def lib():
                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     L.kgw_sampler_scan_ints.argtypes = [C.c_int64, C.c_int64, C.c_int64]
     L.kgw_sampler_scan_ints.restype = C.c_int64
+    L.kgw_segments_copy.argtypes = [C.POINTER(KgwSegCopy), C.c_int32, C.c_void_p]
     L.kgw_softmax_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.kgw_softmax_merge.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.kgw_scatter_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]

@@ -919,9 +919,14 @@ __global__ void __launch_bounds__(KGW_BLK) k_t_end(SampArgs A, int l0, int nl) {
 // ordered walks), at most 2^14 rows each (one wavefront keeps a bucket's row counters in LDS); digits 0 .. nb (nb = "relation
 // not computed by the layer")
 static int ts_plan(int64_t trows, int* sh_, int* nb_, int* nbits_) {
-    // (KGW_TS_MIN_SHIFT, tests only: force the coarse-bucket plans -- 2^12 / 2^14 rows per bucket, the 64 KB-of-LDS launches --
-    //  that otherwise need 8 M / 65 M src-major rows)
-    static const int sh_env = getenv("KGW_TS_MIN_SHIFT") ? atoi(getenv("KGW_TS_MIN_SHIFT")) : 8;
+    // Buckets of at least 2^11 rows (round 6; 2^8 until then).  Measured beside the training step of the benchmark (1.09 M src-major
+    // rows, 1 024-block hop launches): 2^9-row buckets 1.034 ms per step, 2^10 1.023, 2^11 1.012, 2^12 1.009 - 1.016, 2^13 (one
+    // wavefront per bucket) 1.134 -- although the sampler ALONE is fastest with the small ones (0.257 ms against 0.272 / 0.291):
+    // 4x fewer buckets are 4x fewer cells of the [bucket][block] count table (one scattered 4-byte access each in k_ts_keys and
+    // k_ts_scatter) and a quarter of k_ts_scatter's LDS, and what the sampler costs the step is what it takes from the step's
+    // kernels, not its own length.  KGW_TS_MIN_SHIFT (tests): force a plan -- 8: the fine buckets; 12 / 14: the coarse
+    // ones (64 KB-of-LDS launches) that otherwise need 8 M / 65 M src-major rows.
+    static const int sh_env = getenv("KGW_TS_MIN_SHIFT") ? atoi(getenv("KGW_TS_MIN_SHIFT")) : 11;
     int sh = sh_env < 8 ? 8 : (sh_env > 14 ? 14 : sh_env);
     while (sh < 14 && (trows >> sh) + 1 > TS_MAX_NB) ++sh;
     const int64_t nb = (trows >> sh) + 1;
@@ -1032,8 +1037,9 @@ extern "C" int kgw_sample_batch_parts(const KgwGraph* graph, const KgwBatchBuf* 
         }
         int sh, nb, nbits;
         if (ts_plan(trows, &sh, &nb, &nbits)) return KGW_E_UNSUPPORTED;  // (> 147 M src-major rows in one block)
-        static const int nblk_env = getenv("KGW_TS_NBLK") ? atoi(getenv("KGW_TS_NBLK")) : 0;       // (experiment knob: 128 / 256 / 512)
-        const int nblk = (nblk_env == 128 || nblk_env == 256 || nblk_env == 512) ? nblk_env : (SG >= 2048 ? 512 : (SG >= 256 ? 256 : 128));
+        // (round 6, beside the training step at 1 024-block hop launches: 128 / 256 / 512 key blocks measured 1.035 / 1.034 / 1.048 ms
+        //  per step -- the [bucket][block] count table is scattered traffic that grows with the blocks)
+        const int nblk = SG >= 2048 ? 512 : (SG >= 256 ? 256 : 128);
         if ((int64_t)nl * (nb + 1) * nblk + (int64_t)nl * (nb + 2) > buf->scan_cap) return KGW_E_RANGE;
         k_ts_keys<<<nblk, KGW_BLK, (size_t)(nb + 1) * sizeof(int), st>>>(A, l0, nl, sh, nb);
         static KgwPerDevice attr_once;
@@ -1099,6 +1105,44 @@ extern "C" int kgw_accumulate_stats_tick(const KgwBatchMeta* meta_dev, int32_t n
 extern "C" int kgw_accumulate_stats(const KgwBatchMeta* meta_dev, int32_t n_layers, int32_t n_hops, int64_t* stats,
                                     kgw_stream_t stream_) {
     return kgw_accumulate_stats_tick(meta_dev, n_layers, n_hops, stats, nullptr, stream_);
+}
+
+// ---- a sampled batch kept for later epochs (the loader's batch order is fixed: kgwas/kgwas.py:93-101 builds it without shuffle) ----
+// One launch moves every array of a batch the training step reads -- KgwSegCopy: up to KGW_SEGCOPY_MAX (pointer, 16-byte units,
+// offset in the slot) segments -- into slot ``*slot_index`` of a resident cache, or back.  The slot index is DEVICE data, so the
+// launch is captured once and replayed for any batch.  HBM-bound: ~20 MB each way per 512-seed batch of the benchmark graph.
+namespace {
+__global__ void __launch_bounds__(KGW_BLK) k_segments_copy(KgwSegCopy P) {
+    uint8_t* slot = P.slots + *P.slot_index * P.slot_stride;
+    const int64_t tid = (int64_t)blockIdx.x * KGW_BLK + threadIdx.x, nthr = (int64_t)gridDim.x * KGW_BLK;
+    for (int j = 0; j < P.n; ++j) {
+        int4* a = (int4*)P.ptr[j];
+        int4* b = (int4*)(slot + P.slot_off[j]);
+        const int64_t n = P.units[j];
+        if (P.to_slot) { for (int64_t k = tid; k < n; k += nthr) b[k] = a[k]; }
+        else           { for (int64_t k = tid; k < n; k += nthr) a[k] = b[k]; }
+    }
+}
+}  // namespace
+
+extern "C" int kgw_segments_copy(const KgwSegCopy* plan, int32_t grid_blocks, kgw_stream_t stream_) {
+    if (!plan || !plan->slots || !plan->slot_index) return KGW_E_NULL;
+    if (plan->n < 0 || plan->n > KGW_SEGCOPY_MAX || plan->slot_stride < 0 || (plan->slot_stride & 15)) return KGW_E_RANGE;
+    if ((uintptr_t)plan->slots & 15) return KGW_E_UNSUPPORTED;
+    int64_t total = 0;
+    for (int j = 0; j < plan->n; ++j) {
+        if (!plan->ptr[j]) return KGW_E_NULL;
+        if (plan->units[j] < 0 || plan->slot_off[j] < 0 || plan->slot_off[j] + 16 * plan->units[j] > plan->slot_stride) return KGW_E_RANGE;
+        if (((uintptr_t)plan->ptr[j] | (uintptr_t)plan->slot_off[j]) & 15) return KGW_E_UNSUPPORTED;
+        total += plan->units[j];
+    }
+    if (total == 0) return KGW_OK;
+    int64_t g = (total + KGW_BLK - 1) / KGW_BLK;
+    const int64_t cap = grid_blocks > 0 ? grid_blocks : KGW_GRID;
+    if (g > cap) g = cap;
+    k_segments_copy<<<(int)g, KGW_BLK, 0, (hipStream_t)stream_>>>(*plan);
+    KGW_LAUNCH_CHECK();
+    return KGW_OK;
 }
 
 // ---- x[n_id] feature slicing ---------------------------------------------------------------------

@@ -21,10 +21,14 @@ from . import _lib, ops
 from .sampler import BatchBuffers, NeighborLoader, SampledBatch, sample_into
 
 
-# blocks per launch of a sampler that runs beside a step graph: small launches disturb the step's kernels least
-# (measured, 512-seed steps: 2048 blocks 1.74 ms/step, 512: 1.68, 256: 1.67, 128: 1.66, 64: 2.03 -- there the sampler,
-# 1.0 ms on its own, no longer hides); 256 keeps the sampler at 0.42 ms, under the forward-only eval step too
-SIDE_SAMPLER_GRID = int(os.environ.get('KGW_SIDE_SAMPLER_GRID', '256'))       # (the knob: re-measured whenever the sampler changes)
+# Blocks per launch of a sampler that runs beside a step graph.  Round 6: 1 024 (256 until then).  What the side sampler costs the
+# step is not its length but how long each of ITS kernels stays resident: the step's heavy MFMA kernels (k_g3_gemm, k_mlp2_fwd3,
+# k_mlp2_bwd_first3, k_linear_wreg) run workgroups that need a WHOLE compute unit's registers, so one of them cannot start on a CU
+# while any sampler wavefront sits there, and waits for the sampler kernel in flight to drain (tools/side_queue_blocking.py:
+# side kernels that only stay resident -- no memory traffic -- cost the step +1 us at 30 x 10 us, +24 us at 8 x 40 us over 256 blocks,
+# +43 us over 1 024).  More blocks = shorter sampler kernels: 1.060 / 1.045 / 1.041 / 1.051 ms per step at 256 / 512 / 1 024 / 2 048
+# blocks on one box, 1.068 / 1.135 / 1.48 at 128 / 64 / 32 (profiles/r6/r6_sampler_geometry.txt).
+SIDE_SAMPLER_GRID = int(os.environ.get('KGW_SIDE_SAMPLER_GRID', '1024'))       # (the knob: re-measured whenever the sampler changes)
 def side_stream(device):
     """The stream the next batch's sampler graph is captured on and replayed on: an ordinary stream.  (Round 4 measured a CU-masked
     stream -- the two graphs then ran strictly one after the other --, stream priorities and a timed offset at the head of the
@@ -32,10 +36,111 @@ def side_stream(device):
     return torch.cuda.Stream(device=device)
 
 
+class BatchCache:
+    """The sampled batches of epoch 1, kept in HBM and put back in later epochs instead of sampling them again.
+
+    The reference's training loader has a fixed batch order (``NeighborLoader`` without shuffle, kgwas/kgwas.py:93-101), so every
+    epoch asks the sampler for exactly the structures of the first -- ~0.26 ms of sampler kernels per step that cost the step
+    ~50-75 us beside it.  After a batch is sampled (epoch 1) ONE launch on the sampler's stream copies the arrays the step reads --
+    node lists, relabelled columns, chunk records, the src-major structures, the batch's counts: ~20 MB at the benchmark's shape,
+    sized by the trainer's static capacities -- into the batch's slot of a resident cache (kgw_segments_copy); from epoch 2 on one
+    launch copies the slot back into the idle batch buffer where the sampler's ~25 launches ran.  Same bytes in the same
+    buffers => the step's kernels produce the same bits as after live sampling (tests/test_gpu_graph.py).  19 GB for the
+    956 batches of the benchmark; a cache that would take more than ``max_fraction`` of the free HBM is not made."""
+
+    def __init__(self, dg, bufs, n_batches: int, max_fraction: float = 0.5):
+        self.n_batches = int(n_batches)
+        dev = dg.device
+        sc, L, H, caps, g = dg.schema, dg.num_layers, dg.n_hops, dg.caps, dg.kg
+        segs = []                                  # (attribute, layer or None, first byte, bytes)
+
+        def add(name, layer, first_elem, n_elem, width=4):
+            segs.append((name, layer, int(first_elem) * width, int(n_elem) * width))
+        add('meta', None, 0, C.sizeof(_lib.KgwBatchMeta), 1)
+        n_through = lambda t, h: int(caps.node_off[t][h])          # nodes of type t through hop h - 1
+        for t in range(sc.NT):
+            n = n_through(t, H + 1)
+            if n:
+                add('n_id', None, dg.node_base[t], n)
+            if n and 2 * n > dg.n_nodes[t]:                        # (a type the forward may address by global id: model._features)
+                add('g2l', None, dg.node_base[t], dg.n_nodes[t])
+        n_seg = sum(n_through(int(g.rel_dst[r]), H) for r in range(sc.NR))
+        add('seg_ptr', None, 0, n_seg + 2)
+        add('seg_chptr', None, 0, n_seg + 2)
+        add('col_local', None, 0, int(caps.edges[0]) + 1)
+        add('chunks', None, 0, (int(caps.chunks[0]) + 1) * 8)
+        for h in range(H):
+            n_multi = min(int(dg.multi_cap), sum(n_through(int(g.rel_dst[r]), h + 1) for r in range(sc.NR)))
+            add('multi', None, h * int(dg.multi_cap) * 4, n_multi * 4)
+        for l in range(1, L + 1):
+            rows = sum(int(g.cap_src[l - 1][t]) for t in range(sc.NT))
+            trows = sum(int(g.cap_src[l - 1][t]) * int(g.R_src[t]) for t in range(sc.NT))
+            e = int(caps.edges[l - 1]) + 1
+            add('t_ptr', l, 0, trows + 2)
+            add('t_cnt', l, 0, (rows + 7) // 8 + 1)                # (the octet flags of the backward's short-row path)
+            add('t_edge', l, 0, e)
+            add('t_zrow', l, 0, e)
+            add('t_rel', l, 0, e, 1)
+        if len(segs) > _lib.KGW_SEGCOPY_MAX:
+            raise ValueError(f'{len(segs)} arrays per batch: more than kgw_segments_copy takes')
+        off, self.plans, self.slot_off = 0, [], []
+        units = []
+        for name, layer, first, nbytes in segs:
+            t0 = getattr(bufs[0], name)
+            t0 = t0[layer - 1] if layer is not None else t0
+            room = t0.numel() * t0.element_size() - first
+            u = min(-(-nbytes // 16), room // 16)
+            if first % 16 or u * 16 < nbytes:
+                raise ValueError(f'batch array {name} is not laid out in whole 16-byte units')
+            units.append(u)
+            self.slot_off.append(off)
+            off += u * 16
+        self.slot_bytes = off
+        total = self.slot_bytes * self.n_batches
+        free = torch.cuda.mem_get_info(dev)[0]
+        if total > max_fraction * free:
+            raise MemoryError(f'batch cache of {total / 2**30:.1f} GiB against {free / 2**30:.1f} GiB free')
+        self.slots = torch.empty(total, dtype=torch.uint8, device=dev)
+        self.index = torch.zeros(1, dtype=torch.int64, device=dev)         # the slot of the launch being replayed
+        self._all = torch.arange(self.n_batches, dtype=torch.int64, device=dev)
+        self.filled = [False] * self.n_batches
+        self.grid = bufs[0].c.grid_blocks
+        for buf in bufs:
+            pair = []
+            for to_slot in (1, 0):
+                p = _lib.KgwSegCopy()
+                p.n, p.to_slot = len(segs), to_slot
+                for j, ((name, layer, first, _), u) in enumerate(zip(segs, units)):
+                    t = getattr(buf, name)
+                    t = t[layer - 1] if layer is not None else t
+                    p.ptr[j], p.units[j], p.slot_off[j] = t.data_ptr() + first, u, self.slot_off[j]
+                p.slots, p.slot_stride, p.slot_index = self.slots.data_ptr(), self.slot_bytes, self.index.data_ptr()
+                pair.append(p)
+            self.plans.append(pair)
+        self.saved = self.restored = 0
+
+    def _launch(self, which: int, to_slot: bool, i: int):
+        self.index.copy_(self._all[i:i + 1], non_blocking=True)
+        _lib.check(_lib.lib().kgw_segments_copy(C.byref(self.plans[which][0 if to_slot else 1]), self.grid, _lib.stream_ptr()),
+                   'kgw_segments_copy')
+
+    def save(self, which: int, i: int):
+        """Buffer ``which`` holds batch ``i``, freshly sampled on the CURRENT stream: keep it."""
+        self._launch(which, True, i)
+        self.filled[i] = True
+        self.saved += 1
+
+    def restore(self, which: int, i: int):
+        """Batch ``i`` back into buffer ``which`` (on the current stream)."""
+        assert self.filled[i]
+        self._launch(which, False, i)
+        self.restored += 1
+
+
 class GraphTrainStep:
     def __init__(self, run, input_nodes, batch_size: int, lr: float = 1e-4, weight_decay: float = 5e-4,
                  margin: float = 1.03, capture_optimizer: bool = True, overlap_sampling: bool = None,
-                 shard_gene_layer: bool = None):
+                 shard_gene_layer: bool = None, cache_batches: bool = False):
         self.run = run
         self.model = run.model
         self.batch_size = int(batch_size)
@@ -128,6 +233,10 @@ class GraphTrainStep:
         # (timing experiments only: train on stale batches to see what the concurrent sampler costs the step)
         self._skip_resample = os.environ.get('KGW_SKIP_RESAMPLE', '0') == '1'
         self._twin_pending = [False, False]        # the side stream holds an unfinished sample of this buffer
+        # ``cache_batches`` (KGWAS.train with more than one epoch; off for a bench line -- the headline samples live): the batches of
+        # the first pass over the loader are kept and put back in later passes instead of being sampled again (BatchCache)
+        self.cache = None
+        self._want_cache = bool(cache_batches) and os.environ.get('KGW_EPOCH_CACHE', '1') != '0'
         # (parameter-only kernels on a parallel branch of the captured step: measured again in round 5 -- 1.397 ms against 1.081, and
         #  the branch's queue displaces the side sampler's, overlap ratio -0.14 -- HIP-graph branches are not a tool here; removed)
         self._capture()
@@ -300,8 +409,15 @@ class GraphTrainStep:
 
     def _sample_now(self, which: int, i: int):
         b = self.batch_size
-        self.seeds.copy_(self.ids[i * b:(i + 1) * b])
-        sample_into(self.dg, self.bufs[which], self.seeds, self.seed_type, record=False)
+        if self.cache is not None:
+            torch.cuda.current_stream().wait_stream(self._side)    # (the cache's slot index is shared with the side stream's launches)
+        if self.cache is not None and self.cache.filled[i]:
+            self.cache.restore(which, i)
+        else:
+            self.seeds.copy_(self.ids[i * b:(i + 1) * b])
+            sample_into(self.dg, self.bufs[which], self.seeds, self.seed_type, record=False)
+            if self.cache is not None:
+                self.cache.save(which, i)
         self._have[which] = i
 
     def _capture(self):
@@ -396,6 +512,11 @@ class GraphTrainStep:
                     sample_into(self.dg, self.bufs[cur], self.seeds, self.seed_type, record=False)
                 self.sample_graphs[cur] = gs
         self._have = [-1, -1]
+        if self._want_cache and self.twin:
+            try:
+                self.cache = BatchCache(self.dg, self.bufs, self.n_batches)
+            except (MemoryError, ValueError) as e:
+                print(f'kgwas_amd: sampled batches are not kept for later epochs ({e})', file=sys.stderr)
 
     def step(self, i: int):
         """Train on batch ``i`` of the loader's fixed order (and pre-sample batch i+1); returns the (device,
@@ -414,9 +535,15 @@ class GraphTrainStep:
             main = torch.cuda.current_stream()
             self._side.wait_stream(main)          # the previous step (reader of bufs[1 - cur], writer of nothing here) is done
             with torch.cuda.stream(self._side):
-                self.seeds.copy_(self.ids[nxt * b:(nxt + 1) * b])
-                if not self._skip_resample:
-                    self.sample_graphs[1 - cur].replay()
+                cache = self.cache if not self._skip_resample else None
+                if cache is not None and cache.filled[nxt]:
+                    cache.restore(1 - cur, nxt)                     # (a later epoch: one copy launch instead of the sampler's ~25)
+                else:
+                    self.seeds.copy_(self.ids[nxt * b:(nxt + 1) * b])
+                    if not self._skip_resample:
+                        self.sample_graphs[1 - cur].replay()
+                        if cache is not None:
+                            cache.save(1 - cur, nxt)
                 self._sampled[1 - cur].record(self._side)
             if self._twin_pending[cur]:
                 main.wait_event(self._sampled[cur])

@@ -181,7 +181,10 @@ class KGWAS:
             #  Linear is split by gene rows instead of repeated on every rank -- ops.GeneLayerShard)
             graph_step = GraphTrainStep(self, (self.train_loader.input_type, self.train_loader.ids.cpu().numpy()),
                                         self.train_loader.batch_size, lr=lr, weight_decay=weight_decay,
-                                        shard_gene_layer=None)
+                                        shard_gene_layer=None,
+                                        # (the loader's batch order is fixed, kgwas.py:93-101: the batches sampled in epoch 1 are
+                                        #  kept in HBM and put back in later epochs -- graph_step.BatchCache)
+                                        cache_batches=total_epoch > 1)
             optimizer = graph_step.opt
         else:
             optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay)   # kgwas.py:116

@@ -208,24 +208,25 @@ class BatchBuffers:
 
     def __init__(self, dg: DeviceGraph, grid_blocks: int = 0):
         """``grid_blocks``: blocks of the sampler's launches into this buffer (0 = whole-GPU default); a sampler that runs
-        BESIDE a training step (GraphTrainStep / GraphEvalStep) passes 256."""
+        BESIDE a training step (GraphTrainStep / GraphEvalStep) passes graph_step.SIDE_SAMPLER_GRID."""
         dev = dg.device
         L = dg.num_layers
         i32 = dict(dtype=torch.int32, device=dev)
+        r4 = lambda n: (int(n) + 3) // 4 * 4        # (whole 16-byte units: graph_step.BatchCache copies the arrays in int4s)
         self.g2l = torch.empty(dg.node_slots, **i32)
         self.n_id = torch.zeros(dg.node_slots, **i32)
         self.seg_deg = torch.empty(dg.seg_cap + 1, **i32)
         self.seg_nch = torch.empty(dg.seg_cap + 1, **i32)
-        self.seg_ptr = torch.empty(dg.seg_cap + 2, **i32)
-        self.seg_chptr = torch.empty(dg.seg_cap + 2, **i32)
-        self.col_local = torch.empty(dg.edge_cap + 1, **i32)
+        self.seg_ptr = torch.empty(r4(dg.seg_cap + 2), **i32)
+        self.seg_chptr = torch.empty(r4(dg.seg_cap + 2), **i32)
+        self.col_local = torch.empty(r4(dg.edge_cap + 1), **i32)
         self.chunks = torch.empty((dg.chunk_cap + 1) * 8, **i32)
         self.multi = torch.empty(dg.n_hops * dg.multi_cap * 4, **i32)
-        self.t_cnt = [torch.empty(dg.trow_cap + 2, **i32) for _ in range(L)]
-        self.t_ptr = [torch.empty(dg.trow_cap + 2, **i32) for _ in range(L)]
-        self.t_edge = [torch.empty(dg.edge_cap + 1, **i32) for _ in range(L)]
-        self.t_zrow = [torch.empty(dg.edge_cap + 1, **i32) for _ in range(L)]
-        self.t_rel = [torch.empty(dg.edge_cap + 1, dtype=torch.uint8, device=dev) for _ in range(L)]
+        self.t_cnt = [torch.empty(r4(dg.trow_cap + 2), **i32) for _ in range(L)]
+        self.t_ptr = [torch.empty(r4(dg.trow_cap + 2), **i32) for _ in range(L)]
+        self.t_edge = [torch.empty(r4(dg.edge_cap + 1), **i32) for _ in range(L)]
+        self.t_zrow = [torch.empty(r4(dg.edge_cap + 1), **i32) for _ in range(L)]
+        self.t_rel = [torch.empty((dg.edge_cap + 16) // 16 * 16, dtype=torch.uint8, device=dev) for _ in range(L)]
         self.scan_cap = max(2 * (max(dg.seg_cap, dg.node_slots, dg.trow_cap) // KGW_TILE + 4),
                             int(_lib.lib().kgw_sampler_scan_ints(dg.seg_cap, dg.node_slots, dg.trow_cap)))
         self.scan_tmp = torch.empty(self.scan_cap, **i32)

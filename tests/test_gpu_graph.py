@@ -57,6 +57,49 @@ def test_graph_step_equals_eager(small_kg, layers):
     assert den > 0 and (num / den) ** 0.5 < 5e-3, f'relative update difference {(num / den) ** 0.5:.3e}'
 
 
+def test_cached_epochs_are_bit_identical_to_sampled_ones(small_kg):
+    """the loader's batch order is fixed (kgwas/kgwas.py:93-101), so KGWAS.train keeps the batches sampled in
+    epoch 1 (graph_step.BatchCache, kgw_segments_copy) and puts them back in later epochs instead of sampling them again.  Three
+    passes over the loader with the cache against three passes that sample every batch: every loss, every parameter, every
+    optimiser moment and the device-side edge counts bit for bit -- for an even and an odd number of batches (the odd one starts
+    every pass on the other buffer and goes through the out-of-sequence path)."""
+    from kgwas_amd.graph_step import GraphTrainStep
+    from kgwas_amd.kgwas import KGWAS
+    bs = 64
+    for nb in (6, 5):
+        ids = np.asarray(small_kg.train_input_nodes[1][:bs * nb])
+        outs = []
+        for cached in (True, False):
+            run = KGWAS(small_kg, device='cuda:0', seed=17)
+            run.initialize_model()
+            if outs:
+                run.model.load_state_dict(sd0)
+            else:
+                sd0 = copy.deepcopy(run.model.state_dict())
+            gs = GraphTrainStep(run, ('SNP', ids), bs, lr=1e-3, weight_decay=5e-4, cache_batches=cached)
+            assert gs.n_batches == nb and (gs.cache is not None) == cached
+            run.model.train()
+            losses = []
+            for ep in range(3):
+                for i in range(nb):
+                    losses.append(gs.step(i).detach().clone())
+                stats = gs.check()
+            torch.cuda.synchronize()
+            if cached:
+                # every batch sampled exactly once (epoch 1), everything afterwards put back from its slot
+                assert gs.cache.saved == nb and all(gs.cache.filled), (gs.cache.saved, gs.cache.filled)
+                assert gs.cache.restored >= 2 * nb - 1, gs.cache.restored
+            state = {n: (p.detach().clone(), gs.opt.state[p]['exp_avg'].clone(), gs.opt.state[p]['exp_avg_sq'].clone())
+                     for n, p in run.model.named_parameters() if p in gs.opt.state}
+            outs.append((torch.stack(losses), state, stats))
+        assert torch.equal(outs[0][0], outs[1][0]) and float(outs[0][0].abs().sum()) > 0
+        assert outs[0][2] == outs[1][2]
+        assert outs[0][1].keys() == outs[1][1].keys()
+        for n in outs[0][1]:
+            for a, b in zip(outs[0][1][n], outs[1][1][n]):
+                assert torch.equal(a, b), n
+
+
 def test_static_capacity_overflow_is_reported(small_kg):
     """A batch that needs more rows than the static layout holds must raise, never silently truncate."""
     from kgwas_amd import _lib

@@ -197,12 +197,13 @@ def test_loader_on_cached_graph_equals_direct(tiny_kg, tmp_path):
         assert torch.equal(ea[et], eb[et])
 
 
-@pytest.mark.parametrize('shift', [12, 14])
+@pytest.mark.parametrize('shift', [8, 12, 14])
 def test_coarse_bucket_sort_plans_build_the_same_structures(shift):
     """the src-major sort's coarse plans (2^12 rows per bucket, four wavefronts; 2^14, one wavefront) launch
     k_ts_rows with 64 KB of dynamic LDS + its static words -- above the 64 KB default limit -- and are only chosen above
     8 M / 65 M src-major rows, which no test graph has.  KGW_TS_MIN_SHIFT forces them (read once per process, hence the
-    subprocess); the structure checks above must hold unchanged."""
+    subprocess); the structure checks above must hold unchanged.  (8: the fine buckets that were the default until round 6 --
+    the default is 2^11 rows now.)"""
     import os
     import subprocess
     import sys

@@ -19,7 +19,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in kgwas_hip.h but not exported'
     assert sorted(_lib.EXPORTS) == declared
-    assert lib.kgw_version() == 124
+    assert lib.kgw_version() == 125
     assert lib.kgw_status_string(-1) == b'null pointer argument'
 
 
