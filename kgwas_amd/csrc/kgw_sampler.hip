@@ -550,7 +550,8 @@ __global__ void __launch_bounds__(64) k_layer_tables(SampArgs A) {
 //   k_t_end        Z row and relation of every entry looked up from its chunk (independent gathers), octet flags.
 // Measured (512-seed batch of the benchmark graph, sampler alone, 256-block launches): 433 -> 355 us per batch; beside the
 // training step it now costs the step 40 - 50 us instead of 70 - 80 (no global atomics: 1.18 -> 1.155 ms per step).
-// KgwBatchBuf.t_tmp per layer: key[edge], (first layer's slot: chunk[edge] of ALL layers, written by k_relabel), sorted key, sorted edge -- 4 x (edge_cap + 1) ints; the counts live in
+// KgwBatchBuf.t_tmp per layer: key[edge], (first layer's slot: chunk[edge] of ALL layers, written by k_relabel), then the (key, edge)
+// PAIRS sorted by bucket (round 6: one scattered 8-byte store per entry instead of two 4-byte ones) -- 4 x (edge_cap + 1) ints; the counts live in
 // KgwBatchBuf.scan_tmp ([layer][digit][block]); KgwBatchMeta.cur[4 + k] = entries of layer l0 + k.
 // (blocks of k_ts_keys / k_ts_scatter = contiguous edge ranges: 256 beside a training step, 512 when the call has the GPU)
 constexpr int TS_INVALID = 0x7fffffff;
@@ -704,8 +705,7 @@ __global__ void __launch_bounds__(KGW_BLK) k_ts_scatter(SampArgs A, int l0, int 
         const int l = l0 + k;
         const int n = M->n_edges[l - 1];
         const int32_t* keyE = A.B.t_tmp + (int64_t)k * 4 * E1;
-        int32_t* keyS = A.B.t_tmp + (int64_t)k * 4 * E1 + 2 * E1;
-        int32_t* eS = keyS + E1;
+        int2* pairS = (int2*)(A.B.t_tmp + (int64_t)k * 4 * E1 + 2 * E1);      // (key, edge) of every entry, sorted by bucket
         const int32_t* H = A.B.scan_tmp + (int64_t)k * (nb + 1) * gridDim.x;
         const int32_t* dbase = A.B.scan_tmp + (int64_t)nl * (nb + 1) * gridDim.x + (int64_t)k * (nb + 2);
         for (int d = threadIdx.x; d < 4 * (nb + 1); d += KGW_BLK) ts_lds[d] = 0;
@@ -747,7 +747,7 @@ __global__ void __launch_bounds__(KGW_BLK) k_ts_scatter(SampArgs A, int l0, int 
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (pp[u] >= 0) { keyS[pp[u]] = kk[u]; eS[pp[u]] = g + 64 * u + lane; }
+                if (pp[u] >= 0) pairS[pp[u]] = make_int2(kk[u], g + 64 * u + lane);     // (ONE scattered 8-byte store per entry)
         }
         __syncthreads();
     }
@@ -770,8 +770,7 @@ __global__ void __launch_bounds__(64 * W) k_ts_rows(SampArgs A, int l0, int nl, 
     for (int k = 0; k < nl; ++k) {
         const int l = l0 + k;
         const int TR = M->t_base[l - 1][G.n_types];
-        const int32_t* keyS = A.B.t_tmp + (int64_t)k * 4 * E1 + 2 * E1;
-        const int32_t* eS = keyS + E1;
+        const int2* pairS = (const int2*)(A.B.t_tmp + (int64_t)k * 4 * E1 + 2 * E1);
         const int32_t* dbase = A.B.scan_tmp + (int64_t)nl * (nb + 1) * nblk + (int64_t)k * (nb + 2);
         int32_t* tp = A.B.t_ptr[l - 1];
         int32_t* te = A.B.t_edge[l - 1];
@@ -787,7 +786,7 @@ __global__ void __launch_bounds__(64 * W) k_ts_rows(SampArgs A, int l0, int nl, 
             for (int p = wb; p < we; p += TS_TILE) {
                 int kk[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) kk[u] = (p + 64 * u + lane < we) ? keyS[p + 64 * u + lane] : -1;
+                for (int u = 0; u < 8; ++u) kk[u] = (p + 64 * u + lane < we) ? pairS[p + 64 * u + lane].x : -1;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) if (kk[u] >= 0) atomicAdd(&mine[kk[u] - row0], 1);
             }
@@ -825,8 +824,9 @@ __global__ void __launch_bounds__(64 * W) k_ts_rows(SampArgs A, int l0, int nl, 
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const bool in = g + 64 * u + lane < we;
-                    kk[u] = in ? keyS[g + 64 * u + lane] : -1;
-                    ee[u] = in ? eS[g + 64 * u + lane] : 0;
+                    const int2 pr = in ? pairS[g + 64 * u + lane] : make_int2(-1, 0);
+                    kk[u] = pr.x;
+                    ee[u] = pr.y;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {

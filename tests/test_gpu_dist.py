@@ -24,24 +24,28 @@ def _free_port():
     return p
 
 
-def _make_run(seed=11):
+def _make_run(seed=11, device='cuda:0'):
     from kgwas_amd.kgwas import KGWAS
     from kgwas_amd.kgwas_data import KGWAS_Data
     data = KGWAS_Data.from_synthetic(scale=0.01, seed=1, feat_dims={'Gene': 96}, data_path=f'/tmp/kgwas_gpudist_{os.getpid()}')
-    run = KGWAS(data, device='cuda:0', seed=seed)
+    run = KGWAS(data, device=device, seed=seed)
     run.initialize_model()
     return data, run
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, per_device=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = f'cuda:{rank}' if per_device else 'cuda:0'
+    torch.cuda.set_device(rank if per_device else 0)
+    if per_device:                               # one rank per GPU over RCCL / xGMI (a box with >= world devices)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from kgwas_amd import dist as kdist
         from kgwas_amd.graph_step import GraphTrainStep
-        torch.cuda.set_device(0)
-        data, run = _make_run()
+        data, run = _make_run(device=dev)
         kdist.broadcast_params(run.model)
         ids = np.asarray(data.train_input_nodes[1])[:BS * world * (STEPS + 1)]
         mine = ids.reshape(-1, world, BS)[:, rank].reshape(-1)          # this rank's batch of every step
@@ -56,10 +60,15 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_rank_graph_step_equals_hand_averaged_single_process(tmp_path):
+@pytest.mark.parametrize('per_device', [False, True], ids=['gloo_one_device', 'rccl_one_rank_per_device'])
+def test_two_rank_graph_step_equals_hand_averaged_single_process(tmp_path, per_device):
+    """(``rccl_one_rank_per_device``, VERDICT r5 item 6: the seed-parallel captured step with one rank PER GPU over RCCL against
+    the same single-process computation -- skipped on a box with one GPU, where the ranks share cuda:0 over gloo)"""
     world = 2
+    if per_device and torch.cuda.device_count() < world:
+        pytest.skip(f'needs {world} GPUs, this box has {torch.cuda.device_count()}')
     port = _free_port()
-    mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method='spawn')
+    mp.start_processes(_worker, args=(world, port, str(tmp_path), per_device), nprocs=world, join=True, start_method='spawn')
     r0 = torch.load(os.path.join(tmp_path, 'rank0.pt'))
     r1 = torch.load(os.path.join(tmp_path, 'rank1.pt'))
     assert r0.keys() == r1.keys()

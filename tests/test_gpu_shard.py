@@ -31,7 +31,7 @@ def _free_port():
     return p
 
 
-def _make_run(which, seed=11, random_bias=True, no_relu=False):
+def _make_run(which, seed=11, random_bias=True, no_relu=False, device='cuda:0'):
     from kgwas_amd.kgwas import KGWAS
     from kgwas_amd.kgwas_data import KGWAS_Data
     if which == 'small':
@@ -47,7 +47,7 @@ def _make_run(which, seed=11, random_bias=True, no_relu=False):
         data.all_ids = np.arange(n)
         data.ldsc_weight = 0.5 + rng.random(n)
         data.train_input_nodes = ('SNP', rng.permutation(n))
-    run = KGWAS(data, device='cuda:0', seed=seed)
+    run = KGWAS(data, device=device, seed=seed)
     run.initialize_model(no_relu=no_relu)
     if random_bias:
         with torch.no_grad():                               # non-zero relation biases: exercise their path
@@ -64,16 +64,22 @@ def _ids(data):
 def _worker(rank, world, port, out_dir, which, backend='gloo'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    torch.cuda.set_device(0)
-    if backend == 'nccl':                       # RCCL: one rank per device, so ONE rank that still issues every collective
+    dev = 'cuda:0'
+    if backend == 'nccl-per-device':            # the real thing: one rank per GPU over RCCL / xGMI (boxes with >= world devices)
+        dev = f'cuda:{rank}'
+        torch.cuda.set_device(rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
+    elif backend == 'nccl':                     # RCCL on a 1-GPU box: ONE rank that still issues every collective
+        torch.cuda.set_device(0)
         os.environ['KGW_FORCE_MULTIRANK_PATH'] = '1'
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda:0'))
     else:
+        torch.cuda.set_device(0)
         dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from kgwas_amd import dist as kdist
         from kgwas_amd.shard import ShardedTrainer
-        data, run = _make_run(which)
+        data, run = _make_run(which, device=dev)
         kdist.broadcast_params(run.model)
         run.model.train()
         st = ShardedTrainer(run, ('SNP', _ids(data)), BS, lr=1e-3, weight_decay=5e-4)
@@ -103,10 +109,15 @@ def _worker(rank, world, port, out_dir, which, backend='gloo'):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('which,world,backend', [('small', 2, 'gloo'), ('small', 4, 'gloo'), ('edge', 2, 'gloo'), ('small', 1, 'nccl')])
+@pytest.mark.parametrize('which,world,backend', [('small', 2, 'gloo'), ('small', 4, 'gloo'), ('edge', 2, 'gloo'), ('small', 1, 'nccl'),
+                                                 ('small', 2, 'nccl-per-device'), ('edge', 2, 'nccl-per-device')])
 def test_sharded_mode_equals_single_process(tmp_path, which, world, backend):
     """(the 'nccl' case: the exchange's collectives -- MIN all-reduce of the frontier flags, all-gather of the partial softmax
-    states, SUM all-reduce of dZ rows / gradients / predictions -- issued over RCCL by the one rank a 1-GPU box can host)"""
+    states, SUM all-reduce of dZ rows / gradients / predictions -- issued over RCCL by the one rank a 1-GPU box can host;
+    'nccl-per-device' (VERDICT r5 item 6): one rank PER GPU over RCCL, the same assertions -- skipped on a box with fewer GPUs
+    than ranks)"""
+    if backend == 'nccl-per-device' and torch.cuda.device_count() < world:
+        pytest.skip(f'needs {world} GPUs, this box has {torch.cuda.device_count()}')
     port = _free_port()
     mp.start_processes(_worker, args=(world, port, str(tmp_path), which, backend), nprocs=world, join=True, start_method='spawn')
     recs = [torch.load(os.path.join(tmp_path, f'rank{r}.pt'), weights_only=False) for r in range(world)]
