@@ -11,14 +11,17 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(CSRC, 'libkgwas_hip.so')
-OBJ = os.path.join(CSRC, 'build')
-STAMP = os.path.join(OBJ, 'stamp.json')
+STAMP_DIR = os.path.join(CSRC, 'build')
+STAMP = os.path.join(STAMP_DIR, 'stamp.json')          # (what the shipped library was built from: travels with it)
+# the objects are a cache, not a product: outside the tree, so that they neither ship to a GPU box with the snapshot nor sit in it
+OBJ = os.path.join(tempfile.gettempdir(), 'kgwas_amd_build_' + hashlib.sha256(ROOT.encode()).hexdigest()[:12])
 FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC']
 
 
@@ -73,7 +76,7 @@ def build_host(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(' '.join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(STAMP_DIR, exist_ok=True)
     st['host'] = want
     with open(STAMP, 'w') as f:
         json.dump(st, f)
@@ -93,6 +96,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(STAMP_DIR, exist_ok=True)
     want, have = _hashes(), ({} if force else _stamp().get('objects', {}))
     inc = ['-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
     jobs = []

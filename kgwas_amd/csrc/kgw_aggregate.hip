@@ -1162,7 +1162,7 @@ inline int grid_for_waves(int64_t n_waves) {
 // backward-dst 57.1 / 58.0 / 57.6, backward-src 108.4 / 106.8 / 109.3 -- only the src-major pass reaches the cap there), batch 4096
 // (6.2 M edges, 15 k blocks of chunks) 329.6 / 308.1 / 298.7, 343.5 / 326.5 / 325.3, 566.0 / 538.8 / 535.8: 16384.
 inline int grid_fine(int64_t n_items) {
-    static const int64_t cap = getenv("KGW_AGG_GRID_CAP") ? atoll(getenv("KGW_AGG_GRID_CAP")) : 16384;
+    const int64_t cap = 16384;
     int64_t g = (n_items + 3) / 4;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
@@ -1183,12 +1183,10 @@ extern "C" int kgw_gat_aggregate_fwd(const KgwLayerArgs* a, kgw_stream_t stream_
     AggPtrs P = build_ptrs(a);
     hipStream_t st = (hipStream_t)stream_;
     if (a->ev_before) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_before, st));
-    // KGW_AGG_PIPE: bit 0 = pipelined k_agg_fwd, bit 1 = pipelined k_agg_bwd_dst.  Measured at KGW_CHUNK = 128 (layer-1
-    // launch of the benchmark): forward 55.5 us plain / 57.5 pipelined (122 VGPRs cost two wavefronts per SIMD), backward
-    // 56.8 plain / 53.2 pipelined => default 2
-    static const int pipe = (getenv("KGW_AGG_PIPE") ? atoi(getenv("KGW_AGG_PIPE")) : 2) & 1;
+    // (software-pipelined chunks -- next group's rows + next block's ids in flight -- measured at KGW_CHUNK = 128 on the layer-1
+    //  launch of the benchmark: forward 55.5 us plain / 57.5 pipelined (122 VGPRs cost two wavefronts per SIMD), backward-dst
+    //  56.8 plain / 53.2 pipelined => the forward plain, the dst-major backward pipelined)
     if (P.raw) k_agg_fwd<true, false><<<grid_fine(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
-    else if (pipe) k_agg_fwd<false, true><<<grid_fine(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
     else       k_agg_fwd<false, false><<<grid_fine(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
     KGW_LAUNCH_CHECK();
     if (a->ev_after) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_after, st));
@@ -1211,9 +1209,7 @@ extern "C" int kgw_gat_aggregate_bwd_dst(const KgwLayerArgs* a, kgw_stream_t str
     AggPtrs P = build_ptrs(a);
     hipStream_t st = (hipStream_t)stream_;
     if (a->ev_before) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_before, st));
-    static const int pipe = (getenv("KGW_AGG_PIPE") ? atoi(getenv("KGW_AGG_PIPE")) : 2) & 2;
-    if (pipe) k_agg_bwd_dst<true><<<grid_fine(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
-    else k_agg_bwd_dst<false><<<grid_fine(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
+    k_agg_bwd_dst<true><<<grid_fine(a->n_chunks), KGW_BLK, 0, st>>>(T, P, a->neg_slope, a->inv_temp);
     KGW_LAUNCH_CHECK();
     if (a->ev_after) KGW_HIP(hipEventRecord((hipEvent_t)a->ev_after, st));
     if (a->multi && a->multi_cap > 0) {

@@ -259,7 +259,7 @@ extern "C" int kgw_fold_bwd(const KgwFoldArgs* a, kgw_stream_t stream_) {
     if (!P.dUp || !P.dVp || !P.dkappa || !P.dWp || !P.dgamma || !P.dU || !P.dV || !P.dws) return KGW_E_NULL;
     for (int m = 0; m < T.n_mlp; ++m)
         if (!P.dfcw[m] || !P.dfcb[m]) return KGW_E_NULL;
-    static const int parts = getenv("KGW_FOLD_PARTS") ? atoi(getenv("KGW_FOLD_PARTS")) : 15;   // (timing experiments only)
+    const int parts = 15;                             // (all four block classes)
     k_fold_bwd<<<2 * T.n + 16 * T.n_mlp + T.n_rels, 512, 0, (hipStream_t)stream_>>>(T, P, parts);
     KGW_LAUNCH_CHECK();
     return KGW_OK;

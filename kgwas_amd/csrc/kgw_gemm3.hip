@@ -40,11 +40,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned g3_u4;
 
 static constexpr int G3_CH_U4 = 1536;          // uint4 per packed chunk of 32 k: 2 steps x 3 pieces x 4 column tiles x 64 lanes
 static constexpr int G3_FLIP = 16;             // chunks (of 32 k) per sign period of the accumulation, a power of two -- see k_g3_gemm
-// (KGW_G3_FLIP=<power of two, 0 = never>: A/B runs of the period; packing and product read the same value)
-static int g3_flip() {
-    static const int f = getenv("KGW_G3_FLIP") ? atoi(getenv("KGW_G3_FLIP")) : G3_FLIP;
-    return (f > 0 && !(f & (f - 1))) ? f : 0;
-}
+// (periods of 4 chunks measured the same error and 2 - 10 us per step of pipe drains, 16 nothing: round 4; the A/B knob is gone)
+static int g3_flip() { return G3_FLIP; }
 static constexpr int G3_MAX_ITEMS = 512;       // 128-row blocks resident at once (two per CU on 256 CUs; 256-row blocks: half)
 
 // ---- B operand packing ------------------------------------------------------------------------------------------------------
@@ -332,10 +329,7 @@ __global__ void __launch_bounds__(256) k_g3_reduce_t(const float* __restrict__ w
 }
 
 // ---- C ABI ---------------------------------------------------------------------------------------------------------------------
-static int g3_nw() {
-    static const int nw = getenv("KGW_G3_NW") ? atoi(getenv("KGW_G3_NW")) : 8;    // wavefronts per block (experiments: 4)
-    return nw == 4 ? 4 : 8;
-}
+static int g3_nw() { return 8; }               // wavefronts per block (four, 128-row blocks two per CU, read B from L2 twice as often: 151 us against 136)
 
 static int g3_splits(int64_t M, int64_t K) {
     const int rt = 32 * g3_nw();

@@ -955,8 +955,7 @@ extern "C" int kgw_sample_batch_parts(const KgwGraph* graph, const KgwBatchBuf* 
     if (!graph || !buf) return KGW_E_NULL;
     // grid of the sampler's grid-stride kernels: KgwBatchBuf.grid_blocks (a sampler replayed BESIDE a training step keeps
     // its launches small), else the whole-GPU default
-    static const int sg_env = getenv("KGW_SAMPLER_GRID") ? atoi(getenv("KGW_SAMPLER_GRID")) : 0;
-    const int SG = sg_env > 0 ? sg_env : (buf->grid_blocks > 0 ? (buf->grid_blocks < KGW_GRID ? buf->grid_blocks : KGW_GRID) : KGW_GRID);
+    const int SG = buf->grid_blocks > 0 ? (buf->grid_blocks < KGW_GRID ? buf->grid_blocks : KGW_GRID) : KGW_GRID;
     if (!full_graph && (!seeds || n_seeds <= 0)) return KGW_E_NULL;
     if (graph->n_types < 1 || graph->n_types > KGW_MAX_TYPES || graph->n_rels < 1 ||
         graph->n_rels > KGW_MAX_RELS || graph->n_layers < 1 || graph->n_layers > KGW_MAX_LAYERS ||

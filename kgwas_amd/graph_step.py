@@ -185,7 +185,7 @@ class GraphTrainStep:
         self.deferred_gradients = 0
         self.finish_fused = False          # (set below: multi-rank split backward)
         self._images, self._image_params, self._image_version, self._pack_probe = {}, [], {}, None
-        self.split_backward = self._multi and os.environ.get('KGW_SPLIT_BACKWARD', '1') == '1'
+        self.split_backward = self._multi
         self.finish_fused = ops._FUSED_ADAM and self.split_backward
         self.duv_pieces = ops._DUV_PIECES and self.fused_adam           # (single GPU, whole backward in one autograd pass)
         # multi-rank, optional: the first gene Linear over the resident feature matrix (forward + weight gradient: 0.27 of the
@@ -219,7 +219,7 @@ class GraphTrainStep:
         self._flat_grads = None
         self.graphs = [None, None]
         if overlap_sampling is None:
-            overlap_sampling = os.environ.get('KGW_OVERLAP_SAMPLING', '2')
+            overlap_sampling = '2'
         # '2' (default): the next batch is sampled by a graph of its own, replayed on a side stream while the step's
         # graph runs (the sampler is ~50 short dependent launches: they hide under the step's GEMMs; measured 2.21 vs
         # 2.31 ms/step); '0' / False: at the tail of the step's graph; '1' / True: on a forked branch of the same graph
@@ -231,7 +231,7 @@ class GraphTrainStep:
         self._side = side_stream(dev)
         self._have = [-1, -1]                      # batch index currently sampled into each buffer
         # (timing experiments only: train on stale batches to see what the concurrent sampler costs the step)
-        self._skip_resample = os.environ.get('KGW_SKIP_RESAMPLE', '0') == '1'
+        self._skip_resample = False
         self._twin_pending = [False, False]        # the side stream holds an unfinished sample of this buffer
         # ``cache_batches`` (KGWAS.train with more than one epoch; off for a bench line -- the headline samples live): the batches of
         # the first pass over the loader are kept and put back in later passes instead of being sampled again (BatchCache)

@@ -374,7 +374,7 @@ _PARAM_TAIL = os.environ.get('KGW_PARAM_TAIL', '1') != '0'
 # in the SNP MLP's tall weight-gradient product took the carrier's registers and LDS and ran two per CU -- 78.5 us against 8.3 + 47.1.
 # KGW_DEFER_REDUCE=0: every second launch where it is.
 _DEFER_REDUCE = os.environ.get('KGW_DEFER_REDUCE', '1') != '0'
-_RIDE_MAX_BLOCKS = int(os.environ.get('KGW_RIDE_MAX_BLOCKS', '2048'))
+_RIDE_MAX_BLOCKS = 2048
 # The resident first layer's backward writes d(pre-activation) directly as the kgw_gemm3 operand image of the weight gradient
 # (kgw_mlp2_bwd_first_packed): the kgw_gemm3_pack launch (7 us) and the fp32 rows it read disappear.  KGW_PACK_FUSED=0: as before.
 _PACK_FUSED = os.environ.get('KGW_PACK_FUSED', '1') != '0'
@@ -416,8 +416,6 @@ class grad_sink_scope:
         return False
 
 
-_MLP2_FUSED = os.environ.get('KGW_MLP2_FUSED', '1') != '0'        # 0: the two hidden layers of a narrow MLP as two launches
-_TN_GROUP = os.environ.get('KGW_TN_GROUP', '1') != '0'             # 0: one launch pair per destination type in the transform's backward
 _DUV_RIDERS = os.environ.get('KGW_DUV_RIDERS', '1') != '0'        # 0: d u_r / d v_r through the [d a_src | d a_dst] rows + product
 _GEMM3 = os.environ.get('KGW_GEMM3', '1') != '0'                   # 0: the first gene Linear and its weight gradient on the library's fp32 product
 _SHORT_ROWS = os.environ.get('KGW_SHORT_ROWS', '1') != '0'     # 0: every source row on the general path (timing experiments)
@@ -695,7 +693,7 @@ def tn_gemm(A: torch.Tensor, B: torch.Tensor, colsum: bool = False, out: torch.T
 def _tn_gemm_group(jobs) -> bool:
     """Several C^T = (A^T B)^T products with column sums of A (``jobs``: [(A [rows, M], B [rows, N], out [N, M] row-major view,
     colsum_out [q, M])]) in one kgw_tn_gemm_multi launch pair.  False: not taken (one job, shapes outside the grouped tiling)."""
-    if not (_TN_GROUP and 2 <= len(jobs) <= 4):
+    if not (2 <= len(jobs) <= 4):
         return False
     for A, B, out, cs in jobs:
         if not (A.dtype == torch.float32 and B.dtype == torch.float32 and A.stride(1) == 1 and B.stride(1) == 1 and out.stride(1) == 1 and
@@ -794,7 +792,7 @@ def _library_linear(X, W, bias, relu, mask, w_kn, out, fixed_shape):
 
 
 _LIN_MAX_K = 2304        # wider reductions (the 5120 / 57742-wide gene layer) go to the library GEMM
-_SPLITK_MAX_ROWS = int(os.environ.get('KGW_SPLITK_MAX_ROWS', '8192'))     # below: kgw_linear_splitk (0 = off)
+_SPLITK_MAX_ROWS = 8192     # below: kgw_linear_splitk
 
 
 def linear(X: torch.Tensor, W: torch.Tensor, bias=None, relu: bool = False, mask=None, w_kn: bool = False,
@@ -1392,7 +1390,7 @@ class _MLP2(torch.autograd.Function):
         # ``ids``: x is a RESIDENT feature matrix and the input rows are x[ids] (the loader's slicing, kgwas/kgwas.py:135)
         rows, K1 = (x.shape if ids is None else (ids.numel(), x.shape[1]))
         h2 = out.view() if out is not None else None
-        if (_MLP2_FUSED and rows >= 16384 and K1 <= 20 and K1 % 4 == 0 and W1.shape[0] == KGW_C and W2.shape == (KGW_C, KGW_C)
+        if (rows >= 16384 and K1 <= 20 and K1 % 4 == 0 and W1.shape[0] == KGW_C and W2.shape == (KGW_C, KGW_C)
                 and x.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
                 and W1.stride(1) == 1 and W2.stride(1) == 1 and W2.stride(0) % 4 == 0 and W2.data_ptr() % 16 == 0
                 and b1 is not None and b2 is not None and (ids is None or ids.dtype == torch.int32)
@@ -1425,7 +1423,7 @@ class _MLP2(torch.autograd.Function):
         rd = ctx.rows_dev
         dh2 = dh2.contiguous()
         rows, K1 = x.shape
-        if (_MLP2_FUSED and rows >= 16384 and K1 <= 31 and h1.shape[1] == KGW_C and W2.shape == (KGW_C, KGW_C) and x.stride(1) == 1
+        if (rows >= 16384 and K1 <= 31 and h1.shape[1] == KGW_C and W2.shape == (KGW_C, KGW_C) and x.stride(1) == 1
                 and h1.stride(1) == 1 and dh2.stride(0) % 4 == 0 and h1.stride(0) % 4 == 0 and W2.stride(0) % 4 == 0
                 and dh2.data_ptr() % 16 == 0 and h1.data_ptr() % 16 == 0 and W2.data_ptr() % 16 == 0):
             # narrow first layer, no input gradient: dh1 = (dh2 @ W2) * (h1 > 0) is consumed tile by tile by the d W1 / d b1
@@ -1505,7 +1503,7 @@ def mlp2_gathered(jobs, W1, b1, W2, b2, out=None):
 
 
 def mlp2_gathered_ok(jobs, W1, W2) -> bool:
-    return (_MLP2_FUSED and 1 <= len(jobs) <= 4 and W1.shape == (KGW_C, KGW_C) and W2.shape == (KGW_C, KGW_C)
+    return (1 <= len(jobs) <= 4 and W1.shape == (KGW_C, KGW_C) and W2.shape == (KGW_C, KGW_C)
             and all(x.dtype == torch.float32 and x.shape[1] == KGW_C and x.stride(1) == 1 and x.stride(0) % 4 == 0 and
                     x.data_ptr() % 16 == 0 and i.dtype == torch.int32 and x.stride(0) == jobs[0][0].stride(0) for x, i in jobs)
             and 0 < sum(int(i.numel()) for _, i in jobs) <= 16384)
@@ -1662,7 +1660,7 @@ def resident_mlp2(X, W1, b1, W2, b2, ids, g2l, out=None, rows_real=None):
 
 
 def resident_mlp2_ok(X, W1, W2, n_local: int) -> bool:
-    return (_MLP2_FUSED and W1.shape[0] == KGW_C and W2.shape == (KGW_C, KGW_C) and n_local > 0 and X.shape[0] >= 4096
+    return (W1.shape[0] == KGW_C and W2.shape == (KGW_C, KGW_C) and n_local > 0 and X.shape[0] >= 4096
             and W2.stride(1) == 1 and W2.stride(0) % 4 == 0 and W2.data_ptr() % 16 == 0)
 
 

@@ -402,7 +402,7 @@ class ShardedTrainer:
         # ``use_graph``: the step runs from captured HIP graphs, its collectives between them (SegmentedCapture).  That needs a
         # STATIC layout: a rank's share of a batch is padded to a fixed seed count with zero-weight, edge-less pad nodes appended
         # to its SNP range (they contribute nothing to loss, gradients or the exchange)
-        self.use_graph = bool(use_graph) and os.environ.get('KGW_SHARD_GRAPH', '1') == '1'
+        self.use_graph = bool(use_graph)
         self.n_pad = self.batch_size if self.use_graph else 0
         self.local, self.lo, self.hi = shard_graph(full, self.rank, self.world, sharded_type, n_pad=self.n_pad)
         L = run.gnn_num_layers
@@ -510,9 +510,9 @@ class ShardedTrainer:
         self.dg = self.dg_eager.with_static_caps(caps)
         # two batch buffers: while the step computes on one, the NEXT batch is sampled into the other on a side stream (its
         # frontier merge is a collective of that stream's segment list)
-        self.overlap = os.environ.get('KGW_SHARD_OVERLAP_SAMPLING', '1') == '1'
+        self.overlap = True
         from .graph_step import SIDE_SAMPLER_GRID               # (a sampler beside a step keeps its launches small)
-        grid = int(os.environ.get('KGW_SHARD_SAMPLER_GRID', SIDE_SAMPLER_GRID if self.overlap else 0))
+        grid = SIDE_SAMPLER_GRID if self.overlap else 0
         self.bufs = [BatchBuffers(self.dg, grid), BatchBuffers(self.dg, grid)]
         self.buf = self.bufs[0]
         self.seeds2 = [self.seeds_dev, torch.zeros_like(self.seeds_dev)]

@@ -343,6 +343,136 @@ def test_captured_training_steps_at_full_size_track_the_oracle(full_c1):
     assert torch.equal(torch.topk(pred.cpu().double(), 8).indices, torch.topk(pred_o, 8).indices)
 
 
+@pytest.mark.skipif(not int(__import__('os').environ.get('KGW_TRAJECTORY_STEPS', '0')), reason='artifact run: KGW_TRAJECTORY_STEPS=100')
+def test_long_captured_trajectory_beside_the_oracle_as_an_artifact(full_c1):
+    """VERDICT r5 item 7 (kgwas/kgwas.py:129-173): KGW_TRAJECTORY_STEPS captured steps of full-size configs[1] at batch 512 beside the
+    float64 oracle from the same initial state -- per-step loss, the parameter-update error every 10 steps, and validation MSE /
+    Pearson on a fixed subset of the validation SNPs before and after -- written to KGW_TRAJECTORY_OUT.  A hundred Adam steps are
+    not eight: Adam normalises every coordinate by its own second moment, so the coordinates whose gradient is a cancellation
+    residue (lin_dst / att_dst of the relations into the seeds) take +-lr steps whose SIGN is rounding noise -- in any
+    arithmetic.  The yardstick is therefore the reference's own arithmetic: the SAME oracle run in float32 (what PyG computes in)
+    beside the float64 one; this path is held to a small multiple of how far that run drifts.  Opt-in (~4 s of CPU per step)."""
+    import os
+    import time
+    from scipy.stats import pearsonr
+    from kgwas_amd.graph_step import GraphTrainStep
+    from kgwas_amd.kgwas import KGWAS
+    from kgwas_amd.sampler import NeighborLoader
+    from oracle.sampler_np import FullNeighborSamplerNP
+    n_steps = int(os.environ['KGW_TRAJECTORY_STEPS'])
+    n_val = int(os.environ.get('KGW_TRAJECTORY_VAL', '5120'))
+    out_path = os.environ.get('KGW_TRAJECTORY_OUT', 'gpurun_out/trajectory.txt')
+    run = KGWAS(full_c1.data, device='cuda:0', seed=5)
+    run.initialize_model()
+    model = run.model
+    bs, lr, wd = 512, 1e-4, 5e-4
+    ids = np.asarray(run.data.train_input_nodes[1])[:n_steps * bs]
+    val_ids = np.asarray(run.data.val_input_nodes[1])[:n_val]
+    g = run.data.data
+    smp = FullNeighborSamplerNP(g.edge_index_dict, g.num_nodes_dict, 2)
+    y_all = g['SNP'].y.double()
+    w_all = run._ld_weight_vector().cpu()
+    oracle = oracle_from_product(model, dtype=torch.float64)
+    oracle32 = oracle_from_product(model, dtype=torch.float32)
+    p0 = params_by_name(model)
+    lines = [f'{n_steps} captured training steps (GraphTrainStep: HIP graph, fused optimiser launch, side sampler) of full-size configs[1] '
+             f'(batch {bs}, Adam lr {lr}, weight decay {wd}: kgwas/kgwas.py:85-87,116) beside the float64 oracle from the same initial state;',
+             'yardstick: the same oracle in float32 (the reference\'s arithmetic) beside the float64 one.', '']
+
+    def val_hip():
+        model.eval()
+        preds = []
+        with torch.no_grad():
+            for b in NeighborLoader(g, [-1, -1], ('SNP', val_ids), batch_size=bs, device='cuda:0'):
+                preds.append(model(b.x_dict, b.edge_index_dict, b.batch_size).reshape(-1).double().cpu())
+        model.train()
+        return torch.cat(preds)
+
+    def val_oracle(orc, dt):
+        preds = []
+        with torch.no_grad():
+            for k in range(0, len(val_ids), bs):
+                seeds = val_ids[k:k + bs]
+                n_id, ei = smp.sample('SNP', seeds)
+                preds.append(orc({t: g[t].x[n_id[t]].to(dt) for t in g.node_types}, ei, len(seeds)).reshape(-1).double())
+        return torch.cat(preds)
+
+    def metrics(pred):
+        truth = y_all[torch.from_numpy(val_ids)]
+        return float(((pred - truth) ** 2).mean()), float(pearsonr(pred.numpy(), truth.numpy())[0])
+
+    def val_line(tag):
+        ph, po_, p32 = val_hip(), val_oracle(oracle, torch.float64), val_oracle(oracle32, torch.float32)
+        (mh, rh), (mo, ro), (m3, r3) = metrics(ph), metrics(po_), metrics(p32)
+        lines.append(f'validation subset ({len(val_ids)} SNPs) {tag}:')
+        lines.append(f'    oracle float64   MSE {mo:.6f}  Pearson {ro:+.6f}')
+        lines.append(f'    HIP path         MSE {mh:.6f}  Pearson {rh:+.6f}   |d MSE| {abs(mh - mo):.2e}  |d Pearson| {abs(rh - ro):.2e}  max |d pred| {float((ph - po_).abs().max()):.3e}')
+        lines.append(f'    oracle float32   MSE {m3:.6f}  Pearson {r3:+.6f}   |d MSE| {abs(m3 - mo):.2e}  |d Pearson| {abs(r3 - ro):.2e}  max |d pred| {float((p32 - po_).abs().max()):.3e}')
+        return (abs(rh - ro), abs(mh - mo) / max(mo, 1e-12)), (abs(r3 - ro), abs(m3 - mo) / max(mo, 1e-12))
+    val_line('before training')
+    gs = GraphTrainStep(run, ('SNP', ids), bs, lr=lr, weight_decay=wd)
+    model.train()
+    losses, snaps = [], {}
+    for i in range(n_steps):
+        losses.append(gs.step(i).detach().clone())
+        if (i + 1) % 10 == 0 or i + 1 == n_steps:
+            torch.cuda.synchronize()
+            snaps[i + 1] = {n: p.detach().clone().cpu().double() for n, p in params_by_name(model).items()}
+    gs.check()
+    losses = [float(l) for l in losses]
+    p0 = {n: p.cpu().double() for n, p in p0.items()}
+    opt = torch.optim.Adam(oracle.parameters(), lr=lr, weight_decay=wd)
+    opt32 = torch.optim.Adam(oracle32.parameters(), lr=lr, weight_decay=wd)
+    po, po32 = dict(oracle.named_parameters()), dict(oracle32.named_parameters())
+
+    def upd_err(cur):
+        num = den = 0.0
+        for n, p in cur.items():
+            if n in po:
+                d_a, d_ref = p - p0[n], po[n].detach() - p0[n]
+                num += float((d_a - d_ref).pow(2).sum()); den += float(d_ref.pow(2).sum())
+        return (num / max(den, 1e-300)) ** 0.5
+    t0 = time.time()
+    lines.append('')
+    lines.append('step   loss: oracle float64   HIP path (rel. diff)          oracle float32 (rel. diff)       [relative parameter-update error vs float64, norm-wise: HIP | float32 oracle]')
+    worst = {'hip_loss': 0.0, 'f32_loss': 0.0, 'hip_upd': 0.0, 'f32_upd': 0.0}
+    for i in range(n_steps):
+        n_id, ei = smp.sample('SNP', ids[i * bs:(i + 1) * bs])
+        sel = n_id['SNP'][:bs]
+        x = {t: g[t].x[n_id[t]].double() for t in g.node_types}
+        opt.zero_grad()
+        lo = weighted_mse(oracle(x, ei, bs), y_all[sel], w_all[sel])
+        lo.backward()
+        opt.step()
+        opt32.zero_grad()
+        l3 = weighted_mse(oracle32({t: v.float() for t, v in x.items()}, ei, bs), y_all[sel], w_all[sel])       # (float64 loss on float32 predictions: kgwas.py:139-145)
+        l3.backward()
+        opt32.step()
+        rh = abs(losses[i] - float(lo)) / max(abs(float(lo)), 1e-12)
+        r3 = abs(float(l3) - float(lo)) / max(abs(float(lo)), 1e-12)
+        worst['hip_loss'], worst['f32_loss'] = max(worst['hip_loss'], rh), max(worst['f32_loss'], r3)
+        extra = ''
+        if i + 1 in snaps:
+            uh = upd_err(snaps[i + 1])
+            u3 = upd_err({n: p.detach().double() for n, p in po32.items()})
+            worst['hip_upd'], worst['f32_upd'] = max(worst['hip_upd'], uh), max(worst['f32_upd'], u3)
+            extra = f'   update error {uh:.3e} | {u3:.3e}'
+        lines.append(f'{i + 1:4d}   {float(lo):.10f}   {losses[i]:.10f} ({rh:.2e})   {float(l3):.10f} ({r3:.2e}){extra}')
+    lines.append('')
+    lines.append(f'({n_steps} steps of both oracles: {time.time() - t0:.0f} s of CPU)')
+    lines.append(f'worst per-step loss difference from float64: HIP path {worst["hip_loss"]:.2e}, float32 oracle {worst["f32_loss"]:.2e} (relative)')
+    lines.append(f'worst parameter-update error vs float64:     HIP path {worst["hip_upd"]:.3e}, float32 oracle {worst["f32_upd"]:.3e}')
+    (dr_h, dm_h), (dr_3, dm_3) = val_line(f'after {n_steps} steps')
+    os.makedirs(os.path.dirname(out_path) or '.', exist_ok=True)
+    with open(out_path, 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    print('\n'.join(lines[-12:]))
+    # this path drifts from float64 no further than a small multiple of what the reference's own arithmetic does
+    assert worst['hip_loss'] <= max(2e-4, 3.0 * worst['f32_loss']), worst
+    assert worst['hip_upd'] <= max(2e-2, 3.0 * worst['f32_upd']), worst
+    assert dr_h <= max(1e-3, 3.0 * dr_3) and dm_h <= max(1e-3, 3.0 * dm_3), ((dr_h, dm_h), (dr_3, dm_3))
+
+
 def test_full_mode_widths_against_the_oracle_at_a_reduced_gene_count():
     """configs[4] widths 70 / 57 742 / 128 (kgwas_data.py:167,244) on a quarter-scale graph (5 008 genes: the 57 742-wide product
     through kgw_gemm3's zero-padded-K route, 57 760 = 1 805 x 32) against the float64 oracle."""

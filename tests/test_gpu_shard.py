@@ -218,35 +218,38 @@ def _train_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('short_rows', [False, True])
-def test_kgwas_train_in_sharded_mode_matches_single_process_training(tmp_path, monkeypatch, short_rows):
-    """KGWAS.train(parallelism='shard') through the reference's API (training epoch, validation with drop_last, test,
-    whole-genome inference, p-values) on 2 ranks vs the single-process eager training: same batches, same SGD steps up
+@pytest.mark.parametrize('variant', ['pinned_order_fp32_pipe', 'pinned_order_shipped_pipe', 'shipped'])
+def test_kgwas_train_in_sharded_mode_matches_single_process_training(tmp_path, monkeypatch, variant):
+    """KGWAS.train(parallelism='shard') over two ranks vs KGWAS.train on one process: same data, same initial weights, one epoch, up
     to fp32 summation order.
 
     This toy problem has no signal (validation Pearson ~0.02) and several relation weights whose true gradient is zero:
     Adam divides their rounding noise by eps, so ANY change of summation order random-walks them (measured: 7e-9 after
-    step 0, 5e-5 after step 4, 4e-3 after the epoch) and moves the validation MSE by ~0.1 %.  ``short_rows=False`` pins
-    the summation order (the backward's 8-rows-per-wavefront path groups a rank's LOCAL source rows, so it orders the
-    a_src term differently in the sharded and the single-process layout) and holds the run to north_star's bar -- validation
-    Pearson within 1e-3, predictions within tolerance; ``short_rows=True`` is the shipped configuration, held to what that
-    noise allows (the path itself is compared with the general one in test_gpu_aggregate.py)."""
+    step 0, 5e-5 after step 4, 4e-3 after the epoch) and moves the validation MSE by ~0.1 %.  Three variants:
+    * ``pinned_order_fp32_pipe``: summation order pinned on both sides -- the backward's 8-rows-per-wavefront path off (it groups a
+      rank's LOCAL source rows, so it orders the a_src term differently in the sharded and the single-process layout) and the
+      128-wide weight-gradient products on the fp32 matrix pipe (the bf16 x 3 pipe takes 16 rows per MFMA step: a rank's rows sit
+      in other groups of 16 than the single process's) -- held to north_star's bar: validation Pearson within 1e-3, MSE within
+      1e-3, predictions within tolerance;
+    * ``pinned_order_shipped_pipe``: the same with the SHIPPED pipe of those products (bf16 x 3).  Gradients
+      of a step then differ from the fp32 pipe's by 3e-7 (measured), and that alone random-walks the zero-gradient weights like any
+      other change of order: the bounds are what that noise was measured to do, with a factor ~2.5 of head-room;
+    * ``shipped``: every default (short-row path on), held to what the noise allows (the path itself is compared with the general
+      one in test_gpu_aggregate.py)."""
     from kgwas_amd import _lib, ops
+    short_rows = variant == 'shipped'
+    split = variant != 'pinned_order_fp32_pipe'
     monkeypatch.setenv('KGW_SHORT_ROWS', '1' if short_rows else '0')          # the spawned ranks
     monkeypatch.setattr(ops, '_SHORT_ROWS', short_rows)                        # this process
-    # (round 5: the weight-gradient products on the bf16 pipe take 16 rows per MFMA step -- a rank's rows sit in other groups of 16
-    #  than the single process's, one more change of summation order: the pinned variant keeps them on the fp32 pipe, whose result
-    #  does not depend on where a row sits; measured with the bf16 pipe: gradients of a step within 3e-7 of the fp32 pipe's, validation
-    #  MSE 22.987 against 23.013 after the epoch -- the 0.1 % of the paragraph above)
-    monkeypatch.setenv('KGW_TN_SPLIT', '1' if short_rows else '0')
-    was = _lib.lib().kgw_tn_split(1 if short_rows else 0)
+    monkeypatch.setenv('KGW_TN_SPLIT', '1' if split else '0')
+    was = _lib.lib().kgw_tn_split(1 if split else 0)
     try:
-        _sharded_vs_single(tmp_path, short_rows)
+        _sharded_vs_single(tmp_path, variant)
     finally:
         _lib.lib().kgw_tn_split(was)
 
 
-def _sharded_vs_single(tmp_path, short_rows):
+def _sharded_vs_single(tmp_path, variant):
     world = 2
     port = _free_port()
     mp.start_processes(_train_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method='spawn')
@@ -257,14 +260,21 @@ def _sharded_vs_single(tmp_path, short_rows):
     run.train(batch_size=BS, epoch=1, save_best_model=False, save_name='single', use_graph=False)
     assert np.isfinite(run.val_metrics['pearsonr'])
     ref = np.asarray(run.kgwas_res['pred'].values)
-    if short_rows:
-        assert abs(float(r0['val']['mse']) - float(run.val_metrics['mse'])) < 1e-2 * float(run.val_metrics['mse'])
-        assert abs(float(r0['test']['mse']) - float(run.test_metrics['mse'])) < 1e-2 * float(run.test_metrics['mse'])
+    d_r = abs(float(r0['val']['pearsonr']) - float(run.val_metrics['pearsonr']))
+    d_val = abs(float(r0['val']['mse']) - float(run.val_metrics['mse'])) / float(run.val_metrics['mse'])
+    d_test = abs(float(r0['test']['mse']) - float(run.test_metrics['mse'])) / float(run.test_metrics['mse'])
+    d_pred = float(np.abs(r0['pred'] - ref).max())
+    print(f'[sharded vs single, {variant}] |d Pearson| {d_r:.2e}  rel d val MSE {d_val:.2e}  rel d test MSE {d_test:.2e}  '
+          f'max |d pred| {d_pred:.2e}  corr {np.corrcoef(r0["pred"], ref)[0, 1]:.6f}')
+    if variant == 'shipped':
+        assert d_val < 1e-2 and d_test < 1e-2
         assert np.corrcoef(r0['pred'], ref)[0, 1] > 0.999
         return
-    assert abs(float(r0['val']['pearsonr']) - float(run.val_metrics['pearsonr'])) < 1e-3
-    assert abs(float(r0['val']['mse']) - float(run.val_metrics['mse'])) < 1e-3 * float(run.val_metrics['mse'])
-    assert abs(float(r0['test']['mse']) - float(run.test_metrics['mse'])) < 1e-3 * float(run.test_metrics['mse'])
+    if variant == 'pinned_order_shipped_pipe':
+        assert d_r < 3e-3 and d_val < 3e-3 and d_test < 3e-3
+        assert np.corrcoef(r0['pred'], ref)[0, 1] > 0.9995
+        return
+    assert d_r < 1e-3 and d_val < 1e-3 and d_test < 1e-3
     assert np.allclose(r0['pred'], ref, rtol=2e-3, atol=2e-4)
 
 

@@ -19,8 +19,15 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in kgwas_hip.h but not exported'
     assert sorted(_lib.EXPORTS) == declared
-    assert lib.kgw_version() == 125
+    ver = int(re.search(r'#define KGW_VERSION\s+(\d+)', hdr).group(1))
+    assert lib.kgw_version() == ver == 125
     assert lib.kgw_status_string(-1) == b'null pointer argument'
+    # the binding sketch a maintainer of the reference would start from names the same ABI, and every entry point of the header has
+    # its row in INTEGRATION.md's table (the sketch had gone stale)
+    integ = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    assert f'kgw_version() == {ver}' in integ
+    missing = [n for n in declared if f'`{n}`' not in integ and f'`{n}(' not in integ]
+    assert not missing, missing
 
 
 def test_sampler_scratch_size_covers_every_sort_plan():
