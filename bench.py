@@ -776,7 +776,7 @@ def main():
         'metric': 'edges aggregated/sec (full fast-mode KG minibatch training; epoch time in config)',
         'value': edges_kernel / elapsed, 'unit': 'edges/s', 'n_gpus': 1 if emulated is not None else world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
-        'scaling_note': ('weak: every GPU trains on its own 512-seed batches of the reference\'s order against a replicated graph, one '
+        'scaling_note': ('weak: every GPU trains on its own 512-seed batches of the reference\'s order against a replicated graph -- a GLOBAL batch of N x 512 seeds per step, i.e. a different optimisation trajectory from the reference\'s 512 at the same lr --, one '
                          'all-reduce of the parameter gradients per step (SURVEY 8e-i) -- the default of --gpus N and the mode that scales: '
                          'a 784 k-SNP graph fits one MI355X many times over.  The partitioning north_star prescribes (--parallelism shard: '
                          'SNP rows by id range, Gene / GO replicated, partial-softmax exchange) is built and tested but is predicted BELOW '
