@@ -100,6 +100,41 @@ def test_cached_epochs_are_bit_identical_to_sampled_ones(small_kg):
                 assert torch.equal(a, b), n
 
 
+def test_kgwas_train_with_kept_batches_equals_train_that_samples_every_epoch(small_kg, monkeypatch):
+    """The same through the reference's API: KGWAS.train(epoch=3) (kgwas/kgwas.py:85-212) keeps the batches of epoch 1 by default;
+    with KGW_EPOCH_CACHE=0 it samples every batch of every epoch.  Validation metrics of the last epoch, test metrics, the
+    whole-genome predictions and every parameter of the best model: bit for bit."""
+    from kgwas_amd import graph_step
+    from kgwas_amd.kgwas import KGWAS
+    outs, made = [], []
+    real_init = graph_step.BatchCache.__init__
+
+    def counting_init(self, *a, **k):
+        real_init(self, *a, **k)
+        made.append(self)
+    monkeypatch.setattr(graph_step.BatchCache, '__init__', counting_init)
+    for keep in ('1', '0'):
+        monkeypatch.setenv('KGW_EPOCH_CACHE', keep)
+        run = KGWAS(small_kg, device='cuda:0', seed=23)
+        run.initialize_model()
+        if outs:
+            run.model.load_state_dict(sd0)
+        else:
+            sd0 = copy.deepcopy(run.model.state_dict())
+        n_before = len(made)
+        run.train(batch_size=64, epoch=3, save_best_model=False, save_name='keep' + keep)
+        assert (len(made) > n_before) == (keep == '1')
+        if keep == '1':
+            c = made[-1]
+            assert c.saved == c.n_batches and c.restored >= 2 * c.n_batches - 1, (c.saved, c.restored, c.n_batches)
+        outs.append((dict(run.val_metrics), dict(run.test_metrics), np.asarray(run.kgwas_res['pred'].values).copy(),
+                     {k: v.detach().clone() for k, v in run.best_model.named_reference_tensors().items()}))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
+    assert np.array_equal(outs[0][2], outs[1][2]) and float(np.abs(outs[0][2]).sum()) > 0
+    for k in outs[0][3]:
+        assert torch.equal(outs[0][3][k], outs[1][3][k]), k
+
+
 def test_static_capacity_overflow_is_reported(small_kg):
     """A batch that needs more rows than the static layout holds must raise, never silently truncate."""
     from kgwas_amd import _lib
