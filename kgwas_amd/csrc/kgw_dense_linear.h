@@ -896,46 +896,67 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
         for (int q = 0; q < 16; ++q) *(f32x4*)(gp + 4 * q) = xa[q];
     }
-    // product 1: every column tile; operands W1[32 t + li][64 lk + 4 q + c] from LDS, a step ahead
-    f32x16 acc[4];
+    // product 1: THIS wavefront's two column tiles t0, t0 + 1 (round 6; until then both wavefronts of a row tile computed all four:
+    // 256 MFMAs each, half of them twice); the other two come from the partner wavefront through LDS below.  Operands
+    // W1[32 t + li][64 lk + 4 q + c] from LDS, a step ahead
+    f32x16 acc[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    const float* w1p = W1l + li * WST + lk * 64;
-    f32x4 wn[4];
+    const float* w1p = W1l + (t0 * 32 + li) * WST + lk * 64;
+    f32x4 wn[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) wn[t] = *(const f32x4*)(w1p + t * 32 * WST);
+    for (int t = 0; t < 2; ++t) wn[t] = *(const f32x4*)(w1p + t * 32 * WST);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        f32x4 w[4];
+        f32x4 w[2];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) w[t] = wn[t];
+        for (int t = 0; t < 2; ++t) w[t] = wn[t];
         if (q + 1 < 16) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) wn[t] = *(const f32x4*)(w1p + t * 32 * WST + 4 * (q + 1));
+            for (int t = 0; t < 2; ++t) wn[t] = *(const f32x4*)(w1p + t * 32 * WST + 4 * (q + 1));
         }
 #define KGW_MLPW_STEP(C)                                                                                  \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                    \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                    \
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].C, xa[q].C, acc[t], 0, 0, 0);
         KGW_MLPW_STEP(x) KGW_MLPW_STEP(y) KGW_MLPW_STEP(z) KGW_MLPW_STEP(w)
 #undef KGW_MLPW_STEP
     }
-    // h1 = relu(. + b1): accumulator element 4 g + c of tile t = column 32 t + 8 g + 4 lk + c of this lane's row
+    // h1 = relu(. + b1) of my tiles: accumulator element 4 g + c of tile t = column 32 (t0 + t) + 8 g + 4 lk + c of this lane's row
+    f32x4 xh[8];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 b4 = *(const f32x4*)(bl + t * 32 + 8 * g + 4 * lk);
+            const f32x4 b4 = *(const f32x4*)(bl + (t0 + t) * 32 + 8 * g + 4 * lk);
             f32x4 v;
             v.x = fmaxf(acc[t][4 * g + 0] + b4.x, 0.f); v.y = fmaxf(acc[t][4 * g + 1] + b4.y, 0.f);
             v.z = fmaxf(acc[t][4 * g + 2] + b4.z, 0.f); v.w = fmaxf(acc[t][4 * g + 3] + b4.w, 0.f);
-            xa[4 * t + g] = v;
+            xh[4 * t + g] = v;
         }
-    if (half == 0 && live) {
+    if (live) {                                              // (each half writes its own 64 columns of h1)
         float* hp = a.H1 + row * a.ldo + 4 * lk;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) *(f32x4*)(hp + 32 * (q >> 2) + 8 * (q & 3)) = xa[q];
+        for (int q = 0; q < 8; ++q) *(f32x4*)(hp + 32 * (t0 + (q >> 2)) + 8 * (q & 3)) = xh[q];
+    }
+    // exchange with the partner wavefront (same rows, the other two tiles) through the LDS that held W1: lane l of both maps to
+    // the same (row, k group), so slot [wavefront][q][lane] is read back by the same lane of the partner -- no bank conflicts
+    __syncthreads();                                         // (every wavefront is done reading W1)
+    {
+        f32x4* ex = (f32x4*)W1l;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ex[(wave * 8 + q) * 64 + lane] = xh[q];
+    }
+    __syncthreads();
+    {
+        const f32x4* ex = (const f32x4*)W1l + ((wave ^ 1) * 8) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {                        // (static register indices: half 0 owns tiles 0 / 1, half 1 tiles 2 / 3)
+            const f32x4 pq = ex[q * 64];
+            xa[q] = half ? pq : xh[q];
+            xa[8 + q] = half ? xh[q] : pq;
+        }
     }
     // product 2: this wavefront's two column tiles; MFMA step (q, c) multiplies k = 32 (q >> 2) + 8 (q & 3) + 4 lk + c
     f32x16 ac2[2];
