@@ -1527,8 +1527,9 @@ int launch_wreg(const LinArgs& a, hipStream_t st) {
         KGW_HIP(hipFuncSetAttribute((const void*)k_linear_wreg<WKN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     const int64_t ntiles = (a.rows + 31) / 32;
-    const int64_t half_max = 512;
-    // (measured in the step: 1.648 ms with the half-tile kernel up to 512 tiles, 1.653 up to 1024, 1.671 without it)
+    const int64_t half_max = 1024;
+    // (measured in the step, rounds 1-2: 1.648 ms with the half-tile kernel up to 512 tiles, 1.653 up to 1024, 1.671 without it;
+    //  round 6, today's step: up to 1024 -- the gene MLP's 626 tiles of 20 032 rows take it too -- 0.9865 -> 0.9844 ms, A/B)
     if (ntiles <= half_max) {                                 // few tiles: one (tile, column half) per wavefront, all resident
         static KgwPerDevice attr_half;
         if (attr_half.need()) {
